@@ -1,0 +1,449 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the encode -> score -> loss / rank hot path.
+
+This file is a CPU (torch fp32 / numpy) *restatement* of the reference algorithm
+(WangFei-2019/Image-text-Retrieval), written from the maths, each function citing the
+reference file:line it follows (paths relative to the reference root).  It is the checker
+for the HIP path; it is never the thing shipped or measured:
+
+  * only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py`
+    may import it;
+  * the product package (`image-text-retrieval_amd/itr_amd`) never imports it and has no
+    CPU fallback.
+
+Parity pinning: the reference ships no tests or golden vectors, so the
+oracle is pinned against outputs of the reference itself, generated in the build container by
+`oracle/make_goldens.py` (which imports /root/reference under `oracle/ref_shim.py`) and
+committed as `tests/golden/*.npz`.  `tests/test_oracle_golden.py` re-checks every one of
+them on every CPU test run.
+
+Third-party arithmetic: the reference's GRU is `torch.nn.GRU` (cuDNN / ATen); its published
+cell equations (PyTorch docs, gate order r,z,n) are restated in `gru_direction` below.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# a1  norms  (itr/modalmodule/utils.py:4-15)
+# --------------------------------------------------------------------------------------
+
+
+def l2norm(x, dim=1, eps=1e-8):
+    """x / (sqrt(sum x^2) + eps): eps is added AFTER the sqrt (utils.py:11-15)."""
+    return x / (x.pow(2).sum(dim=dim, keepdim=True).sqrt() + eps)
+
+
+def l1norm(x, dim=1, eps=1e-8):
+    """x / (sum |x| + eps) (utils.py:4-8)."""
+    return x / (x.abs().sum(dim=dim, keepdim=True) + eps)
+
+
+# --------------------------------------------------------------------------------------
+# a2  image tower  (itr/modalmodule/ImgEncoder.py:133-147)
+# --------------------------------------------------------------------------------------
+
+
+def encoder_image_precomp(images, fc_weight, fc_bias, no_imgnorm=False, use_abs=False):
+    """l2norm(images @ W^T + b, dim=-1) [abs].  images (..., F) -> (..., D)."""
+    feat = images @ fc_weight.t() + fc_bias
+    if not no_imgnorm:
+        feat = l2norm(feat, dim=-1)
+    if use_abs:
+        feat = feat.abs()
+    return feat
+
+
+# --------------------------------------------------------------------------------------
+# a3  text tower: Embedding -> packed (bi)GRU -> dir-average -> [last step] -> [l2norm]
+#     (itr/modalmodule/TextEncoder.py:38-70)
+# --------------------------------------------------------------------------------------
+
+
+def gru_direction(x, lengths, w_ih, w_hh, b_ih, b_hh, reverse=False):
+    """One direction of a 1-layer GRU over padded x (B, L, E) with packed-sequence semantics:
+    sample b only advances for t < lengths[b]; outputs at t >= lengths[b] are 0.
+    Gate order (r, z, n); n = tanh(W_in x + b_in + r * (W_hn h + b_hn));
+    h' = (1 - z) * n + z * h   (torch.nn.GRU, used at TextEncoder.py:30,48)."""
+    B, L, _ = x.shape
+    H = w_hh.shape[1]
+    out = x.new_zeros(B, L, H)
+    h = x.new_zeros(B, H)
+    gi_all = x @ w_ih.t() + b_ih  # (B, L, 3H)
+    lens = torch.as_tensor(lengths, dtype=torch.long)
+    steps = range(L - 1, -1, -1) if reverse else range(L)
+    for t in steps:
+        active = (lens > t)
+        if not bool(active.any()):
+            continue
+        gi = gi_all[:, t]
+        gh = h @ w_hh.t() + b_hh
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h_new = (1.0 - z) * n + z * h
+        m = active.unsqueeze(1)
+        h = torch.where(m, h_new, h)
+        out[:, t] = torch.where(m, h_new, torch.zeros_like(h_new))
+    return out
+
+
+def encoder_text(ids, lengths, weights, use_bi_gru=False, no_txtnorm=False, use_abs=False,
+                 method_name=None):
+    """weights: dict with the reference's state_dict names ('embed.weight',
+    'rnn.weight_ih_l0', 'rnn.weight_hh_l0', 'rnn.bias_ih_l0', 'rnn.bias_hh_l0' and the
+    '_reverse' variants).  Dropout is identity in eval mode.  Returns (cap_emb, cap_len)
+    with cap_emb (B, max(lengths), D), or (B, D) when method_name in {VSE++, VSRN}
+    (TextEncoder.py:57-60: gather at len-1)."""
+    lengths = [int(l) for l in lengths]
+    L = max(lengths)
+    x = weights['embed.weight'][ids[:, :L]]
+    fwd = gru_direction(x, lengths, weights['rnn.weight_ih_l0'], weights['rnn.weight_hh_l0'],
+                        weights['rnn.bias_ih_l0'], weights['rnn.bias_hh_l0'])
+    if use_bi_gru:
+        bwd = gru_direction(x, lengths, weights['rnn.weight_ih_l0_reverse'],
+                            weights['rnn.weight_hh_l0_reverse'],
+                            weights['rnn.bias_ih_l0_reverse'],
+                            weights['rnn.bias_hh_l0_reverse'], reverse=True)
+        cap = (fwd + bwd) / 2  # TextEncoder.py:54-55
+    else:
+        cap = fwd
+    if method_name in ('VSE++', 'VSRN'):
+        idx = torch.as_tensor(lengths, dtype=torch.long) - 1
+        cap = cap[torch.arange(cap.shape[0]), idx]
+    if not no_txtnorm:
+        cap = l2norm(cap, dim=-1)
+    if use_abs:
+        cap = cap.abs()
+    return cap, torch.as_tensor(lengths, dtype=torch.long)
+
+
+# --------------------------------------------------------------------------------------
+# a4 / a9 / a8  pooled similarities
+# --------------------------------------------------------------------------------------
+
+
+def cosine_sim(im, s):
+    """im @ s^T, inputs already normalised (Objectives.py:18-21)."""
+    return im @ s.t()
+
+
+def order_sim(im, s):
+    """-|| max(0, s - im) ||_2 for every pair (Objectives.py:24-30). -> (n_im, n_s)."""
+    d = (s.unsqueeze(1) - im.unsqueeze(0)).clamp(min=0)
+    return -d.pow(2).sum(2).sqrt().t()
+
+
+def pdist_cos(x1, x2):
+    """rows renormalised by their plain L2 norm (no eps), mm, NaN -> 0 (Objectives.py:310-323)."""
+    a = x1 / x1.norm(dim=1)[:, None]
+    b = x2 / x2.norm(dim=1)[:, None]
+    res = a @ b.t()
+    return torch.where(torch.isnan(res), torch.zeros_like(res), res)
+
+
+def multi_view_matching(imgs, caps):
+    """max over the k views of img[i, v] . cap[c]  (Fusionmodule.py:674-692). Both branches of
+    the reference (square batched matmul / per-caption loop) compute the same thing."""
+    return torch.einsum('ivd,cd->ivc', imgs, caps).max(1)[0]
+
+
+# --------------------------------------------------------------------------------------
+# a5 / a10  bidirectional hinge (Objectives.py:76-115, 492-517)
+# --------------------------------------------------------------------------------------
+
+
+def hinge_loss(scores, margin=0.2, max_violation=False):
+    """sum_i red_j!=i [m + S_ij - S_ii]_+  +  sum_j red_i!=j [m + S_ij - S_jj]_+ with
+    red = max (max_violation) or sum; the diagonal is zeroed before the reduction."""
+    n = scores.shape[0]
+    diag = scores.diag().view(n, 1)
+    cost_s = (margin + scores - diag).clamp(min=0)
+    cost_im = (margin + scores - diag.t()).clamp(min=0)
+    eye = torch.eye(n, dtype=torch.bool)
+    cost_s = cost_s.masked_fill(eye, 0)
+    cost_im = cost_im.masked_fill(eye, 0)
+    if max_violation:
+        return cost_s.max(1)[0].sum() + cost_im.max(0)[0].sum()
+    return cost_s.sum() + cost_im.sum()
+
+
+def hinge_loss_and_grad(scores, margin=0.2, max_violation=False):
+    with torch.enable_grad():
+        s = scores.detach().clone().requires_grad_(True)
+        loss = hinge_loss(s, margin, max_violation)
+        loss.backward()
+    return loss.detach(), s.grad.detach()
+
+
+# --------------------------------------------------------------------------------------
+# a6  SCAN cross attention (Objectives.py:329-476, cosine_similarity :10-15)
+# --------------------------------------------------------------------------------------
+
+_LEAKY = 0.1
+
+
+def _raw_feature_norm(attn, kind):
+    """attn: (batch, sourceL, queryL); every norm acts along queryL (dim 2)
+    (Objectives.py:436-457).  'l1norm'/'clipped_l1norm' call an undefined `l1norm_d` in the
+    reference (NameError); the evident intent l1norm(attn, 2) is implemented."""
+    if kind == 'softmax':
+        return torch.softmax(attn, dim=2)
+    if kind == 'l2norm':
+        return l2norm(attn, 2)
+    if kind == 'clipped_l2norm':
+        return l2norm(F.leaky_relu(attn, _LEAKY), 2)
+    if kind == 'l1norm':
+        return l1norm(attn, 2)
+    if kind == 'clipped_l1norm':
+        return l1norm(F.leaky_relu(attn, _LEAKY), 2)
+    if kind == 'clipped':
+        return F.leaky_relu(attn, _LEAKY)
+    if kind == 'no_norm':
+        return attn
+    raise ValueError("unknown first norm type:", kind)
+
+
+def func_attention(query, context, raw_feature_norm, smooth):
+    """query (B, qL, d), context (B, sL, d) -> weighted context (B, qL, d), attn (B, qL, sL)
+    (Objectives.py:421-476)."""
+    attn = torch.bmm(context, query.transpose(1, 2))          # (B, sL, qL)
+    attn = _raw_feature_norm(attn, raw_feature_norm)
+    attn = torch.softmax(attn.transpose(1, 2) * smooth, dim=2)  # (B, qL, sL): over sL
+    return torch.bmm(attn, context), attn
+
+
+def _cos_rows(x1, x2, eps=1e-8):
+    """w12 / clamp(|x1||x2|, min=eps) along the last dim (Objectives.py:10-15)."""
+    w12 = (x1 * x2).sum(-1)
+    return w12 / (x1.norm(2, -1) * x2.norm(2, -1)).clamp(min=eps)
+
+
+def _aggregate(row_sim, agg_func, lambda_lse):
+    """row_sim (B, n) -> (B,) (Objectives.py:355-366). LSE has no max-shift."""
+    if agg_func == 'LogSumExp':
+        return torch.log(torch.exp(row_sim * lambda_lse).sum(1)) / lambda_lse
+    if agg_func == 'Max':
+        return row_sim.max(1)[0]
+    if agg_func == 'Sum':
+        return row_sim.sum(1)
+    if agg_func == 'Mean':
+        return row_sim.mean(1)
+    raise ValueError("unknown aggfunc: {}".format(agg_func))
+
+
+def xattn_score(images, captions, cap_lens, cross_attn='t2i', raw_feature_norm='clipped_l2norm',
+                agg_func='LogSumExp', lambda_lse=6.0, lambda_softmax=9.0):
+    """images (Ni, R, d), captions (Nc, L, d) padded, cap_lens (Nc,) -> (Ni, Nc).
+    t2i: words attend over regions (Objectives.py:329-372); i2t: regions attend over words
+    (:376-417).  One caption at a time, like the reference."""
+    if cross_attn not in ('t2i', 'i2t'):
+        raise ValueError("unknown cross_attn:", cross_attn)
+    n_image = images.shape[0]
+    cols = []
+    for c in range(captions.shape[0]):
+        w = int(cap_lens[c])
+        cap = captions[c, :w].unsqueeze(0).expand(n_image, w, -1)
+        if cross_attn == 't2i':
+            ctx, _ = func_attention(cap, images, raw_feature_norm, lambda_softmax)
+            row_sim = _cos_rows(cap, ctx)            # (Ni, w)
+        else:
+            ctx, _ = func_attention(images, cap, raw_feature_norm, lambda_softmax)
+            row_sim = _cos_rows(images, ctx)         # (Ni, R)
+        cols.append(_aggregate(row_sim, agg_func, lambda_lse))
+    return torch.stack(cols, 1)
+
+
+# --------------------------------------------------------------------------------------
+# a7  SGRAF similarity (Fusionmodule.py:373-664), eval mode (BN running stats, no dropout)
+# --------------------------------------------------------------------------------------
+
+
+def _linear(x, w, p):
+    return x @ w[p + '.weight'].t() + w[p + '.bias']
+
+
+def _bn_eval(x, w, p, channel_dim, eps=1e-5):
+    shape = [1] * x.dim()
+    shape[channel_dim] = -1
+    mean = w[p + '.running_mean'].view(shape)
+    var = w[p + '.running_var'].view(shape)
+    return (x - mean) / torch.sqrt(var + eps) * w[p + '.weight'].view(shape) + w[p + '.bias'].view(shape)
+
+
+def sgraf_visual_sa(w, local, raw_global):
+    """VisualSA.forward (Fusionmodule.py:491-507). local (B, 36, D), raw_global (B, D)."""
+    l_emb = torch.tanh(_bn_eval(_linear(local, w, 'v_global_w.embedding_local.0'), w,
+                                'v_global_w.embedding_local.1', 1))
+    g_emb = torch.tanh(_bn_eval(_linear(raw_global, w, 'v_global_w.embedding_global.0'), w,
+                                'v_global_w.embedding_global.1', 1))
+    common = l_emb * g_emb.unsqueeze(1)
+    weights = torch.softmax(_linear(common, w, 'v_global_w.embedding_common.0').squeeze(2), dim=1)
+    return l2norm((weights.unsqueeze(2) * local).sum(1), dim=-1)
+
+
+def sgraf_text_sa(w, local, raw_global):
+    """TextSA.forward (Fusionmodule.py:543-559). local (1, W, D), raw_global (1, D)."""
+    l_emb = torch.tanh(_linear(local, w, 't_global_w.embedding_local.0'))
+    g_emb = torch.tanh(_linear(raw_global, w, 't_global_w.embedding_global.0'))
+    common = l_emb * g_emb.unsqueeze(1)
+    weights = torch.softmax(_linear(common, w, 't_global_w.embedding_common.0').squeeze(2), dim=1)
+    return l2norm((weights.unsqueeze(2) * local).sum(1), dim=-1)
+
+
+def sgraf_scan_attention(query, context, smooth=9.0):
+    """SCAN_attention (Fusionmodule.py:632-664): clipped_l2norm attention, softmax over the
+    context axis, weighted context then l2-normalised."""
+    attn = torch.bmm(context, query.transpose(1, 2))
+    attn = l2norm(F.leaky_relu(attn, _LEAKY), 2)
+    attn = torch.softmax(attn.transpose(1, 2) * smooth, dim=2)
+    return l2norm(torch.bmm(attn, context), dim=-1)
+
+
+def sgraf_similarity(w, img_emb, cap_emb, cap_lens, module_name='SAF', sgr_step=3):
+    """EncoderSimilarity.forward (Fusionmodule.py:406-451). w: dict of the module's state_dict
+    tensors.  -> (Ni, Nc) in (0, 1)."""
+    n_image = img_emb.shape[0]
+    img_glo = sgraf_visual_sa(w, img_emb, img_emb.mean(1))
+    cols = []
+    for c in range(cap_emb.shape[0]):
+        nw = int(cap_lens[c])
+        cap_i = cap_emb[c, :nw].unsqueeze(0)
+        cap_exp = cap_i.expand(n_image, nw, -1)
+        cap_glo = sgraf_text_sa(w, cap_i, cap_i.mean(1))
+        ctx = sgraf_scan_attention(cap_exp, img_emb, smooth=9.0)
+        sim_loc = l2norm(_linear((ctx - cap_exp).pow(2), w, 'sim_tranloc_w'), dim=-1)
+        sim_glo = l2norm(_linear((img_glo - cap_glo).pow(2), w, 'sim_tranglo_w'), dim=-1)
+        sim_emb = torch.cat([sim_glo.unsqueeze(1), sim_loc], 1)     # (Ni, nw+1, s)
+        if module_name == 'SGR':
+            for k in range(sgr_step):                                # GraphReasoning :581-587
+                p = 'SGR_module.sgr%d' % k
+                q = _linear(sim_emb, w, p + '.graph_query_w')
+                kk = _linear(sim_emb, w, p + '.graph_key_w')
+                edge = torch.softmax(torch.bmm(q, kk.transpose(1, 2)), dim=-1)
+                sim_emb = torch.relu(_linear(torch.bmm(edge, sim_emb), w, p + '.sim_graph_w'))
+            sim_vec = sim_emb[:, 0]
+        elif module_name == 'SAF':                                   # AttentionFiltration :615-619
+            a = _linear(sim_emb, w, 'SAF_module.attn_sim_w').transpose(1, 2)   # (Ni, 1, nw+1)
+            a = l1norm(torch.sigmoid(_bn_eval(a, w, 'SAF_module.bn', 1)), dim=-1)
+            sim_vec = l2norm(torch.bmm(a, sim_emb).squeeze(1), dim=-1)
+        else:
+            raise ValueError('Invalid input of config.module_name in configs.py')
+        cols.append(torch.sigmoid(_linear(sim_vec, w, 'sim_eval_w')).squeeze(1))
+    return torch.stack(cols, 1)
+
+
+# --------------------------------------------------------------------------------------
+# a17  ranker (itr/metricmodule/evaluation.py:156-259)
+# --------------------------------------------------------------------------------------
+
+
+def _summary(ranks):
+    n = len(ranks)
+    r1 = 100.0 * int((ranks < 1).sum()) / n
+    r5 = 100.0 * int((ranks < 5).sum()) / n
+    r10 = 100.0 * int((ranks < 10).sum()) / n
+    medr = np.floor(np.median(ranks)) + 1
+    meanr = ranks.mean() + 1
+    return (r1, r5, r10, medr, meanr)
+
+
+def i2t_argsort(sims, return_ranks=False):
+    """Literal restatement (argsort descending per image row, best of the 5 GT captions,
+    evaluation.py:156-189).  Tie order follows numpy's argsort[::-1] like the reference."""
+    sims = np.asarray(sims)
+    npts = sims.shape[0]
+    ranks = np.zeros(npts)
+    top1 = np.zeros(npts)
+    for i in range(npts):
+        inds = np.argsort(sims[i])[::-1]
+        pos = np.empty_like(inds)
+        pos[inds] = np.arange(len(inds))
+        ranks[i] = pos[5 * i:5 * i + 5].min()
+        top1[i] = inds[0]
+    out = _summary(ranks)
+    return (out, (ranks, top1)) if return_ranks else out
+
+
+def t2i_argsort(sims, return_ranks=False):
+    """Literal restatement of evaluation.py:192-222 (caption j <-> image j // 5)."""
+    sims = np.asarray(sims)
+    npts = sims.shape[0]
+    ranks = np.zeros(5 * npts)
+    top1 = np.zeros(5 * npts)
+    st = sims.T
+    for j in range(5 * npts):
+        inds = np.argsort(st[j])[::-1]
+        ranks[j] = np.where(inds == j // 5)[0][0]
+        top1[j] = inds[0]
+    out = _summary(ranks)
+    return (out, (ranks, top1)) if return_ranks else out
+
+
+def rank_counts(sims, im_div=5):
+    """Sort-free ranker used as the bit-exact checker of the HIP rank kernel.
+    rank(query, gt) = #{k: S_k > S_gt} + #{k: S_k == S_gt and k > gt}   (with
+    argsort(...)[::-1] the higher index wins a tie), i2t takes the min over the im_div GT
+    captions; top1 = argmax with the highest index on ties.
+    -> (i2t_rank[Ni], i2t_top1[Ni], t2i_rank[Nc], t2i_top1[Nc]) int64."""
+    s = np.asarray(sims)
+    ni, nc = s.shape
+    i2t_rank = np.zeros(ni, np.int64)
+    i2t_top1 = np.zeros(ni, np.int64)
+    cidx = np.arange(nc)
+    for i in range(ni):
+        row = s[i]
+        best = None
+        for g in range(im_div * i, min(im_div * i + im_div, nc)):
+            r = int((row > row[g]).sum() + ((row == row[g]) & (cidx > g)).sum())
+            best = r if best is None else min(best, r)
+        i2t_rank[i] = best
+        i2t_top1[i] = nc - 1 - int(np.argmax(row[::-1]))
+    t2i_rank = np.zeros(nc, np.int64)
+    t2i_top1 = np.zeros(nc, np.int64)
+    iidx = np.arange(ni)
+    for j in range(nc):
+        col = s[:, j]
+        g = j // im_div
+        t2i_rank[j] = int((col > col[g]).sum() + ((col == col[g]) & (iidx > g)).sum())
+        t2i_top1[j] = ni - 1 - int(np.argmax(col[::-1]))
+    return i2t_rank, i2t_top1, t2i_rank, t2i_top1
+
+
+def recall_from_ranks(ranks):
+    """(r1, r5, r10, medr, meanr) from 0-based ranks (evaluation.py:181-185)."""
+    return _summary(np.asarray(ranks, dtype=np.float64))
+
+
+def cal_recall(sims):
+    """Same dict as evaluation.py:225-259 (without the prints)."""
+    r, rt = i2t_argsort(sims, True)
+    ri, rti = t2i_argsort(sims, True)
+    ar = (r[0] + r[1] + r[2]) / 3
+    ari = (ri[0] + ri[1] + ri[2]) / 3
+    rsum = r[0] + r[1] + r[2] + ri[0] + ri[1] + ri[2]
+    return {'rsum': rsum, 'i2t': r, 't2i': ri, 'i2t_ranks': rt[0], 'i2t_top1': rt[1],
+            't2i_ranks': rti[0], 't2i_top1': rti[1],
+            'result': [list(r) + list(ri) + [ar, ari, rsum]]}
+
+
+# --------------------------------------------------------------------------------------
+# a16  tiled similarity driver (evaluation.py:124-153), including quirk Q1
+# --------------------------------------------------------------------------------------
+
+
+def cal_sims(sim_fn, img_embs, cap_embs, lengths, shard_size, ref_quirk_unsliced_lengths=False):
+    """sim_fn(img_block, cap_block, lens_block) -> (ni, nc).  The reference passes the FULL,
+    un-sliced `lengths` to every caption shard (evaluation.py:149), so shard j > 0 is scored
+    with the lengths of shard 0; set ref_quirk_unsliced_lengths=True to reproduce that."""
+    n_img, n_cap = len(img_embs), len(cap_embs)
+    d = np.zeros((n_img, n_cap))
+    for i0 in range(0, n_img, shard_size):
+        for j0 in range(0, n_cap, shard_size):
+            j1 = min(j0 + shard_size, n_cap)
+            lens = lengths if (ref_quirk_unsliced_lengths or lengths is None) else lengths[j0:j1]
+            sim = sim_fn(torch.as_tensor(img_embs[i0:i0 + shard_size]),
+                         torch.as_tensor(cap_embs[j0:j1]), lens)
+            d[i0:i0 + shard_size, j0:j1] = sim.numpy()
+    return d

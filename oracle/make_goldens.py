@@ -1,0 +1,370 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.npz from the *reference itself*.
+
+Runs only in the build container (needs /root/reference): imports the reference under
+`oracle/ref_shim.py`, feeds it seeded synthetic inputs + seeded weights, and stores
+inputs, weights and the reference's outputs as small .npz fixtures (data only -- no
+reference source travels).  While generating, every fixture is also cross-checked against
+the CPU restatement in `oracle/itr_oracle.py`; a mismatch aborts.
+
+    python oracle/make_goldens.py            # regenerate everything
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+import ref_shim  # noqa: E402
+
+if not ref_shim.reference_available():
+    print("reference tree absent -- nothing to do")
+    sys.exit(0)
+
+Objectives, ImgEncoder, TextEncoder, Fusionmodule, Models, evaluation, mutils = \
+    ref_shim.import_reference()
+import itr_oracle as O  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def npd(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **npd(arrays))
+    print("wrote %-28s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def check(name, got, want, tol=1e-5):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    err = float(np.abs(got - want).max()) if got.size else 0.0
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert err <= tol, "oracle != reference for %s: max abs err %.3e" % (name, err)
+    print("   oracle==reference %-34s max|d|=%.2e" % (name, err))
+
+
+def ragged_lengths(rng, n, lo, hi):
+    """descending lengths like collate_fn (data_loader.py:146)."""
+    return sorted([int(x) for x in rng.randint(lo, hi + 1, size=n)], reverse=True)
+
+
+def sd(module, prefix=''):
+    return {prefix + k: v.clone() for k, v in module.state_dict().items()}
+
+
+# ------------------------------------------------------------------ G1 norms
+def g1():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(7, 5, 33, generator=g)
+    x[2, 3] = 0.0  # zero row: eps keeps it finite
+    out = dict(x=x, l2_last=mutils.l2norm(x, dim=-1), l2_dim1=mutils.l2norm(x, dim=1),
+               l1_last=mutils.l1norm(x, dim=-1), l1_dim2=mutils.l1norm(x, dim=2))
+    check('l2norm', O.l2norm(x, -1), out['l2_last'], 0)
+    check('l1norm', O.l1norm(x, -1), out['l1_last'], 0)
+    save('g1_norms', **out)
+
+
+# ------------------------------------------------------------------ G2 image tower
+def g2():
+    torch.manual_seed(2)
+    enc = ImgEncoder.EncoderImagePrecomp(256, 96, no_imgnorm=False).eval()
+    enc.fc.bias.data.uniform_(-0.05, 0.05)
+    x = mutils.l2norm(torch.randn(6, 36, 256), dim=-1)
+    y3 = enc(x)
+    y2 = enc(x.mean(1))                    # VSE++ build decision: pooled 2-D input
+    enc_nn = ImgEncoder.EncoderImagePrecomp(256, 96, no_imgnorm=True, use_abs=True).eval()
+    enc_nn.load_state_dict(enc.state_dict())
+    y_abs = enc_nn(x)
+    w, b = enc.fc.weight, enc.fc.bias
+    check('img_precomp_3d', O.encoder_image_precomp(x, w, b), y3)
+    check('img_precomp_2d', O.encoder_image_precomp(x.mean(1), w, b), y2)
+    check('img_precomp_abs', O.encoder_image_precomp(x, w, b, True, True), y_abs)
+    save('g2_img_precomp', images=x, fc_weight=w, fc_bias=b, out_3d=y3, out_2d=y2, out_nonorm_abs=y_abs)
+
+
+# ------------------------------------------------------------------ G3 text tower
+def g3():
+    rng = np.random.RandomState(3)
+    V, E, D, B = 60, 20, 48, 9
+    lengths = ragged_lengths(rng, B, 1, 11)
+    L = max(lengths)
+    ids = torch.zeros(B, L, dtype=torch.long)
+    for b, l in enumerate(lengths):
+        ids[b, :l] = torch.from_numpy(rng.randint(4, V, size=l))
+    out = dict(ids=ids, lengths=np.array(lengths))
+    for bi in (False, True):
+        for method in (None, 'VSE++'):
+            for no_norm in (False, True):
+                torch.manual_seed(30 + bi)
+                enc = TextEncoder.EncoderText(V, E, D, 1, use_bi_gru=bi, no_txtnorm=no_norm,
+                                              method_name=method).eval()
+                cap, cap_len = enc(ids, lengths)
+                tag = "%s_%s_%s" % ('bi' if bi else 'uni', 'last' if method else 'seq',
+                                    'raw' if no_norm else 'l2')
+                w = sd(enc)
+                got, _ = O.encoder_text(ids, lengths, w, bi, no_norm, False, method)
+                check('text_' + tag, got, cap, 2e-6)
+                out['out_' + tag] = cap
+                for k, v in w.items():
+                    out["w_%s_%s" % ('bi' if bi else 'uni', k)] = v
+                assert [int(x) for x in cap_len] == lengths
+    save('g3_text_gru', **out)
+
+
+# ------------------------------------------------------------------ G4 cosine + hinge (cfg 1 shape)
+def g4():
+    torch.manual_seed(4)
+    B, D = 128, 1024
+    im = mutils.l2norm(torch.randn(B, D), dim=-1)
+    s = mutils.l2norm(torch.randn(B, D) + 0.35 * im, dim=-1)   # some signal so hinges are mixed
+    scores = Objectives.cosine_sim(im, s)
+    check('cosine_sim', O.cosine_sim(im, s), scores, 1e-6)
+    out = dict(im=im, s=s, scores=scores)
+    cfg = {'name': 'VSE++'}
+    for mv in (False, True):
+        crit = Objectives.ContrastiveLoss(cfg, margin=0.2, measure='cosine', max_violation=mv)
+        with torch.enable_grad():
+            im_g = im.clone().requires_grad_(True)
+            s_g = s.clone().requires_grad_(True)
+            sc = Objectives.cosine_sim(im_g, s_g)
+            sc.retain_grad()
+            loss = crit(im_g, s_g)
+            # loss on an explicit score leaf, to capture dL/dS
+            sleaf = scores.clone().requires_grad_(True)
+            trip = Objectives.TripletLoss(margin=0.2, max_violation=mv)
+            l2 = trip(sleaf)
+            l2.backward()
+            loss.backward()
+        tag = 'maxviol' if mv else 'sum'
+        ol, og = O.hinge_loss_and_grad(scores, 0.2, mv)
+        check('hinge_' + tag, ol, l2, 1e-4)
+        check('hinge_grad_' + tag, og, sleaf.grad, 0)
+        assert abs(float(loss) - float(l2)) < 1e-4
+        out['loss_' + tag] = loss
+        out['dscores_' + tag] = sleaf.grad
+        out['dim_' + tag] = im_g.grad
+        out['ds_' + tag] = s_g.grad
+    save('g4_cosine_hinge', **out)
+
+
+# ------------------------------------------------------------------ G5 SCAN cross attention
+def g5():
+    rng = np.random.RandomState(5)
+    torch.manual_seed(5)
+    Ni, Nc, R, D = 8, 12, 36, 64
+    lens = ragged_lengths(rng, Nc, 2, 9)
+    L = max(lens)
+    img = mutils.l2norm(torch.randn(Ni, R, D), dim=-1)
+    cap = torch.randn(Nc, L, D) * 0.7
+    for c, l in enumerate(lens):
+        cap[c, l:] = 0
+    out = dict(images=img, captions=cap, cap_lens=np.array(lens))
+    base = dict(name='SCAN', lambda_lse=6.0, lambda_softmax=9.0)
+    for xa, fn in (('t2i', Objectives.xattn_score_t2i), ('i2t', Objectives.xattn_score_i2t)):
+        for agg in ('LogSumExp', 'Mean', 'Max', 'Sum'):
+            for norm in ('clipped_l2norm', 'l2norm', 'softmax', 'no_norm', 'clipped'):
+                cfg = dict(base, cross_attn=xa, agg_func=agg, raw_feature_norm=norm)
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    ref = fn(img, cap, lens, cfg)
+                got = O.xattn_score(img, cap, lens, xa, norm, agg, 6.0, 9.0)
+                check('xattn_%s_%s_%s' % (xa, agg, norm), got, ref, 2e-5)
+                out['sim_%s_%s_%s' % (xa, agg, norm)] = ref
+    save('g5_scan_xattn', **out)
+
+
+# ------------------------------------------------------------------ G6 SGRAF similarity
+def g6():
+    rng = np.random.RandomState(6)
+    Ni, Nc, R, D, S = 8, 12, 36, 64, 32
+    lens = ragged_lengths(rng, Nc, 2, 9)
+    L = max(lens)
+    torch.manual_seed(6)
+    img = mutils.l2norm(torch.randn(Ni, R, D), dim=-1)
+    cap = mutils.l2norm(torch.randn(Nc, L, D), dim=-1)
+    for c, l in enumerate(lens):
+        cap[c, l:] = 0
+    out = dict(images=img, captions=cap, cap_lens=np.array(lens))
+    for mod in ('SAF', 'SGR'):
+        torch.manual_seed(60)
+        enc = Fusionmodule.EncoderSimilarity(D, S, mod, 3)
+        # non-trivial BN running stats / affine + non-zero biases
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.8, 1.2)
+                m.bias.data.normal_(0, 0.05)
+            if isinstance(m, torch.nn.Linear):
+                m.bias.data.normal_(0, 0.02)
+        enc.eval()
+        ref = enc(img, cap, lens)
+        w = {k: v for k, v in sd(enc).items() if 'num_batches_tracked' not in k}
+        got = O.sgraf_similarity(w, img, cap, lens, mod, 3)
+        check('sgraf_' + mod, got, ref, 2e-6)
+        out['sim_' + mod] = ref
+        for k, v in w.items():
+            out['w_%s_%s' % (mod, k)] = v
+    save('g6_sgraf', **out)
+
+
+# ------------------------------------------------------------------ G7/G8 MVM, pdist_cos
+def g78():
+    torch.manual_seed(7)
+    imgs = torch.nn.functional.normalize(torch.randn(10, 12, 40), dim=-1)
+    caps_sq = torch.nn.functional.normalize(torch.randn(10, 40), dim=-1)
+    caps_ns = torch.nn.functional.normalize(torch.randn(23, 40), dim=-1)
+    mvm = Fusionmodule.MultiViewMatching()
+    r_sq, r_ns = mvm(imgs, caps_sq), mvm(imgs, caps_ns)
+    check('mvm_square', O.multi_view_matching(imgs, caps_sq), r_sq, 1e-6)
+    check('mvm_nonsquare', O.multi_view_matching(imgs, caps_ns), r_ns, 1e-6)
+    x1 = torch.randn(9, 24)
+    x2 = torch.randn(14, 24)
+    x2[3] = 0  # zero row -> NaN -> 0
+    pc = Objectives.pdist_cos(x1, x2)
+    check('pdist_cos', O.pdist_cos(x1, x2), pc, 1e-6)
+    save('g7_mvm_pdist', imgs=imgs, caps_sq=caps_sq, caps_ns=caps_ns, mvm_sq=r_sq, mvm_ns=r_ns,
+         x1=x1, x2=x2, pdist_cos=pc)
+
+
+# ------------------------------------------------------------------ G9 TripletLoss on non-cosine scores
+def g9():
+    torch.manual_seed(9)
+    sc = torch.rand(33, 33)
+    out = dict(scores=sc)
+    for mv in (False, True):
+        with torch.enable_grad():
+            leaf = sc.clone().requires_grad_(True)
+            l = Objectives.TripletLoss(margin=0.2, max_violation=mv)(leaf)
+            l.backward()
+        ol, og = O.hinge_loss_and_grad(sc, 0.2, mv)
+        check('triplet_%d' % mv, ol, l, 1e-5)
+        check('triplet_grad_%d' % mv, og, leaf.grad, 0)
+        out['loss_%d' % mv] = l
+        out['grad_%d' % mv] = leaf.grad
+    save('g9_triplet', **out)
+
+
+# ------------------------------------------------------------------ G11 eval harness (SCAN, Q1 quirk)
+class _FakeLoader:
+    """Minimal stand-in for the DataLoader: yields the collate_fn 8-tuple (data_loader.py:178)
+    with `ids` listified."""
+
+    def __init__(self, images, ids_tok, lengths, batch):
+        self.dataset = list(range(len(lengths)))
+        self.batches = []
+        n = len(lengths)
+        for b0 in range(0, n, batch):
+            idx = list(range(b0, min(b0 + batch, n)))
+            idx.sort(key=lambda i: -lengths[i])
+            lens = [lengths[i] for i in idx]
+            tok = torch.zeros(len(idx), max(lens), dtype=torch.long)
+            for r, i in enumerate(idx):
+                tok[r, :lengths[i]] = ids_tok[i][:lengths[i]]
+            self.batches.append((images[idx], None, None, tok, lens, idx, None, None))
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def g11():
+    rng = np.random.RandomState(11)
+    torch.manual_seed(11)
+    NI, F_, D, E, V = 40, 48, 32, 16, 50
+    n = NI * 5
+    feats = mutils.l2norm(torch.randn(NI, 36, F_), dim=-1)
+    images = feats.repeat_interleave(5, 0)                  # each image stored once per caption
+    lengths = [int(x) for x in rng.randint(3, 10, size=n)]
+    ids_tok = [torch.from_numpy(rng.randint(4, V, size=12)) for _ in range(n)]
+    cfg = dict(name='SCAN', grad_clip=2.0, img_dim=F_, embed_size=D, precomp_enc_type='basic',
+               no_imgnorm=False, vocab_size=V, word_dim=E, num_layers=1, bi_gru=True,
+               no_txtnorm=True, margin=0.2, measure='cosine', max_violation=False,
+               learning_rate=2e-4, cross_attn='t2i', raw_feature_norm='clipped_l2norm',
+               agg_func='LogSumExp', lambda_lse=6.0, lambda_softmax=9.0, data_name='coco_precomp')
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = Models.SCAN(cfg)
+    loader = _FakeLoader(images, ids_tok, lengths, 32)
+    img_embs, cap_embs, cap_lens = evaluation.encode_data(model, loader, islength=True)
+    img_u = img_embs[::5]
+    with contextlib.redirect_stdout(io.StringIO()):
+        sims_q1 = evaluation.cal_sims(model, img_u, cap_embs, cap_lens, shard_size=100)
+        sims_ok = evaluation.cal_sims(model, img_u, cap_embs, cap_lens, shard_size=10 ** 9)
+    (ri, (ranks_i, top_i)) = evaluation.i2t(sims_ok, True)
+    (rt, (ranks_t, top_t)) = evaluation.t2i(sims_ok, True)
+
+    # oracle cross-check
+    wi = sd(model.img_enc)
+    wt = sd(model.txt_enc)
+    o_img = O.encoder_image_precomp(feats, wi['fc.weight'], wi['fc.bias'])
+    check('harness_img_embs', o_img, img_u, 2e-6)
+    fn = lambda a, b, l: O.xattn_score(a, b, l, 't2i', 'clipped_l2norm', 'LogSumExp', 6.0, 9.0)
+    check('harness_sims_correct', O.cal_sims(fn, img_u, cap_embs, cap_lens, 10 ** 9), sims_ok, 2e-5)
+    check('harness_sims_q1', O.cal_sims(fn, img_u, cap_embs, cap_lens, 100, True), sims_q1, 2e-5)
+    check('harness_sims_sliced', O.cal_sims(fn, img_u, cap_embs, cap_lens, 100, False), sims_ok, 2e-5)
+    oi = O.i2t_argsort(sims_ok, True)
+    ot = O.t2i_argsort(sims_ok, True)
+    assert oi[0] == ri and ot[0] == rt
+    assert (oi[1][0] == ranks_i).all() and (ot[1][0] == ranks_t).all()
+    c = O.rank_counts(sims_ok)
+    assert (c[0] == ranks_i).all() and (c[2] == ranks_t).all()
+    assert (c[1] == top_i).all() and (c[3] == top_t).all()
+    print("   oracle==reference harness ranks/top1 exact")
+    out = dict(features=feats, lengths=np.array(lengths), token_ids=torch.stack(ids_tok),
+               img_embs=img_u, cap_embs=cap_embs, cap_lens=cap_lens,
+               sims_q1_shard100=sims_q1.astype(np.float32), sims=sims_ok.astype(np.float32),
+               i2t=np.array(ri), t2i=np.array(rt), i2t_ranks=ranks_i, i2t_top1=top_i,
+               t2i_ranks=ranks_t, t2i_top1=top_t)
+    for k, v in wi.items():
+        out['wimg_' + k] = v
+    for k, v in wt.items():
+        out['wtxt_' + k] = v
+    save('g11_harness_scan', **out)
+
+
+# ------------------------------------------------------------------ G12 ranker only (+ ties)
+def g12():
+    rng = np.random.RandomState(12)
+    sims = rng.randn(100, 500)
+    (ri, (ranks_i, top_i)) = evaluation.i2t(sims, True)
+    (rt, (ranks_t, top_t)) = evaluation.t2i(sims, True)
+    c = O.rank_counts(sims)
+    assert (c[0] == ranks_i).all() and (c[2] == ranks_t).all()
+    assert (c[1] == top_i).all() and (c[3] == top_t).all()
+    # tie case: quantised scores -> many exact ties
+    tie = np.round(rng.randn(30, 150) * 2) / 2
+    (tri, (tranks_i, ttop_i)) = evaluation.i2t(tie, True)
+    (trt, (tranks_t, ttop_t)) = evaluation.t2i(tie, True)
+    ct = O.rank_counts(tie)
+    n_i = int((ct[0] != tranks_i).sum())
+    n_t = int((ct[2] != tranks_t).sum())
+    print("   tie case: rank_counts vs reference argsort: %d/%d i2t, %d/%d t2i rows differ "
+          "(numpy argsort is unstable; see SURVEY Q8)" % (n_i, len(tranks_i), n_t, len(tranks_t)))
+    zeros = np.zeros((6, 30))
+    (_, (zr_i, zt_i)) = evaluation.i2t(zeros, True)
+    (_, (zr_t, zt_t)) = evaluation.t2i(zeros, True)
+    cz = O.rank_counts(zeros)
+    assert (cz[0] == zr_i).all() and (cz[2] == zr_t).all(), "all-zeros tie rule"
+    save('g12_ranker', sims=sims, i2t=np.array(ri), t2i=np.array(rt), i2t_ranks=ranks_i,
+         i2t_top1=top_i, t2i_ranks=ranks_t, t2i_top1=top_t,
+         tie_sims=tie, tie_i2t_ranks=tranks_i, tie_t2i_ranks=tranks_t, tie_i2t=np.array(tri),
+         tie_t2i=np.array(trt), zeros_i2t_ranks=zr_i, zeros_t2i_ranks=zr_t)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g11', 'g12']
+    for name in which:
+        print("== " + name)
+        globals()[name]()
