@@ -1,0 +1,90 @@
+// Shared helpers for the gfx950 kernels of libitr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/itr_hip.h"
+
+namespace itr {
+
+void set_error(const char *fmt, ...);
+
+#define ITR_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            itr::set_error(__VA_ARGS__);       \
+            return ITR_ERR_BADARG;             \
+        }                                      \
+    } while (0)
+
+#define ITR_UNSUPPORTED(cond, ...)             \
+    do {                                       \
+        if (cond) {                            \
+            itr::set_error(__VA_ARGS__);       \
+            return ITR_ERR_UNSUPPORTED;        \
+        }                                      \
+    } while (0)
+
+// Launch-error check only (no sync): the ABI just enqueues work.
+#define ITR_CHECK_LAUNCH(what)                                                         \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            itr::set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e__)); \
+            return ITR_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define ITR_CHECK_HIP(expr)                                                           \
+    do {                                                                              \
+        hipError_t e__ = (expr);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            itr::set_error("%s failed: %s", #expr, hipGetErrorString(e__));           \
+            return ITR_ERR_HIP;                                                       \
+        }                                                                             \
+    } while (0)
+
+static inline hipStream_t as_stream(itr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- wave (64-lane) reductions --------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case 1: return fmaxf(v, 0.f);
+        case 2: return tanhf(v);
+        case 3: return 1.f / (1.f + expf(-v));
+        case 4: return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+        case 5: return v > 0.f ? v : 0.1f * v;
+        default: return v;
+    }
+}
+
+// Order-preserving map float -> uint32 (larger float <=> larger key).
+__device__ __forceinline__ uint32_t float_order_key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+}  // namespace itr

@@ -1,0 +1,220 @@
+// Recall@K ranker (itr/metricmodule/evaluation.py:156-222) without sorting.
+//
+// The reference argsorts every row (i2t) and every column (t2i) of the float64 similarity
+// matrix on the host.  The rank of a ground-truth item is just a count:
+//     rank(q, gt) = #{k : S[q,k] > S[q,gt]} + #{k > gt : S[q,k] == S[q,gt]}
+// (with np.argsort(...)[::-1] the higher index wins exact ties), so one streaming
+// pass over S per direction is enough: integer compares, HBM-bound (4 bytes/pair/direction).
+//
+//   i2t : one workgroup per image row; 5 GT captions -> 5 counters per lane, float4 loads,
+//         wave + LDS reduction, min over the 5.
+//   t2i : one lane owns 4 consecutive caption columns (float4, coalesced across the wave) and
+//         walks down a chunk of image rows; partial counts are added with one atomic per column
+//         so row blocks (other workgroups, or other GPUs after an all-reduce) just sum.
+// S may be a row block of the global matrix (multi-GPU row sharding): row0 is the global index
+// of its first row, and s_gt[] carries the GT score of every caption (gathered over ranks).
+#include "itr_common.h"
+
+namespace itr {
+
+constexpr int MAX_IMDIV = 8;
+constexpr int RANK_THREADS = 256;
+
+__global__ void gather_gt_kernel(const float *__restrict__ S, int64_t ldS, int64_t row0, int64_t nrows,
+                                 int64_t Nc, int im_div, float *__restrict__ s_gt) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Nc) return;
+    const int64_t g = j / im_div - row0;
+    if (g >= 0 && g < nrows) s_gt[j] = S[g * ldS + j];
+}
+
+__global__ __launch_bounds__(RANK_THREADS) void i2t_rank_kernel(const float *__restrict__ S, int64_t ldS,
+                                                                int64_t row0, int64_t Nc, int im_div,
+                                                                int32_t *__restrict__ rank_out,
+                                                                int32_t *__restrict__ top1_out) {
+    __shared__ int s_cnt[RANK_THREADS / 64][MAX_IMDIV];
+    __shared__ unsigned long long s_best[RANK_THREADS / 64];
+    const int64_t r = blockIdx.x;
+    const float *row = S + r * ldS;
+    const int64_t gi = row0 + r;  // global image index
+    float gt[MAX_IMDIV];
+    int64_t gidx[MAX_IMDIV];
+    int cnt[MAX_IMDIV];
+#pragma unroll
+    for (int g = 0; g < MAX_IMDIV; ++g) {
+        gidx[g] = gi * im_div + g;
+        const bool ok = g < im_div && gidx[g] < Nc;
+        gt[g] = ok ? row[gidx[g]] : INFINITY;
+        cnt[g] = 0;
+    }
+    unsigned long long best = 0;  // (ordered score << 32) | index ; max => highest index on ties
+    const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+    const int64_t nvec = vec ? (Nc >> 2) : 0;
+    for (int64_t c = threadIdx.x; c < nvec; c += RANK_THREADS) {
+        const float4 v = reinterpret_cast<const float4 *>(row)[c];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t k = c * 4 + u;
+            const unsigned long long key = ((unsigned long long)float_order_key(e[u]) << 32) | (unsigned)k;
+            best = key > best ? key : best;
+#pragma unroll
+            for (int g = 0; g < MAX_IMDIV; ++g)
+                cnt[g] += (e[u] > gt[g]) || (e[u] == gt[g] && k > gidx[g]);
+        }
+    }
+    for (int64_t k = nvec * 4 + threadIdx.x; k < Nc; k += RANK_THREADS) {
+        const float e = row[k];
+        const unsigned long long key = ((unsigned long long)float_order_key(e) << 32) | (unsigned)k;
+        best = key > best ? key : best;
+#pragma unroll
+        for (int g = 0; g < MAX_IMDIV; ++g) cnt[g] += (e > gt[g]) || (e == gt[g] && k > gidx[g]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int g = 0; g < MAX_IMDIV; ++g) cnt[g] = wave_sum_i(cnt[g]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < MAX_IMDIV; ++g) s_cnt[wave][g] = cnt[g];
+        s_best[wave] = best;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int rank = 0x7fffffff;
+        for (int g = 0; g < im_div; ++g) {
+            if (gi * im_div + g >= Nc) break;
+            int t = 0;
+            for (int w = 0; w < RANK_THREADS / 64; ++w) t += s_cnt[w][g];
+            rank = t < rank ? t : rank;
+        }
+        unsigned long long b = 0;
+        for (int w = 0; w < RANK_THREADS / 64; ++w) b = s_best[w] > b ? s_best[w] : b;
+        rank_out[r] = rank;
+        top1_out[r] = (int32_t)(b & 0xffffffffu);
+    }
+}
+
+constexpr int T2I_ROWS = 64;  // image rows per workgroup
+
+__global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__restrict__ S, int64_t ldS,
+                                                                int64_t row0, int64_t nrows, int64_t Nc,
+                                                                int im_div, const float *__restrict__ s_gt,
+                                                                int32_t *__restrict__ rank_acc,
+                                                                unsigned long long *__restrict__ best_acc) {
+    const int64_t c0 = ((int64_t)blockIdx.x * RANK_THREADS + threadIdx.x) * 4;
+    if (c0 >= Nc) return;
+    const int64_t r_begin = (int64_t)blockIdx.y * T2I_ROWS;
+    const int64_t r_end = (r_begin + T2I_ROWS < nrows) ? r_begin + T2I_ROWS : nrows;
+    const int ncol = (Nc - c0 >= 4) ? 4 : (int)(Nc - c0);
+    float gt[4];
+    int64_t gimg[4];
+    int cnt[4] = {0, 0, 0, 0};
+    unsigned long long best[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        gt[u] = u < ncol ? s_gt[c0 + u] : INFINITY;
+        gimg[u] = (c0 + u) / im_div;
+    }
+    const bool vec = (ncol == 4) && ((ldS & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
+    for (int64_t r = r_begin; r < r_end; ++r) {
+        const float *p = S + r * ldS + c0;
+        float e[4];
+        if (vec) {
+            const float4 v = *reinterpret_cast<const float4 *>(p);
+            e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) e[u] = u < ncol ? p[u] : -INFINITY;
+        }
+        const int64_t gr = row0 + r;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            cnt[u] += (e[u] > gt[u]) || (e[u] == gt[u] && gr > gimg[u]);
+            const unsigned long long key = ((unsigned long long)float_order_key(e[u]) << 32) | (unsigned)gr;
+            best[u] = key > best[u] ? key : best[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (u < ncol) {
+            if (cnt[u]) atomicAdd(&rank_acc[c0 + u], cnt[u]);
+            atomicMax(&best_acc[c0 + u], best[u]);
+        }
+}
+
+}  // namespace itr
+
+extern "C" int itr_rank_gather_gt(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
+                                  int im_div, float *s_gt, itr_stream_t stream) {
+    ITR_REQUIRE(S && s_gt, "itr_rank_gather_gt: null pointer");
+    ITR_REQUIRE(im_div >= 1 && Nc >= 0 && ldS >= Nc && row0 >= 0 && n_rows_local >= 0,
+                "itr_rank_gather_gt: bad shape");
+    if (Nc == 0) return ITR_OK;
+    hipLaunchKernelGGL(itr::gather_gt_kernel, dim3((unsigned)itr::ceil_div(Nc, 256)), dim3(256), 0,
+                       itr::as_stream(stream), S, ldS, row0, n_rows_local, Nc, im_div, s_gt);
+    ITR_CHECK_LAUNCH("gather_gt");
+    return ITR_OK;
+}
+
+extern "C" int itr_rank_counts(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
+                               int im_div, const float *s_gt, int32_t *i2t_rank, int32_t *i2t_top1,
+                               int32_t *t2i_rank, uint64_t *t2i_best, itr_stream_t stream) {
+    ITR_REQUIRE(S && s_gt && i2t_rank && i2t_top1 && t2i_rank && t2i_best, "itr_rank_counts: null pointer");
+    ITR_REQUIRE(im_div >= 1 && im_div <= itr::MAX_IMDIV, "itr_rank_counts: im_div must be in [1, %d]",
+                itr::MAX_IMDIV);
+    ITR_REQUIRE(Nc >= 0 && ldS >= Nc && row0 >= 0 && n_rows_local >= 0, "itr_rank_counts: bad shape");
+    ITR_REQUIRE(Nc < 0x7fffffffLL && row0 + n_rows_local < 0x7fffffffLL, "itr_rank_counts: index overflow");
+    if (Nc == 0 || n_rows_local == 0) return ITR_OK;
+    hipStream_t st = itr::as_stream(stream);
+    hipLaunchKernelGGL(itr::i2t_rank_kernel, dim3((unsigned)n_rows_local), dim3(itr::RANK_THREADS), 0, st, S,
+                       ldS, row0, Nc, im_div, i2t_rank, i2t_top1);
+    ITR_CHECK_LAUNCH("i2t_rank");
+    dim3 grid((unsigned)itr::ceil_div(Nc, (int64_t)itr::RANK_THREADS * 4),
+              (unsigned)itr::ceil_div(n_rows_local, itr::T2I_ROWS));
+    hipLaunchKernelGGL(itr::t2i_rank_kernel, grid, dim3(itr::RANK_THREADS), 0, st, S, ldS, row0, n_rows_local,
+                       Nc, im_div, s_gt, t2i_rank, reinterpret_cast<unsigned long long *>(t2i_best));
+    ITR_CHECK_LAUNCH("t2i_rank");
+    return ITR_OK;
+}
+
+extern "C" int itr_recall_from_ranks(const int32_t *ranks_host, int64_t n, double *out5) {
+    ITR_REQUIRE(ranks_host && out5 && n > 0, "itr_recall_from_ranks: bad argument");
+    // evaluation.py:181-185: R@K = 100 * #{rank < K} / n ; medr = floor(median) + 1 ; meanr = mean + 1
+    int64_t c1 = 0, c5 = 0, c10 = 0;
+    double sum = 0;
+    int32_t *tmp = new int32_t[n];
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t r = ranks_host[i];
+        c1 += r < 1; c5 += r < 5; c10 += r < 10;
+        sum += r;
+        tmp[i] = r;
+    }
+    // median via counting-free selection (n is small: <= number of queries)
+    auto nth = [&](int64_t k) {
+        int64_t lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int32_t pivot = tmp[(lo + hi) / 2];
+            int64_t i = lo, j = hi;
+            while (i <= j) {
+                while (tmp[i] < pivot) ++i;
+                while (tmp[j] > pivot) --j;
+                if (i <= j) { const int32_t t = tmp[i]; tmp[i] = tmp[j]; tmp[j] = t; ++i; --j; }
+            }
+            if (k <= j) hi = j; else if (k >= i) lo = i; else break;
+        }
+        return (double)tmp[k];
+    };
+    double med;
+    if (n & 1) med = nth(n / 2);
+    else { const double a = nth(n / 2 - 1); const double b = nth(n / 2); med = 0.5 * (a + b); }
+    delete[] tmp;
+    out5[0] = 100.0 * c1 / n; out5[1] = 100.0 * c5 / n; out5[2] = 100.0 * c10 / n;
+    out5[3] = (double)(int64_t)med + 1.0;  // floor (ranks are non-negative)
+    out5[4] = sum / n + 1.0;
+    return ITR_OK;
+}

@@ -1,0 +1,595 @@
+// SCAN stacked cross attention similarity (xattn_score_t2i / xattn_score_i2t,
+// itr/modalmodule/Objectives.py:329-476) as ONE fused gfx950 kernel.
+//
+// The reference loops over captions in Python; per (image i, caption c) pair it does
+//     A      = V_i E_c^T                       [R x W]   (bmm, K = D)
+//     Ahat   = raw_feature_norm(A)             (LeakyReLU(0.1) + l2norm over the query axis ...)
+//     P      = softmax(lambda_s * Ahat)        over the context axis
+//     ctx    = P * context                     [W x D] (t2i) or [R x D] (i2t)   (bmm, K = R or W)
+//     sim    = cosine(query, ctx)  per query row;   score = LSE / max / sum / mean over rows.
+//
+// Mapping: all pairs together are one big fp32 GEMM  (Ni*R) x (sum W) x D  whose 36 x W blocks
+// never leave the chip.  A workgroup owns 4 images (144 rows = 9 MFMA row tiles of 16) x one
+// column tile of <= 64 words (whole captions only, planned host-side), accumulates the raw
+// dot products with v_mfma_f32_16x16x4_f32 (exact fp32), parks the 144 x 64 block in LDS and
+// finishes every pair in the epilogue.
+//
+// The second bmm is never executed.  With G_i = V_i V_i^T (36 x 36 Gram matrix per image,
+// precomputed once, 5 KB/image) and the raw A already on chip:
+//     query . ctx_w   = sum_r P[r,w] * A[r,w]
+//     || ctx_w ||^2   = P[:,w]^T G_i P[:,w]
+// (t2i; for i2t the caption Gram H_c = E_c E_c^T plays the same role).  This removes half of
+// the reference's FLOPs (the 2*W*R*D context GEMM and the 3 D-long reductions per word) and all
+// of its HBM traffic for `ctx`; the result differs from the literal evaluation order only by
+// fp32 rounding (tests bound it at 2e-5 absolute on scores in (-1, 1)).
+//
+// LDS operand layout (both operands K-contiguous): 8 planes of float4 per 32-wide K chunk,
+// lds[plane][row ^ plane]; see gemm_f32.hip for the bank-conflict argument (the 16x16x4 MFMA
+// lane groups need plane = 4q + (lane >> 4) so both planes of a ds_read_b128 lane group share
+// bits [3:2] of the XOR).
+#include "itr_common.h"
+
+namespace itr {
+
+constexpr int SC_R = 36;                 // regions per image (precomp bottom-up features)
+constexpr int SC_IMGS = 4;               // images per workgroup
+constexpr int SC_MT = SC_IMGS * SC_R;    // 144 rows = 9 x 16
+constexpr int SC_MTILES = SC_MT / 16;    // 9
+constexpr int SC_NT = ITR_SCAN_NT;       // 64 word columns = 4 waves x 16
+constexpr int SC_ROWS = SC_MT + SC_NT;   // 208 staged rows per K chunk
+constexpr int SC_BK = 32, SC_PLANES = 8;
+constexpr int SC_THREADS = 256;
+constexpr int SC_MAXCAP = 16;            // captions per column tile (planner guarantees it)
+constexpr int SC_LDA = SC_NT + 1;        // padded row stride of the parked A block
+constexpr int SC_STAGE = 7;              // ceil(208 * 8 / 256) float4 per thread per chunk
+
+struct ScanArgs {
+    const float *img;        // [Ni, 36, D]
+    const float *words;      // [n_rows, D]
+    const int64_t *cap_off;  // [Nc] first word row of caption c
+    const int32_t *cap_len;  // [Nc]
+    const int32_t *tile_begin;  // [n_tiles + 1] caption range of each column tile
+    const float *gram;       // [Ni, 36, 36]        (t2i)   V_i V_i^T
+    const float *wnorm;      // [n_rows]            (t2i)   ||E_w||
+    const float *vnorm;      // [Ni * 36]           (i2t)   ||V_r||
+    const float *cgram;      // [sum W_c^2]         (i2t)   E_c E_c^T, caption c at cgram_off[c]
+    const int64_t *cgram_off;  // [Nc]
+    float *S;
+    int64_t ldS;
+    int64_t Ni, Nc, n_tiles;
+    int D;
+    int mode, norm, agg;
+    float lambda_softmax, lambda_lse;
+};
+
+struct ScanSmem {
+    union {
+        float4 stage[2][SC_PLANES][SC_ROWS];  // 53,248 B   main loop operand staging
+        float araw[SC_MT][SC_LDA];            // 37,440 B   parked raw dot products (epilogue)
+    };
+    union {
+        float stat[SC_MT][SC_MAXCAP][2];      // 18,432 B   t2i: per (row, caption) norm statistics
+        float rsim2[SC_MT][SC_MAXCAP];        //  9,216 B   i2t: per (region row, caption) term
+    };
+    float colstat[SC_IMGS][SC_NT][2];         //  2,048 B   i2t: per (image, word) norm statistics
+    float rowsim[SC_IMGS][SC_NT];             //  1,024 B   t2i: per (image, word) similarity term
+    int32_t col_row[SC_NT];                   // word row of each column (-1 = padding)
+    int32_t col_cap[SC_NT];                   // caption slot of each column
+    int32_t cap_start[SC_MAXCAP + 1];
+    int32_t cap_id[SC_MAXCAP];
+    int32_t ncap;
+};
+
+__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : 0.1f * v; }
+
+// value of the normalised attention logit b (before * lambda_softmax) from the raw a and the
+// statistics of its normalisation group (Objectives.py:436-457)
+__device__ __forceinline__ float norm_apply(float a, int norm, float s0, float s1) {
+    switch (norm) {
+        case 0: return leaky(a) / s0;             // clipped_l2norm: s0 = sqrt(sum leaky^2) + eps
+        case 1: return a / s0;                    // l2norm
+        case 2: return expf(a - s0) / s1;         // softmax: s0 = max, s1 = sum exp
+        case 3: return a;                         // no_norm
+        case 4: return leaky(a);                  // clipped
+        case 5: return a / s0;                    // l1norm: s0 = sum |a| + eps
+        default: return leaky(a) / s0;            // clipped_l1norm
+    }
+}
+
+// accumulate / finish the statistics of one normalisation group
+struct NormAcc {
+    float s0, s1;
+    __device__ __forceinline__ void init(int norm) { s0 = (norm == 2) ? -INFINITY : 0.f; s1 = 0.f; }
+    __device__ __forceinline__ void pass1(float a, int norm) {
+        switch (norm) {
+            case 0: { const float b = leaky(a); s0 += b * b; break; }
+            case 1: s0 += a * a; break;
+            case 2: s0 = fmaxf(s0, a); break;
+            case 5: s0 += fabsf(a); break;
+            case 6: s0 += fabsf(leaky(a)); break;
+            default: break;
+        }
+    }
+    __device__ __forceinline__ void pass2(float a, int norm) {
+        if (norm == 2) s1 += expf(a - s0);
+    }
+    __device__ __forceinline__ void finish(int norm) {
+        if (norm == 0 || norm == 1) s0 = sqrtf(s0) + 1e-8f;
+        else if (norm == 5 || norm == 6) s0 = s0 + 1e-8f;
+    }
+};
+
+__global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ScanSmem &sm = *reinterpret_cast<ScanSmem *>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- XCD-aware work mapping: each XCD walks 8 x 8 patches of (image tile, column tile) so
+    // that the ~64 workgroups resident on one XCD share operand panels in its private L2.
+    const int64_t img_tiles = (g.Ni + SC_IMGS - 1) / SC_IMGS;
+    const int64_t PI = (img_tiles + 7) / 8, PJ = (g.n_tiles + 7) / 8;
+    const int64_t bid = blockIdx.x;
+    const int64_t xcd = bid & 7, seq = bid >> 3;
+    const int64_t patch = (seq >> 6) * 8 + xcd;
+    const int within = (int)(seq & 63);
+    if (patch >= PI * PJ) return;
+    const int64_t it = (patch / PJ) * 8 + (within & 7);
+    const int64_t ct = (patch % PJ) * 8 + (within >> 3);
+    if (it >= img_tiles || ct >= g.n_tiles) return;
+    const int64_t img0 = it * SC_IMGS;
+
+    // ---- column tile metadata
+    if (tid == 0) {
+        const int c0 = g.tile_begin[ct], c1 = g.tile_begin[ct + 1];
+        int n = c1 - c0;
+        if (n > SC_MAXCAP) n = SC_MAXCAP;
+        int pos = 0;
+        for (int k = 0; k < n; ++k) {
+            sm.cap_start[k] = pos;
+            sm.cap_id[k] = c0 + k;
+            int w = g.cap_len[c0 + k];
+            if (pos + w > SC_NT) w = SC_NT - pos;  // planner never lets this happen
+            pos += w;
+        }
+        sm.cap_start[n] = pos;
+        sm.ncap = n;
+    }
+    if (tid < SC_NT) { sm.col_row[tid] = -1; sm.col_cap[tid] = -1; }
+    __syncthreads();
+    const int ncap = sm.ncap;
+    for (int idx = tid; idx < ncap * SC_NT; idx += SC_THREADS) {
+        const int k = idx / SC_NT, w = idx % SC_NT;
+        const int st = sm.cap_start[k];
+        if (w < sm.cap_start[k + 1] - st) {
+            sm.col_row[st + w] = (int32_t)(g.cap_off[sm.cap_id[k]] + w);
+            sm.col_cap[st + w] = k;
+        }
+    }
+    __syncthreads();
+
+    // ---- main loop: raw dot products A[144 x 64] over K = D ------------------------------
+    const int64_t n_img_rows = g.Ni * SC_R;
+    const float *src[SC_STAGE];
+    int dst[SC_STAGE];
+#pragma unroll
+    for (int s = 0; s < SC_STAGE; ++s) {
+        const int idx = tid + SC_THREADS * s;
+        const int row = idx >> 3, p = idx & 7;
+        src[s] = nullptr;
+        dst[s] = p * SC_ROWS + (row ^ p);
+        if (row < SC_MT) {
+            const int64_t grow = img0 * SC_R + row;
+            if (grow < n_img_rows) src[s] = g.img + grow * g.D + p * 4;
+        } else if (row < SC_ROWS) {
+            const int wr = sm.col_row[row - SC_MT];
+            if (wr >= 0) src[s] = g.words + (int64_t)wr * g.D + p * 4;
+        } else {
+            dst[s] = -1;
+        }
+    }
+
+    f32x4 acc[SC_MTILES];
+#pragma unroll
+    for (int m = 0; m < SC_MTILES; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 stg[SC_STAGE];
+    const int nk = g.D / SC_BK;  // D % 32 == 0 is checked on the host
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int s = 0; s < SC_STAGE; ++s)
+            stg[s] = src[s] ? *reinterpret_cast<const float4 *>(src[s] + kc * SC_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto lstore = [&](int buf) {
+        float4 *base = &sm.stage[buf][0][0];
+#pragma unroll
+        for (int s = 0; s < SC_STAGE; ++s)
+            if (dst[s] >= 0) base[dst[s]] = stg[s];
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    const int fi = lane & 15, fg = lane >> 4;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) gload(kc + 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = 4 * q + fg;
+            const float4 *plane = &sm.stage[buf][p][0];
+            const float4 b = plane[(SC_MT + wave * 16 + fi) ^ p];
+            float4 a[SC_MTILES];
+#pragma unroll
+            for (int m = 0; m < SC_MTILES; ++m) a[m] = plane[(m * 16 + fi) ^ p];
+#pragma unroll
+            for (int m = 0; m < SC_MTILES; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b.x, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < SC_MTILES; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b.y, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < SC_MTILES; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b.z, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < SC_MTILES; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b.w, acc[m], 0, 0, 0);
+        }
+        if (kc + 1 < nk) {
+            lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- park the raw block in LDS (aliases the staging buffers) -----------------------
+    __syncthreads();
+    {
+        const int col = wave * 16 + fi;
+#pragma unroll
+        for (int m = 0; m < SC_MTILES; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm.araw[m * 16 + fg * 4 + r][col] = acc[m][r];
+    }
+    __syncthreads();
+
+    const int norm = g.norm;
+    const float ls = g.lambda_softmax;
+
+    if (g.mode == 0) {
+        // ================= t2i: words attend over the 36 regions of every image ============
+        // E1: statistics of the first normalisation, along the caption's words, per region row
+        if (tid < SC_MT && norm != 3 && norm != 4) {
+            for (int k = 0; k < ncap; ++k) {
+                const int c0 = sm.cap_start[k], c1 = sm.cap_start[k + 1];
+                NormAcc na;
+                na.init(norm);
+                for (int c = c0; c < c1; ++c) na.pass1(sm.araw[tid][c], norm);
+                if (norm == 2)
+                    for (int c = c0; c < c1; ++c) na.pass2(sm.araw[tid][c], norm);
+                na.finish(norm);
+                sm.stat[tid][k][0] = na.s0;
+                sm.stat[tid][k][1] = na.s1;
+            }
+        }
+        __syncthreads();
+        // E2: one lane per (image = wave, word column = lane)
+        {
+            const int ii = wave;
+            const int w = lane;
+            const int64_t img = img0 + ii;
+            const int k = sm.col_cap[w];
+            float simv = 0.f;
+            if (img < g.Ni) {  // wave-uniform
+                float a[SC_R], p[SC_R];
+                float mx = -INFINITY;
+                const int kk = k < 0 ? 0 : k;
+#pragma unroll
+                for (int r = 0; r < SC_R; ++r) {
+                    a[r] = sm.araw[ii * SC_R + r][w];
+                    const float b = norm_apply(a[r], norm, sm.stat[ii * SC_R + r][kk][0], sm.stat[ii * SC_R + r][kk][1]);
+                    p[r] = b * ls;
+                    mx = fmaxf(mx, p[r]);
+                }
+                float den = 0.f;
+#pragma unroll
+                for (int r = 0; r < SC_R; ++r) { p[r] = expf(p[r] - mx); den += p[r]; }
+                float num = 0.f;
+#pragma unroll
+                for (int r = 0; r < SC_R; ++r) { p[r] = p[r] / den; num += p[r] * a[r]; }
+                // ||ctx||^2 = p^T G p ; G is symmetric and wave-uniform (scalar loads)
+                const float *G = g.gram + img * (SC_R * SC_R);
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < SC_R; ++r) {
+                    float t = 0.5f * G[r * SC_R + r] * p[r];
+#pragma unroll
+                    for (int r2 = r + 1; r2 < SC_R; ++r2) t += G[r * SC_R + r2] * p[r2];
+                    q += p[r] * t;
+                }
+                q = 2.f * q;
+                const int wr = sm.col_row[w];
+                const float w1 = wr >= 0 ? g.wnorm[wr] : 0.f;
+                const float w2 = sqrtf(fmaxf(q, 0.f));
+                simv = num / fmaxf(w1 * w2, 1e-8f);   // cosine_similarity, Objectives.py:10-15
+            }
+            sm.rowsim[ii][w] = simv;
+        }
+        __syncthreads();
+        // E3: aggregate over the words of each caption (Objectives.py:355-366)
+        if (tid < SC_IMGS * SC_MAXCAP) {
+            const int ii = tid / SC_MAXCAP, k = tid % SC_MAXCAP;
+            const int64_t img = img0 + ii;
+            if (k < ncap && img < g.Ni) {
+                const int c0 = sm.cap_start[k], c1 = sm.cap_start[k + 1];
+                float r;
+                if (g.agg == 0) {
+                    r = 0.f;
+                    for (int c = c0; c < c1; ++c) r += expf(sm.rowsim[ii][c] * g.lambda_lse);
+                    r = logf(r) / g.lambda_lse;
+                } else if (g.agg == 1) {
+                    r = -INFINITY;
+                    for (int c = c0; c < c1; ++c) r = fmaxf(r, sm.rowsim[ii][c]);
+                } else {
+                    r = 0.f;
+                    for (int c = c0; c < c1; ++c) r += sm.rowsim[ii][c];
+                    if (g.agg == 3) r /= (float)(c1 - c0);
+                }
+                g.S[img * g.ldS + sm.cap_id[k]] = r;
+            }
+        }
+    } else {
+        // ================= i2t: regions attend over the words of every caption ============
+        // E1: first normalisation runs along the 36 regions (query axis), per (image, word)
+        {
+            const int ii = wave, w = lane;
+            if (norm != 3 && norm != 4) {
+                NormAcc na;
+                na.init(norm);
+#pragma unroll 4
+                for (int r = 0; r < SC_R; ++r) na.pass1(sm.araw[ii * SC_R + r][w], norm);
+                if (norm == 2)
+                    for (int r = 0; r < SC_R; ++r) na.pass2(sm.araw[ii * SC_R + r][w], norm);
+                na.finish(norm);
+                sm.colstat[ii][w][0] = na.s0;
+                sm.colstat[ii][w][1] = na.s1;
+            }
+        }
+        __syncthreads();
+        // E2: one lane per region row, loop over the captions of the tile.  The attention
+        // weights overwrite the raw block row segment once the numerator has been taken.
+        for (int k = 0; k < ncap; ++k) {
+            const int c0 = sm.cap_start[k], c1 = sm.cap_start[k + 1];
+            if (tid < SC_MT) {
+                const int ii = tid / SC_R;
+                const int64_t img = img0 + ii;
+                float mx = -INFINITY;
+                for (int c = c0; c < c1; ++c) {
+                    const float b = norm_apply(sm.araw[tid][c], norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
+                    mx = fmaxf(mx, b * ls);
+                }
+                float den = 0.f;
+                for (int c = c0; c < c1; ++c) {
+                    const float b = norm_apply(sm.araw[tid][c], norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
+                    den += expf(b * ls - mx);
+                }
+                float num = 0.f;
+                for (int c = c0; c < c1; ++c) {
+                    const float a = sm.araw[tid][c];
+                    const float b = norm_apply(a, norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
+                    const float pw = expf(b * ls - mx) / den;
+                    num += pw * a;
+                    sm.araw[tid][c] = pw;  // own row, own caption segment: no other reader left
+                }
+                // ||ctx_r||^2 = p^T H_c p with the caption Gram H_c (uniform across lanes)
+                const int W = c1 - c0;
+                const float *H = g.cgram + g.cgram_off[sm.cap_id[k]];
+                float q = 0.f;
+                for (int u = 0; u < W; ++u) {
+                    float t = 0.f;
+                    for (int v = 0; v < W; ++v) t += H[u * W + v] * sm.araw[tid][c0 + v];
+                    q += sm.araw[tid][c0 + u] * t;
+                }
+                const float w1 = img < g.Ni ? g.vnorm[img * SC_R + tid % SC_R] : 0.f;
+                const float w2 = sqrtf(fmaxf(q, 0.f));
+                sm.rsim2[tid][k] = num / fmaxf(w1 * w2, 1e-8f);
+            }
+        }
+        __syncthreads();
+        // E3: aggregate over the 36 regions
+        if (tid < SC_IMGS * SC_MAXCAP) {
+            const int ii = tid / SC_MAXCAP, k = tid % SC_MAXCAP;
+            const int64_t img = img0 + ii;
+            if (k < ncap && img < g.Ni) {
+                float r;
+                if (g.agg == 0) {
+                    r = 0.f;
+                    for (int t = 0; t < SC_R; ++t) r += expf(sm.rsim2[ii * SC_R + t][k] * g.lambda_lse);
+                    r = logf(r) / g.lambda_lse;
+                } else if (g.agg == 1) {
+                    r = -INFINITY;
+                    for (int t = 0; t < SC_R; ++t) r = fmaxf(r, sm.rsim2[ii * SC_R + t][k]);
+                } else {
+                    r = 0.f;
+                    for (int t = 0; t < SC_R; ++t) r += sm.rsim2[ii * SC_R + t][k];
+                    if (g.agg == 3) r /= (float)SC_R;
+                }
+                g.S[img * g.ldS + sm.cap_id[k]] = r;
+            }
+        }
+    }
+}
+
+// ---- precompute kernels -------------------------------------------------------------------
+// G[n] = X_n X_n^T for X_n [rows, D] (rows <= 64): one workgroup per matrix.
+__global__ __launch_bounds__(256) void gram_kernel(const float *__restrict__ X, const int64_t *__restrict__ row_off,
+                                                   const int32_t *__restrict__ row_cnt, int fixed_rows, int D,
+                                                   float *__restrict__ G, const int64_t *__restrict__ g_off) {
+    __shared__ float xs[64][33];
+    const int64_t n = blockIdx.x;
+    const int rows = row_cnt ? row_cnt[n] : fixed_rows;
+    const float *x = X + (row_off ? row_off[n] : n * (int64_t)fixed_rows) * D;
+    float *out = G + (g_off ? g_off[n] : n * (int64_t)fixed_rows * fixed_rows);
+    const int npair = rows * rows;
+    float acc[16];  // up to 64*64/256 pairs per thread
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < D; k0 += 32) {
+        for (int idx = threadIdx.x; idx < rows * 32; idx += 256) {
+            const int r = idx >> 5, k = idx & 31;
+            xs[r][k] = (k0 + k < D) ? x[(int64_t)r * D + k0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int pidx = threadIdx.x + 256 * e;
+            if (pidx < npair) {
+                const int r1 = pidx / rows, r2 = pidx % rows;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) s += xs[r1][k] * xs[r2][k];
+                acc[e] += s;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int pidx = threadIdx.x + 256 * e;
+        if (pidx < npair) out[pidx] = acc[e];
+    }
+}
+
+// plain row L2 norms (no eps): one wave per row
+__global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ X, int64_t rows, int D,
+                                                      float *__restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) { const float v = X[row * D + k]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = sqrtf(s);
+}
+
+// exclusive prefix sum of len^2 (caption Gram offsets); single workgroup, Nc is small (<= ~1e5)
+__global__ __launch_bounds__(1024) void sq_prefix_kernel(const int32_t *__restrict__ len, int64_t n,
+                                                         int64_t *__restrict__ off) {
+    __shared__ long long part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b = t * per, e = (b + per < n) ? b + per : n;
+    long long s = 0;
+    for (int64_t i = b; i < e; ++i) s += (long long)len[i] * len[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; }
+    }
+    __syncthreads();
+    long long run = part[t];
+    for (int64_t i = b; i < e; ++i) { off[i] = run; run += (long long)len[i] * len[i]; }
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+static_assert(sizeof(ScanSmem) <= 80 * 1024, "two workgroups per CU need <= 80 KiB of LDS each");
+
+}  // namespace itr
+
+extern "C" int itr_scan_plan_tiles(const int32_t *len_host, int64_t Nc, int nt, int32_t *tile_begin_host,
+                                   int64_t *n_tiles) {
+    ITR_REQUIRE(len_host && tile_begin_host && n_tiles, "itr_scan_plan_tiles: null pointer");
+    ITR_REQUIRE(nt == ITR_SCAN_NT, "itr_scan_plan_tiles: nt must be %d", ITR_SCAN_NT);
+    int64_t t = 0;
+    int used = 0, caps = 0;
+    tile_begin_host[0] = 0;
+    for (int64_t c = 0; c < Nc; ++c) {
+        const int w = len_host[c];
+        ITR_REQUIRE(w >= 1, "itr_scan_plan_tiles: caption %lld has length %d (< 1)", (long long)c, w);
+        ITR_UNSUPPORTED(w > nt, "itr_scan_plan_tiles: caption %lld has %d words; this build supports <= %d",
+                        (long long)c, w, nt);
+        if (used + w > nt || caps == itr::SC_MAXCAP) {
+            tile_begin_host[++t] = (int32_t)c;
+            used = 0;
+            caps = 0;
+        }
+        used += w;
+        ++caps;
+    }
+    if (Nc > 0) tile_begin_host[++t] = (int32_t)Nc;
+    *n_tiles = t;
+    return ITR_OK;
+}
+
+extern "C" size_t itr_scan_workspace_bytes(int64_t Ni, int R, int64_t n_rows, int64_t Nc) {
+    using itr::align256;
+    // t2i: gram[Ni,R,R] + wnorm[n_rows];  i2t: vnorm[Ni*R] + cgram_off[Nc] + cgram[<= n_rows * NT]
+    size_t t2i = align256((size_t)Ni * R * R * 4) + align256((size_t)n_rows * 4);
+    size_t i2t = align256((size_t)Ni * R * 4) + align256((size_t)Nc * 8) + align256((size_t)n_rows * ITR_SCAN_NT * 4);
+    return t2i > i2t ? t2i : i2t;
+}
+
+extern "C" int itr_scan_xattn_scores(const float *img, const float *words, const int64_t *cap_off,
+                                     const int32_t *cap_len, const int32_t *tile_begin_dev, int64_t n_tiles,
+                                     int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D, int mode, int norm,
+                                     int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
+                                     void *workspace, size_t workspace_bytes, itr_stream_t stream) {
+    using namespace itr;
+    ITR_REQUIRE(img && words && cap_off && cap_len && tile_begin_dev && S && workspace,
+                "itr_scan_xattn_scores: null pointer");
+    ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && n_tiles >= 0 && ldS >= Nc, "itr_scan_xattn_scores: bad shape");
+    if (mode != 0 && mode != 1) { set_error("unknown cross_attn mode %d", mode); return ITR_ERR_BADARG; }
+    if (norm < 0 || norm > 6) { set_error("unknown first norm type: %d", norm); return ITR_ERR_BADARG; }
+    if (agg < 0 || agg > 3) { set_error("unknown aggfunc: %d", agg); return ITR_ERR_BADARG; }
+    ITR_UNSUPPORTED(R != SC_R, "itr_scan_xattn_scores: this build handles %d regions per image, got %d", SC_R, R);
+    ITR_UNSUPPORTED(D <= 0 || D % SC_BK != 0, "itr_scan_xattn_scores: embed dim must be a multiple of %d, got %d",
+                    SC_BK, D);
+    ITR_REQUIRE((reinterpret_cast<uintptr_t>(img) & 15) == 0 && (reinterpret_cast<uintptr_t>(words) & 15) == 0,
+                "itr_scan_xattn_scores: operands must be 16-byte aligned");
+    ITR_REQUIRE(n_rows < 0x7fffffffLL, "itr_scan_xattn_scores: too many word rows");
+    ITR_REQUIRE(workspace_bytes >= itr_scan_workspace_bytes(Ni, R, n_rows, Nc),
+                "itr_scan_xattn_scores: workspace too small");
+    if (Ni == 0 || Nc == 0) return ITR_OK;
+    hipStream_t st = as_stream(stream);
+
+    ScanArgs a{};
+    a.img = img; a.words = words; a.cap_off = cap_off; a.cap_len = cap_len; a.tile_begin = tile_begin_dev;
+    a.S = S; a.ldS = ldS; a.Ni = Ni; a.Nc = Nc; a.n_tiles = n_tiles; a.D = D;
+    a.mode = mode; a.norm = norm; a.agg = agg; a.lambda_softmax = lambda_softmax; a.lambda_lse = lambda_lse;
+    char *ws = static_cast<char *>(workspace);
+    if (mode == 0) {
+        float *gram = reinterpret_cast<float *>(ws);
+        float *wnorm = reinterpret_cast<float *>(ws + align256((size_t)Ni * R * R * 4));
+        hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Ni), dim3(256), 0, st, img, (const int64_t *)nullptr,
+                           (const int32_t *)nullptr, R, D, gram, (const int64_t *)nullptr);
+        ITR_CHECK_LAUNCH("scan gram");
+        hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, st, words, n_rows, D, wnorm);
+        ITR_CHECK_LAUNCH("scan wnorm");
+        a.gram = gram; a.wnorm = wnorm;
+    } else {
+        float *vnorm = reinterpret_cast<float *>(ws);
+        int64_t *coff = reinterpret_cast<int64_t *>(ws + align256((size_t)Ni * R * 4));
+        float *cgram = reinterpret_cast<float *>(ws + align256((size_t)Ni * R * 4) + align256((size_t)Nc * 8));
+        hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)ceil_div(Ni * R, 4)), dim3(256), 0, st, img, Ni * R, D, vnorm);
+        ITR_CHECK_LAUNCH("scan vnorm");
+        hipLaunchKernelGGL(sq_prefix_kernel, dim3(1), dim3(1024), 0, st, cap_len, Nc, coff);
+        ITR_CHECK_LAUNCH("scan cgram offsets");
+        hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Nc), dim3(256), 0, st, words, cap_off, cap_len, 0, D, cgram,
+                           (const int64_t *)coff);
+        ITR_CHECK_LAUNCH("scan caption gram");
+        a.vnorm = vnorm; a.cgram = cgram; a.cgram_off = coff;
+    }
+
+    const int64_t img_tiles = ceil_div(Ni, SC_IMGS);
+    const int64_t PI = ceil_div(img_tiles, 8), PJ = ceil_div(n_tiles, 8);
+    const int64_t nblk = ceil_div(PI * PJ, 8) * 64 * 8;
+    ITR_UNSUPPORTED(nblk > 0x7fffffffLL, "itr_scan_xattn_scores: grid too large; shard the call");
+    static bool attr_set = false;
+    if (!attr_set) {
+        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanSmem)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(scan_xattn_kernel, dim3((unsigned)nblk), dim3(SC_THREADS), sizeof(ScanSmem), st, a);
+    ITR_CHECK_LAUNCH("scan_xattn");
+    return ITR_OK;
+}

@@ -1,0 +1,174 @@
+// Image / text towers of the GRU model family (VSE++, SCAN, SGRAF):
+//   itr_proj_l2norm : EncoderImagePrecomp.forward (itr/modalmodule/ImgEncoder.py:133-147)
+//   itr_gru_fwd     : EncoderText.forward         (itr/modalmodule/TextEncoder.py:38-70)
+//
+// GRU layout: captions are PACKED (caption b owns token rows tok_off[b] .. +len[b]) and sorted by
+// length descending, so the set of captions still running at step t is the prefix [0, n_t) --
+// exactly torch's pack_padded_sequence batch_sizes.  The input projection of ALL tokens is hoisted
+// into one MFMA GEMM [n_tok, E] x [E, 3D]; each time step is then one MFMA GEMM on the active
+// prefix (h[0:n_t] x W_hh^T) plus one fused gate kernel (sigmoid / tanh / state update / output
+// write, direction average and last-step gather folded in).
+#include "itr_common.h"
+
+namespace itr {
+
+int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+            int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
+int norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, int kind, int take_abs,
+              hipStream_t st);
+
+__global__ void embed_gather_kernel(const int64_t *__restrict__ tokens, int64_t n_tok, const float *__restrict__ embed,
+                                    int64_t V, int E, float *__restrict__ x, int *__restrict__ bad) {
+    const int64_t row = blockIdx.x;
+    int64_t id = tokens[row];
+    if (id < 0 || id >= V) {  // nn.Embedding would raise IndexError: flag it, keep memory safe
+        if (threadIdx.x == 0) atomicExch(bad, 1);
+        id = 0;
+    }
+    const float *src = embed + id * E;
+    float *dst = x + row * E;
+    for (int k = threadIdx.x; k < E; k += blockDim.x) dst[k] = src[k];
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// One GRU time step for the active prefix [0, n_act).  Gate order (r, z, n) (torch.nn.GRU):
+//   r = s(gi_r + gh_r); z = s(gi_z + gh_z); n = tanh(gi_n + r * gh_n); h' = (1 - z) * n + z * h
+// mode 0: out[row] = h'            (forward direction, or uni-directional)
+// mode 1: out[row] = (out[row] + h') / 2   (reverse direction of a bi-GRU, TextEncoder.py:54-55)
+__global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__ gi, const float *__restrict__ gh,
+                                                       float *__restrict__ h, float *__restrict__ out,
+                                                       const int64_t *__restrict__ tok_off,
+                                                       const int32_t *__restrict__ len, int t, int reverse,
+                                                       int mode, int D, int64_t n_act) {
+    const int64_t b = blockIdx.x;
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;
+    if (b >= n_act || j >= D) return;
+    const int64_t row = tok_off[b] + (reverse ? (len[b] - 1 - t) : t);
+    const float *gir = gi + row * 3 * D;
+    const float *ghr = gh + b * 3 * D;
+    const float r = sigmoidf_(gir[j] + ghr[j]);
+    const float z = sigmoidf_(gir[D + j] + ghr[D + j]);
+    const float n = tanhf(gir[2 * D + j] + r * ghr[2 * D + j]);
+    const float hp = h[b * D + j];
+    const float hn = (1.f - z) * n + z * hp;
+    h[b * D + j] = hn;
+    float *o = out + row * D + j;
+    *o = mode ? (*o + hn) / 2.f : hn;
+}
+
+__global__ void gather_last_kernel(const float *__restrict__ out, const int64_t *__restrict__ tok_off,
+                                   const int32_t *__restrict__ len, int D, float *__restrict__ out_last) {
+    const int64_t b = blockIdx.x;
+    const float *src = out + (tok_off[b] + len[b] - 1) * D;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) out_last[b * D + k] = src[k];
+}
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct GruWs {
+    float *x, *gi, *gh, *h, *out_tmp;
+    int *bad;
+};
+
+static GruWs carve(void *ws, int64_t n_tok, int64_t B, int E, int D) {
+    char *p = static_cast<char *>(ws);
+    GruWs w;
+    w.x = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * E * 4);
+    w.gi = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * 3 * D * 4);
+    w.gh = reinterpret_cast<float *>(p); p += al256((size_t)B * 3 * D * 4);
+    w.h = reinterpret_cast<float *>(p); p += al256((size_t)B * D * 4);
+    w.out_tmp = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * D * 4);
+    w.bad = reinterpret_cast<int *>(p);
+    return w;
+}
+
+}  // namespace itr
+
+extern "C" int itr_proj_l2norm(const float *x, const float *W, const float *b, float *out, int64_t rows, int F,
+                               int D, int no_imgnorm, int use_abs, itr_stream_t stream) {
+    ITR_REQUIRE(x && W && out, "itr_proj_l2norm: null pointer");
+    ITR_REQUIRE(rows >= 0 && F > 0 && D > 0, "itr_proj_l2norm: bad shape");
+    hipStream_t st = itr::as_stream(stream);
+    int rc = itr::gemm_nt(x, F, W, F, b, out, D, rows, D, F, 0, st);
+    if (rc != ITR_OK) return rc;
+    if (!no_imgnorm) return itr::norm_rows(out, out, rows, D, 1e-8f, 0, use_abs, st);
+    if (use_abs) {
+        // abs without normalisation: kind 2 with eps = +inf would rescale; do it as l1 of nothing.
+        itr::set_error("itr_proj_l2norm: use_abs without normalisation is not supported");
+        return ITR_ERR_UNSUPPORTED;
+    }
+    return ITR_OK;
+}
+
+extern "C" size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional) {
+    using itr::al256;
+    (void)bidirectional;
+    return al256((size_t)n_tok * E * 4) + al256((size_t)n_tok * 3 * D * 4) + al256((size_t)B * 3 * D * 4) +
+           al256((size_t)B * D * 4) + al256((size_t)n_tok * D * 4) + 256;
+}
+
+extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev,
+                           const int32_t *len_host, int64_t B, int64_t n_tok, const float *embed, int64_t V, int E,
+                           int D, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                           const float *w_ih_rev, const float *w_hh_rev, const float *b_ih_rev,
+                           const float *b_hh_rev, int no_txtnorm, int use_abs, int gather_last, float *out,
+                           float *out_last, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
+    using namespace itr;
+    ITR_REQUIRE(tokens && tok_off && len_dev && len_host && embed && w_ih && w_hh && b_ih && b_hh && workspace,
+                "itr_gru_fwd: null pointer");
+    ITR_REQUIRE(B >= 1 && n_tok >= 1 && E > 0 && D > 0 && V > 0, "itr_gru_fwd: bad shape");
+    const bool bi = w_ih_rev != nullptr;
+    ITR_REQUIRE(!bi || (w_hh_rev && b_ih_rev && b_hh_rev), "itr_gru_fwd: incomplete reverse-direction weights");
+    ITR_REQUIRE(gather_last ? out_last != nullptr : out != nullptr, "itr_gru_fwd: output pointer missing");
+    ITR_REQUIRE(workspace_bytes >= itr_gru_workspace_bytes(n_tok, B, E, D, bi), "itr_gru_fwd: workspace too small");
+    ITR_REQUIRE(use_abs == 0 || no_txtnorm == 0, "itr_gru_fwd: use_abs without l2norm is not supported");
+    int64_t total = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        ITR_REQUIRE(len_host[b] >= 1, "itr_gru_fwd: caption %lld has length %d", (long long)b, len_host[b]);
+        ITR_REQUIRE(b == 0 || len_host[b] <= len_host[b - 1],
+                    "itr_gru_fwd: captions must be sorted by length, descending (pack_padded_sequence)");
+        total += len_host[b];
+    }
+    ITR_REQUIRE(total == n_tok, "itr_gru_fwd: sum(len) = %lld != n_tok = %lld", (long long)total, (long long)n_tok);
+    hipStream_t st = as_stream(stream);
+    GruWs w = carve(workspace, n_tok, B, E, D);
+    float *seq = out ? out : w.out_tmp;
+    const int Lmax = len_host[0];
+
+    ITR_CHECK_HIP(hipMemsetAsync(w.bad, 0, sizeof(int), st));
+    hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, w.x,
+                       w.bad);
+    ITR_CHECK_LAUNCH("embed_gather");
+
+    for (int dir = 0; dir < (bi ? 2 : 1); ++dir) {
+        const float *wi = dir ? w_ih_rev : w_ih, *wh = dir ? w_hh_rev : w_hh;
+        const float *bi_ = dir ? b_ih_rev : b_ih, *bh = dir ? b_hh_rev : b_hh;
+        int rc = gemm_nt(w.x, E, wi, E, bi_, w.gi, 3 * D, n_tok, 3 * D, E, 0, st);
+        if (rc != ITR_OK) return rc;
+        ITR_CHECK_HIP(hipMemsetAsync(w.h, 0, (size_t)B * D * 4, st));
+        int64_t n_act = B;
+        for (int t = 0; t < Lmax; ++t) {
+            while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
+            rc = gemm_nt(w.h, D, wh, D, bh, w.gh, 3 * D, n_act, 3 * D, D, 0, st);
+            if (rc != ITR_OK) return rc;
+            dim3 grid((unsigned)n_act, (unsigned)ceil_div(D, 256));
+            hipLaunchKernelGGL(gru_gate_kernel, grid, dim3(256), 0, st, w.gi, w.gh, w.h, seq, tok_off, len_dev, t, dir,
+                               dir, D, n_act);
+            ITR_CHECK_LAUNCH("gru_gate");
+        }
+    }
+    float *final_ = seq;
+    int64_t final_rows = n_tok;
+    if (gather_last) {
+        hipLaunchKernelGGL(gather_last_kernel, dim3((unsigned)B), dim3(256), 0, st, seq, tok_off, len_dev, D, out_last);
+        ITR_CHECK_LAUNCH("gather_last");
+        final_ = out_last;
+        final_rows = B;
+    }
+    if (!no_txtnorm) {
+        int rc = norm_rows(final_, final_, final_rows, D, 1e-8f, 0, use_abs, st);
+        if (rc != ITR_OK) return rc;
+    }
+    return ITR_OK;
+}

@@ -1,0 +1,78 @@
+"""ctypes binding of libitr_hip.so (C ABI declared in include/itr_hip.h).
+
+There is NO CPU fallback: importing the ops without the built library, or calling them with
+CPU tensors, raises.  Error codes map onto the reference's exception types:
+ITR_ERR_BADARG -> ValueError, ITR_ERR_UNSUPPORTED -> NotImplementedError, ITR_ERR_HIP ->
+RuntimeError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
+
+ABI_VERSION = 1
+
+i32, i64, f32, vp, sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes).  Kept in one table so tests can check that every symbol the
+# header declares is exported with the arity the binding expects.
+SIGNATURES = {
+    "itr_last_error": (C.c_char_p, []),
+    "itr_abi_version": (i32, []),
+    "itr_l2norm_rows": (i32, [vp, vp, i64, i32, f32, i32, i32, vp]),
+    "itr_gemm_nt": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
+    "itr_proj_l2norm": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "itr_gru_workspace_bytes": (sz, [i64, i64, i32, i32, i32]),
+    "itr_gru_fwd": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp,
+                          i32, i32, i32, vp, vp, vp, sz, vp]),
+    "itr_cosine_scores": (i32, [vp, vp, vp, i64, i64, i32, i64, vp]),
+    "itr_mvm_scores": (i32, [vp, vp, vp, i64, i64, i32, i32, i64, vp]),
+    "itr_hinge_maxviol_fwd": (i32, [vp, i32, i64, f32, i32, vp, vp, vp, vp, vp]),
+    "itr_hinge_maxviol_bwd": (i32, [vp, i32, i64, f32, i32, vp, vp, vp, vp, i64, vp]),
+    "itr_scan_plan_tiles": (i32, [vp, i64, i32, vp, vp]),
+    "itr_scan_workspace_bytes": (sz, [i64, i32, i64, i64]),
+    "itr_scan_xattn_scores": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32,
+                                    f32, f32, vp, i64, vp, sz, vp]),
+    "itr_rank_gather_gt": (i32, [vp, i64, i64, i64, i64, i32, vp, vp]),
+    "itr_rank_counts": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
+    "itr_recall_from_ranks": (i32, [vp, i64, vp]),
+}
+
+_lib = None
+
+
+class ItrLibraryMissing(ImportError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raises ItrLibraryMissing loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ItrLibraryMissing(
+            "libitr_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C image-text-retrieval_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.itr_abi_version() != ABI_VERSION:
+        raise ItrLibraryMissing("libitr_hip.so ABI %d != binding ABI %d: rebuild" %
+                                (lib.itr_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code == 0:
+        return
+    msg = load().itr_last_error().decode("utf-8", "replace")
+    if code == -1:
+        raise ValueError(msg)
+    if code == -2:
+        raise NotImplementedError(msg)
+    raise RuntimeError("libitr_hip (code %d): %s" % (code, msg))

@@ -1,0 +1,312 @@
+"""Thin torch-tensor front end of the C ABI (include/itr_hip.h).
+
+torch is plumbing here: it owns device memory and the current HIP stream; every op below hands
+raw device pointers + sizes to libitr_hip.so.  CPU tensors are rejected -- there is no fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SCAN_NT = 64
+_NORMS = {'clipped_l2norm': 0, 'l2norm': 1, 'softmax': 2, 'no_norm': 3, 'clipped': 4, 'l1norm': 5,
+          'clipped_l1norm': 6}
+_AGGS = {'LogSumExp': 0, 'Max': 1, 'Sum': 2, 'Mean': 3}
+_ACTS = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'gelu': 4, 'leaky_relu': 5}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=torch.float32, name="tensor"):
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a torch tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s is on %s: the itr_amd ops only run on the GPU (no CPU fallback)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t.contiguous()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _host_i32(a):
+    arr = np.ascontiguousarray(np.asarray([int(x) for x in a] if not isinstance(a, np.ndarray) else a, dtype=np.int32))
+    return arr
+
+
+# ------------------------------------------------------------------------------------------
+def l2norm(x, dim=-1, eps=1e-8):
+    """utils.l2norm (eps after the sqrt).  Any `dim`: the tensor is viewed with `dim` last."""
+    return _norm(x, dim, eps, 0)
+
+
+def l1norm(x, dim=-1, eps=1e-8):
+    return _norm(x, dim, eps, 1)
+
+
+def normalize(x, dim=-1, eps=1e-12):
+    """F.normalize(p=2) semantics: x / max(||x||, eps)."""
+    return _norm(x, dim, eps, 2)
+
+
+def _norm(x, dim, eps, kind, take_abs=False):
+    lib = _lib.load()
+    x = _dev(x, name="x")
+    dim = dim % x.dim()
+    moved = dim != x.dim() - 1
+    xs = x.movedim(dim, -1).contiguous() if moved else x
+    y = torch.empty_like(xs)
+    rows = xs.numel() // xs.shape[-1] if xs.numel() else 0
+    _lib.check(lib.itr_l2norm_rows(_p(xs), _p(y), rows, xs.shape[-1], eps, kind, int(take_abs), _stream()))
+    return y.movedim(-1, dim).contiguous() if moved else y
+
+
+def linear(x, weight, bias=None, act=None):
+    """act(x @ weight^T + bias) on the fp32 MFMA GEMM.  x (..., K), weight (N, K)."""
+    lib = _lib.load()
+    x = _dev(x, name="x")
+    weight = _dev(weight, name="weight")
+    K = x.shape[-1]
+    if weight.shape[1] != K:
+        raise ValueError("linear: x (..., %d) vs weight %s" % (K, tuple(weight.shape)))
+    M = x.numel() // K if K else 0
+    N = weight.shape[0]
+    b = _dev(bias, name="bias") if bias is not None else None
+    out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+    _lib.check(lib.itr_gemm_nt(_p(x), K, _p(weight), K, _p(b), _p(out), N, M, N, K, _ACTS[act], _stream()))
+    return out
+
+
+def proj_l2norm(images, weight, bias, no_imgnorm=False, use_abs=False):
+    """EncoderImagePrecomp.forward (ImgEncoder.py:133-147)."""
+    lib = _lib.load()
+    images = _dev(images, name="images")
+    weight = _dev(weight, name="fc.weight")
+    bias = _dev(bias, name="fc.bias")
+    F_, D = images.shape[-1], weight.shape[0]
+    if weight.shape[1] != F_:
+        raise ValueError("proj_l2norm: feature dim %d vs fc.weight %s" % (F_, tuple(weight.shape)))
+    rows = images.numel() // F_
+    out = torch.empty(images.shape[:-1] + (D,), device=images.device, dtype=torch.float32)
+    _lib.check(lib.itr_proj_l2norm(_p(images), _p(weight), _p(bias), _p(out), rows, F_, D, int(no_imgnorm),
+                                   int(use_abs), _stream()))
+    return out
+
+
+def cosine_scores(im, s):
+    """cosine_sim (Objectives.py:18-21): im @ s^T."""
+    lib = _lib.load()
+    im = _dev(im, name="im")
+    s = _dev(s, name="s")
+    if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
+        raise ValueError("cosine_scores: expected (Ni, D) and (Nc, D), got %s and %s" % (tuple(im.shape), tuple(s.shape)))
+    S = torch.empty(im.shape[0], s.shape[0], device=im.device, dtype=torch.float32)
+    _lib.check(lib.itr_cosine_scores(_p(im), _p(s), _p(S), im.shape[0], s.shape[0], im.shape[1], s.shape[0], _stream()))
+    return S
+
+
+def pdist_cos(x1, x2):
+    """Objectives.pdist_cos (:310-323): rows / ||row|| (no eps), mm, NaN -> 0."""
+    a = _norm(x1, -1, 0.0, 3)
+    b = _norm(x2, -1, 0.0, 3)
+    res = cosine_scores(a, b)
+    return torch.nan_to_num_(res, nan=0.0, posinf=float('inf'), neginf=float('-inf'))
+
+
+def mvm_scores(imgs, caps):
+    """MultiViewMatching.forward (Fusionmodule.py:674-692)."""
+    lib = _lib.load()
+    imgs = _dev(imgs, name="imgs")
+    caps = _dev(caps, name="caps")
+    if imgs.dim() != 3 or caps.dim() != 2 or imgs.shape[2] != caps.shape[1]:
+        raise ValueError("mvm_scores: expected (Ni, k, D) and (Nc, D)")
+    Ni, k, D = imgs.shape
+    S = torch.empty(Ni, caps.shape[0], device=imgs.device, dtype=torch.float32)
+    _lib.check(lib.itr_mvm_scores(_p(imgs), _p(caps), _p(S), Ni, caps.shape[0], k, D, caps.shape[0], _stream()))
+    return S
+
+
+# ------------------------------------------------------------------------------------------
+def hinge_fwd(scores, margin, max_violation):
+    """-> (loss[1], row_arg, col_arg)."""
+    lib = _lib.load()
+    scores = _dev(scores, name="scores")
+    if scores.dim() != 2 or scores.shape[0] != scores.shape[1]:
+        raise ValueError("hinge loss needs a square score matrix, got %s" % (tuple(scores.shape),))
+    B = scores.shape[0]
+    loss = torch.empty(1, device=scores.device, dtype=torch.float32)
+    row_arg = torch.empty(B, device=scores.device, dtype=torch.int32)
+    col_arg = torch.empty(B, device=scores.device, dtype=torch.int32)
+    ws = torch.empty(2 * B, device=scores.device, dtype=torch.float32)
+    _lib.check(lib.itr_hinge_maxviol_fwd(_p(scores), B, B, float(margin), int(bool(max_violation)), _p(loss),
+                                         _p(row_arg), _p(col_arg), _p(ws), _stream()))
+    return loss, row_arg, col_arg
+
+
+def hinge_bwd(scores, margin, max_violation, row_arg, col_arg, grad_loss):
+    lib = _lib.load()
+    scores = _dev(scores, name="scores")
+    B = scores.shape[0]
+    g = _dev(grad_loss.reshape(1), name="grad_loss")
+    dS = torch.empty_like(scores)
+    _lib.check(lib.itr_hinge_maxviol_bwd(_p(scores), B, B, float(margin), int(bool(max_violation)), _p(row_arg),
+                                         _p(col_arg), _p(g), _p(dS), B, _stream()))
+    return dS
+
+
+class _HingeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, margin, max_violation):
+        scores = scores.contiguous()
+        loss, ra, ca = hinge_fwd(scores, margin, max_violation)
+        ctx.save_for_backward(scores, ra, ca)
+        ctx.margin, ctx.mv = margin, max_violation
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad):
+        scores, ra, ca = ctx.saved_tensors
+        return hinge_bwd(scores, ctx.margin, ctx.mv, ra, ca, grad.contiguous()), None, None
+
+
+def hinge_loss(scores, margin=0.2, max_violation=False):
+    """Differentiable (w.r.t. scores) bidirectional hinge loss, HIP forward and backward."""
+    return _HingeFn.apply(scores, margin, max_violation)
+
+
+# ------------------------------------------------------------------------------------------
+class ScanPlan:
+    """Column-tile plan of a caption set for the SCAN kernel (host-side, cheap, reusable)."""
+
+    def __init__(self, cap_off, cap_len, n_rows, device):
+        lib = _lib.load()
+        self.len_host = _host_i32(cap_len)
+        self.Nc = len(self.len_host)
+        self.n_rows = int(n_rows)
+        tb = np.zeros(self.Nc + 1, dtype=np.int32)
+        nt = C.c_int64(0)
+        _lib.check(lib.itr_scan_plan_tiles(self.len_host.ctypes.data_as(C.c_void_p), self.Nc, SCAN_NT,
+                                           tb.ctypes.data_as(C.c_void_p), C.byref(nt)))
+        self.n_tiles = int(nt.value)
+        self.tile_begin = torch.from_numpy(tb[:self.n_tiles + 1].copy()).to(device)
+        self.cap_len = torch.from_numpy(self.len_host.copy()).to(device)
+        self.cap_off = torch.as_tensor(np.asarray(cap_off, dtype=np.int64)).to(device)
+
+
+def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='clipped_l2norm',
+                      agg_func='LogSumExp', lambda_lse=6.0, lambda_softmax=9.0, out=None):
+    """xattn_score_t2i / _i2t (Objectives.py:329-417).  images (Ni, 36, D); words (n_rows, D) with the
+    caption layout described by `plan` (ScanPlan).  -> (Ni, Nc)."""
+    lib = _lib.load()
+    if cross_attn not in ('t2i', 'i2t'):
+        raise ValueError("unknown first norm type:", raw_feature_norm)  # the reference's message (Objectives.py:71)
+    if raw_feature_norm not in _NORMS:
+        raise ValueError("unknown first norm type:", raw_feature_norm)
+    if agg_func not in _AGGS:
+        raise ValueError("unknown aggfunc: {}".format(agg_func))
+    images = _dev(images, name="images")
+    words = _dev(words, name="words")
+    Ni, R, D = images.shape
+    n_rows = words.shape[0]
+    if out is None:
+        out = torch.empty(Ni, plan.Nc, device=images.device, dtype=torch.float32)
+    wsb = lib.itr_scan_workspace_bytes(Ni, R, n_rows, plan.Nc)
+    ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
+    _lib.check(lib.itr_scan_xattn_scores(
+        _p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin), plan.n_tiles, Ni, plan.Nc,
+        n_rows, R, D, 0 if cross_attn == 't2i' else 1, _NORMS[raw_feature_norm], _AGGS[agg_func],
+        float(lambda_softmax), float(lambda_lse), _p(out), out.stride(0), _p(ws), wsb, _stream()))
+    return out
+
+
+def scan_xattn_padded(images, captions, cap_lens, **kw):
+    """Reference call shape: captions (Nc, L, D) padded + cap_lens (Objectives.py:329)."""
+    Nc, L, D = captions.shape
+    lens = [int(x) for x in cap_lens][:Nc]
+    plan = ScanPlan(np.arange(Nc, dtype=np.int64) * L, lens, Nc * L, captions.device)
+    return scan_xattn_scores(images, _dev(captions, name="captions").reshape(Nc * L, D), plan, **kw)
+
+
+# ------------------------------------------------------------------------------------------
+def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtnorm=False, use_abs=False,
+               gather_last=False):
+    """EncoderText.forward on packed captions (TextEncoder.py:38-70).
+    tokens_packed (n_tok,) int64 cuda; tok_off (B,) int64; lengths: host list sorted descending.
+    weights: dict with the reference's state_dict names.  -> (n_tok, D) packed word embeddings, or
+    (B, D) when gather_last."""
+    lib = _lib.load()
+    tokens_packed = _dev(tokens_packed, torch.int64, "tokens")
+    len_host = _host_i32(lengths)
+    B = len(len_host)
+    n_tok = int(tokens_packed.numel())
+    dev = tokens_packed.device
+    tok_off = _dev(tok_off, torch.int64, "tok_off")
+    len_dev = torch.from_numpy(len_host.copy()).to(dev)
+    emb = _dev(weights['embed.weight'], name="embed.weight")
+    V, E = emb.shape
+    w_ih = _dev(weights['rnn.weight_ih_l0'])
+    w_hh = _dev(weights['rnn.weight_hh_l0'])
+    b_ih = _dev(weights['rnn.bias_ih_l0'])
+    b_hh = _dev(weights['rnn.bias_hh_l0'])
+    D = w_hh.shape[1]
+    rev = [None] * 4
+    if bidirectional:
+        rev = [_dev(weights['rnn.weight_ih_l0_reverse']), _dev(weights['rnn.weight_hh_l0_reverse']),
+               _dev(weights['rnn.bias_ih_l0_reverse']), _dev(weights['rnn.bias_hh_l0_reverse'])]
+    wsb = lib.itr_gru_workspace_bytes(n_tok, B, E, D, int(bool(bidirectional)))
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    out = None if gather_last else torch.empty(n_tok, D, device=dev, dtype=torch.float32)
+    out_last = torch.empty(B, D, device=dev, dtype=torch.float32) if gather_last else None
+    _lib.check(lib.itr_gru_fwd(_p(tokens_packed), _p(tok_off), _p(len_dev), len_host.ctypes.data_as(C.c_void_p), B,
+                               n_tok, _p(emb), V, E, D, _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), _p(rev[0]),
+                               _p(rev[1]), _p(rev[2]), _p(rev[3]), int(no_txtnorm), int(use_abs), int(gather_last),
+                               _p(out), _p(out_last), _p(ws), wsb, _stream()))
+    return out_last if gather_last else out
+
+
+# ------------------------------------------------------------------------------------------
+def rank_counts(S, im_div=5, row0=0, s_gt=None, t2i_rank=None, t2i_best=None):
+    """Sort-free ranks of a (local row block of a) similarity matrix.
+    -> (i2t_rank int32[n_rows], i2t_top1 int32[n_rows], t2i_rank int32[Nc], t2i_best uint64-as-int64[Nc], s_gt)
+    For a single GPU (row0 = 0, all rows local) t2i_rank is final and t2i_top1 = t2i_best & 0xffffffff."""
+    lib = _lib.load()
+    S = _dev(S, name="S")
+    n_rows, Nc = S.shape
+    dev = S.device
+    if s_gt is None:
+        s_gt = torch.full((Nc,), float('-inf'), device=dev, dtype=torch.float32)
+        _lib.check(lib.itr_rank_gather_gt(_p(S), S.stride(0), row0, n_rows, Nc, im_div, _p(s_gt), _stream()))
+    i2t_rank = torch.empty(n_rows, device=dev, dtype=torch.int32)
+    i2t_top1 = torch.empty(n_rows, device=dev, dtype=torch.int32)
+    if t2i_rank is None:
+        t2i_rank = torch.zeros(Nc, device=dev, dtype=torch.int32)
+    if t2i_best is None:
+        t2i_best = torch.zeros(Nc, device=dev, dtype=torch.int64)
+    _lib.check(lib.itr_rank_counts(_p(S), S.stride(0), row0, n_rows, Nc, im_div, _p(s_gt), _p(i2t_rank), _p(i2t_top1),
+                                   _p(t2i_rank), _p(t2i_best), _stream()))
+    return i2t_rank, i2t_top1, t2i_rank, t2i_best, s_gt
+
+
+def gather_gt(S, im_div=5, row0=0, s_gt=None):
+    lib = _lib.load()
+    S = _dev(S, name="S")
+    n_rows, Nc = S.shape
+    if s_gt is None:
+        s_gt = torch.full((Nc,), float('-inf'), device=S.device, dtype=torch.float32)
+    _lib.check(lib.itr_rank_gather_gt(_p(S), S.stride(0), row0, n_rows, Nc, im_div, _p(s_gt), _stream()))
+    return s_gt
+
+
+def recall_from_ranks(ranks):
+    """(r1, r5, r10, medr, meanr) from 0-based integer ranks (evaluation.py:181-185); host side."""
+    lib = _lib.load()
+    r = np.ascontiguousarray(np.asarray(ranks, dtype=np.int32))
+    out = (C.c_double * 5)()
+    _lib.check(lib.itr_recall_from_ranks(r.ctypes.data_as(C.c_void_p), len(r), out))
+    return tuple(float(v) for v in out)

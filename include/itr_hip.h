@@ -1,0 +1,145 @@
+/*
+ * itr_hip.h -- C ABI of libitr_hip.so: the MI355X (gfx950) encode -> score -> loss / rank
+ * hot path of WangFei-2019/Image-text-Retrieval.
+ *
+ * The reference is 100 % Python and has no FFI layer; its seams for this path are the
+ * Python callables listed in SURVEY.md section 8(b).  Each entry point below replaces the
+ * arithmetic of one of them (reference file:line cited per function); the Python package
+ * `itr_amd` keeps the reference's call signatures on top of this ABI (see INTEGRATION.md for
+ * the ctypes binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major data unless the name ends in
+ *     `_host`; fp32 unless stated; the caller owns all memory (no allocation inside);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call only
+ *     enqueues work on it and returns;
+ *   - return value: ITR_OK (0) or a negative ITR_ERR_* code; `itr_last_error()` returns a
+ *     thread-local message for the last failing call on this thread;
+ *   - no exceptions cross the ABI, no global mutable state besides the error string.
+ */
+#ifndef ITR_HIP_H
+#define ITR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ITR_OK 0
+#define ITR_ERR_BADARG (-1)      /* -> Python ValueError */
+#define ITR_ERR_UNSUPPORTED (-2) /* -> Python NotImplementedError */
+#define ITR_ERR_HIP (-3)         /* -> Python RuntimeError */
+
+typedef void *itr_stream_t;
+
+const char *itr_last_error(void);
+/* ABI version, bumped on any signature change. */
+int itr_abi_version(void);
+
+/* ---- a1: l2norm / l1norm  (itr/modalmodule/utils.py:4-15) ----------------------------
+ * y[r,:] = x[r,:] / (norm(x[r,:]) + eps), eps added AFTER the sqrt.  kind: 0 = L2, 1 = L1,
+ * 2 = F.normalize semantics x / max(||x||_2, eps) (TextEncoder.py:151, ImgEncoder.py:349),
+ * 3 = plain x / ||x||_2 without eps (pdist_cos, Objectives.py:318-319; 0/0 stays NaN).
+ * take_abs != 0 additionally applies |.| (use_abs, ImgEncoder.py:144).  In place allowed. */
+int itr_l2norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, int kind,
+                    int take_abs, itr_stream_t stream);
+
+/* ---- generic fp32 MFMA GEMM used by the towers ----------------------------------------
+ * C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]);  lda/ldb/ldc are row strides in elements.
+ * bias may be NULL.  act: 0 none, 1 relu, 2 tanh, 3 sigmoid, 4 gelu(erf), 5 leaky_relu(0.1).
+ * Exact fp32 (v_mfma_f32_32x32x2_f32).  Replaces nn.Linear / torch.mm call sites on the path
+ * (ImgEncoder.py:137, Objectives.py:21, Fusionmodule.py:427-431 ...). */
+int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
+                itr_stream_t stream);
+
+/* ---- a2: EncoderImagePrecomp.forward (itr/modalmodule/ImgEncoder.py:133-147) -----------
+ * out[rows, D] = l2norm(x[rows, F] * W[D, F]^T + b[D]) [abs]; rows = n_img * n_regions.
+ * no_imgnorm / use_abs as in the reference constructor. */
+int itr_proj_l2norm(const float *x, const float *W, const float *b, float *out, int64_t rows,
+                    int F, int D, int no_imgnorm, int use_abs, itr_stream_t stream);
+
+/* ---- a3: EncoderText.forward (itr/modalmodule/TextEncoder.py:38-70) --------------------
+ * Embedding -> (bi)GRU with packed-sequence semantics -> (fwd+bwd)/2 -> [l2norm] [abs].
+ * Captions are PACKED: caption c owns rows [tok_off[c], tok_off[c]+len[c]) of `tokens`
+ * (int64 ids, device) and of `out` (fp32 [n_tok, D]).  Captions must be sorted by length
+ * DESCENDING (collate_fn does this, data_loader.py:146).  Host arrays: len_host[B].
+ * w_ih [3D,E], w_hh [3D,D], b_ih/b_hh [3D] with torch gate order (r,z,n); *_rev = NULL for a
+ * uni-directional GRU.  gather_last != 0 writes only the len-1 state of every caption to
+ * out_last[B,D] (method_name in {VSE++,VSRN}, TextEncoder.py:57-60) -- `out` may be NULL then.
+ * workspace: itr_gru_workspace_bytes(n_tok, B, E, D, bi) bytes. */
+size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional);
+int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev,
+                const int32_t *len_host, int64_t B, int64_t n_tok, const float *embed, int64_t V,
+                int E, int D, const float *w_ih, const float *w_hh, const float *b_ih,
+                const float *b_hh, const float *w_ih_rev, const float *w_hh_rev,
+                const float *b_ih_rev, const float *b_hh_rev, int no_txtnorm, int use_abs,
+                int gather_last, float *out, float *out_last, void *workspace,
+                size_t workspace_bytes, itr_stream_t stream);
+
+/* ---- a4: cosine_sim (itr/modalmodule/Objectives.py:18-21) ------------------------------
+ * S[Ni,Nc] = im[Ni,D] * s[Nc,D]^T.  Also serves pdist_cos (a9, :310-323) after
+ * itr_l2norm_rows(kind=3) and MultiViewMatching (a8) via itr_mvm_scores. */
+int itr_cosine_scores(const float *im, const float *s, float *S, int64_t Ni, int64_t Nc, int D,
+                      int64_t ldS, itr_stream_t stream);
+
+/* ---- a8: MultiViewMatching.forward (itr/modalmodule/Fusionmodule.py:674-692) ------------
+ * S[i,c] = max_v imgs[i,v,:] . caps[c,:]   (imgs [Ni,k,D], caps [Nc,D]). */
+int itr_mvm_scores(const float *imgs, const float *caps, float *S, int64_t Ni, int64_t Nc, int k,
+                   int D, int64_t ldS, itr_stream_t stream);
+
+/* ---- a5/a10: ContrastiveLoss / TripletLoss (Objectives.py:76-115, :492-517) ------------
+ * loss = sum_i red_{j!=i}[m + S_ij - S_ii]_+ + sum_j red_{i!=j}[m + S_ij - S_jj]_+,
+ * red = max if max_violation else sum.  fwd writes loss[0] and, for the backward, the arg of
+ * the row / column maxima (row_arg[B], col_arg[B]; unused for the sum form, may be NULL).
+ * bwd writes dS[B,B] = grad_loss[0] * dloss/dS. */
+int itr_hinge_maxviol_fwd(const float *S, int B, int64_t ldS, float margin, int max_violation,
+                          float *loss, int32_t *row_arg, int32_t *col_arg, float *cost_ws /* [2B] */,
+                          itr_stream_t stream);
+int itr_hinge_maxviol_bwd(const float *S, int B, int64_t ldS, float margin, int max_violation,
+                          const int32_t *row_arg, const int32_t *col_arg, const float *grad_loss,
+                          float *dS, int64_t lddS, itr_stream_t stream);
+
+/* ---- a6: xattn_score_t2i / xattn_score_i2t (Objectives.py:329-476) ---------------------
+ * img [Ni,R,D]; words [n_rows,D] with caption c owning rows cap_off[c] .. cap_off[c]+len[c]-1
+ * (padded (Nc,L,D) input: cap_off[c] = c*L).  S[i,c] written with row stride ldS.
+ * mode: 0 t2i, 1 i2t.  norm: 0 clipped_l2norm, 1 l2norm, 2 softmax, 3 no_norm, 4 clipped,
+ * 5 l1norm, 6 clipped_l1norm.  agg: 0 LogSumExp, 1 Max, 2 Sum, 3 Mean.
+ * Tile plan: captions are grouped host-side into column tiles of <= ITR_SCAN_NT words by
+ * itr_scan_plan_tiles (pure CPU); tile_begin_dev[n_tiles+1] is that plan on the device.
+ * workspace: itr_scan_workspace_bytes(Ni, R, n_rows, Nc) bytes (Gram matrices + norms). */
+#define ITR_SCAN_NT 64
+int itr_scan_plan_tiles(const int32_t *len_host, int64_t Nc, int nt, int32_t *tile_begin_host,
+                        int64_t *n_tiles);
+size_t itr_scan_workspace_bytes(int64_t Ni, int R, int64_t n_rows, int64_t Nc);
+int itr_scan_xattn_scores(const float *img, const float *words, const int64_t *cap_off,
+                          const int32_t *cap_len, const int32_t *tile_begin_dev, int64_t n_tiles,
+                          int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D, int mode, int norm,
+                          int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
+                          void *workspace, size_t workspace_bytes, itr_stream_t stream);
+
+/* ---- a17: i2t / t2i ranker (itr/metricmodule/evaluation.py:156-222) --------------------
+ * Sort-free: rank(query, gt) = #{k: S_k > S_gt} + #{k > gt: S_k == S_gt}; i2t takes the min
+ * over the im_div GT captions im_div*i .. im_div*i+im_div-1; t2i's GT image is j / im_div.
+ * top1 = argmax (highest index on ties).  S is the LOCAL row block [n_rows_local, Nc] holding
+ * global image rows row0 .. row0+n_rows_local-1 (row0 = 0 for a single GPU).
+ *   i2t_rank/top1 [n_rows_local]  -- complete (rows are local).
+ *   t2i needs the GT score of every caption: pass s_gt[Nc] (gathered over ranks); the kernel
+ *   ACCUMULATES partial counts into t2i_rank[Nc] (int32, zero it first) and max-reduces
+ *   t2i_best[Nc] (uint64 key = ordered(score) << 32 | row; zero it first), so a sum /
+ *   max all-reduce over ranks completes them.  itr_rank_gather_gt fills s_gt for the GT
+ *   rows this rank owns (others left untouched; buffer pre-filled with -inf + max-reduce). */
+int itr_rank_gather_gt(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
+                       int im_div, float *s_gt, itr_stream_t stream);
+int itr_rank_counts(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
+                    int im_div, const float *s_gt, int32_t *i2t_rank, int32_t *i2t_top1,
+                    int32_t *t2i_rank, uint64_t *t2i_best, itr_stream_t stream);
+/* host-side summary (evaluation.py:181-185): out5 = r1, r5, r10, medr, meanr. */
+int itr_recall_from_ranks(const int32_t *ranks_host, int64_t n, double *out5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ITR_HIP_H */

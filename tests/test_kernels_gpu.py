@@ -1,0 +1,307 @@
+"""GPU parity tests: every HIP kernel (through the C ABI) against the CPU oracle and the golden
+vectors captured from the reference.  Tolerances: fp32 score/embedding values 2e-5 abs unless
+stated (different summation order than the CPU bmm); loss 1e-4 (north_star); integer rank /
+index work bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import itr_oracle as O
+from itr_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxdiff(got, want):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = want.detach().cpu().double().numpy() if torch.is_tensor(want) else np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.abs(got - want).max()) if got.size else 0.0
+
+
+# ------------------------------------------------------------------------------------------ norms
+def test_norms_golden(golden, dev):
+    g = golden("g1_norms")
+    x = T(g["x"]).to(dev)
+    assert maxdiff(ops.l2norm(x, -1), g["l2_last"]) <= 1e-6
+    assert maxdiff(ops.l2norm(x, 1), g["l2_dim1"]) <= 1e-6
+    assert maxdiff(ops.l1norm(x, -1), g["l1_last"]) <= 1e-6
+    assert maxdiff(ops.l1norm(x, 2), g["l1_dim2"]) <= 1e-6
+
+
+@pytest.mark.parametrize("dim", [1, 3, 64, 300, 1024, 2048, 4100])
+def test_l2norm_shapes(dev, dim):
+    torch.manual_seed(dim)
+    x = torch.randn(37, dim)
+    x[5] = 0
+    got = ops.l2norm(x.to(dev))
+    assert maxdiff(got, O.l2norm(x, -1)) <= 2e-6
+    got = ops.normalize(x.to(dev))
+    assert maxdiff(got, torch.nn.functional.normalize(x, dim=-1)) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 1, 4), (128, 128, 32), (130, 257, 300), (1000, 96, 2048), (4, 3072, 1024),
+                                   (333, 12, 6), (257, 129, 37)])
+def test_gemm_vs_fp64(dev, M, N, K):
+    torch.manual_seed(M * 7 + N)
+    a, b, bias = torch.randn(M, K), torch.randn(N, K), torch.randn(N)
+    want = (a.double() @ b.double().t() + bias.double())
+    got = ops.linear(a.to(dev), b.to(dev), bias.to(dev))
+    scale = (a.abs().double() @ b.abs().double().t()).max()
+    assert maxdiff(got, want) <= 2e-6 * float(scale) + 1e-6
+    got_relu = ops.linear(a.to(dev), b.to(dev), bias.to(dev), act='relu')
+    assert maxdiff(got_relu, want.clamp(min=0)) <= 2e-6 * float(scale) + 1e-6
+
+
+def test_gemm_transpose_detecting(dev):
+    """A = I with an asymmetric B catches a swapped C layout."""
+    n = 96
+    b = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 7.0
+    got = ops.linear(torch.eye(n).to(dev), b.to(dev))
+    assert maxdiff(got, b.t()) == 0.0
+
+
+def test_image_tower_golden(golden, dev):
+    g = golden("g2_img_precomp")
+    x, w, b = (T(g[k]).to(dev) for k in ("images", "fc_weight", "fc_bias"))
+    assert maxdiff(ops.proj_l2norm(x, w, b), g["out_3d"]) <= 2e-6
+    assert maxdiff(ops.proj_l2norm(x.mean(1), w, b), g["out_2d"]) <= 2e-6
+
+
+def test_cosine_golden_cfg1(golden, dev):
+    g = golden("g4_cosine_hinge")
+    S = ops.cosine_scores(T(g["im"]).to(dev), T(g["s"]).to(dev))
+    assert maxdiff(S, g["scores"]) <= 2e-6
+
+
+def test_mvm_and_pdist_golden(golden, dev):
+    g = golden("g7_mvm_pdist")
+    imgs = T(g["imgs"]).to(dev)
+    assert maxdiff(ops.mvm_scores(imgs, T(g["caps_sq"]).to(dev)), g["mvm_sq"]) <= 2e-6
+    assert maxdiff(ops.mvm_scores(imgs, T(g["caps_ns"]).to(dev)), g["mvm_ns"]) <= 2e-6
+    assert maxdiff(ops.pdist_cos(T(g["x1"]).to(dev), T(g["x2"]).to(dev)), g["pdist_cos"]) <= 2e-6
+
+
+@pytest.mark.parametrize("Ni,k,Nc,D", [(50, 12, 333, 256), (11, 12, 7, 2048), (130, 5, 200, 64)])
+def test_mvm_random(dev, Ni, k, Nc, D):
+    torch.manual_seed(0)
+    imgs, caps = torch.randn(Ni, k, D), torch.randn(Nc, D)
+    want = O.multi_view_matching(imgs.double(), caps.double())
+    assert maxdiff(ops.mvm_scores(imgs.to(dev), caps.to(dev)), want) <= 1e-4 * (D ** 0.5)
+
+
+# ------------------------------------------------------------------------------------------ hinge
+@pytest.mark.parametrize("mv", [False, True])
+def test_hinge_golden_cfg1(golden, dev, mv):
+    g = golden("g4_cosine_hinge")
+    tag = "maxviol" if mv else "sum"
+    sc = T(g["scores"]).to(dev).requires_grad_(True)
+    loss = ops.hinge_loss(sc, 0.2, mv)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss_" + tag])) <= 1e-4
+    assert maxdiff(sc.grad, g["dscores_" + tag]) == 0.0
+
+
+@pytest.mark.parametrize("mv", [False, True])
+@pytest.mark.parametrize("B", [1, 2, 33, 128, 300])
+def test_hinge_random(golden, dev, mv, B):
+    torch.manual_seed(B)
+    sc = torch.rand(B, B)
+    want_l, want_g = O.hinge_loss_and_grad(sc, 0.2, mv)
+    s = sc.to(dev).requires_grad_(True)
+    loss = ops.hinge_loss(s, 0.2, mv)
+    (loss * 3.0).backward()
+    assert abs(float(loss) - float(want_l)) <= 1e-4 * max(1.0, float(want_l))
+    assert maxdiff(s.grad, want_g * 3.0) == 0.0
+
+
+def test_triplet_golden(golden, dev):
+    g = golden("g9_triplet")
+    for mv in (0, 1):
+        s = T(g["scores"]).to(dev).requires_grad_(True)
+        loss = ops.hinge_loss(s, 0.2, bool(mv))
+        loss.backward()
+        assert abs(float(loss) - float(g["loss_%d" % mv])) <= 1e-5
+        assert maxdiff(s.grad, g["grad_%d" % mv]) == 0.0
+
+
+# ------------------------------------------------------------------------------------------ ranker
+def run_ranker(sims32, dev, im_div=5):
+    S = torch.from_numpy(sims32).to(dev)
+    i_rank, i_top, t_rank, t_best, _ = ops.rank_counts(S, im_div)
+    t_top = (t_best & 0xffffffff).to(torch.int64)
+    return [x.cpu().numpy().astype(np.int64) for x in (i_rank, i_top, t_rank, t_top)]
+
+
+def test_ranker_golden(golden, dev):
+    g = golden("g12_ranker")
+    sims = g["sims"].astype(np.float32)  # the reference ranks float64 copies of fp32 scores
+    got = run_ranker(sims, dev)
+    want = O.rank_counts(sims)
+    for a, b in zip(got, want):
+        assert (a == b).all()
+    # fp32 rounding of this float64 fixture creates no new ties: equal to the reference's ranks
+    assert (got[0] == g["i2t_ranks"]).all() and (got[2] == g["t2i_ranks"]).all()
+    assert (got[1] == g["i2t_top1"]).all() and (got[3] == g["t2i_top1"]).all()
+    assert ops.recall_from_ranks(got[0]) == pytest.approx(tuple(g["i2t"]))
+    assert ops.recall_from_ranks(got[2]) == pytest.approx(tuple(g["t2i"]))
+
+
+def test_ranker_ties_and_zeros(golden, dev):
+    g = golden("g12_ranker")
+    tie = g["tie_sims"].astype(np.float32)
+    got = run_ranker(tie, dev)
+    want = O.rank_counts(tie)
+    for a, b in zip(got, want):
+        assert (a == b).all()
+    z = run_ranker(np.zeros((6, 30), np.float32), dev)
+    assert (z[0] == g["zeros_i2t_ranks"]).all() and (z[2] == g["zeros_t2i_ranks"]).all()
+
+
+@pytest.mark.parametrize("Ni,extra", [(1, 0), (7, 0), (40, 3), (257, 0)])
+def test_ranker_ragged_shapes(dev, Ni, extra):
+    rng = np.random.RandomState(Ni)
+    sims = rng.randn(Ni, 5 * Ni + extra).astype(np.float32)   # Nc not a multiple of 4 / extra distractors
+    got = run_ranker(sims, dev)
+    want = O.rank_counts(sims)
+    for a, b in zip(got, want):
+        assert (a == b).all()
+
+
+def test_ranker_row_blocks_sum_to_full(dev):
+    """Row-sharded evaluation: partial t2i counts of row blocks add up to the full-matrix ranks."""
+    rng = np.random.RandomState(3)
+    sims = rng.randn(64, 320).astype(np.float32)
+    S = torch.from_numpy(sims).to(dev)
+    full = run_ranker(sims, dev)
+    s_gt = torch.full((320,), float('-inf'), device=dev)
+    for r0 in (0, 16, 48):
+        r1 = {0: 16, 16: 48, 48: 64}[r0]
+        ops.gather_gt(S[r0:r1], 5, r0, s_gt)
+    t_rank = torch.zeros(320, dtype=torch.int32, device=dev)
+    t_best = torch.zeros(320, dtype=torch.int64, device=dev)
+    i_rank = []
+    for r0, r1 in ((0, 16), (16, 48), (48, 64)):
+        ir, it, _, _, _ = ops.rank_counts(S[r0:r1], 5, r0, s_gt, t_rank, t_best)
+        i_rank.append(ir.cpu().numpy())
+    assert (np.concatenate(i_rank) == full[0]).all()
+    assert (t_rank.cpu().numpy() == full[2]).all()
+    assert ((t_best & 0xffffffff).cpu().numpy() == full[3]).all()
+
+
+# ------------------------------------------------------------------------------------------ SCAN
+NORMS = ['clipped_l2norm', 'l2norm', 'softmax', 'no_norm', 'clipped']
+AGGS = ['LogSumExp', 'Mean', 'Max', 'Sum']
+
+
+@pytest.mark.parametrize("xa", ['t2i', 'i2t'])
+@pytest.mark.parametrize("agg", AGGS)
+def test_scan_golden(golden, dev, xa, agg):
+    g = golden("g5_scan_xattn")
+    img, cap = T(g["images"]).to(dev), T(g["captions"]).to(dev)
+    lens = [int(x) for x in g["cap_lens"]]
+    for norm in NORMS:
+        got = ops.scan_xattn_padded(img, cap, lens, cross_attn=xa, raw_feature_norm=norm, agg_func=agg,
+                                    lambda_lse=6.0, lambda_softmax=9.0)
+        tol = 2e-5 * (36 if agg == 'Sum' and xa == 'i2t' else (9 if agg == 'Sum' else 1))
+        assert maxdiff(got, g["sim_%s_%s_%s" % (xa, agg, norm)]) <= tol, (xa, agg, norm)
+
+
+@pytest.mark.parametrize("xa", ['t2i', 'i2t'])
+@pytest.mark.parametrize("Ni,Nc,D", [(1, 1, 32), (5, 40, 1024), (9, 70, 256)])
+def test_scan_random_vs_oracle(dev, xa, Ni, Nc, D):
+    rng = np.random.RandomState(Ni + Nc)
+    torch.manual_seed(Ni)
+    lens = [int(x) for x in rng.randint(1 if xa == 'i2t' else 2, 21, size=Nc)]
+    L = max(lens)
+    img = O.l2norm(torch.randn(Ni, 36, D), -1)
+    cap = torch.randn(Nc, L, D) * 0.5
+    want = O.xattn_score(img, cap, lens, xa)
+    got = ops.scan_xattn_padded(img.to(dev), cap.to(dev), lens, cross_attn=xa)
+    assert maxdiff(got, want) <= 2e-5
+
+
+def test_scan_l1_norms_run(dev):
+    """l1norm / clipped_l1norm raise NameError in the reference; the evident intent is
+    implemented and pinned against the oracle."""
+    torch.manual_seed(0)
+    img = O.l2norm(torch.randn(3, 36, 64), -1)
+    cap = torch.randn(4, 6, 64)
+    lens = [6, 5, 3, 2]
+    for norm in ('l1norm', 'clipped_l1norm'):
+        want = O.xattn_score(img, cap, lens, 't2i', norm)
+        got = ops.scan_xattn_padded(img.to(dev), cap.to(dev), lens, raw_feature_norm=norm)
+        assert maxdiff(got, want) <= 2e-5
+
+
+def test_scan_errors(dev):
+    img, cap = torch.zeros(2, 36, 32, device=dev), torch.zeros(2, 3, 32, device=dev)
+    with pytest.raises(ValueError):
+        ops.scan_xattn_padded(img, cap, [3, 3], raw_feature_norm='bogus')
+    with pytest.raises(ValueError):
+        ops.scan_xattn_padded(img, cap, [3, 3], agg_func='bogus')
+    with pytest.raises(NotImplementedError):
+        ops.scan_xattn_padded(torch.zeros(2, 30, 32, device=dev), cap, [3, 3])
+
+
+# ------------------------------------------------------------------------------------------ GRU
+def pack(ids, lengths, dev):
+    toks = torch.cat([ids[b, :l] for b, l in enumerate(lengths)]).to(dev)
+    off = torch.tensor(np.concatenate([[0], np.cumsum(lengths)[:-1]]), dtype=torch.int64, device=dev)
+    return toks, off
+
+
+@pytest.mark.parametrize("bi", [False, True])
+@pytest.mark.parametrize("last", [False, True])
+@pytest.mark.parametrize("raw", [False, True])
+def test_gru_golden(golden, dev, bi, last, raw):
+    g = golden("g3_text_gru")
+    pre = "w_%s_" % ("bi" if bi else "uni")
+    w = {k[len(pre):]: T(g[k]).to(dev) for k in g.files if k.startswith(pre)}
+    ids, lengths = T(g["ids"]), [int(x) for x in g["lengths"]]
+    toks, off = pack(ids, lengths, dev)
+    tag = "%s_%s_%s" % ("bi" if bi else "uni", "last" if last else "seq", "raw" if raw else "l2")
+    got = ops.gru_encode(toks, off, lengths, w, bi, no_txtnorm=raw, gather_last=last)
+    want = g["out_" + tag]
+    if last:
+        assert maxdiff(got, want) <= 5e-6
+    else:
+        got = got.cpu()
+        o = 0
+        for b, l in enumerate(lengths):
+            assert maxdiff(got[o:o + l], want[b, :l]) <= 5e-6
+            o += l
+
+
+def test_gru_full_size_vs_oracle(dev):
+    """coco vocabulary, word_dim 300, D = 1024, bi-GRU: the BASELINE text tower shape."""
+    rng = np.random.RandomState(0)
+    torch.manual_seed(0)
+    V, E, D, B = 11353, 300, 1024, 24
+    lengths = sorted([int(x) for x in rng.randint(6, 21, size=B)], reverse=True)
+    ids = torch.from_numpy(rng.randint(4, V, size=(B, max(lengths))))
+    rnn = torch.nn.GRU(E, D, 1, batch_first=True, bidirectional=True)
+    w = {'embed.weight': torch.empty(V, E).uniform_(-0.1, 0.1)}
+    w.update({'rnn.' + k: v.detach() for k, v in rnn.state_dict().items()})
+    want, _ = O.encoder_text(ids, lengths, w, True, False, False, None)
+    toks, off = pack(ids, lengths, dev)
+    got = ops.gru_encode(toks, off, lengths, {k: v.to(dev) for k, v in w.items()}, True).cpu()
+    o = 0
+    for b, l in enumerate(lengths):
+        assert maxdiff(got[o:o + l], want[b, :l]) <= 5e-6
+        o += l
+
+
+def test_gru_rejects_unsorted(dev):
+    w = {'embed.weight': torch.zeros(10, 4, device=dev), 'rnn.weight_ih_l0': torch.zeros(12, 4, device=dev),
+         'rnn.weight_hh_l0': torch.zeros(12, 4, device=dev), 'rnn.bias_ih_l0': torch.zeros(12, device=dev),
+         'rnn.bias_hh_l0': torch.zeros(12, device=dev)}
+    toks = torch.zeros(5, dtype=torch.int64, device=dev)
+    off = torch.tensor([0, 2], dtype=torch.int64, device=dev)
+    with pytest.raises(ValueError, match="sorted"):
+        ops.gru_encode(toks, off, [2, 3], w, False)
