@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pairs/sec scored on the MS-COCO 5k x 25k evaluation (BASELINE.json metric).
+
+Workload (default `scan_t2i_coco5k`, BASELINE.json configs[2]): SCAN t2i LogSumExp,
+5 000 images x 36 regions x 2048-d precomp features, 25 000 captions of 6..20 tokens, coco vocabulary
+(11 353), word_dim 300, bi-GRU, embed 1024.  One "step" = the whole metric path on inputs already
+resident in HBM:   image projection + l2norm -> embedding + bi-GRU -> [all-gather of word embeddings]
+-> fused SCAN cross-attention scores (N_img x N_cap) -> Recall ranks (i2t + t2i).
+
+    python bench.py                      # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N      # N GPUs, one rank per GPU over RCCL
+
+The 5k x 25k score matrix is row-sharded over ranks (strong scaling: total work is fixed).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "image-text-retrieval_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* peak = fp32 vector peak
+
+WORKLOADS = {
+    # name: (n_img, vocab, model)
+    "scan_t2i_coco5k": dict(n_img=5000, vocab=11353, cross_attn="t2i", agg_func="LogSumExp", lambda_lse=6.0,
+                            lambda_softmax=9.0, raw_feature_norm="clipped_l2norm"),
+    "scan_t2i_f30k1k": dict(n_img=1000, vocab=8481, cross_attn="t2i", agg_func="LogSumExp", lambda_lse=6.0,
+                            lambda_softmax=9.0, raw_feature_norm="clipped_l2norm"),
+    "scan_i2t_coco5k": dict(n_img=5000, vocab=11353, cross_attn="i2t", agg_func="LogSumExp", lambda_lse=20.0,
+                            lambda_softmax=4.0, raw_feature_norm="clipped_l2norm"),
+}
+
+
+def make_weights(vocab, F_=2048, D=1024, E=300, seed=0):
+    torch.manual_seed(seed)
+    r = float(np.sqrt(6.0) / np.sqrt(F_ + D))
+    wi = {"fc.weight": torch.empty(D, F_).uniform_(-r, r), "fc.bias": torch.zeros(D)}   # ImgEncoder.py:126-131
+    rnn = torch.nn.GRU(E, D, 1, batch_first=True, bidirectional=True)
+    wt = {"embed.weight": torch.empty(vocab, E).uniform_(-0.1, 0.1)}                      # TextEncoder.py:35-36
+    wt.update({"rnn." + k: v.detach().clone() for k, v in rnn.state_dict().items()})
+    return wi, wt
+
+
+def make_captions(n_cap, vocab, seed=0):
+    rng = np.random.RandomState(seed)
+    lengths = rng.randint(6, 21, size=n_cap)                      # randint(6, 21)
+    tokens = [rng.randint(4, vocab, size=int(l)) for l in lengths]
+    return lengths, tokens
+
+
+def shard_captions(lengths, tokens, c0, c1, dev):
+    """This rank's caption slice as the loader would hand it over: sorted by length (descending, like
+    collate_fn, data_loader.py:146), packed."""
+    loc_len = lengths[c0:c1]
+    order = np.argsort(-loc_len, kind="stable")
+    lens_sorted = loc_len[order]
+    packed = np.concatenate([tokens[c0 + int(i)] for i in order]) if len(order) else np.zeros(0, np.int64)
+    tok_off = np.concatenate([[0], np.cumsum(lens_sorted)[:-1]]) if len(order) else np.zeros(0, np.int64)
+    return (torch.from_numpy(packed.astype(np.int64)).to(dev), torch.from_numpy(tok_off.astype(np.int64)).to(dev),
+            [int(x) for x in lens_sorted], order)
+
+
+def cpu_baseline(wl, wi, wt, feats_cpu, lengths, tokens, n_img_s, seconds_cap=60.0):
+    """The CPU oracle (a port of the reference's algorithm, oracle/itr_oracle.py) timed on the host cores on
+    a bounded sample of the same workload: the first n_img_s images and their 5*n_img_s captions."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import itr_oracle as O
+    n_cap_s = 5 * n_img_s
+    lens = lengths[:n_cap_s]
+    order = np.argsort(-lens, kind="stable")
+    L = int(lens.max())
+    ids = torch.zeros(n_cap_s, L, dtype=torch.long)
+    for r, i in enumerate(order):
+        ids[r, :lens[i]] = torch.from_numpy(tokens[int(i)])
+    lens_sorted = [int(lens[i]) for i in order]
+    with torch.no_grad():
+        t0 = time.time()
+        img = O.encoder_image_precomp(feats_cpu[:n_img_s], wi["fc.weight"], wi["fc.bias"])
+        cap_sorted, _ = O.encoder_text(ids, lens_sorted, wt, True, True, False, None)
+        cap = torch.zeros_like(cap_sorted)
+        cap[torch.as_tensor(order)] = cap_sorted
+        S = O.xattn_score(img, cap, [int(x) for x in lens], wl["cross_attn"], wl["raw_feature_norm"], wl["agg_func"],
+                          wl["lambda_lse"], wl["lambda_softmax"])
+        ranks = O.rank_counts(S.numpy())
+        dt = time.time() - t0
+    return dict(value=n_img_s * n_cap_s / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample="first %d images x %d captions of the same synthetic workload: encode+score+rank in %.1f s"
+                       % (n_img_s, n_cap_s, dt)), S, ranks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="scan_t2i_coco5k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-images", type=int, default=120)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from itr_amd import evalpipe, ops
+    wl = WORKLOADS[args.workload]
+    n_img, n_cap = wl["n_img"], 5 * wl["n_img"]
+    F_, D, R = 2048, 1024, 36
+    cfg = dict(wl, bi_gru=True, no_txtnorm=True, no_imgnorm=False)
+
+    # ---- synthetic inputs (seeded; identical on every rank, each rank keeps its shard in HBM)
+    wi, wt = make_weights(wl["vocab"])
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    feats = torch.randn(n_img, R, F_, device=dev, generator=g)
+    feats = ops.l2norm(feats)                                       # precomp features are l2-normalised
+    lengths, tokens = make_captions(n_cap, wl["vocab"])
+    comm = evalpipe.Comm()
+    i0, i1 = evalpipe.block_range(n_img, comm.world, comm.rank, 4)
+    c0, c1 = evalpipe.block_range(n_cap, comm.world, comm.rank)
+    feats_local = feats[i0:i1].contiguous()
+    feats_head = feats[:args.cpu_sample_images].cpu() if rank == 0 else None
+    del feats
+    toks, tok_off, lens_sorted, order = shard_captions(lengths, tokens, c0, c1, dev)
+    model = evalpipe.GruModelEval({k: v.to(dev) for k, v in wi.items()}, {k: v.to(dev) for k, v in wt.items()}, cfg, comm)
+    torch.cuda.synchronize()
+
+    timers = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
+
+    def step(tm=None):
+        return model.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    scan_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        S, ranks, plan = step(timers)
+        # the step already synchronised the stream when it copied the ranks to the host
+        scan_ms.append(timers["scan_start"].elapsed_time(timers["scan_end"]))
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        pairs = float(n_img) * n_cap
+        n_words = int(lengths.sum())
+        # SCAN K7 = (4*36+6) * W * D flop per (image, caption) pair, summed over the pairs this rank scored
+        alg_flop = float(i1 - i0) * n_words * (4 * 36 + 6) * D
+        # executed by this design: raw dot products only (2*36*W*D) + the 36x36 quadratic form per (image, word)
+        exe_flop = float(i1 - i0) * n_words * (2 * 36 * D + 36 * 37)
+        k_ms = float(np.mean(scan_ms))
+        from itr_amd import ops as _ops
+        i2t = _ops.recall_from_ranks(ranks[0])
+        t2i = _ops.recall_from_ranks(ranks[2])
+        out = {
+            "metric": "pairs/sec scored (5k img x 25k cap) + Recall@1 parity, 1/2/4/8 MI355X",
+            "value": pairs / (dt / args.steps), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "model": "SCAN %s %s bi-GRU" % (wl["cross_attn"], wl["agg_func"]),
+                       "n_img": n_img, "n_cap": n_cap, "regions": R, "feat_dim": F_, "embed": D,
+                       "n_words": n_words, "parallelism": "row-shard x%d + 1 all-gather" % world,
+                       "step": "encode(img proj + bi-GRU) + score + rank(i2t,t2i)"},
+            "recall": {"i2t_r1": i2t[0], "i2t_r5": i2t[1], "i2t_r10": i2t[2], "t2i_r1": t2i[0], "t2i_r5": t2i[1],
+                       "t2i_r10": t2i[2]},
+            "roofline": {"kernel": "scan_xattn_kernel", "bound": "mfma", "achieved": alg_flop / (k_ms * 1e-3) / 1e12,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": alg_flop / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel_ms": k_ms, "algorithmic_flop_per_launch": alg_flop,
+                         "executed_flop_per_launch": exe_flop,
+                         "executed_tflops": exe_flop / (k_ms * 1e-3) / 1e12,
+                         "executed_frac": exe_flop / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "note": "achieved uses SURVEY 8d's algorithmic (4*36+6)*W*D flop/pair; the kernel "
+                                 "executes about half of it (Gram-matrix identity, DESIGN.md)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, S_cpu, ranks_cpu = cpu_baseline(wl, wi, wt, feats_head, lengths, tokens, args.cpu_sample_images)
+            ns, ncs = args.cpu_sample_images, 5 * args.cpu_sample_images
+            base["max_abs_diff_vs_gpu"] = float((S[:ns, :ncs].cpu() - S_cpu).abs().max())
+            out["cpu_baseline"] = base
+            out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -528,6 +528,57 @@ extern "C" size_t itr_scan_workspace_bytes(int64_t Ni, int R, int64_t n_rows, in
     return t2i > i2t ? t2i : i2t;
 }
 
+// Workspace layout (both entry points agree on it)
+namespace itr {
+struct ScanWs {
+    float *gram, *wnorm, *vnorm, *cgram;
+    int64_t *coff;
+};
+static ScanWs scan_carve(void *workspace, int64_t Ni, int R, int64_t n_rows, int64_t Nc, int mode) {
+    char *ws = static_cast<char *>(workspace);
+    ScanWs w{};
+    if (mode == 0) {
+        w.gram = reinterpret_cast<float *>(ws);
+        w.wnorm = reinterpret_cast<float *>(ws + align256((size_t)Ni * R * R * 4));
+    } else {
+        w.vnorm = reinterpret_cast<float *>(ws);
+        w.coff = reinterpret_cast<int64_t *>(ws + align256((size_t)Ni * R * 4));
+        w.cgram = reinterpret_cast<float *>(ws + align256((size_t)Ni * R * 4) + align256((size_t)Nc * 8));
+    }
+    return w;
+}
+}  // namespace itr
+
+extern "C" int itr_scan_prepare(const float *img, const float *words, const int64_t *cap_off,
+                                const int32_t *cap_len, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
+                                int mode, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
+    using namespace itr;
+    ITR_REQUIRE(img && words && cap_off && cap_len && workspace, "itr_scan_prepare: null pointer");
+    ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && D > 0, "itr_scan_prepare: bad shape");
+    if (mode != 0 && mode != 1) { set_error("unknown cross_attn mode %d", mode); return ITR_ERR_BADARG; }
+    ITR_UNSUPPORTED(R != SC_R, "itr_scan_prepare: this build handles %d regions per image, got %d", SC_R, R);
+    ITR_REQUIRE(workspace_bytes >= itr_scan_workspace_bytes(Ni, R, n_rows, Nc), "itr_scan_prepare: workspace too small");
+    if (Ni == 0 || Nc == 0) return ITR_OK;
+    hipStream_t st = as_stream(stream);
+    ScanWs w = scan_carve(workspace, Ni, R, n_rows, Nc, mode);
+    if (mode == 0) {
+        hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Ni), dim3(256), 0, st, img, (const int64_t *)nullptr,
+                           (const int32_t *)nullptr, R, D, w.gram, (const int64_t *)nullptr);
+        ITR_CHECK_LAUNCH("scan gram");
+        hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, st, words, n_rows, D, w.wnorm);
+        ITR_CHECK_LAUNCH("scan wnorm");
+    } else {
+        hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)ceil_div(Ni * R, 4)), dim3(256), 0, st, img, Ni * R, D, w.vnorm);
+        ITR_CHECK_LAUNCH("scan vnorm");
+        hipLaunchKernelGGL(sq_prefix_kernel, dim3(1), dim3(1024), 0, st, cap_len, Nc, w.coff);
+        ITR_CHECK_LAUNCH("scan cgram offsets");
+        hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Nc), dim3(256), 0, st, words, cap_off, cap_len, 0, D, w.cgram,
+                           (const int64_t *)w.coff);
+        ITR_CHECK_LAUNCH("scan caption gram");
+    }
+    return ITR_OK;
+}
+
 extern "C" int itr_scan_xattn_scores(const float *img, const float *words, const int64_t *cap_off,
                                      const int32_t *cap_len, const int32_t *tile_begin_dev, int64_t n_tiles,
                                      int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D, int mode, int norm,
@@ -555,29 +606,8 @@ extern "C" int itr_scan_xattn_scores(const float *img, const float *words, const
     a.img = img; a.words = words; a.cap_off = cap_off; a.cap_len = cap_len; a.tile_begin = tile_begin_dev;
     a.S = S; a.ldS = ldS; a.Ni = Ni; a.Nc = Nc; a.n_tiles = n_tiles; a.D = D;
     a.mode = mode; a.norm = norm; a.agg = agg; a.lambda_softmax = lambda_softmax; a.lambda_lse = lambda_lse;
-    char *ws = static_cast<char *>(workspace);
-    if (mode == 0) {
-        float *gram = reinterpret_cast<float *>(ws);
-        float *wnorm = reinterpret_cast<float *>(ws + align256((size_t)Ni * R * R * 4));
-        hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Ni), dim3(256), 0, st, img, (const int64_t *)nullptr,
-                           (const int32_t *)nullptr, R, D, gram, (const int64_t *)nullptr);
-        ITR_CHECK_LAUNCH("scan gram");
-        hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, st, words, n_rows, D, wnorm);
-        ITR_CHECK_LAUNCH("scan wnorm");
-        a.gram = gram; a.wnorm = wnorm;
-    } else {
-        float *vnorm = reinterpret_cast<float *>(ws);
-        int64_t *coff = reinterpret_cast<int64_t *>(ws + align256((size_t)Ni * R * 4));
-        float *cgram = reinterpret_cast<float *>(ws + align256((size_t)Ni * R * 4) + align256((size_t)Nc * 8));
-        hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)ceil_div(Ni * R, 4)), dim3(256), 0, st, img, Ni * R, D, vnorm);
-        ITR_CHECK_LAUNCH("scan vnorm");
-        hipLaunchKernelGGL(sq_prefix_kernel, dim3(1), dim3(1024), 0, st, cap_len, Nc, coff);
-        ITR_CHECK_LAUNCH("scan cgram offsets");
-        hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Nc), dim3(256), 0, st, words, cap_off, cap_len, 0, D, cgram,
-                           (const int64_t *)coff);
-        ITR_CHECK_LAUNCH("scan caption gram");
-        a.vnorm = vnorm; a.cgram = cgram; a.cgram_off = coff;
-    }
+    ScanWs w = scan_carve(workspace, Ni, R, n_rows, Nc, mode);
+    a.gram = w.gram; a.wnorm = w.wnorm; a.vnorm = w.vnorm; a.cgram = w.cgram; a.cgram_off = w.coff;
 
     const int64_t img_tiles = ceil_div(Ni, SC_IMGS);
     const int64_t PI = ceil_div(img_tiles, 8), PJ = ceil_div(n_tiles, 8);

@@ -1,0 +1,173 @@
+"""Row-sharded encode -> score -> rank evaluation (the metric path of utils.validate_step /
+evalrank_single: encode_data -> [::5] -> cal_sims -> i2t + t2i; itr/utils.py:144-168,
+itr/metricmodule/evaluation.py:75-222), one process per GPU.
+
+Partitioning:
+  1. rank p encodes image rows [i0_p, i1_p) -- unique images only, no 5x redundancy -- and a
+     contiguous caption slice [c0_p, c1_p);
+  2. ONE exchange: all-gather of the packed word (or pooled caption) embeddings over RCCL;
+  3. rank p scores its row block S_p = sim(img_p, all captions)  -- no communication;
+  4. i2t ranks are row-local; t2i needs the GT score of every caption (max all-reduce of a
+     -inf-initialised vector), then partial "greater-than" counts are summed (int32 sum
+     all-reduce) and the best-row keys max-reduced.  Integer counts => the result is identical to
+     the single-GPU one by construction.
+With world_size == 1 every collective is skipped.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+_SIGN = -(1 << 63)  # XOR flips unsigned 64-bit order into signed int64 order for the max all-reduce
+
+
+def block_range(n, world, rank, align=1):
+    """Contiguous, `align`-aligned, near-equal partition of range(n)."""
+    per = -(-n // world)
+    per = -(-per // align) * align
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+class Comm:
+    """Minimal collective layer: torch.distributed (backend nccl == RCCL over xGMI on ROCm, gloo in
+    the CPU tests) or a no-op for a single process."""
+
+    def __init__(self, group=None):
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+
+    def all_gather_rows(self, local, counts):
+        """Concatenate row blocks of different heights.  Returns (buffer [world*maxrows, ...], maxrows):
+        rank q's rows live at buffer[q*maxrows : q*maxrows + counts[q]] (padded, no repacking pass)."""
+        maxrows = int(max(counts))
+        if not self.on:
+            return local, maxrows
+        pad = torch.zeros((maxrows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+        out = torch.empty((self.world * maxrows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, pad, group=self.group)
+        return out, maxrows
+
+    def all_gather_list(self, obj_array):
+        """all-gather a small host int array (same length on every rank)."""
+        if not self.on:
+            return [np.asarray(obj_array)]
+        t = torch.as_tensor(np.asarray(obj_array, dtype=np.int64))
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else t.device
+        t = t.to(dev)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return [o.cpu().numpy() for o in out]
+
+    def all_reduce(self, t, op):
+        if self.on:
+            dist.all_reduce(t, op=op, group=self.group)
+        return t
+
+
+def finalize_ranks(comm, S_local, row0, n_img_total, im_div=5, rank_fn=None, gather_fn=None):
+    """Step 4 above.  Returns host arrays (i2t_rank[Ni], i2t_top1[Ni], t2i_rank[Nc], t2i_top1[Nc]).
+    rank_fn / gather_fn default to the HIP kernels; the gloo CPU tests inject reference versions to
+    exercise exactly this collective logic."""
+    rank_fn = rank_fn or ops.rank_counts
+    gather_fn = gather_fn or ops.gather_gt
+    n_local, Nc = S_local.shape
+    s_gt = torch.full((Nc,), float('-inf'), device=S_local.device, dtype=torch.float32)
+    if n_local:
+        gather_fn(S_local, im_div, row0, s_gt)
+    comm.all_reduce(s_gt, dist.ReduceOp.MAX)
+    t_rank = torch.zeros(Nc, device=S_local.device, dtype=torch.int32)
+    t_best = torch.zeros(Nc, device=S_local.device, dtype=torch.int64)
+    if n_local:
+        i_rank, i_top, _, _, _ = rank_fn(S_local, im_div, row0, s_gt, t_rank, t_best)
+    else:
+        i_rank = torch.zeros(0, device=S_local.device, dtype=torch.int32)
+        i_top = torch.zeros(0, device=S_local.device, dtype=torch.int32)
+    comm.all_reduce(t_rank, dist.ReduceOp.SUM)
+    if comm.on:
+        t_best ^= _SIGN
+        comm.all_reduce(t_best, dist.ReduceOp.MAX)
+        t_best ^= _SIGN
+    counts = [block_range(n_img_total, comm.world, q, _IMG_ALIGN)[1] - block_range(n_img_total, comm.world, q, _IMG_ALIGN)[0]
+              for q in range(comm.world)]
+    both = torch.stack([i_rank, i_top], 1)
+    allb, maxrows = comm.all_gather_rows(both, counts)
+    allb = allb.cpu().numpy()
+    if comm.on:
+        allb = np.concatenate([allb[q * maxrows:q * maxrows + counts[q]] for q in range(comm.world)], 0)
+    t_top = (t_best & 0xffffffff).cpu().numpy()
+    return allb[:, 0].astype(np.int64), allb[:, 1].astype(np.int64), t_rank.cpu().numpy().astype(np.int64), t_top
+
+
+_IMG_ALIGN = 4  # the SCAN kernel works on 4 images per workgroup
+
+
+class GruModelEval:
+    """Sharded evaluation of the GRU model family (SCAN; VSE++ pooled cosine) on packed inputs."""
+
+    def __init__(self, weights_img, weights_txt, config, comm=None):
+        self.wi, self.wt, self.cfg = weights_img, weights_txt, config
+        self.comm = comm or Comm()
+
+    # -- step 1
+    def encode_images(self, feats_local):
+        return ops.proj_l2norm(feats_local, self.wi['fc.weight'], self.wi['fc.bias'],
+                               no_imgnorm=self.cfg.get('no_imgnorm', False))
+
+    def encode_captions(self, tokens_packed, tok_off, lengths_sorted, gather_last=False):
+        return ops.gru_encode(tokens_packed, tok_off, lengths_sorted, self.wt, self.cfg.get('bi_gru', False),
+                              no_txtnorm=self.cfg.get('no_txtnorm', False), gather_last=gather_last)
+
+    # -- whole step for SCAN.  Local inputs:
+    #   feats_local [n_img_local, 36, F]          unique images rows [i0, i1)
+    #   tokens_packed / tok_off / lengths_sorted  this rank's caption slice, sorted by length (descending)
+    #   order_local                               original LOCAL caption index of each sorted position
+    #   n_img_total, n_cap_total
+    def scan_eval(self, feats_local, tokens_packed, tok_off, lengths_sorted, order_local, n_img_total,
+                  n_cap_total, im_div=5, timers=None):
+        comm = self.comm
+        cfg = self.cfg
+        dev = feats_local.device
+        img = self.encode_images(feats_local)
+        words = self.encode_captions(tokens_packed, tok_off, lengths_sorted)
+        # -- step 2: one all-gather of packed word embeddings (+ tiny host metadata)
+        n_tok_local = int(words.shape[0])
+        lens_sorted = np.asarray(lengths_sorted, dtype=np.int64)
+        off_sorted = np.concatenate([[0], np.cumsum(lens_sorted)[:-1]]) if len(lens_sorted) else np.zeros(0, np.int64)
+        n_loc = len(lens_sorted)
+        len_loc = np.zeros(n_loc, np.int64)
+        off_loc = np.zeros(n_loc, np.int64)
+        len_loc[np.asarray(order_local)] = lens_sorted       # back to the original caption order
+        off_loc[np.asarray(order_local)] = off_sorted
+        cap_counts = [block_range(n_cap_total, comm.world, q)[1] - block_range(n_cap_total, comm.world, q)[0]
+                      for q in range(comm.world)]
+        maxcap = max(cap_counts)
+        meta = np.zeros(2 * maxcap + 1, np.int64)
+        meta[0] = n_tok_local
+        meta[1:1 + n_loc] = len_loc
+        meta[1 + maxcap:1 + maxcap + n_loc] = off_loc
+        metas = comm.all_gather_list(meta)
+        tok_counts = [int(m[0]) for m in metas]
+        words_all, maxtok = comm.all_gather_rows(words, tok_counts)
+        cap_len = np.concatenate([m[1:1 + cap_counts[q]] for q, m in enumerate(metas)])
+        cap_off = np.concatenate([m[1 + maxcap:1 + maxcap + cap_counts[q]] + q * maxtok for q, m in enumerate(metas)])
+        plan = ops.ScanPlan(cap_off, cap_len, words_all.shape[0], dev)
+        # -- step 3: local row block
+        xa = cfg.get('cross_attn', 't2i')
+        ws = ops.scan_prepare(img, words_all, plan, xa)
+        if timers is not None:
+            timers['scan_start'].record()
+        S = ops.scan_xattn_scores(img, words_all, plan, cross_attn=xa,
+                                  raw_feature_norm=cfg.get('raw_feature_norm', 'clipped_l2norm'),
+                                  agg_func=cfg.get('agg_func', 'LogSumExp'), lambda_lse=cfg.get('lambda_lse', 6.0),
+                                  lambda_softmax=cfg.get('lambda_softmax', 9.0), workspace=ws)
+        if timers is not None:
+            timers['scan_end'].record()
+        # -- step 4
+        row0 = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)[0]
+        ranks = finalize_ranks(comm, S, row0, n_img_total, im_div)
+        return S, ranks, plan

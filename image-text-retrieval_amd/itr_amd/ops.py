@@ -199,8 +199,21 @@ class ScanPlan:
         self.cap_off = torch.as_tensor(np.asarray(cap_off, dtype=np.int64)).to(device)
 
 
+def scan_prepare(images, words, plan, cross_attn='t2i'):
+    """Per (image block, caption set) precompute for the SCAN kernel: Gram matrices + norms."""
+    lib = _lib.load()
+    images = _dev(images, name="images")
+    words = _dev(words, name="words")
+    Ni, R, D = images.shape
+    wsb = lib.itr_scan_workspace_bytes(Ni, R, words.shape[0], plan.Nc)
+    ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
+    _lib.check(lib.itr_scan_prepare(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), Ni, plan.Nc,
+                                    words.shape[0], R, D, 0 if cross_attn == 't2i' else 1, _p(ws), wsb, _stream()))
+    return ws
+
+
 def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='clipped_l2norm',
-                      agg_func='LogSumExp', lambda_lse=6.0, lambda_softmax=9.0, out=None):
+                      agg_func='LogSumExp', lambda_lse=6.0, lambda_softmax=9.0, out=None, workspace=None):
     """xattn_score_t2i / _i2t (Objectives.py:329-417).  images (Ni, 36, D); words (n_rows, D) with the
     caption layout described by `plan` (ScanPlan).  -> (Ni, Nc)."""
     lib = _lib.load()
@@ -216,8 +229,8 @@ def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='c
     n_rows = words.shape[0]
     if out is None:
         out = torch.empty(Ni, plan.Nc, device=images.device, dtype=torch.float32)
-    wsb = lib.itr_scan_workspace_bytes(Ni, R, n_rows, plan.Nc)
-    ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
+    ws = workspace if workspace is not None else scan_prepare(images, words, plan, cross_attn)
+    wsb = ws.numel()
     _lib.check(lib.itr_scan_xattn_scores(
         _p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin), plan.n_tiles, Ni, plan.Nc,
         n_rows, R, D, 0 if cross_attn == 't2i' else 1, _NORMS[raw_feature_norm], _AGGS[agg_func],

@@ -109,11 +109,17 @@ int itr_hinge_maxviol_bwd(const float *S, int B, int64_t ldS, float margin, int 
  * 5 l1norm, 6 clipped_l1norm.  agg: 0 LogSumExp, 1 Max, 2 Sum, 3 Mean.
  * Tile plan: captions are grouped host-side into column tiles of <= ITR_SCAN_NT words by
  * itr_scan_plan_tiles (pure CPU); tile_begin_dev[n_tiles+1] is that plan on the device.
- * workspace: itr_scan_workspace_bytes(Ni, R, n_rows, Nc) bytes (Gram matrices + norms). */
+ * workspace: itr_scan_workspace_bytes(Ni, R, n_rows, Nc) bytes.  itr_scan_prepare fills it for one
+ * (image block, caption set, mode): region Gram matrices V_i V_i^T + word norms (t2i) or region norms
+ * + caption Gram matrices E_c E_c^T (i2t); itr_scan_xattn_scores then needs that prepared workspace
+ * and may be called repeatedly (other norm / agg / lambda) without preparing again. */
 #define ITR_SCAN_NT 64
 int itr_scan_plan_tiles(const int32_t *len_host, int64_t Nc, int nt, int32_t *tile_begin_host,
                         int64_t *n_tiles);
 size_t itr_scan_workspace_bytes(int64_t Ni, int R, int64_t n_rows, int64_t Nc);
+int itr_scan_prepare(const float *img, const float *words, const int64_t *cap_off,
+                     const int32_t *cap_len, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
+                     int mode, void *workspace, size_t workspace_bytes, itr_stream_t stream);
 int itr_scan_xattn_scores(const float *img, const float *words, const int64_t *cap_off,
                           const int32_t *cap_len, const int32_t *tile_begin_dev, int64_t n_tiles,
                           int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D, int mode, int norm,
