@@ -27,6 +27,9 @@
 // lds[plane][row ^ plane]; see gemm_f32.hip for the bank-conflict argument (the 16x16x4 MFMA
 // lane groups need plane = 4q + (lane >> 4) so both planes of a ds_read_b128 lane group share
 // bits [3:2] of the XOR).
+#include <stdlib.h>
+#include <vector>
+
 #include "itr_common.h"
 
 namespace itr {
@@ -36,21 +39,28 @@ constexpr int SC_IMGS = 4;               // images per workgroup
 constexpr int SC_MT = SC_IMGS * SC_R;    // 144 rows = 9 x 16
 constexpr int SC_MTILES = SC_MT / 16;    // 9
 constexpr int SC_NT = ITR_SCAN_NT;       // 64 word columns = 4 waves x 16
-constexpr int SC_ROWS = SC_MT + SC_NT;   // 208 staged rows per K chunk
+constexpr int SC_ROWS = SC_MT + SC_NT + 16;  // 208 staged rows per K chunk + 16 dump rows (224 = 7*256/8)
 constexpr int SC_BK = 32, SC_PLANES = 8;
 constexpr int SC_THREADS = 256;
 constexpr int SC_MAXCAP = 16;            // captions per column tile (planner guarantees it)
-constexpr int SC_LDA = SC_NT + 1;        // padded row stride of the parked A block
-constexpr int SC_STAGE = 7;              // ceil(208 * 8 / 256) float4 per thread per chunk
+constexpr int SC_LDT = SC_MT + 4;        // 148: row stride of the parked block, stored TRANSPOSED [col][row]
+
+// Per column tile: which captions it holds and where (built on the device by scan_pack_kernel).
+struct alignas(16) ScanTileMeta {
+    int32_t ncap;
+    int32_t cap_id[SC_MAXCAP];
+    int32_t cap_start[SC_MAXCAP + 1];
+    int8_t col_cap[SC_NT];       // caption slot of each column, -1 = padding
+    int32_t pad_[64 - 1 - SC_MAXCAP - (SC_MAXCAP + 1) - SC_NT / 4];
+};
+static_assert(sizeof(ScanTileMeta) == 256, "one 256-byte record per tile");
 
 struct ScanArgs {
     const float *img;        // [Ni, 36, D]
-    const float *words;      // [n_rows, D]
-    const int64_t *cap_off;  // [Nc] first word row of caption c
-    const int32_t *cap_len;  // [Nc]
-    const int32_t *tile_begin;  // [n_tiles + 1] caption range of each column tile
+    const float *wtiled;     // [n_tiles * 64, D]   words re-packed tile by tile (zero rows = padding)
+    const ScanTileMeta *meta;  // [n_tiles]
     const float *gram;       // [Ni, 36, 36]        (t2i)   V_i V_i^T
-    const float *wnorm;      // [n_rows]            (t2i)   ||E_w||
+    const float *wnorm;      // [n_tiles * 64]      (t2i)   ||E_w|| per tiled column
     const float *vnorm;      // [Ni * 36]           (i2t)   ||V_r||
     const float *cgram;      // [sum W_c^2]         (i2t)   E_c E_c^T, caption c at cgram_off[c]
     const int64_t *cgram_off;  // [Nc]
@@ -60,39 +70,40 @@ struct ScanArgs {
     int D;
     int mode, norm, agg;
     float lambda_softmax, lambda_lse;
+    int debug;  // ablation switches for tools/scan_ablate.py (env ITR_SCAN_DEBUG); 0 in production
+    unsigned long long *dbg_cycles;  // [8] phase cycle sums (debug & 16), normally null
 };
 
 struct ScanSmem {
     union {
-        float4 stage[2][SC_PLANES][SC_ROWS];  // 53,248 B   main loop operand staging
-        float araw[SC_MT][SC_LDA];            // 37,440 B   parked raw dot products (epilogue)
+        float4 stage[2][SC_PLANES][SC_ROWS];  // 57,344 B   main loop operand staging
+        float arawt[SC_NT][SC_LDT];           // 37,888 B   parked raw dot products, [word column][region row]
     };
     union {
-        float stat[SC_MT][SC_MAXCAP][2];      // 18,432 B   t2i: per (row, caption) norm statistics
+        float stat[2][SC_MAXCAP][SC_LDT];     // 18,944 B   t2i: per (caption, row) norm statistics s0 / s1
         float rsim2[SC_MT][SC_MAXCAP];        //  9,216 B   i2t: per (region row, caption) term
     };
     float colstat[SC_IMGS][SC_NT][2];         //  2,048 B   i2t: per (image, word) norm statistics
     float rowsim[SC_IMGS][SC_NT];             //  1,024 B   t2i: per (image, word) similarity term
-    int32_t col_row[SC_NT];                   // word row of each column (-1 = padding)
-    int32_t col_cap[SC_NT];                   // caption slot of each column
-    int32_t cap_start[SC_MAXCAP + 1];
-    int32_t cap_id[SC_MAXCAP];
-    int32_t ncap;
+    ScanTileMeta meta;                        //    256 B
 };
 
-__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : 0.1f * v; }
+__device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.1f * v); }   // LeakyReLU(0.1)
+// exp via v_exp_f32 (2^x): 2 VALU instructions instead of ~12; relative error ~|x| * 1e-7, far inside the
+// parity budget for the softmax / LogSumExp arguments here (|x| <= ~10).
+__device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
 
 // value of the normalised attention logit b (before * lambda_softmax) from the raw a and the
 // statistics of its normalisation group (Objectives.py:436-457)
 __device__ __forceinline__ float norm_apply(float a, int norm, float s0, float s1) {
     switch (norm) {
-        case 0: return leaky(a) / s0;             // clipped_l2norm: s0 = sqrt(sum leaky^2) + eps
-        case 1: return a / s0;                    // l2norm
-        case 2: return expf(a - s0) / s1;         // softmax: s0 = max, s1 = sum exp
+        case 0: return leaky(a) * s0;             // clipped_l2norm: s0 = 1 / (sqrt(sum leaky^2) + eps)
+        case 1: return a * s0;                    // l2norm
+        case 2: return expf(a - s0) * s1;         // softmax: s0 = max, s1 = 1 / sum exp
         case 3: return a;                         // no_norm
         case 4: return leaky(a);                  // clipped
-        case 5: return a / s0;                    // l1norm: s0 = sum |a| + eps
-        default: return leaky(a) / s0;            // clipped_l1norm
+        case 5: return a * s0;                    // l1norm: s0 = 1 / (sum |a| + eps)
+        default: return leaky(a) * s0;            // clipped_l1norm
     }
 }
 
@@ -114,10 +125,19 @@ struct NormAcc {
         if (norm == 2) s1 += expf(a - s0);
     }
     __device__ __forceinline__ void finish(int norm) {
-        if (norm == 0 || norm == 1) s0 = sqrtf(s0) + 1e-8f;
-        else if (norm == 5 || norm == 6) s0 = s0 + 1e-8f;
+        // stored as reciprocals: the consumers multiply (<= 1 ulp away from the reference's division)
+        if (norm == 0 || norm == 1) s0 = 1.f / (sqrtf(s0) + 1e-8f);
+        else if (norm == 5 || norm == 6) s0 = 1.f / (s0 + 1e-8f);
+        else if (norm == 2) s1 = 1.f / s1;
     }
 };
+
+#define SC_TICK(slot)                                                                              \
+    if (g.dbg_cycles && tid == 0) {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                              \
+        atomicAdd(&g.dbg_cycles[slot], now_ - tick_);                                              \
+        tick_ = now_;                                                                              \
+    }
 
 __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -141,185 +161,351 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
     if (it >= img_tiles || ct >= g.n_tiles) return;
     const int64_t img0 = it * SC_IMGS;
 
-    // ---- column tile metadata
-    if (tid == 0) {
-        const int c0 = g.tile_begin[ct], c1 = g.tile_begin[ct + 1];
-        int n = c1 - c0;
-        if (n > SC_MAXCAP) n = SC_MAXCAP;
-        int pos = 0;
-        for (int k = 0; k < n; ++k) {
-            sm.cap_start[k] = pos;
-            sm.cap_id[k] = c0 + k;
-            int w = g.cap_len[c0 + k];
-            if (pos + w > SC_NT) w = SC_NT - pos;  // planner never lets this happen
-            pos += w;
-        }
-        sm.cap_start[n] = pos;
-        sm.ncap = n;
-    }
-    if (tid < SC_NT) { sm.col_row[tid] = -1; sm.col_cap[tid] = -1; }
-    __syncthreads();
-    const int ncap = sm.ncap;
-    for (int idx = tid; idx < ncap * SC_NT; idx += SC_THREADS) {
-        const int k = idx / SC_NT, w = idx % SC_NT;
-        const int st = sm.cap_start[k];
-        if (w < sm.cap_start[k + 1] - st) {
-            sm.col_row[st + w] = (int32_t)(g.cap_off[sm.cap_id[k]] + w);
-            sm.col_cap[st + w] = k;
-        }
-    }
-    __syncthreads();
+    unsigned long long tick_ = g.dbg_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
+    // ---- tile metadata: needed by the epilogue only, so its load overlaps the main loop
+    if (tid < 64) reinterpret_cast<int32_t *>(&sm.meta)[tid] = reinterpret_cast<const int32_t *>(g.meta + ct)[tid];
 
     // ---- main loop: raw dot products A[144 x 64] over K = D ------------------------------
+    // On gfx950 the fp32 MFMA shares the vector ALU with ordinary VALU work (tools/ubench: an MFMA wave and
+    // a VALU wave on one SIMD take the SUM of their times), so every VALU instruction in this loop is paid
+    // in matrix throughput.  All addressing is therefore loop-invariant:
+    //   * global loads use  uniform 64-bit base (SGPR, advanced by a scalar add per chunk) + per-lane 32-bit
+    //     byte offset (VGPR, fixed);  7 passes per chunk, each homogeneous in its base:
+    //       A0..A3: image rows 0..127 | A4: rows 128..143 (waves 0,1; waves 2,3 re-load row 0 into the 16
+    //       dump rows) | B0,B1: the 64 word columns of this tile;
+    //   * LDS stores / fragment reads use a per-lane byte address (VGPR, fixed) + immediate offset (buffer,
+    //     row tile): (m*16 + fi) ^ p == m*16 + (fi ^ p) because p < 8.
+    // Rows that do not exist (image tail) re-read row 0: their outputs are never consumed.
+    const int nk = g.D / SC_BK;  // D % 32 == 0 is checked on the host
+    const int fi = lane & 15, fg = lane >> 4;
+    const unsigned rowbytes = (unsigned)g.D * 4u;
     const int64_t n_img_rows = g.Ni * SC_R;
-    const float *src[SC_STAGE];
-    int dst[SC_STAGE];
-#pragma unroll
-    for (int s = 0; s < SC_STAGE; ++s) {
-        const int idx = tid + SC_THREADS * s;
-        const int row = idx >> 3, p = idx & 7;
-        src[s] = nullptr;
-        dst[s] = p * SC_ROWS + (row ^ p);
-        if (row < SC_MT) {
-            const int64_t grow = img0 * SC_R + row;
-            if (grow < n_img_rows) src[s] = g.img + grow * g.D + p * 4;
-        } else if (row < SC_ROWS) {
-            const int wr = sm.col_row[row - SC_MT];
-            if (wr >= 0) src[s] = g.words + (int64_t)wr * g.D + p * 4;
-        } else {
-            dst[s] = -1;
-        }
+    const char *abase = reinterpret_cast<const char *>(g.img) + img0 * SC_R * (int64_t)rowbytes;
+    const char *bbase = reinterpret_cast<const char *>(g.wtiled) + ct * SC_NT * (int64_t)rowbytes;
+    unsigned va0, va1, va2, va3, va4, vb0, vb1;       // per-lane global byte offsets
+    unsigned la0, la1, la2, la3, la4, lb0, lb1;       // per-lane LDS byte addresses (buffer 0)
+    {
+        const int p = tid & 7, r8 = tid >> 3;          // 32 rows per pass
+        auto a_off = [&](int row) -> unsigned {
+            const bool ok = img0 * SC_R + row < n_img_rows;
+            return (ok ? (unsigned)row : 0u) * rowbytes + p * 16u;
+        };
+        auto l_off = [&](int row) -> unsigned { return (unsigned)(p * SC_ROWS + (row ^ p)) * 16u; };
+        va0 = a_off(r8); va1 = a_off(r8 + 32); va2 = a_off(r8 + 64); va3 = a_off(r8 + 96);
+        la0 = l_off(r8); la1 = l_off(r8 + 32); la2 = l_off(r8 + 64); la3 = l_off(r8 + 96);
+        const int r4 = (tid & 127) >> 3;                // 16 rows in the fifth A pass
+        if (wave < 2) { va4 = a_off(128 + r4); la4 = l_off(128 + r4); }
+        else          { va4 = p * 16u;          la4 = l_off(SC_MT + SC_NT + r4); }   // dump rows 208..223
+        vb0 = (unsigned)r8 * rowbytes + p * 16u;        lb0 = l_off(SC_MT + r8);
+        vb1 = (unsigned)(r8 + 32) * rowbytes + p * 16u; lb1 = l_off(SC_MT + r8 + 32);
     }
+    // fragment read addresses: plane p = 4q + fg, physical row (fi ^ p) (+ m*16, + 144 + wave*16 for B)
+    constexpr unsigned STAGE_BYTES = SC_PLANES * SC_ROWS * 16u;   // one buffer
+    const unsigned ra0 = (unsigned)((fg) * SC_ROWS + (fi ^ fg)) * 16u;
+    const unsigned ra1 = (unsigned)((4 + fg) * SC_ROWS + (fi ^ (4 + fg))) * 16u;
+    const unsigned rb0 = ra0 + (unsigned)(SC_MT + wave * 16) * 16u;
+    const unsigned rb1 = ra1 + (unsigned)(SC_MT + wave * 16) * 16u;
+    char *const lds = smem_raw;   // sm.stage sits at offset 0 of the dynamic LDS block
 
     f32x4 acc[SC_MTILES];
 #pragma unroll
     for (int m = 0; m < SC_MTILES; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 stg[SC_STAGE];
-    const int nk = g.D / SC_BK;  // D % 32 == 0 is checked on the host
-    auto gload = [&](int kc) {
-#pragma unroll
-        for (int s = 0; s < SC_STAGE; ++s)
-            stg[s] = src[s] ? *reinterpret_cast<const float4 *>(src[s] + kc * SC_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto lstore = [&](int buf) {
-        float4 *base = &sm.stage[buf][0][0];
-#pragma unroll
-        for (int s = 0; s < SC_STAGE; ++s)
-            if (dst[s] >= 0) base[dst[s]] = stg[s];
-    };
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    const int fi = lane & 15, fg = lane >> 4;
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) gload(kc + 1);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int p = 4 * q + fg;
-            const float4 *plane = &sm.stage[buf][p][0];
-            const float4 b = plane[(SC_MT + wave * 16 + fi) ^ p];
-            float4 a[SC_MTILES];
-#pragma unroll
-            for (int m = 0; m < SC_MTILES; ++m) a[m] = plane[(m * 16 + fi) ^ p];
-#pragma unroll
-            for (int m = 0; m < SC_MTILES; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b.x, acc[m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < SC_MTILES; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b.y, acc[m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < SC_MTILES; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b.z, acc[m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < SC_MTILES; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b.w, acc[m], 0, 0, 0);
-        }
-        if (kc + 1 < nk) {
-            lstore(buf ^ 1);
-            __syncthreads();
-        }
+    // two register stages: chunk kc+2 is in flight while chunk kc is multiplied and chunk kc+1 is
+    // parked in the other LDS buffer, so an HBM-miss has ~2 chunks (>= 4.6k cycles) to land.
+    // The global loads are issued through inline asm so that hipcc's own s_waitcnt bookkeeping does not see
+    // them: at the loop header it merged the two stages' states into vmcnt(0) before the LDS stores, i.e. it
+    // waited for the loads issued half a chunk earlier and exposed a full L2/HBM latency every chunk.  We
+    // count ourselves: when stage P is parked, the 7 loads of the OTHER stage (issued one chunk later) may
+    // still be in flight -> s_waitcnt vmcnt(7).  The wait statement names P's registers as read-write
+    // operands, which pins every consumer of P behind it (cdna_hip_programming.md 5.7 form (ii)).
+    f32x4 sa0, sa1, sa2, sa3, sa4, sa5, sa6;   // register stage A
+    f32x4 sb0, sb1, sb2, sb3, sb4, sb5, sb6;   // register stage B
+#define SC_LDG(dst, base, voff)                                                                    \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+#define SC_GLOAD(P, KC)                                                                            \
+    {                                                                                              \
+        const char *ab_ = abase + (int64_t)(KC) * (SC_BK * 4);                                     \
+        const char *bb_ = bbase + (int64_t)(KC) * (SC_BK * 4);                                     \
+        SC_LDG(P##0, ab_, va0) SC_LDG(P##1, ab_, va1) SC_LDG(P##2, ab_, va2) SC_LDG(P##3, ab_, va3) \
+        SC_LDG(P##4, ab_, va4) SC_LDG(P##5, bb_, vb0) SC_LDG(P##6, bb_, vb1)                       \
+    }
+#define SC_VMWAIT(P, N)                                                                            \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                         \
+                 : "+v"(P##0), "+v"(P##1), "+v"(P##2), "+v"(P##3), "+v"(P##4), "+v"(P##5), "+v"(P##6)::"memory");
+#define SC_STS(addr, BUF, v) (*reinterpret_cast<f32x4 *>(lds + (addr) + (BUF) * STAGE_BYTES) = (v))
+#define SC_LSTORE(P, BUF)                                                                          \
+    {                                                                                              \
+        SC_STS(la0, BUF, P##0); SC_STS(la1, BUF, P##1); SC_STS(la2, BUF, P##2); SC_STS(la3, BUF, P##3); \
+        SC_STS(la4, BUF, P##4); SC_STS(lb0, BUF, P##5); SC_STS(lb1, BUF, P##6);                    \
+    }
+#define SC_LDS4(addr) (*reinterpret_cast<const float4 *>(lds + (addr)))
+    // fragment sets: F0 = k-planes 0..3 (q = 0), F1 = k-planes 4..7 (q = 1) of one 32-wide chunk
+    float4 f0a[SC_MTILES], f0b, f1a[SC_MTILES], f1b;
+#define SC_FREAD(FA, FB, RA, RB, BUF)                                                              \
+    {                                                                                              \
+        FB = SC_LDS4((RB) + (BUF) * STAGE_BYTES);                                                  \
+        _Pragma("unroll") for (int m = 0; m < SC_MTILES; ++m)                                      \
+            FA[m] = SC_LDS4((RA) + (BUF) * STAGE_BYTES + m * 256);                                 \
+    }
+#define SC_FMFMA(FA, FB)                                                                           \
+    {                                                                                              \
+        _Pragma("unroll") for (int m = 0; m < SC_MTILES; ++m)                                      \
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[m].x, FB.x, acc[m], 0, 0, 0);         \
+        _Pragma("unroll") for (int m = 0; m < SC_MTILES; ++m)                                      \
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[m].y, FB.y, acc[m], 0, 0, 0);         \
+        _Pragma("unroll") for (int m = 0; m < SC_MTILES; ++m)                                      \
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[m].z, FB.z, acc[m], 0, 0, 0);         \
+        _Pragma("unroll") for (int m = 0; m < SC_MTILES; ++m)                                      \
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[m].w, FB.w, acc[m], 0, 0, 0);         \
+    }
+    // One chunk (software pipelined so that every LDS / barrier latency sits under 36 MFMAs = 1152 cycles):
+    //   park chunk kc+1 (register stage P) in the other LDS buffer; refill P with chunk kc+3;
+    //   read F1(kc);  MFMA F0(kc);  barrier  (=> chunk kc+1 visible, every wave is done reading chunk kc);
+    //   read F0(kc+1) from the other buffer;  MFMA F1(kc).
+    // One barrier per chunk, placed mid-way.  Tail iterations re-load the last chunk and park / read data
+    // nobody consumes, which keeps the body branch-free.
+    // Instruction interleave (sched_group_barrier): the wave issues in order, and a ds_write_b128 occupies its
+    // issue slot for >= 13 cycles (more when the 4 waves contend for the LDS store path), a ds_read_b128 /
+    // global_load a few.  Issued in a clump they starve the matrix pipe (tools/ubench/mfma_pipe: 3091 cycles
+    // per 72-MFMA chunk); slotted one per MFMA they execute under the previous MFMA's 32 cycles (2686).
+#define SC_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define SC_CHUNK(P, CUR, NXT, KC)                                                                  \
+    {                                                                                              \
+        SC_VMWAIT(P, 7)                                                                            \
+        SC_LSTORE(P, NXT)                                                                          \
+        SC_GLOAD(P, ((KC) + 3 < klast ? (KC) + 3 : klast))                                         \
+        SC_FREAD(f1a, f1b, ra1, rb1, CUR)                                                          \
+        SC_FMFMA(f0a, f0b)                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 7; ++i_) { SC_SGB(0x008, 1) SC_SGB(0x200, 1) }     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { SC_SGB(0x008, 1) SC_SGB(0x100, 1) }    \
+        SC_SGB(0x008, 19)                                                                          \
+        __syncthreads();                                                                           \
+        SC_FREAD(f0a, f0b, ra0, rb0, NXT)                                                          \
+        SC_FMFMA(f1a, f1b)                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { SC_SGB(0x008, 1) SC_SGB(0x100, 1) }    \
+        SC_SGB(0x008, 26)                                                                          \
     }
 
-    // ---- park the raw block in LDS (aliases the staging buffers) -----------------------
+    const int klast = nk - 1;
+    // prologue: chunk 0 -> LDS buffer 0, stage B = chunk 1, stage A = chunk 2
+    SC_GLOAD(sa, 0)
+    SC_GLOAD(sb, (1 < klast ? 1 : klast))
+    SC_VMWAIT(sa, 7)
+    SC_LSTORE(sa, 0)
+    SC_GLOAD(sa, (2 < klast ? 2 : klast))
     __syncthreads();
+    SC_TICK(4)   // prologue: first operand chunk in LDS
+    SC_FREAD(f0a, f0b, ra0, rb0, 0)
+    for (int kc = 0; kc < nk; kc += 2) {
+        SC_CHUNK(sb, 0, 1, kc)            // chunk kc   lives in buffer 0; parks chunk kc+1, refills B with kc+3
+        if (kc + 1 >= nk) break;
+        SC_CHUNK(sa, 1, 0, kc + 1)        // chunk kc+1 lives in buffer 1; parks chunk kc+2, refills A with kc+4
+    }
+    // drain the (unused) tail prefetches before the compiler recycles their destination registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef SC_LDG
+#undef SC_GLOAD
+#undef SC_STS
+#undef SC_VMWAIT
+#undef SC_LSTORE
+#undef SC_LDS4
+#undef SC_FREAD
+#undef SC_FMFMA
+#undef SC_CHUNK
+#undef SC_SGB
+
+    // ---- epilogue ------------------------------------------------------------------------------------------
+    // Next to a wave that streams 32-cycle fp32 MFMAs (the other workgroup of this CU) every VALU instruction
+    // of this wave waits for an MFMA slot, so the epilogue is built to issue few instructions: the block is
+    // parked TRANSPOSED ([word column][region row]) so that every access below is a 16-byte LDS access, and
+    // the two reductions with real arithmetic (first-norm statistics, ||ctx||^2) run on the matrix core.
+    __syncthreads();
+    SC_TICK(0)   // prologue + main loop
     {
-        const int col = wave * 16 + fi;
+        float *colp = &sm.arawt[wave * 16 + fi][fg * 4];
 #pragma unroll
-        for (int m = 0; m < SC_MTILES; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sm.araw[m * 16 + fg * 4 + r][col] = acc[m][r];
+        for (int m = 0; m < SC_MTILES; ++m) *reinterpret_cast<f32x4 *>(colp + m * 16) = acc[m];
     }
     __syncthreads();
+    SC_TICK(1)   // park
 
     const int norm = g.norm;
     const float ls = g.lambda_softmax;
+    const int ncap = sm.meta.ncap;
+    if (g.debug & 1) {  // ablation: no epilogue
+        if (tid < SC_IMGS && img0 + tid < g.Ni) g.S[(img0 + tid) * g.ldS + sm.meta.cap_id[0]] = sm.arawt[0][tid * SC_R];
+        return;
+    }
+#define AT(row, col) sm.arawt[col][row]
 
     if (g.mode == 0) {
         // ================= t2i: words attend over the 36 regions of every image ============
-        // E1: statistics of the first normalisation, along the caption's words, per region row
-        if (tid < SC_MT && norm != 3 && norm != 4) {
-            for (int k = 0; k < ncap; ++k) {
-                const int c0 = sm.cap_start[k], c1 = sm.cap_start[k + 1];
+        // The Gram matrix of this wave's image is the A operand of the ||ctx||^2 product; fetch its fragments
+        // now (27 floats per lane), the latency hides behind E1.
+        // Fragment (row tile mt, lane (fi, fg)): G[mt*16 + fi][16u + 4fg .. +3] (u = 0, 1) and G[..][32 + fg].
+        float4 gfa[3][2];
+        float gfb[3];
+        {
+            const int64_t gimg = (img0 + wave < g.Ni) ? img0 + wave : img0;
+            const float *G = g.gram + gimg * (SC_R * SC_R);
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                int row = mt * 16 + fi;
+                row = row < SC_R ? row : SC_R - 1;       // rows 36..47 of the last tile: their outputs are ignored
+                gfa[mt][0] = *reinterpret_cast<const float4 *>(G + row * SC_R + 4 * fg);
+                gfa[mt][1] = *reinterpret_cast<const float4 *>(G + row * SC_R + 16 + 4 * fg);
+                gfb[mt] = G[row * SC_R + 32 + fg];
+            }
+        }
+        // E1: statistics of the first normalisation, along each caption's words, per (region row, caption).
+        if (norm == 0 || norm == 1 || norm == 5 || norm == 6) {
+            // sum_w f(a[row][w]) * [w in caption k]  =  (f(A) [144 x 64]) x (indicator [64 x 16]) on the matrix
+            // core; f = leaky^2 | a^2 | |a| | |leaky|.  Wave w owns row tiles w, w+4 (and 8 for wave 0).
+            float ind[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ind[4 * u + j] = (sm.meta.col_cap[16 * u + 4 * fg + j] == fi) ? 1.f : 0.f;
+            for (int mt = wave; mt < SC_MTILES; mt += 4) {
+                f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = AT(mt * 16 + fi, 16 * u + 4 * fg + j);
+                        if (norm == 0 || norm == 6) v = leaky(v);
+                        v = (norm <= 1) ? v * v : fabsf(v);
+                        sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, ind[4 * u + j], sacc, 0, 0, 0);
+                    }
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = 1.f / ((norm <= 1 ? sqrtf(sacc[j]) : sacc[j]) + 1e-8f);
+                if (fi < SC_MAXCAP) *reinterpret_cast<f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]) = o;   // caption slot fi
+            }
+        } else if (norm == 2) {
+            for (int idx = tid; idx < SC_MT * ncap; idx += SC_THREADS) {
+                const int k = idx / SC_MT, row = idx - k * SC_MT;
+                const int c0 = sm.meta.cap_start[k], c1 = sm.meta.cap_start[k + 1];
                 NormAcc na;
                 na.init(norm);
-                for (int c = c0; c < c1; ++c) na.pass1(sm.araw[tid][c], norm);
-                if (norm == 2)
-                    for (int c = c0; c < c1; ++c) na.pass2(sm.araw[tid][c], norm);
+                for (int c = c0; c < c1; ++c) na.pass1(AT(row, c), norm);
+                for (int c = c0; c < c1; ++c) na.pass2(AT(row, c), norm);
                 na.finish(norm);
-                sm.stat[tid][k][0] = na.s0;
-                sm.stat[tid][k][1] = na.s1;
+                sm.stat[0][k][row] = na.s0;
+                sm.stat[1][k][row] = na.s1;
             }
         }
         __syncthreads();
-        // E2: one lane per (image = wave, word column = lane)
+        SC_TICK(2)   // E1
+        // E2: one wave per image, one lane per word column.
+        //   (a) attention weights e = exp(lambda_s * b [- max]); the max shift is skipped whenever the first
+        //       normalisation bounds |b| <= 1 (all l2 / l1 / softmax forms; exp(+-lambda_s) is harmless in fp32);
+        //       e overwrites the raw dot products of this lane's column;
+        //   (b) ||ctx||^2 = e^T G e / den^2:  T = G E on the matrix core (3 x 4 tiles, K = 36 -> 108 MFMAs per
+        //       wave), then a 12-term dot per lane and a 4-lane reduction.
         {
             const int ii = wave;
             const int w = lane;
             const int64_t img = img0 + ii;
-            const int k = sm.col_cap[w];
+            const int k = sm.meta.col_cap[w];
             float simv = 0.f;
             if (img < g.Ni) {  // wave-uniform
-                float a[SC_R], p[SC_R];
-                float mx = -INFINITY;
                 const int kk = k < 0 ? 0 : k;
+                float *colp = &sm.arawt[w][ii * SC_R];
+                float a[SC_R], e[SC_R];
+#pragma unroll
+                for (int r4 = 0; r4 < SC_R / 4; ++r4) {
+                    const f32x4 av = *reinterpret_cast<const f32x4 *>(colp + 4 * r4);
+                    f32x4 s0 = f32x4{1.f, 1.f, 1.f, 1.f}, s1 = s0;
+                    if (norm != 3 && norm != 4) s0 = *reinterpret_cast<const f32x4 *>(&sm.stat[0][kk][ii * SC_R + 4 * r4]);
+                    if (norm == 2) s1 = *reinterpret_cast<const f32x4 *>(&sm.stat[1][kk][ii * SC_R + 4 * r4]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a[4 * r4 + j] = av[j];
+                        e[4 * r4 + j] = norm_apply(av[j], norm, s0[j], s1[j]) * ls;
+                    }
+                }
+                float mx = 0.f;
+                if (norm == 3 || norm == 4) {
+                    mx = e[0];
+#pragma unroll
+                    for (int r = 1; r < SC_R; ++r) mx = fmaxf(mx, e[r]);
+                }
+                float den = 0.f, num = 0.f;
 #pragma unroll
                 for (int r = 0; r < SC_R; ++r) {
-                    a[r] = sm.araw[ii * SC_R + r][w];
-                    const float b = norm_apply(a[r], norm, sm.stat[ii * SC_R + r][kk][0], sm.stat[ii * SC_R + r][kk][1]);
-                    p[r] = b * ls;
-                    mx = fmaxf(mx, p[r]);
+                    e[r] = fast_exp(e[r] - mx);
+                    den += e[r];
+                    num += e[r] * a[r];
                 }
-                float den = 0.f;
 #pragma unroll
-                for (int r = 0; r < SC_R; ++r) { p[r] = expf(p[r] - mx); den += p[r]; }
-                float num = 0.f;
+                for (int r4 = 0; r4 < SC_R / 4; ++r4)
+                    *reinterpret_cast<f32x4 *>(colp + 4 * r4) = f32x4{e[4 * r4], e[4 * r4 + 1], e[4 * r4 + 2], e[4 * r4 + 3]};
+                const float rden = 1.f / den;
+                // T = G E.  B operand (k = region r2, n = word): lane (fi, fg) feeds E[16u + 4fg + j][nt*16 + fi].
+                // Only this wave touches rows ii*36 .. +35, and LDS operations of one wave are ordered.
+                f32x4 tacc[3][4];
 #pragma unroll
-                for (int r = 0; r < SC_R; ++r) { p[r] = p[r] / den; num += p[r] * a[r]; }
-                // ||ctx||^2 = p^T G p ; G is symmetric and wave-uniform (scalar loads)
-                const float *G = g.gram + img * (SC_R * SC_R);
-                float q = 0.f;
+                for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-                for (int r = 0; r < SC_R; ++r) {
-                    float t = 0.5f * G[r * SC_R + r] * p[r];
+                    for (int nt = 0; nt < 4; ++nt) tacc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int r2 = r + 1; r2 < SC_R; ++r2) t += G[r * SC_R + r2] * p[r2];
-                    q += p[r] * t;
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float *ec = &sm.arawt[nt * 16 + fi][ii * SC_R];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(ec + 16 * u + 4 * fg);
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt) {
+                            tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].x, bv[0], tacc[mt][nt], 0, 0, 0);
+                            tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].y, bv[1], tacc[mt][nt], 0, 0, 0);
+                            tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].z, bv[2], tacc[mt][nt], 0, 0, 0);
+                            tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].w, bv[3], tacc[mt][nt], 0, 0, 0);
+                        }
+                    }
+                    const float b4 = ec[32 + fg];
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt)
+                        tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfb[mt], b4, tacc[mt][nt], 0, 0, 0);
                 }
-                q = 2.f * q;
-                const int wr = sm.col_row[w];
-                const float w1 = wr >= 0 ? g.wnorm[wr] : 0.f;
+                // q[nt] = sum_r E[r][col] * T[r][col], col = nt*16 + fi; this lane holds rows mt*16 + 4fg + j
+                float qn[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float *ec = &sm.arawt[nt * 16 + fi][ii * SC_R];
+                    const f32x4 e0 = *reinterpret_cast<const f32x4 *>(ec + 4 * fg);
+                    const f32x4 e1 = *reinterpret_cast<const f32x4 *>(ec + 16 + 4 * fg);
+                    const f32x4 e2 = *reinterpret_cast<const f32x4 *>(ec + 32);          // rows 32..35, used by fg == 0
+                    float part = 0.f, tail = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        part += e0[j] * tacc[0][nt][j] + e1[j] * tacc[1][nt][j];
+                        tail += e2[j] * tacc[2][nt][j];
+                    }
+                    part += (fg == 0) ? tail : 0.f;
+                    part += __shfl_xor(part, 16, 64);
+                    part += __shfl_xor(part, 32, 64);
+                    qn[nt] = part;
+                }
+                // this lane's own column is w = fg*16 + fi -> n-tile fg
+                float q = fg == 0 ? qn[0] : (fg == 1 ? qn[1] : (fg == 2 ? qn[2] : qn[3]));
+                q = q * rden * rden;
+                num *= rden;
+                const float w1 = g.wnorm[ct * SC_NT + w];
                 const float w2 = sqrtf(fmaxf(q, 0.f));
                 simv = num / fmaxf(w1 * w2, 1e-8f);   // cosine_similarity, Objectives.py:10-15
             }
             sm.rowsim[ii][w] = simv;
         }
         __syncthreads();
+        SC_TICK(3)   // E2
         // E3: aggregate over the words of each caption (Objectives.py:355-366)
         if (tid < SC_IMGS * SC_MAXCAP) {
             const int ii = tid / SC_MAXCAP, k = tid % SC_MAXCAP;
             const int64_t img = img0 + ii;
             if (k < ncap && img < g.Ni) {
-                const int c0 = sm.cap_start[k], c1 = sm.cap_start[k + 1];
+                const int c0 = sm.meta.cap_start[k], c1 = sm.meta.cap_start[k + 1];
                 float r;
                 if (g.agg == 0) {
                     r = 0.f;
@@ -333,7 +519,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                     for (int c = c0; c < c1; ++c) r += sm.rowsim[ii][c];
                     if (g.agg == 3) r /= (float)(c1 - c0);
                 }
-                g.S[img * g.ldS + sm.cap_id[k]] = r;
+                g.S[img * g.ldS + sm.meta.cap_id[k]] = r;
             }
         }
     } else {
@@ -345,9 +531,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                 NormAcc na;
                 na.init(norm);
 #pragma unroll 4
-                for (int r = 0; r < SC_R; ++r) na.pass1(sm.araw[ii * SC_R + r][w], norm);
+                for (int r = 0; r < SC_R; ++r) na.pass1(AT(ii * SC_R + r, w), norm);
                 if (norm == 2)
-                    for (int r = 0; r < SC_R; ++r) na.pass2(sm.araw[ii * SC_R + r][w], norm);
+                    for (int r = 0; r < SC_R; ++r) na.pass2(AT(ii * SC_R + r, w), norm);
                 na.finish(norm);
                 sm.colstat[ii][w][0] = na.s0;
                 sm.colstat[ii][w][1] = na.s1;
@@ -357,36 +543,36 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
         // E2: one lane per region row, loop over the captions of the tile.  The attention
         // weights overwrite the raw block row segment once the numerator has been taken.
         for (int k = 0; k < ncap; ++k) {
-            const int c0 = sm.cap_start[k], c1 = sm.cap_start[k + 1];
+            const int c0 = sm.meta.cap_start[k], c1 = sm.meta.cap_start[k + 1];
             if (tid < SC_MT) {
                 const int ii = tid / SC_R;
                 const int64_t img = img0 + ii;
                 float mx = -INFINITY;
                 for (int c = c0; c < c1; ++c) {
-                    const float b = norm_apply(sm.araw[tid][c], norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
+                    const float b = norm_apply(AT(tid, c), norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
                     mx = fmaxf(mx, b * ls);
                 }
                 float den = 0.f;
                 for (int c = c0; c < c1; ++c) {
-                    const float b = norm_apply(sm.araw[tid][c], norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
+                    const float b = norm_apply(AT(tid, c), norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
                     den += expf(b * ls - mx);
                 }
                 float num = 0.f;
                 for (int c = c0; c < c1; ++c) {
-                    const float a = sm.araw[tid][c];
+                    const float a = AT(tid, c);
                     const float b = norm_apply(a, norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
                     const float pw = expf(b * ls - mx) / den;
                     num += pw * a;
-                    sm.araw[tid][c] = pw;  // own row, own caption segment: no other reader left
+                    AT(tid, c) = pw;  // own row, own caption segment: no other reader left
                 }
                 // ||ctx_r||^2 = p^T H_c p with the caption Gram H_c (uniform across lanes)
                 const int W = c1 - c0;
-                const float *H = g.cgram + g.cgram_off[sm.cap_id[k]];
+                const float *H = g.cgram + g.cgram_off[sm.meta.cap_id[k]];
                 float q = 0.f;
                 for (int u = 0; u < W; ++u) {
                     float t = 0.f;
-                    for (int v = 0; v < W; ++v) t += H[u * W + v] * sm.araw[tid][c0 + v];
-                    q += sm.araw[tid][c0 + u] * t;
+                    for (int v = 0; v < W; ++v) t += H[u * W + v] * AT(tid, c0 + v);
+                    q += AT(tid, c0 + u) * t;
                 }
                 const float w1 = img < g.Ni ? g.vnorm[img * SC_R + tid % SC_R] : 0.f;
                 const float w2 = sqrtf(fmaxf(q, 0.f));
@@ -412,7 +598,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                     for (int t = 0; t < SC_R; ++t) r += sm.rsim2[ii * SC_R + t][k];
                     if (g.agg == 3) r /= (float)SC_R;
                 }
-                g.S[img * g.ldS + sm.cap_id[k]] = r;
+                g.S[img * g.ldS + sm.meta.cap_id[k]] = r;
             }
         }
     }
@@ -490,83 +676,181 @@ __global__ __launch_bounds__(1024) void sq_prefix_kernel(const int32_t *__restri
     for (int64_t i = b; i < e; ++i) { off[i] = run; run += (long long)len[i] * len[i]; }
 }
 
+// Re-pack the word embeddings tile by tile: wtiled[t*64 + j] = words[row of column j of tile t] (zero rows
+// for padding columns), so that the main kernel addresses its B operand from blockIdx alone; also emits the
+// per-tile metadata record and (t2i) the word norms ||E_w||.  One workgroup per tile; HBM-bound copy.
+__global__ __launch_bounds__(256) void scan_pack_kernel(const float *__restrict__ words, const int64_t *__restrict__ cap_off,
+                                                        const int32_t *__restrict__ cap_len,
+                                                        const int32_t *__restrict__ tile_begin,
+                                                        const int32_t *__restrict__ cap_order, int D,
+                                                        float *__restrict__ wtiled, ScanTileMeta *__restrict__ meta,
+                                                        float *__restrict__ wnorm) {
+    __shared__ ScanTileMeta m;
+    __shared__ int64_t off[SC_MAXCAP];
+    __shared__ int32_t len[SC_MAXCAP];
+    __shared__ int64_t col_row[SC_NT];
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int c0 = tile_begin[t];
+    int n = tile_begin[t + 1] - c0;
+    if (n > SC_MAXCAP) n = SC_MAXCAP;
+    if (tid < SC_MAXCAP) {
+        int32_t cid = -1, l = 0;
+        int64_t o = 0;
+        if (tid < n) { cid = cap_order[c0 + tid]; l = cap_len[cid]; o = cap_off[cid]; }
+        m.cap_id[tid] = cid; len[tid] = l; off[tid] = o;
+    }
+    if (tid < SC_NT) { m.col_cap[tid] = -1; col_row[tid] = -1; }
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int k = 0; k < n; ++k) {
+            m.cap_start[k] = pos;
+            int w = len[k];
+            if (pos + w > SC_NT) w = SC_NT - pos;  // the planner never lets this happen
+            pos += w;
+        }
+        for (int k = n; k <= SC_MAXCAP; ++k) m.cap_start[k] = pos;
+        m.ncap = n;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * SC_NT; idx += 256) {
+        const int k = idx / SC_NT, w = idx % SC_NT;
+        const int st = m.cap_start[k];
+        if (w < m.cap_start[k + 1] - st) { col_row[st + w] = off[k] + w; m.col_cap[st + w] = (int8_t)k; }
+    }
+    __syncthreads();
+    if (tid < 64) reinterpret_cast<int32_t *>(meta + t)[tid] = reinterpret_cast<const int32_t *>(&m)[tid];
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int j = wave; j < SC_NT; j += 4) {
+        const int64_t r = col_row[j];
+        float *dst = wtiled + (t * SC_NT + j) * (int64_t)D;
+        float ss = 0.f;
+        if (r >= 0) {
+            const float *src = words + r * D;
+            for (int k = lane * 4; k < D; k += 256) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + k);
+                *reinterpret_cast<float4 *>(dst + k) = v;
+                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        } else {
+            for (int k = lane * 4; k < D; k += 256) *reinterpret_cast<float4 *>(dst + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (wnorm) {
+            ss = wave_sum(ss);
+            if (lane == 0) wnorm[t * SC_NT + j] = sqrtf(ss);
+        }
+    }
+}
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static_assert(sizeof(ScanSmem) <= 80 * 1024, "two workgroups per CU need <= 80 KiB of LDS each");
+
+// Workspace layout (prepare and scores agree on it)
+struct ScanWs {
+    float *gram, *wnorm, *vnorm, *cgram, *wtiled;
+    int64_t *coff;
+    ScanTileMeta *meta;
+};
+static size_t scan_ws_bytes(int64_t Ni, int R, int64_t n_rows, int64_t Nc, int64_t n_tiles, int D) {
+    const size_t common = align256((size_t)n_tiles * sizeof(ScanTileMeta)) + align256((size_t)n_tiles * SC_NT * D * 4);
+    const size_t t2i = align256((size_t)Ni * R * R * 4) + align256((size_t)n_tiles * SC_NT * 4);
+    const size_t i2t = align256((size_t)Ni * R * 4) + align256((size_t)Nc * 8) + align256((size_t)n_rows * SC_NT * 4);
+    return common + (t2i > i2t ? t2i : i2t);
+}
+static ScanWs scan_carve(void *workspace, int64_t Ni, int R, int64_t n_rows, int64_t Nc, int64_t n_tiles, int D, int mode) {
+    char *ws = static_cast<char *>(workspace);
+    ScanWs w{};
+    w.meta = reinterpret_cast<ScanTileMeta *>(ws); ws += align256((size_t)n_tiles * sizeof(ScanTileMeta));
+    w.wtiled = reinterpret_cast<float *>(ws); ws += align256((size_t)n_tiles * SC_NT * D * 4);
+    if (mode == 0) {
+        w.gram = reinterpret_cast<float *>(ws); ws += align256((size_t)Ni * R * R * 4);
+        w.wnorm = reinterpret_cast<float *>(ws);
+    } else {
+        w.vnorm = reinterpret_cast<float *>(ws); ws += align256((size_t)Ni * R * 4);
+        w.coff = reinterpret_cast<int64_t *>(ws); ws += align256((size_t)Nc * 8);
+        w.cgram = reinterpret_cast<float *>(ws);
+    }
+    return w;
+}
 
 }  // namespace itr
 
 extern "C" int itr_scan_plan_tiles(const int32_t *len_host, int64_t Nc, int nt, int32_t *tile_begin_host,
-                                   int64_t *n_tiles) {
-    ITR_REQUIRE(len_host && tile_begin_host && n_tiles, "itr_scan_plan_tiles: null pointer");
+                                   int32_t *cap_order_host, int64_t *n_tiles) {
+    // Best-fit-decreasing bin packing of whole captions into column tiles of `nt` words and at most
+    // SC_MAXCAP captions (lengths are small integers, so "best fit" is a bucket lookup: O(Nc * nt)).
+    // Output: cap_order_host[Nc] = caption ids grouped by tile, tile_begin_host[n_tiles + 1] into it.
+    ITR_REQUIRE(len_host && tile_begin_host && cap_order_host && n_tiles, "itr_scan_plan_tiles: null pointer");
     ITR_REQUIRE(nt == ITR_SCAN_NT, "itr_scan_plan_tiles: nt must be %d", ITR_SCAN_NT);
-    int64_t t = 0;
-    int used = 0, caps = 0;
-    tile_begin_host[0] = 0;
+    ITR_REQUIRE(Nc >= 0 && Nc < 0x7fffffffLL, "itr_scan_plan_tiles: bad caption count");
+    std::vector<std::vector<int32_t>> by_len(nt + 1);
     for (int64_t c = 0; c < Nc; ++c) {
         const int w = len_host[c];
         ITR_REQUIRE(w >= 1, "itr_scan_plan_tiles: caption %lld has length %d (< 1)", (long long)c, w);
         ITR_UNSUPPORTED(w > nt, "itr_scan_plan_tiles: caption %lld has %d words; this build supports <= %d",
                         (long long)c, w, nt);
-        if (used + w > nt || caps == itr::SC_MAXCAP) {
-            tile_begin_host[++t] = (int32_t)c;
-            used = 0;
-            caps = 0;
-        }
-        used += w;
-        ++caps;
+        by_len[w].push_back((int32_t)c);
     }
-    if (Nc > 0) tile_begin_host[++t] = (int32_t)Nc;
-    *n_tiles = t;
+    struct Tile { int32_t n; int32_t cap[itr::SC_MAXCAP]; };
+    std::vector<Tile> tiles;
+    std::vector<std::vector<int32_t>> open(nt + 1);  // open[r] = tiles with r free columns and < MAXCAP captions
+    for (int w = nt; w >= 1; --w)
+        for (int32_t c : by_len[w]) {
+            int r = w;
+            while (r <= nt && open[r].empty()) ++r;
+            int32_t t;
+            if (r <= nt) {
+                t = open[r].back();
+                open[r].pop_back();
+            } else {
+                t = (int32_t)tiles.size();
+                tiles.push_back(Tile{0, {}});
+                r = nt;
+            }
+            Tile &T = tiles[t];
+            T.cap[T.n++] = c;
+            if (T.n < itr::SC_MAXCAP && r - w > 0) open[r - w].push_back(t);
+        }
+    int64_t pos = 0;
+    for (size_t t = 0; t < tiles.size(); ++t) {
+        tile_begin_host[t] = (int32_t)pos;
+        for (int k = 0; k < tiles[t].n; ++k) cap_order_host[pos++] = tiles[t].cap[k];
+    }
+    tile_begin_host[tiles.size()] = (int32_t)pos;
+    *n_tiles = (int64_t)tiles.size();
     return ITR_OK;
 }
 
-extern "C" size_t itr_scan_workspace_bytes(int64_t Ni, int R, int64_t n_rows, int64_t Nc) {
-    using itr::align256;
-    // t2i: gram[Ni,R,R] + wnorm[n_rows];  i2t: vnorm[Ni*R] + cgram_off[Nc] + cgram[<= n_rows * NT]
-    size_t t2i = align256((size_t)Ni * R * R * 4) + align256((size_t)n_rows * 4);
-    size_t i2t = align256((size_t)Ni * R * 4) + align256((size_t)Nc * 8) + align256((size_t)n_rows * ITR_SCAN_NT * 4);
-    return t2i > i2t ? t2i : i2t;
+extern "C" size_t itr_scan_workspace_bytes(int64_t Ni, int R, int64_t n_rows, int64_t Nc, int64_t n_tiles, int D) {
+    return itr::scan_ws_bytes(Ni, R, n_rows, Nc, n_tiles, D);
 }
-
-// Workspace layout (both entry points agree on it)
-namespace itr {
-struct ScanWs {
-    float *gram, *wnorm, *vnorm, *cgram;
-    int64_t *coff;
-};
-static ScanWs scan_carve(void *workspace, int64_t Ni, int R, int64_t n_rows, int64_t Nc, int mode) {
-    char *ws = static_cast<char *>(workspace);
-    ScanWs w{};
-    if (mode == 0) {
-        w.gram = reinterpret_cast<float *>(ws);
-        w.wnorm = reinterpret_cast<float *>(ws + align256((size_t)Ni * R * R * 4));
-    } else {
-        w.vnorm = reinterpret_cast<float *>(ws);
-        w.coff = reinterpret_cast<int64_t *>(ws + align256((size_t)Ni * R * 4));
-        w.cgram = reinterpret_cast<float *>(ws + align256((size_t)Ni * R * 4) + align256((size_t)Nc * 8));
-    }
-    return w;
-}
-}  // namespace itr
 
 extern "C" int itr_scan_prepare(const float *img, const float *words, const int64_t *cap_off,
-                                const int32_t *cap_len, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
-                                int mode, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
+                                const int32_t *cap_len, const int32_t *tile_begin_dev,
+                                const int32_t *cap_order_dev, int64_t n_tiles, int64_t Ni, int64_t Nc,
+                                int64_t n_rows, int R, int D, int mode, void *workspace, size_t workspace_bytes,
+                                itr_stream_t stream) {
     using namespace itr;
-    ITR_REQUIRE(img && words && cap_off && cap_len && workspace, "itr_scan_prepare: null pointer");
-    ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && D > 0, "itr_scan_prepare: bad shape");
+    ITR_REQUIRE(img && words && cap_off && cap_len && tile_begin_dev && cap_order_dev && workspace,
+                "itr_scan_prepare: null pointer");
+    ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && n_tiles >= 0 && D > 0, "itr_scan_prepare: bad shape");
     if (mode != 0 && mode != 1) { set_error("unknown cross_attn mode %d", mode); return ITR_ERR_BADARG; }
     ITR_UNSUPPORTED(R != SC_R, "itr_scan_prepare: this build handles %d regions per image, got %d", SC_R, R);
-    ITR_REQUIRE(workspace_bytes >= itr_scan_workspace_bytes(Ni, R, n_rows, Nc), "itr_scan_prepare: workspace too small");
+    ITR_UNSUPPORTED(D % SC_BK != 0, "itr_scan_prepare: embed dim must be a multiple of %d, got %d", SC_BK, D);
+    ITR_REQUIRE((reinterpret_cast<uintptr_t>(img) & 15) == 0 && (reinterpret_cast<uintptr_t>(words) & 15) == 0,
+                "itr_scan_prepare: operands must be 16-byte aligned");
+    ITR_REQUIRE(workspace_bytes >= scan_ws_bytes(Ni, R, n_rows, Nc, n_tiles, D), "itr_scan_prepare: workspace too small");
     if (Ni == 0 || Nc == 0) return ITR_OK;
     hipStream_t st = as_stream(stream);
-    ScanWs w = scan_carve(workspace, Ni, R, n_rows, Nc, mode);
+    ScanWs w = scan_carve(workspace, Ni, R, n_rows, Nc, n_tiles, D, mode);
+    hipLaunchKernelGGL(scan_pack_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, words, cap_off, cap_len,
+                       tile_begin_dev, cap_order_dev, D, w.wtiled, w.meta, w.wnorm);
+    ITR_CHECK_LAUNCH("scan pack");
     if (mode == 0) {
         hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Ni), dim3(256), 0, st, img, (const int64_t *)nullptr,
                            (const int32_t *)nullptr, R, D, w.gram, (const int64_t *)nullptr);
         ITR_CHECK_LAUNCH("scan gram");
-        hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, st, words, n_rows, D, w.wnorm);
-        ITR_CHECK_LAUNCH("scan wnorm");
     } else {
         hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)ceil_div(Ni * R, 4)), dim3(256), 0, st, img, Ni * R, D, w.vnorm);
         ITR_CHECK_LAUNCH("scan vnorm");
@@ -579,14 +863,12 @@ extern "C" int itr_scan_prepare(const float *img, const float *words, const int6
     return ITR_OK;
 }
 
-extern "C" int itr_scan_xattn_scores(const float *img, const float *words, const int64_t *cap_off,
-                                     const int32_t *cap_len, const int32_t *tile_begin_dev, int64_t n_tiles,
-                                     int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D, int mode, int norm,
-                                     int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
-                                     void *workspace, size_t workspace_bytes, itr_stream_t stream) {
+extern "C" int itr_scan_xattn_scores(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows,
+                                     int R, int D, int mode, int norm, int agg, float lambda_softmax,
+                                     float lambda_lse, float *S, int64_t ldS, void *workspace,
+                                     size_t workspace_bytes, itr_stream_t stream) {
     using namespace itr;
-    ITR_REQUIRE(img && words && cap_off && cap_len && tile_begin_dev && S && workspace,
-                "itr_scan_xattn_scores: null pointer");
+    ITR_REQUIRE(img && S && workspace, "itr_scan_xattn_scores: null pointer");
     ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && n_tiles >= 0 && ldS >= Nc, "itr_scan_xattn_scores: bad shape");
     if (mode != 0 && mode != 1) { set_error("unknown cross_attn mode %d", mode); return ITR_ERR_BADARG; }
     if (norm < 0 || norm > 6) { set_error("unknown first norm type: %d", norm); return ITR_ERR_BADARG; }
@@ -594,20 +876,24 @@ extern "C" int itr_scan_xattn_scores(const float *img, const float *words, const
     ITR_UNSUPPORTED(R != SC_R, "itr_scan_xattn_scores: this build handles %d regions per image, got %d", SC_R, R);
     ITR_UNSUPPORTED(D <= 0 || D % SC_BK != 0, "itr_scan_xattn_scores: embed dim must be a multiple of %d, got %d",
                     SC_BK, D);
-    ITR_REQUIRE((reinterpret_cast<uintptr_t>(img) & 15) == 0 && (reinterpret_cast<uintptr_t>(words) & 15) == 0,
-                "itr_scan_xattn_scores: operands must be 16-byte aligned");
-    ITR_REQUIRE(n_rows < 0x7fffffffLL, "itr_scan_xattn_scores: too many word rows");
-    ITR_REQUIRE(workspace_bytes >= itr_scan_workspace_bytes(Ni, R, n_rows, Nc),
+    ITR_REQUIRE((reinterpret_cast<uintptr_t>(img) & 15) == 0, "itr_scan_xattn_scores: operands must be 16-byte aligned");
+    ITR_REQUIRE(workspace_bytes >= scan_ws_bytes(Ni, R, n_rows, Nc, n_tiles, D),
                 "itr_scan_xattn_scores: workspace too small");
     if (Ni == 0 || Nc == 0) return ITR_OK;
     hipStream_t st = as_stream(stream);
 
+    ScanWs w = scan_carve(workspace, Ni, R, n_rows, Nc, n_tiles, D, mode);
     ScanArgs a{};
-    a.img = img; a.words = words; a.cap_off = cap_off; a.cap_len = cap_len; a.tile_begin = tile_begin_dev;
+    a.img = img; a.wtiled = w.wtiled; a.meta = w.meta;
     a.S = S; a.ldS = ldS; a.Ni = Ni; a.Nc = Nc; a.n_tiles = n_tiles; a.D = D;
     a.mode = mode; a.norm = norm; a.agg = agg; a.lambda_softmax = lambda_softmax; a.lambda_lse = lambda_lse;
-    ScanWs w = scan_carve(workspace, Ni, R, n_rows, Nc, mode);
     a.gram = w.gram; a.wnorm = w.wnorm; a.vnorm = w.vnorm; a.cgram = w.cgram; a.cgram_off = w.coff;
+    if (const char *dbg = getenv("ITR_SCAN_DEBUG")) a.debug = atoi(dbg);
+    if (a.debug & 16) {   // phase timing: the caller reads the 8 counters placed at the start of S (S is garbage then)
+        a.dbg_cycles = reinterpret_cast<unsigned long long *>(S);
+        ITR_CHECK_HIP(hipMemsetAsync(S, 0, 64, st));
+        a.S = S + 16;
+    }
 
     const int64_t img_tiles = ceil_div(Ni, SC_IMGS);
     const int64_t PI = ceil_div(img_tiles, 8), PJ = ceil_div(n_tiles, 8);
@@ -616,10 +902,24 @@ extern "C" int itr_scan_xattn_scores(const float *img, const float *words, const
     static bool attr_set = false;
     if (!attr_set) {
         ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanSmem)));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(scan_xattn_kernel, dim3((unsigned)nblk), dim3(SC_THREADS), sizeof(ScanSmem), st, a);
+    size_t lds = sizeof(ScanSmem);
+    if (const char *ex = getenv("ITR_SCAN_LDS_EXTRA")) lds += (size_t)atoi(ex);   // occupancy experiments only
+    hipLaunchKernelGGL(scan_xattn_kernel, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
     ITR_CHECK_LAUNCH("scan_xattn");
+    return ITR_OK;
+}
+
+// Diagnostics for tools/: resident workgroups per CU of the SCAN kernel as the runtime sees it.
+extern "C" int itr_debug_scan_occupancy(int *blocks_per_cu, int *lds_bytes) {
+    using namespace itr;
+    ITR_REQUIRE(blocks_per_cu && lds_bytes, "itr_debug_scan_occupancy: null pointer");
+    ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanSmem)));
+    ITR_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(scan_xattn_kernel),
+                                                               SC_THREADS, sizeof(ScanSmem)));
+    *lds_bytes = (int)sizeof(ScanSmem);
     return ITR_OK;
 }

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 i32, i64, f32, vp, sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -30,11 +30,11 @@ SIGNATURES = {
     "itr_mvm_scores": (i32, [vp, vp, vp, i64, i64, i32, i32, i64, vp]),
     "itr_hinge_maxviol_fwd": (i32, [vp, i32, i64, f32, i32, vp, vp, vp, vp, vp]),
     "itr_hinge_maxviol_bwd": (i32, [vp, i32, i64, f32, i32, vp, vp, vp, vp, i64, vp]),
-    "itr_scan_plan_tiles": (i32, [vp, i64, i32, vp, vp]),
-    "itr_scan_workspace_bytes": (sz, [i64, i32, i64, i64]),
-    "itr_scan_prepare": (i32, [vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp, sz, vp]),
-    "itr_scan_xattn_scores": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32,
-                                    f32, f32, vp, i64, vp, sz, vp]),
+    "itr_scan_plan_tiles": (i32, [vp, i64, i32, vp, vp, vp]),
+    "itr_scan_workspace_bytes": (sz, [i64, i32, i64, i64, i64, i32]),
+    "itr_scan_prepare": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, sz, vp]),
+    "itr_scan_xattn_scores": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp, sz, vp]),
+    "itr_debug_scan_occupancy": (i32, [vp, vp]),
     "itr_rank_gather_gt": (i32, [vp, i64, i64, i64, i64, i32, vp, vp]),
     "itr_rank_counts": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
     "itr_recall_from_ranks": (i32, [vp, i64, vp]),

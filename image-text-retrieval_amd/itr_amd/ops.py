@@ -190,25 +190,30 @@ class ScanPlan:
         self.Nc = len(self.len_host)
         self.n_rows = int(n_rows)
         tb = np.zeros(self.Nc + 1, dtype=np.int32)
+        order = np.zeros(max(self.Nc, 1), dtype=np.int32)
         nt = C.c_int64(0)
         _lib.check(lib.itr_scan_plan_tiles(self.len_host.ctypes.data_as(C.c_void_p), self.Nc, SCAN_NT,
-                                           tb.ctypes.data_as(C.c_void_p), C.byref(nt)))
+                                           tb.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p),
+                                           C.byref(nt)))
         self.n_tiles = int(nt.value)
         self.tile_begin = torch.from_numpy(tb[:self.n_tiles + 1].copy()).to(device)
+        self.cap_order = torch.from_numpy(order).to(device)
         self.cap_len = torch.from_numpy(self.len_host.copy()).to(device)
         self.cap_off = torch.as_tensor(np.asarray(cap_off, dtype=np.int64)).to(device)
 
 
 def scan_prepare(images, words, plan, cross_attn='t2i'):
-    """Per (image block, caption set) precompute for the SCAN kernel: Gram matrices + norms."""
+    """Per (image block, caption set) precompute for the SCAN kernel: tile-packed words, Gram matrices,
+    norms.  Returns the prepared workspace (a uint8 tensor)."""
     lib = _lib.load()
     images = _dev(images, name="images")
     words = _dev(words, name="words")
     Ni, R, D = images.shape
-    wsb = lib.itr_scan_workspace_bytes(Ni, R, words.shape[0], plan.Nc)
+    wsb = lib.itr_scan_workspace_bytes(Ni, R, words.shape[0], plan.Nc, plan.n_tiles, D)
     ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
-    _lib.check(lib.itr_scan_prepare(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), Ni, plan.Nc,
-                                    words.shape[0], R, D, 0 if cross_attn == 't2i' else 1, _p(ws), wsb, _stream()))
+    _lib.check(lib.itr_scan_prepare(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
+                                    _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc, words.shape[0], R, D,
+                                    0 if cross_attn == 't2i' else 1, _p(ws), wsb, _stream()))
     return ws
 
 
@@ -230,11 +235,10 @@ def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='c
     if out is None:
         out = torch.empty(Ni, plan.Nc, device=images.device, dtype=torch.float32)
     ws = workspace if workspace is not None else scan_prepare(images, words, plan, cross_attn)
-    wsb = ws.numel()
     _lib.check(lib.itr_scan_xattn_scores(
-        _p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin), plan.n_tiles, Ni, plan.Nc,
-        n_rows, R, D, 0 if cross_attn == 't2i' else 1, _NORMS[raw_feature_norm], _AGGS[agg_func],
-        float(lambda_softmax), float(lambda_lse), _p(out), out.stride(0), _p(ws), wsb, _stream()))
+        _p(images), plan.n_tiles, Ni, plan.Nc, n_rows, R, D, 0 if cross_attn == 't2i' else 1,
+        _NORMS[raw_feature_norm], _AGGS[agg_func], float(lambda_softmax), float(lambda_lse), _p(out), out.stride(0),
+        _p(ws), ws.numel(), _stream()))
     return out
 
 

@@ -107,24 +107,32 @@ int itr_hinge_maxviol_bwd(const float *S, int B, int64_t ldS, float margin, int 
  * (padded (Nc,L,D) input: cap_off[c] = c*L).  S[i,c] written with row stride ldS.
  * mode: 0 t2i, 1 i2t.  norm: 0 clipped_l2norm, 1 l2norm, 2 softmax, 3 no_norm, 4 clipped,
  * 5 l1norm, 6 clipped_l1norm.  agg: 0 LogSumExp, 1 Max, 2 Sum, 3 Mean.
- * Tile plan: captions are grouped host-side into column tiles of <= ITR_SCAN_NT words by
- * itr_scan_plan_tiles (pure CPU); tile_begin_dev[n_tiles+1] is that plan on the device.
- * workspace: itr_scan_workspace_bytes(Ni, R, n_rows, Nc) bytes.  itr_scan_prepare fills it for one
- * (image block, caption set, mode): region Gram matrices V_i V_i^T + word norms (t2i) or region norms
- * + caption Gram matrices E_c E_c^T (i2t); itr_scan_xattn_scores then needs that prepared workspace
- * and may be called repeatedly (other norm / agg / lambda) without preparing again. */
+ * Three steps:
+ *  1. itr_scan_plan_tiles (pure CPU): whole captions are bin-packed (best fit decreasing) into column
+ *     tiles of <= ITR_SCAN_NT words: cap_order[Nc] lists the caption ids tile by tile and
+ *     tile_begin[n_tiles+1] indexes it; the caller copies both to the device.
+ *  2. itr_scan_prepare: once per (image block, caption set, mode) -- re-packs the word embeddings tile
+ *     by tile into the workspace and precomputes region Gram matrices V_i V_i^T + word norms (t2i) or
+ *     region norms + caption Gram matrices E_c E_c^T (i2t).
+ *  3. itr_scan_xattn_scores: the fused MFMA kernel; needs only `img` and the prepared workspace and may
+ *     be called repeatedly (other norm / agg / lambda) without preparing again.
+ * workspace: itr_scan_workspace_bytes(Ni, R, n_rows, Nc, n_tiles, D) bytes. */
 #define ITR_SCAN_NT 64
 int itr_scan_plan_tiles(const int32_t *len_host, int64_t Nc, int nt, int32_t *tile_begin_host,
-                        int64_t *n_tiles);
-size_t itr_scan_workspace_bytes(int64_t Ni, int R, int64_t n_rows, int64_t Nc);
+                        int32_t *cap_order_host, int64_t *n_tiles);
+size_t itr_scan_workspace_bytes(int64_t Ni, int R, int64_t n_rows, int64_t Nc, int64_t n_tiles, int D);
 int itr_scan_prepare(const float *img, const float *words, const int64_t *cap_off,
-                     const int32_t *cap_len, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
-                     int mode, void *workspace, size_t workspace_bytes, itr_stream_t stream);
-int itr_scan_xattn_scores(const float *img, const float *words, const int64_t *cap_off,
-                          const int32_t *cap_len, const int32_t *tile_begin_dev, int64_t n_tiles,
-                          int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D, int mode, int norm,
-                          int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
-                          void *workspace, size_t workspace_bytes, itr_stream_t stream);
+                     const int32_t *cap_len, const int32_t *tile_begin_dev,
+                     const int32_t *cap_order_dev, int64_t n_tiles, int64_t Ni, int64_t Nc,
+                     int64_t n_rows, int R, int D, int mode, void *workspace, size_t workspace_bytes,
+                     itr_stream_t stream);
+int itr_scan_xattn_scores(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows,
+                          int R, int D, int mode, int norm, int agg, float lambda_softmax,
+                          float lambda_lse, float *S, int64_t ldS, void *workspace,
+                          size_t workspace_bytes, itr_stream_t stream);
+
+/* diagnostics (tools/): occupancy of the SCAN kernel as reported by the HIP runtime */
+int itr_debug_scan_occupancy(int *blocks_per_cu, int *lds_bytes);
 
 /* ---- a17: i2t / t2i ranker (itr/metricmodule/evaluation.py:156-222) --------------------
  * Sort-free: rank(query, gt) = #{k: S_k > S_gt} + #{k > gt: S_k == S_gt}; i2t takes the min

@@ -50,35 +50,40 @@ def plan(lens):
     lib = _lib.load()
     lens = np.asarray(lens, dtype=np.int32)
     tb = np.zeros(len(lens) + 1, dtype=np.int32)
+    order = np.zeros(max(len(lens), 1), dtype=np.int32)
     nt = C.c_int64(0)
     rc = lib.itr_scan_plan_tiles(lens.ctypes.data_as(C.c_void_p), len(lens), 64, tb.ctypes.data_as(C.c_void_p),
-                                 C.byref(nt))
-    return rc, tb[:nt.value + 1]
+                                 order.ctypes.data_as(C.c_void_p), C.byref(nt))
+    return rc, tb[:nt.value + 1], order[:len(lens)]
 
 
 def test_scan_tile_planner():
     rng = np.random.RandomState(0)
-    lens = rng.randint(1, 65, size=500)
-    rc, tb = plan(lens)
-    assert rc == 0 and tb[0] == 0 and tb[-1] == len(lens)
-    for a, b in zip(tb[:-1], tb[1:]):
-        assert 1 <= b - a <= 16                       # <= SC_MAXCAP captions per tile
-        assert lens[a:b].sum() <= 64                  # whole captions only, <= 64 words
-        if b < len(lens) and b - a < 16:
-            assert lens[a:b].sum() + lens[b] > 64     # greedy: the next caption did not fit
-    rc, tb = plan([])
+    for lo, hi, n in ((1, 65, 500), (6, 21, 25000), (64, 65, 10), (1, 2, 100)):
+        lens = rng.randint(lo, hi, size=n)
+        rc, tb, order = plan(lens)
+        assert rc == 0 and tb[0] == 0 and tb[-1] == n
+        assert sorted(order.tolist()) == list(range(n))          # every caption exactly once
+        for a, b in zip(tb[:-1], tb[1:]):
+            assert 1 <= b - a <= 16                              # <= SC_MAXCAP captions per tile
+            assert lens[order[a:b]].sum() <= 64                  # whole captions only, <= 64 words
+    # the BASELINE length distribution packs to >= 97 % column occupancy
+    lens = rng.randint(6, 21, size=25000)
+    rc, tb, order = plan(lens)
+    assert lens.sum() / (64.0 * (len(tb) - 1)) >= 0.97
+    rc, tb, order = plan([])
     assert rc == 0 and len(tb) == 1
-    rc, tb = plan([1] * 40)                           # many 1-word captions: split by the caption cap
+    rc, tb, order = plan([1] * 40)                               # 1-word captions: the caption cap splits them
     assert rc == 0 and list(tb) == [0, 16, 32, 40]
 
 
 def test_scan_tile_planner_errors():
     lib = _lib.load()
-    rc, _ = plan([5, 0, 3])
+    rc, _, _ = plan([5, 0, 3])
     assert rc == -1 and b"length 0" in lib.itr_last_error()
     with pytest.raises(ValueError):
         _lib.check(rc)
-    rc, _ = plan([5, 65])
+    rc, _, _ = plan([5, 65])
     assert rc == -2
     with pytest.raises(NotImplementedError):
         _lib.check(rc)

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Ablations at 1 vs 2 workgroups per CU."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "image-text-retrieval_amd"))
+import numpy as np, torch
+from itr_amd import ops
+dev = torch.device("cuda:0")
+Ni = 1000
+Nc, D = 5 * Ni, 1024
+rng = np.random.RandomState(0)
+lens = rng.randint(6, 21, size=Nc)
+off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+n_rows = int(lens.sum())
+img = ops.l2norm(torch.randn(Ni, 36, D, device=dev))
+words = torch.randn(n_rows, D, device=dev) * 0.3
+plan = ops.ScanPlan(off, lens, n_rows, dev)
+ws = ops.scan_prepare(img, words, plan)
+flop = Ni * n_rows * (2 * 36 * D)
+for extra in (0, 4000):
+    os.environ["ITR_SCAN_LDS_EXTRA"] = str(extra)
+    for name, flag in (("full", 0), ("no_epilogue", 1), ("no_gload_no_epi", 3), ("no_mfma_no_epi", 5)):
+        os.environ["ITR_SCAN_DEBUG"] = str(flag)
+        for _ in range(2):
+            ops.scan_xattn_scores(img, words, plan, workspace=ws)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            ops.scan_xattn_scores(img, words, plan, workspace=ws)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        print("blocks/CU=%d %-18s %8.2f ms   %6.1f TF/s" % (2 if extra == 0 else 1, name, ms, flop / ms / 1e9))
+
+for extra in (0, 4000):
+    os.environ["ITR_SCAN_LDS_EXTRA"] = str(extra)
+    for flag in (16, 17):
+        os.environ["ITR_SCAN_DEBUG"] = str(flag)
+        out = torch.zeros(Ni, Nc + 64, device=dev)
+        ops.scan_xattn_scores(img, words, plan, workspace=ws, out=out)
+        torch.cuda.synchronize()
+        cyc = out.view(torch.int64).flatten()[:8].cpu().numpy()
+        nblocks = ((Ni + 3) // 4) * plan.n_tiles
+        print("blocks/CU=%d flag %d: cycles per workgroup: prologue %.0f  main %.0f  park %.0f  E1 %.0f  E2 %.0f" % (
+            2 if extra == 0 else 1, flag, cyc[4] / nblocks, cyc[0] / nblocks, cyc[1] / nblocks, cyc[2] / nblocks, cyc[3] / nblocks))
