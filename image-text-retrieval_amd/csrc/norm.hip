@@ -96,3 +96,42 @@ extern "C" int itr_l2norm_rows(const float *x, float *y, int64_t rows, int dim, 
     ITR_REQUIRE(rows < (int64_t)4 * 0x7fffffff, "itr_l2norm_rows: too many rows");
     return itr::norm_rows(x, y, rows, dim, eps, kind, take_abs, itr::as_stream(stream));
 }
+
+// ---- mean over the middle axis: y[b, :] = mean_r x[b, r, :]  (torch.mean(x, 1) on the path:
+// Fusionmodule.py:412 img_ave, :422 cap_ave; TextEncoder.py:191; ImgEncoder.py:348).  HBM-bound.
+namespace itr {
+__global__ __launch_bounds__(256) void mean_mid_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t B,
+                                                       int R, int F) {
+    const int64_t b = blockIdx.y;
+    const int f = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (f >= F) return;
+    const float *p = x + (b * R) * (int64_t)F + f;
+    if (f + 3 < F && (F & 3) == 0) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < R; ++r) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + (int64_t)r * F);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const float inv = (float)R;
+        *reinterpret_cast<float4 *>(y + b * F + f) = make_float4(s.x / inv, s.y / inv, s.z / inv, s.w / inv);
+    } else {
+        for (int u = 0; u < 4 && f + u < F; ++u) {
+            float s = 0.f;
+            for (int r = 0; r < R; ++r) s += p[(int64_t)r * F + u];
+            y[b * F + f + u] = s / (float)R;
+        }
+    }
+}
+}  // namespace itr
+
+extern "C" int itr_mean_mid(const float *x, float *y, int64_t B, int R, int F, itr_stream_t stream) {
+    ITR_REQUIRE(x && y, "itr_mean_mid: null pointer");
+    ITR_REQUIRE(B >= 0 && R >= 1 && F >= 1 && B <= 65535 * (int64_t)1024, "itr_mean_mid: bad shape");
+    ITR_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "itr_mean_mid: unaligned");
+    if (B == 0) return ITR_OK;
+    ITR_REQUIRE(B <= 65535, "itr_mean_mid: at most 65535 groups per call");
+    dim3 grid((unsigned)itr::ceil_div(itr::ceil_div(F, 4), 256), (unsigned)B);
+    hipLaunchKernelGGL(itr::mean_mid_kernel, grid, dim3(256), 0, itr::as_stream(stream), x, y, B, R, F);
+    ITR_CHECK_LAUNCH("mean_mid");
+    return ITR_OK;
+}

@@ -21,6 +21,7 @@ SIGNATURES = {
     "itr_last_error": (C.c_char_p, []),
     "itr_abi_version": (i32, []),
     "itr_l2norm_rows": (i32, [vp, vp, i64, i32, f32, i32, i32, vp]),
+    "itr_mean_mid": (i32, [vp, vp, i64, i32, i32, vp]),
     "itr_gemm_nt": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "itr_proj_l2norm": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "itr_gru_workspace_bytes": (sz, [i64, i64, i32, i32, i32]),

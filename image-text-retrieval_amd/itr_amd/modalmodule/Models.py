@@ -1,0 +1,129 @@
+"""Model wrappers with the reference's interface (itr/modalmodule/Models.py): attributes config, img_enc,
+txt_enc, sim_enc, criterion, Eiters, logger; methods forward_emb / forward_loss / val_start / train_start /
+state_dict / load_state_dict.  Towers and losses run on the HIP kernels.
+
+`train_emb` (backward through the towers + Adam) is SURVEY.md 8(f) item 3 and not built yet: the hinge
+loss has a HIP backward (dL/dS), the towers do not."""
+import torch
+from torch import nn
+
+from . import ImgEncoder, TextEncoder, Objectives
+
+
+class base_module(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.grad_clip = config.get('grad_clip', 2.)
+        self.Eiters = 0
+        self.img_enc = None
+        self.txt_enc = None
+        self.sim_enc = None
+        self.criterion = None
+        self.optimizer = None
+        self.params = None
+        self.logger = None
+
+    def calculate_params(self):
+        self.params_num = sum(p.numel() for p in self.params)
+
+    def state_dict(self):
+        """List layout of the reference (Models.py:37-40).  The reference stores the sim_enc MODULE as the third
+        entry; its state_dict is stored here, and load_state_dict accepts either."""
+        sd = [self.img_enc.state_dict(), self.txt_enc.state_dict()]
+        if self.sim_enc is not None:
+            sd.append(self.sim_enc.state_dict())
+        return sd
+
+    def load_state_dict(self, state_dict):
+        self.img_enc.load_state_dict(state_dict[0])
+        self.txt_enc.load_state_dict(state_dict[1])
+        if self.sim_enc is not None:
+            third = state_dict[2]
+            self.sim_enc.load_state_dict(third.state_dict() if isinstance(third, nn.Module) else third)
+
+    def train_start(self):
+        self.img_enc.train()
+        self.txt_enc.train()
+        if self.sim_enc is not None:
+            self.sim_enc.train()
+
+    def val_start(self):
+        self.img_enc.eval()
+        self.txt_enc.eval()
+        if self.sim_enc is not None:
+            self.sim_enc.eval()
+
+    def _log(self, k, v, n=0):
+        if self.logger is not None:
+            self.logger.update(k, v, n)
+
+    def train_emb(self, train_data, *a, **k):
+        raise NotImplementedError("train_emb needs backward kernels for the towers (SURVEY.md 8f-3); "
+                                  "forward_emb / forward_loss are available")
+
+    @staticmethod
+    def _dev(t):
+        return t.cuda() if torch.is_tensor(t) and not t.is_cuda else t
+
+
+class VSE_PP(base_module):
+    """VSE++ (Models.py:63-145) with the build decisions of SURVEY Q3 for *_precomp data: mean-pooled regions
+    -> fc -> l2norm; text = last valid GRU state -> l2norm; honours bi_gru."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        if not config['data_name'].endswith('_precomp'):
+            raise NotImplementedError("raw-image VSE++ (EncoderImageFull: torchvision CNN) is out of scope")
+        self.img_enc = ImgEncoder.EncoderImagePooledPrecomp(config['img_dim'], config['embed_size'],
+                                                            no_imgnorm=config['no_imgnorm'],
+                                                            precomp_enc_type='basic', use_abs=config['use_abs'])
+        self.txt_enc = TextEncoder.EncoderText(config['vocab_size'], config['word_dim'], config['embed_size'],
+                                               config['num_layers'], use_bi_gru=config.get('bi_gru', False),
+                                               use_abs=config['use_abs'], no_txtnorm=False, method_name='VSE++')
+        self.img_enc.cuda()
+        self.txt_enc.cuda()
+        self.criterion = Objectives.ContrastiveLoss(config=config, margin=config['margin'],
+                                                    max_violation=config['max_violation'], measure=config['measure'])
+        self.params = list(self.txt_enc.parameters()) + list(self.img_enc.fc.parameters())
+        self.calculate_params()
+
+    def forward_emb(self, images, captions, lengths, *args, **kwargs):
+        img_emb = self.img_enc(self._dev(images))
+        cap_emb, _ = self.txt_enc(self._dev(captions), lengths)
+        return img_emb, cap_emb
+
+    def forward_loss(self, img_emb, cap_emb):
+        loss = self.criterion(img_emb, cap_emb)
+        self._log('Loss', loss.data, img_emb.size(0))
+        return loss
+
+
+class SCAN(base_module):
+    """Stacked Cross Attention Network (Models.py:148-225)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.img_enc = ImgEncoder.EncoderImagePrecomp(config['img_dim'], config['embed_size'],
+                                                      precomp_enc_type=config['precomp_enc_type'],
+                                                      no_imgnorm=config['no_imgnorm'])
+        self.txt_enc = TextEncoder.EncoderText(config['vocab_size'], config['word_dim'], config['embed_size'],
+                                               config['num_layers'], use_bi_gru=config['bi_gru'],
+                                               no_txtnorm=config['no_txtnorm'])
+        self.img_enc.cuda()
+        self.txt_enc.cuda()
+        self.criterion = Objectives.ContrastiveLoss(config=config, margin=config['margin'],
+                                                    measure=config['measure'],
+                                                    max_violation=config['max_violation'])
+        self.params = list(self.txt_enc.parameters()) + list(self.img_enc.fc.parameters())
+        self.calculate_params()
+
+    def forward_emb(self, images, captions, lengths, *args, **kwargs):
+        img_emb = self.img_enc(self._dev(images))
+        cap_emb, cap_lens = self.txt_enc(self._dev(captions), lengths)
+        return img_emb, cap_emb, cap_lens
+
+    def forward_loss(self, img_emb, cap_emb, cap_lens):
+        loss = self.criterion(img_emb, cap_emb, cap_lens)
+        self._log('Loss', loss.data, img_emb.size(0))
+        return loss

@@ -1,0 +1,93 @@
+"""Similarity measures and ranking losses with the reference's names and signatures
+(itr/modalmodule/Objectives.py), computed by the HIP kernels."""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def cosine_similarity(x1, x2, dim=1, eps=1e-8):
+    """w12 / clamp(|x1||x2|, min=eps) along `dim` (Objectives.py:10-15).  Small glue op kept for API parity;
+    the SCAN kernel evaluates this expression in its epilogue."""
+    w12 = torch.sum(x1 * x2, dim)
+    w1 = torch.norm(x1, 2, dim)
+    w2 = torch.norm(x2, 2, dim)
+    return (w12 / (w1 * w2).clamp(min=eps)).squeeze()
+
+
+def cosine_sim(im, s, *args):
+    """Cosine similarity between all image / sentence pairs (Objectives.py:18-21)."""
+    return ops.cosine_scores(im, s)
+
+
+def order_sim(im, s, *args):
+    raise NotImplementedError("measure='order' (Objectives.py:24-30) is not on the BASELINE path; see DESIGN.md")
+
+
+def pdist_cos(x1, x2, *args):
+    """SAEM cosine (Objectives.py:310-323)."""
+    return ops.pdist_cos(x1, x2)
+
+
+def _xattn(images, captions, cap_lens, config, cross_attn):
+    return ops.scan_xattn_padded(images, captions, cap_lens, cross_attn=cross_attn,
+                                 raw_feature_norm=config['raw_feature_norm'], agg_func=config['agg_func'],
+                                 lambda_lse=config['lambda_lse'], lambda_softmax=config['lambda_softmax'])
+
+
+def xattn_score_t2i(images, captions, cap_lens, config):
+    """(n_image, n_regions, d), (n_caption, max_n_word, d), lengths -> (n_image, n_caption)
+    (Objectives.py:329-372)."""
+    return _xattn(images, captions, cap_lens, config, 't2i')
+
+
+def xattn_score_i2t(images, captions, cap_lens, config):
+    """Objectives.py:376-417."""
+    return _xattn(images, captions, cap_lens, config, 'i2t')
+
+
+class ContrastiveLoss(nn.Module):
+    """Bidirectional hinge loss, optionally with hardest negatives (Objectives.py:34-115).
+    `self.sim` is dispatched on config['name'] exactly like the reference (:45-74)."""
+
+    def __init__(self, config, margin=0, measure=None, max_violation=False):
+        super().__init__()
+        self.config = config
+        self.margin = margin
+        self.max_violation = max_violation
+        if measure == 'order':
+            self.sim = order_sim
+        elif measure == 'cosine':
+            self.sim = cosine_sim
+        else:
+            raise ValueError("unknown measure:", measure)
+        if self.config['name'] == 'SAEM':
+            if measure == 'cosine':
+                self.sim = pdist_cos
+            else:
+                raise NotImplementedError("SAEM pdist (order) is not on the BASELINE path")
+        elif self.config['name'] == 'SCAN':
+            if self.config['cross_attn'] == 't2i':
+                self.sim = xattn_score_t2i
+            elif self.config['cross_attn'] == 'i2t':
+                self.sim = xattn_score_i2t
+            else:
+                raise ValueError("unknown first norm type:", self.config['raw_feature_norm'])
+        elif self.config['name'] == 'SGRAF':
+            self.sim = lambda x, y, m, n: x
+
+    def forward(self, im, s=None, s_l=None):
+        scores = self.sim(im, s, s_l, self.config)
+        return ops.hinge_loss(scores, self.margin, self.max_violation)
+
+
+class TripletLoss(nn.Module):
+    """CAMERA's loss on a given score matrix (Objectives.py:482-517)."""
+
+    def __init__(self, margin=0, max_violation=False):
+        super().__init__()
+        self.margin = margin
+        self.max_violation = max_violation
+
+    def forward(self, scores):
+        return ops.hinge_loss(scores, self.margin, self.max_violation)

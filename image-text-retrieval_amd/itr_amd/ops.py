@@ -67,6 +67,18 @@ def _norm(x, dim, eps, kind, take_abs=False):
     return y.movedim(-1, dim).contiguous() if moved else y
 
 
+def mean_mid(x):
+    """torch.mean(x, 1) for x (B, R, F)."""
+    lib = _lib.load()
+    x = _dev(x, name="x")
+    B, R, F_ = x.shape
+    y = torch.empty(B, F_, device=x.device, dtype=torch.float32)
+    for b0 in range(0, B, 65535):
+        b1 = min(B, b0 + 65535)
+        _lib.check(lib.itr_mean_mid(_p(x[b0:b1]), _p(y[b0:b1]), b1 - b0, R, F_, _stream()))
+    return y
+
+
 def linear(x, weight, bias=None, act=None):
     """act(x @ weight^T + bias) on the fp32 MFMA GEMM.  x (..., K), weight (N, K)."""
     lib = _lib.load()

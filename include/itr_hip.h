@@ -46,6 +46,10 @@ int itr_abi_version(void);
 int itr_l2norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, int kind,
                     int take_abs, itr_stream_t stream);
 
+/* y[b,:] = mean_r x[b,r,:] for x [B,R,F]  (torch.mean(x, 1): Fusionmodule.py:412,422; TextEncoder.py:191;
+ * ImgEncoder.py:348; the VSE++ region pooling of SURVEY Q3). */
+int itr_mean_mid(const float *x, float *y, int64_t B, int R, int F, itr_stream_t stream);
+
 /* ---- generic fp32 MFMA GEMM used by the towers ----------------------------------------
  * C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]);  lda/ldb/ldc are row strides in elements.
  * bias may be NULL.  act: 0 none, 1 relu, 2 tanh, 3 sigmoid, 4 gelu(erf), 5 leaky_relu(0.1).

@@ -1,0 +1,143 @@
+"""GPU: the reference's Python seams (get_model / forward_emb / forward_loss / encode_data / cal_sims / i2t / t2i)
+re-implemented on the HIP kernels, checked against golden vectors captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+import itr_oracle as O
+from itr_amd import config as C
+from itr_amd.modalmodule import get_model
+from itr_amd.metricmodule import evaluation
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+class FakeLoader:
+    """The collate_fn 8-tuple (data_loader.py:178), batches sorted by caption length."""
+
+    def __init__(self, images, token_ids, lengths, batch):
+        n = len(lengths)
+        self.dataset = list(range(n))
+        self.batches = []
+        for b0 in range(0, n, batch):
+            idx = sorted(range(b0, min(b0 + batch, n)), key=lambda i: -lengths[i])
+            lens = [lengths[i] for i in idx]
+            tok = torch.zeros(len(idx), max(lens), dtype=torch.long)
+            for r, i in enumerate(idx):
+                tok[r, :lengths[i]] = token_ids[i][:lengths[i]]
+            self.batches.append((images[idx], None, None, tok, lens, idx, None, None))
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def scan_model_from_golden(g):
+    cfg = C.build_config(['with', 'SCAN', 'bi_gru=True', 'data_name=coco_precomp'])
+    cfg.update(img_dim=48, embed_size=32, word_dim=16, vocab_size=50)
+    model = get_model(cfg)
+    wi = {k[5:]: T(g[k]) for k in g.files if k.startswith("wimg_")}
+    wt = {k[5:]: T(g[k]) for k in g.files if k.startswith("wtxt_")}
+    model.load_state_dict([wi, wt])
+    return model
+
+
+def test_scan_harness_golden(golden, dev):
+    g = golden("g11_harness_scan")
+    model = scan_model_from_golden(g)
+    feats = T(g["features"])
+    lengths = [int(x) for x in g["lengths"]]
+    loader = FakeLoader(feats.repeat_interleave(5, 0), T(g["token_ids"]), lengths, 32)
+    img_embs, cap_embs, cap_lens = evaluation.encode_data(model, loader, islength=True)
+    assert img_embs.shape == (200, 36, 32) and cap_embs.shape == g["cap_embs"].shape
+    assert np.abs(img_embs[::5] - g["img_embs"]).max() <= 2e-6
+    assert np.abs(cap_embs - g["cap_embs"]).max() <= 5e-6
+    assert (cap_lens == g["cap_lens"]).all()
+    img_u = img_embs[::5]
+    sims = evaluation.cal_sims(model, img_u, cap_embs, cap_lens, shard_size=10 ** 9)
+    assert sims.dtype == np.float64 and np.abs(sims - g["sims"]).max() <= 2e-5
+    sims_sh = evaluation.cal_sims(model, img_u, cap_embs, cap_lens, shard_size=100)       # sliced lengths
+    assert np.abs(sims_sh - g["sims"]).max() <= 2e-5
+    sims_q1 = evaluation.cal_sims(model, img_u, cap_embs, cap_lens, shard_size=100, ref_quirk_unsliced_lengths=True)
+    assert np.abs(sims_q1 - g["sims_q1_shard100"]).max() <= 2e-5
+    # ranks on the reference's own matrix: bit-exact
+    (ri, (ranks_i, top_i)) = evaluation.i2t(g["sims"], True)
+    (rt, (ranks_t, top_t)) = evaluation.t2i(g["sims"], True)
+    assert ri == pytest.approx(tuple(g["i2t"])) and rt == pytest.approx(tuple(g["t2i"]))
+    assert (ranks_i == g["i2t_ranks"]).all() and (ranks_t == g["t2i_ranks"]).all()
+    assert (top_i == g["i2t_top1"]).all() and (top_t == g["t2i_top1"]).all()
+    # Recall@K of the HIP-scored matrix within +-0.1 of the reference (north_star)
+    res = evaluation.cal_recall(sims)
+    for k, want in zip(("i2t_r1", "i2t_r5", "i2t_r10"), g["i2t"][:3]):
+        assert abs(res[k] - want) <= 0.1 + 1e-9
+    for k, want in zip(("t2i_r1", "t2i_r5", "t2i_r10"), g["t2i"][:3]):
+        assert abs(res[k] - want) <= 0.1 + 1e-9
+
+
+def test_scan_forward_loss_vs_oracle(golden, dev):
+    g = golden("g11_harness_scan")
+    model = scan_model_from_golden(g)
+    model.val_start()
+    lengths = [int(x) for x in g["lengths"]]
+    idx = sorted(range(24), key=lambda i: -lengths[i])
+    lens = [lengths[i] for i in idx]
+    tok = torch.zeros(24, max(lens), dtype=torch.long)
+    for r, i in enumerate(idx):
+        tok[r, :lengths[i]] = T(g["token_ids"])[i][:lengths[i]]
+    feats = T(g["features"])[:24]
+    img_emb, cap_emb, cap_lens = model.forward_emb(feats, tok, lens)
+    loss = model.forward_loss(img_emb, cap_emb, cap_lens)
+    wi = {k[5:]: T(g[k]) for k in g.files if k.startswith("wimg_")}
+    wt = {k[5:]: T(g[k]) for k in g.files if k.startswith("wtxt_")}
+    o_img = O.encoder_image_precomp(feats, wi["fc.weight"], wi["fc.bias"])
+    o_cap, _ = O.encoder_text(tok, lens, wt, True, True, False, None)
+    o_S = O.xattn_score(o_img, o_cap, lens)
+    o_loss = O.hinge_loss(o_S, 0.2, False)
+    assert abs(float(loss.detach()) - float(o_loss)) <= 1e-4 * max(1.0, float(o_loss))
+
+
+def test_vsepp_cfg1_toy_batch(golden, dev):
+    """BASELINE config 1 shape: 128-pair batch, bi-GRU text, pooled precomp regions, hinge with hardest negatives."""
+    rng = np.random.RandomState(0)
+    torch.manual_seed(0)
+    cfg = C.build_config(['with', 'VSE_PP', 'data_name=coco_precomp', 'max_violation=True', 'bi_gru=True'])
+    cfg.update(img_dim=256, embed_size=128, word_dim=32, vocab_size=300)
+    model = get_model(cfg)
+    model.val_start()
+    B = 128
+    lens = sorted([int(x) for x in rng.randint(3, 15, size=B)], reverse=True)
+    tok = torch.zeros(B, max(lens), dtype=torch.long)
+    for r, l in enumerate(lens):
+        tok[r, :l] = torch.from_numpy(rng.randint(4, 300, size=l))
+    feats = O.l2norm(torch.randn(B, 36, 256), -1)
+    img_emb, cap_emb = model.forward_emb(feats, tok, lens)
+    assert img_emb.shape == (B, 128) and cap_emb.shape == (B, 128)
+    loss = model.forward_loss(img_emb, cap_emb)
+    wi = {k: v.detach().cpu() for k, v in model.img_enc.state_dict().items()}
+    wt = {k: v.detach().cpu() for k, v in model.txt_enc.state_dict().items()}
+    o_img = O.encoder_image_precomp(feats.mean(1), wi["fc.weight"], wi["fc.bias"])
+    o_cap, _ = O.encoder_text(tok, lens, wt, True, False, False, 'VSE++')
+    assert float((img_emb.cpu() - o_img).abs().max()) <= 2e-6
+    assert float((cap_emb.cpu() - o_cap).abs().max()) <= 5e-6
+    o_loss = O.hinge_loss(O.cosine_sim(o_img, o_cap), 0.2, True)
+    assert abs(float(loss.detach()) - float(o_loss)) <= 1e-4
+
+
+def test_get_model_errors(dev):
+    with pytest.raises(KeyError):
+        get_model({'name': 'nope'})
+    with pytest.raises(NotImplementedError):
+        get_model({'name': 'VSRN'})
+
+
+def test_state_dict_round_trip(golden, dev):
+    g = golden("g11_harness_scan")
+    m1 = scan_model_from_golden(g)
+    sd = m1.state_dict()
+    assert isinstance(sd, list) and len(sd) == 2 and 'fc.weight' in sd[0] and 'rnn.weight_ih_l0_reverse' in sd[1]
+    m2 = scan_model_from_golden(g)
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.img_enc.fc.weight, m1.img_enc.fc.weight)
