@@ -97,6 +97,22 @@ def cpu_baseline(wl, wi, wt, feats_cpu, lengths, tokens, n_img_s, seconds_cap=60
                        % (n_img_s, n_cap_s, dt)), S, ranks
 
 
+def pmc_traffic(workload, world):
+    """HBM bytes per launch of the dominant kernel as measured by the committed rocprofv3 PMC passes
+    (profiles/rNN/scan_pmc.json; FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md).  bench.py cannot collect
+    PMC counters itself; null when no matching profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "scan_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("n_gpus") == world:
+            best = d
+    return (best["hbm_bytes_per_launch"], best["source"]) if best else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,7 +207,9 @@ def main():
                        "t2i_r10": t2i[2]},
             "roofline": {"kernel": "scan_xattn_kernel", "bound": "mfma", "achieved": alg_flop / (k_ms * 1e-3) / 1e12,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": alg_flop / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": alg_flop / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": pmc_traffic(args.workload, world)[0],
+                         "traffic_source": pmc_traffic(args.workload, world)[1],
                          "kernel_ms": k_ms, "algorithmic_flop_per_launch": alg_flop,
                          "executed_flop_per_launch": exe_flop,
                          "executed_tflops": exe_flop / (k_ms * 1e-3) / 1e12,
