@@ -37,7 +37,25 @@ WORKLOADS = {
                             lambda_softmax=9.0, raw_feature_norm="clipped_l2norm"),
     "scan_i2t_coco5k": dict(n_img=5000, vocab=11353, cross_attn="i2t", agg_func="LogSumExp", lambda_lse=20.0,
                             lambda_softmax=4.0, raw_feature_norm="clipped_l2norm"),
+    # BASELINE.json configs[4]: SGRAF (EncoderSimilarity), sim_dim 256, l2-normalised bi-GRU words
+    "sgraf_saf_coco5k": dict(n_img=5000, vocab=11353, sgraf="SAF"),
+    "sgraf_sgr_coco5k": dict(n_img=5000, vocab=11353, sgraf="SGR"),
+    "sgraf_saf_f30k1k": dict(n_img=1000, vocab=8481, sgraf="SAF"),
+    "sgraf_sgr_f30k1k": dict(n_img=1000, vocab=8481, sgraf="SGR"),
 }
+
+
+def make_sgraf_weights(module_name, D=1024, S=256, sgr_step=3, seed=0):
+    """EncoderSimilarity with the reference's initialisation (Xavier linears) and non-trivial BatchNorm running
+    statistics (mean N(0, 0.1), var U(0.5, 1.5))."""
+    from itr_amd.modalmodule import Fusionmodule
+    torch.manual_seed(seed + 7)
+    enc = Fusionmodule.EncoderSimilarity(D, S, module_name, sgr_step)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    return {k: v.detach().clone() for k, v in enc.state_dict().items() if "num_batches_tracked" not in k}
 
 
 def make_weights(vocab, F_=2048, D=1024, E=300, seed=0):
@@ -88,8 +106,11 @@ def cpu_baseline(wl, wi, wt, feats_cpu, lengths, tokens, n_img_s, seconds_cap=60
         cap_sorted, _ = O.encoder_text(ids, lens_sorted, wt, True, True, False, None)
         cap = torch.zeros_like(cap_sorted)
         cap[torch.as_tensor(order)] = cap_sorted
-        S = O.xattn_score(img, cap, [int(x) for x in lens], wl["cross_attn"], wl["raw_feature_norm"], wl["agg_func"],
-                          wl["lambda_lse"], wl["lambda_softmax"])
+        if "sgraf" in wl:
+            S = O.sgraf_similarity(wl["_sim_weights"], img, O.l2norm(cap, -1), [int(x) for x in lens], wl["sgraf"], 3)
+        else:
+            S = O.xattn_score(img, cap, [int(x) for x in lens], wl["cross_attn"], wl["raw_feature_norm"],
+                              wl["agg_func"], wl["lambda_lse"], wl["lambda_softmax"])
         ranks = O.rank_counts(S.numpy())
         dt = time.time() - t0
     return dict(value=n_img_s * n_cap_s / dt, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
@@ -137,7 +158,14 @@ def main():
     wl = WORKLOADS[args.workload]
     n_img, n_cap = wl["n_img"], 5 * wl["n_img"]
     F_, D, R = 2048, 1024, 36
-    cfg = dict(wl, bi_gru=True, no_txtnorm=True, no_imgnorm=False)
+    is_sgraf = "sgraf" in wl
+    cfg = dict(wl, bi_gru=True, no_txtnorm=not is_sgraf, no_imgnorm=False)
+    sim_w = None
+    if is_sgraf:
+        cfg.update(module_name=wl["sgraf"], sgr_step=3)
+        sim_w_cpu = make_sgraf_weights(wl["sgraf"])
+        sim_w = {k: v.to(dev) for k, v in sim_w_cpu.items()}
+        wl = dict(wl, _sim_weights=sim_w_cpu)
 
     # ---- synthetic inputs (seeded; identical on every rank, each rank keeps its shard in HBM)
     wi, wt = make_weights(wl["vocab"])
@@ -159,7 +187,7 @@ def main():
     timers = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
 
     def step(tm=None):
-        return model.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm)
+        return model.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm, sgraf_weights=sim_w)
 
     def barrier():
         if world > 1:
@@ -191,6 +219,19 @@ def main():
         # executed by this design: raw dot products only (2*36*W*D) + the 36x36 quadratic form per (image, word)
         exe_flop = float(i1 - i0) * n_words * (2 * 36 * D + 36 * 37)
         k_ms = float(np.mean(scan_ms))
+        model_name = "SCAN %s %s bi-GRU" % (wl.get("cross_attn"), wl.get("agg_func"))
+        kernel_name, note = "scan_xattn_kernel", ("achieved uses SURVEY 8d's algorithmic (4*36+6)*W*D flop/pair; the kernel "
+                                                  "executes about half of it (Gram-matrix identity, DESIGN.md)")
+        if is_sgraf:
+            # 4*36*W*D + 2*W*D*s + 2*D*s + T*(6*(W+1)*s^2 + 4*(W+1)^2*s) + 2s per pair (T = 0 for SAF)
+            s_, T_ = 256, (3 if wl["sgraf"] == "SGR" else 0)
+            W_ = lengths.astype(np.float64)
+            per_img = (4 * 36 * W_ * D + 2 * W_ * D * s_ + 2 * D * s_ + T_ * (6 * (W_ + 1) * s_ ** 2 + 4 * (W_ + 1) ** 2 * s_) + 2 * s_).sum()
+            alg_flop = float(i1 - i0) * per_img
+            exe_flop = alg_flop
+            model_name = "SGRAF-%s bi-GRU" % wl["sgraf"]
+            kernel_name = "sgraf pair stage (scan_xattn_kernel emit + gemm_nt chain + pair kernels)"
+            note = "time = the whole itr_sgraf_scores call (global nodes + per-4-image pair stage); flop = SURVEY 8d K8"
         from itr_amd import ops as _ops
         i2t = _ops.recall_from_ranks(ranks[0])
         t2i = _ops.recall_from_ranks(ranks[2])
@@ -199,13 +240,13 @@ def main():
             "value": pairs / (dt / args.steps), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "model": "SCAN %s %s bi-GRU" % (wl["cross_attn"], wl["agg_func"]),
+            "config": {"workload": args.workload, "model": model_name,
                        "n_img": n_img, "n_cap": n_cap, "regions": R, "feat_dim": F_, "embed": D,
                        "n_words": n_words, "parallelism": "row-shard x%d + 1 all-gather" % world,
                        "step": "encode(img proj + bi-GRU) + score + rank(i2t,t2i)"},
             "recall": {"i2t_r1": i2t[0], "i2t_r5": i2t[1], "i2t_r10": i2t[2], "t2i_r1": t2i[0], "t2i_r5": t2i[1],
                        "t2i_r10": t2i[2]},
-            "roofline": {"kernel": "scan_xattn_kernel", "bound": "mfma", "achieved": alg_flop / (k_ms * 1e-3) / 1e12,
+            "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": alg_flop / (k_ms * 1e-3) / 1e12,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": alg_flop / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic(args.workload, world)[0],
@@ -214,8 +255,7 @@ def main():
                          "executed_flop_per_launch": exe_flop,
                          "executed_tflops": exe_flop / (k_ms * 1e-3) / 1e12,
                          "executed_frac": exe_flop / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                         "note": "achieved uses SURVEY 8d's algorithmic (4*36+6)*W*D flop/pair; the kernel "
-                                 "executes about half of it (Gram-matrix identity, DESIGN.md)"},
+                         "note": note},
         }
         if world == 1 and not args.no_cpu_baseline:
             base, S_cpu, ranks_cpu = cpu_baseline(wl, wi, wt, feats_head, lengths, tokens, args.cpu_sample_images)

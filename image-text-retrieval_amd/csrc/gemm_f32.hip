@@ -32,6 +32,11 @@ struct GemmArgs {
     int act;
     int group;       // 1 = plain GEMM; >1 = max over `group` consecutive rows of A*B^T
     int rows_per_tile;  // BM, or (BM / group) * group
+    // optional "squared difference" epilogue (SGRAF, Fusionmodule.py:426-427: (Context_img - cap_i)^2 with the
+    // l2norm of the context folded in as a per-row scale):  C = (acc * rowscale[m] - Z[m, n])^2
+    const float *rowscale;
+    const float *Z;
+    int64_t ldz;
 };
 
 template <bool ALIGNED>
@@ -152,7 +157,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < m_end) g.C[row * g.ldc + col] = apply_act(acc[i][j][r] + bv, g.act);
+                    if (row < m_end) {
+                        float v = acc[i][j][r];
+                        if (g.Z) {
+                            v = v * g.rowscale[row] - g.Z[row * g.ldz + col];
+                            v = v * v;
+                        } else {
+                            v = apply_act(v + bv, g.act);
+                        }
+                        g.C[row * g.ldc + col] = v;
+                    }
                 }
             }
     } else {
@@ -205,13 +219,19 @@ static int launch_gemm(const GemmArgs &g, hipStream_t st) {
 
 int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
-    GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM};
+    GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0};
+    return launch_gemm(g, st);
+}
+
+int gemm_nt_sqdiff(const float *A, int64_t lda, const float *B, int64_t ldb, const float *rowscale, const float *Z,
+                   int64_t ldz, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, M, N, K, 0, 1, BM, rowscale, Z, ldz};
     return launch_gemm(g, st);
 }
 
 int gemm_nt_groupmax(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                      int64_t Mgroups, int group, int64_t N, int64_t K, hipStream_t st) {
-    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, Mgroups * group, N, K, 0, group, (BM / group) * group};
+    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, Mgroups * group, N, K, 0, group, (BM / group) * group, nullptr, nullptr, 0};
     return launch_gemm(g, st);
 }
 

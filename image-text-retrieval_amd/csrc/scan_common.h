@@ -1,0 +1,41 @@
+// Definitions shared by the SCAN (scan_xattn.hip) and SGRAF (sgraf.hip) kernels.
+#pragma once
+#include "itr_common.h"
+
+namespace itr {
+
+constexpr int SC_R = 36;                 // regions per image (precomp bottom-up features)
+constexpr int SC_IMGS = 4;               // images per workgroup
+constexpr int SC_MT = SC_IMGS * SC_R;    // 144 rows = 9 x 16
+constexpr int SC_MTILES = SC_MT / 16;    // 9
+constexpr int SC_NT = ITR_SCAN_NT;       // 64 word columns = 4 waves x 16
+constexpr int SC_ROWS = SC_MT + SC_NT + 16;  // 208 staged rows per K chunk + 16 dump rows (224 = 7*256/8)
+constexpr int SC_BK = 32, SC_PLANES = 8;
+constexpr int SC_THREADS = 256;
+constexpr int SC_MAXCAP = 16;            // captions per column tile (planner guarantees it)
+constexpr int SC_LDT = SC_MT + 4;        // 148: row stride of the parked block, stored TRANSPOSED [col][row]
+
+// Per column tile: which captions it holds and where (built on the device by scan_pack_kernel).
+struct alignas(16) ScanTileMeta {
+    int32_t ncap;
+    int32_t cap_id[SC_MAXCAP];
+    int32_t cap_start[SC_MAXCAP + 1];
+    int8_t col_cap[SC_NT];       // caption slot of each column, -1 = padding
+    int32_t pad_[64 - 1 - SC_MAXCAP - (SC_MAXCAP + 1) - SC_NT / 4];
+};
+static_assert(sizeof(ScanTileMeta) == 256, "one 256-byte record per tile");
+
+__device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.1f * v); }   // LeakyReLU(0.1)
+// exp via v_exp_f32 (2^x): 2 VALU instructions instead of ~12; relative error ~|x| * 1e-7, far inside the
+// parity budget for the softmax / LogSumExp arguments here (|x| <= ~10).
+__device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+
+#define SC_TICK(slot)                                                                              \
+    if (g.dbg_cycles && tid == 0) {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                              \
+        atomicAdd(&g.dbg_cycles[slot], now_ - tick_);                                              \
+        tick_ = now_;                                                                              \
+    }
+
+
+}  // namespace itr

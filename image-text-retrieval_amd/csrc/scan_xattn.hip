@@ -30,30 +30,9 @@
 #include <stdlib.h>
 #include <vector>
 
-#include "itr_common.h"
+#include "scan_common.h"
 
 namespace itr {
-
-constexpr int SC_R = 36;                 // regions per image (precomp bottom-up features)
-constexpr int SC_IMGS = 4;               // images per workgroup
-constexpr int SC_MT = SC_IMGS * SC_R;    // 144 rows = 9 x 16
-constexpr int SC_MTILES = SC_MT / 16;    // 9
-constexpr int SC_NT = ITR_SCAN_NT;       // 64 word columns = 4 waves x 16
-constexpr int SC_ROWS = SC_MT + SC_NT + 16;  // 208 staged rows per K chunk + 16 dump rows (224 = 7*256/8)
-constexpr int SC_BK = 32, SC_PLANES = 8;
-constexpr int SC_THREADS = 256;
-constexpr int SC_MAXCAP = 16;            // captions per column tile (planner guarantees it)
-constexpr int SC_LDT = SC_MT + 4;        // 148: row stride of the parked block, stored TRANSPOSED [col][row]
-
-// Per column tile: which captions it holds and where (built on the device by scan_pack_kernel).
-struct alignas(16) ScanTileMeta {
-    int32_t ncap;
-    int32_t cap_id[SC_MAXCAP];
-    int32_t cap_start[SC_MAXCAP + 1];
-    int8_t col_cap[SC_NT];       // caption slot of each column, -1 = padding
-    int32_t pad_[64 - 1 - SC_MAXCAP - (SC_MAXCAP + 1) - SC_NT / 4];
-};
-static_assert(sizeof(ScanTileMeta) == 256, "one 256-byte record per tile");
 
 struct ScanArgs {
     const float *img;        // [Ni, 36, D]
@@ -70,6 +49,8 @@ struct ScanArgs {
     int D;
     int mode, norm, agg;
     float lambda_softmax, lambda_lse;
+    float *emit_p;    // [Ni, n_tiles*64, 36] normalised attention weights (SGRAF: SCAN_attention), or null
+    float *emit_cn;   // [Ni, n_tiles*64]     1 / (||ctx|| + eps)
     int debug;  // ablation switches for tools/scan_ablate.py (env ITR_SCAN_DEBUG); 0 in production
     unsigned long long *dbg_cycles;  // [8] phase cycle sums (debug & 16), normally null
 };
@@ -87,11 +68,6 @@ struct ScanSmem {
     float rowsim[SC_IMGS][SC_NT];             //  1,024 B   t2i: per (image, word) similarity term
     ScanTileMeta meta;                        //    256 B
 };
-
-__device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.1f * v); }   // LeakyReLU(0.1)
-// exp via v_exp_f32 (2^x): 2 VALU instructions instead of ~12; relative error ~|x| * 1e-7, far inside the
-// parity budget for the softmax / LogSumExp arguments here (|x| <= ~10).
-__device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
 
 // value of the normalised attention logit b (before * lambda_softmax) from the raw a and the
 // statistics of its normalisation group (Objectives.py:436-457)
@@ -132,13 +108,6 @@ struct NormAcc {
     }
 };
 
-#define SC_TICK(slot)                                                                              \
-    if (g.dbg_cycles && tid == 0) {                                                                \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                              \
-        atomicAdd(&g.dbg_cycles[slot], now_ - tick_);                                              \
-        tick_ = now_;                                                                              \
-    }
-
 __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ScanSmem &sm = *reinterpret_cast<ScanSmem *>(smem_raw);
@@ -165,170 +134,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
     // ---- tile metadata: needed by the epilogue only, so its load overlaps the main loop
     if (tid < 64) reinterpret_cast<int32_t *>(&sm.meta)[tid] = reinterpret_cast<const int32_t *>(g.meta + ct)[tid];
 
-    // ---- main loop: raw dot products A[144 x 64] over K = D ------------------------------
-    // On gfx950 the fp32 MFMA shares the vector ALU with ordinary VALU work (tools/ubench: an MFMA wave and
-    // a VALU wave on one SIMD take the SUM of their times), so every VALU instruction in this loop is paid
-    // in matrix throughput.  All addressing is therefore loop-invariant:
-    //   * global loads use  uniform 64-bit base (SGPR, advanced by a scalar add per chunk) + per-lane 32-bit
-    //     byte offset (VGPR, fixed);  7 passes per chunk, each homogeneous in its base:
-    //       A0..A3: image rows 0..127 | A4: rows 128..143 (waves 0,1; waves 2,3 re-load row 0 into the 16
-    //       dump rows) | B0,B1: the 64 word columns of this tile;
-    //   * LDS stores / fragment reads use a per-lane byte address (VGPR, fixed) + immediate offset (buffer,
-    //     row tile): (m*16 + fi) ^ p == m*16 + (fi ^ p) because p < 8.
-    // Rows that do not exist (image tail) re-read row 0: their outputs are never consumed.
-    const int nk = g.D / SC_BK;  // D % 32 == 0 is checked on the host
-    const int fi = lane & 15, fg = lane >> 4;
-    const unsigned rowbytes = (unsigned)g.D * 4u;
-    const int64_t n_img_rows = g.Ni * SC_R;
-    const char *abase = reinterpret_cast<const char *>(g.img) + img0 * SC_R * (int64_t)rowbytes;
-    const char *bbase = reinterpret_cast<const char *>(g.wtiled) + ct * SC_NT * (int64_t)rowbytes;
-    unsigned va0, va1, va2, va3, va4, vb0, vb1;       // per-lane global byte offsets
-    unsigned la0, la1, la2, la3, la4, lb0, lb1;       // per-lane LDS byte addresses (buffer 0)
-    {
-        const int p = tid & 7, r8 = tid >> 3;          // 32 rows per pass
-        auto a_off = [&](int row) -> unsigned {
-            const bool ok = img0 * SC_R + row < n_img_rows;
-            return (ok ? (unsigned)row : 0u) * rowbytes + p * 16u;
-        };
-        auto l_off = [&](int row) -> unsigned { return (unsigned)(p * SC_ROWS + (row ^ p)) * 16u; };
-        va0 = a_off(r8); va1 = a_off(r8 + 32); va2 = a_off(r8 + 64); va3 = a_off(r8 + 96);
-        la0 = l_off(r8); la1 = l_off(r8 + 32); la2 = l_off(r8 + 64); la3 = l_off(r8 + 96);
-        const int r4 = (tid & 127) >> 3;                // 16 rows in the fifth A pass
-        if (wave < 2) { va4 = a_off(128 + r4); la4 = l_off(128 + r4); }
-        else          { va4 = p * 16u;          la4 = l_off(SC_MT + SC_NT + r4); }   // dump rows 208..223
-        vb0 = (unsigned)r8 * rowbytes + p * 16u;        lb0 = l_off(SC_MT + r8);
-        vb1 = (unsigned)(r8 + 32) * rowbytes + p * 16u; lb1 = l_off(SC_MT + r8 + 32);
-    }
-    // fragment read addresses: plane p = 4q + fg, physical row (fi ^ p) (+ m*16, + 144 + wave*16 for B)
-    constexpr unsigned STAGE_BYTES = SC_PLANES * SC_ROWS * 16u;   // one buffer
-    const unsigned ra0 = (unsigned)((fg) * SC_ROWS + (fi ^ fg)) * 16u;
-    const unsigned ra1 = (unsigned)((4 + fg) * SC_ROWS + (fi ^ (4 + fg))) * 16u;
-    const unsigned rb0 = ra0 + (unsigned)(SC_MT + wave * 16) * 16u;
-    const unsigned rb1 = ra1 + (unsigned)(SC_MT + wave * 16) * 16u;
-    char *const lds = smem_raw;   // sm.stage sits at offset 0 of the dynamic LDS block
-
-    f32x4 acc[SC_MTILES];
-#pragma unroll
-    for (int m = 0; m < SC_MTILES; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // two register stages: chunk kc+2 is in flight while chunk kc is multiplied and chunk kc+1 is
-    // parked in the other LDS buffer, so an HBM-miss has ~2 chunks (>= 4.6k cycles) to land.
-    // The global loads are issued through inline asm so that hipcc's own s_waitcnt bookkeeping does not see
-    // them: at the loop header it merged the two stages' states into vmcnt(0) before the LDS stores, i.e. it
-    // waited for the loads issued half a chunk earlier and exposed a full L2/HBM latency every chunk.  We
-    // count ourselves: when stage P is parked, the 7 loads of the OTHER stage (issued one chunk later) may
-    // still be in flight -> s_waitcnt vmcnt(7).  The wait statement names P's registers as read-write
-    // operands, which pins every consumer of P behind it (cdna_hip_programming.md 5.7 form (ii)).
-    f32x4 sa0, sa1, sa2, sa3, sa4, sa5, sa6;   // register stage A
-    f32x4 sb0, sb1, sb2, sb3, sb4, sb5, sb6;   // register stage B
-#define SC_LDG(dst, base, voff)                                                                    \
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
-#define SC_GLOAD(P, KC)                                                                            \
-    {                                                                                              \
-        const char *ab_ = abase + (int64_t)(KC) * (SC_BK * 4);                                     \
-        const char *bb_ = bbase + (int64_t)(KC) * (SC_BK * 4);                                     \
-        SC_LDG(P##0, ab_, va0) SC_LDG(P##1, ab_, va1) SC_LDG(P##2, ab_, va2) SC_LDG(P##3, ab_, va3) \
-        SC_LDG(P##4, ab_, va4) SC_LDG(P##5, bb_, vb0) SC_LDG(P##6, bb_, vb1)                       \
-    }
-#define SC_VMWAIT(P, N)                                                                            \
-    asm volatile("s_waitcnt vmcnt(" #N ")"                                                         \
-                 : "+v"(P##0), "+v"(P##1), "+v"(P##2), "+v"(P##3), "+v"(P##4), "+v"(P##5), "+v"(P##6)::"memory");
-#define SC_STS(addr, BUF, v) (*reinterpret_cast<f32x4 *>(lds + (addr) + (BUF) * STAGE_BYTES) = (v))
-#define SC_LSTORE(P, BUF)                                                                          \
-    {                                                                                              \
-        SC_STS(la0, BUF, P##0); SC_STS(la1, BUF, P##1); SC_STS(la2, BUF, P##2); SC_STS(la3, BUF, P##3); \
-        SC_STS(la4, BUF, P##4); SC_STS(lb0, BUF, P##5); SC_STS(lb1, BUF, P##6);                    \
-    }
-#define SC_LDS4(addr) (*reinterpret_cast<const float4 *>(lds + (addr)))
-    // fragment sets: F0 = k-planes 0..3 (q = 0), F1 = k-planes 4..7 (q = 1) of one 32-wide chunk
-    float4 f0a[SC_MTILES], f0b, f1a[SC_MTILES], f1b;
-#define SC_FREAD(FA, FB, RA, RB, BUF)                                                              \
-    {                                                                                              \
-        FB = SC_LDS4((RB) + (BUF) * STAGE_BYTES);                                                  \
-        _Pragma("unroll") for (int m = 0; m < SC_MTILES; ++m)                                      \
-            FA[m] = SC_LDS4((RA) + (BUF) * STAGE_BYTES + m * 256);                                 \
-    }
-#define SC_FMFMA(FA, FB)                                                                           \
-    {                                                                                              \
-        _Pragma("unroll") for (int m = 0; m < SC_MTILES; ++m)                                      \
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[m].x, FB.x, acc[m], 0, 0, 0);         \
-        _Pragma("unroll") for (int m = 0; m < SC_MTILES; ++m)                                      \
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[m].y, FB.y, acc[m], 0, 0, 0);         \
-        _Pragma("unroll") for (int m = 0; m < SC_MTILES; ++m)                                      \
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[m].z, FB.z, acc[m], 0, 0, 0);         \
-        _Pragma("unroll") for (int m = 0; m < SC_MTILES; ++m)                                      \
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[m].w, FB.w, acc[m], 0, 0, 0);         \
-    }
-    // One chunk (software pipelined so that every LDS / barrier latency sits under 36 MFMAs = 1152 cycles):
-    //   park chunk kc+1 (register stage P) in the other LDS buffer; refill P with chunk kc+3;
-    //   read F1(kc);  MFMA F0(kc);  barrier  (=> chunk kc+1 visible, every wave is done reading chunk kc);
-    //   read F0(kc+1) from the other buffer;  MFMA F1(kc).
-    // One barrier per chunk, placed mid-way.  Tail iterations re-load the last chunk and park / read data
-    // nobody consumes, which keeps the body branch-free.
-    // Instruction interleave (sched_group_barrier): the wave issues in order, and a ds_write_b128 occupies its
-    // issue slot for >= 13 cycles (more when the 4 waves contend for the LDS store path), a ds_read_b128 /
-    // global_load a few.  Issued in a clump they starve the matrix pipe (tools/ubench/mfma_pipe: 3091 cycles
-    // per 72-MFMA chunk); slotted one per MFMA they execute under the previous MFMA's 32 cycles (2686).
-#define SC_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
-#define SC_CHUNK(P, CUR, NXT, KC)                                                                  \
-    {                                                                                              \
-        SC_VMWAIT(P, 7)                                                                            \
-        SC_LSTORE(P, NXT)                                                                          \
-        SC_GLOAD(P, ((KC) + 3 < klast ? (KC) + 3 : klast))                                         \
-        SC_FREAD(f1a, f1b, ra1, rb1, CUR)                                                          \
-        SC_FMFMA(f0a, f0b)                                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < 7; ++i_) { SC_SGB(0x008, 1) SC_SGB(0x200, 1) }     \
-        _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { SC_SGB(0x008, 1) SC_SGB(0x100, 1) }    \
-        SC_SGB(0x008, 19)                                                                          \
-        __syncthreads();                                                                           \
-        SC_FREAD(f0a, f0b, ra0, rb0, NXT)                                                          \
-        SC_FMFMA(f1a, f1b)                                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { SC_SGB(0x008, 1) SC_SGB(0x100, 1) }    \
-        SC_SGB(0x008, 26)                                                                          \
-    }
-
-    const int klast = nk - 1;
-    // prologue: chunk 0 -> LDS buffer 0, stage B = chunk 1, stage A = chunk 2
-    SC_GLOAD(sa, 0)
-    SC_GLOAD(sb, (1 < klast ? 1 : klast))
-    SC_VMWAIT(sa, 7)
-    SC_LSTORE(sa, 0)
-    SC_GLOAD(sa, (2 < klast ? 2 : klast))
-    __syncthreads();
-    SC_TICK(4)   // prologue: first operand chunk in LDS
-    SC_FREAD(f0a, f0b, ra0, rb0, 0)
-    for (int kc = 0; kc < nk; kc += 2) {
-        SC_CHUNK(sb, 0, 1, kc)            // chunk kc   lives in buffer 0; parks chunk kc+1, refills B with kc+3
-        if (kc + 1 >= nk) break;
-        SC_CHUNK(sa, 1, 0, kc + 1)        // chunk kc+1 lives in buffer 1; parks chunk kc+2, refills A with kc+4
-    }
-    // drain the (unused) tail prefetches before the compiler recycles their destination registers
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef SC_LDG
-#undef SC_GLOAD
-#undef SC_STS
-#undef SC_VMWAIT
-#undef SC_LSTORE
-#undef SC_LDS4
-#undef SC_FREAD
-#undef SC_FMFMA
-#undef SC_CHUNK
-#undef SC_SGB
-
-    // ---- epilogue ------------------------------------------------------------------------------------------
-    // Next to a wave that streams 32-cycle fp32 MFMAs (the other workgroup of this CU) every VALU instruction
-    // of this wave waits for an MFMA slot, so the epilogue is built to issue few instructions: the block is
-    // parked TRANSPOSED ([word column][region row]) so that every access below is a 16-byte LDS access, and
-    // the two reductions with real arithmetic (first-norm statistics, ||ctx||^2) run on the matrix core.
-    __syncthreads();
-    SC_TICK(0)   // prologue + main loop
-    {
-        float *colp = &sm.arawt[wave * 16 + fi][fg * 4];
-#pragma unroll
-        for (int m = 0; m < SC_MTILES; ++m) *reinterpret_cast<f32x4 *>(colp + m * 16) = acc[m];
-    }
-    __syncthreads();
-    SC_TICK(1)   // park
+#include "scan_mainloop.inc"
 
     const int norm = g.norm;
     const float ls = g.lambda_softmax;
@@ -492,6 +298,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                 float q = fg == 0 ? qn[0] : (fg == 1 ? qn[1] : (fg == 2 ? qn[2] : qn[3]));
                 q = q * rden * rden;
                 num *= rden;
+                if (g.emit_p) {   // SGRAF: hand the attention weights and the context norm to the GEMM chain
+                    const int64_t orow = img * (g.n_tiles * SC_NT) + ct * SC_NT + w;
+                    f32x4 *pd = reinterpret_cast<f32x4 *>(g.emit_p + orow * SC_R);
+#pragma unroll
+                    for (int r4 = 0; r4 < SC_R / 4; ++r4)
+                        pd[r4] = f32x4{e[4 * r4] * rden, e[4 * r4 + 1] * rden, e[4 * r4 + 2] * rden, e[4 * r4 + 3] * rden};
+                    g.emit_cn[orow] = 1.f / (sqrtf(fmaxf(q, 0.f)) + 1e-8f);
+                }
                 const float w1 = g.wnorm[ct * SC_NT + w];
                 const float w2 = sqrtf(fmaxf(q, 0.f));
                 simv = num / fmaxf(w1 * w2, 1e-8f);   // cosine_similarity, Objectives.py:10-15
@@ -684,7 +498,7 @@ __global__ __launch_bounds__(256) void scan_pack_kernel(const float *__restrict_
                                                         const int32_t *__restrict__ tile_begin,
                                                         const int32_t *__restrict__ cap_order, int D,
                                                         float *__restrict__ wtiled, ScanTileMeta *__restrict__ meta,
-                                                        float *__restrict__ wnorm) {
+                                                        float *__restrict__ wnorm, int32_t *__restrict__ cap_col) {
     __shared__ ScanTileMeta m;
     __shared__ int64_t off[SC_MAXCAP];
     __shared__ int32_t len[SC_MAXCAP];
@@ -712,6 +526,8 @@ __global__ __launch_bounds__(256) void scan_pack_kernel(const float *__restrict_
         }
         for (int k = n; k <= SC_MAXCAP; ++k) m.cap_start[k] = pos;
         m.ncap = n;
+        if (cap_col)
+            for (int k = 0; k < n; ++k) cap_col[m.cap_id[k]] = (int32_t)(t * SC_NT + m.cap_start[k]);
     }
     __syncthreads();
     for (int idx = tid; idx < n * SC_NT; idx += 256) {
@@ -826,12 +642,11 @@ extern "C" size_t itr_scan_workspace_bytes(int64_t Ni, int R, int64_t n_rows, in
     return itr::scan_ws_bytes(Ni, R, n_rows, Nc, n_tiles, D);
 }
 
-extern "C" int itr_scan_prepare(const float *img, const float *words, const int64_t *cap_off,
-                                const int32_t *cap_len, const int32_t *tile_begin_dev,
-                                const int32_t *cap_order_dev, int64_t n_tiles, int64_t Ni, int64_t Nc,
-                                int64_t n_rows, int R, int D, int mode, void *workspace, size_t workspace_bytes,
-                                itr_stream_t stream) {
-    using namespace itr;
+namespace itr {
+int scan_prepare_impl(const float *img, const float *words, const int64_t *cap_off, const int32_t *cap_len,
+                      const int32_t *tile_begin_dev, const int32_t *cap_order_dev, int64_t n_tiles, int64_t Ni,
+                      int64_t Nc, int64_t n_rows, int R, int D, int mode, void *workspace, size_t workspace_bytes,
+                      int32_t *cap_col, itr_stream_t stream) {
     ITR_REQUIRE(img && words && cap_off && cap_len && tile_begin_dev && cap_order_dev && workspace,
                 "itr_scan_prepare: null pointer");
     ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && n_tiles >= 0 && D > 0, "itr_scan_prepare: bad shape");
@@ -845,7 +660,7 @@ extern "C" int itr_scan_prepare(const float *img, const float *words, const int6
     hipStream_t st = as_stream(stream);
     ScanWs w = scan_carve(workspace, Ni, R, n_rows, Nc, n_tiles, D, mode);
     hipLaunchKernelGGL(scan_pack_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, words, cap_off, cap_len,
-                       tile_begin_dev, cap_order_dev, D, w.wtiled, w.meta, w.wnorm);
+                       tile_begin_dev, cap_order_dev, D, w.wtiled, w.meta, w.wnorm, cap_col);
     ITR_CHECK_LAUNCH("scan pack");
     if (mode == 0) {
         hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Ni), dim3(256), 0, st, img, (const int64_t *)nullptr,
@@ -862,12 +677,24 @@ extern "C" int itr_scan_prepare(const float *img, const float *words, const int6
     }
     return ITR_OK;
 }
+}  // namespace itr
 
-extern "C" int itr_scan_xattn_scores(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows,
-                                     int R, int D, int mode, int norm, int agg, float lambda_softmax,
-                                     float lambda_lse, float *S, int64_t ldS, void *workspace,
-                                     size_t workspace_bytes, itr_stream_t stream) {
-    using namespace itr;
+extern "C" int itr_scan_prepare(const float *img, const float *words, const int64_t *cap_off,
+                                const int32_t *cap_len, const int32_t *tile_begin_dev,
+                                const int32_t *cap_order_dev, int64_t n_tiles, int64_t Ni, int64_t Nc,
+                                int64_t n_rows, int R, int D, int mode, void *workspace, size_t workspace_bytes,
+                                itr_stream_t stream) {
+    return itr::scan_prepare_impl(img, words, cap_off, cap_len, tile_begin_dev, cap_order_dev, n_tiles, Ni, Nc, n_rows,
+                                  R, D, mode, workspace, workspace_bytes, nullptr, stream);
+}
+
+namespace itr {
+// emit_p / emit_cn != null: also write the normalised attention weights [Ni, n_tiles*64, 36] and
+// 1 / (||ctx|| + eps) [Ni, n_tiles*64] (SGRAF); S may then be null-free scratch of the usual shape.
+int scan_scores_impl(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
+                     int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
+                     void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
+                     int64_t img_count, itr_stream_t stream) {
     ITR_REQUIRE(img && S && workspace, "itr_scan_xattn_scores: null pointer");
     ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && n_tiles >= 0 && ldS >= Nc, "itr_scan_xattn_scores: bad shape");
     if (mode != 0 && mode != 1) { set_error("unknown cross_attn mode %d", mode); return ITR_ERR_BADARG; }
@@ -888,6 +715,16 @@ extern "C" int itr_scan_xattn_scores(const float *img, int64_t n_tiles, int64_t 
     a.S = S; a.ldS = ldS; a.Ni = Ni; a.Nc = Nc; a.n_tiles = n_tiles; a.D = D;
     a.mode = mode; a.norm = norm; a.agg = agg; a.lambda_softmax = lambda_softmax; a.lambda_lse = lambda_lse;
     a.gram = w.gram; a.wnorm = w.wnorm; a.vnorm = w.vnorm; a.cgram = w.cgram; a.cgram_off = w.coff;
+    a.emit_p = emit_p; a.emit_cn = emit_cn;
+    if (img_count >= 0) {   // score only images [img_index0, img_index0 + img_count) of the prepared set (S, emit_*: local rows)
+        ITR_REQUIRE(img_index0 >= 0 && img_index0 + img_count <= Ni, "scan: image sub-range out of bounds");
+        a.img = img + img_index0 * (int64_t)R * D;
+        if (a.gram) a.gram += img_index0 * (int64_t)R * R;
+        if (a.vnorm) a.vnorm += img_index0 * (int64_t)R;
+        a.Ni = img_count;
+        Ni = img_count;
+        if (Ni == 0) return ITR_OK;
+    }
     if (const char *dbg = getenv("ITR_SCAN_DEBUG")) a.debug = atoi(dbg);
     if (a.debug & 16) {   // phase timing: the caller reads the 8 counters placed at the start of S (S is garbage then)
         a.dbg_cycles = reinterpret_cast<unsigned long long *>(S);
@@ -910,6 +747,15 @@ extern "C" int itr_scan_xattn_scores(const float *img, int64_t n_tiles, int64_t 
     hipLaunchKernelGGL(scan_xattn_kernel, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
     ITR_CHECK_LAUNCH("scan_xattn");
     return ITR_OK;
+}
+}  // namespace itr
+
+extern "C" int itr_scan_xattn_scores(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows,
+                                     int R, int D, int mode, int norm, int agg, float lambda_softmax,
+                                     float lambda_lse, float *S, int64_t ldS, void *workspace,
+                                     size_t workspace_bytes, itr_stream_t stream) {
+    return itr::scan_scores_impl(img, n_tiles, Ni, Nc, n_rows, R, D, mode, norm, agg, lambda_softmax, lambda_lse, S,
+                                 ldS, workspace, workspace_bytes, nullptr, nullptr, 0, -1, stream);
 }
 
 // Diagnostics for tools/: resident workgroups per CU of the SCAN kernel as the runtime sees it.

@@ -1,0 +1,390 @@
+// SGRAF similarity: EncoderSimilarity.forward + VisualSA / TextSA / SCAN_attention / AttentionFiltration /
+// GraphReasoning (itr/modalmodule/Fusionmodule.py:373-664), eval mode (BatchNorm running statistics, no dropout).
+//
+// Round-1 structure ("v1": correct first, HBM round trips between stages, all heavy arithmetic on the fp32
+// matrix core).  Per block of IB images:
+//   1. SCAN kernel (scan_xattn.hip) in emit mode  -> attention weights P[i, word, 36] and 1/(||ctx||+eps)
+//      (SCAN_attention :632-664 is SCAN t2i with clipped_l2norm and smooth = 9)
+//   2. per image:  (P_i V_i * cn - E)^2          -> GEMM [words,36]x[36,D] with the squared-difference epilogue
+//   3. sim_loc = l2norm(W_loc (.) + b)            -> GEMM [IB*words, D] x [D, S] + row l2norm          (:427)
+//   4. sim_glo = l2norm(W_glo (img_glo - cap_glo)^2 + b)  -> elementwise + GEMM + row l2norm          (:429-430)
+//   5. SAF (:615-619) or SGR x sgr_step (:581-587) + sigmoid(sim_eval_w)                                (:443-444)
+// The global nodes img_glo / cap_glo (VisualSA :491-507, TextSA :543-559) are computed once per call.
+// A fused "flash" version that keeps (ctx - E)^2 on chip is the next step.
+#include "scan_common.h"
+
+namespace itr {
+
+int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc,
+            int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
+int gemm_nt_sqdiff(const float *A, int64_t lda, const float *B, int64_t ldb, const float *rowscale, const float *Z,
+                   int64_t ldz, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t st);
+int norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, int kind, int take_abs, hipStream_t st);
+int scan_prepare_impl(const float *img, const float *words, const int64_t *cap_off, const int32_t *cap_len,
+                      const int32_t *tile_begin_dev, const int32_t *cap_order_dev, int64_t n_tiles, int64_t Ni,
+                      int64_t Nc, int64_t n_rows, int R, int D, int mode, void *workspace, size_t workspace_bytes,
+                      int32_t *cap_col, itr_stream_t stream);
+int scan_scores_impl(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
+                     int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
+                     void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
+                     int64_t img_count, itr_stream_t stream);
+
+constexpr float BN_EPS = 1e-5f;
+
+// y = tanh(bn(x)) in place; the BN channel is (row % period) when by_row, else the column (eval statistics)
+__global__ __launch_bounds__(256) void bn_tanh_kernel(float *__restrict__ x, int64_t rows, int cols, int by_row, int period,
+                                                      const float *__restrict__ w, const float *__restrict__ b,
+                                                      const float *__restrict__ mean, const float *__restrict__ var) {
+    const int64_t row = blockIdx.y;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows || col >= cols) return;
+    const int ch = by_row ? (int)(row % period) : col;
+    const float v = (x[row * cols + col] - mean[ch]) / sqrtf(var[ch] + BN_EPS) * w[ch] + b[ch];
+    x[row * cols + col] = tanhf(v);
+}
+
+// out[g, :] = mean over the rows of group g (ragged: rows off[g] .. off[g]+len[g]-1)
+__global__ __launch_bounds__(256) void seg_mean_kernel(const float *__restrict__ x, const int64_t *__restrict__ off,
+                                                       const int32_t *__restrict__ len, int D, float *__restrict__ out) {
+    const int64_t gidx = blockIdx.x;
+    const int n = len[gidx];
+    const float *p = x + off[gidx] * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float s = 0.f;
+        for (int r = 0; r < n; ++r) s += p[(int64_t)r * D + d];
+        out[gidx * D + d] = s / (float)n;
+    }
+}
+
+// Self-attention pooling of VisualSA / TextSA (Fusionmodule.py:499-507 / :551-559):
+//   w_r = softmax_r( sum_d l_emb[r,d] * g_emb[d] * wc[d] + bc );  out = l2norm( sum_r w_r * local[r,:] )
+// one workgroup per group (image: 36 rows, caption: len rows <= 64)
+__global__ __launch_bounds__(256) void sa_pool_kernel(const float *__restrict__ local, const float *__restrict__ l_emb,
+                                                      const float *__restrict__ g_emb, const float *__restrict__ wc,
+                                                      const float *__restrict__ bc, const int64_t *__restrict__ off,
+                                                      const int32_t *__restrict__ len, int fixed_rows, int D,
+                                                      float *__restrict__ out) {
+    __shared__ float s_w[64];
+    __shared__ float s_red[4];
+    const int64_t gidx = blockIdx.x;
+    const int n = len ? len[gidx] : fixed_rows;
+    const int64_t r0 = off ? off[gidx] : gidx * fixed_rows;
+    const float *ge = g_emb + gidx * D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < n; r += 4) {
+        const float *le = l_emb + (r0 + r) * D;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += le[d] * ge[d] * wc[d];
+        s = wave_sum(s);
+        if (lane == 0) s_w[r] = s + bc[0];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mx = -INFINITY;
+        for (int r = 0; r < n; ++r) mx = fmaxf(mx, s_w[r]);
+        float den = 0.f;
+        for (int r = 0; r < n; ++r) { s_w[r] = expf(s_w[r] - mx); den += s_w[r]; }
+        for (int r = 0; r < n; ++r) s_w[r] /= den;
+    }
+    __syncthreads();
+    float ss = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float v = 0.f;
+        for (int r = 0; r < n; ++r) v += s_w[r] * local[(r0 + r) * D + d];
+        out[gidx * D + d] = v;
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) s_red[wave] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]) + 1e-8f;
+    for (int d = threadIdx.x; d < D; d += 256) out[gidx * D + d] /= nrm;
+}
+
+// imgT[i, d, r] = img[i, r, d]  (B operand of the context GEMM, K = 36 contiguous)
+__global__ __launch_bounds__(256) void transpose_img_kernel(const float *__restrict__ img, int R, int D, float *__restrict__ out) {
+    __shared__ float t[36][65];
+    const int64_t i = blockIdx.y;
+    const int d0 = blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < R * 64; idx += 256) {
+        const int r = idx / 64, d = idx % 64;
+        t[r][d] = (d0 + d < D) ? img[(i * R + r) * D + d0 + d] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * R; idx += 256) {
+        const int d = idx / R, r = idx % R;
+        if (d0 + d < D) out[(i * D + d0 + d) * R + r] = t[r][d];
+    }
+}
+
+// Aglo[(ii, c), d] = (img_glo[ii, d] - cap_glo[c, d])^2
+__global__ __launch_bounds__(256) void glo_sqdiff_kernel(const float *__restrict__ img_glo, const float *__restrict__ cap_glo,
+                                                         int64_t Nc, int D, float *__restrict__ out) {
+    const int64_t c = blockIdx.x, ii = blockIdx.y;
+    const float *a = img_glo + ii * D, *b = cap_glo + c * D;
+    float *o = out + (ii * Nc + c) * D;
+    for (int d = threadIdx.x; d < D; d += 256) { const float v = a[d] - b[d]; o[d] = v * v; }
+}
+
+struct PairArgs {
+    const float *xglo, *xloc;      // [nb*Nc, S], [nb*ncols, S]
+    const int32_t *cap_col, *cap_len;
+    int64_t Nc, ncols;
+    int S;
+};
+
+__device__ __forceinline__ const float *node_row(const PairArgs &p, const float *glo, const float *loc, int64_t ii,
+                                                 int64_t c, int col0, int n) {
+    return n == 0 ? glo + (ii * p.Nc + c) * p.S : loc + (ii * p.ncols + col0 + n - 1) * p.S;
+}
+
+// AttentionFiltration + final score (Fusionmodule.py:615-619, :443-444); one wave per (image, caption) pair
+__global__ __launch_bounds__(256) void saf_pair_kernel(PairArgs p, const float *__restrict__ saf_w, const float *__restrict__ saf_b,
+                                                       const float *__restrict__ bn_w, const float *__restrict__ bn_b,
+                                                       const float *__restrict__ bn_mean, const float *__restrict__ bn_var,
+                                                       const float *__restrict__ eval_w, const float *__restrict__ eval_b,
+                                                       int64_t npairs, float *__restrict__ S, int64_t ldS, int64_t img_index0) {
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= npairs) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t ii = pair / p.Nc, c = pair % p.Nc;
+    const int nn = p.cap_len[c] + 1, col0 = p.cap_col[c];
+    const float bscale = bn_w[0] / sqrtf(bn_var[0] + BN_EPS);
+    float asum = 0.f;
+    // pass 1: attention weights (kept per node in a register ring of the wave: recomputed in pass 2 instead)
+    for (int n = 0; n < nn; ++n) {
+        const float *x = node_row(p, p.xglo, p.xloc, ii, c, col0, n);
+        float s = 0.f;
+        for (int d = lane; d < p.S; d += 64) s += x[d] * saf_w[d];
+        s = wave_sum(s) + saf_b[0];
+        const float a = 1.f / (1.f + expf(-((s - bn_mean[0]) * bscale + bn_b[0])));
+        asum += fabsf(a);
+    }
+    const float inv = 1.f / (asum + 1e-8f);   // l1norm
+    // pass 2: filtered aggregate, this lane's columns d = lane, lane+64, ... (S <= 1024)
+    float vec[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) vec[u] = 0.f;
+    for (int n = 0; n < nn; ++n) {
+        const float *x = node_row(p, p.xglo, p.xloc, ii, c, col0, n);
+        float s = 0.f;
+        for (int d = lane; d < p.S; d += 64) s += x[d] * saf_w[d];
+        s = wave_sum(s) + saf_b[0];
+        const float a = inv / (1.f + expf(-((s - bn_mean[0]) * bscale + bn_b[0])));
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int d = lane + 64 * u; if (d < p.S) vec[u] += a * x[d]; }
+    }
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int d = lane + 64 * u; if (d < p.S) { ss += vec[u] * vec[u]; dot += vec[u] * eval_w[d]; } }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float score = dot / (sqrtf(ss) + 1e-8f) + eval_b[0];     // eval_w . l2norm(vec) + b
+    if (lane == 0) S[(img_index0 + ii) * ldS + c] = 1.f / (1.f + expf(-score));
+}
+
+// One GraphReasoning step per pair (Fusionmodule.py:581-587): edge = softmax(Q K^T), Y = edge X.
+// One wave per pair; K and X rows of the pair are staged in LDS (dynamic: 2 * maxnodes * S floats per wave).
+__global__ __launch_bounds__(64) void sgr_pair_kernel(PairArgs p, const float *__restrict__ qglo, const float *__restrict__ qloc,
+                                                      const float *__restrict__ kglo, const float *__restrict__ kloc,
+                                                      float *__restrict__ yglo, float *__restrict__ yloc, int64_t npairs,
+                                                      int maxnodes, int glo_only) {
+    extern __shared__ float sm[];
+    const int64_t pair = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t ii = pair / p.Nc, c = pair % p.Nc;
+    const int nn = p.cap_len[c] + 1, col0 = p.cap_col[c];
+    float *ks = sm, *xs = sm + (size_t)maxnodes * p.S;
+    for (int n = 0; n < nn; ++n) {
+        const float *kr = node_row(p, kglo, kloc, ii, c, col0, n);
+        const float *xr = node_row(p, p.xglo, p.xloc, ii, c, col0, n);
+        for (int d = lane; d < p.S; d += 64) { ks[n * p.S + d] = kr[d]; xs[n * p.S + d] = xr[d]; }
+    }
+    __syncthreads();
+    const int na = glo_only ? 1 : nn;   // the last step only needs node 0 (sim_emb[:, 0, :], :439)
+    for (int a = 0; a < na; ++a) {
+        const float *qr = node_row(p, qglo, qloc, ii, c, col0, a);
+        float e[64];
+        float mx = -INFINITY;
+        for (int b = 0; b < nn; ++b) {
+            float s = 0.f;
+            for (int d = lane; d < p.S; d += 64) s += qr[d] * ks[b * p.S + d];
+            s = wave_sum(s);
+            e[b] = s;
+            mx = fmaxf(mx, s);
+        }
+        float den = 0.f;
+        for (int b = 0; b < nn; ++b) { e[b] = expf(e[b] - mx); den += e[b]; }
+        float *yr = const_cast<float *>(node_row(p, yglo, yloc, ii, c, col0, a));
+        for (int d = lane; d < p.S; d += 64) {
+            float v = 0.f;
+            for (int b = 0; b < nn; ++b) v += e[b] * xs[b * p.S + d];
+            yr[d] = v / den;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sgr_final_kernel(const float *__restrict__ xglo, int64_t Nc, int S_, const float *__restrict__ eval_w,
+                                                        const float *__restrict__ eval_b, int64_t npairs, float *__restrict__ S,
+                                                        int64_t ldS, int64_t img_index0) {
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= npairs) return;
+    const int lane = threadIdx.x & 63;
+    const float *x = xglo + pair * S_;
+    float s = 0.f;
+    for (int d = lane; d < S_; d += 64) s += x[d] * eval_w[d];
+    s = wave_sum(s) + eval_b[0];
+    if (lane == 0) S[(img_index0 + pair / Nc) * ldS + pair % Nc] = 1.f / (1.f + expf(-s));
+}
+
+static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr int SGRAF_IB = 4;   // images per block (== SCAN image tile)
+
+}  // namespace itr
+
+extern "C" size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_rows, int64_t n_tiles, int D, int S,
+                                            int module) {
+    using namespace itr;
+    const int64_t ncols = n_tiles * SC_NT, IB = SGRAF_IB;
+    size_t b = itr_scan_workspace_bytes(Ni, SC_R, n_rows, Nc, n_tiles, D) + 256;
+    b += al((size_t)Ni * D * 4) * 3 + al((size_t)Ni * SC_R * D * 4) * 2;        // img_ave, g_emb_v, img_glo; l_emb_v, imgT
+    b += al((size_t)n_rows * D * 4) + al((size_t)Nc * D * 4) * 3;                // l_emb_t; cap_ave, g_emb_t, cap_glo
+    b += al((size_t)Nc * 4) + al((size_t)Nc * 8);                                // cap_col, seg offsets (unused slot)
+    b += al((size_t)IB * ncols * SC_R * 4) + al((size_t)IB * ncols * 4) + al((size_t)IB * Nc * 4);   // P, cn, scan scratch
+    b += al((size_t)IB * ncols * D * 4) + al((size_t)IB * Nc * D * 4);           // Aloc, Aglo
+    const int nbuf = module == 1 ? 4 : 1;                                        // X (+ Q, K, Y for SGR)
+    b += (al((size_t)IB * ncols * S * 4) + al((size_t)IB * Nc * S * 4)) * nbuf;
+    return b;
+}
+
+extern "C" int itr_sgraf_scores(const float *img, const float *words, const int64_t *cap_off, const int32_t *cap_len,
+                                const int32_t *tile_begin_dev, const int32_t *cap_order_dev, int64_t n_tiles,
+                                int64_t Ni, int64_t Nc, int64_t n_rows, int max_len, int R, int D, int S, int module,
+                                int sgr_step, const itr_sgraf_weights *w, float *Sout, int64_t ldS, void *workspace,
+                                size_t workspace_bytes, itr_stream_t stream) {
+    using namespace itr;
+    ITR_REQUIRE(img && words && cap_off && cap_len && tile_begin_dev && cap_order_dev && w && Sout && workspace,
+                "itr_sgraf_scores: null pointer");
+    ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && D > 0 && S > 0 && ldS >= Nc, "itr_sgraf_scores: bad shape");
+    if (module != 0 && module != 1) { set_error("Invalid input of config.module_name in configs.py"); return ITR_ERR_BADARG; }
+    ITR_UNSUPPORTED(R != SC_R, "itr_sgraf_scores: VisualSA is built for %d regions (BatchNorm1d(36)), got %d", SC_R, R);
+    ITR_UNSUPPORTED(S > 1024 || (D % SC_BK) != 0, "itr_sgraf_scores: need sim_dim <= 1024 and embed dim %% 32 == 0");
+    ITR_UNSUPPORTED(module == 1 && (sgr_step < 1 || sgr_step > 8), "itr_sgraf_scores: sgr_step must be in [1, 8]");
+    ITR_UNSUPPORTED(max_len < 1 || max_len > 63, "itr_sgraf_scores: captions of 1..63 words are supported");
+    ITR_REQUIRE(workspace_bytes >= itr_sgraf_workspace_bytes(Ni, Nc, n_rows, n_tiles, D, S, module),
+                "itr_sgraf_scores: workspace too small");
+    if (Ni == 0 || Nc == 0) return ITR_OK;
+    hipStream_t st = as_stream(stream);
+    const int64_t ncols = n_tiles * SC_NT, IB = SGRAF_IB;
+
+    // ---- carve
+    char *p = static_cast<char *>(workspace);
+    auto take = [&](size_t bytes) { char *q = p; p += al(bytes); return q; };
+    const size_t scan_bytes = itr_scan_workspace_bytes(Ni, SC_R, n_rows, Nc, n_tiles, D);
+    void *scan_ws = take(scan_bytes + 256);
+    float *img_ave = (float *)take((size_t)Ni * D * 4), *g_emb_v = (float *)take((size_t)Ni * D * 4);
+    float *img_glo = (float *)take((size_t)Ni * D * 4);
+    float *l_emb_v = (float *)take((size_t)Ni * SC_R * D * 4), *imgT = (float *)take((size_t)Ni * SC_R * D * 4);
+    float *l_emb_t = (float *)take((size_t)n_rows * D * 4);
+    float *cap_ave = (float *)take((size_t)Nc * D * 4), *g_emb_t = (float *)take((size_t)Nc * D * 4);
+    float *cap_glo = (float *)take((size_t)Nc * D * 4);
+    int32_t *cap_col = (int32_t *)take((size_t)Nc * 4);
+    take((size_t)Nc * 8);
+    float *P = (float *)take((size_t)IB * ncols * SC_R * 4), *cn = (float *)take((size_t)IB * ncols * 4);
+    float *sscr = (float *)take((size_t)IB * Nc * 4);
+    float *Aloc = (float *)take((size_t)IB * ncols * D * 4), *Aglo = (float *)take((size_t)IB * Nc * D * 4);
+    float *Xloc = (float *)take((size_t)IB * ncols * S * 4), *Xglo = (float *)take((size_t)IB * Nc * S * 4);
+    float *Qloc = nullptr, *Qglo = nullptr, *Kloc = nullptr, *Kglo = nullptr, *Yloc = nullptr, *Yglo = nullptr;
+    if (module == 1) {
+        Qloc = (float *)take((size_t)IB * ncols * S * 4); Qglo = (float *)take((size_t)IB * Nc * S * 4);
+        Kloc = (float *)take((size_t)IB * ncols * S * 4); Kglo = (float *)take((size_t)IB * Nc * S * 4);
+        Yloc = (float *)take((size_t)IB * ncols * S * 4); Yglo = (float *)take((size_t)IB * Nc * S * 4);
+    }
+    int rc;
+#define SG_TRY(x) { rc = (x); if (rc != ITR_OK) return rc; }
+
+    // ---- global nodes: VisualSA (:491-507)
+    ITR_REQUIRE(Ni <= 65535, "itr_sgraf_scores: at most 65535 images per call");
+    SG_TRY(itr_mean_mid(img, img_ave, Ni, SC_R, D, stream));
+    SG_TRY(gemm_nt(img, D, w->v_loc_w, D, w->v_loc_b, l_emb_v, D, Ni * SC_R, D, D, 0, st));
+    {
+        dim3 grid((unsigned)ceil_div(D, 256), (unsigned)1);
+        // rows can exceed 65535: launch in slabs
+        for (int64_t r0 = 0; r0 < Ni * SC_R; r0 += 65520) {   // 65520 is a multiple of 36
+            const int64_t nr = (Ni * SC_R - r0 < 65520) ? Ni * SC_R - r0 : 65520;
+            hipLaunchKernelGGL(bn_tanh_kernel, dim3((unsigned)ceil_div(D, 256), (unsigned)nr), dim3(256), 0, st,
+                               l_emb_v + r0 * D, nr, D, 1, SC_R, w->v_loc_bn_w, w->v_loc_bn_b, w->v_loc_bn_mean, w->v_loc_bn_var);
+        }
+        ITR_CHECK_LAUNCH("sgraf bn_tanh (local)");
+        (void)grid;
+    }
+    SG_TRY(gemm_nt(img_ave, D, w->v_glo_w, D, w->v_glo_b, g_emb_v, D, Ni, D, D, 0, st));
+    hipLaunchKernelGGL(bn_tanh_kernel, dim3((unsigned)ceil_div(D, 256), (unsigned)Ni), dim3(256), 0, st, g_emb_v, Ni, D, 0, 1,
+                       w->v_glo_bn_w, w->v_glo_bn_b, w->v_glo_bn_mean, w->v_glo_bn_var);
+    ITR_CHECK_LAUNCH("sgraf bn_tanh (global)");
+    hipLaunchKernelGGL(sa_pool_kernel, dim3((unsigned)Ni), dim3(256), 0, st, img, l_emb_v, g_emb_v, w->v_com_w, w->v_com_b,
+                       (const int64_t *)nullptr, (const int32_t *)nullptr, SC_R, D, img_glo);
+    ITR_CHECK_LAUNCH("sgraf sa_pool (image)");
+    // ---- TextSA (:543-559)
+    SG_TRY(gemm_nt(words, D, w->t_loc_w, D, w->t_loc_b, l_emb_t, D, n_rows, D, D, 2 /*tanh*/, st));
+    hipLaunchKernelGGL(seg_mean_kernel, dim3((unsigned)Nc), dim3(256), 0, st, words, cap_off, cap_len, D, cap_ave);
+    ITR_CHECK_LAUNCH("sgraf seg_mean");
+    SG_TRY(gemm_nt(cap_ave, D, w->t_glo_w, D, w->t_glo_b, g_emb_t, D, Nc, D, D, 2, st));
+    hipLaunchKernelGGL(sa_pool_kernel, dim3((unsigned)Nc), dim3(256), 0, st, words, l_emb_t, g_emb_t, w->t_com_w, w->t_com_b, cap_off,
+                       cap_len, 0, D, cap_glo);
+    ITR_CHECK_LAUNCH("sgraf sa_pool (caption)");
+    // ---- operand prep for the pair stage
+    hipLaunchKernelGGL(transpose_img_kernel, dim3((unsigned)ceil_div(D, 64), (unsigned)Ni), dim3(256), 0, st, img, SC_R, D, imgT);
+    ITR_CHECK_LAUNCH("sgraf transpose");
+    SG_TRY(scan_prepare_impl(img, words, cap_off, cap_len, tile_begin_dev, cap_order_dev, n_tiles, Ni, Nc, n_rows, SC_R, D, 0,
+                             scan_ws, scan_bytes, cap_col, stream));
+    // the tile-packed words live at a fixed place of the scan workspace (scan_carve: meta first, then wtiled)
+    const float *wtiled = reinterpret_cast<const float *>(static_cast<char *>(scan_ws) + al((size_t)n_tiles * sizeof(ScanTileMeta)));
+
+    PairArgs pa{Xglo, Xloc, cap_col, cap_len, Nc, ncols, S};
+    for (int64_t i0 = 0; i0 < Ni; i0 += IB) {
+        const int64_t nb = (Ni - i0 < IB) ? Ni - i0 : IB;
+        // 1. attention weights + context norms  (SCAN_attention: clipped_l2norm, smooth 9)
+        SG_TRY(scan_scores_impl(img, n_tiles, Ni, Nc, n_rows, SC_R, D, 0, 0, 0, 9.0f, 6.0f, sscr, Nc, scan_ws, scan_bytes, P, cn, i0,
+                                nb, stream));
+        // 2. (l2norm(ctx) - E)^2 per image, 3. sim_loc
+        for (int64_t ii = 0; ii < nb; ++ii)
+            SG_TRY(gemm_nt_sqdiff(P + ii * ncols * SC_R, SC_R, imgT + (i0 + ii) * D * SC_R, SC_R, cn + ii * ncols, wtiled, D,
+                                  Aloc + ii * ncols * D, D, ncols, D, SC_R, st));
+        SG_TRY(gemm_nt(Aloc, D, w->loc_w, D, w->loc_b, Xloc, S, nb * ncols, S, D, 0, st));
+        SG_TRY(norm_rows(Xloc, Xloc, nb * ncols, S, 1e-8f, 0, 0, st));
+        // 4. sim_glo
+        hipLaunchKernelGGL(glo_sqdiff_kernel, dim3((unsigned)Nc, (unsigned)nb), dim3(256), 0, st, img_glo + i0 * D, cap_glo, Nc, D, Aglo);
+        ITR_CHECK_LAUNCH("sgraf glo_sqdiff");
+        SG_TRY(gemm_nt(Aglo, D, w->glo_w, D, w->glo_b, Xglo, S, nb * Nc, S, D, 0, st));
+        SG_TRY(norm_rows(Xglo, Xglo, nb * Nc, S, 1e-8f, 0, 0, st));
+        const int64_t npairs = nb * Nc;
+        if (module == 0) {
+            hipLaunchKernelGGL(saf_pair_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), 0, st, pa, w->saf_w, w->saf_b, w->saf_bn_w,
+                               w->saf_bn_b, w->saf_bn_mean, w->saf_bn_var, w->eval_w, w->eval_b, npairs, Sout, ldS, i0);
+            ITR_CHECK_LAUNCH("sgraf saf_pair");
+        } else {
+            const size_t lds = (size_t)2 * (max_len + 1) * S * 4;
+            ITR_UNSUPPORTED(lds > 64 * 1024, "itr_sgraf_scores: (max_len+1) * sim_dim too large for the SGR pair kernel");
+            for (int k = 0; k < sgr_step; ++k) {
+                const int last = (k == sgr_step - 1);
+                SG_TRY(gemm_nt(Xloc, S, w->sgr_q_w[k], S, w->sgr_q_b[k], Qloc, S, nb * ncols, S, S, 0, st));
+                SG_TRY(gemm_nt(Xglo, S, w->sgr_q_w[k], S, w->sgr_q_b[k], Qglo, S, nb * Nc, S, S, 0, st));
+                SG_TRY(gemm_nt(Xloc, S, w->sgr_k_w[k], S, w->sgr_k_b[k], Kloc, S, nb * ncols, S, S, 0, st));
+                SG_TRY(gemm_nt(Xglo, S, w->sgr_k_w[k], S, w->sgr_k_b[k], Kglo, S, nb * Nc, S, S, 0, st));
+                hipLaunchKernelGGL(sgr_pair_kernel, dim3((unsigned)npairs), dim3(64), lds, st, pa, Qglo, Qloc, Kglo, Kloc, Yglo, Yloc,
+                                   npairs, max_len + 1, last);
+                ITR_CHECK_LAUNCH("sgraf sgr_pair");
+                // NOTE: a word node is shared by all captions... it is NOT: node rows are per (image, word) and a word
+                // belongs to one caption, so writing Yloc rows per pair is race-free.
+                if (!last) SG_TRY(gemm_nt(Yloc, S, w->sgr_g_w[k], S, w->sgr_g_b[k], Xloc, S, nb * ncols, S, S, 1 /*relu*/, st));
+                SG_TRY(gemm_nt(Yglo, S, w->sgr_g_w[k], S, w->sgr_g_b[k], Xglo, S, nb * Nc, S, S, 1, st));
+            }
+            hipLaunchKernelGGL(sgr_final_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), 0, st, Xglo, Nc, S, w->eval_w, w->eval_b,
+                               npairs, Sout, ldS, i0);
+            ITR_CHECK_LAUNCH("sgraf sgr_final");
+        }
+    }
+#undef SG_TRY
+    return ITR_OK;
+}

@@ -35,11 +35,26 @@ SIGNATURES = {
     "itr_scan_workspace_bytes": (sz, [i64, i32, i64, i64, i64, i32]),
     "itr_scan_prepare": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, sz, vp]),
     "itr_scan_xattn_scores": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp, sz, vp]),
+    "itr_sgraf_workspace_bytes": (sz, [i64, i64, i64, i64, i32, i32, i32]),
+    "itr_sgraf_scores": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, i64, vp, sz, vp]),
     "itr_debug_scan_occupancy": (i32, [vp, vp]),
     "itr_rank_gather_gt": (i32, [vp, i64, i64, i64, i64, i32, vp, vp]),
     "itr_rank_counts": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
     "itr_recall_from_ranks": (i32, [vp, i64, vp]),
 }
+
+
+
+class SgrafWeights(C.Structure):
+    """itr_sgraf_weights (include/itr_hip.h)."""
+    _single = ["v_loc_w", "v_loc_b", "v_loc_bn_w", "v_loc_bn_b", "v_loc_bn_mean", "v_loc_bn_var",
+               "v_glo_w", "v_glo_b", "v_glo_bn_w", "v_glo_bn_b", "v_glo_bn_mean", "v_glo_bn_var", "v_com_w", "v_com_b",
+               "t_loc_w", "t_loc_b", "t_glo_w", "t_glo_b", "t_com_w", "t_com_b",
+               "loc_w", "loc_b", "glo_w", "glo_b", "eval_w", "eval_b",
+               "saf_w", "saf_b", "saf_bn_w", "saf_bn_b", "saf_bn_mean", "saf_bn_var"]
+    _arrays = ["sgr_q_w", "sgr_q_b", "sgr_k_w", "sgr_k_b", "sgr_g_w", "sgr_g_b"]
+    _fields_ = [(n, C.c_void_p) for n in _single] + [(n, C.c_void_p * 8) for n in _arrays]
+
 
 _lib = None
 

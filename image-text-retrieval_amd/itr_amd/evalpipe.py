@@ -127,8 +127,14 @@ class GruModelEval:
     #   tokens_packed / tok_off / lengths_sorted  this rank's caption slice, sorted by length (descending)
     #   order_local                               original LOCAL caption index of each sorted position
     #   n_img_total, n_cap_total
+    def sgraf_eval(self, sim_weights, feats_local, tokens_packed, tok_off, lengths_sorted, order_local, n_img_total,
+                   n_cap_total, im_div=5, timers=None):
+        """Same sharding as scan_eval with the SGRAF similarity (EncoderSimilarity) as the scorer."""
+        return self.scan_eval(feats_local, tokens_packed, tok_off, lengths_sorted, order_local, n_img_total,
+                              n_cap_total, im_div, timers, sgraf_weights=sim_weights)
+
     def scan_eval(self, feats_local, tokens_packed, tok_off, lengths_sorted, order_local, n_img_total,
-                  n_cap_total, im_div=5, timers=None):
+                  n_cap_total, im_div=5, timers=None, sgraf_weights=None):
         comm = self.comm
         cfg = self.cfg
         dev = feats_local.device
@@ -158,6 +164,14 @@ class GruModelEval:
         plan = ops.ScanPlan(cap_off, cap_len, words_all.shape[0], dev)
         # -- step 3: local row block
         xa = cfg.get('cross_attn', 't2i')
+        if sgraf_weights is not None:
+            if timers is not None:
+                timers['scan_start'].record()
+            S = ops.sgraf_scores(img, words_all, plan, sgraf_weights, cfg.get('module_name', 'SAF'), cfg.get('sgr_step', 3))
+            if timers is not None:
+                timers['scan_end'].record()
+            row0 = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)[0]
+            return S, finalize_ranks(comm, S, row0, n_img_total, im_div), plan
         ws = ops.scan_prepare(img, words_all, plan, xa)
         if timers is not None:
             timers['scan_start'].record()

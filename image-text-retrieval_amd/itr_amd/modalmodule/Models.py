@@ -7,7 +7,7 @@ loss has a HIP backward (dL/dS), the towers do not."""
 import torch
 from torch import nn
 
-from . import ImgEncoder, TextEncoder, Objectives
+from . import ImgEncoder, TextEncoder, Objectives, Fusionmodule
 
 
 class base_module(nn.Module):
@@ -126,4 +126,35 @@ class SCAN(base_module):
     def forward_loss(self, img_emb, cap_emb, cap_lens):
         loss = self.criterion(img_emb, cap_emb, cap_lens)
         self._log('Loss', loss.data, img_emb.size(0))
+        return loss
+
+
+class SGRAF(base_module):
+    """Similarity Reasoning and Filtration network (Models.py:468-546)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.img_enc = ImgEncoder.EncoderImagePrecomp(config['img_dim'], config['embed_size'],
+                                                      no_imgnorm=config['no_imgnorm'], precomp_enc_type='basic')
+        self.txt_enc = TextEncoder.EncoderText(config['vocab_size'], config['word_dim'], config['embed_size'],
+                                               config['num_layers'], use_bi_gru=config['bi_gru'],
+                                               no_txtnorm=config['no_txtnorm'], dropout=.4)
+        self.sim_enc = Fusionmodule.EncoderSimilarity(config['embed_size'], config['sim_dim'], config['module_name'],
+                                                      config['sgr_step'])
+        self.img_enc.cuda()
+        self.txt_enc.cuda()
+        self.sim_enc.cuda()
+        self.criterion = Objectives.ContrastiveLoss(config=config, margin=config['margin'], measure=config['measure'],
+                                                    max_violation=config['max_violation'])
+        self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters()) + list(self.sim_enc.parameters())
+        self.calculate_params()
+
+    def forward_emb(self, images, captions, lengths, *args, **kwargs):
+        img_embs = self.img_enc(self._dev(images))
+        cap_embs, _ = self.txt_enc(self._dev(captions), lengths)
+        return img_embs, cap_embs
+
+    def forward_loss(self, sims):
+        loss = self.criterion(sims)
+        self._log('Loss', loss.item(), sims.size(0))
         return loss

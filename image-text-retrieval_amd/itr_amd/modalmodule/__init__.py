@@ -1,6 +1,6 @@
 """get_model with the reference's dispatch (itr/modalmodule/__init__.py:4-19).  The reference's config hook
 renames 'VSE++' to 'VSE_PP' while get_model only matches 'VSE++' (KeyError); both spell here."""
-from . import Models, ImgEncoder, TextEncoder, Objectives, utils  # noqa: F401
+from . import Models, ImgEncoder, TextEncoder, Objectives, Fusionmodule, utils  # noqa: F401
 
 _BUILT = {'VSE++': 'VSE_PP', 'VSE_PP': 'VSE_PP', 'SCAN': 'SCAN', 'SGRAF': 'SGRAF', 'SAEM': 'SAEM', 'CAMERA': 'CAMERA'}
 

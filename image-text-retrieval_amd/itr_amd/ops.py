@@ -263,6 +263,74 @@ def scan_xattn_padded(images, captions, cap_lens, **kw):
 
 
 # ------------------------------------------------------------------------------------------
+_SGRAF_MAP = {
+    "v_loc_w": "v_global_w.embedding_local.0.weight", "v_loc_b": "v_global_w.embedding_local.0.bias",
+    "v_loc_bn_w": "v_global_w.embedding_local.1.weight", "v_loc_bn_b": "v_global_w.embedding_local.1.bias",
+    "v_loc_bn_mean": "v_global_w.embedding_local.1.running_mean", "v_loc_bn_var": "v_global_w.embedding_local.1.running_var",
+    "v_glo_w": "v_global_w.embedding_global.0.weight", "v_glo_b": "v_global_w.embedding_global.0.bias",
+    "v_glo_bn_w": "v_global_w.embedding_global.1.weight", "v_glo_bn_b": "v_global_w.embedding_global.1.bias",
+    "v_glo_bn_mean": "v_global_w.embedding_global.1.running_mean", "v_glo_bn_var": "v_global_w.embedding_global.1.running_var",
+    "v_com_w": "v_global_w.embedding_common.0.weight", "v_com_b": "v_global_w.embedding_common.0.bias",
+    "t_loc_w": "t_global_w.embedding_local.0.weight", "t_loc_b": "t_global_w.embedding_local.0.bias",
+    "t_glo_w": "t_global_w.embedding_global.0.weight", "t_glo_b": "t_global_w.embedding_global.0.bias",
+    "t_com_w": "t_global_w.embedding_common.0.weight", "t_com_b": "t_global_w.embedding_common.0.bias",
+    "loc_w": "sim_tranloc_w.weight", "loc_b": "sim_tranloc_w.bias", "glo_w": "sim_tranglo_w.weight",
+    "glo_b": "sim_tranglo_w.bias", "eval_w": "sim_eval_w.weight", "eval_b": "sim_eval_w.bias",
+}
+_SAF_MAP = {"saf_w": "SAF_module.attn_sim_w.weight", "saf_b": "SAF_module.attn_sim_w.bias",
+            "saf_bn_w": "SAF_module.bn.weight", "saf_bn_b": "SAF_module.bn.bias",
+            "saf_bn_mean": "SAF_module.bn.running_mean", "saf_bn_var": "SAF_module.bn.running_var"}
+
+
+def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, out=None):
+    """EncoderSimilarity.forward (Fusionmodule.py:406-451), eval mode.  images (Ni, 36, D); words (n_rows, D)
+    with the caption layout of `plan` (ScanPlan on the WORD lengths); weights: the module's state_dict."""
+    lib = _lib.load()
+    if module_name not in ('SAF', 'SGR'):
+        raise ValueError('Invalid input of config.module_name in configs.py')
+    images = _dev(images, name="images")
+    words = _dev(words, name="words")
+    Ni, R, D = images.shape
+    keep = []
+    st = _lib.SgrafWeights()
+
+    def ptr(name):
+        t = _dev(weights[name].detach(), name=name)
+        keep.append(t)
+        return t.data_ptr()
+
+    for f, name in _SGRAF_MAP.items():
+        setattr(st, f, ptr(name))
+    S_dim = weights["sim_tranloc_w.weight"].shape[0]
+    if module_name == 'SAF':
+        for f, name in _SAF_MAP.items():
+            setattr(st, f, ptr(name))
+    else:
+        for k in range(sgr_step):
+            pre = "SGR_module.sgr%d." % k
+            st.sgr_q_w[k] = ptr(pre + "graph_query_w.weight"); st.sgr_q_b[k] = ptr(pre + "graph_query_w.bias")
+            st.sgr_k_w[k] = ptr(pre + "graph_key_w.weight"); st.sgr_k_b[k] = ptr(pre + "graph_key_w.bias")
+            st.sgr_g_w[k] = ptr(pre + "sim_graph_w.weight"); st.sgr_g_b[k] = ptr(pre + "sim_graph_w.bias")
+    mod = 0 if module_name == 'SAF' else 1
+    if out is None:
+        out = torch.empty(Ni, plan.Nc, device=images.device, dtype=torch.float32)
+    wsb = lib.itr_sgraf_workspace_bytes(Ni, plan.Nc, words.shape[0], plan.n_tiles, D, S_dim, mod)
+    ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
+    max_len = int(plan.len_host.max()) if plan.Nc else 1
+    _lib.check(lib.itr_sgraf_scores(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
+                                    _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc, words.shape[0], max_len, R, D, S_dim,
+                                    mod, int(sgr_step), C.byref(st), _p(out), out.stride(0), _p(ws), wsb, _stream()))
+    return out
+
+
+def sgraf_padded(images, captions, cap_lens, weights, module_name='SAF', sgr_step=3):
+    """Reference call shape: captions (Nc, L, D) padded + cap_lens (Fusionmodule.py:406)."""
+    Nc, L, D = captions.shape
+    lens = [int(x) for x in cap_lens][:Nc]
+    plan = ScanPlan(np.arange(Nc, dtype=np.int64) * L, lens, Nc * L, captions.device)
+    return sgraf_scores(images, _dev(captions, name="captions").reshape(Nc * L, D), plan, weights, module_name, sgr_step)
+
+
 def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtnorm=False, use_abs=False,
                gather_last=False):
     """EncoderText.forward on packed captions (TextEncoder.py:38-70).

@@ -135,6 +135,33 @@ int itr_scan_xattn_scores(const float *img, int64_t n_tiles, int64_t Ni, int64_t
                           float lambda_lse, float *S, int64_t ldS, void *workspace,
                           size_t workspace_bytes, itr_stream_t stream);
 
+/* ---- a7: EncoderSimilarity.forward (SGRAF; itr/modalmodule/Fusionmodule.py:373-664), eval mode ----
+ * img [Ni,36,D] (l2-normalised regions), words [n_rows,D] with the caption layout of the SCAN entry points
+ * (cap_off / cap_len / tile plan from itr_scan_plan_tiles on the word lengths).  module: 0 = SAF, 1 = SGR.
+ * weights: device pointers named after the reference's state_dict (row-major [out,in] like nn.Linear).
+ * S[i,c] in (0,1).  max_len = longest caption (<= 63).  workspace: itr_sgraf_workspace_bytes(...). */
+typedef struct {
+    /* v_global_w (VisualSA :464-507) */
+    const float *v_loc_w, *v_loc_b, *v_loc_bn_w, *v_loc_bn_b, *v_loc_bn_mean, *v_loc_bn_var; /* Linear[D,D], BN(36) */
+    const float *v_glo_w, *v_glo_b, *v_glo_bn_w, *v_glo_bn_b, *v_glo_bn_mean, *v_glo_bn_var; /* Linear[D,D], BN(D)  */
+    const float *v_com_w, *v_com_b;                                                          /* Linear[1,D]         */
+    /* t_global_w (TextSA :519-559) */
+    const float *t_loc_w, *t_loc_b, *t_glo_w, *t_glo_b, *t_com_w, *t_com_b;
+    /* sim_tranloc_w / sim_tranglo_w [S,D], sim_eval_w [1,S] (:391-395) */
+    const float *loc_w, *loc_b, *glo_w, *glo_b, *eval_w, *eval_b;
+    /* SAF_module.attn_sim_w [1,S], SAF_module.bn (1 channel) (:608-611) */
+    const float *saf_w, *saf_b, *saf_bn_w, *saf_bn_b, *saf_bn_mean, *saf_bn_var;
+    /* SGR_module.sgr{k}.graph_query_w / graph_key_w / sim_graph_w [S,S] (:573-576) */
+    const float *sgr_q_w[8], *sgr_q_b[8], *sgr_k_w[8], *sgr_k_b[8], *sgr_g_w[8], *sgr_g_b[8];
+} itr_sgraf_weights;
+size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_rows, int64_t n_tiles, int D, int S,
+                                 int module);
+int itr_sgraf_scores(const float *img, const float *words, const int64_t *cap_off, const int32_t *cap_len,
+                     const int32_t *tile_begin_dev, const int32_t *cap_order_dev, int64_t n_tiles,
+                     int64_t Ni, int64_t Nc, int64_t n_rows, int max_len, int R, int D, int S, int module,
+                     int sgr_step, const itr_sgraf_weights *w, float *S_out, int64_t ldS, void *workspace,
+                     size_t workspace_bytes, itr_stream_t stream);
+
 /* diagnostics (tools/): occupancy of the SCAN kernel as reported by the HIP runtime */
 int itr_debug_scan_occupancy(int *blocks_per_cu, int *lds_bytes);
 

@@ -250,6 +250,48 @@ def test_scan_errors(dev):
         ops.scan_xattn_padded(torch.zeros(2, 30, 32, device=dev), cap, [3, 3])
 
 
+# ------------------------------------------------------------------------------------------ SGRAF
+@pytest.mark.parametrize("mod", ['SAF', 'SGR'])
+def test_sgraf_golden(golden, dev, mod):
+    g = golden("g6_sgraf")
+    pre = "w_%s_" % mod
+    w = {k[len(pre):]: T(g[k]).to(dev) for k in g.files if k.startswith(pre)}
+    got = ops.sgraf_padded(T(g["images"]).to(dev), T(g["captions"]).to(dev), [int(x) for x in g["cap_lens"]], w, mod, 3)
+    assert maxdiff(got, g["sim_" + mod]) <= 5e-6
+
+
+@pytest.mark.parametrize("mod", ['SAF', 'SGR'])
+def test_sgraf_random_vs_oracle(dev, mod):
+    """more images than one 4-image block, ragged captions, D = 128, sim_dim = 64."""
+    rng = np.random.RandomState(5)
+    torch.manual_seed(5)
+    Ni, Nc, D, S = 9, 23, 128, 64
+    lens = [int(x) for x in rng.randint(1, 18, size=Nc)]
+    L = max(lens)
+    img = O.l2norm(torch.randn(Ni, 36, D), -1)
+    cap = O.l2norm(torch.randn(Nc, L, D), -1)
+    w = {}
+    def lin(name, o, i):
+        r = float(np.sqrt(6.0 / (i + o)))
+        w[name + ".weight"] = torch.empty(o, i).uniform_(-r, r)
+        w[name + ".bias"] = torch.randn(o) * 0.02
+    def bn(name, n):
+        w[name + ".weight"] = torch.empty(n).uniform_(0.8, 1.2); w[name + ".bias"] = torch.randn(n) * 0.05
+        w[name + ".running_mean"] = torch.randn(n) * 0.1; w[name + ".running_var"] = torch.empty(n).uniform_(0.5, 1.5)
+    lin("v_global_w.embedding_local.0", D, D); bn("v_global_w.embedding_local.1", 36)
+    lin("v_global_w.embedding_global.0", D, D); bn("v_global_w.embedding_global.1", D)
+    lin("v_global_w.embedding_common.0", 1, D)
+    lin("t_global_w.embedding_local.0", D, D); lin("t_global_w.embedding_global.0", D, D); lin("t_global_w.embedding_common.0", 1, D)
+    lin("sim_tranloc_w", S, D); lin("sim_tranglo_w", S, D); lin("sim_eval_w", 1, S)
+    lin("SAF_module.attn_sim_w", 1, S); bn("SAF_module.bn", 1)
+    for k in range(3):
+        for nm in ("graph_query_w", "graph_key_w", "sim_graph_w"):
+            lin("SGR_module.sgr%d.%s" % (k, nm), S, S)
+    want = O.sgraf_similarity(w, img, cap, lens, mod, 3)
+    got = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, {k: v.to(dev) for k, v in w.items()}, mod, 3)
+    assert maxdiff(got, want) <= 5e-6
+
+
 # ------------------------------------------------------------------------------------------ GRU
 def pack(ids, lengths, dev):
     toks = torch.cat([ids[b, :l] for b, l in enumerate(lengths)]).to(dev)
