@@ -242,7 +242,8 @@ extern "C" int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t 
                            itr_stream_t stream) {
     ITR_REQUIRE(A && B && C, "itr_gemm_nt: null pointer");
     ITR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "itr_gemm_nt: negative dimension");
-    ITR_REQUIRE(lda >= K && ldb >= K && ldc >= N, "itr_gemm_nt: leading dimension smaller than row");
+    // lda < K is allowed: overlapping A rows express a convolution over consecutive rows (SAEM conv head)
+    ITR_REQUIRE(lda >= 1 && ldb >= K && ldc >= N, "itr_gemm_nt: leading dimension smaller than row");
     ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt: unknown activation %d", act);
     return itr::gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream));
 }

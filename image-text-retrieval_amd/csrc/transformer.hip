@@ -1,0 +1,201 @@
+// Transformer building blocks of the BERT text tower (itr/modalmodule/bert.py:113-358) and of the SAEM / CAMERA
+// heads.  The dense layers run on gemm_nt (fp32 MFMA, erf-GELU / tanh / relu epilogues); this file holds the
+// HBM-bound glue, written as fused row kernels:
+//   itr_bert_embed_ln   word + position + token-type embedding sum + TF-style LayerNorm   (bert.py:127-157, :113-126)
+//   itr_add_layernorm   LayerNorm(x + residual), epsilon INSIDE the sqrt (1e-12)          (bert.py:216-220, :253-257)
+//   itr_mha_small       softmax(Q K^T / sqrt(dk) + (1 - mask) * -10000) V for short sequences (L <= 64), one wave
+//                       per (sequence, head), one lane per query row, online softmax       (bert.py:185-207; camera_.py:42-53)
+//   itr_relu_maxpool    max over time of relu(x) with a per-sequence valid length          (TextEncoder.py:148-149)
+#include "itr_common.h"
+
+namespace itr {
+
+constexpr int LN_MAXV = 16;   // float4 per lane -> hidden size <= 4096
+
+__device__ __forceinline__ void ln_finish(float4 (&v)[LN_MAXV], int nv, int lane, int H, const float *gamma,
+                                          const float *beta, float eps, float *out) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+        if (lane + 64 * i < nv) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    const float u = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+        if (lane + 64 * i < nv) {
+            const float a = v[i].x - u, b = v[i].y - u, c = v[i].z - u, d = v[i].w - u;
+            q += a * a + b * b + c * c + d * d;
+        }
+    const float denom = sqrtf(wave_sum(q) / (float)H + eps);   // TF style: epsilon inside the sqrt
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < nv) {
+            const float4 g = reinterpret_cast<const float4 *>(gamma)[c4], b = reinterpret_cast<const float4 *>(beta)[c4];
+            float4 o;
+            o.x = g.x * ((v[i].x - u) / denom) + b.x;
+            o.y = g.y * ((v[i].y - u) / denom) + b.y;
+            o.z = g.z * ((v[i].z - u) / denom) + b.z;
+            o.w = g.w * ((v[i].w - u) / denom) + b.w;
+            reinterpret_cast<float4 *>(out)[c4] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t *__restrict__ ids, const int64_t *__restrict__ type_ids,
+                                                       const float *__restrict__ word, const float *__restrict__ pos,
+                                                       const float *__restrict__ type, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float *__restrict__ out, int64_t rows,
+                                                       int L, int H, int64_t V, int P, int Tv, float eps) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63, nv = H >> 2;
+    int64_t id = ids[row];
+    int64_t ty = type_ids ? type_ids[row] : 0;
+    const int t = (int)(row % L);
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);        // nn.Embedding would raise; stay memory safe
+    ty = ty < 0 ? 0 : (ty >= Tv ? Tv - 1 : ty);
+    const float4 *w4 = reinterpret_cast<const float4 *>(word + id * H);
+    const float4 *p4 = reinterpret_cast<const float4 *>(pos + (int64_t)(t < P ? t : P - 1) * H);
+    const float4 *t4 = reinterpret_cast<const float4 *>(type + ty * H);
+    float4 v[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < nv) {
+            const float4 a = w4[c4], b = p4[c4], c = t4[c4];
+            v[i] = make_float4(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w);
+        }
+    }
+    ln_finish(v, nv, lane, H, gamma, beta, eps, out + row * H);
+}
+
+__global__ __launch_bounds__(256) void add_ln_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                     float *__restrict__ out, int64_t rows, int H, float eps) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63, nv = H >> 2;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + row * H);
+    const float4 *r4 = res ? reinterpret_cast<const float4 *>(res + row * H) : nullptr;
+    float4 v[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < nv) {
+            v[i] = x4[c4];
+            if (r4) { const float4 r = r4[c4]; v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w; }
+        }
+    }
+    ln_finish(v, nv, lane, H, gamma, beta, eps, out + row * H);
+}
+
+// One wave per (sequence b, head h); lane i < L owns query row i.  K and V of the head are staged in LDS.
+template <int DK>
+__global__ __launch_bounds__(64) void mha_small_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                       const float *__restrict__ v, int64_t ldq, int64_t ldk, int64_t ldv,
+                                                       const float *__restrict__ mask, float *__restrict__ out, int64_t ldo,
+                                                       int L, int heads, float scale) {
+    __shared__ float ks[64][DK + 1];
+    __shared__ float vs[64][DK + 1];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)b * L;
+    for (int idx = lane; idx < L * DK; idx += 64) {
+        const int j = idx / DK, d = idx % DK;
+        ks[j][d] = k[(row0 + j) * ldk + h * DK + d];
+        vs[j][d] = v[(row0 + j) * ldv + h * DK + d];
+    }
+    __syncthreads();
+    if (lane >= L) return;
+    float qr[DK], ctx[DK];
+#pragma unroll
+    for (int d = 0; d < DK; ++d) { qr[d] = q[(row0 + lane) * ldq + h * DK + d]; ctx[d] = 0.f; }
+    float mx = -INFINITY, den = 0.f;
+    for (int j = 0; j < L; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < DK; ++d) s += qr[d] * ks[j][d];
+        s = s * scale;
+        if (mask) s += (1.0f - mask[row0 + j]) * -10000.0f;     // bert.py:340-341 additive mask
+        const float nm = fmaxf(mx, s);
+        const float corr = expf(mx - nm), p = expf(s - nm);
+        den = den * corr + p;
+#pragma unroll
+        for (int d = 0; d < DK; ++d) ctx[d] = ctx[d] * corr + p * vs[j][d];
+        mx = nm;
+    }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int d = 0; d < DK; ++d) out[(row0 + lane) * ldo + h * DK + d] = ctx[d] * inv;
+}
+
+// out[b, c] = max_{t < valid} relu(x[b, t, c])
+__global__ __launch_bounds__(256) void relu_maxpool_kernel(const float *__restrict__ x, int L, int C, int valid,
+                                                           float *__restrict__ out, int64_t ldo) {
+    const int64_t b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float m = 0.f;   // relu >= 0
+    for (int t = 0; t < valid; ++t) m = fmaxf(m, x[(b * L + t) * (int64_t)C + c]);
+    out[b * ldo + c] = m;
+}
+
+}  // namespace itr
+
+extern "C" int itr_bert_embed_ln(const int64_t *ids, const int64_t *type_ids, const float *word_emb, const float *pos_emb,
+                                 const float *type_emb, const float *gamma, const float *beta, float *out, int64_t B,
+                                 int L, int H, int64_t vocab, int max_pos, int type_vocab, float eps,
+                                 itr_stream_t stream) {
+    ITR_REQUIRE(ids && word_emb && pos_emb && type_emb && gamma && beta && out, "itr_bert_embed_ln: null pointer");
+    ITR_REQUIRE(B >= 0 && L >= 1 && H >= 4 && vocab >= 1 && max_pos >= 1 && type_vocab >= 1, "itr_bert_embed_ln: bad shape");
+    ITR_UNSUPPORTED(H % 4 != 0 || H > 64 * 4 * itr::LN_MAXV, "itr_bert_embed_ln: hidden size must be a multiple of 4, <= 4096");
+    ITR_REQUIRE(L <= max_pos, "itr_bert_embed_ln: sequence length %d exceeds max_position_embeddings %d", L, max_pos);
+    if (B == 0) return ITR_OK;
+    const int64_t rows = B * L;
+    hipLaunchKernelGGL(itr::embed_ln_kernel, dim3((unsigned)itr::ceil_div(rows, 4)), dim3(256), 0, itr::as_stream(stream), ids,
+                       type_ids, word_emb, pos_emb, type_emb, gamma, beta, out, rows, L, H, vocab, max_pos, type_vocab, eps);
+    ITR_CHECK_LAUNCH("embed_ln");
+    return ITR_OK;
+}
+
+extern "C" int itr_add_layernorm(const float *x, const float *residual, const float *gamma, const float *beta, float *out,
+                                 int64_t rows, int H, float eps, itr_stream_t stream) {
+    ITR_REQUIRE(x && gamma && beta && out, "itr_add_layernorm: null pointer");
+    ITR_REQUIRE(rows >= 0 && H >= 4, "itr_add_layernorm: bad shape");
+    ITR_UNSUPPORTED(H % 4 != 0 || H > 64 * 4 * itr::LN_MAXV, "itr_add_layernorm: hidden size must be a multiple of 4, <= 4096");
+    if (rows == 0) return ITR_OK;
+    hipLaunchKernelGGL(itr::add_ln_kernel, dim3((unsigned)itr::ceil_div(rows, 4)), dim3(256), 0, itr::as_stream(stream), x, residual,
+                       gamma, beta, out, rows, H, eps);
+    ITR_CHECK_LAUNCH("add_layernorm");
+    return ITR_OK;
+}
+
+extern "C" int itr_mha_small(const float *q, const float *k, const float *v, int64_t ldq, int64_t ldk, int64_t ldv,
+                             const float *mask, float *out, int64_t ldo, int64_t B, int L, int heads, int dk,
+                             float scale, itr_stream_t stream) {
+    ITR_REQUIRE(q && k && v && out, "itr_mha_small: null pointer");
+    ITR_REQUIRE(B >= 0 && L >= 1 && heads >= 1, "itr_mha_small: bad shape");
+    ITR_UNSUPPORTED(L > 64, "itr_mha_small: sequences of at most 64 positions (got %d)", L);
+    ITR_UNSUPPORTED(dk != 16 && dk != 32 && dk != 64, "itr_mha_small: head size must be 16, 32 or 64 (got %d)", dk);
+    ITR_REQUIRE(B * heads < 0x7fffffffLL, "itr_mha_small: grid too large");
+    if (B == 0) return ITR_OK;
+    const dim3 grid((unsigned)(B * heads));
+    hipStream_t st = itr::as_stream(stream);
+    if (dk == 16) hipLaunchKernelGGL(itr::mha_small_kernel<16>, grid, dim3(64), 0, st, q, k, v, ldq, ldk, ldv, mask, out, ldo, L, heads, scale);
+    else if (dk == 32) hipLaunchKernelGGL(itr::mha_small_kernel<32>, grid, dim3(64), 0, st, q, k, v, ldq, ldk, ldv, mask, out, ldo, L, heads, scale);
+    else hipLaunchKernelGGL(itr::mha_small_kernel<64>, grid, dim3(64), 0, st, q, k, v, ldq, ldk, ldv, mask, out, ldo, L, heads, scale);
+    ITR_CHECK_LAUNCH("mha_small");
+    return ITR_OK;
+}
+
+extern "C" int itr_relu_maxpool(const float *x, float *out, int64_t ldo, int64_t B, int L, int C, int valid,
+                                itr_stream_t stream) {
+    ITR_REQUIRE(x && out, "itr_relu_maxpool: null pointer");
+    ITR_REQUIRE(B >= 0 && B <= 65535 && L >= 1 && C >= 1 && valid >= 1 && valid <= L && ldo >= C, "itr_relu_maxpool: bad shape");
+    if (B == 0) return ITR_OK;
+    hipLaunchKernelGGL(itr::relu_maxpool_kernel, dim3((unsigned)itr::ceil_div(C, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), x,
+                       L, C, valid, out, ldo);
+    ITR_CHECK_LAUNCH("relu_maxpool");
+    return ITR_OK;
+}

@@ -35,6 +35,10 @@ SIGNATURES = {
     "itr_scan_workspace_bytes": (sz, [i64, i32, i64, i64, i64, i32]),
     "itr_scan_prepare": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, sz, vp]),
     "itr_scan_xattn_scores": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp, sz, vp]),
+    "itr_bert_embed_ln": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, i32, i32, f32, vp]),
+    "itr_add_layernorm": (i32, [vp, vp, vp, vp, vp, i64, i32, f32, vp]),
+    "itr_mha_small": (i32, [vp, vp, vp, i64, i64, i64, vp, vp, i64, i64, i32, i32, i32, f32, vp]),
+    "itr_relu_maxpool": (i32, [vp, vp, i64, i64, i32, i32, i32, vp]),
     "itr_sgraf_workspace_bytes": (sz, [i64, i64, i64, i64, i32, i32, i32]),
     "itr_sgraf_scores": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, i64, vp, sz, vp]),
     "itr_debug_scan_occupancy": (i32, [vp, vp]),

@@ -8,6 +8,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from . import bert
 
 
 class EncoderImagePrecomp(nn.Module):
@@ -60,3 +61,22 @@ class EncoderImagePooledPrecomp(EncoderImagePrecomp):
         if images.dim() == 3:
             images = ops.mean_mid(images)
         return super().forward(images)
+
+
+class TransformerMapping(nn.Module):
+    """SAEM image tower: Linear(img_dim -> final_dims) -> one BERTLayer -> mean over regions -> F.normalize
+    (ImgEncoder.py:324-350).  `trans_cfg` is not shipped with the reference: hidden_size must equal
+    final_dims, the head size must be 16 / 32 / 64."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        bert_config = bert.BertConfig.from_json_file(config['trans_cfg'])
+        self.layer = bert.BERTLayer(bert_config)
+        self.mapping = nn.Linear(config['img_dim'], config['final_dims'])
+
+    def forward(self, x):
+        x = ops.linear(x, self.mapping.weight.detach(), self.mapping.bias.detach())
+        hidden_states = self.layer(x, None)                 # all-ones mask == no mask
+        embed = ops.mean_mid(hidden_states)
+        return ops.normalize(embed, dim=1)

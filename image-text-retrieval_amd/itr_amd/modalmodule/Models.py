@@ -158,3 +158,31 @@ class SGRAF(base_module):
         loss = self.criterion(sims)
         self._log('Loss', loss.item(), sims.size(0))
         return loss
+
+
+class SAEM(base_module):
+    """SAEM (Models.py:369-464): BERT text tower + transformer image tower, cosine via pdist_cos."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.img_enc = ImgEncoder.TransformerMapping(config)
+        self.txt_enc = TextEncoder.BertMapping(config)
+        self.txt_enc.cuda()
+        self.img_enc.cuda()
+        self.criterion = Objectives.ContrastiveLoss(config=config, margin=config['margin'], measure=config['measure'],
+                                                    max_violation=config['max_violation'])
+        self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters())
+        self.calculate_params()
+        self.no_decay = ['bias', 'gamma', 'beta']
+
+    def forward_emb(self, images, captions, captions_mask, captions_type_ids, lengths, *args, **kwargs):
+        cap_embs = self.txt_enc(self._dev(captions), self._dev(captions_mask), self._dev(captions_type_ids), lengths)
+        img_embs = self.img_enc(self._dev(images))
+        return img_embs, cap_embs
+
+    def forward_loss(self, epoch, img_emb, cap_emb, cap_len, ids):
+        """Ranking term only: the AngularLoss / weight-decay terms (Models.py:419-442) are training-time
+        auxiliaries and belong with the tower backward (8f-3)."""
+        loss1 = self.criterion(img_emb, cap_emb, cap_len)
+        self._log('Loss1', loss1.item(), img_emb.size(0))
+        return loss1

@@ -4,6 +4,8 @@ import torch
 from torch import nn
 
 from .. import ops
+from . import bert
+from .bert import BertConfig, BertModel
 
 
 def pack_tokens(x, lengths):
@@ -64,3 +66,64 @@ class EncoderText(nn.Module):
         cap_emb = torch.zeros(B, L, self.embed_size, device=x.device, dtype=torch.float32)
         cap_emb[mask[:, :L]] = out                    # scatter back to the padded layout (plumbing)
         return cap_emb, cap_len
+
+
+class BertMapping(nn.Module):
+    """SAEM text tower: frozen BERT + conv / pooling / transformer head + Linear + F.normalize
+    (TextEncoder.py:74-157).  txt_stru='rnn' divides tensor sizes by a float in the reference
+    (TextEncoder.py:135) and cannot run there either: not built."""
+
+    def __init__(self, config):
+        super().__init__()
+        bert_config = BertConfig.from_json_file(config['bert_config_file'])
+        self.bert = BertModel(bert_config)
+        self.bert.load_state_dict(torch.load(config['init_checkpoint'], map_location='cpu'))
+        self.freeze_layers(self.bert)
+        self.txt_stru = config['txt_stru']
+        if config['txt_stru'] == 'pooling':
+            self.mapping_0 = nn.Linear(bert_config.hidden_size, bert_config.hidden_size)
+            self.mapping = nn.Linear(bert_config.hidden_size, config['final_dims'])
+        elif config['txt_stru'] == 'cnn':
+            Ks = [1, 2, 3]
+            self.convs1 = nn.ModuleList([nn.Conv2d(1, 512, (K, bert_config.hidden_size)) for K in Ks])
+            self.mapping = nn.Linear(len(Ks) * 512, config['final_dims'])
+        elif config['txt_stru'] == 'trans':
+            trans_config = BertConfig.from_json_file(config['trans_cfg'])
+            self.layer = bert.BERTLayer(trans_config)
+            self.mapping_0 = nn.Linear(bert_config.hidden_size, trans_config.hidden_size)
+            self.mapping = nn.Linear(trans_config.hidden_size, config['final_dims'])
+        elif config['txt_stru'] == 'rnn':
+            raise NotImplementedError("txt_stru='rnn' is broken in the reference (float slicing, TextEncoder.py:135)")
+        else:
+            raise ValueError("Unknown txt_stru: {}".format(config['txt_stru']))
+
+    def forward(self, input_ids, attention_mask, token_type_ids, lengths):
+        all_encoder_layers, _ = self.bert(input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask)
+        last = all_encoder_layers[-1]
+        B, L, H = last.shape
+        if self.txt_stru == 'pooling':
+            output = ops.mean_mid(ops.linear(last, self.mapping_0.weight.detach(), self.mapping_0.bias.detach()))
+        elif self.txt_stru == 'cnn':
+            flat = last.reshape(B * L, H)
+            C = self.convs1[0].out_channels
+            output = torch.empty(B, C * len(self.convs1), device=last.device, dtype=torch.float32)
+            for n, conv in enumerate(self.convs1):
+                K = conv.kernel_size[0]
+                if L < K:
+                    raise ValueError("sequence shorter than the conv window")
+                buf = torch.empty(B * L, C, device=last.device, dtype=torch.float32)
+                # Conv2d(1, C, (K, H)) == GEMM over K consecutive token rows (rows overlap: lda = H, K_dim = K*H)
+                ops.linear_strided(flat, H, B * L - (K - 1), K * H, conv.weight.detach().reshape(C, K * H),
+                                   conv.bias.detach(), None, out=buf)
+                ops.relu_maxpool(buf.view(B, L, C), L - K + 1, out=output[:, n * C:(n + 1) * C])
+        else:  # trans
+            hidden = ops.linear(last, self.mapping_0.weight.detach(), self.mapping_0.bias.detach())
+            hidden = self.layer(hidden, attention_mask.to(last.device).to(torch.float32))
+            output = ops.mean_mid(hidden)
+        code = ops.linear(output, self.mapping.weight.detach(), self.mapping.bias.detach())
+        return ops.normalize(code, dim=1)
+
+    def freeze_layers(self, model):
+        for child in model.children():
+            for param in child.parameters():
+                param.requires_grad = False

@@ -95,6 +95,24 @@ def linear(x, weight, bias=None, act=None):
     return out
 
 
+def linear_strided(base, lda, M, K, weight, bias=None, act=None, out=None):
+    """act(A @ weight^T + bias) where row m of A starts at base.data_ptr() + m*lda floats and is K long (rows may
+    overlap: SAEM's Conv2d(1, C, (k, 768)) over a token sequence is this GEMM with lda = 768, K = k*768)."""
+    lib = _lib.load()
+    base = _dev(base, name="base")
+    weight = _dev(weight, name="weight")
+    if weight.shape[1] != K:
+        raise ValueError("linear_strided: K=%d vs weight %s" % (K, tuple(weight.shape)))
+    if (M - 1) * lda + K > base.numel():
+        raise ValueError("linear_strided: the last row reads past the end of the buffer")
+    N = weight.shape[0]
+    b = _dev(bias, name="bias") if bias is not None else None
+    if out is None:
+        out = torch.empty(M, N, device=base.device, dtype=torch.float32)
+    _lib.check(lib.itr_gemm_nt(_p(base), lda, _p(weight), K, _p(b), _p(out), out.stride(0), M, N, K, _ACTS[act], _stream()))
+    return out
+
+
 def proj_l2norm(images, weight, bias, no_imgnorm=False, use_abs=False):
     """EncoderImagePrecomp.forward (ImgEncoder.py:133-147)."""
     lib = _lib.load()
@@ -260,6 +278,59 @@ def scan_xattn_padded(images, captions, cap_lens, **kw):
     lens = [int(x) for x in cap_lens][:Nc]
     plan = ScanPlan(np.arange(Nc, dtype=np.int64) * L, lens, Nc * L, captions.device)
     return scan_xattn_scores(images, _dev(captions, name="captions").reshape(Nc * L, D), plan, **kw)
+
+
+# ------------------------------------------------------------------------------------------ transformer blocks
+def bert_embed_ln(ids, type_ids, word_emb, pos_emb, type_emb, gamma, beta, eps=1e-12):
+    lib = _lib.load()
+    ids = _dev(ids, torch.int64, "input_ids")
+    ty = _dev(type_ids, torch.int64, "token_type_ids") if type_ids is not None else None
+    B, L = ids.shape
+    H = word_emb.shape[1]
+    out = torch.empty(B, L, H, device=ids.device, dtype=torch.float32)
+    _lib.check(lib.itr_bert_embed_ln(_p(ids), _p(ty), _p(_dev(word_emb)), _p(_dev(pos_emb)), _p(_dev(type_emb)),
+                                     _p(_dev(gamma)), _p(_dev(beta)), _p(out), B, L, H, word_emb.shape[0],
+                                     pos_emb.shape[0], type_emb.shape[0], eps, _stream()))
+    return out
+
+
+def add_layernorm(x, residual, gamma, beta, eps=1e-12):
+    """BERTLayerNorm(x + residual) (bert.py:113-126): epsilon inside the sqrt."""
+    lib = _lib.load()
+    x = _dev(x, name="x")
+    r = _dev(residual, name="residual") if residual is not None else None
+    H = x.shape[-1]
+    out = torch.empty_like(x)
+    _lib.check(lib.itr_add_layernorm(_p(x), _p(r), _p(_dev(gamma)), _p(_dev(beta)), _p(out), x.numel() // H, H, eps,
+                                     _stream()))
+    return out
+
+
+def mha_small(q, k, v, mask, B, L, heads, dk, scale):
+    """q, k, v: 2-D views [B*L, *] (last dim contiguous, head h at columns h*dk .. h*dk+dk-1; they may be column
+    slices of one fused QKV buffer).  mask: (B, L) float 0/1 or None.  -> (B*L, heads*dk)."""
+    lib = _lib.load()
+    for t in (q, k, v):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise ValueError("mha_small: q/k/v must be fp32 CUDA tensors with a contiguous last dim")
+    m = _dev(mask.to(torch.float32), name="mask") if mask is not None else None
+    out = torch.empty(B * L, heads * dk, device=q.device, dtype=torch.float32)
+    _lib.check(lib.itr_mha_small(_p(q), _p(k), _p(v), q.stride(0), k.stride(0), v.stride(0), _p(m), _p(out),
+                                 out.stride(0), B, L, heads, dk, float(scale), _stream()))
+    return out
+
+
+def relu_maxpool(x, valid, out=None):
+    """x (B, L, C) -> max over t < valid of relu(x) -> (B, C)."""
+    lib = _lib.load()
+    x = _dev(x, name="x")
+    B, L, Cc = x.shape
+    if out is None:
+        out = torch.empty(B, Cc, device=x.device, dtype=torch.float32)
+    for b0 in range(0, B, 65535):
+        b1 = min(B, b0 + 65535)
+        _lib.check(lib.itr_relu_maxpool(_p(x[b0:b1]), _p(out[b0:b1]), out.stride(0), b1 - b0, L, Cc, int(valid), _stream()))
+    return out
 
 
 # ------------------------------------------------------------------------------------------

@@ -52,7 +52,7 @@ int itr_mean_mid(const float *x, float *y, int64_t B, int R, int F, itr_stream_t
 
 /* ---- generic fp32 MFMA GEMM used by the towers ----------------------------------------
  * C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]);  lda/ldb/ldc are row strides in elements.
- * bias may be NULL.  act: 0 none, 1 relu, 2 tanh, 3 sigmoid, 4 gelu(erf), 5 leaky_relu(0.1).
+ * bias may be NULL.  lda < K is allowed (overlapping A rows = a convolution over consecutive rows).  act: 0 none, 1 relu, 2 tanh, 3 sigmoid, 4 gelu(erf), 5 leaky_relu(0.1).
  * Exact fp32 (v_mfma_f32_32x32x2_f32).  Replaces nn.Linear / torch.mm call sites on the path
  * (ImgEncoder.py:137, Objectives.py:21, Fusionmodule.py:427-431 ...). */
 int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
@@ -134,6 +134,24 @@ int itr_scan_xattn_scores(const float *img, int64_t n_tiles, int64_t Ni, int64_t
                           int R, int D, int mode, int norm, int agg, float lambda_softmax,
                           float lambda_lse, float *S, int64_t ldS, void *workspace,
                           size_t workspace_bytes, itr_stream_t stream);
+
+/* ---- a11: BERT building blocks (itr/modalmodule/bert.py:113-358); the dense layers use itr_gemm_nt (act 4 =
+ * erf-GELU :29-34, act 2 = tanh pooler :299-302).
+ * itr_bert_embed_ln : out[b,t,:] = LN(word[ids] + pos[t] + type[type_ids]) (:127-157); type_ids may be NULL (zeros).
+ * itr_add_layernorm : out = LN(x + residual) with the TF-style epsilon inside the sqrt (:113-126); residual may be NULL.
+ * itr_mha_small     : per (sequence, head): softmax(Q K^T * scale + (1 - mask) * -10000) V for L <= 64 (:185-207);
+ *                     q/k/v are [B*L, ld*] views (heads contiguous, head h at column h*dk); mask [B*L] of 0/1 or NULL.
+ * itr_relu_maxpool  : out[b,c] = max_{t<valid} relu(x[b,t,c])  (SAEM conv head, TextEncoder.py:148-149). */
+int itr_bert_embed_ln(const int64_t *ids, const int64_t *type_ids, const float *word_emb, const float *pos_emb,
+                      const float *type_emb, const float *gamma, const float *beta, float *out, int64_t B,
+                      int L, int H, int64_t vocab, int max_pos, int type_vocab, float eps, itr_stream_t stream);
+int itr_add_layernorm(const float *x, const float *residual, const float *gamma, const float *beta, float *out,
+                      int64_t rows, int H, float eps, itr_stream_t stream);
+int itr_mha_small(const float *q, const float *k, const float *v, int64_t ldq, int64_t ldk, int64_t ldv,
+                  const float *mask, float *out, int64_t ldo, int64_t B, int L, int heads, int dk, float scale,
+                  itr_stream_t stream);
+int itr_relu_maxpool(const float *x, float *out, int64_t ldo, int64_t B, int L, int C, int valid,
+                     itr_stream_t stream);
 
 /* ---- a7: EncoderSimilarity.forward (SGRAF; itr/modalmodule/Fusionmodule.py:373-664), eval mode ----
  * img [Ni,36,D] (l2-normalised regions), words [n_rows,D] with the caption layout of the SCAN entry points

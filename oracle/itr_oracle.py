@@ -447,3 +447,91 @@ def cal_sims(sim_fn, img_embs, cap_embs, lengths, shard_size, ref_quirk_unsliced
                          torch.as_tensor(cap_embs[j0:j1]), lens)
             d[i0:i0 + shard_size, j0:j1] = sim.numpy()
     return d
+
+
+# --------------------------------------------------------------------------------------
+# a11  BERT (itr/modalmodule/bert.py:113-358) -- eval mode; weights: the BertModel state_dict
+# --------------------------------------------------------------------------------------
+
+
+def bert_layernorm(x, gamma, beta, eps=1e-12):
+    """TF-style LayerNorm: epsilon inside the sqrt (bert.py:113-126)."""
+    u = x.mean(-1, keepdim=True)
+    s = (x - u).pow(2).mean(-1, keepdim=True)
+    return gamma * ((x - u) / torch.sqrt(s + eps)) + beta
+
+
+def bert_gelu(x):
+    """erf GELU (bert.py:29-34)."""
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def bert_layer(w, p, x, mask01, heads):
+    """One BERTLayer (bert.py:262-273) with parameter prefix p; mask01 (B, L) of 0/1 or None."""
+    B, L, H = x.shape
+    dk = H // heads
+
+    def split(t):
+        return t.view(B, L, heads, dk).permute(0, 2, 1, 3)
+    q = split(_linear(x, w, p + 'attention.self.query'))
+    k = split(_linear(x, w, p + 'attention.self.key'))
+    v = split(_linear(x, w, p + 'attention.self.value'))
+    scores = q @ k.transpose(-1, -2) / math.sqrt(dk)
+    if mask01 is not None:
+        scores = scores + ((1.0 - mask01.float()) * -10000.0)[:, None, None, :]
+    ctx = (torch.softmax(scores, -1) @ v).permute(0, 2, 1, 3).reshape(B, L, H)
+    att = bert_layernorm(_linear(ctx, w, p + 'attention.output.dense') + x, w[p + 'attention.output.LayerNorm.gamma'],
+                         w[p + 'attention.output.LayerNorm.beta'])
+    inter = bert_gelu(_linear(att, w, p + 'intermediate.dense'))
+    return bert_layernorm(_linear(inter, w, p + 'output.dense') + att, w[p + 'output.LayerNorm.gamma'],
+                          w[p + 'output.LayerNorm.beta'])
+
+
+def bert_model(w, input_ids, token_type_ids, mask01, n_layers, heads, prefix=''):
+    """BertModel.forward (bert.py:333-358) -> (all_encoder_layers, pooled_output)."""
+    B, L = input_ids.shape
+    if token_type_ids is None:
+        token_type_ids = torch.zeros_like(input_ids)
+    pos = torch.arange(L).unsqueeze(0).expand(B, L)
+    e = (w[prefix + 'embeddings.word_embeddings.weight'][input_ids] + w[prefix + 'embeddings.position_embeddings.weight'][pos]
+         + w[prefix + 'embeddings.token_type_embeddings.weight'][token_type_ids])
+    x = bert_layernorm(e, w[prefix + 'embeddings.LayerNorm.gamma'], w[prefix + 'embeddings.LayerNorm.beta'])
+    layers = []
+    for n in range(n_layers):
+        x = bert_layer(w, prefix + 'encoder.layer.%d.' % n, x, mask01, heads)
+        layers.append(x)
+    pooled = torch.tanh(_linear(x[:, 0], w, prefix + 'pooler.dense'))
+    return layers, pooled
+
+
+# a12  SAEM heads (TextEncoder.py:115-152, ImgEncoder.py:337-350)
+
+
+def saem_text(w, txt_stru, input_ids, mask01, token_type_ids, n_layers, heads, trans_heads=None):
+    """BertMapping.forward: w = the module's state_dict ('bert.*', 'convs1.k.*' | 'mapping_0.*' | 'layer.*', 'mapping.*')."""
+    layers, _ = bert_model(w, input_ids, token_type_ids, mask01, n_layers, heads, prefix='bert.')
+    last = layers[-1]
+    if txt_stru == 'pooling':
+        out = _linear(last, w, 'mapping_0').mean(1)
+    elif txt_stru == 'cnn':
+        B, L, H = last.shape
+        feats = []
+        for n in range(3):
+            wk = w['convs1.%d.weight' % n]              # (512, 1, K, H)
+            K = wk.shape[2]
+            win = torch.stack([last[:, t:t + K].reshape(B, K * H) for t in range(L - K + 1)], 1)   # (B, L-K+1, K*H)
+            y = torch.relu(win @ wk.reshape(wk.shape[0], K * H).t() + w['convs1.%d.bias' % n])
+            feats.append(y.max(1)[0])
+        out = torch.cat(feats, 1)
+    elif txt_stru == 'trans':
+        hid = _linear(last, w, 'mapping_0')
+        out = bert_layer(w, 'layer.', hid, mask01, trans_heads).mean(1)
+    else:
+        raise ValueError("Unknown txt_stru: {}".format(txt_stru))
+    return F.normalize(_linear(out, w, 'mapping'), p=2, dim=1)
+
+
+def saem_image(w, x, heads):
+    """TransformerMapping.forward: Linear -> BERTLayer (all-ones mask) -> mean over regions -> F.normalize."""
+    h = bert_layer(w, 'layer.', _linear(x, w, 'mapping'), None, heads)
+    return F.normalize(h.mean(1), p=2, dim=1)

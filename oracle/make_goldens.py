@@ -362,9 +362,106 @@ def g12():
          tie_t2i=np.array(trt), zeros_i2t_ranks=zr_i, zeros_t2i_ranks=zr_t)
 
 
+# ------------------------------------------------------------------ G10 BERT + SAEM towers
+def g10():
+    import json
+    import tempfile
+    from itr.modalmodule import bert as rbert
+    rng = np.random.RandomState(10)
+    out = {}
+
+    def rand_init(m, seed):
+        torch.manual_seed(seed)
+        for p_ in m.parameters():
+            p_.data.normal_(0, 0.05)
+        for name, p_ in m.named_parameters():
+            if name.endswith('gamma'):
+                p_.data.uniform_(0.8, 1.2)
+
+    # tiny BERT: 2 layers, hidden 64, 4 heads (dk 16)
+    cfg_d = dict(vocab_size=100, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                 max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    cfg = rbert.BertConfig.from_dict(cfg_d)
+    model = rbert.BertModel(cfg).eval()
+    rand_init(model, 100)
+    B, L = 5, 12
+    lens = [12, 9, 7, 4, 2]
+    ids = torch.from_numpy(rng.randint(1, 100, size=(B, L)))
+    mask = torch.zeros(B, L, dtype=torch.long)
+    for b, l in enumerate(lens):
+        mask[b, :l] = 1
+        ids[b, l:] = 0
+    types = torch.zeros(B, L, dtype=torch.long)
+    types[:, 6:] = 1
+    layers, pooled = model(ids, types, mask)
+    w = sd(model)
+    ol, op = O.bert_model(w, ids, types, mask, 2, 4)
+    for n in range(2):
+        check('bert_layer%d' % n, ol[n], layers[n], 2e-5)
+    check('bert_pooled', op, pooled, 2e-5)
+    out.update(bert_ids=ids, bert_types=types, bert_mask=mask, bert_layer0=layers[0], bert_layer1=layers[1],
+               bert_pooled=pooled, bert_cfg=json.dumps(cfg_d))
+    for k, v in w.items():
+        out['wbert_' + k] = v
+
+    # one wider layer: hidden 256, 4 heads (dk 64 like BERT-base), intermediate 512
+    cfg2_d = dict(vocab_size=10, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512,
+                  max_position_embeddings=40, type_vocab_size=2)
+    lay = rbert.BERTLayer(rbert.BertConfig.from_dict(cfg2_d)).eval()
+    rand_init(lay, 101)
+    x = torch.randn(3, 36, 256)
+    m2 = torch.ones(3, 36)
+    m2[1, 30:] = 0
+    ext = ((1.0 - m2) * -10000.0)[:, None, None, :]
+    y = lay(x, ext)
+    w2 = sd(lay, 'layer.')
+    check('bert_wide_layer', O.bert_layer(w2, 'layer.', x, m2, 4), y, 2e-5)
+    out.update(wide_x=x, wide_mask=m2, wide_y=y, wide_cfg=json.dumps(cfg2_d))
+    for k, v in w2.items():
+        out['wwide_' + k] = v
+
+    # SAEM heads on the tiny BERT
+    tmp = tempfile.mkdtemp()
+    json.dump(cfg_d, open(os.path.join(tmp, 'bert_config.json'), 'w'))
+    torch.save(model.state_dict(), os.path.join(tmp, 'pytorch_model.bin'))
+    trans_d = dict(vocab_size=10, hidden_size=64, num_hidden_layers=1, num_attention_heads=4, intermediate_size=128,
+                   max_position_embeddings=40, type_vocab_size=2)
+    json.dump(trans_d, open(os.path.join(tmp, 'trans_cfg.json'), 'w'))
+    out['trans_cfg'] = json.dumps(trans_d)
+    for stru in ('cnn', 'pooling', 'trans'):
+        scfg = dict(bert_config_file=os.path.join(tmp, 'bert_config.json'), init_checkpoint=os.path.join(tmp, 'pytorch_model.bin'),
+                    txt_stru=stru, final_dims=64, trans_cfg=os.path.join(tmp, 'trans_cfg.json'), bi_gru=False, embed_size=64,
+                    num_layers=1)
+        torch.manual_seed(110)
+        tm = TextEncoder.BertMapping(scfg).eval()
+        for name, p_ in tm.named_parameters():
+            if not name.startswith('bert.'):
+                p_.data.normal_(0, 0.05)
+        code = tm(ids, mask, types, lens)
+        wt = sd(tm)
+        check('saem_text_' + stru, O.saem_text(wt, stru, ids, mask, types, 2, 4, 4), code, 2e-5)
+        out['saem_text_' + stru] = code
+        for k, v in wt.items():
+            if not k.startswith('bert.'):
+                out['wsaem_%s_%s' % (stru, k)] = v
+    icfg = dict(trans_cfg=os.path.join(tmp, 'trans_cfg.json'), img_dim=96, final_dims=64)
+    torch.manual_seed(111)
+    im = ImgEncoder.TransformerMapping(icfg).eval()
+    for p_ in im.parameters():
+        p_.data.normal_(0, 0.05)
+    xi = mutils.l2norm(torch.randn(4, 36, 96), dim=-1)
+    yi = im(xi)
+    wi = sd(im)
+    check('saem_image', O.saem_image(wi, xi, 4), yi, 2e-5)
+    out.update(saem_img_x=xi, saem_img_y=yi)
+    for k, v in wi.items():
+        out['wsaemimg_' + k] = v
+    save('g10_bert_saem', **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g11', 'g12']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12']
     for name in which:
         print("== " + name)
         globals()[name]()
