@@ -37,6 +37,7 @@ struct GemmArgs {
     const float *rowscale;
     const float *Z;
     int64_t ldz;
+    int accumulate;   // C = act(C + A*B^T + bias): sums the taps of a dilated Conv1d (camera_.py:100-103)
 };
 
 template <bool ALIGNED>
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                             v = v * g.rowscale[row] - g.Z[row * g.ldz + col];
                             v = v * v;
                         } else {
+                            if (g.accumulate) v += g.C[row * g.ldc + col];
                             v = apply_act(v + bv, g.act);
                         }
                         g.C[row * g.ldc + col] = v;
@@ -219,19 +221,25 @@ static int launch_gemm(const GemmArgs &g, hipStream_t st) {
 
 int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
-    GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0};
+    GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, 0};
+    return launch_gemm(g, st);
+}
+
+int gemm_nt_acc(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc,
+                int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
+    GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, 1};
     return launch_gemm(g, st);
 }
 
 int gemm_nt_sqdiff(const float *A, int64_t lda, const float *B, int64_t ldb, const float *rowscale, const float *Z,
                    int64_t ldz, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t st) {
-    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, M, N, K, 0, 1, BM, rowscale, Z, ldz};
+    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, M, N, K, 0, 1, BM, rowscale, Z, ldz, 0};
     return launch_gemm(g, st);
 }
 
 int gemm_nt_groupmax(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                      int64_t Mgroups, int group, int64_t N, int64_t K, hipStream_t st) {
-    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, Mgroups * group, N, K, 0, group, (BM / group) * group, nullptr, nullptr, 0};
+    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, Mgroups * group, N, K, 0, group, (BM / group) * group, nullptr, nullptr, 0, 0};
     return launch_gemm(g, st);
 }
 
@@ -246,6 +254,14 @@ extern "C" int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t 
     ITR_REQUIRE(lda >= 1 && ldb >= K && ldc >= N, "itr_gemm_nt: leading dimension smaller than row");
     ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt: unknown activation %d", act);
     return itr::gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream));
+}
+
+extern "C" int itr_gemm_nt_acc(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                               int64_t ldc, int64_t M, int64_t N, int64_t K, int act, itr_stream_t stream) {
+    ITR_REQUIRE(A && B && C, "itr_gemm_nt_acc: null pointer");
+    ITR_REQUIRE(M >= 0 && N >= 0 && K >= 0 && lda >= 1 && ldb >= K && ldc >= N, "itr_gemm_nt_acc: bad shape");
+    ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt_acc: unknown activation %d", act);
+    return itr::gemm_nt_acc(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream));
 }
 
 extern "C" int itr_cosine_scores(const float *im, const float *s, float *S, int64_t Ni, int64_t Nc, int D,

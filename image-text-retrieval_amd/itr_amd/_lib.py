@@ -39,6 +39,11 @@ SIGNATURES = {
     "itr_add_layernorm": (i32, [vp, vp, vp, vp, vp, i64, i32, f32, vp]),
     "itr_mha_small": (i32, [vp, vp, vp, i64, i64, i64, vp, vp, i64, i64, i32, i32, i32, f32, vp]),
     "itr_relu_maxpool": (i32, [vp, vp, i64, i64, i32, i32, i32, vp]),
+    "itr_gemm_nt_acc": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
+    "itr_mul_rows": (i32, [vp, vp, i64, vp, i64, i32, vp]),
+    "itr_affine_cols": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "itr_camera_posenc": (i32, [vp, vp, vp, i64, i32, vp]),
+    "itr_camera_summarize": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
     "itr_sgraf_workspace_bytes": (sz, [i64, i64, i64, i64, i32, i32, i32]),
     "itr_sgraf_scores": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, i64, vp, sz, vp]),
     "itr_debug_scan_occupancy": (i32, [vp, vp]),

@@ -80,3 +80,39 @@ class TransformerMapping(nn.Module):
         hidden_states = self.layer(x, None)                 # all-ones mask == no mask
         embed = ops.mean_mid(hidden_states)
         return ops.normalize(embed, dim=1)
+
+
+from .camera_ import AGSA, Summarization, PositionEncoder  # noqa: E402
+
+
+class EncoderImagePrecompSelfAttn(nn.Module):
+    """CAMERA image tower (ImgEncoder.py:355-401).  NB the reference's l2norm calls use the DEFAULT dim=1, i.e.
+    they normalise across the 36 regions, not across the features (:378, :384) -- reproduced."""
+
+    def __init__(self, img_dim, embed_size, head, smry_k, drop=0.0):
+        super().__init__()
+        self.embed_size = embed_size
+        self.fc = nn.Linear(img_dim, embed_size)
+        self.init_weights()
+        self.position_enc = PositionEncoder(embed_size)
+        self.agsa = AGSA(1, embed_size, h=head, is_share=False, drop=drop)
+        self.mvs = Summarization(embed_size, smry_k)
+
+    def init_weights(self):
+        r = np.sqrt(6.) / np.sqrt(self.fc.in_features + self.fc.out_features)
+        self.fc.weight.data.uniform_(-r, r)
+        self.fc.bias.data.fill_(0)
+
+    def forward(self, images, boxes, imgs_wh):
+        fc_img_emd = ops.linear(images, self.fc.weight.detach(), self.fc.bias.detach())
+        fc_img_emd = ops.l2norm(fc_img_emd, dim=1)
+        posi_emb = self.position_enc(boxes, imgs_wh)
+        self_att_emb = self.agsa(fc_img_emd, posi_emb)
+        self_att_emb = ops.l2norm(self_att_emb, dim=1)
+        smry_mat = self.mvs(self_att_emb)
+        return ops.camera_summarize(smry_mat, self_att_emb), smry_mat
+
+    def load_state_dict(self, state_dict):
+        own_state = self.state_dict()
+        new_state = OrderedDict((k, v) for k, v in state_dict.items() if k in own_state)
+        super().load_state_dict(new_state)

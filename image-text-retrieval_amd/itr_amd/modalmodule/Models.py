@@ -186,3 +186,33 @@ class SAEM(base_module):
         loss1 = self.criterion(img_emb, cap_emb, cap_len)
         self._log('Loss1', loss1.item(), img_emb.size(0))
         return loss1
+
+
+class CAMERA(base_module):
+    """CAMERA (Models.py:550-645): multi-view image embeddings (k x D per image), BERT + AGSA caption embedding,
+    MultiViewMatching similarity, TripletLoss."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.img_enc = ImgEncoder.EncoderImagePrecompSelfAttn(config['img_dim'], config['embed_size'], config['head'],
+                                                              config['smry_k'], drop=config['drop'])
+        self.txt_enc = TextEncoder.CAMERAEncoderText(config['bert_config_file'], config['init_checkpoint'],
+                                                     config['embed_size'], config['head'], drop=config['drop'])
+        self.mvm = Fusionmodule.MultiViewMatching()
+        self.img_enc.cuda()       # one process per GPU: no nn.DataParallel wrapper (Models.py:561-562)
+        self.txt_enc.cuda()
+        self.crit_ranking = Objectives.TripletLoss(margin=config['margin'], max_violation=config['max_violation'])
+        self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters())
+        self.calculate_params()
+
+    def forward_emb(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, *args, **kwargs):
+        cap_emb = self.txt_enc(self._dev(captions), self._dev(captions_mask), self._dev(captions_type_ids))
+        img_emb, smry_mat = self.img_enc(self._dev(images), self._dev(boxes), self._dev(imgs_wh))
+        return img_emb, cap_emb, smry_mat
+
+    def forward_loss(self, sim_mat, smry_mat):
+        """Ranking term; the diversity regulariser (Objectives.py:521-542, weight smry_lamda) is a training-time
+        auxiliary left with the tower backward (8f-3)."""
+        ranking_loss = self.crit_ranking(sim_mat)
+        self._log('Rank_Loss', ranking_loss.item(), len(sim_mat))
+        return ranking_loss

@@ -127,3 +127,38 @@ class BertMapping(nn.Module):
         for child in model.children():
             for param in child.parameters():
                 param.requires_grad = False
+
+
+from .camera_ import AGSA, bn_affine  # noqa: E402
+
+
+class CAMERAEncoderText(nn.Module):
+    """CAMERA text tower (TextEncoder.py:162-197): frozen BERT -> Linear -> AGSA -> MLP + BatchNorm residual ->
+    mean over ALL token positions (the reference does not mask padding) -> F.normalize."""
+
+    def __init__(self, cfg_file, init_ckpt, embed_size, head, drop=0.0):
+        super().__init__()
+        bert_config = BertConfig.from_json_file(cfg_file)
+        self.bert = BertModel(bert_config)
+        self.bert.load_state_dict(torch.load(init_ckpt, map_location='cpu'))
+        self.freeze_layers(self.bert)
+        self.mapping = nn.Linear(bert_config.hidden_size, embed_size)
+        self.agsa = AGSA(1, embed_size, h=head, is_share=False, drop=drop)
+        self.fc1 = nn.Linear(embed_size, embed_size)
+        self.fc2 = nn.Linear(embed_size, embed_size)
+        self.bn = nn.BatchNorm1d(embed_size)
+
+    def forward(self, input_ids, attention_mask, token_type_ids, lengths=None):
+        all_encoder_layers, _ = self.bert(input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask)
+        x = ops.linear(all_encoder_layers[-1], self.mapping.weight.detach(), self.mapping.bias.detach())
+        agsa_emb = self.agsa(x)
+        h = ops.linear(agsa_emb, self.fc1.weight.detach(), self.fc1.bias.detach(), act='relu')
+        h = ops.linear(h, self.fc2.weight.detach(), self.fc2.bias.detach())
+        sc, sh = bn_affine(self.bn)
+        x = ops.affine_cols(h, sc, sh, residual=agsa_emb)
+        return ops.normalize(ops.mean_mid(x), dim=-1)
+
+    def freeze_layers(self, model):
+        for child in model.children():
+            for param in child.parameters():
+                param.requires_grad = False

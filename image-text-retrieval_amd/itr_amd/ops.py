@@ -333,6 +333,65 @@ def relu_maxpool(x, valid, out=None):
     return out
 
 
+# ------------------------------------------------------------------------------------------ CAMERA helpers
+def mul_rows(a, b2d):
+    """a (..., C) * b where b is a 2-D (R, C) view with contiguous last dim (may be a column slice)."""
+    lib = _lib.load()
+    a = _dev(a, name="a")
+    Cc = a.shape[-1]
+    R = a.numel() // Cc
+    if not (b2d.is_cuda and b2d.dim() == 2 and b2d.stride(1) == 1 and b2d.shape[0] == R and b2d.shape[1] == Cc):
+        raise ValueError("mul_rows: b must be a (R, C) CUDA view with a contiguous last dim")
+    out = torch.empty_like(a)
+    _lib.check(lib.itr_mul_rows(_p(a), _p(b2d), b2d.stride(0), _p(out), R, Cc, _stream()))
+    return out
+
+
+def affine_cols(x, scale=None, shift=None, residual=None, act=None):
+    """act(x*scale[c] + shift[c]) + residual (eval-mode BatchNorm1d folded to scale / shift)."""
+    lib = _lib.load()
+    x = _dev(x, name="x")
+    Cc = x.shape[-1]
+    out = torch.empty_like(x)
+    sc = _dev(scale) if scale is not None else None
+    sh = _dev(shift) if shift is not None else None
+    rs = _dev(residual) if residual is not None else None
+    _lib.check(lib.itr_affine_cols(_p(x), _p(sc), _p(sh), _p(rs), _p(out), x.numel() // Cc, Cc, _ACTS[act], _stream()))
+    return out
+
+
+def gemm_acc(x2d, lda, M, K, weight, bias, out, act=None):
+    """out = act(out + A @ weight^T + bias), A rows at x2d.data_ptr() + m*lda."""
+    lib = _lib.load()
+    weight = _dev(weight, name="weight")
+    b = _dev(bias) if bias is not None else None
+    _lib.check(lib.itr_gemm_nt_acc(_p(x2d), lda, _p(weight), weight.shape[1], _p(b), _p(out), out.stride(0), M,
+                                   weight.shape[0], K, _ACTS[act], _stream()))
+    return out
+
+
+def camera_posenc(boxes, imgs_wh):
+    lib = _lib.load()
+    boxes = _dev(boxes.to(torch.float32), name="boxes")
+    wh = _dev(imgs_wh.to(torch.float32), name="imgs_wh")
+    B, R = boxes.shape[:2]
+    out = torch.empty(B, R, 6, device=boxes.device, dtype=torch.float32)
+    _lib.check(lib.itr_camera_posenc(_p(boxes), _p(wh), _p(out), B, R, _stream()))
+    return out
+
+
+def camera_summarize(smry_mat, X):
+    """softmax over regions of smry (B, R, k); (L^T X) -> F.normalize -> (B, k, D)."""
+    lib = _lib.load()
+    smry_mat = _dev(smry_mat, name="smry_mat")
+    X = _dev(X, name="X")
+    B, R, k = smry_mat.shape
+    D = X.shape[2]
+    out = torch.empty(B, k, D, device=X.device, dtype=torch.float32)
+    _lib.check(lib.itr_camera_summarize(_p(smry_mat), _p(X), _p(out), B, R, k, D, _stream()))
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 _SGRAF_MAP = {
     "v_loc_w": "v_global_w.embedding_local.0.weight", "v_loc_b": "v_global_w.embedding_local.0.bias",

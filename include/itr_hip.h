@@ -153,6 +153,21 @@ int itr_mha_small(const float *q, const float *k, const float *v, int64_t ldq, i
 int itr_relu_maxpool(const float *x, float *out, int64_t ldo, int64_t B, int L, int C, int valid,
                      itr_stream_t stream);
 
+/* ---- a13: CAMERA helpers (itr/modalmodule/camera_.py; ImgEncoder.py:355-433; TextEncoder.py:162-197) ----
+ * itr_gemm_nt_acc     : C = act(C + A B^T + bias)  -- sums the taps of the dilated Conv1d summarisation (:100-103)
+ * itr_mul_rows        : out[r,c] = a[r,c] * b[r*ldb + c]   (position gating :75, query/key gates :38-40)
+ * itr_affine_cols     : out = act(x*scale[c] + shift[c]) + residual  (eval BatchNorm1d folded; scale/shift/residual may be NULL)
+ * itr_camera_posenc   : absoluteEncode(boxes, imgs_wh) -> [B*R, 6]   (:118-128)
+ * itr_camera_summarize: softmax over regions of smry[B,R,k], L^T X, F.normalize -> [B,k,D]  (ImgEncoder.py:385-389) */
+int itr_gemm_nt_acc(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                    int64_t ldc, int64_t M, int64_t N, int64_t K, int act, itr_stream_t stream);
+int itr_mul_rows(const float *a, const float *b, int64_t ldb, float *out, int64_t R, int C, itr_stream_t stream);
+int itr_affine_cols(const float *x, const float *scale, const float *shift, const float *residual, float *out,
+                    int64_t R, int C, int act, itr_stream_t stream);
+int itr_camera_posenc(const float *boxes, const float *imgs_wh, float *out, int64_t B, int R, itr_stream_t stream);
+int itr_camera_summarize(const float *smry, const float *X, float *out, int64_t B, int R, int k, int D,
+                         itr_stream_t stream);
+
 /* ---- a7: EncoderSimilarity.forward (SGRAF; itr/modalmodule/Fusionmodule.py:373-664), eval mode ----
  * img [Ni,36,D] (l2-normalised regions), words [n_rows,D] with the caption layout of the SCAN entry points
  * (cap_off / cap_len / tile plan from itr_scan_plan_tiles on the word lengths).  module: 0 = SAF, 1 = SGR.

@@ -535,3 +535,77 @@ def saem_image(w, x, heads):
     """TransformerMapping.forward: Linear -> BERTLayer (all-ones mask) -> mean over regions -> F.normalize."""
     h = bert_layer(w, 'layer.', _linear(x, w, 'mapping'), None, heads)
     return F.normalize(h.mean(1), p=2, dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# a13  CAMERA towers (camera_.py:14-147; ImgEncoder.py:375-389; TextEncoder.py:181-192), eval mode
+# --------------------------------------------------------------------------------------
+
+
+def camera_gated_attention(w, p, inp, h):
+    """GatedQueryAttLayer.forward (camera_.py:31-54), no mask."""
+    B, L, D = inp.shape
+    dk = D // h
+    q, k, v = [_linear(inp, w, p + 'linears.%d' % n).view(B, L, h, dk).transpose(1, 2) for n in range(3)]
+    G = _linear(q, w, p + 'fc_q') * _linear(k, w, p + 'fc_k')
+    M = torch.sigmoid(_linear(G, w, p + 'fc_g'))
+    q = q * M[..., :dk]
+    k = k * M[..., dk:]
+    att = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(dk), -1)
+    return (att @ v).transpose(1, 2).reshape(B, L, D)
+
+
+def camera_agsa(w, p, rgn_emb, pos_emb, h):
+    """AGSA.forward with num_layers == 1 (camera_.py:70-89): rgn + bn(att(rgn * pos))."""
+    B, L, D = rgn_emb.shape
+    x = rgn_emb if pos_emb is None else rgn_emb * pos_emb
+    x = camera_gated_attention(w, p + 'att_layers.0.', x, h)
+    x = _bn_eval(x.reshape(B * L, D), w, p + 'bns.0', 1).view(B, L, D)
+    return rgn_emb + x
+
+
+def camera_position(w, p, boxes, imgs_wh):
+    """absoluteEncode + PositionEncoder (camera_.py:118-147)."""
+    x, y = boxes[:, :, 0], boxes[:, :, 1]
+    bw, bh = boxes[:, :, 2] - x, boxes[:, :, 3] - y
+    W, H = imgs_wh[:, 0:1], imgs_wh[:, 1:2]
+    feat = torch.stack([x / W, y / H, bw / W, bh / H, bw / bh, (bw * bh) / (W * H)], dim=-1)
+    return torch.sigmoid(_linear(feat, w, p + 'proj'))
+
+
+def camera_summarization(w, p, rgn_emb):
+    """Summarization.forward (camera_.py:108-114): 7 dilated Conv1d -> relu -> cat -> Linear."""
+    ksz, dil, pad = [1, 3, 3, 3, 5, 5, 5], [1, 1, 2, 3, 1, 2, 3], [0, 1, 2, 3, 2, 4, 6]
+    xt = rgn_emb.transpose(1, 2)
+    ys = [torch.relu(F.conv1d(xt, w[p + 'convs_dilate.%d.weight' % i], w[p + 'convs_dilate.%d.bias' % i],
+                              dilation=dil[i], padding=pad[i])) for i in range(7)]
+    return _linear(torch.cat(ys, 1).transpose(1, 2), w, p + 'convs_fc')
+
+
+def camera_image(w, images, boxes, imgs_wh, h):
+    """EncoderImagePrecompSelfAttn.forward (ImgEncoder.py:375-389) -> (img_emb (B,k,D), smry_mat (B,R,k)).
+    The two l2norm calls use the default dim=1 (the region axis), as in the reference."""
+    fc = l2norm(_linear(images, w, 'fc'))
+    pos = camera_position(w, 'position_enc.', boxes, imgs_wh)
+    att = l2norm(camera_agsa(w, 'agsa.', fc, pos, h))
+    smry = camera_summarization(w, 'mvs.', att)
+    L = torch.softmax(smry, dim=1)
+    return F.normalize(L.transpose(1, 2) @ att, dim=-1), smry
+
+
+def camera_text(w, input_ids, mask01, token_type_ids, n_layers, bert_heads, h):
+    """CAMERAEncoderText.forward (TextEncoder.py:181-192)."""
+    layers, _ = bert_model(w, input_ids, token_type_ids, mask01, n_layers, bert_heads, prefix='bert.')
+    x = _linear(layers[-1], w, 'mapping')
+    B, L, D = x.shape
+    agsa = camera_agsa(w, 'agsa.', x, None, h)
+    y = _linear(torch.relu(_linear(agsa, w, 'fc1')), w, 'fc2')
+    y = _bn_eval(y.reshape(B * L, D), w, 'bn', 1).view(B, L, D)
+    return F.normalize((agsa + y).mean(1), p=2, dim=-1)
+
+
+def diversity_regularization(smry_mat):
+    """DiversityRegularization.forward (Objectives.py:532-542)."""
+    s = F.normalize(smry_mat, dim=1)
+    d = s.transpose(1, 2) @ s - torch.eye(s.shape[2]).unsqueeze(0)
+    return (d ** 2).sum()

@@ -459,9 +459,85 @@ def g10():
     save('g10_bert_saem', **out)
 
 
+# ------------------------------------------------------------------ G13 CAMERA towers
+def g13():
+    import json
+    import tempfile
+    from itr.modalmodule import bert as rbert
+    rng = np.random.RandomState(13)
+    cfg_d = dict(vocab_size=100, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                 max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    bm = rbert.BertModel(rbert.BertConfig.from_dict(cfg_d)).eval()
+    torch.manual_seed(130)
+    for p_ in bm.parameters():
+        p_.data.normal_(0, 0.05)
+    tmp = tempfile.mkdtemp()
+    json.dump(cfg_d, open(os.path.join(tmp, 'bert_config.json'), 'w'))
+    torch.save(bm.state_dict(), os.path.join(tmp, 'pytorch_model.bin'))
+
+    def randomize(m, seed):
+        torch.manual_seed(seed)
+        for name, p_ in m.named_parameters():
+            if not name.startswith('bert.'):
+                p_.data.normal_(0, 0.08)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.data.uniform_(0.8, 1.2)
+                mod.bias.data.normal_(0, 0.05)
+
+    D, H, K = 64, 4, 12
+    # image tower
+    ie = ImgEncoder.EncoderImagePrecompSelfAttn(96, D, H, K, drop=0.0)
+    randomize(ie, 131)
+    ie.eval()
+    B, R = 5, 36
+    images = mutils.l2norm(torch.randn(B, R, 96), dim=-1)
+    x1 = torch.from_numpy(rng.uniform(0, 400, size=(B, R))).float()
+    y1 = torch.from_numpy(rng.uniform(0, 300, size=(B, R))).float()
+    bw = torch.from_numpy(rng.uniform(20, 200, size=(B, R))).float()
+    bh = torch.from_numpy(rng.uniform(20, 200, size=(B, R))).float()
+    boxes = torch.stack([x1, y1, x1 + bw, y1 + bh], -1)
+    wh = torch.tensor([[640., 480.]]).repeat(B, 1)
+    img_emb, smry = ie(images, boxes, wh)
+    wi = {k: v for k, v in sd(ie).items() if 'num_batches_tracked' not in k}
+    oi, osm = O.camera_image(wi, images, boxes, wh, H)
+    check('camera_img_emb', oi, img_emb, 2e-5)
+    check('camera_smry', osm, smry, 2e-5)
+    # text tower
+    te = TextEncoder.CAMERAEncoderText(os.path.join(tmp, 'bert_config.json'), os.path.join(tmp, 'pytorch_model.bin'), D, H, drop=0.0)
+    randomize(te, 132)
+    te.eval()
+    Bc, L = 7, 12
+    lens = [12, 10, 9, 7, 5, 3, 2]
+    ids = torch.from_numpy(rng.randint(1, 100, size=(Bc, L)))
+    mask = torch.zeros(Bc, L, dtype=torch.long)
+    for b, l in enumerate(lens):
+        mask[b, :l] = 1
+        ids[b, l:] = 0
+    types = torch.zeros(Bc, L, dtype=torch.long)
+    cap = te(ids, mask, types)
+    wt = {k: v for k, v in sd(te).items() if 'num_batches_tracked' not in k}
+    check('camera_text', O.camera_text(wt, ids, mask, types, 2, 4, H), cap, 2e-5)
+    # similarity + losses
+    mvm = Fusionmodule.MultiViewMatching()
+    sim = mvm(img_emb, cap)
+    check('camera_mvm', O.multi_view_matching(img_emb, cap), sim, 1e-6)
+    div = Objectives.DiversityRegularization(K, B)(smry)
+    check('camera_divreg', O.diversity_regularization(smry), div, 1e-4)
+    out = dict(images=images, boxes=boxes, imgs_wh=wh, img_emb=img_emb, smry_mat=smry, ids=ids, mask=mask, types=types,
+               cap_emb=cap, sim=sim, div_reg=div, bert_cfg=json.dumps(cfg_d))
+    for k, v in wi.items():
+        out['wimg_' + k] = v
+    for k, v in wt.items():
+        out['wtxt_' + k] = v
+    save('g13_camera', **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13']
     for name in which:
         print("== " + name)
         globals()[name]()
