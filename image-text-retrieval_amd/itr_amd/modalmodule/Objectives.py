@@ -91,3 +91,46 @@ class TripletLoss(nn.Module):
 
     def forward(self, scores):
         return ops.hinge_loss(scores, self.margin, self.max_violation)
+
+
+class DiversityRegularization(nn.Module):
+    """CAMERA diversity regulariser (Objectives.py:521-542).  Training-time auxiliary (torch
+    composition accepted): runs as torch ops on the GPU, not as a dedicated kernel."""
+
+    def __init__(self, smry_k, batch_size):
+        super().__init__()
+        self.smry_k = smry_k
+        self.batch_size = batch_size
+
+    def forward(self, smry_mat):
+        s = torch.nn.functional.normalize(smry_mat, dim=1)
+        d = torch.matmul(s.transpose(1, 2), s) - torch.eye(self.smry_k, device=s.device).unsqueeze(0)
+        return (d ** 2).sum()
+
+
+class AngularLoss(nn.Module):
+    """SAEM angular loss (Objectives.py:238-290); training-time auxiliary composed of torch GPU ops."""
+
+    def __init__(self, l2_reg=0.02, angle_bound=1., lambda_ang=2, max_violation=True):
+        super().__init__()
+        self.l2_reg = l2_reg
+        self.angle_bound = angle_bound
+        self.lambda_ang = lambda_ang
+        self.max_violation = max_violation
+
+    def forward(self, im, s, s_l=None, ids=None):
+        return self.angular_loss(im, s, s) + self.angular_loss(s, im, im)
+
+    def angular_loss(self, anchors, positives, others):
+        n = anchors.shape[0]
+        idx = torch.tensor([[j for j in range(n) if j != i] for i in range(n)], dtype=torch.long, device=anchors.device)
+        neg = others[idx]
+        a, p = anchors.unsqueeze(1), positives.unsqueeze(1)
+        ab = self.angle_bound
+        x = 4. * ab * torch.matmul(a + p, neg.transpose(1, 2)) - 2. * (1. + ab) * torch.matmul(a, p.transpose(1, 2))
+        if self.max_violation:
+            return torch.log(1 + torch.exp(x.max(2)[0])).sum()
+        with torch.no_grad():
+            t = torch.max(x, dim=2)[0]
+        x = torch.exp(x - t.unsqueeze(dim=1))
+        return torch.mean(t + torch.log(torch.exp(-t) + torch.sum(x, 2)))

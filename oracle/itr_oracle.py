@@ -609,3 +609,18 @@ def diversity_regularization(smry_mat):
     s = F.normalize(smry_mat, dim=1)
     d = s.transpose(1, 2) @ s - torch.eye(s.shape[2]).unsqueeze(0)
     return (d ** 2).sum()
+
+
+def angular_loss(im, s, angle_bound=1.0, max_violation=True):
+    """AngularLoss.forward (Objectives.py:252-290): both directions, every other sample is a negative."""
+    def one(anchors, positives, others):
+        n = anchors.shape[0]
+        idx = torch.tensor([[j for j in range(n) if j != i] for i in range(n)], dtype=torch.long)
+        neg = others[idx]                                                   # (n, n-1, d)
+        a, p = anchors.unsqueeze(1), positives.unsqueeze(1)
+        x = 4.0 * angle_bound * ((a + p) @ neg.transpose(1, 2)) - 2.0 * (1.0 + angle_bound) * (a @ p.transpose(1, 2))
+        if max_violation:
+            return torch.log(1 + torch.exp(x.max(2)[0])).sum()
+        t = x.max(2)[0]
+        return (t + torch.log(torch.exp(-t) + torch.exp(x - t.unsqueeze(1)).sum(2))).mean()
+    return one(im, s, s) + one(s, im, im)

@@ -524,10 +524,15 @@ def g13():
     mvm = Fusionmodule.MultiViewMatching()
     sim = mvm(img_emb, cap)
     check('camera_mvm', O.multi_view_matching(img_emb, cap), sim, 1e-6)
+    torch.manual_seed(133)
+    a_im = torch.nn.functional.normalize(torch.randn(9, 32), dim=1)
+    a_s = torch.nn.functional.normalize(torch.randn(9, 32), dim=1)
+    ang = Objectives.AngularLoss()(a_im, a_s, None, list(range(9)))
+    check('angular_loss', O.angular_loss(a_im, a_s), ang, 1e-4)
     div = Objectives.DiversityRegularization(K, B)(smry)
     check('camera_divreg', O.diversity_regularization(smry), div, 1e-4)
     out = dict(images=images, boxes=boxes, imgs_wh=wh, img_emb=img_emb, smry_mat=smry, ids=ids, mask=mask, types=types,
-               cap_emb=cap, sim=sim, div_reg=div, bert_cfg=json.dumps(cfg_d))
+               cap_emb=cap, sim=sim, div_reg=div, bert_cfg=json.dumps(cfg_d), ang_im=a_im, ang_s=a_s, ang_loss=ang)
     for k, v in wi.items():
         out['wimg_' + k] = v
     for k, v in wt.items():

@@ -123,3 +123,13 @@ def test_camera_towers_golden(golden, dev, tmp_path):
     import itr_oracle as O
     want = O.hinge_loss(T(g["sim"])[:, :5], 0.2, True)
     assert abs(float(loss) - float(want)) <= 1e-4
+
+
+def test_aux_losses_golden(golden, dev):
+    """a18: training-time auxiliaries (torch-composed on the GPU)."""
+    from itr_amd.modalmodule import Objectives
+    g = golden("g13_camera")
+    div = Objectives.DiversityRegularization(12, 5)(T(g["smry_mat"]).to(dev))
+    assert abs(float(div) - float(g["div_reg"])) <= 1e-3 * max(1.0, abs(float(g["div_reg"])))
+    ang = Objectives.AngularLoss()(T(g["ang_im"]).to(dev), T(g["ang_s"]).to(dev))
+    assert abs(float(ang) - float(g["ang_loss"])) <= 1e-3 * max(1.0, abs(float(g["ang_loss"])))

@@ -141,3 +141,30 @@ def test_state_dict_round_trip(golden, dev):
     m2 = scan_model_from_golden(g)
     m2.load_state_dict(sd)
     assert torch.equal(m2.img_enc.fc.weight, m1.img_enc.fc.weight)
+
+
+@pytest.mark.parametrize("mod", ["SAF", "SGR"])
+def test_sgraf_model_wrapper(golden, dev, mod):
+    """get_model('SGRAF'): forward_emb -> sim_enc -> forward_loss, checkpoint-style state_dict round trip."""
+    g = golden("g6_sgraf")
+    cfg = C.build_config(['with', 'SGRAF', 'module_name=%s' % mod, 'max_violation=True'])
+    cfg.update(img_dim=48, embed_size=64, word_dim=16, vocab_size=50, sim_dim=32)
+    model = get_model(cfg)
+    pre = "w_%s_" % mod
+    w = {k[len(pre):]: T(g[k]) for k in g.files if k.startswith(pre)}
+    sd = model.sim_enc.state_dict()
+    sd.update(w)
+    model.sim_enc.load_state_dict(sd)
+    model.val_start()
+    sims = model.sim_enc(T(g["images"]).to(dev), T(g["captions"]).to(dev), [int(x) for x in g["cap_lens"]])
+    assert float((sims.cpu() - T(g["sim_" + mod])).abs().max()) <= 5e-6
+    loss = model.forward_loss(sims[:, :8].contiguous())
+    want = O.hinge_loss(T(g["sim_" + mod])[:, :8], 0.2, True)
+    assert abs(float(loss.detach()) - float(want)) <= 1e-4
+    full = model.state_dict()
+    assert len(full) == 3 and 'sim_tranloc_w.weight' in full[2]
+    model.load_state_dict(full)
+    # eval pipeline entry point used by cal_sims
+    from itr_amd.metricmodule import evaluation
+    d = evaluation.cal_sims(model, g["images"], g["captions"], g["cap_lens"], shard_size=10 ** 9)
+    assert np.abs(d - g["sim_" + mod]).max() <= 5e-6
