@@ -183,45 +183,140 @@ __global__ __launch_bounds__(256) void saf_pair_kernel(PairArgs p, const float *
     if (lane == 0) S[(img_index0 + ii) * ldS + c] = 1.f / (1.f + expf(-score));
 }
 
-// One GraphReasoning step per pair (Fusionmodule.py:581-587): edge = softmax(Q K^T), Y = edge X.
-// One wave per pair; K and X rows of the pair are staged in LDS (dynamic: 2 * maxnodes * S floats per wave).
-__global__ __launch_bounds__(64) void sgr_pair_kernel(PairArgs p, const float *__restrict__ qglo, const float *__restrict__ qloc,
-                                                      const float *__restrict__ kglo, const float *__restrict__ kloc,
-                                                      float *__restrict__ yglo, float *__restrict__ yloc, int64_t npairs,
-                                                      int maxnodes, int glo_only) {
-    extern __shared__ float sm[];
-    const int64_t pair = blockIdx.x;
-    const int lane = threadIdx.x;
+// One GraphReasoning step per pair (Fusionmodule.py:581-587): edge = softmax(Q K^T), Y = edge X, on the matrix
+// core.  One wave per (image, caption) pair; NT = ceil((W+1)/16) node tiles.
+//   E  = Q K^T   : A / B fragments straight from L2 (lane (i, g) reads row i, floats 16u+4g..+3), K dim = S
+//   P  = softmax over the key axis in the accumulator layout (16-lane shuffles), parked in wave-private LDS
+//   Y  = P X     : A = P from LDS (one ds_read_b128 per tile), B = X rows from L2, written row by row
+template <int NT>
+__device__ __forceinline__ void sgr_pair_body(const PairArgs &p, const float *qglo, const float *qloc, const float *kglo,
+                                              const float *kloc, float *yglo, float *yloc, int64_t ii, int64_t c, int col0,
+                                              int nn, int glo_only, float *pl /* [NT*16][NT*16+4] wave-private */) {
+    const int lane = threadIdx.x & 63, fi = lane & 15, fg = lane >> 4;
+    const int S = p.S;
+    constexpr int LDP = NT * 16 + 4;
+    const int TI = glo_only ? 1 : NT;        // the last step only needs node 0 (row tile 0)
+    // ---- E = Q K^T
+    f32x4 e[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) e[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *qrow[NT], *krow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int n = t * 16 + fi;
+        n = n < nn ? n : nn - 1;             // rows past the graph re-read the last node; masked below
+        qrow[t] = node_row(p, qglo, qloc, ii, c, col0, n);
+        krow[t] = node_row(p, kglo, kloc, ii, c, col0, n);
+    }
+    for (int u = 0; u < S / 16; ++u) {
+        float4 qf[NT], kf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < TI) qf[t] = *reinterpret_cast<const float4 *>(qrow[t] + 16 * u + 4 * fg);
+            kf[t] = *reinterpret_cast<const float4 *>(krow[t] + 16 * u + 4 * fg);
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+            if (a < TI) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    e[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[a].x, kf[b].x, e[a][b], 0, 0, 0);
+                    e[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[a].y, kf[b].y, e[a][b], 0, 0, 0);
+                    e[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[a].z, kf[b].z, e[a][b], 0, 0, 0);
+                    e[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[a].w, kf[b].w, e[a][b], 0, 0, 0);
+                }
+            }
+    }
+    // ---- softmax over keys (columns): this lane holds, per tile, column fi of rows 4fg + r
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+        if (a < TI) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    if (b * 16 + fi >= nn) e[a][b][r] = -INFINITY;
+                    mx = fmaxf(mx, e[a][b][r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+                float den = 0.f;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) { e[a][b][r] = expf(e[a][b][r] - mx); den += e[a][b][r]; }
+                den += __shfl_xor(den, 1, 64); den += __shfl_xor(den, 2, 64);
+                den += __shfl_xor(den, 4, 64); den += __shfl_xor(den, 8, 64);
+                const float inv = 1.f / den;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) pl[(a * 16 + 4 * fg + r) * LDP + b * 16 + fi] = e[a][b][r] * inv;
+            }
+        }
+    // (wave-private LDS: ds operations of one wave are ordered, no barrier needed)
+    // ---- Y = P X, 16 output columns at a time
+    const float *xrow[NT][4];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = b * 16 + 4 * fg + j;
+            n = n < nn ? n : nn - 1;         // P is exactly 0 there
+            xrow[b][j] = node_row(p, p.xglo, p.xloc, ii, c, col0, n);
+        }
+    float4 pf[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+        if (a < TI) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) pf[a][b] = *reinterpret_cast<const float4 *>(&pl[(a * 16 + fi) * LDP + b * 16 + 4 * fg]);
+        }
+    for (int nt = 0; nt < S / 16; ++nt) {
+        f32x4 y[NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) y[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const float x0 = xrow[b][0][nt * 16 + fi], x1 = xrow[b][1][nt * 16 + fi];
+            const float x2 = xrow[b][2][nt * 16 + fi], x3 = xrow[b][3][nt * 16 + fi];
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+                if (a < TI) {
+                    y[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a][b].x, x0, y[a], 0, 0, 0);
+                    y[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a][b].y, x1, y[a], 0, 0, 0);
+                    y[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a][b].z, x2, y[a], 0, 0, 0);
+                    y[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[a][b].w, x3, y[a], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+            if (a < TI) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = a * 16 + 4 * fg + r;
+                    if (n < (glo_only ? 1 : nn))
+                        const_cast<float *>(node_row(p, yglo, yloc, ii, c, col0, n))[nt * 16 + fi] = y[a][r];
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void sgr_pair_kernel(PairArgs p, const float *__restrict__ qglo, const float *__restrict__ qloc,
+                                                       const float *__restrict__ kglo, const float *__restrict__ kloc,
+                                                       float *__restrict__ yglo, float *__restrict__ yloc, int64_t npairs,
+                                                       int maxnodes, int glo_only) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= npairs) return;
     const int64_t ii = pair / p.Nc, c = pair % p.Nc;
     const int nn = p.cap_len[c] + 1, col0 = p.cap_col[c];
-    float *ks = sm, *xs = sm + (size_t)maxnodes * p.S;
-    for (int n = 0; n < nn; ++n) {
-        const float *kr = node_row(p, kglo, kloc, ii, c, col0, n);
-        const float *xr = node_row(p, p.xglo, p.xloc, ii, c, col0, n);
-        for (int d = lane; d < p.S; d += 64) { ks[n * p.S + d] = kr[d]; xs[n * p.S + d] = xr[d]; }
-    }
-    __syncthreads();
-    const int na = glo_only ? 1 : nn;   // the last step only needs node 0 (sim_emb[:, 0, :], :439)
-    for (int a = 0; a < na; ++a) {
-        const float *qr = node_row(p, qglo, qloc, ii, c, col0, a);
-        float e[64];
-        float mx = -INFINITY;
-        for (int b = 0; b < nn; ++b) {
-            float s = 0.f;
-            for (int d = lane; d < p.S; d += 64) s += qr[d] * ks[b * p.S + d];
-            s = wave_sum(s);
-            e[b] = s;
-            mx = fmaxf(mx, s);
-        }
-        float den = 0.f;
-        for (int b = 0; b < nn; ++b) { e[b] = expf(e[b] - mx); den += e[b]; }
-        float *yr = const_cast<float *>(node_row(p, yglo, yloc, ii, c, col0, a));
-        for (int d = lane; d < p.S; d += 64) {
-            float v = 0.f;
-            for (int b = 0; b < nn; ++b) v += e[b] * xs[b * p.S + d];
-            yr[d] = v / den;
-        }
-    }
+    const int ntmax = (maxnodes + 15) / 16;
+    float *pl = sm + (size_t)(threadIdx.x >> 6) * (ntmax * 16) * (ntmax * 16 + 4);
+    const int NT = (nn + 15) / 16;
+    if (NT == 1) sgr_pair_body<1>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
+    else if (NT == 2) sgr_pair_body<2>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
+    else if (NT == 3) sgr_pair_body<3>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
+    else sgr_pair_body<4>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
 }
 
 __global__ __launch_bounds__(256) void sgr_final_kernel(const float *__restrict__ xglo, int64_t Nc, int S_, const float *__restrict__ eval_w,
@@ -364,16 +459,17 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
                                w->saf_bn_b, w->saf_bn_mean, w->saf_bn_var, w->eval_w, w->eval_b, npairs, Sout, ldS, i0);
             ITR_CHECK_LAUNCH("sgraf saf_pair");
         } else {
-            const size_t lds = (size_t)2 * (max_len + 1) * S * 4;
-            ITR_UNSUPPORTED(lds > 64 * 1024, "itr_sgraf_scores: (max_len+1) * sim_dim too large for the SGR pair kernel");
+            const int ntmax = (max_len + 1 + 15) / 16;
+            const size_t lds = (size_t)4 * (ntmax * 16) * (ntmax * 16 + 4) * 4;   // 4 waves x P[NT*16][NT*16+4]
+            ITR_UNSUPPORTED(S % 16 != 0, "itr_sgraf_scores: SGR needs sim_dim %% 16 == 0");
             for (int k = 0; k < sgr_step; ++k) {
                 const int last = (k == sgr_step - 1);
                 SG_TRY(gemm_nt(Xloc, S, w->sgr_q_w[k], S, w->sgr_q_b[k], Qloc, S, nb * ncols, S, S, 0, st));
                 SG_TRY(gemm_nt(Xglo, S, w->sgr_q_w[k], S, w->sgr_q_b[k], Qglo, S, nb * Nc, S, S, 0, st));
                 SG_TRY(gemm_nt(Xloc, S, w->sgr_k_w[k], S, w->sgr_k_b[k], Kloc, S, nb * ncols, S, S, 0, st));
                 SG_TRY(gemm_nt(Xglo, S, w->sgr_k_w[k], S, w->sgr_k_b[k], Kglo, S, nb * Nc, S, S, 0, st));
-                hipLaunchKernelGGL(sgr_pair_kernel, dim3((unsigned)npairs), dim3(64), lds, st, pa, Qglo, Qloc, Kglo, Kloc, Yglo, Yloc,
-                                   npairs, max_len + 1, last);
+                hipLaunchKernelGGL(sgr_pair_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), lds, st, pa, Qglo, Qloc, Kglo, Kloc,
+                                   Yglo, Yloc, npairs, max_len + 1, last);
                 ITR_CHECK_LAUNCH("sgraf sgr_pair");
                 // NOTE: a word node is shared by all captions... it is NOT: node rows are per (image, word) and a word
                 // belongs to one caption, so writing Yloc rows per pair is race-free.
