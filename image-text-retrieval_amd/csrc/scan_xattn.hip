@@ -28,6 +28,7 @@
 // lane groups need plane = 4q + (lane >> 4) so both planes of a ds_read_b128 lane group share
 // bits [3:2] of the XOR).
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 #include "scan_common.h"
@@ -71,6 +72,31 @@ struct ScanSmem {
 
 // value of the normalised attention logit b (before * lambda_softmax) from the raw a and the
 // statistics of its normalisation group (Objectives.py:436-457)
+template <int NORM>
+__device__ __forceinline__ float norm_apply_c(float a, float s0, float s1) {
+    if (NORM == 0) return leaky(a) * s0;
+    if (NORM == 1) return a * s0;
+    if (NORM == 2) return expf(a - s0) * s1;
+    if (NORM == 3) return a;
+    if (NORM == 4) return leaky(a);
+    if (NORM == 5) return a * s0;
+    return leaky(a) * s0;
+}
+// Runs f(std::integral_constant<int, norm>) so that the per-element code is specialised at compile time: with a
+// run-time `norm` hipcc emits a tree of scalar branches (and an lgkmcnt(0)) PER ELEMENT.
+template <typename F>
+__device__ __forceinline__ void dispatch_norm(int norm, F &&f) {
+    switch (norm) {
+        case 0: f(std::integral_constant<int, 0>{}); break;
+        case 1: f(std::integral_constant<int, 1>{}); break;
+        case 2: f(std::integral_constant<int, 2>{}); break;
+        case 3: f(std::integral_constant<int, 3>{}); break;
+        case 4: f(std::integral_constant<int, 4>{}); break;
+        case 5: f(std::integral_constant<int, 5>{}); break;
+        default: f(std::integral_constant<int, 6>{}); break;
+    }
+}
+
 __device__ __forceinline__ float norm_apply(float a, int norm, float s0, float s1) {
     switch (norm) {
         case 0: return leaky(a) * s0;             // clipped_l2norm: s0 = 1 / (sqrt(sum leaky^2) + eps)
@@ -131,6 +157,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
     const int64_t img0 = it * SC_IMGS;
 
     unsigned long long tick_ = g.dbg_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
+    // t2i: ||E_w|| of this lane's word column is only needed at the very end -- fetch it now
+    const float wnorm_pre = (g.mode == 0) ? g.wnorm[ct * SC_NT + lane] : 0.f;
     // ---- tile metadata: needed by the epilogue only, so its load overlaps the main loop
     if (tid < 64) reinterpret_cast<int32_t *>(&sm.meta)[tid] = reinterpret_cast<const int32_t *>(g.meta + ct)[tid];
 
@@ -173,22 +201,25 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ind[4 * u + j] = (sm.meta.col_cap[16 * u + 4 * fg + j] == fi) ? 1.f : 0.f;
-            for (int mt = wave; mt < SC_MTILES; mt += 4) {
-                f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+            dispatch_norm(norm, [&](auto NC) {
+                constexpr int NORM = decltype(NC)::value;
+                for (int mt = wave; mt < SC_MTILES; mt += 4) {
+                    f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = AT(mt * 16 + fi, 16 * u + 4 * fg + j);
-                        if (norm == 0 || norm == 6) v = leaky(v);
-                        v = (norm <= 1) ? v * v : fabsf(v);
-                        sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, ind[4 * u + j], sacc, 0, 0, 0);
-                    }
-                f32x4 o;
+                        for (int j = 0; j < 4; ++j) {
+                            float v = AT(mt * 16 + fi, 16 * u + 4 * fg + j);
+                            if (NORM == 0 || NORM == 6) v = leaky(v);
+                            v = (NORM <= 1) ? v * v : fabsf(v);
+                            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, ind[4 * u + j], sacc, 0, 0, 0);
+                        }
+                    f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = 1.f / ((norm <= 1 ? sqrtf(sacc[j]) : sacc[j]) + 1e-8f);
-                if (fi < SC_MAXCAP) *reinterpret_cast<f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]) = o;   // caption slot fi
-            }
+                    for (int j = 0; j < 4; ++j) o[j] = 1.f / ((NORM <= 1 ? sqrtf(sacc[j]) : sacc[j]) + 1e-8f);
+                    if (fi < SC_MAXCAP) *reinterpret_cast<f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]) = o;   // caption slot fi
+                }
+            });
         } else if (norm == 2) {
             for (int idx = tid; idx < SC_MT * ncap; idx += SC_THREADS) {
                 const int k = idx / SC_MT, row = idx - k * SC_MT;
@@ -220,24 +251,27 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                 const int kk = k < 0 ? 0 : k;
                 float *colp = &sm.arawt[w][ii * SC_R];
                 float a[SC_R], e[SC_R];
-#pragma unroll
-                for (int r4 = 0; r4 < SC_R / 4; ++r4) {
-                    const f32x4 av = *reinterpret_cast<const f32x4 *>(colp + 4 * r4);
-                    f32x4 s0 = f32x4{1.f, 1.f, 1.f, 1.f}, s1 = s0;
-                    if (norm != 3 && norm != 4) s0 = *reinterpret_cast<const f32x4 *>(&sm.stat[0][kk][ii * SC_R + 4 * r4]);
-                    if (norm == 2) s1 = *reinterpret_cast<const f32x4 *>(&sm.stat[1][kk][ii * SC_R + 4 * r4]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        a[4 * r4 + j] = av[j];
-                        e[4 * r4 + j] = norm_apply(av[j], norm, s0[j], s1[j]) * ls;
-                    }
-                }
                 float mx = 0.f;
-                if (norm == 3 || norm == 4) {
-                    mx = e[0];
+                dispatch_norm(norm, [&](auto NC) {
+                    constexpr int NORM = decltype(NC)::value;
 #pragma unroll
-                    for (int r = 1; r < SC_R; ++r) mx = fmaxf(mx, e[r]);
-                }
+                    for (int r4 = 0; r4 < SC_R / 4; ++r4) {
+                        const f32x4 av = *reinterpret_cast<const f32x4 *>(colp + 4 * r4);
+                        f32x4 s0 = f32x4{1.f, 1.f, 1.f, 1.f}, s1 = s0;
+                        if (NORM != 3 && NORM != 4) s0 = *reinterpret_cast<const f32x4 *>(&sm.stat[0][kk][ii * SC_R + 4 * r4]);
+                        if (NORM == 2) s1 = *reinterpret_cast<const f32x4 *>(&sm.stat[1][kk][ii * SC_R + 4 * r4]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            a[4 * r4 + j] = av[j];
+                            e[4 * r4 + j] = norm_apply_c<NORM>(av[j], s0[j], s1[j]) * ls;
+                        }
+                    }
+                    if (NORM == 3 || NORM == 4) {
+                        mx = e[0];
+#pragma unroll
+                        for (int r = 1; r < SC_R; ++r) mx = fmaxf(mx, e[r]);
+                    }
+                });
                 float den = 0.f, num = 0.f;
 #pragma unroll
                 for (int r = 0; r < SC_R; ++r) {
@@ -249,6 +283,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                 for (int r4 = 0; r4 < SC_R / 4; ++r4)
                     *reinterpret_cast<f32x4 *>(colp + 4 * r4) = f32x4{e[4 * r4], e[4 * r4 + 1], e[4 * r4 + 2], e[4 * r4 + 3]};
                 const float rden = 1.f / den;
+                SC_TICK(5)   // E2a: weights
                 // T = G E.  B operand (k = region r2, n = word): lane (fi, fg) feeds E[16u + 4fg + j][nt*16 + fi].
                 // Only this wave touches rows ii*36 .. +35, and LDS operations of one wave are ordered.
                 f32x4 tacc[3][4];
@@ -263,18 +298,20 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                     for (int u = 0; u < 2; ++u) {
                         const f32x4 bv = *reinterpret_cast<const f32x4 *>(ec + 16 * u + 4 * fg);
 #pragma unroll
-                        for (int mt = 0; mt < 3; ++mt) {
-                            tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].x, bv[0], tacc[mt][nt], 0, 0, 0);
-                            tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].y, bv[1], tacc[mt][nt], 0, 0, 0);
-                            tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].z, bv[2], tacc[mt][nt], 0, 0, 0);
-                            tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].w, bv[3], tacc[mt][nt], 0, 0, 0);
-                        }
+                        for (int mt = 0; mt < 3; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].x, bv[0], tacc[mt][nt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].y, bv[1], tacc[mt][nt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].z, bv[2], tacc[mt][nt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].w, bv[3], tacc[mt][nt], 0, 0, 0);
                     }
                     const float b4 = ec[32 + fg];
 #pragma unroll
                     for (int mt = 0; mt < 3; ++mt)
                         tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfb[mt], b4, tacc[mt][nt], 0, 0, 0);
                 }
+                SC_TICK(6)   // E2b: T = G E
                 // q[nt] = sum_r E[r][col] * T[r][col], col = nt*16 + fi; this lane holds rows mt*16 + 4fg + j
                 float qn[4];
 #pragma unroll
@@ -306,7 +343,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                         pd[r4] = f32x4{e[4 * r4] * rden, e[4 * r4 + 1] * rden, e[4 * r4 + 2] * rden, e[4 * r4 + 3] * rden};
                     g.emit_cn[orow] = 1.f / (sqrtf(fmaxf(q, 0.f)) + 1e-8f);
                 }
-                const float w1 = g.wnorm[ct * SC_NT + w];
+                const float w1 = wnorm_pre;
                 const float w2 = sqrtf(fmaxf(q, 0.f));
                 simv = num / fmaxf(w1 * w2, 1e-8f);   // cosine_similarity, Objectives.py:10-15
             }
