@@ -150,8 +150,12 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ITR_FORCE_COLLECTIVES=1: run every RCCL call of the N>1 path with a single rank (1-GPU box smoke of the
+    # collectives' dtypes/ops; see tests/test_kernels_gpu.py::test_bench_collectives_single_rank)
+    use_dist = world > 1 or os.environ.get("ITR_FORCE_COLLECTIVES") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from itr_amd import evalpipe, ops
@@ -190,7 +194,7 @@ def main():
         return model.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm, sgraf_weights=sim_w)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -206,7 +210,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -263,8 +267,8 @@ def main():
             base["max_abs_diff_vs_gpu"] = float((S[:ns, :ncs].cpu() - S_cpu).abs().max())
             out["cpu_baseline"] = base
             out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if use_dist:
         dist.destroy_process_group()
 
 

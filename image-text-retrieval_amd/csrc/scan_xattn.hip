@@ -157,6 +157,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
     const int64_t img0 = it * SC_IMGS;
 
     unsigned long long tick_ = g.dbg_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long real0_ = g.dbg_cycles ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz
     // t2i: ||E_w|| of this lane's word column is only needed at the very end -- fetch it now
     const float wnorm_pre = (g.mode == 0) ? g.wnorm[ct * SC_NT + lane] : 0.f;
     // ---- tile metadata: needed by the epilogue only, so its load overlaps the main loop
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
         }
         __syncthreads();
         SC_TICK(3)   // E2
+        if (g.dbg_cycles && tid == 0) atomicAdd(&g.dbg_cycles[7], __builtin_amdgcn_s_memrealtime() - real0_);
         // E3: aggregate over the words of each caption (Objectives.py:355-366)
         if (tid < SC_IMGS * SC_MAXCAP) {
             const int ii = tid / SC_MAXCAP, k = tid % SC_MAXCAP;

@@ -13,6 +13,8 @@ Partitioning:
      the single-GPU one by construction.
 With world_size == 1 every collective is skipped.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -35,7 +37,8 @@ class Comm:
     the CPU tests) or a no-op for a single process."""
 
     def __init__(self, group=None):
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.on = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get("ITR_FORCE_COLLECTIVES") == "1")
         self.group = group
         self.rank = dist.get_rank(group) if self.on else 0
         self.world = dist.get_world_size(group) if self.on else 1

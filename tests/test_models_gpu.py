@@ -168,3 +168,26 @@ def test_sgraf_model_wrapper(golden, dev, mod):
     from itr_amd.metricmodule import evaluation
     d = evaluation.cal_sims(model, g["images"], g["captions"], g["cap_lens"], shard_size=10 ** 9)
     assert np.abs(d - g["sim_" + mod]).max() <= 5e-6
+
+
+@pytest.mark.gpu
+def test_bench_collectives_single_rank():
+    """Every RCCL call of the N>1 path (all-gather of the packed words, fp32 max / int32 sum / sign-flipped int64
+    max all-reduces) executed with a 1-rank nccl group on the 1-GPU box: same ranks as the no-collective run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "scan_t2i_f30k1k", "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline"]
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, ITR_FORCE_COLLECTIVES=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]   # RCCL prints a version banner too
+        assert len(line) == 1, r.stdout[-2000:]
+        outs.append(json.loads(line[0]))
+    assert outs[0]["recall"] == outs[1]["recall"]
+    assert outs[1]["n_gpus"] == 1

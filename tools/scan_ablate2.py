@@ -41,5 +41,8 @@ for extra in (0, 4000):
         torch.cuda.synchronize()
         cyc = out.view(torch.int64).flatten()[:8].cpu().numpy()
         nblocks = ((Ni + 3) // 4) * plan.n_tiles
+        if cyc[7] > 0:
+            print("   shader clock during the kernel: %.3f GHz (sum of phase cycles / 100 MHz real-time ticks)" % (
+                float(cyc[:7].sum()) / float(cyc[7]) * 0.1))
         print("blocks/CU=%d flag %d: cycles per workgroup: prologue %.0f  main %.0f  park %.0f  E1 %.0f  E2 %.0f" % (
             2 if extra == 0 else 1, flag, cyc[4] / nblocks, cyc[0] / nblocks, cyc[1] / nblocks, cyc[2] / nblocks, cyc[3] / nblocks), " E2a %.0f E2b %.0f (E2 = rest after E2b)" % (cyc[5] / nblocks, cyc[6] / nblocks))
