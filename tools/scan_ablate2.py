@@ -37,11 +37,18 @@ for extra in (0, 4000):
     for flag in (16, 17):
         os.environ["ITR_SCAN_DEBUG"] = str(flag)
         out = torch.zeros(Ni, Nc + 64, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         ops.scan_xattn_scores(img, words, plan, workspace=ws, out=out)
+        e1.record()
         torch.cuda.synchronize()
+        wall_ms = e0.elapsed_time(e1)
         cyc = out.view(torch.int64).flatten()[:8].cpu().numpy()
         nblocks = ((Ni + 3) // 4) * plan.n_tiles
         if cyc[7] > 0:
+            slots = 256 * (2 if extra == 0 else 1)
+            print("   wall %.2f ms; workgroup residency (sum of per-workgroup real time / (%d slots x wall)) = %.3f; "
+                  "workgroups %d" % (wall_ms, slots, float(cyc[7]) * 1e-5 / (slots * wall_ms), nblocks))
             print("   shader clock during the kernel: %.3f GHz (sum of phase cycles / 100 MHz real-time ticks)" % (
                 float(cyc[:7].sum()) / float(cyc[7]) * 0.1))
         print("blocks/CU=%d flag %d: cycles per workgroup: prologue %.0f  main %.0f  park %.0f  E1 %.0f  E2 %.0f" % (
