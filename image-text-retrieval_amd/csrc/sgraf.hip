@@ -29,6 +29,9 @@ int scan_scores_impl(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, 
                      void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
                      int64_t img_count, itr_stream_t stream);
 
+int sgraf_loc_fused(const float *P, const float *cn, const float *img, const float *wtiled, const float *W, const float *bias,
+                    float *X, int64_t nb, int64_t n_tiles, int D, hipStream_t st);
+
 constexpr float BN_EPS = 1e-5f;
 
 // y = tanh(bn(x)) in place; the BN channel is (row % period) when by_row, else the column (eval statistics)
@@ -115,6 +118,12 @@ __global__ __launch_bounds__(256) void transpose_img_kernel(const float *__restr
         const int d = idx / R, r = idx % R;
         if (d0 + d < D) out[(i * D + d0 + d) * R + r] = t[r][d];
     }
+}
+
+// out[c, r] = in[r, c] for the small (sim_dim x sim_dim) weight matrices; runs 2 x sgr_step times per call
+__global__ __launch_bounds__(256) void transpose_small_kernel(const float *__restrict__ in, int rows, int cols, float *__restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < rows * cols) { const int r = idx / cols, c = idx % cols; out[c * rows + r] = in[idx]; }
 }
 
 // Aglo[(ii, c), d] = (img_glo[ii, d] - cap_glo[c, d])^2
@@ -347,8 +356,9 @@ extern "C" size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_ro
     b += al((size_t)Nc * 4) + al((size_t)Nc * 8);                                // cap_col, seg offsets (unused slot)
     b += al((size_t)IB * ncols * SC_R * 4) + al((size_t)IB * ncols * 4) + al((size_t)IB * Nc * 4);   // P, cn, scan scratch
     b += al((size_t)IB * ncols * D * 4) + al((size_t)IB * Nc * D * 4);           // Aloc, Aglo
-    const int nbuf = module == 1 ? 4 : 1;                                        // X (+ Q, K, Y for SGR)
+    const int nbuf = module == 1 ? 3 : 1;                                        // X (+ Q', Y for SGR)
     b += (al((size_t)IB * ncols * S * 4) + al((size_t)IB * Nc * S * 4)) * nbuf;
+    if (module == 1) b += al((size_t)S * S * 4) * 2 + (al((size_t)S * S * 4) + al((size_t)S * 4)) * 8;   // W^T scratch, folded query weights
     return b;
 }
 
@@ -389,11 +399,13 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     float *sscr = (float *)take((size_t)IB * Nc * 4);
     float *Aloc = (float *)take((size_t)IB * ncols * D * 4), *Aglo = (float *)take((size_t)IB * Nc * D * 4);
     float *Xloc = (float *)take((size_t)IB * ncols * S * 4), *Xglo = (float *)take((size_t)IB * Nc * S * 4);
-    float *Qloc = nullptr, *Qglo = nullptr, *Kloc = nullptr, *Kglo = nullptr, *Yloc = nullptr, *Yglo = nullptr;
+    float *Qloc = nullptr, *Qglo = nullptr, *Yloc = nullptr, *Yglo = nullptr;
+    float *WqT = nullptr, *WkT = nullptr, *Wfold[8] = {nullptr}, *vfold[8] = {nullptr};
     if (module == 1) {
         Qloc = (float *)take((size_t)IB * ncols * S * 4); Qglo = (float *)take((size_t)IB * Nc * S * 4);
-        Kloc = (float *)take((size_t)IB * ncols * S * 4); Kglo = (float *)take((size_t)IB * Nc * S * 4);
         Yloc = (float *)take((size_t)IB * ncols * S * 4); Yglo = (float *)take((size_t)IB * Nc * S * 4);
+        WqT = (float *)take((size_t)S * S * 4); WkT = (float *)take((size_t)S * S * 4);
+        for (int k = 0; k < 8; ++k) { Wfold[k] = (float *)take((size_t)S * S * 4); vfold[k] = (float *)take((size_t)S * 4); }
     }
     int rc;
 #define SG_TRY(x) { rc = (x); if (rc != ITR_OK) return rc; }
@@ -436,6 +448,23 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     // the tile-packed words live at a fixed place of the scan workspace (scan_carve: meta first, then wtiled)
     const float *wtiled = reinterpret_cast<const float *>(static_cast<char *>(scan_ws) + al((size_t)n_tiles * sizeof(ScanTileMeta)));
 
+    // ---- SGR: fold the key projection into the query projection (GraphReasoning, Fusionmodule.py:589-597).
+    // edge = softmax_j(q_i . k_j) with q = Wq x + bq, k = Wk x + bk.  q_i . k_j = (Wk^T q_i) . x_j + q_i . bk and the
+    // second term does not depend on j, so it cancels in the softmax:  edge = softmax_j(q'_i . x_j) with
+    //     q' = (Wk^T Wq) x + Wk^T bq.
+    // One S x S projection per node and step instead of two; the pair kernel reads the nodes themselves as keys.
+    if (module == 1) {
+        const unsigned tb = (unsigned)ceil_div((int64_t)S * S, 256);
+        for (int k = 0; k < sgr_step; ++k) {
+            hipLaunchKernelGGL(transpose_small_kernel, dim3(tb), dim3(256), 0, st, w->sgr_q_w[k], S, S, WqT);
+            hipLaunchKernelGGL(transpose_small_kernel, dim3(tb), dim3(256), 0, st, w->sgr_k_w[k], S, S, WkT);
+            ITR_CHECK_LAUNCH("sgraf weight transpose");
+            // Wfold[b][a] = sum_o Wk[o][b] Wq[o][a];  vfold[b] = sum_o bq[o] Wk[o][b]
+            SG_TRY(gemm_nt(WkT, S, WqT, S, nullptr, Wfold[k], S, S, S, S, 0, st));
+            SG_TRY(gemm_nt(w->sgr_q_b[k], S, WkT, S, nullptr, vfold[k], S, 1, S, S, 0, st));
+        }
+    }
+
     PairArgs pa{Xglo, Xloc, cap_col, cap_len, Nc, ncols, S};
     for (int64_t i0 = 0; i0 < Ni; i0 += IB) {
         const int64_t nb = (Ni - i0 < IB) ? Ni - i0 : IB;
@@ -443,11 +472,15 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
         SG_TRY(scan_scores_impl(img, n_tiles, Ni, Nc, n_rows, SC_R, D, 0, 0, 0, 9.0f, 6.0f, sscr, Nc, scan_ws, scan_bytes, P, cn, i0,
                                 nb, stream));
         // 2. (l2norm(ctx) - E)^2 per image, 3. sim_loc
-        for (int64_t ii = 0; ii < nb; ++ii)
-            SG_TRY(gemm_nt_sqdiff(P + ii * ncols * SC_R, SC_R, imgT + (i0 + ii) * D * SC_R, SC_R, cn + ii * ncols, wtiled, D,
-                                  Aloc + ii * ncols * D, D, ncols, D, SC_R, st));
-        SG_TRY(gemm_nt(Aloc, D, w->loc_w, D, w->loc_b, Xloc, S, nb * ncols, S, D, 0, st));
-        SG_TRY(norm_rows(Xloc, Xloc, nb * ncols, S, 1e-8f, 0, 0, st));
+        if (S == 256) {   // the configured sim_dim: fused, (ctx - E)^2 never leaves the chip (sgraf_loc.hip)
+            SG_TRY(sgraf_loc_fused(P, cn, img + i0 * SC_R * D, wtiled, w->loc_w, w->loc_b, Xloc, nb, n_tiles, D, st));
+        } else {
+            for (int64_t ii = 0; ii < nb; ++ii)
+                SG_TRY(gemm_nt_sqdiff(P + ii * ncols * SC_R, SC_R, imgT + (i0 + ii) * D * SC_R, SC_R, cn + ii * ncols, wtiled, D,
+                                      Aloc + ii * ncols * D, D, ncols, D, SC_R, st));
+            SG_TRY(gemm_nt(Aloc, D, w->loc_w, D, w->loc_b, Xloc, S, nb * ncols, S, D, 0, st));
+            SG_TRY(norm_rows(Xloc, Xloc, nb * ncols, S, 1e-8f, 0, 0, st));
+        }
         // 4. sim_glo
         hipLaunchKernelGGL(glo_sqdiff_kernel, dim3((unsigned)Nc, (unsigned)nb), dim3(256), 0, st, img_glo + i0 * D, cap_glo, Nc, D, Aglo);
         ITR_CHECK_LAUNCH("sgraf glo_sqdiff");
@@ -464,11 +497,9 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
             ITR_UNSUPPORTED(S % 16 != 0, "itr_sgraf_scores: SGR needs sim_dim %% 16 == 0");
             for (int k = 0; k < sgr_step; ++k) {
                 const int last = (k == sgr_step - 1);
-                SG_TRY(gemm_nt(Xloc, S, w->sgr_q_w[k], S, w->sgr_q_b[k], Qloc, S, nb * ncols, S, S, 0, st));
-                SG_TRY(gemm_nt(Xglo, S, w->sgr_q_w[k], S, w->sgr_q_b[k], Qglo, S, nb * Nc, S, S, 0, st));
-                SG_TRY(gemm_nt(Xloc, S, w->sgr_k_w[k], S, w->sgr_k_b[k], Kloc, S, nb * ncols, S, S, 0, st));
-                SG_TRY(gemm_nt(Xglo, S, w->sgr_k_w[k], S, w->sgr_k_b[k], Kglo, S, nb * Nc, S, S, 0, st));
-                hipLaunchKernelGGL(sgr_pair_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), lds, st, pa, Qglo, Qloc, Kglo, Kloc,
+                SG_TRY(gemm_nt(Xloc, S, Wfold[k], S, vfold[k], Qloc, S, nb * ncols, S, S, 0, st));
+                SG_TRY(gemm_nt(Xglo, S, Wfold[k], S, vfold[k], Qglo, S, nb * Nc, S, S, 0, st));
+                hipLaunchKernelGGL(sgr_pair_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), lds, st, pa, Qglo, Qloc, Xglo, Xloc,
                                    Yglo, Yloc, npairs, max_len + 1, last);
                 ITR_CHECK_LAUNCH("sgraf sgr_pair");
                 // NOTE: a word node is shared by all captions... it is NOT: node rows are per (image, word) and a word

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "image-text-retrieval_amd"))
 import torch
 from itr_amd import ops
 dev = torch.device("cuda:0")
-for (M, N, K) in [(4096, 4096, 4096), (180000, 1024, 2048), (265000, 256, 1024), (285000, 256, 256), (25000, 3072, 1024), (66000, 1024, 36)]:
+for (M, N, K) in [(4096, 4096, 4096), (180000, 1024, 2048), (265000, 256, 1024), (265000, 256, 256), (20000, 256, 1024), (20000, 256, 256), (25000, 3072, 1024), (66000, 1024, 36)]:
     a = torch.randn(M, K, device=dev); b = torch.randn(N, K, device=dev); bias = torch.randn(N, device=dev)
     for _ in range(2): ops.linear(a, b, bias)
     torch.cuda.synchronize()
