@@ -342,20 +342,22 @@ __global__ __launch_bounds__(256) void sgr_final_kernel(const float *__restrict_
 }
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
-constexpr int SGRAF_IB = 4;   // images per block (== SCAN image tile)
+// images per block of the pair stage (a multiple of the SCAN image tile).  16 gives every launch of the chain >= 4k
+// workgroups at Flickr size; the unfused fallback (sim_dim != 256) materialises (ctx - E)^2 and stays at 4.
+static inline int64_t sgraf_ib(int S) { return S == 256 ? 16 : 4; }
 
 }  // namespace itr
 
 extern "C" size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_rows, int64_t n_tiles, int D, int S,
                                             int module) {
     using namespace itr;
-    const int64_t ncols = n_tiles * SC_NT, IB = SGRAF_IB;
+    const int64_t ncols = n_tiles * SC_NT, IB = sgraf_ib(S);
     size_t b = itr_scan_workspace_bytes(Ni, SC_R, n_rows, Nc, n_tiles, D) + 256;
     b += al((size_t)Ni * D * 4) * 3 + al((size_t)Ni * SC_R * D * 4) * 2;        // img_ave, g_emb_v, img_glo; l_emb_v, imgT
     b += al((size_t)n_rows * D * 4) + al((size_t)Nc * D * 4) * 3;                // l_emb_t; cap_ave, g_emb_t, cap_glo
     b += al((size_t)Nc * 4) + al((size_t)Nc * 8);                                // cap_col, seg offsets (unused slot)
     b += al((size_t)IB * ncols * SC_R * 4) + al((size_t)IB * ncols * 4) + al((size_t)IB * Nc * 4);   // P, cn, scan scratch
-    b += al((size_t)IB * ncols * D * 4) + al((size_t)IB * Nc * D * 4);           // Aloc, Aglo
+    b += (S == 256 ? 0 : al((size_t)IB * ncols * D * 4)) + al((size_t)IB * Nc * D * 4);   // Aloc (unfused path only), Aglo
     const int nbuf = module == 1 ? 3 : 1;                                        // X (+ Q', Y for SGR)
     b += (al((size_t)IB * ncols * S * 4) + al((size_t)IB * Nc * S * 4)) * nbuf;
     if (module == 1) b += al((size_t)S * S * 4) * 2 + (al((size_t)S * S * 4) + al((size_t)S * 4)) * 8;   // W^T scratch, folded query weights
@@ -380,7 +382,7 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
                 "itr_sgraf_scores: workspace too small");
     if (Ni == 0 || Nc == 0) return ITR_OK;
     hipStream_t st = as_stream(stream);
-    const int64_t ncols = n_tiles * SC_NT, IB = SGRAF_IB;
+    const int64_t ncols = n_tiles * SC_NT, IB = sgraf_ib(S);
 
     // ---- carve
     char *p = static_cast<char *>(workspace);
@@ -397,7 +399,8 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     take((size_t)Nc * 8);
     float *P = (float *)take((size_t)IB * ncols * SC_R * 4), *cn = (float *)take((size_t)IB * ncols * 4);
     float *sscr = (float *)take((size_t)IB * Nc * 4);
-    float *Aloc = (float *)take((size_t)IB * ncols * D * 4), *Aglo = (float *)take((size_t)IB * Nc * D * 4);
+    float *Aloc = (S == 256) ? nullptr : (float *)take((size_t)IB * ncols * D * 4);
+    float *Aglo = (float *)take((size_t)IB * Nc * D * 4);
     float *Xloc = (float *)take((size_t)IB * ncols * S * 4), *Xglo = (float *)take((size_t)IB * Nc * S * 4);
     float *Qloc = nullptr, *Qglo = nullptr, *Yloc = nullptr, *Yglo = nullptr;
     float *WqT = nullptr, *WkT = nullptr, *Wfold[8] = {nullptr}, *vfold[8] = {nullptr};

@@ -261,11 +261,12 @@ def test_sgraf_golden(golden, dev, mod):
 
 
 @pytest.mark.parametrize("mod", ['SAF', 'SGR'])
-def test_sgraf_random_vs_oracle(dev, mod):
-    """more images than one 4-image block, ragged captions, D = 128, sim_dim = 64."""
+@pytest.mark.parametrize("Ni,Nc,D,S", [(9, 23, 128, 64), (21, 70, 256, 256)])
+def test_sgraf_random_vs_oracle(dev, mod, Ni, Nc, D, S):
+    """more images than one image block, ragged captions; sim_dim 64 = unfused chain, 256 = fused local-node kernel
+    (sgraf_loc.hip) with 16-image blocks and more than one caption tile."""
     rng = np.random.RandomState(5)
     torch.manual_seed(5)
-    Ni, Nc, D, S = 9, 23, 128, 64
     lens = [int(x) for x in rng.randint(1, 18, size=Nc)]
     L = max(lens)
     img = O.l2norm(torch.randn(Ni, 36, D), -1)
