@@ -1,0 +1,202 @@
+"""Precomp data layer with the reference's loader contract (itr/datamodule/data_loader.py:17-233).
+
+Files of one dataset directory `<data_path>/<data_name>/` (README.md:395-441):
+    {split}_ims.npy        (N_img, 36, 2048) float32 region features
+    {split}_caps.txt       one caption per line, 5 lines per image (N_cap = 5 N_img unless the features are
+                           already repeated per caption, data_loader.py:73-77)
+    {split}_boxes.npy      (N_img, 36, 4), {split}_img_sizes.npy (N_img, 2)       when config['use_bbox']
+    <vocab_path>/<data_name>_vocab.json                                            GRU models
+    config['vocab_file'] (BERT word-piece vocabulary)                              SAEM / CAMERA
+
+A batch is the reference's 8-tuple  (images, boxes, imgs_wh, captions_ids, lengths, ids, captions_mask,
+captions_type_ids)  (data_loader.py:178), sorted by caption length, descending.
+
+MI355X-first differences (none changes a value):
+  * the feature file is memory-mapped (`np.load(mmap_mode='r')`), never read whole: coco testall is 1.47 GB;
+  * `FeaturePrefetcher` overlaps the pinned-host -> HBM copy of batch k+1 with the encode of batch k on a side
+    HIP stream, so a real-data evaluation is not PCIe-bound;
+  * captions are decoded as UTF-8.  The reference tokenises `str(bytes)` (data_loader.py:113 with the 'rb' read at
+    :63-65), so every caption starts with the token  b'<first word>  and ends with a quote;
+    `config['ref_quirk_bytes_repr'] = True` reproduces that for checkpoints trained on the reference's ids.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.utils.data as data
+
+from . import tokenization
+from . import vocab as vocab_mod
+
+
+def convert_to_feature(raw, seq_length, tokenizer):
+    """BERT input features of one caption (data_loader.py:17-48), including the reference's `insert(-1, "[SEP]")`,
+    which puts [SEP] BEFORE the last word piece instead of after it."""
+    pieces = tokenizer.tokenize(tokenization.convert_to_unicode(raw))[:seq_length - 2]
+    tokens = ["[CLS]"] + list(pieces)
+    tokens.insert(-1, "[SEP]")
+    input_ids = tokenizer.convert_tokens_to_ids(tokens)
+    n = len(input_ids)
+    pad = seq_length - n
+    assert pad >= 0
+    return tokens, input_ids + [0] * pad, [1] * n + [0] * pad, [0] * seq_length
+
+
+class PrecompDataset(data.Dataset):
+    """data_loader.py:51-131."""
+
+    def __init__(self, data_path, data_split, config):
+        self.config = config
+        with open(os.path.join(data_path, '%s_caps.txt' % data_split), 'rb') as f:
+            self.captions = [line.strip() for line in f]
+        self.images = np.load(os.path.join(data_path, '%s_ims.npy' % data_split), mmap_mode='r')
+        if config.get('use_bbox'):
+            self.boxes = np.load(os.path.join(data_path, '%s_boxes.npy' % data_split), mmap_mode='r')
+            self.img_wh = np.load(os.path.join(data_path, '%s_img_sizes.npy' % data_split), mmap_mode='r')
+        self.length = len(self.captions)
+        # rkiros data has redundancy in images: 5 captions per image row unless the rows are already repeated
+        self.im_div = 5 if self.images.shape[0] != self.length else 1
+        if data_split == 'dev':
+            self.length = 5000     # "the development set for coco is large" (data_loader.py:78-80), applied to every dataset
+        if config.get('text_encoder') == 'bert':
+            self.max_words = config['max_words']
+            self.tokenizer = tokenization.FullTokenizer(vocab_file=config['vocab_file'], do_lower_case=True)
+        elif config.get('vocab_type', 'json') == 'json':
+            self.vocab = vocab_mod.deserialize_vocab(os.path.join(config['vocab_path'], '%s_vocab.json' % config['data_name']))
+        else:
+            self.vocab = pickle.load(open(os.path.join(config['vocab_path'], '%s_vocab.pkl' % config['data_name']), 'rb'))
+        self.word_tokenize = config.get('word_tokenize') or tokenization.word_tokenize
+
+    def caption_text(self, caption):
+        if self.config.get('ref_quirk_bytes_repr'):
+            return str(caption)                    # "b'...'" -- what the reference tokenises
+        return caption.decode('utf-8', 'ignore') if isinstance(caption, bytes) else str(caption)
+
+    def token_ids(self, index):
+        """<start> w1 ... wn <end> as vocabulary ids (data_loader.py:113-116)."""
+        tokens = self.word_tokenize(self.caption_text(self.captions[index]).lower())
+        return [self.vocab('<start>')] + [self.vocab(t) for t in tokens] + [self.vocab('<end>')]
+
+    def __getitem__(self, index):
+        img_id = index // self.im_div
+        image = torch.from_numpy(np.array(self.images[img_id], dtype=np.float32))
+        if self.config.get('use_bbox'):
+            boxes = torch.from_numpy(np.array(self.boxes[img_id], dtype=np.float32))
+            img_wh = torch.from_numpy(np.array(self.img_wh[img_id], dtype=np.float32))
+        else:
+            boxes, img_wh = None, None
+        if self.config.get('text_encoder') == 'bert':
+            _, ids, mask, types = convert_to_feature(self.captions[index], self.max_words, self.tokenizer)
+            captions_ids, captions_mask, captions_type_ids = (torch.tensor(v, dtype=torch.long) for v in (ids, mask, types))
+        else:
+            captions_ids = torch.tensor(self.token_ids(index), dtype=torch.long)
+            if self.config.get('name') == 'VSRN':
+                raise NotImplementedError("VSRN caption layout (SURVEY 8(f)-4) is not built")
+            captions_mask, captions_type_ids = None, None
+        return image, boxes, img_wh, captions_ids, index, img_id, captions_mask, captions_type_ids
+
+    def __len__(self):
+        return self.length
+
+
+def collate_fn(batch):
+    """data_loader.py:134-178: sort by len(captions_ids) descending (stable), stack, pad the GRU ids with 0.
+    `ids` is always a list / array (the reference leaves a tuple on CPU-only hosts)."""
+    batch = sorted(batch, key=lambda x: len(x[3]), reverse=True)
+    images, boxes, imgs_wh, captions_ids, ids, img_ids, captions_mask, captions_type_ids = zip(*batch)
+    images = torch.stack(images, 0)
+    if None not in boxes:
+        boxes = torch.stack(boxes, 0)
+        imgs_wh = torch.stack(imgs_wh, 0)
+        lengths = [torch.sum(m) for m in captions_mask]
+        captions_ids = torch.stack(captions_ids, 0)
+        captions_mask = torch.stack(captions_mask, 0)
+        captions_type_ids = torch.stack(captions_type_ids, 0)
+        ids = np.array(ids)
+    else:
+        lengths = [len(cap) for cap in captions_ids]
+        targets = torch.zeros(len(captions_ids), max(lengths), dtype=torch.long)
+        for i, cap in enumerate(captions_ids):
+            targets[i, :lengths[i]] = cap[:lengths[i]]
+        captions_ids = targets
+        if None not in captions_mask:
+            captions_mask = torch.stack(captions_mask, 0)
+        if None not in captions_type_ids:
+            captions_type_ids = torch.stack(captions_type_ids, 0)
+        ids = list(ids)
+    return images, boxes, imgs_wh, captions_ids, lengths, ids, captions_mask, captions_type_ids
+
+
+def get_precomp_loader(data_path, data_split, config, batch_size=100, shuffle=True, num_workers=5):
+    """data_loader.py:181-196 -> (loader, vocab_size)."""
+    dset = PrecompDataset(data_path, data_split, config)
+    vocab_size = len(dset.tokenizer.vocab) if config.get('text_encoder') == 'bert' else len(dset.vocab)
+    loader = torch.utils.data.DataLoader(dataset=dset, batch_size=batch_size, shuffle=shuffle, pin_memory=torch.cuda.is_available(),
+                                         collate_fn=collate_fn, num_workers=num_workers)
+    return loader, vocab_size
+
+
+def get_loaders(data_name, batch_size, workers, config):
+    """data_loader.py:199-227; only the *_precomp datasets are on the path (raw-image datasets: SURVEY section 2, out of scope)."""
+    if not config['data_name'].endswith('_precomp'):
+        raise NotImplementedError("raw-image datasets (CocoDataset / FlickrDataset) are outside the precomp hot path")
+    dpath = os.path.join(config['data_path'], data_name)
+    train_loader, vocab_size = get_precomp_loader(dpath, 'train', config, batch_size, True, workers)
+    val_loader, vocab_size = get_precomp_loader(dpath, 'dev', config, batch_size, False, workers)
+    return train_loader, val_loader, vocab_size
+
+
+def get_test_loader(split_name, data_name, batch_size, workers, config):
+    """data_loader.py:230-234."""
+    dpath = os.path.join(config['data_path'], data_name)
+    return get_precomp_loader(dpath, split_name, config, batch_size, False, workers)
+
+
+class FeaturePrefetcher(object):
+    """Iterates a loader and hands out batches whose tensors already live in HBM: while the consumer encodes
+    batch k on the current stream, batch k+1 is copied pinned-host -> device on a side HIP stream.
+
+        for images, boxes, imgs_wh, captions_ids, lengths, ids, mask, types in FeaturePrefetcher(loader, device):
+            ...
+    Non-tensor members (lengths, ids, None) pass through unchanged."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError("FeaturePrefetcher stages batches into GPU memory: no CPU fallback")
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def _stage(self, batch):
+        out = []
+        with torch.cuda.stream(self.stream):
+            for item in batch:
+                if torch.is_tensor(item):
+                    src = item if item.is_pinned() else item.pin_memory()
+                    out.append(src.to(self.device, non_blocking=True))
+                else:
+                    out.append(item)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return tuple(out), ev
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            try:
+                nxt = self._stage(next(it))      # queue the next copy before the consumer starts computing
+            except StopIteration:
+                nxt = None
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for t in cur:
+                if torch.is_tensor(t):
+                    t.record_stream(torch.cuda.current_stream(self.device))
+            yield cur

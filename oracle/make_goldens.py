@@ -540,9 +540,90 @@ def g13():
     save('g13_camera', **out)
 
 
+# ------------------------------------------------------------------ G14 data layer
+G14_CAPTIONS = [
+    "A man riding a wave on top of a surfboard .", "a dog, running; through the GRASS!", "Two children play.",
+    "the quick brown fox", "A woman in a red dress is standing near a café table with a zebra",
+    "people", "An old man sits on a bench and reads a newspaper while pigeons gather around his feet",
+    "a b c d e f g", "Snow-covered mountains behind a small wooden hut", "a cat sleeps on the sofa",
+    "A man riding a horse", "the dog runs", "children play in the park near a fountain .", "a plate of food with broccoli",
+    "Two dogs", "a skateboarder does a trick on a ramp", "the woman is reading", "A bus drives down the street , past a stop sign",
+    "a man", "a giraffe eats leaves from a tall tree", "sheep graze", "a red dress", "A table with a laptop and a cup of coffee",
+    "the park", "a horse and a dog run through the grass", "zebra", "A small hut", "the man reads a newspaper on a bench",
+    "a child", "pigeons gather near the fountain in the park",
+]
+G14_BERT_VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "a", "the", "man", "dog", "rid", "##ing", "##s", "run", "##ning",
+                  "wave", "on", "top", "of", "surf", "##board", ".", ",", ";", "!", "-", "grass", "through", "two", "child",
+                  "##ren", "play", "quick", "brown", "fox", "woman", "in", "red", "dress", "is", "stand", "near", "cafe",
+                  "table", "with", "zebra", "people", "snow", "covered", "mountain", "behind", "small", "wood", "##en", "hut",
+                  "cat", "sleep", "sofa", "un", "##aff", "##able", "'"]
+
+
+def g14():
+    import json
+    import tempfile
+    from itr.datamodule import data_loader as rdl, vocab as rvocab, tokenization as rtok
+    rng = np.random.RandomState(14)
+    root = tempfile.mkdtemp()
+    name = 'toy_precomp'
+    d = os.path.join(root, name)
+    os.makedirs(d)
+    n_img = 6
+    ims = rng.randn(n_img, 36, 8).astype(np.float32)
+    boxes = rng.uniform(0, 300, size=(n_img, 36, 4)).astype(np.float32)
+    sizes = np.tile(np.array([[640., 480.]], np.float32), (n_img, 1))
+    caps_blob = ("\n".join(G14_CAPTIONS) + "\n").encode('utf-8')
+    for split in ('train', 'dev', 'test'):
+        np.save(os.path.join(d, '%s_ims.npy' % split), ims)
+        np.save(os.path.join(d, '%s_boxes.npy' % split), boxes)
+        np.save(os.path.join(d, '%s_img_sizes.npy' % split), sizes)
+        open(os.path.join(d, '%s_caps.txt' % split), 'wb').write(caps_blob)
+    # -- vocabulary: the reference's build_vocab (threshold 2) + JSON round trip
+    v = rvocab.build_vocab(root, name, caption_file={name: ['train_caps.txt']}, threshold=2)
+    vdir = os.path.join(root, 'vocab')
+    os.makedirs(vdir)
+    rvocab.serialize_vocab(v, os.path.join(vdir, '%s_vocab.json' % name))
+    vocab_json = open(os.path.join(vdir, '%s_vocab.json' % name)).read()
+    out = dict(ims=ims, boxes=boxes, img_sizes=sizes, caps_blob=np.frombuffer(caps_blob, np.uint8),
+               vocab_json=np.frombuffer(vocab_json.encode(), np.uint8), vocab_len=len(v),
+               tokenizer_note="nltk absent: word_tokenize = regex  \\w+|[^\\w\\s]  (oracle/ref_shim.py)")
+    # -- GRU dataset (the reference tokenises str(bytes): SURVEY Q6) + collate_fn
+    cfg = {'use_bbox': False, 'text_encoder': 'gru', 'vocab_path': vdir, 'data_name': name, 'vocab_type': 'json', 'name': 'SCAN'}
+    ds = rdl.PrecompDataset(d, 'test', cfg)
+    out.update(test_len=len(ds), test_im_div=ds.im_div, dev_len=len(rdl.PrecompDataset(d, 'dev', cfg)))
+    ids_all = [ds[i][3].numpy() for i in range(len(ds))]
+    out['gru_ids_concat'] = np.concatenate(ids_all)
+    out['gru_ids_len'] = np.array([len(x) for x in ids_all])
+    out['item7_image'] = ds[7][0].numpy()
+    out['item7_meta'] = np.array([ds[7][4], ds[7][5]])
+    pick = [3, 17, 4, 29, 8, 0, 11, 5]
+    batch = rdl.collate_fn([ds[i] for i in pick])
+    out.update(pick=np.array(pick), col_images=batch[0], col_ids=batch[3], col_lengths=np.array(batch[4]), col_index=np.array(batch[5]))
+    assert batch[1] == (None,) * len(pick) and batch[6] == (None,) * len(pick)
+    # -- BERT tokenizer + features (+ bbox branch of collate_fn)
+    vfile = os.path.join(root, 'bert_vocab.txt')
+    open(vfile, 'w').write("\n".join(G14_BERT_VOCAB) + "\n")
+    tk = rtok.FullTokenizer(vocab_file=vfile, do_lower_case=True)
+    sentences = G14_CAPTIONS[:10] + ["unaffable", "x" * 101 + " dog", "café\tdog\x00s  run", "", "dog's", "running.surfboard"]
+    toks = [tk.tokenize(sn) for sn in sentences]
+    out['bert_vocab'] = np.frombuffer(("\n".join(G14_BERT_VOCAB) + "\n").encode(), np.uint8)
+    out['bert_sentences'] = np.frombuffer(("\n".join(sentences)).encode('utf-8'), np.uint8)
+    out['bert_tokens'] = np.frombuffer(("\n".join(" ".join(t) for t in toks)).encode('utf-8'), np.uint8)
+    feats = [rdl.convert_to_feature(sn.encode('utf-8'), 12, tk) for sn in sentences]
+    out['bert_input_ids'] = np.array([f[1] for f in feats])
+    out['bert_input_mask'] = np.array([f[2] for f in feats])
+    out['bert_type_ids'] = np.array([f[3] for f in feats])
+    cfgb = {'use_bbox': True, 'text_encoder': 'bert', 'max_words': 12, 'vocab_file': vfile, 'data_name': name, 'name': 'CAMERA'}
+    dsb = rdl.PrecompDataset(d, 'test', cfgb)
+    bb = rdl.collate_fn([dsb[i] for i in pick])
+    out.update(bcol_images=bb[0], bcol_boxes=bb[1], bcol_wh=bb[2], bcol_ids=bb[3], bcol_lengths=np.array([int(x) for x in bb[4]]),
+               bcol_index=np.asarray(bb[5]), bcol_mask=bb[6], bcol_types=bb[7])
+    save('g14_data_layer', **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14']
     for name in which:
         print("== " + name)
         globals()[name]()

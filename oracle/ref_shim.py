@@ -46,7 +46,12 @@ def install():
     tv = _stub("torchvision")
     tv.models = _stub("torchvision.models")
     tv.transforms = _stub("torchvision.transforms")
-    _stub("nltk")
+    # nltk is absent: the reference's `nltk.tokenize.word_tokenize` (data_loader.py:113, vocab.py:87) is replaced by
+    # "words | single punctuation marks"; fixtures made through it say so (tests/golden/g14_data_layer.npz).
+    import re
+    _word_re = re.compile(r"\w+|[^\w\s]", re.UNICODE)
+    nl = _stub("nltk")
+    nl.tokenize = _stub("nltk.tokenize", word_tokenize=lambda text: _word_re.findall(text))
     pc = _stub("pycocotools")
     pc.coco = _stub("pycocotools.coco", COCO=object)
     _stub("tensorboard_logger")
