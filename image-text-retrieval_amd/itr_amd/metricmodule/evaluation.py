@@ -175,3 +175,120 @@ def cal_recall(sims):
            'i2t_top1': rt[1], 't2i_ave_r': ari, 't2i_r1': ri[0], 't2i_r5': ri[1], 't2i_r10': ri[2],
            't2i_medr': ri[3], 't2i_meanr': ri[4], 't2i_ranks': rti[0], 't2i_top1': rti[1]}
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# evalrank_single / evalrank_ensemble (evaluation.py:262-435): checkpoint -> loader -> encode -> score -> rank ->
+# `<save_dir>/<data_name>[_5fold]_{single,ensemble}_result.yaml`.
+_MEAN_KEYS = ('i2t_r1', 'i2t_r5', 'i2t_r10', 'i2t_medr', 'i2t_meanr', 't2i_r1', 't2i_r5', 't2i_r10', 't2i_medr', 't2i_meanr')
+
+
+def _plain(res):
+    """YAML-portable copy: numpy scalars / arrays -> python floats / lists (the reference dumps numpy objects,
+    which needs yaml's unsafe loader to read back)."""
+    out = {}
+    for k, v in res.items():
+        if isinstance(v, dict):
+            out[k] = _plain(v)
+        elif isinstance(v, np.ndarray):
+            out[k] = [float(x) for x in v.tolist()]
+        elif isinstance(v, (list, tuple)):
+            out[k] = [[float(x) for x in row] if isinstance(row, (list, tuple, np.ndarray)) else
+                      (float(row) if isinstance(row, (float, int, np.floating, np.integer)) else row) for row in v]
+        elif isinstance(v, (np.floating, np.integer)):
+            out[k] = float(v)
+        else:
+            out[k] = v
+    return out
+
+
+def _mean_metrics(res_dic):
+    """fold5 averaging (evaluation.py:307-333).  The reference writes the means INTO the last fold's dict (the same
+    object as PART_5), so its PART_5 entry shows the averages; here PART_5 keeps its own numbers and
+    `Mean_metrics` is a dict of its own."""
+    mean = tuple(np.array(res_dic['sum_result']).mean(axis=0).flatten())
+    print("---------------------------------------------------------")
+    print("--------------------- Mean metrics: ---------------------")
+    print("rsum: %.1f" % (mean[10] * 6))
+    print("Average i2t Recall: %.1f" % mean[11])
+    print("Image to text: r1 %.1f; r5 %.1f; r10 %.1f; medr %.1f; meanr %.1f" % mean[:5])
+    print("Average t2i Recall: %.1f" % mean[12])
+    print("Text to image: r1 %.1f; r5 %.1f; r10 %.1f; medr %.1f; meanr %.1f" % mean[5:10])
+    out = {'rsum': mean[10] * 6, 'i2t_ave_r': mean[11], 't2i_ave_r': mean[12]}
+    out.update({k: mean[i] for i, k in enumerate(_MEAN_KEYS)})
+    return out
+
+
+def _load_for_eval(model_path, data_path):
+    from ..modalmodule import get_model
+    from ..utils import load_checkpoint
+    checkpoint = load_checkpoint(model_path)
+    _config = checkpoint['_config']
+    print('Best model: Epoch = {}, Eiters = {}, Rsum = {:.2f}, R1 = {:.2f}'.format(
+        checkpoint['epoch'], checkpoint['Eiters'], checkpoint['best_rsum'], checkpoint.get('best_r1', checkpoint.get('best_rl', 0.0))))
+    if data_path is not None:
+        _config['data_path'] = data_path
+    model = get_model(_config)
+    model.load_state_dict(checkpoint['model'])
+    return model, _config
+
+
+def _score_blocks(models_embs, fold5):
+    """models_embs: list of (model, img_embs, cap_embs, cap_lens, shard_size); the similarity matrices of the
+    models are averaged (ensemble, evaluation.py:377-381)."""
+    def sims_of(sl_img, sl_cap):
+        acc = None
+        for model, img, cap, lens, shard in models_embs:
+            s = cal_sims(model, img[sl_img], cap[sl_cap], lengths=lens[sl_cap], shard_size=shard)
+            acc = s if acc is None else acc + s
+        return acc / len(models_embs)
+
+    n = len(models_embs[0][1])
+    if not fold5:
+        return cal_recall(sims_of(slice(0, n, 5), slice(None)))
+    res_dic = {'sum_result': []}
+    for i in range(5):
+        print(f"--------------------- The {i + 1} part ---------------------")
+        part = cal_recall(sims_of(slice(i * 5000, (i + 1) * 5000, 5), slice(i * 5000, (i + 1) * 5000)))
+        res_dic[f'PART_{i + 1}'] = part
+        res_dic['sum_result'] += part['result']
+    res_dic['Mean_metrics'] = _mean_metrics(res_dic)
+    return res_dic
+
+
+def _evalrank(model_paths, data_path, split, fold5, tag):
+    import os
+    import yaml
+    from ..datamodule import data_loader as data
+    loaded = [_load_for_eval(p, data_path) for p in model_paths]
+    _config = loaded[0][1]
+    print(f'Loading dataset : {_config["data_name"]} ......')
+    data_loader, _ = data.get_test_loader(split, _config['data_name'], _config['batch_size'], _config['workers'], _config)
+    print('Computing results...')
+    # the reference asks for max-length sizing only for SGRAF (evaluation.py:284), which breaks SCAN whenever a later
+    # batch holds a longer caption than the first (SURVEY Q6); word-level models all need it
+    islength = _config['name'] in ['SGRAF', 'SCAN']
+    embs = []
+    for model, cfg in loaded:
+        img, cap, lens = encode_data(model, data_loader, islength=islength)
+        embs.append((model, img, cap, lens, cfg['batch_size'] * 5))
+    print('#Images: %d, #Captions: %d' % (embs[0][1].shape[0] / 5, embs[0][2].shape[0]))
+    res_dic = _score_blocks(embs, fold5)
+    res_dic['data_name'] = _config['data_name'] + ('_5fold' if fold5 else '')
+    if len(model_paths) > 1 and fold5:
+        res_dic['modal_path_1'], res_dic['modal_path_2'] = model_paths[0], model_paths[1]
+    save_dir = os.path.dirname(model_paths[0])
+    out_file = os.path.join(save_dir, f'{res_dic["data_name"]}_{tag}_result.yaml')
+    with open(out_file, 'w') as yaml_file:
+        yaml.safe_dump(_plain(res_dic), yaml_file)
+    return res_dic
+
+
+def evalrank_single(model_path, data_path=None, split='dev', fold5=False):
+    """evaluation.py:262-335."""
+    return _evalrank([model_path], data_path, split, fold5, 'single')
+
+
+def evalrank_ensemble(model_path, model_path2, data_path=None, split='dev', fold5=False):
+    """evaluation.py:338-435: the two models' similarity matrices are averaged before ranking."""
+    return _evalrank([model_path, model_path2], data_path, split, fold5, 'ensemble')

@@ -1,0 +1,134 @@
+"""GPU: checkpoint -> precomp files -> loader -> encode -> score -> rank -> result yaml (evalrank_single / _ensemble,
+utils.validate_step, load_resume) on a toy dataset materialised from tests/golden/g14_data_layer.npz, against the
+CPU oracle run on the same batches."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import itr_oracle as O
+from itr_amd import config as C, utils
+from itr_amd.datamodule import data_loader as dl, tokenization as tok
+from itr_amd.metricmodule import evaluation
+from itr_amd.modalmodule import get_model
+import itr_amd.modalmodule as models
+
+pytestmark = pytest.mark.gpu
+
+
+def _materialise(g, tmp_path, n_rep=1):
+    name = 'toy_precomp'
+    d = tmp_path / 'data' / name
+    d.mkdir(parents=True)
+    for split in ('train', 'dev', 'test'):
+        np.save(d / ('%s_ims.npy' % split), g["ims"])
+        (d / ('%s_caps.txt' % split)).write_bytes(bytes(g["caps_blob"]))
+    vdir = tmp_path / 'vocab'
+    vdir.mkdir()
+    (vdir / ('%s_vocab.json' % name)).write_text(bytes(g["vocab_json"]).decode())
+    return name, str(tmp_path / 'data'), str(vdir)
+
+
+def _scan_cfg(name, data_path, vdir, save_dir, seed):
+    cfg = C.build_config(['with', 'SCAN', 'data_name=%s' % name, 'bi_gru=True', 'max_violation=True', 'seed=%d' % seed])
+    cfg.update(img_dim=8, embed_size=32, word_dim=16, vocab_size=int(0), data_path=data_path, vocab_path=vdir,
+               batch_size=7, workers=0, save_dir=save_dir, word_tokenize=None)
+    return cfg
+
+
+def _oracle_eval(model, cfg, name, data_path):
+    """Same batches through the CPU oracle -> similarity matrix (N_img, N_cap)."""
+    loader, _ = dl.get_test_loader('test', name, cfg['batch_size'], 0, cfg)
+    wi = {k: v.detach().cpu() for k, v in model.img_enc.state_dict().items()}
+    wt = {k: v.detach().cpu() for k, v in model.txt_enc.state_dict().items()}
+    n = len(loader.dataset)
+    img_rows, caps, lens_all = [None] * n, [None] * n, [0] * n
+    for images, _, _, cap_ids, lengths, ids, _, _ in loader:
+        im = O.encoder_image_precomp(images, wi["fc.weight"], wi["fc.bias"])
+        ce, _ = O.encoder_text(cap_ids, [int(x) for x in lengths], wt, True, True, False, None)
+        for r, i in enumerate(ids):
+            img_rows[i], caps[i], lens_all[i] = im[r], ce[r, :int(lengths[r])], int(lengths[r])
+    L = max(lens_all)
+    cap_pad = torch.zeros(n, L, 32)
+    for i in range(n):
+        cap_pad[i, :lens_all[i]] = caps[i]
+    img_u = torch.stack(img_rows[::5])
+    return O.xattn_score(img_u, cap_pad, lens_all, 't2i', 'clipped_l2norm', 'LogSumExp', cfg['lambda_lse'], cfg['lambda_softmax'])
+
+
+def test_evalrank_single_and_ensemble(golden, dev, tmp_path):
+    g = golden("g14_data_layer")
+    name, data_path, vdir = _materialise(g, tmp_path)
+    paths, sims_o = [], []
+    for seed in (1, 2):
+        save_dir = str(tmp_path / ('run%d' % seed))
+        os.makedirs(save_dir)
+        cfg = _scan_cfg(name, data_path, vdir, save_dir, seed)
+        cfg['vocab_size'] = int(g["vocab_len"])
+        torch.manual_seed(seed)
+        model = get_model(cfg)
+        p = os.path.join(save_dir, 'model_best.pth.tar')
+        utils.save_checkpoint({'epoch': 3, 'model': model.state_dict(), 'best_rsum': 12.5, 'best_r1': 1.5, '_config': cfg,
+                               'Eiters': 77}, True, prefix=save_dir)
+        paths.append(p)
+        sims_o.append(_oracle_eval(model, cfg, name, data_path))
+    # ---- single
+    res = evaluation.evalrank_single(paths[0], split='test')
+    want = O.rank_counts(sims_o[0].numpy())
+    assert (np.asarray(res['i2t_ranks']) == want[0]).all() and (np.asarray(res['t2i_ranks']) == want[2]).all()
+    assert (np.asarray(res['i2t_top1']) == want[1]).all() and (np.asarray(res['t2i_top1']) == want[3]).all()
+    ri, rt = O.recall_from_ranks(want[0]), O.recall_from_ranks(want[2])
+    assert res['i2t_r1'] == pytest.approx(ri[0]) and res['t2i_r10'] == pytest.approx(rt[2])
+    assert res['rsum'] == pytest.approx(sum(ri[:3]) + sum(rt[:3]))
+    y = yaml.safe_load(open(os.path.join(os.path.dirname(paths[0]), '%s_single_result.yaml' % name)))
+    assert y['data_name'] == name and y['rsum'] == pytest.approx(res['rsum']) and len(y['t2i_ranks']) == 30
+    assert y['result'][0][:5] == pytest.approx(list(ri))
+    # ---- ensemble: the two similarity matrices are averaged before ranking (evaluation.py:377-381)
+    res2 = evaluation.evalrank_ensemble(paths[0], paths[1], split='test')
+    want2 = O.rank_counts(((sims_o[0] + sims_o[1]) / 2).numpy())
+    assert (np.asarray(res2['i2t_ranks']) == want2[0]).all() and (np.asarray(res2['t2i_ranks']) == want2[2]).all()
+    assert os.path.exists(os.path.join(os.path.dirname(paths[0]), '%s_ensemble_result.yaml' % name))
+
+
+def test_validate_step_and_resume(golden, dev, tmp_path):
+    g = golden("g14_data_layer")
+    name, data_path, vdir = _materialise(g, tmp_path)
+    save_dir = str(tmp_path / 'run')
+    os.makedirs(save_dir)
+    cfg = _scan_cfg(name, data_path, vdir, save_dir, 5)
+    cfg['vocab_size'] = int(g["vocab_len"])
+    torch.manual_seed(5)
+    model = get_model(cfg)
+    loader, _ = dl.get_test_loader('test', name, cfg['batch_size'], 0, cfg)
+    r_sum, r1 = utils.validate_step(cfg, loader, model)
+    want = O.rank_counts(_oracle_eval(model, cfg, name, data_path).numpy())
+    ri, rt = O.recall_from_ranks(want[0]), O.recall_from_ranks(want[2])
+    assert r1 == pytest.approx(ri[0]) and r_sum == pytest.approx(sum(ri[:3]) + sum(rt[:3]))
+    utils.save_checkpoint({'epoch': 1, 'model': model.state_dict(), 'best_rsum': r_sum, 'best_r1': r1, '_config': cfg, 'Eiters': 9},
+                          False, prefix=save_dir, is_epo_end=True)
+    cfg2 = dict(cfg, resume=os.path.join(save_dir, 'epo1_checkpoint.pth.tar'))
+    m2, start_epoch, best_rsum, best_r1 = utils.load_resume(models, cfg2, reload=True)
+    assert start_epoch == 1 and m2.Eiters == 9 and best_rsum == pytest.approx(r_sum)
+    for a, b in zip(model.state_dict(), m2.state_dict()):
+        for k in a:
+            assert torch.equal(a[k].cpu(), b[k].cpu()), k
+    with pytest.raises(FileNotFoundError):
+        utils.load_resume(models, dict(cfg, resume=os.path.join(save_dir, 'nope.tar')))
+
+
+def test_feature_prefetcher_matches_plain_loader(golden, dev, tmp_path):
+    g = golden("g14_data_layer")
+    name, data_path, vdir = _materialise(g, tmp_path)
+    cfg = _scan_cfg(name, data_path, vdir, str(tmp_path), 1)
+    loader, _ = dl.get_test_loader('test', name, 4, 0, cfg)
+    plain = list(loader)
+    pre = list(dl.FeaturePrefetcher(loader, dev))
+    assert len(plain) == len(pre) == len(dl.FeaturePrefetcher(loader, dev))
+    for a, b in zip(plain, pre):
+        assert b[0].is_cuda and b[3].is_cuda
+        assert torch.equal(a[0], b[0].cpu()) and torch.equal(a[3], b[3].cpu())
+        assert list(a[4]) == list(b[4]) and list(a[5]) == list(b[5])
+    with pytest.raises(RuntimeError):
+        dl.FeaturePrefetcher(loader, 'cpu')
