@@ -1,0 +1,267 @@
+// EncoderText (bi)GRU, training forward (keeps the gate activations) and backward through time
+// (TextEncoder.py:38-70 under autograd; torch.nn.GRU equations, gate order r, z, n):
+//     r = s(gi_r + gh_r)   z = s(gi_z + gh_z)   n = tanh(gi_n + r * gh_n)   h' = (1 - z) n + z h
+// with gi = W_ih x + b_ih (all tokens, one GEMM) and gh = W_hh h + b_hh (one GEMM per step on the active prefix).
+//
+// Same packed layout as itr_gru_fwd (towers.hip): caption b owns token rows tok_off[b] .. +len[b], captions sorted
+// by length descending, so the captions alive at step t are the prefix [0, n_t).
+//
+// save (per direction d, 5 planes of [n_tok, D] floats, indexed by TOKEN ROW):  h | r | z | n | gh_n
+//
+// Backward, per direction, t = Lmax-1 .. 0:
+//     dh   = d_out[row] * (bi ? 1/2 : 1) + carry[b]
+//     dn   = dh (1 - z)(1 - n^2);   dz = dh (h_prev - n) z (1 - z);   dr = dn gh_n r (1 - r)
+//     dgi[row] = (dr, dz, dn)       dgh[row] = (dr, dz, dn r)          carry[b] = dh z  (+)= dgh W_hh   (MFMA GEMM)
+// then, over ALL tokens at once (MFMA GEMMs on transposed operands):
+//     dW_hh = dgh^T H_prev    db_hh = colsum(dgh)    dW_ih = dgi^T X    db_ih = colsum(dgi)    dX (+)= dgi W_ih
+// and dE[token] += dX (atomic scatter; the only non-deterministic summation order of the step).
+#include "itr_common.h"
+
+namespace itr {
+
+int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc,
+            int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
+int gemm_nt_acc(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc,
+                int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
+
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ void embed_gather_train_kernel(const int64_t *__restrict__ tokens, int64_t n_tok, const float *__restrict__ embed, int64_t V,
+                                          int E, float *__restrict__ x, int *__restrict__ bad) {
+    const int64_t row = blockIdx.x;
+    int64_t id = tokens[row];
+    if (id < 0 || id >= V) {
+        if (threadIdx.x == 0) atomicExch(bad, 1);
+        id = 0;
+    }
+    for (int k = threadIdx.x; k < E; k += blockDim.x) x[row * E + k] = embed[id * E + k];
+}
+
+struct GruSave {
+    float *h, *r, *z, *n, *ghn;
+};
+static GruSave save_planes(void *save, int dir, int64_t n_tok, int D) {
+    float *p = static_cast<float *>(save) + (size_t)dir * 5 * n_tok * D;
+    const size_t pl = (size_t)n_tok * D;
+    return GruSave{p, p + pl, p + 2 * pl, p + 3 * pl, p + 4 * pl};
+}
+
+// forward step; mode 0: out[row] = h', mode 1: out[row] = (out[row] + h') / 2
+__global__ __launch_bounds__(256) void gru_gate_train_kernel(const float *__restrict__ gi, const float *__restrict__ gh, float *__restrict__ h,
+                                                             float *__restrict__ out, GruSave sv, const int64_t *__restrict__ tok_off,
+                                                             const int32_t *__restrict__ len, int t, int reverse, int mode, int D,
+                                                             int64_t n_act) {
+    const int64_t b = blockIdx.x;
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;
+    if (b >= n_act || j >= D) return;
+    const int64_t row = tok_off[b] + (reverse ? (len[b] - 1 - t) : t);
+    const float *gir = gi + row * 3 * D;
+    const float *ghr = gh + b * 3 * D;
+    const float r = sigm(gir[j] + ghr[j]);
+    const float z = sigm(gir[D + j] + ghr[D + j]);
+    const float ghn = ghr[2 * D + j];
+    const float n = tanhf(gir[2 * D + j] + r * ghn);
+    const float hp = h[b * D + j];
+    const float hn = (1.f - z) * n + z * hp;
+    h[b * D + j] = hn;
+    const int64_t o = row * D + j;
+    sv.h[o] = hn; sv.r[o] = r; sv.z[o] = z; sv.n[o] = n; sv.ghn[o] = ghn;
+    out[o] = mode ? (out[o] + hn) / 2.f : hn;
+}
+
+__global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float *__restrict__ d_out, float dscale, GruSave sv, float *__restrict__ carry,
+                                                           float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dgh_step,
+                                                           float *__restrict__ hprev_all, const int64_t *__restrict__ tok_off,
+                                                           const int32_t *__restrict__ len, int t, int reverse, int D, int64_t n_act) {
+    const int64_t b = blockIdx.x;
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;
+    if (b >= n_act || j >= D) return;
+    const int pos = reverse ? (len[b] - 1 - t) : t;
+    const int64_t row = tok_off[b] + pos;
+    const int64_t o = row * D + j;
+    const float hp = (t > 0) ? sv.h[(row + (reverse ? 1 : -1)) * D + j] : 0.f;   // the state this step started from
+    const float r = sv.r[o], z = sv.z[o], n = sv.n[o], ghn = sv.ghn[o];
+    const float dh = d_out[o] * dscale + carry[b * D + j];
+    const float dn = dh * (1.f - z) * (1.f - n * n);
+    const float dz = dh * (hp - n) * z * (1.f - z);
+    const float dr = dn * ghn * r * (1.f - r);
+    float *gi_ = dgi + row * 3 * D, *gh_ = dgh + row * 3 * D, *gs_ = dgh_step + b * 3 * D;
+    gi_[j] = dr; gi_[D + j] = dz; gi_[2 * D + j] = dn;
+    const float dnr = dn * r;
+    gh_[j] = dr; gh_[D + j] = dz; gh_[2 * D + j] = dnr;
+    gs_[j] = dr; gs_[D + j] = dz; gs_[2 * D + j] = dnr;
+    hprev_all[o] = hp;
+    carry[b * D + j] = dh * z;
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t rows, int64_t cols) {
+    __shared__ float t[64][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        if (r0 + i < rows && c0 + tx < cols) t[i][tx] = in[(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < cols && r0 + tx < rows) out[(c0 + i) * rows + r0 + tx] = t[tx][i];
+}
+static int transpose(const float *in, float *out, int64_t rows, int64_t cols, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(rows, 64)), dim3(256), 0, st, in, out, rows, cols);
+    ITR_CHECK_LAUNCH("gru transpose");
+    return ITR_OK;
+}
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int check_lengths(const int32_t *len_host, int64_t B, int64_t n_tok, const char *who) {
+    int64_t total = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        ITR_REQUIRE(len_host[b] >= 1, "%s: caption %lld has length %d", who, (long long)b, len_host[b]);
+        ITR_REQUIRE(b == 0 || len_host[b] <= len_host[b - 1], "%s: captions must be sorted by length, descending", who);
+        total += len_host[b];
+    }
+    ITR_REQUIRE(total == n_tok, "%s: sum(len) = %lld != n_tok = %lld", who, (long long)total, (long long)n_tok);
+    return ITR_OK;
+}
+
+}  // namespace itr
+
+using namespace itr;
+
+extern "C" int itr_gather_rows(const int64_t *idx, int64_t n, const float *table, int64_t V, int E, float *out, int *bad_flag,
+                               itr_stream_t stream) {
+    ITR_REQUIRE(idx && table && out && bad_flag, "itr_gather_rows: null pointer");
+    ITR_REQUIRE(n >= 0 && V > 0 && E > 0, "itr_gather_rows: bad shape");
+    if (n == 0) return ITR_OK;
+    hipLaunchKernelGGL(embed_gather_train_kernel, dim3((unsigned)n), dim3(128), 0, as_stream(stream), idx, n, table, V, E, out, bad_flag);
+    ITR_CHECK_LAUNCH("gather_rows");
+    return ITR_OK;
+}
+
+extern "C" size_t itr_gru_train_save_bytes(int64_t n_tok, int D, int bidirectional) {
+    return (size_t)(bidirectional ? 2 : 1) * 5 * (size_t)n_tok * D * 4;
+}
+
+extern "C" size_t itr_gru_train_workspace_bytes(int64_t n_tok, int64_t B, int E, int D) {
+    // forward: x, gi, gh, h, bad.  backward: x, dgi, dgh, hprev, carry, dgh_step, dx, and the transposes
+    // (dgi^T | dgh^T share one [3D, n_tok] buffer, x^T | hprev^T one [max(E, D), n_tok]), W_hh^T, W_ih^T, colsum partials.
+    const size_t nt = (size_t)n_tok, d3 = (size_t)3 * D;
+    size_t b = al256(nt * E * 4) + 2 * al256(nt * d3 * 4) + al256(nt * D * 4) + al256((size_t)B * D * 4) + al256((size_t)B * d3 * 4) +
+               al256(nt * E * 4) + al256(d3 * nt * 4) + al256((size_t)(E > D ? E : D) * nt * 4) + al256(d3 * D * 4) + al256(d3 * E * 4) +
+               al256(((size_t)ceil_div(n_tok > 0 ? n_tok : 1, 256)) * d3 * 4) + 512;
+    return b;
+}
+
+extern "C" int itr_gru_fwd_train(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev, const int32_t *len_host, int64_t B,
+                                 int64_t n_tok, const float *embed, int64_t V, int E, int D, const float *w_ih, const float *w_hh,
+                                 const float *b_ih, const float *b_hh, const float *w_ih_rev, const float *w_hh_rev, const float *b_ih_rev,
+                                 const float *b_hh_rev, float *out, void *save, size_t save_bytes, void *workspace, size_t workspace_bytes,
+                                 itr_stream_t stream) {
+    ITR_REQUIRE(tokens && tok_off && len_dev && len_host && embed && w_ih && w_hh && b_ih && b_hh && out && save && workspace,
+                "itr_gru_fwd_train: null pointer");
+    ITR_REQUIRE(B >= 1 && n_tok >= 1 && E > 0 && D > 0 && V > 0, "itr_gru_fwd_train: bad shape");
+    const bool bi = w_ih_rev != nullptr;
+    ITR_REQUIRE(!bi || (w_hh_rev && b_ih_rev && b_hh_rev), "itr_gru_fwd_train: incomplete reverse-direction weights");
+    ITR_REQUIRE(save_bytes >= itr_gru_train_save_bytes(n_tok, D, bi), "itr_gru_fwd_train: save buffer too small");
+    ITR_REQUIRE(workspace_bytes >= itr_gru_train_workspace_bytes(n_tok, B, E, D), "itr_gru_fwd_train: workspace too small");
+    int rc = check_lengths(len_host, B, n_tok, "itr_gru_fwd_train");
+    if (rc != ITR_OK) return rc;
+    hipStream_t st = as_stream(stream);
+    char *p = static_cast<char *>(workspace);
+    float *x = (float *)p; p += al256((size_t)n_tok * E * 4);
+    float *gi = (float *)p; p += al256((size_t)n_tok * 3 * D * 4);
+    float *gh = (float *)p; p += al256((size_t)n_tok * 3 * D * 4);   // only [B, 3D] used
+    float *h = (float *)p; p += al256((size_t)n_tok * D * 4);        // only [B, D] used
+    int *bad = (int *)p;
+    const int Lmax = len_host[0];
+    ITR_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
+    hipLaunchKernelGGL(embed_gather_train_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, x, bad);
+    ITR_CHECK_LAUNCH("embed_gather(train)");
+    for (int dir = 0; dir < (bi ? 2 : 1); ++dir) {
+        const float *wi = dir ? w_ih_rev : w_ih, *wh = dir ? w_hh_rev : w_hh;
+        const float *bi_ = dir ? b_ih_rev : b_ih, *bh = dir ? b_hh_rev : b_hh;
+        GruSave sv = save_planes(save, dir, n_tok, D);
+        rc = gemm_nt(x, E, wi, E, bi_, gi, 3 * D, n_tok, 3 * D, E, 0, st);
+        if (rc != ITR_OK) return rc;
+        ITR_CHECK_HIP(hipMemsetAsync(h, 0, (size_t)B * D * 4, st));
+        int64_t n_act = B;
+        for (int t = 0; t < Lmax; ++t) {
+            while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
+            rc = gemm_nt(h, D, wh, D, bh, gh, 3 * D, n_act, 3 * D, D, 0, st);
+            if (rc != ITR_OK) return rc;
+            hipLaunchKernelGGL(gru_gate_train_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, gi, gh, h, out, sv,
+                               tok_off, len_dev, t, dir, dir, D, n_act);
+            ITR_CHECK_LAUNCH("gru_gate(train)");
+        }
+    }
+    return ITR_OK;
+}
+
+extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev, const int32_t *len_host, int64_t B,
+                           int64_t n_tok, const float *embed, int64_t V, int E, int D, const float *w_ih, const float *w_hh,
+                           const float *w_ih_rev, const float *w_hh_rev, const void *save, const float *d_out, float *d_embed, float *d_w_ih,
+                           float *d_w_hh, float *d_b_ih, float *d_b_hh, float *d_w_ih_rev, float *d_w_hh_rev, float *d_b_ih_rev,
+                           float *d_b_hh_rev, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
+    ITR_REQUIRE(tokens && tok_off && len_dev && len_host && embed && w_ih && w_hh && save && d_out && d_embed && d_w_ih && d_w_hh && d_b_ih &&
+                    d_b_hh && workspace, "itr_gru_bwd: null pointer");
+    ITR_REQUIRE(B >= 1 && n_tok >= 1 && E > 0 && D > 0 && V > 0, "itr_gru_bwd: bad shape");
+    const bool bi = w_ih_rev != nullptr;
+    ITR_REQUIRE(!bi || (w_hh_rev && d_w_ih_rev && d_w_hh_rev && d_b_ih_rev && d_b_hh_rev), "itr_gru_bwd: incomplete reverse-direction buffers");
+    ITR_REQUIRE(workspace_bytes >= itr_gru_train_workspace_bytes(n_tok, B, E, D), "itr_gru_bwd: workspace too small");
+    int rc = check_lengths(len_host, B, n_tok, "itr_gru_bwd");
+    if (rc != ITR_OK) return rc;
+    hipStream_t st = as_stream(stream);
+    const size_t nt = (size_t)n_tok, d3 = (size_t)3 * D;
+    char *p = static_cast<char *>(workspace);
+    float *x = (float *)p; p += al256(nt * E * 4);
+    float *dgi = (float *)p; p += al256(nt * d3 * 4);
+    float *dgh = (float *)p; p += al256(nt * d3 * 4);
+    float *hprev = (float *)p; p += al256(nt * D * 4);
+    float *carry = (float *)p; p += al256((size_t)B * D * 4);
+    float *dgh_step = (float *)p; p += al256((size_t)B * d3 * 4);
+    float *dx = (float *)p; p += al256(nt * E * 4);
+    float *gT = (float *)p; p += al256(d3 * nt * 4);                       // dgi^T, then dgh^T
+    float *aT = (float *)p; p += al256((size_t)(E > D ? E : D) * nt * 4);   // x^T, then hprev^T
+    float *whhT = (float *)p; p += al256(d3 * D * 4);
+    float *wihT = (float *)p; p += al256(d3 * E * 4);
+    float *cs = (float *)p; p += al256(((size_t)ceil_div(n_tok, 256)) * d3 * 4);
+    int *bad = (int *)p;
+    const int Lmax = len_host[0];
+    const int64_t nparts = ceil_div(n_tok, 256);
+    ITR_UNSUPPORTED(nparts > 65535, "itr_gru_bwd: more than 16M tokens");
+
+    ITR_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
+    hipLaunchKernelGGL(embed_gather_train_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, x, bad);
+    ITR_CHECK_LAUNCH("embed_gather(bwd)");
+#define GB_TRY(e) { rc = (e); if (rc != ITR_OK) return rc; }
+    for (int dir = 0; dir < (bi ? 2 : 1); ++dir) {
+        const float *wi = dir ? w_ih_rev : w_ih, *wh = dir ? w_hh_rev : w_hh;
+        float *dwi = dir ? d_w_ih_rev : d_w_ih, *dwh = dir ? d_w_hh_rev : d_w_hh;
+        float *dbi = dir ? d_b_ih_rev : d_b_ih, *dbh = dir ? d_b_hh_rev : d_b_hh;
+        GruSave sv = save_planes(const_cast<void *>(save), dir, n_tok, D);
+        GB_TRY(transpose(wh, whhT, 3 * D, D, st));    // [3D, D] -> [D, 3D]:  carry += dgh_step . W_hh  ==  gemm_nt(dgh_step, W_hh^T)
+        GB_TRY(transpose(wi, wihT, 3 * D, E, st));    // [3D, E] -> [E, 3D]
+        ITR_CHECK_HIP(hipMemsetAsync(carry, 0, (size_t)B * D * 4, st));
+        for (int t = Lmax - 1; t >= 0; --t) {
+            int64_t n_act = 0;
+            while (n_act < B && len_host[n_act] > t) ++n_act;
+            hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, d_out, bi ? 0.5f : 1.f,
+                               sv, carry, dgi, dgh, dgh_step, hprev, tok_off, len_dev, t, dir, D, n_act);
+            ITR_CHECK_LAUNCH("gru_gate_bwd");
+            if (t > 0) GB_TRY(gemm_nt_acc(dgh_step, 3 * D, whhT, 3 * D, nullptr, carry, D, n_act, D, 3 * D, 0, st));
+        }
+        // weight gradients over all tokens
+        GB_TRY(transpose(dgh, gT, n_tok, 3 * D, st));
+        GB_TRY(transpose(hprev, aT, n_tok, D, st));
+        GB_TRY(gemm_nt(gT, n_tok, aT, n_tok, nullptr, dwh, D, 3 * D, D, n_tok, 0, st));
+        GB_TRY(transpose(dgi, gT, n_tok, 3 * D, st));
+        GB_TRY(transpose(x, aT, n_tok, E, st));
+        GB_TRY(gemm_nt(gT, n_tok, aT, n_tok, nullptr, dwi, E, 3 * D, E, n_tok, 0, st));
+        GB_TRY(itr_colsum(dgh, dbh, n_tok, 3 * D, 0, cs, al256((size_t)nparts * d3 * 4) + 256, stream));
+        GB_TRY(itr_colsum(dgi, dbi, n_tok, 3 * D, 0, cs, al256((size_t)nparts * d3 * 4) + 256, stream));
+        // input gradient: dx (+)= dgi . W_ih
+        if (dir == 0) GB_TRY(gemm_nt(dgi, 3 * D, wihT, 3 * D, nullptr, dx, E, n_tok, E, 3 * D, 0, st))
+        else GB_TRY(gemm_nt_acc(dgi, 3 * D, wihT, 3 * D, nullptr, dx, E, n_tok, E, 3 * D, 0, st));
+    }
+#undef GB_TRY
+    return itr_embed_scatter_add(tokens, dx, n_tok, V, E, d_embed, stream);
+}

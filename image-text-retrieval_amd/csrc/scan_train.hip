@@ -1,0 +1,351 @@
+// SCAN t2i similarity for TRAINING batches: forward that keeps what the backward needs, and the backward
+// (xattn_score_t2i + func_attention + cosine_similarity, Objectives.py:329-372, :420-476, :10-15, under autograd).
+//
+// A training batch is small (128 images x 128 captions), so the layout differs from the 5k x 25k evaluation
+// kernel (scan_xattn.hip): the raw dot products of ALL pairs are one plain GEMM
+//       A[B_i * 36, n_tok] = V[B_i * 36, D] . E[n_tok, D]^T                      (gemm_nt_kernel)
+// and one workgroup per (image, caption) pair does the per-pair arithmetic on its 36 x W block of A in LDS, using the
+// same Gram-matrix identity as the evaluation kernel (G_i = V_i V_i^T):
+//       b = f(a)                                   f: leaky(0.1) | id          (clipped_* | plain)
+//       u[r, w] = b[r, w] / (||b[r, :]||_w + eps)   first norm over the caption's words, per region (l2 forms) | b
+//       p[r, w] = softmax_r(lambda_s u[r, w])
+//       num_w = sum_r p a      q_w = p^T G p      s_w = num_w / max(||e_w|| sqrt(q_w), 1e-8)
+//       S = LSE_w(lambda_lse s_w) / lambda_lse | max | sum | mean
+// Backward (dS given): ds_w -> dnum_w, dq_w, d||e_w||;  dp = dnum a + 2 dq (G p);  da += dnum p;  softmax and norm
+// backward to da;  outputs per pair:  dA block (disjoint, no atomics), dG partial [36 x 36] (summed over captions by a
+// second kernel), d||e_w|| partial (summed over images by itr_colsum).  The D-long contractions of the backward are
+// again plain GEMMs done by the caller:  dV = dA E + (dG + dG^T) V,   dE = dA^T V + d||e|| e / ||e||.
+#include "scan_common.h"
+
+namespace itr {
+
+constexpr int ST_MAXW = 64;   // words per caption (same bound as the evaluation kernel's tile)
+
+struct ScanTrainArgs {
+    const float *A;        // [Bi*36, ldA]  raw dot products
+    int64_t ldA;           //               (= n_tok)
+    const float *G;        // [Bi, 36, 36]
+    const float *enorm;    // [n_tok]       ||e_w||
+    const int64_t *cap_off;
+    const int32_t *cap_len;
+    int64_t Bi, Bc;
+    int norm, agg;         // norm: 0 clipped_l2norm, 1 l2norm, 3 no_norm, 4 clipped;  agg: 0 LSE, 1 Max, 2 Sum, 3 Mean
+    float ls, ll;
+    float *S;              // [Bi, Bc]
+    // backward only
+    const float *dS;       // [Bi, Bc]
+    float *dA;             // [Bi*36, ldA]
+    float *dGp;            // [Bi, Bc, 36, 36]   per-pair partials
+    float *den;            // [Bi, n_tok]        per (image, word) d||e_w||
+};
+
+struct PairSmem {
+    float a[SC_R][ST_MAXW + 1];   // raw
+    float p[SC_R][ST_MAXW + 1];   // attention weights
+    float g[SC_R][SC_R + 1];      // Gram
+    float gp[SC_R][ST_MAXW + 1];  // G p
+    float rn[SC_R];               // 1 / (||b[r,:]|| + eps)
+    float rs[SC_R];               // sqrt(sum_w b^2) per region (norm backward)
+    float s[ST_MAXW], num[ST_MAXW], q[ST_MAXW], ds[ST_MAXW];
+    float red;
+};
+
+// everything up to s_w; returns with sm.{a,p,g,gp,rn,rs,s,num,q} valid
+__device__ __forceinline__ void pair_forward(const ScanTrainArgs &g, PairSmem &sm, int64_t i, int64_t c, int W, int64_t off) {
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < SC_R * W; idx += 256) {
+        const int r = idx / W, w = idx - r * W;
+        sm.a[r][w] = g.A[(i * SC_R + r) * g.ldA + off + w];
+    }
+    for (int idx = tid; idx < SC_R * SC_R; idx += 256) sm.g[idx / SC_R][idx % SC_R] = g.G[i * SC_R * SC_R + idx];
+    __syncthreads();
+    const bool clip = (g.norm == 0 || g.norm == 4), l2 = (g.norm == 0 || g.norm == 1);
+    if (tid < SC_R) {
+        float ss = 0.f;
+        if (l2)
+            for (int w = 0; w < W; ++w) {
+                const float b = clip ? leaky(sm.a[tid][w]) : sm.a[tid][w];
+                ss += b * b;
+            }
+        const float rt = sqrtf(ss);
+        sm.rs[tid] = rt;
+        sm.rn[tid] = l2 ? 1.f / (rt + 1e-8f) : 1.f;
+    }
+    __syncthreads();
+    if (tid < W) {   // one lane per word: softmax over the 36 regions
+        const int w = tid;
+        float mx = -INFINITY;
+        for (int r = 0; r < SC_R; ++r) {
+            const float b = clip ? leaky(sm.a[r][w]) : sm.a[r][w];
+            const float u = b * sm.rn[r] * g.ls;
+            sm.p[r][w] = u;
+            mx = fmaxf(mx, u);
+        }
+        float den = 0.f;
+        for (int r = 0; r < SC_R; ++r) {
+            const float e = expf(sm.p[r][w] - mx);
+            sm.p[r][w] = e;
+            den += e;
+        }
+        float num = 0.f;
+        for (int r = 0; r < SC_R; ++r) {
+            const float pv = sm.p[r][w] / den;
+            sm.p[r][w] = pv;
+            num += pv * sm.a[r][w];
+        }
+        float q = 0.f;
+        for (int r = 0; r < SC_R; ++r) {
+            float t = 0.f;
+            for (int s2 = 0; s2 < SC_R; ++s2) t += sm.g[r][s2] * sm.p[s2][w];
+            sm.gp[r][w] = t;
+            q += sm.p[r][w] * t;
+        }
+        q = fmaxf(q, 0.f);
+        sm.num[w] = num;
+        sm.q[w] = q;
+        sm.s[w] = num / fmaxf(g.enorm[off + w] * sqrtf(q), 1e-8f);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void scan_train_fwd_kernel(ScanTrainArgs g) {
+    __shared__ PairSmem sm;
+    const int64_t c = blockIdx.x, i = blockIdx.y;
+    const int W = g.cap_len[c];
+    const int64_t off = g.cap_off[c];
+    pair_forward(g, sm, i, c, W, off);
+    if (threadIdx.x == 0) {
+        float r;
+        if (g.agg == 0) {
+            float mx = -INFINITY;
+            for (int w = 0; w < W; ++w) mx = fmaxf(mx, sm.s[w] * g.ll);
+            float acc = 0.f;
+            for (int w = 0; w < W; ++w) acc += expf(sm.s[w] * g.ll - mx);
+            r = (logf(acc) + mx) / g.ll;
+        } else if (g.agg == 1) {
+            r = -INFINITY;
+            for (int w = 0; w < W; ++w) r = fmaxf(r, sm.s[w]);
+        } else {
+            r = 0.f;
+            for (int w = 0; w < W; ++w) r += sm.s[w];
+            if (g.agg == 3) r /= (float)W;
+        }
+        g.S[i * g.Bc + c] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
+    __shared__ PairSmem sm;
+    __shared__ float da[SC_R][ST_MAXW + 1];
+    __shared__ float dqs[ST_MAXW];
+    const int tid = threadIdx.x;
+    const int64_t c = blockIdx.x, i = blockIdx.y;
+    const int W = g.cap_len[c];
+    const int64_t off = g.cap_off[c];
+    pair_forward(g, sm, i, c, W, off);
+    const float dS = g.dS[i * g.Bc + c];
+    // ---- aggregation backward: ds_w
+    if (tid == 0) {
+        if (g.agg == 0) {
+            float mx = -INFINITY;
+            for (int w = 0; w < W; ++w) mx = fmaxf(mx, sm.s[w] * g.ll);
+            float acc = 0.f;
+            for (int w = 0; w < W; ++w) acc += expf(sm.s[w] * g.ll - mx);
+            for (int w = 0; w < W; ++w) sm.ds[w] = dS * expf(sm.s[w] * g.ll - mx) / acc;
+        } else if (g.agg == 1) {
+            int best = 0;
+            for (int w = 1; w < W; ++w)
+                if (sm.s[w] > sm.s[best]) best = w;      // torch.max: the first maximal index receives the gradient
+            for (int w = 0; w < W; ++w) sm.ds[w] = (w == best) ? dS : 0.f;
+        } else {
+            const float k = (g.agg == 3) ? dS / (float)W : dS;
+            for (int w = 0; w < W; ++w) sm.ds[w] = k;
+        }
+    }
+    __syncthreads();
+    const bool clip = (g.norm == 0 || g.norm == 4), l2 = (g.norm == 0 || g.norm == 1);
+    // ---- per word: cosine backward, attention backward through the softmax -> du (kept in da)
+    if (tid < W) {
+        const int w = tid;
+        const float ew = g.enorm[off + w];
+        const float sq = sqrtf(sm.q[w]);
+        const float den = ew * sq;
+        float dnum = 0.f, dq = 0.f, dew = 0.f;
+        if (den > 1e-8f) {   // the clamp of cosine_similarity is inactive
+            dnum = sm.ds[w] / den;
+            const float dden = -sm.ds[w] * sm.num[w] / (den * den);
+            dew = dden * sq;
+            dq = sq > 0.f ? dden * ew / (2.f * sq) : 0.f;
+        } else {
+            dnum = sm.ds[w] / 1e-8f;
+        }
+        dqs[w] = dq;
+        g.den[i * g.ldA + off + w] = dew;
+        // dp = dnum a + 2 dq (G p);  du = ls * p (dp - sum_r p dp)
+        float dot = 0.f;
+        for (int r = 0; r < SC_R; ++r) {
+            const float dp = dnum * sm.a[r][w] + 2.f * dq * sm.gp[r][w];
+            da[r][w] = dp;
+            dot += sm.p[r][w] * dp;
+        }
+        for (int r = 0; r < SC_R; ++r) da[r][w] = g.ls * sm.p[r][w] * (da[r][w] - dot);   // = du[r][w]
+        sm.num[w] = dnum;   // reuse: dnum per word
+    }
+    __syncthreads();
+    // ---- per region: first-norm backward  u = b * rn,  rn = 1 / (sqrt(sum b^2) + eps)
+    if (tid < SC_R) {
+        const int r = tid;
+        float dotb = 0.f;
+        if (l2)
+            for (int w = 0; w < W; ++w) {
+                const float b = clip ? leaky(sm.a[r][w]) : sm.a[r][w];
+                dotb += da[r][w] * b;
+            }
+        const float rn = sm.rn[r], rt = sm.rs[r];
+        const float k = (l2 && rt > 0.f) ? dotb * rn * rn / rt : 0.f;
+        for (int w = 0; w < W; ++w) {
+            const float araw = sm.a[r][w];
+            const float b = clip ? leaky(araw) : araw;
+            float db = da[r][w] * rn - b * k;
+            if (clip) db *= (araw > 0.f) ? 1.f : 0.1f;    // LeakyReLU(0.1); slope at exactly 0 = 0.1 like torch
+            da[r][w] = db + sm.num[w] * sm.p[r][w];        // + the direct path of num = sum p a
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < SC_R * W; idx += 256) {
+        const int r = idx / W, w = idx - r * W;
+        g.dA[(i * SC_R + r) * g.ldA + off + w] = da[r][w];
+    }
+    // ---- dG partial of this pair:  sum_w dq_w p_w p_w^T
+    float *dgp = g.dGp + (i * g.Bc + c) * (SC_R * SC_R);
+    for (int idx = tid; idx < SC_R * SC_R; idx += 256) {
+        const int r = idx / SC_R, s2 = idx - r * SC_R;
+        float acc = 0.f;
+        for (int w = 0; w < W; ++w) acc += dqs[w] * sm.p[r][w] * sm.p[s2][w];
+        dgp[idx] = acc;
+    }
+}
+
+// dG[i] = sum_c dGp[i, c];  then dV[i] += (dG + dG^T) V[i]   (G = V V^T)
+__global__ __launch_bounds__(256) void scan_train_gram_bwd_kernel(const float *__restrict__ dGp, int64_t Bc, const float *__restrict__ V, int D,
+                                                                  float *__restrict__ dV) {
+    __shared__ float dg[SC_R][SC_R + 1];
+    const int64_t i = blockIdx.x;
+    for (int idx = threadIdx.x; idx < SC_R * SC_R; idx += 256) {
+        float acc = 0.f;
+        for (int64_t c = 0; c < Bc; ++c) acc += dGp[(i * Bc + c) * (SC_R * SC_R) + idx];
+        dg[idx / SC_R][idx % SC_R] = acc;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float v[SC_R];
+#pragma unroll
+        for (int r = 0; r < SC_R; ++r) v[r] = V[(i * SC_R + r) * D + d];
+        for (int r = 0; r < SC_R; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < SC_R; ++s2) acc += (dg[r][s2] + dg[s2][r]) * v[s2];
+            dV[(i * SC_R + r) * D + d] += acc;
+        }
+    }
+}
+
+// G[i] = V[i] V[i]^T  (36 x 36, one workgroup per image) and ||e_w||
+__global__ __launch_bounds__(256) void scan_train_gram_kernel(const float *__restrict__ V, int D, float *__restrict__ G) {
+    const int64_t i = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int idx = wave; idx < SC_R * SC_R; idx += 4) {
+        const int r = idx / SC_R, s2 = idx % SC_R;
+        const float *a = V + (i * SC_R + r) * D, *b = V + (i * SC_R + s2) * D;
+        float acc = 0.f;
+        for (int d = lane; d < D; d += 64) acc += a[d] * b[d];
+        acc = wave_sum(acc);
+        if (lane == 0) G[i * SC_R * SC_R + idx] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void rownorm_train_kernel(const float *__restrict__ x, int64_t rows, int D, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += x[row * D + d] * x[row * D + d];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = sqrtf(s);
+}
+// dE[w, :] += den[w] * e_w / ||e_w||
+__global__ __launch_bounds__(256) void enorm_bwd_kernel(const float *__restrict__ E, const float *__restrict__ enorm, const float *__restrict__ den,
+                                                        int64_t rows, int D, float *__restrict__ dE) {
+    const int64_t row = blockIdx.y;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows || d >= D) return;
+    const float n = enorm[row];
+    if (n > 0.f) dE[row * D + d] += den[row] * E[row * D + d] / n;
+}
+
+static int check_train_args(const char *who, int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int norm, int agg, int max_len) {
+    ITR_REQUIRE(Bi >= 1 && Bc >= 1 && n_tok >= 1 && D > 0, "%s: bad shape", who);
+    ITR_UNSUPPORTED(R != SC_R, "%s: built for %d regions, got %d", who, SC_R, R);
+    ITR_UNSUPPORTED(max_len > ST_MAXW, "%s: captions of at most %d words are supported, got %d", who, ST_MAXW, max_len);
+    ITR_UNSUPPORTED(!(norm == 0 || norm == 1 || norm == 3 || norm == 4),
+                    "%s: training supports raw_feature_norm in {clipped_l2norm, l2norm, no_norm, clipped}", who);
+    ITR_REQUIRE(agg >= 0 && agg <= 3, "%s: unknown aggregation %d", who, agg);
+    ITR_UNSUPPORTED(Bi > 65535, "%s: at most 65535 images per training batch", who);
+    return ITR_OK;
+}
+
+}  // namespace itr
+
+using namespace itr;
+
+extern "C" int itr_scan_train_prepare(const float *V, const float *E, int64_t Bi, int64_t n_tok, int R, int D, float *G, float *enorm,
+                                      itr_stream_t stream) {
+    ITR_REQUIRE(V && E && G && enorm, "itr_scan_train_prepare: null pointer");
+    ITR_REQUIRE(Bi >= 1 && n_tok >= 1 && D > 0, "itr_scan_train_prepare: bad shape");
+    ITR_UNSUPPORTED(R != SC_R, "itr_scan_train_prepare: built for %d regions", SC_R);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(scan_train_gram_kernel, dim3((unsigned)Bi), dim3(256), 0, st, V, D, G);
+    ITR_CHECK_LAUNCH("scan_train_gram");
+    hipLaunchKernelGGL(rownorm_train_kernel, dim3((unsigned)ceil_div(n_tok, 4)), dim3(256), 0, st, E, n_tok, D, enorm);
+    ITR_CHECK_LAUNCH("scan_train_rownorm");
+    return ITR_OK;
+}
+
+extern "C" int itr_scan_train_fwd(const float *A, int64_t ldA, const float *G, const float *enorm, const int64_t *cap_off, const int32_t *cap_len,
+                                  int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int max_len, int norm, int agg, float lambda_softmax,
+                                  float lambda_lse, float *S, itr_stream_t stream) {
+    ITR_REQUIRE(A && G && enorm && cap_off && cap_len && S, "itr_scan_train_fwd: null pointer");
+    ITR_REQUIRE(ldA >= n_tok, "itr_scan_train_fwd: ldA < n_tok");
+    int rc = check_train_args("itr_scan_train_fwd", Bi, Bc, n_tok, R, D, norm, agg, max_len);
+    if (rc != ITR_OK) return rc;
+    ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, norm, agg, lambda_softmax, lambda_lse, S, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(scan_train_fwd_kernel, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
+    ITR_CHECK_LAUNCH("scan_train_fwd");
+    return ITR_OK;
+}
+
+extern "C" int itr_scan_train_bwd(const float *A, int64_t ldA, const float *G, const float *enorm, const int64_t *cap_off, const int32_t *cap_len,
+                                  int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int max_len, int norm, int agg, float lambda_softmax,
+                                  float lambda_lse, const float *dS, float *dA, float *dG_pairs, float *d_enorm_pairs, itr_stream_t stream) {
+    ITR_REQUIRE(A && G && enorm && cap_off && cap_len && dS && dA && dG_pairs && d_enorm_pairs, "itr_scan_train_bwd: null pointer");
+    ITR_REQUIRE(ldA >= n_tok, "itr_scan_train_bwd: ldA < n_tok");
+    int rc = check_train_args("itr_scan_train_bwd", Bi, Bc, n_tok, R, D, norm, agg, max_len);
+    if (rc != ITR_OK) return rc;
+    ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, norm, agg, lambda_softmax, lambda_lse, nullptr, dS, dA, dG_pairs, d_enorm_pairs};
+    hipLaunchKernelGGL(scan_train_bwd_kernel, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
+    ITR_CHECK_LAUNCH("scan_train_bwd");
+    return ITR_OK;
+}
+
+extern "C" int itr_scan_train_finish(const float *dG_pairs, int64_t Bi, int64_t Bc, const float *V, const float *E, const float *enorm,
+                                     const float *d_enorm, int64_t n_tok, int R, int D, float *dV, float *dE, itr_stream_t stream) {
+    ITR_REQUIRE(dG_pairs && V && E && enorm && d_enorm && dV && dE, "itr_scan_train_finish: null pointer");
+    ITR_REQUIRE(Bi >= 1 && Bc >= 1 && n_tok >= 1 && D > 0, "itr_scan_train_finish: bad shape");
+    ITR_UNSUPPORTED(R != SC_R, "itr_scan_train_finish: built for %d regions", SC_R);
+    ITR_UNSUPPORTED(n_tok > 65535, "itr_scan_train_finish: at most 65535 words per training batch");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(scan_train_gram_bwd_kernel, dim3((unsigned)Bi), dim3(256), 0, st, dG_pairs, Bc, V, D, dV);
+    ITR_CHECK_LAUNCH("scan_train_gram_bwd");
+    hipLaunchKernelGGL(enorm_bwd_kernel, dim3((unsigned)ceil_div(D, 256), (unsigned)n_tok), dim3(256), 0, st, E, enorm, d_enorm, n_tok, D, dE);
+    ITR_CHECK_LAUNCH("scan_train_enorm_bwd");
+    return ITR_OK;
+}

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 i32, i64, f32, vp, sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -50,6 +50,27 @@ SIGNATURES = {
     "itr_rank_gather_gt": (i32, [vp, i64, i64, i64, i64, i32, vp, vp]),
     "itr_rank_counts": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
     "itr_recall_from_ranks": (i32, [vp, i64, vp]),
+    # ---- training step
+    "itr_l2norm_fwd_save": (i32, [vp, vp, vp, i64, i32, f32, vp]),
+    "itr_l2norm_bwd": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),
+    "itr_transpose2d": (i32, [vp, vp, i64, i64, vp]),
+    "itr_colsum_workspace_bytes": (sz, [i64, i64]),
+    "itr_colsum": (i32, [vp, vp, i64, i64, i32, vp, sz, vp]),
+    "itr_embed_scatter_add": (i32, [vp, vp, i64, i64, i32, vp, vp]),
+    "itr_gather_rows": (i32, [vp, i64, vp, i64, i32, vp, vp, vp]),
+    "itr_sq_sum_blocks": (i32, [i64]),
+    "itr_sq_sum": (i32, [vp, i64, vp, vp]),
+    "itr_clip_coef": (i32, [vp, i64, f32, vp, vp]),
+    "itr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, vp]),
+    "itr_gru_train_save_bytes": (sz, [i64, i32, i32]),
+    "itr_gru_train_workspace_bytes": (sz, [i64, i64, i32, i32]),
+    "itr_gru_fwd_train": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]),
+    "itr_gru_bwd": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                          vp, sz, vp]),
+    "itr_scan_train_prepare": (i32, [vp, vp, i64, i64, i32, i32, vp, vp, vp]),
+    "itr_scan_train_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, vp]),
+    "itr_scan_train_bwd": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
+    "itr_scan_train_finish": (i32, [vp, i64, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]),
 }
 
 

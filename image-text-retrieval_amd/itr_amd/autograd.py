@@ -1,0 +1,340 @@
+"""Differentiable wrappers of the HIP kernels for `model.train_emb` (itr/modalmodule/Models.py:115-145, :198-225).
+
+torch.autograd is used as the tape only: every forward and every backward below is a call into libitr_hip.so
+(MFMA GEMMs on transposed operands + the small kernels of csrc/train.hip, gru_train.hip, scan_train.hip).
+There is no CPU path: tensors must live on the GPU.
+
+    linear(x, W, b)              y = x W^T + b                          dW = dy^T x, db = colsum(dy), dx = dy W
+    l2norm_rows(x)               z = x / (||x|| + eps)                  utils.py:10-15
+    gru_sequence(...)            packed (bi)GRU, raw outputs            TextEncoder.py:38-56
+    gather_rows(x, idx)          rows of x                              last valid GRU step (TextEncoder.py:57-60)
+    cosine_scores(im, s)         im s^T                                 Objectives.py:18-21
+    scan_t2i_scores(...)         SCAN t2i similarity matrix             Objectives.py:329-372
+    Adam / clip_grad_norm        torch.optim.Adam + clip_grad_norm_     Models.py:88-90, :222-224
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _dev, _p, _stream, _host_i32, _NORMS, _AGGS
+
+
+def _f32(*shape, dev):
+    return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+
+def transpose2d(x):
+    lib = _lib.load()
+    x = _dev(x, name="x")
+    rows, cols = x.shape
+    out = _f32(cols, rows, dev=x.device)
+    _lib.check(lib.itr_transpose2d(_p(x), _p(out), rows, cols, _stream()))
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    lib = _lib.load()
+    x = _dev(x, name="x")
+    rows, cols = x.shape
+    if out is None:
+        out = _f32(cols, dev=x.device)
+    wsb = lib.itr_colsum_workspace_bytes(rows, cols)
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+    _lib.check(lib.itr_colsum(_p(x), _p(out), rows, cols, int(accumulate), _p(ws), wsb, _stream()))
+    return out
+
+
+def _gemm_nt(a, b, out=None, accumulate=False):
+    """a [M, K] . b [N, K]^T -> [M, N] on the MFMA GEMM."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    if out is None:
+        out = _f32(M, N, dev=a.device)
+    fn = lib.itr_gemm_nt_acc if accumulate else lib.itr_gemm_nt
+    _lib.check(fn(_p(a), K, _p(b), K, _p(None), _p(out), N, M, N, K, 0, _stream()))
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x2 = _dev(x, name="x").reshape(-1, x.shape[-1])
+        w = _dev(weight, name="weight")
+        b = _dev(bias, name="bias") if bias is not None else None
+        M, K = x2.shape
+        N = w.shape[0]
+        out = _f32(M, N, dev=x.device)
+        _lib.check(lib.itr_gemm_nt(_p(x2), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, _stream()))
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        return out.reshape(x.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.contiguous().reshape(-1, dy.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm_nt(dy2, transpose2d(w)).reshape(ctx.xshape)        # dy [M, N] . (W^T [K, N])^T
+        if ctx.needs_input_grad[1]:
+            dw = _gemm_nt(transpose2d(dy2), transpose2d(x2))             # dy^T [N, M] . (x^T [K, M])^T
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib = _lib.load()
+        x2 = _dev(x, name="x").reshape(-1, x.shape[-1])
+        rows, dim = x2.shape
+        z = torch.empty_like(x2)
+        n = _f32(rows, dev=x.device)
+        _lib.check(lib.itr_l2norm_fwd_save(_p(x2), _p(z), _p(n), rows, dim, float(eps), _stream()))
+        ctx.save_for_backward(z, n)
+        ctx.eps = float(eps)
+        return z.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        z, n = ctx.saved_tensors
+        dz2 = dz.contiguous().reshape(z.shape)
+        dx = torch.empty_like(z)
+        _lib.check(lib.itr_l2norm_bwd(_p(dz2), _p(z), _p(n), _p(dx), z.shape[0], z.shape[1], ctx.eps, _stream()))
+        return dx.reshape(dz.shape), None
+
+
+def l2norm_rows(x, eps=1e-8):
+    """utils.l2norm over the last axis, differentiable."""
+    return _L2Norm.apply(x, eps)
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        lib = _lib.load()
+        x = _dev(x, name="x")
+        idx = _dev(idx, torch.int64, "idx")
+        out = _f32(idx.numel(), x.shape[1], dev=x.device)
+        out.zero_()
+        # gather == scatter-add into a zero buffer with the roles swapped is not expressible; use the embedding path:
+        # out[r] = x[idx[r]]  is the forward of an embedding whose table is x
+        bad = torch.zeros(1, device=x.device, dtype=torch.int32)
+        _lib.check(lib.itr_gather_rows(_p(idx), idx.numel(), _p(x), x.shape[0], x.shape[1], _p(out), _p(bad), _stream()))
+        ctx.save_for_backward(idx)
+        ctx.n_rows = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = torch.zeros(ctx.n_rows, dout.shape[1], device=dout.device, dtype=torch.float32)
+        _lib.check(lib.itr_embed_scatter_add(_p(idx), _p(dout), idx.numel(), ctx.n_rows, dout.shape[1], _p(dx), _stream()))
+        return dx, None
+
+
+def gather_rows(x, idx):
+    return _GatherRows.apply(x, idx)
+
+
+class _Gru(torch.autograd.Function):
+    """inputs: tokens / tok_off / len (non-differentiable), then embed, w_ih, w_hh, b_ih, b_hh[, reverse x4]."""
+
+    @staticmethod
+    def forward(ctx, tokens, tok_off, len_dev, len_host, embed, *w):
+        lib = _lib.load()
+        bi = len(w) == 8
+        tokens = _dev(tokens, torch.int64, "tokens")
+        tok_off = _dev(tok_off, torch.int64, "tok_off")
+        embed = _dev(embed, name="embed.weight")
+        w = [_dev(t) for t in w]
+        B, n_tok = len(len_host), int(tokens.numel())
+        V, E = embed.shape
+        D = w[1].shape[1]
+        dev = tokens.device
+        save_b = lib.itr_gru_train_save_bytes(n_tok, D, int(bi))
+        ws_b = lib.itr_gru_train_workspace_bytes(n_tok, B, E, D)
+        save = torch.empty(save_b, device=dev, dtype=torch.uint8)
+        ws = torch.empty(ws_b, device=dev, dtype=torch.uint8)
+        out = _f32(n_tok, D, dev=dev)
+        rev = w[4:] if bi else [None] * 4
+        _lib.check(lib.itr_gru_fwd_train(_p(tokens), _p(tok_off), _p(len_dev), len_host.ctypes.data_as(C.c_void_p), B, n_tok,
+                                         _p(embed), V, E, D, _p(w[0]), _p(w[1]), _p(w[2]), _p(w[3]), _p(rev[0]), _p(rev[1]),
+                                         _p(rev[2]), _p(rev[3]), _p(out), _p(save), save_b, _p(ws), ws_b, _stream()))
+        ctx.save_for_backward(tokens, tok_off, len_dev, embed, save, *w)
+        ctx.len_host, ctx.bi, ctx.dims = len_host, bi, (B, n_tok, V, E, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        tokens, tok_off, len_dev, embed, save = ctx.saved_tensors[:5]
+        w = ctx.saved_tensors[5:]
+        B, n_tok, V, E, D = ctx.dims
+        bi = ctx.bi
+        dev = tokens.device
+        d_out = d_out.contiguous()
+        ws_b = lib.itr_gru_train_workspace_bytes(n_tok, B, E, D)
+        ws = torch.empty(ws_b, device=dev, dtype=torch.uint8)
+        d_embed = torch.zeros_like(embed)
+        grads = [torch.empty_like(t) for t in w]
+        rev_w = [w[4], w[5]] if bi else [None, None]
+        rev_g = grads[4:] if bi else [None] * 4
+        _lib.check(lib.itr_gru_bwd(_p(tokens), _p(tok_off), _p(len_dev), ctx.len_host.ctypes.data_as(C.c_void_p), B, n_tok, _p(embed),
+                                   V, E, D, _p(w[0]), _p(w[1]), _p(rev_w[0]), _p(rev_w[1]), _p(save), _p(d_out), _p(d_embed),
+                                   _p(grads[0]), _p(grads[1]), _p(grads[2]), _p(grads[3]), _p(rev_g[0]), _p(rev_g[1]), _p(rev_g[2]),
+                                   _p(rev_g[3]), _p(ws), ws_b, _stream()))
+        return (None, None, None, None, d_embed) + tuple(grads)
+
+
+def gru_sequence(tokens_packed, tok_off, lengths, embed, rnn_params, bidirectional):
+    """Raw packed GRU outputs (n_tok, D) = (fwd + bwd) / 2 for a bi-GRU, differentiable w.r.t. the weights.
+    rnn_params: dict of nn.GRU parameters (weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0[, *_reverse])."""
+    len_host = _host_i32(lengths)
+    len_dev = torch.from_numpy(len_host.copy()).to(tokens_packed.device)
+    names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+    w = [rnn_params[n] for n in names]
+    if bidirectional:
+        w += [rnn_params[n + '_reverse'] for n in names]
+    return _Gru.apply(tokens_packed, tok_off, len_dev, len_host, embed, *w)
+
+
+class _Cosine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im, s):
+        im, s = _dev(im, name="im"), _dev(s, name="s")
+        ctx.save_for_backward(im, s)
+        return _gemm_nt(im, s)
+
+    @staticmethod
+    def backward(ctx, dS):
+        im, s = ctx.saved_tensors
+        dS = dS.contiguous()
+        d_im = _gemm_nt(dS, transpose2d(s)) if ctx.needs_input_grad[0] else None          # dS [Ni, Nc] . s [Nc, D]
+        d_s = _gemm_nt(transpose2d(dS), transpose2d(im)) if ctx.needs_input_grad[1] else None
+        return d_im, d_s
+
+
+def cosine_scores(im, s):
+    return _Cosine.apply(im, s)
+
+
+class _ScanT2I(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, V, E, cap_off, cap_len, max_len, norm, agg, ls, ll):
+        lib = _lib.load()
+        V = _dev(V, name="images")
+        E = _dev(E, name="words")
+        Bi, R, D = V.shape
+        n_tok = E.shape[0]
+        Bc = cap_len.numel()
+        dev = V.device
+        V2 = V.reshape(Bi * R, D)
+        A = _gemm_nt(V2, E)                                           # raw dot products of all pairs
+        G = _f32(Bi, R, R, dev=dev)
+        enorm = _f32(n_tok, dev=dev)
+        _lib.check(lib.itr_scan_train_prepare(_p(V2), _p(E), Bi, n_tok, R, D, _p(G), _p(enorm), _stream()))
+        S = _f32(Bi, Bc, dev=dev)
+        _lib.check(lib.itr_scan_train_fwd(_p(A), n_tok, _p(G), _p(enorm), _p(cap_off), _p(cap_len), Bi, Bc, n_tok, R, D, max_len,
+                                          norm, agg, ls, ll, _p(S), _stream()))
+        ctx.save_for_backward(V2, E, A, G, enorm, cap_off, cap_len)
+        ctx.opts = (Bi, Bc, n_tok, R, D, max_len, norm, agg, ls, ll)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        lib = _lib.load()
+        V2, E, A, G, enorm, cap_off, cap_len = ctx.saved_tensors
+        Bi, Bc, n_tok, R, D, max_len, norm, agg, ls, ll = ctx.opts
+        dev = V2.device
+        dS = dS.contiguous()
+        dA = torch.zeros_like(A)
+        dGp = _f32(Bi, Bc, R, R, dev=dev)
+        denp = torch.zeros(Bi, n_tok, device=dev, dtype=torch.float32)
+        _lib.check(lib.itr_scan_train_bwd(_p(A), n_tok, _p(G), _p(enorm), _p(cap_off), _p(cap_len), Bi, Bc, n_tok, R, D, max_len, norm,
+                                          agg, ls, ll, _p(dS), _p(dA), _p(dGp), _p(denp), _stream()))
+        dV = _gemm_nt(dA, transpose2d(E))                             # dA [Bi*36, n_tok] . E [n_tok, D]
+        dE = _gemm_nt(transpose2d(dA), transpose2d(V2))               # dA^T [n_tok, Bi*36] . V [Bi*36, D]
+        den = colsum(denp)
+        _lib.check(lib.itr_scan_train_finish(_p(dGp), Bi, Bc, _p(V2), _p(E), _p(enorm), _p(den), n_tok, R, D, _p(dV), _p(dE), _stream()))
+        return dV.reshape(Bi, R, D), dE, None, None, None, None, None, None, None
+
+
+def scan_t2i_scores(images, words_packed, cap_off, cap_lens, raw_feature_norm='clipped_l2norm', agg_func='LogSumExp',
+                    lambda_lse=6.0, lambda_softmax=9.0):
+    """xattn_score_t2i on a training batch -> (n_img, n_cap), differentiable w.r.t. images and words."""
+    if raw_feature_norm not in _NORMS:
+        raise ValueError("unknown first norm type:", raw_feature_norm)
+    if agg_func not in _AGGS:
+        raise ValueError("unknown aggfunc: {}".format(agg_func))
+    lens = _host_i32(cap_lens)
+    dev = images.device
+    off = cap_off if torch.is_tensor(cap_off) else torch.as_tensor(np.asarray(cap_off, np.int64), device=dev)
+    return _ScanT2I.apply(images, words_packed, _dev(off, torch.int64, "cap_off"), torch.from_numpy(lens.copy()).to(dev), int(lens.max()),
+                          _NORMS[raw_feature_norm], _AGGS[agg_func], float(lambda_softmax), float(lambda_lse))
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+class Adam(object):
+    """torch.optim.Adam(params, lr) as the reference builds it (betas (0.9, 0.999), eps 1e-8, no weight decay),
+    one fused kernel per tensor; `step(max_norm)` folds clip_grad_norm_(params, max_norm) into the update."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        self.param_groups = [{'lr': lr, 'betas': betas, 'eps': eps, 'params': self.params}]
+        self.state = {}
+        self.t = 0
+        self.last_grad_norm = None
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def _coef(self, max_norm):
+        lib = _lib.load()
+        grads = [p.grad for p in self.params if p.grad is not None]
+        dev = grads[0].device
+        counts = [lib.itr_sq_sum_blocks(g.numel()) for g in grads]
+        part = torch.empty(sum(counts), device=dev, dtype=torch.float32)
+        o = 0
+        for g, n in zip(grads, counts):
+            gc = g.contiguous()
+            _lib.check(lib.itr_sq_sum(_p(gc), gc.numel(), C.c_void_p(part.data_ptr() + 4 * o), _stream()))
+            o += n
+        out = torch.empty(2, device=dev, dtype=torch.float32)
+        _lib.check(lib.itr_clip_coef(_p(part), part.numel(), float(max_norm), _p(out), _stream()))
+        return out
+
+    def step(self, max_norm=0.0):
+        lib = _lib.load()
+        self.t += 1
+        g0 = self.param_groups[0]
+        coef = None
+        if any(p.grad is not None for p in self.params):
+            coef = self._coef(max_norm)
+            self.last_grad_norm = coef[1:]
+        for p in self.params:
+            if p.grad is None:
+                continue
+            if not p.is_cuda:
+                raise RuntimeError("Adam: parameter on %s (no CPU fallback)" % p.device)
+            st = self.state.get(p)
+            if st is None:
+                st = self.state[p] = {'exp_avg': torch.zeros_like(p.data), 'exp_avg_sq': torch.zeros_like(p.data)}
+            g = p.grad.contiguous()
+            _lib.check(lib.itr_adam_step(_p(p.data), _p(g), _p(st['exp_avg']), _p(st['exp_avg_sq']), p.numel(), float(g0['lr']),
+                                         float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), self.t, _p(coef), _stream()))

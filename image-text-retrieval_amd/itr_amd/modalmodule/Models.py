@@ -1,12 +1,15 @@
 """Model wrappers with the reference's interface (itr/modalmodule/Models.py): attributes config, img_enc,
-txt_enc, sim_enc, criterion, Eiters, logger; methods forward_emb / forward_loss / val_start / train_start /
-state_dict / load_state_dict.  Towers and losses run on the HIP kernels.
+txt_enc, sim_enc, criterion, optimizer, Eiters, logger; methods forward_emb / forward_loss / train_emb / val_start /
+train_start / state_dict / load_state_dict.  Towers and losses run on the HIP kernels.
 
-`train_emb` (backward through the towers + Adam) is SURVEY.md 8(f) item 3 and not built yet: the hinge
-loss has a HIP backward (dL/dS), the towers do not."""
+`train_emb` (forward -> hinge -> backward -> clip_grad_norm_ -> Adam, Models.py:115-145, :198-225) is built for the
+GRU family with a pooled or SCAN t2i similarity (VSE++, SCAN): itr_amd/autograd.py wires the HIP forward / backward
+kernels into torch's tape.  SGRAF / SAEM / CAMERA training (backward through EncoderSimilarity / BERT) is not built."""
 import torch
 from torch import nn
 
+from .. import autograd as ag
+from .. import ops
 from . import ImgEncoder, TextEncoder, Objectives, Fusionmodule
 
 
@@ -26,6 +29,8 @@ class base_module(nn.Module):
 
     def calculate_params(self):
         self.params_num = sum(p.numel() for p in self.params)
+        if self.optimizer is None:       # every wrapper owns Adam(params, lr) like the reference (Models.py:88-90)
+            self.optimizer = ag.Adam(self.params, lr=self.config['learning_rate'])
 
     def state_dict(self):
         """List layout of the reference (Models.py:37-40).  The reference stores the sim_enc MODULE as the third
@@ -59,8 +64,36 @@ class base_module(nn.Module):
             self.logger.update(k, v, n)
 
     def train_emb(self, train_data, *a, **k):
-        raise NotImplementedError("train_emb needs backward kernels for the towers (SURVEY.md 8f-3); "
-                                  "forward_emb / forward_loss are available")
+        raise NotImplementedError("train_emb of %s needs backward kernels that are not built (SURVEY.md 8f-3); "
+                                  "forward_emb / forward_loss are available" % type(self).__name__)
+
+    # ---- shared by the GRU-family training steps
+    def _train_towers(self, images, captions, lengths, pooled_images, last_state):
+        """Differentiable towers on one batch -> (img_emb, packed word / caption embeddings, tok_off, lens).
+        Same arithmetic as forward_emb; captions arrive sorted by length (collate_fn)."""
+        images = self._dev(images)
+        captions = self._dev(captions)
+        ie, te = self.img_enc, self.txt_enc
+        if getattr(te, 'dropout_p', 0.) > 0:
+            raise NotImplementedError("training-mode dropout on the word embeddings is not built")
+        x = ops.mean_mid(images) if pooled_images else images
+        img = ag.linear(x, ie._weight(), ie.fc.bias)
+        if not ie.no_imgnorm:
+            img = ag.l2norm_rows(img)
+        toks, off, lens, _ = TextEncoder.pack_tokens(captions, lengths)
+        seq = ag.gru_sequence(toks, off, lens, te.embed.weight, dict(te.rnn.named_parameters()), te.use_bi_gru)
+        if last_state:
+            last = off + torch.as_tensor(lens, device=off.device, dtype=torch.int64) - 1
+            seq = ag.gather_rows(seq, last)
+        if not te.no_txtnorm:
+            seq = ag.l2norm_rows(seq)
+        return img, seq, off, lens
+
+    def _step(self, loss, batch_size):
+        """backward -> clip_grad_norm_(params, grad_clip) -> Adam (Models.py:137-145)."""
+        self._log('Loss', float(loss.detach()), batch_size)
+        loss.backward()
+        self.optimizer.step(max_norm=self.grad_clip if self.grad_clip > 0 else 0.0)
 
     @staticmethod
     def _dev(t):
@@ -86,12 +119,27 @@ class VSE_PP(base_module):
         self.criterion = Objectives.ContrastiveLoss(config=config, margin=config['margin'],
                                                     max_violation=config['max_violation'], measure=config['measure'])
         self.params = list(self.txt_enc.parameters()) + list(self.img_enc.fc.parameters())
+        self.optimizer = ag.Adam(self.params, lr=config['learning_rate'])
         self.calculate_params()
 
     def forward_emb(self, images, captions, lengths, *args, **kwargs):
         img_emb = self.img_enc(self._dev(images))
         cap_emb, _ = self.txt_enc(self._dev(captions), lengths)
         return img_emb, cap_emb
+
+    def train_emb(self, train_data, *args, **kwargs):
+        """One training step (Models.py:115-145)."""
+        images, _, _, captions, lengths, _, _, _ = train_data
+        if self.config['measure'] != 'cosine':
+            raise NotImplementedError("training with measure='order' is not built")
+        self.Eiters += 1
+        self._log('Eit', self.Eiters)
+        self._log('lr', self.optimizer.param_groups[0]['lr'])
+        self.optimizer.zero_grad()
+        with torch.enable_grad():
+            img, cap, _, _ = self._train_towers(images, captions, lengths, pooled_images=True, last_state=True)
+            loss = ops.hinge_loss(ag.cosine_scores(img, cap), self.config['margin'], self.config['max_violation'])
+            self._step(loss, img.size(0))
 
     def forward_loss(self, img_emb, cap_emb):
         loss = self.criterion(img_emb, cap_emb)
@@ -116,12 +164,30 @@ class SCAN(base_module):
                                                     measure=config['measure'],
                                                     max_violation=config['max_violation'])
         self.params = list(self.txt_enc.parameters()) + list(self.img_enc.fc.parameters())
+        self.optimizer = ag.Adam(self.params, lr=config['learning_rate'])
         self.calculate_params()
 
     def forward_emb(self, images, captions, lengths, *args, **kwargs):
         img_emb = self.img_enc(self._dev(images))
         cap_emb, cap_lens = self.txt_enc(self._dev(captions), lengths)
         return img_emb, cap_emb, cap_lens
+
+    def train_emb(self, train_data, *args, **kwargs):
+        """One training step (Models.py:198-225)."""
+        images, _, _, captions, lengths, _, _, _ = train_data
+        cfg = self.config
+        if cfg['cross_attn'] != 't2i':
+            raise NotImplementedError("SCAN training is built for cross_attn='t2i' (the configured default); i2t is evaluation-only")
+        self.Eiters += 1
+        self._log('Eit', self.Eiters)
+        self._log('lr', self.optimizer.param_groups[0]['lr'])
+        self.optimizer.zero_grad()
+        with torch.enable_grad():
+            img, words, off, lens = self._train_towers(images, captions, lengths, pooled_images=False, last_state=False)
+            scores = ag.scan_t2i_scores(img, words, off, lens, cfg['raw_feature_norm'], cfg['agg_func'], cfg['lambda_lse'],
+                                        cfg['lambda_softmax'])
+            loss = ops.hinge_loss(scores, cfg['margin'], cfg['max_violation'])
+            self._step(loss, img.size(0))
 
     def forward_loss(self, img_emb, cap_emb, cap_lens):
         loss = self.criterion(img_emb, cap_emb, cap_lens)

@@ -217,6 +217,75 @@ int itr_rank_counts(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_lo
 /* host-side summary (evaluation.py:181-185): out5 = r1, r5, r10, medr, meanr. */
 int itr_recall_from_ranks(const int32_t *ranks_host, int64_t n, double *out5);
 
+/* ---- a14: the training step  model.train_emb (itr/modalmodule/Models.py:198-225, :115-145): forward -> loss ->
+ * backward -> clip_grad_norm_(2.0) -> Adam.  Backward contractions are itr_gemm_nt on transposed operands;
+ * these are the pieces around them. ------------------------------------------------------------------------- */
+/* z = x / (||x|| + eps) keeping the row norms (utils.py:10-15), and its backward
+ *   dx = dz / (n + eps) - z (z . dz) / n. */
+int itr_l2norm_fwd_save(const float *x, float *z, float *norms, int64_t rows, int dim, float eps, itr_stream_t stream);
+int itr_l2norm_bwd(const float *dz, const float *z, const float *norms, float *dx, int64_t rows, int dim, float eps,
+                   itr_stream_t stream);
+/* out[c, r] = in[r, c] (row-major [rows, cols] -> [cols, rows]). */
+int itr_transpose2d(const float *in, float *out, int64_t rows, int64_t cols, itr_stream_t stream);
+/* out[c] (+)= sum_r x[r, c], fixed summation order (bias gradients). */
+size_t itr_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int itr_colsum(const float *x, float *out, int64_t rows, int64_t cols, int accumulate, void *workspace,
+               size_t workspace_bytes, itr_stream_t stream);
+/* nn.Embedding backward: dE[tokens[r], :] += dx[r, :] (atomic adds). */
+int itr_embed_scatter_add(const int64_t *tokens, const float *dx, int64_t n_tok, int64_t V, int E, float *dE,
+                          itr_stream_t stream);
+/* out[r, :] = table[idx[r], :]  (nn.Embedding forward; the last-valid-step gather of TextEncoder.py:57-60).  Indices
+ * outside [0, V) read row 0 and set *bad_flag (device int) to 1. */
+int itr_gather_rows(const int64_t *idx, int64_t n, const float *table, int64_t V, int E, float *out, int *bad_flag,
+                    itr_stream_t stream);
+/* clip_grad_norm_ (Models.py:222-223): itr_sq_sum writes itr_sq_sum_blocks(n) partial sums of squares of one gradient
+ * tensor; itr_clip_coef turns all partials of all tensors into coef_and_norm[0] = min(1, max_norm / (||g|| + 1e-6)),
+ * coef_and_norm[1] = ||g|| (device floats). */
+int itr_sq_sum_blocks(int64_t n);
+int itr_sq_sum(const float *g, int64_t n, float *partials, itr_stream_t stream);
+int itr_clip_coef(const float *partials, int64_t nparts, float max_norm, float *coef_and_norm, itr_stream_t stream);
+/* torch.optim.Adam step on one tensor (no weight decay / amsgrad); the gradient is multiplied by *grad_scale_dev
+ * (device float, may be NULL) first; `step` is the 1-based update count. */
+int itr_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  int64_t step, const float *grad_scale_dev, itr_stream_t stream);
+
+/* EncoderText (bi)GRU under autograd (TextEncoder.py:38-70): training forward that keeps the gate activations, and
+ * backpropagation through time.  Same packed layout / sorting contract as itr_gru_fwd.  `out` [n_tok, D] is the RAW
+ * sequence output ((fwd + bwd) / 2 for a bi-GRU); l2norm / last-step gather are separate differentiable steps.
+ * Gradients: d_embed [V, E] is ACCUMULATED into (zero it first); d_w_* / d_b_* are overwritten. */
+size_t itr_gru_train_save_bytes(int64_t n_tok, int D, int bidirectional);
+size_t itr_gru_train_workspace_bytes(int64_t n_tok, int64_t B, int E, int D);
+int itr_gru_fwd_train(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev, const int32_t *len_host,
+                      int64_t B, int64_t n_tok, const float *embed, int64_t V, int E, int D, const float *w_ih,
+                      const float *w_hh, const float *b_ih, const float *b_hh, const float *w_ih_rev,
+                      const float *w_hh_rev, const float *b_ih_rev, const float *b_hh_rev, float *out, void *save,
+                      size_t save_bytes, void *workspace, size_t workspace_bytes, itr_stream_t stream);
+int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev, const int32_t *len_host, int64_t B,
+                int64_t n_tok, const float *embed, int64_t V, int E, int D, const float *w_ih, const float *w_hh,
+                const float *w_ih_rev, const float *w_hh_rev, const void *save, const float *d_out, float *d_embed,
+                float *d_w_ih, float *d_w_hh, float *d_b_ih, float *d_b_hh, float *d_w_ih_rev, float *d_w_hh_rev,
+                float *d_b_ih_rev, float *d_b_hh_rev, void *workspace, size_t workspace_bytes, itr_stream_t stream);
+
+/* SCAN t2i similarity of a TRAINING batch (xattn_score_t2i, Objectives.py:329-372, under autograd).
+ *   A [Bi*36, ldA] = V E^T  raw dot products (itr_gemm_nt), G [Bi, 36, 36] = V_i V_i^T and enorm[n_tok] = ||e_w||
+ *   (itr_scan_train_prepare);  captions packed: cap_off[Bc], cap_len[Bc] (any order), at most 64 words.
+ *   norm in {0 clipped_l2norm, 1 l2norm, 3 no_norm, 4 clipped};  agg in {0 LogSumExp, 1 Max, 2 Sum, 3 Mean}.
+ * itr_scan_train_bwd (dS [Bi, Bc]) writes dA [Bi*36, ldA], per-pair Gram gradients dG_pairs [Bi, Bc, 36, 36] and
+ * d_enorm_pairs [Bi, ldA]; the caller finishes with GEMMs  dV = dA E,  dE = dA^T V  and itr_scan_train_finish, which
+ * ADDS (sum_c dG + its transpose) V_i to dV and  colsum_i(d_enorm_pairs) e / ||e||  (d_enorm [n_tok]) to dE. */
+int itr_scan_train_prepare(const float *V, const float *E, int64_t Bi, int64_t n_tok, int R, int D, float *G,
+                           float *enorm, itr_stream_t stream);
+int itr_scan_train_fwd(const float *A, int64_t ldA, const float *G, const float *enorm, const int64_t *cap_off,
+                       const int32_t *cap_len, int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int max_len, int norm,
+                       int agg, float lambda_softmax, float lambda_lse, float *S, itr_stream_t stream);
+int itr_scan_train_bwd(const float *A, int64_t ldA, const float *G, const float *enorm, const int64_t *cap_off,
+                       const int32_t *cap_len, int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int max_len, int norm,
+                       int agg, float lambda_softmax, float lambda_lse, const float *dS, float *dA, float *dG_pairs,
+                       float *d_enorm_pairs, itr_stream_t stream);
+int itr_scan_train_finish(const float *dG_pairs, int64_t Bi, int64_t Bc, const float *V, const float *E,
+                          const float *enorm, const float *d_enorm, int64_t n_tok, int R, int D, float *dV, float *dE,
+                          itr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

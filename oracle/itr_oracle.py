@@ -624,3 +624,76 @@ def angular_loss(im, s, angle_bound=1.0, max_violation=True):
         t = x.max(2)[0]
         return (t + torch.log(torch.exp(-t) + torch.exp(x - t.unsqueeze(1)).sum(2))).mean()
     return one(im, s, s) + one(s, im, im)
+
+
+# --------------------------------------------------------------------------------------
+# a14  one optimisation step  model.train_emb  (itr/modalmodule/Models.py:115-145 VSE++, :198-225 SCAN):
+#      forward_emb -> criterion -> backward -> clip_grad_norm_(params, grad_clip) -> Adam(lr).step()
+# --------------------------------------------------------------------------------------
+
+
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (norm type 2): total = ||(||g_1||, ..., ||g_n||)||;
+    every gradient is multiplied by min(1, max_norm / (total + 1e-6)).  Returns (scaled grads, total)."""
+    total = torch.norm(torch.stack([torch.norm(g, 2) for g in grads]), 2)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return [g * coef for g in grads], total
+
+
+def adam_update(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam, single tensor, no weight decay / amsgrad; t is the 1-based step.  Returns (p, m, v)."""
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1 = 1 - beta1 ** t
+    bc2 = 1 - beta2 ** t
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    return p - (lr / bc1) * (m / denom), m, v
+
+
+def gru_model_loss(kind, wi, wt, images, ids, lengths, cfg):
+    """Training-mode forward of the GRU model family on one batch -> scalar loss.
+    kind 'SCAN': region embeddings x word embeddings -> xattn_score -> hinge (Models.py:182-205);
+    kind 'VSE++': mean-pooled regions (SURVEY Q3 build decision) x last GRU state -> cosine -> hinge."""
+    bi = bool(cfg.get('bi_gru', False))
+    if kind == 'SCAN':
+        img = encoder_image_precomp(images, wi['fc.weight'], wi['fc.bias'], cfg.get('no_imgnorm', False))
+        cap, cap_len = encoder_text(ids, lengths, wt, bi, cfg.get('no_txtnorm', False), False, None)
+        if cfg.get('cross_attn', 't2i') != 't2i':
+            raise NotImplementedError
+        scores = xattn_score(img, cap, cap_len, 't2i', cfg.get('raw_feature_norm', 'clipped_l2norm'),
+                             cfg.get('agg_func', 'LogSumExp'), cfg.get('lambda_lse', 6.0), cfg.get('lambda_softmax', 9.0))
+    elif kind == 'VSE++':
+        img = encoder_image_precomp(images.mean(1), wi['fc.weight'], wi['fc.bias'], cfg.get('no_imgnorm', False))
+        cap, _ = encoder_text(ids, lengths, wt, bi, cfg.get('no_txtnorm', False), False, 'VSE++')
+        scores = cosine_sim(img, cap)
+    else:
+        raise ValueError(kind)
+    return hinge_loss(scores, cfg.get('margin', 0.2), cfg.get('max_violation', False))
+
+
+def gru_model_train_step(kind, wi, wt, images, ids, lengths, cfg, state=None):
+    """One train_emb step.  wi: {'fc.weight', 'fc.bias'}; wt: EncoderText state_dict.  state: None or
+    {'t': int, 'm': {name: tensor}, 'v': {...}} with names 'txt.<k>' / 'img.<k>'.
+    Returns (loss, clipped grads dict, new wi, new wt, new state).  Parameter order as the reference builds
+    it: txt_enc.parameters() then img_enc.fc.parameters() (Models.py:85-87, :176-178)."""
+    names = [('txt.' + k, wt, k) for k in wt] + [('img.' + k, wi, k) for k in ('fc.weight', 'fc.bias')]
+    with torch.enable_grad():
+        leaves = {n: d[k].detach().clone().requires_grad_(True) for n, d, k in names}
+        wi_l = {k: leaves['img.' + k] for k in ('fc.weight', 'fc.bias')}
+        wt_l = {k: leaves['txt.' + k] for k in wt}
+        loss = gru_model_loss(kind, wi_l, wt_l, images, ids, lengths, cfg)
+        loss.backward()
+    grads = [leaves[n].grad if leaves[n].grad is not None else torch.zeros_like(leaves[n]) for n, _, _ in names]
+    if cfg.get('grad_clip', 2.0) > 0:
+        grads, _ = clip_grad_norm(grads, cfg.get('grad_clip', 2.0))
+    if state is None:
+        state = {'t': 0, 'm': {n: torch.zeros_like(leaves[n]) for n, _, _ in names}, 'v': {n: torch.zeros_like(leaves[n]) for n, _, _ in names}}
+    t = state['t'] + 1
+    new = {'t': t, 'm': {}, 'v': {}}
+    out = {}
+    for (n, _, _), g in zip(names, grads):
+        p, m, v = adam_update(leaves[n].detach(), g, state['m'][n], state['v'][n], t, cfg['learning_rate'])
+        out[n], new['m'][n], new['v'][n] = p, m, v
+    new_wi = {k: out['img.' + k] for k in ('fc.weight', 'fc.bias')}
+    new_wt = {k: out['txt.' + k] for k in wt}
+    return loss.detach(), {n: g for (n, _, _), g in zip(names, grads)}, new_wi, new_wt, new

@@ -621,9 +621,102 @@ def g14():
     save('g14_data_layer', **out)
 
 
+# ------------------------------------------------------------------ G15 training step (a14 train_emb)
+def _train_batch(rng, B, V, F_):
+    lens = sorted([int(x) for x in rng.randint(2, 12, size=B)], reverse=True)
+    ids = torch.zeros(B, max(lens), dtype=torch.long)
+    for b, l in enumerate(lens):
+        ids[b, :l] = torch.from_numpy(rng.randint(4, V, size=l))
+    feats = mutils.l2norm(torch.randn(B, 36, F_), dim=-1)
+    return feats, ids, lens
+
+
+def g15():
+    """The reference's own SCAN.train_emb (Models.py:198-225) run twice on CPU: loss, clipped gradients and the
+    parameters after each Adam step; the oracle's restated step must agree.  VSE++ is non-functional in the
+    reference, so its step is assembled from the reference components + torch's own
+    clip_grad_norm_ / Adam."""
+    rng = np.random.RandomState(15)
+    torch.manual_seed(15)
+    V, F_, D, E, B = 60, 24, 32, 16, 10
+    cfg = dict(name='SCAN', img_dim=F_, embed_size=D, precomp_enc_type='basic', no_imgnorm=False, vocab_size=V, word_dim=E,
+               num_layers=1, bi_gru=True, no_txtnorm=False, margin=0.2, measure='cosine', max_violation=True, learning_rate=2e-3,
+               grad_clip=2.0, cross_attn='t2i', raw_feature_norm='clipped_l2norm', agg_func='LogSumExp', lambda_lse=6.0,
+               lambda_softmax=9.0)
+    out = {}
+    with torch.enable_grad():
+        model = Models.SCAN(cfg)
+        model.train_start()
+        model.logger = evaluation.LogCollector()
+        w0_img, w0_txt = sd(model.img_enc), sd(model.txt_enc)
+        for k, v in w0_img.items():
+            out['w0_img_' + k] = v
+        for k, v in w0_txt.items():
+            out['w0_txt_' + k] = v
+        state, wi, wt = None, w0_img, w0_txt
+        for step in (1, 2):
+            feats, ids, lens = _train_batch(rng, B, V, F_)
+            batch = (feats, None, None, ids, lens, list(range(B)), None, None)
+            model.train_emb(batch)
+            loss = float(model.logger.meters['Loss'].val)
+            out.update({'s%d_feats' % step: feats, 's%d_ids' % step: ids, 's%d_lens' % step: np.array(lens), 's%d_loss' % step: loss})
+            grads = {('txt.' + n): p.grad.detach().clone() for n, p in model.txt_enc.named_parameters()}
+            grads.update({('img.' + n): p.grad.detach().clone() for n, p in model.img_enc.named_parameters()})
+            for n, gten in grads.items():
+                out['s%d_grad_%s' % (step, n)] = gten
+            for k, v in sd(model.img_enc).items():
+                out['s%d_img_%s' % (step, k)] = v
+            for k, v in sd(model.txt_enc).items():
+                out['s%d_txt_%s' % (step, k)] = v
+            # ---- oracle cross-check
+            o_loss, o_grads, wi, wt, state = O.gru_model_train_step('SCAN', wi, wt, feats, ids, lens, cfg, state)
+            check('train loss step %d' % step, o_loss, loss, 1e-5)
+            for n in grads:
+                check('grad %s (step %d)' % (n, step), o_grads[n], grads[n], 2e-6)
+            for k, v in sd(model.img_enc).items():
+                check('img %s after step %d' % (k, step), wi[k], v, 5e-5)   # Adam amplifies 1e-7 gradient noise where |g| ~ eps
+            for k, v in sd(model.txt_enc).items():
+                check('txt %s after step %d' % (k, step), wt[k], v, 5e-5)
+    out['cfg_json'] = np.frombuffer(__import__('json').dumps(cfg).encode(), np.uint8)
+    # ---- VSE++ from components (uni-GRU, sum of violations)
+    torch.manual_seed(16)
+    cfgv = dict(cfg, name='VSE++', bi_gru=False, max_violation=False, learning_rate=1e-3)
+    with torch.enable_grad():
+        ie = ImgEncoder.EncoderImagePrecomp(F_, D)
+        te = TextEncoder.EncoderText(V, E, D, 1, use_bi_gru=False, method_name='VSE++')
+        crit = Objectives.ContrastiveLoss(config=cfgv, margin=0.2, measure='cosine', max_violation=False)
+        params = list(te.parameters()) + list(ie.fc.parameters())
+        opt = torch.optim.Adam(params, lr=cfgv['learning_rate'])
+        wi, wt = sd(ie), sd(te)
+        for k, v in wi.items():
+            out['v_w0_img_' + k] = v
+        for k, v in wt.items():
+            out['v_w0_txt_' + k] = v
+        feats, ids, lens = _train_batch(rng, B, V, F_)
+        opt.zero_grad()
+        cap, _ = te(ids, lens)
+        loss = crit(ie(feats.mean(1)), cap)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 2.0)
+        opt.step()
+        out.update(v_feats=feats, v_ids=ids, v_lens=np.array(lens), v_loss=float(loss))
+        o_loss, o_grads, nwi, nwt, _ = O.gru_model_train_step('VSE++', wi, wt, feats, ids, lens, cfgv, None)
+        check('vse++ train loss', o_loss, float(loss), 1e-5)
+        for k, v in sd(ie).items():
+            out['v_s1_img_' + k] = v
+            check('vse++ img %s' % k, nwi[k], v, 5e-5)
+        for k, v in sd(te).items():
+            out['v_s1_txt_' + k] = v
+            check('vse++ txt %s' % k, nwt[k], v, 5e-5)
+        for n, p_ in list(('txt.' + n, p_) for n, p_ in te.named_parameters()) + list(('img.' + n, p_) for n, p_ in ie.named_parameters()):
+            out['v_grad_' + n] = p_.grad.detach().clone()
+            check('vse++ grad ' + n, o_grads[n], p_.grad, 2e-6)
+    save('g15_train_step', **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15']
     for name in which:
         print("== " + name)
         globals()[name]()

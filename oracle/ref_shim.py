@@ -60,6 +60,7 @@ def install():
     torch.Tensor.cuda = lambda self, *a, **k: self
     nn.Module.cuda = lambda self, *a, **k: self
     torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.is_current_stream_capturing = lambda: False   # torch.optim's capture health check (is_available is faked)
 
     class _IdentityDP(nn.Module):
         def __init__(self, module, *a, **k):
