@@ -7,7 +7,7 @@
 //   itr_transpose2d                        out[c, r] = in[r, c]           (LDS-tiled, coalesced both ways)
 //   itr_colsum                             out[c] = sum_r x[r, c]         (bias gradients; fixed summation order)
 //   itr_embed_scatter_add                  dE[token[r], :] += dx[r, :]    (nn.Embedding backward)
-//   itr_sq_sum                             partial sums of squares        (clip_grad_norm_, Models.py:222-223)
+//   itr_sq_sum                             partial sums of squares        (clip_grad_norm_, Models.py:223-224)
 //   itr_adam_step                          torch.optim.Adam update (no weight decay, no amsgrad), gradient pre-scaled
 #include "itr_common.h"
 
@@ -119,10 +119,13 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float *__restrict__ p, c
 }
 
 // total_norm = sqrt(sum of all partials); coef = min(1, max_norm / (total_norm + 1e-6))   (torch clip_grad_norm_)
-__global__ void clip_coef_kernel(const float *__restrict__ part, int64_t nparts, float max_norm, float *__restrict__ out2) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void clip_coef_kernel(const float *__restrict__ part, int64_t nparts, float max_norm, float *__restrict__ out2) {
+    const int lane = threadIdx.x;
     double s = 0.0;
-    for (int64_t i = 0; i < nparts; ++i) s += (double)part[i];
+    for (int64_t i = lane; i < nparts; i += 64) s += (double)part[i];        // fixed lane-strided order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane != 0) return;
     const float total = (float)sqrt(s);
     out2[1] = total;
     const float c = max_norm / (total + 1e-6f);

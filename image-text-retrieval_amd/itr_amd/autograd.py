@@ -10,7 +10,7 @@ There is no CPU path: tensors must live on the GPU.
     gather_rows(x, idx)          rows of x                              last valid GRU step (TextEncoder.py:57-60)
     cosine_scores(im, s)         im s^T                                 Objectives.py:18-21
     scan_t2i_scores(...)         SCAN t2i similarity matrix             Objectives.py:329-372
-    Adam / clip_grad_norm        torch.optim.Adam + clip_grad_norm_     Models.py:88-90, :222-224
+    Adam / clip_grad_norm        torch.optim.Adam + clip_grad_norm_     Models.py:98, :178, :223-225
 """
 import ctypes as C
 
@@ -68,6 +68,8 @@ class _Linear(torch.autograd.Function):
         b = _dev(bias, name="bias") if bias is not None else None
         M, K = x2.shape
         N = w.shape[0]
+        if w.dim() != 2 or w.shape[1] != K:
+            raise ValueError("linear: x (..., %d) vs weight %s" % (K, tuple(w.shape)))
         out = _f32(M, N, dev=x.device)
         _lib.check(lib.itr_gemm_nt(_p(x2), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, _stream()))
         ctx.save_for_backward(x2, w)
@@ -217,6 +219,8 @@ class _Cosine(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, s):
         im, s = _dev(im, name="im"), _dev(s, name="s")
+        if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
+            raise ValueError("cosine_scores: im %s vs s %s" % (tuple(im.shape), tuple(s.shape)))
         ctx.save_for_backward(im, s)
         return _gemm_nt(im, s)
 
@@ -240,6 +244,8 @@ class _ScanT2I(torch.autograd.Function):
         V = _dev(V, name="images")
         E = _dev(E, name="words")
         Bi, R, D = V.shape
+        if E.dim() != 2 or E.shape[1] != D:
+            raise ValueError("scan_t2i_scores: images (.., %d) vs words %s" % (D, tuple(E.shape)))
         n_tok = E.shape[0]
         Bc = cap_len.numel()
         dev = V.device

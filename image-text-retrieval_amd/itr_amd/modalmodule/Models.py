@@ -29,7 +29,7 @@ class base_module(nn.Module):
 
     def calculate_params(self):
         self.params_num = sum(p.numel() for p in self.params)
-        if self.optimizer is None:       # every wrapper owns Adam(params, lr) like the reference (Models.py:88-90)
+        if self.optimizer is None:       # every wrapper owns Adam(params, lr) like the reference (Models.py:98, :178)
             self.optimizer = ag.Adam(self.params, lr=self.config['learning_rate'])
 
     def state_dict(self):
@@ -90,7 +90,7 @@ class base_module(nn.Module):
         return img, seq, off, lens
 
     def _step(self, loss, batch_size):
-        """backward -> clip_grad_norm_(params, grad_clip) -> Adam (Models.py:137-145)."""
+        """backward -> clip_grad_norm_(params, grad_clip) -> Adam (Models.py:139-144, :220-225)."""
         self._log('Loss', float(loss.detach()), batch_size)
         loss.backward()
         self.optimizer.step(max_norm=self.grad_clip if self.grad_clip > 0 else 0.0)

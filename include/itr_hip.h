@@ -238,7 +238,7 @@ int itr_embed_scatter_add(const int64_t *tokens, const float *dx, int64_t n_tok,
  * outside [0, V) read row 0 and set *bad_flag (device int) to 1. */
 int itr_gather_rows(const int64_t *idx, int64_t n, const float *table, int64_t V, int E, float *out, int *bad_flag,
                     itr_stream_t stream);
-/* clip_grad_norm_ (Models.py:222-223): itr_sq_sum writes itr_sq_sum_blocks(n) partial sums of squares of one gradient
+/* clip_grad_norm_ (Models.py:223-224): itr_sq_sum writes itr_sq_sum_blocks(n) partial sums of squares of one gradient
  * tensor; itr_clip_coef turns all partials of all tensors into coef_and_norm[0] = min(1, max_norm / (||g|| + 1e-6)),
  * coef_and_norm[1] = ||g|| (device floats). */
 int itr_sq_sum_blocks(int64_t n);

@@ -675,7 +675,7 @@ def gru_model_train_step(kind, wi, wt, images, ids, lengths, cfg, state=None):
     """One train_emb step.  wi: {'fc.weight', 'fc.bias'}; wt: EncoderText state_dict.  state: None or
     {'t': int, 'm': {name: tensor}, 'v': {...}} with names 'txt.<k>' / 'img.<k>'.
     Returns (loss, clipped grads dict, new wi, new wt, new state).  Parameter order as the reference builds
-    it: txt_enc.parameters() then img_enc.fc.parameters() (Models.py:85-87, :176-178)."""
+    it: txt_enc.parameters() then img_enc.fc.parameters() (Models.py:95-97, :175-177)."""
     names = [('txt.' + k, wt, k) for k in wt] + [('img.' + k, wi, k) for k in ('fc.weight', 'fc.bias')]
     with torch.enable_grad():
         leaves = {n: d[k].detach().clone().requires_grad_(True) for n, d, k in names}

@@ -172,6 +172,8 @@ def test_scan_train_rejects(dev):
         ag.scan_t2i_scores(img, words, [0, 2], [2, 3], 'bogus')
     with pytest.raises(RuntimeError):
         ag.linear(torch.zeros(2, 3), torch.zeros(4, 3))
+    with pytest.raises(ValueError):
+        ag.linear(torch.zeros(2, 3, device=dev), torch.zeros(4, 5, device=dev))
 
 
 # ------------------------------------------------------------------------------------------ optimizer

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Time model.train_emb at the reference's training shape (batch 128, 36 x 2048 regions, coco vocabulary, word_dim 300,
+embed 1024, bi-GRU): ms per step and the split forward / backward / optimizer.  Run on the GPU box."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "image-text-retrieval_amd"))
+import numpy as np
+import torch
+from itr_amd import config as C, ops
+from itr_amd.modalmodule import get_model
+from itr_amd.metricmodule.evaluation import LogCollector
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="SCAN", choices=["SCAN", "VSE_PP"])
+ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--steps", type=int, default=10)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+cfg = C.build_config(['with', a.model, 'data_name=coco_precomp', 'bi_gru=True', 'max_violation=True'])
+cfg['vocab_size'] = 11353
+cfg['img_dim'] = 2048        # precomp region features
+torch.manual_seed(0)
+model = get_model(cfg)
+model.train_start()
+model.logger = LogCollector()
+rng = np.random.RandomState(0)
+B = a.batch
+
+
+def batch():
+    lens = sorted([int(x) for x in rng.randint(6, 21, size=B)], reverse=True)
+    ids = torch.zeros(B, max(lens), dtype=torch.long)
+    for b, l in enumerate(lens):
+        ids[b, :l] = torch.from_numpy(rng.randint(4, 11353, size=l))
+    feats = ops.l2norm(torch.randn(B, 36, 2048, device=dev))
+    return (feats, None, None, ids.to(dev), lens, list(range(B)), None, None)
+
+
+batches = [batch() for _ in range(4)]
+for i in range(3):
+    model.train_emb(batches[i % 4])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(a.steps):
+    model.train_emb(batches[i % 4])
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+n_tok = sum(batches[0][4])
+print("%s train_emb  batch %d (%d words): %.2f ms/step  (%.0f pairs/s, %.0f img-cap pairs scored per step); loss %.4f" % (
+    a.model, B, n_tok, dt * 1e3, B * B / dt, B * B, float(model.logger.meters['Loss'].val)))
