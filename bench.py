@@ -42,6 +42,11 @@ WORKLOADS = {
     "sgraf_sgr_coco5k": dict(n_img=5000, vocab=11353, sgraf="SGR"),
     "sgraf_saf_f30k1k": dict(n_img=1000, vocab=8481, sgraf="SAF"),
     "sgraf_sgr_f30k1k": dict(n_img=1000, vocab=8481, sgraf="SGR"),
+    # BASELINE.json configs[1]: VSE++ f30k 1k x 5k cosine; configs[3]: SAEM / CAMERA with the BERT-base text tower
+    "vsepp_f30k1k": dict(n_img=1000, vocab=8481, pooled="VSE++"),
+    "saem_coco5k": dict(n_img=5000, pooled="SAEM"),
+    "camera_coco5k": dict(n_img=5000, pooled="CAMERA"),
+    "camera_f30k1k": dict(n_img=1000, pooled="CAMERA"),
 }
 
 
@@ -134,6 +139,152 @@ def pmc_traffic(workload, world):
     return (best["hbm_bytes_per_launch"], best["source"]) if best else (None, None)
 
 
+# ------------------------------------------------------------------------------------------ pooled models
+BERT_BASE = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                 max_position_embeddings=512, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                 hidden_act="gelu", initializer_range=0.02)
+
+
+def bert_files(tmp):
+    """bert_config.json + a seeded random pytorch_model.bin + SAEM's trans_cfg.json (pretrained weights are external
+    to the reference and there is no network: SURVEY 8c)."""
+    from itr_amd.modalmodule import bert
+    os.makedirs(tmp, exist_ok=True)
+    cfg_file, ckpt, trans = (os.path.join(tmp, n) for n in ("bert_config.json", "pytorch_model.bin", "trans_cfg.json"))
+    json.dump(BERT_BASE, open(cfg_file, "w"))
+    json.dump(dict(BERT_BASE, hidden_size=256, num_attention_heads=4, intermediate_size=1024), open(trans, "w"))   # SURVEY Q5
+    if not os.path.exists(ckpt):
+        torch.manual_seed(1)
+        m = bert.BertModel(bert.BertConfig.from_dict(BERT_BASE))
+        for p_ in m.parameters():
+            p_.data.normal_(0, 0.02)
+        torch.save(m.state_dict(), ckpt)
+    return cfg_file, ckpt, trans
+
+
+def pooled_inputs(n_img, n_cap, kind, dev, seed=0):
+    """SURVEY 8d synthetic inputs: region features, boxes x1,y1~U(0,400), w,h~U(20,200), wh = (640, 480); BERT ids
+    randint(1000, 30522) with [CLS]=101 first, mask = first `len` ones of 32, lengths randint(6, 21)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rng = np.random.RandomState(seed)
+    from itr_amd import ops
+    feats = ops.l2norm(torch.randn(n_img, 36, 2048, device=dev, generator=g))
+    xy = torch.rand(n_img, 36, 2, device=dev, generator=g) * 400
+    wh = torch.rand(n_img, 36, 2, device=dev, generator=g) * 180 + 20
+    boxes = torch.cat([xy, xy + wh], -1)
+    imgs_wh = torch.tensor([[640., 480.]], device=dev).repeat(n_img, 1)
+    lens = rng.randint(6, 21, size=n_cap)
+    ids = rng.randint(1000, 30522, size=(n_cap, 32))
+    ids[:, 0] = 101
+    mask = (np.arange(32)[None, :] < lens[:, None]).astype(np.int64)
+    ids = ids * mask
+    return feats, boxes, imgs_wh, torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev), torch.zeros(n_cap, 32, dtype=torch.long, device=dev), lens
+
+
+def main_pooled(args, wl, world, rank, dev, use_dist):
+    from itr_amd import config as C, evalpipe, ops
+    from itr_amd.modalmodule import get_model
+    kind = wl["pooled"]
+    n_img, n_cap = wl["n_img"], 5 * wl["n_img"]
+    comm = evalpipe.Comm()
+    i0, i1 = evalpipe.block_range(n_img, comm.world, comm.rank, 4)
+    c0, c1 = evalpipe.block_range(n_cap, comm.world, comm.rank)
+    torch.manual_seed(0)
+    if kind == "VSE++":
+        cfg = C.build_config(['with', 'VSE_PP', 'data_name=f30k_precomp', 'bi_gru=True', 'max_violation=True'])
+        cfg.update(img_dim=2048, vocab_size=wl["vocab"])
+    else:
+        cfg_file, ckpt, trans = bert_files(os.path.join("/tmp", "itr_bench_bert"))
+        cfg = C.build_config(['with', kind, 'data_name=coco_precomp'])
+        cfg.update(bert_config_file=cfg_file, init_checkpoint=ckpt, trans_cfg=trans, vocab_size=30522)
+    model = get_model(cfg)
+    model.val_start()
+    if kind == "VSE++":
+        # packed captions of this rank, sorted by length once (like the SCAN workload): ONE GRU call per step
+        lengths, tokens = make_captions(n_cap, wl["vocab"])
+        g = torch.Generator(device=dev)
+        g.manual_seed(0)
+        feats = ops.l2norm(torch.randn(n_img, 36, 2048, device=dev, generator=g))
+        toks, tok_off, lens_sorted, order = shard_captions(lengths, tokens, c0, c1, dev)
+        order_dev = torch.from_numpy(np.ascontiguousarray(order)).to(dev)
+        towers = evalpipe.GruModelEval({k: v.detach() for k, v in model.img_enc.state_dict().items()},
+                                       {k: v.detach() for k, v in model.txt_enc.state_dict().items()},
+                                       dict(bi_gru=True, no_txtnorm=False, no_imgnorm=False), comm)
+    else:
+        feats, boxes, imgs_wh, ids, mask, types, lengths = pooled_inputs(n_img, n_cap, kind, dev)
+    pe = evalpipe.PooledModelEval(model, comm, batch=1000)
+    timers = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
+
+    def step(tm=None):
+        if kind == "VSE++":
+            img = ops.proj_l2norm(ops.mean_mid(feats[i0:i1]), towers.wi['fc.weight'], towers.wi['fc.bias'])
+            cap_sorted = towers.encode_captions(toks, tok_off, lens_sorted, gather_last=True)
+            cap = torch.empty_like(cap_sorted)
+            cap[order_dev] = cap_sorted                      # back to the dataset order
+            cap_counts = [evalpipe.block_range(n_cap, comm.world, q)[1] - evalpipe.block_range(n_cap, comm.world, q)[0] for q in range(comm.world)]
+            cap_all, maxrows = comm.all_gather_rows(cap, cap_counts)
+            if comm.on and any(c != maxrows for c in cap_counts):
+                cap_all = torch.cat([cap_all[q * maxrows:q * maxrows + cap_counts[q]] for q in range(comm.world)], 0)
+            if tm is not None:
+                tm['scan_start'].record()
+            S = ops.cosine_scores(img, cap_all)
+            if tm is not None:
+                tm['scan_end'].record()
+            return S, evalpipe.finalize_ranks(comm, S, i0, n_img, 5)
+        return pe.eval(feats[i0:i1], boxes[i0:i1], imgs_wh[i0:i1], ids[c0:c1], mask[c0:c1], types[c0:c1], [int(x) for x in lengths[c0:c1]],
+                       n_img, n_cap, timers=tm)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    score_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        S, ranks = step(timers)
+        score_ms.append(timers["scan_start"].elapsed_time(timers["scan_end"]))
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank != 0:
+        return
+    from itr_amd import ops as _ops
+    ms_per_step = 1e3 * dt / args.steps
+    # SURVEY 8d algorithmic flop of the step on this rank
+    if kind == "VSE++":
+        n_tok = float(lengths[c0:c1].sum())
+        flop = (i1 - i0) * 2 * 2048 * 1024 + n_tok * 16.27e6 + float(i1 - i0) * n_cap * 2 * 1024
+        model_name, dims = "VSE++ bi-GRU (mean-pooled regions)", 1024
+    elif kind == "SAEM":
+        flop = (c1 - c0) * 5.47e9 + float(i1 - i0) * n_cap * 512
+        model_name, dims = "SAEM (BERT-base + cnn head, transformer image tower)", 256
+    else:
+        flop = (c1 - c0) * (5.47e9 + 1.45e9) + (i1 - i0) * 1.55e9 + float(i1 - i0) * n_cap * 2 * 12 * 2048
+        model_name, dims = "CAMERA (BERT-base + AGSA, 12 views x 2048)", 2048
+    i2t, t2i = _ops.recall_from_ranks(ranks[0]), _ops.recall_from_ranks(ranks[2])
+    out = {"metric": "pairs/sec scored (5k img x 25k cap) + Recall@1 parity, 1/2/4/8 MI355X", "value": float(n_img) * n_cap / (dt / args.steps),
+           "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": args.workload, "model": model_name, "n_img": n_img, "n_cap": n_cap, "regions": 36, "feat_dim": 2048,
+                      "embed": dims, "parallelism": "row-shard x%d + 1 all-gather of caption embeddings" % world,
+                      "step": "encode(image tower + text tower) + score + rank(i2t,t2i)"},
+           "recall": {"i2t_r1": i2t[0], "i2t_r5": i2t[1], "i2t_r10": i2t[2], "t2i_r1": t2i[0], "t2i_r5": t2i[1], "t2i_r10": t2i[2]},
+           "roofline": {"kernel": "gemm_nt_kernel (every dense layer of the towers + the score GEMM)", "bound": "mfma",
+                        "achieved": flop / (ms_per_step * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flop / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "score_kernel_ms": float(np.mean(score_ms)), "algorithmic_flop_per_step": flop,
+                        "note": "time = the whole step (the towers are hundreds of GEMM launches); flop = SURVEY 8d per-unit figures"}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +311,11 @@ def main():
 
     from itr_amd import evalpipe, ops
     wl = WORKLOADS[args.workload]
+    if "pooled" in wl:
+        main_pooled(args, wl, world, rank, dev, use_dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     n_img, n_cap = wl["n_img"], 5 * wl["n_img"]
     F_, D, R = 2048, 1024, 36
     is_sgraf = "sgraf" in wl

@@ -58,6 +58,207 @@ __device__ __forceinline__ float4 load4(const float *base, int64_t row, int64_t 
     return v;
 }
 
+// Shared epilogue: bias / activation / accumulate / squared-difference / max over row groups.
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2][2], float4 (*lds_raw), int tid, int lane, int wm, int wn,
+                                              int64_t m0, int64_t n0, int64_t m_end) {
+    float4(*lds)[2][NPLANE][BM] = reinterpret_cast<float4(*)[2][NPLANE][BM]>(lds_raw);
+    // ---- epilogue ---------------------------------------------------------------------
+    if (g.group <= 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
+                if (col >= g.N) continue;
+                const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < m_end) {
+                        float v = acc[i][j][r];
+                        if (g.Z) {
+                            v = v * g.rowscale[row] - g.Z[row * g.ldz + col];
+                            v = v * v;
+                        } else {
+                            if (g.accumulate) v += g.C[row * g.ldc + col];
+                            v = apply_act(v + bv, g.act);
+                        }
+                        g.C[row * g.ldc + col] = v;
+                    }
+                }
+            }
+    } else {
+        // max over `group` consecutive rows: stage the 128 x 128 tile in LDS (reusing the
+        // operand buffers: 64 KB needed, 64 KB available), then one thread per (group, col).
+        __syncthreads();
+        float *tile = reinterpret_cast<float *>(&lds[0][0][0][0]);  // [128][128]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    tile[row * BN + col] = acc[i][j][r];
+                }
+            }
+        __syncthreads();
+        const int ngroups = g.rows_per_tile / g.group;
+        for (int idx = tid; idx < ngroups * BN; idx += GEMM_THREADS) {
+            const int gi = idx / BN, col = idx % BN;
+            const int64_t grow = m0 / g.group + gi;
+            if (m0 + (int64_t)gi * g.group >= g.M || n0 + col >= g.N) continue;
+            float mx = -INFINITY;
+            for (int v = 0; v < g.group; ++v) mx = fmaxf(mx, tile[(gi * g.group + v) * BN + col]);
+            g.C[grow * g.ldc + n0 + col] = mx;
+        }
+    }
+}
+
+// Fast path: K % 32 == 0, 16-byte aligned rows.  Same tiling; the K loop is branch-free and free of vector-ALU work
+// (on gfx950 the fp32 MFMA shares the vector ALU, so address arithmetic in the loop costs matrix throughput):
+//   * global loads: uniform 64-bit base (advanced by a scalar add per chunk) + fixed per-lane 32-bit byte offset,
+//     issued through inline asm with our own s_waitcnt; rows past the edge re-read the last valid row (their outputs
+//     are never stored), the tail iterations re-load the last chunk and park data nobody reads;
+//   * chunk kc+1 (loaded one iteration earlier) is parked in the other LDS buffer and chunk kc+2 requested at the TOP of
+//     iteration kc, all slotted between the 64 MFMAs of chunk kc by sched_group_barrier; one barrier per chunk;
+//   * MFMAs are issued component-major so that consecutive instructions never touch the same accumulator.
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) {
+    __shared__ float4 lds[2][2][NPLANE][BM];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t tiles_m = (g.M + BM - 1) / BM;
+    const int64_t tiles_n = (g.N + BN - 1) / BN;
+    int64_t bid = blockIdx.x;
+    const int64_t ntile = tiles_m * tiles_n;
+    {
+        const int64_t q = ntile / 8, r = ntile % 8;
+        const int64_t xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int64_t tm = bid % tiles_m, tn = bid / tiles_m;
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+    const int64_t m_end = (m0 + BM < g.M) ? m0 + BM : g.M;
+    const int ld_row = tid >> 3, ld_p = tid & 7;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (int)(g.K / BK), klast = nk - 1;
+    const char *abase = reinterpret_cast<const char *>(g.A + m0 * g.lda);
+    const char *bbase = reinterpret_cast<const char *>(g.B + n0 * g.ldb);
+    unsigned oa0, oa1, oa2, oa3, ob0, ob1, ob2, ob3;    // per-lane byte offsets (host checked: 128 rows * ld * 4 < 2^32)
+    {
+        auto offa = [&](int s_) -> unsigned {
+            int64_t r = m0 + ld_row + 32 * s_;
+            r = (r < m_end ? r : m_end - 1) - m0;
+            return (unsigned)r * (unsigned)g.lda * 4u + ld_p * 16u;
+        };
+        auto offb = [&](int s_) -> unsigned {
+            int64_t r = n0 + ld_row + 32 * s_;
+            r = (r < g.N ? r : g.N - 1) - n0;
+            return (unsigned)r * (unsigned)g.ldb * 4u + ld_p * 16u;
+        };
+        oa0 = offa(0); oa1 = offa(1); oa2 = offa(2); oa3 = offa(3);
+        ob0 = offb(0); ob1 = offb(1); ob2 = offb(2); ob3 = offb(3);
+    }
+    char *const lbase = reinterpret_cast<char *>(&lds[0][0][0][0]);
+    constexpr unsigned OPER_BYTES = NPLANE * BM * 16u, BUF_BYTES = 2u * OPER_BYTES;
+    // LDS store byte addresses of this lane inside one operand of one buffer (row s: ld_row + 32 s; (r + 32 s) ^ p == (r ^ p) + 32 s)
+    const unsigned ls0 = (unsigned)(ld_p * BM + (ld_row ^ ld_p)) * 16u;
+    f32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define GF_LDG(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+#define GF_GLOAD(KC)                                                                                \
+    {                                                                                               \
+        const char *ab_ = abase + (int64_t)(KC) * (BK * 4);                                         \
+        const char *bb_ = bbase + (int64_t)(KC) * (BK * 4);                                         \
+        GF_LDG(ra0, ab_, oa0) GF_LDG(rb0, bb_, ob0) GF_LDG(ra1, ab_, oa1) GF_LDG(rb1, bb_, ob1)     \
+        GF_LDG(ra2, ab_, oa2) GF_LDG(rb2, bb_, ob2) GF_LDG(ra3, ab_, oa3) GF_LDG(rb3, bb_, ob3)     \
+    }
+#define GF_VMWAIT0                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(ra2), "+v"(ra3), "+v"(rb0), "+v"(rb1), "+v"(rb2), "+v"(rb3)::"memory");
+#define GF_STS(off, v) (*reinterpret_cast<f32x4 *>(lbase + (off)) = (v))
+#define GF_LSTORE(BUF)                                                                              \
+    {                                                                                               \
+        const unsigned b_ = (BUF) * BUF_BYTES + ls0;                                                \
+        GF_STS(b_, ra0); GF_STS(b_ + 32 * 16, ra1); GF_STS(b_ + 64 * 16, ra2); GF_STS(b_ + 96 * 16, ra3); \
+        GF_STS(b_ + OPER_BYTES, rb0); GF_STS(b_ + OPER_BYTES + 32 * 16, rb1);                       \
+        GF_STS(b_ + OPER_BYTES + 64 * 16, rb2); GF_STS(b_ + OPER_BYTES + 96 * 16, rb3);             \
+    }
+    GF_GLOAD(0)
+    GF_VMWAIT0
+    GF_LSTORE(0)
+    GF_GLOAD((1 < klast ? 1 : klast))
+    __syncthreads();
+
+    const int fi = lane & 31, fg = lane >> 5;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        GF_VMWAIT0
+        GF_LSTORE(buf ^ 1)
+        GF_GLOAD((kc + 2 < klast ? kc + 2 : klast))
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = 2 * q + fg;
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = lds[buf][0][p][(wm * 64 + i * 32 + fi) ^ p];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = lds[buf][1][p][(wn * 64 + j * 32 + fi) ^ p];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+        // 64 MFMAs per chunk against 16 ds_read_b128 + 8 ds_write_b128 + 8 global loads: one memory instruction per MFMA slot
+#pragma unroll
+        for (int i_ = 0; i_ < 4; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // first fragment reads before the first MFMA
+        }
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+#pragma unroll
+        for (int i_ = 0; i_ < 12; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the unused tail prefetch
+#undef GF_LDG
+#undef GF_GLOAD
+#undef GF_VMWAIT0
+#undef GF_STS
+#undef GF_LSTORE
+    gemm_epilogue(g, acc, &lds[0][0][0][0], tid, lane, wm, wn, m0, n0, m_end);
+}
+
 template <bool ALIGNED>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
     // [buffer][operand][plane][row] float4
@@ -146,58 +347,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
         }
     }
 
-    // ---- epilogue ---------------------------------------------------------------------
-    if (g.group <= 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
-                if (col >= g.N) continue;
-                const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < m_end) {
-                        float v = acc[i][j][r];
-                        if (g.Z) {
-                            v = v * g.rowscale[row] - g.Z[row * g.ldz + col];
-                            v = v * v;
-                        } else {
-                            if (g.accumulate) v += g.C[row * g.ldc + col];
-                            v = apply_act(v + bv, g.act);
-                        }
-                        g.C[row * g.ldc + col] = v;
-                    }
-                }
-            }
-    } else {
-        // max over `group` consecutive rows: stage the 128 x 128 tile in LDS (reusing the
-        // operand buffers: 64 KB needed, 64 KB available), then one thread per (group, col).
-        __syncthreads();
-        float *tile = reinterpret_cast<float *>(&lds[0][0][0][0]);  // [128][128]
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    tile[row * BN + col] = acc[i][j][r];
-                }
-            }
-        __syncthreads();
-        const int ngroups = g.rows_per_tile / g.group;
-        for (int idx = tid; idx < ngroups * BN; idx += GEMM_THREADS) {
-            const int gi = idx / BN, col = idx % BN;
-            const int64_t grow = m0 / g.group + gi;
-            if (m0 + (int64_t)gi * g.group >= g.M || n0 + col >= g.N) continue;
-            float mx = -INFINITY;
-            for (int v = 0; v < g.group; ++v) mx = fmaxf(mx, tile[(gi * g.group + v) * BN + col]);
-            g.C[grow * g.ldc + n0 + col] = mx;
-        }
-    }
+    gemm_epilogue(g, acc, &lds[0][0][0][0], tid, lane, wm, wn, m0, n0, m_end);
 }
 
 static int launch_gemm(const GemmArgs &g, hipStream_t st) {
@@ -211,7 +361,11 @@ static int launch_gemm(const GemmArgs &g, hipStream_t st) {
     const bool aligned = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.K % 4 == 0) &&
                          ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
-    if (aligned)
+    const bool fast = aligned && g.group <= 1 && (g.K % BK == 0) && g.K >= BK && g.rows_per_tile == BM &&
+                      (uint64_t)g.lda * 4u * BM < (1ull << 32) && (uint64_t)g.ldb * 4u * BN < (1ull << 32);
+    if (fast)
+        hipLaunchKernelGGL(gemm_nt_fast_kernel, dim3((unsigned)nblk), dim3(GEMM_THREADS), 0, st, g);
+    else if (aligned)
         hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)nblk), dim3(GEMM_THREADS), 0, st, g);
     else
         hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3((unsigned)nblk), dim3(GEMM_THREADS), 0, st, g);

@@ -188,3 +188,60 @@ class GruModelEval:
         row0 = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)[0]
         ranks = finalize_ranks(comm, S, row0, n_img_total, im_div)
         return S, ranks, plan
+
+
+class PooledModelEval:
+    """Sharded evaluation of the models whose caption embedding is ONE vector (VSE++, SAEM, CAMERA):
+    rank p encodes its image rows and its caption slice in batches, ONE all-gather moves the caption embeddings
+    (Nc x D floats: 25.6 MB SAEM, 205 MB CAMERA at coco size), the row block of the similarity matrix is one GEMM
+    (cosine / pdist_cos / MultiViewMatching with its max-over-views epilogue) and the ranks are finished exactly as
+    for SCAN (finalize_ranks)."""
+
+    def __init__(self, model, comm=None, batch=1000):
+        self.model, self.comm, self.batch = model, comm or Comm(), batch
+        self.name = model.config['name']
+
+    def _score(self, img, cap):
+        if self.name == 'CAMERA':
+            return ops.mvm_scores(img, cap)                 # Fusionmodule.py:674-692
+        if self.name == 'SAEM':
+            return ops.pdist_cos(img, cap)                  # Objectives.py:310-323
+        return ops.cosine_scores(img, cap)                  # Objectives.py:18-21
+
+    def encode(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, lengths):
+        """Local shards -> (img_emb, cap_emb); image and caption counts are independent here (unique images)."""
+        m, bs = self.model, self.batch
+        imgs, caps = [], []
+        with torch.no_grad():
+            for b0 in range(0, images.shape[0], bs):
+                sl = slice(b0, b0 + bs)
+                if self.name == 'CAMERA':
+                    imgs.append(m.img_enc(images[sl], boxes[sl], imgs_wh[sl])[0])
+                else:
+                    imgs.append(m.img_enc(images[sl]))
+            for b0 in range(0, captions.shape[0], bs):
+                sl = slice(b0, b0 + bs)
+                if self.name == 'CAMERA':
+                    caps.append(m.txt_enc(captions[sl], captions_mask[sl], captions_type_ids[sl]))
+                elif self.name == 'SAEM':
+                    caps.append(m.txt_enc(captions[sl], captions_mask[sl], captions_type_ids[sl], lengths[b0:b0 + bs]))
+                else:
+                    caps.append(m.txt_enc(captions[sl], lengths[b0:b0 + bs])[0])
+        return torch.cat(imgs, 0), torch.cat(caps, 0)
+
+    def eval(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, lengths, n_img_total, n_cap_total,
+             im_div=5, timers=None):
+        comm = self.comm
+        img, cap = self.encode(images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, lengths)
+        cap_counts = [block_range(n_cap_total, comm.world, q)[1] - block_range(n_cap_total, comm.world, q)[0]
+                      for q in range(comm.world)]
+        cap_all, maxrows = comm.all_gather_rows(cap, cap_counts)
+        if comm.on and any(c != maxrows for c in cap_counts):
+            cap_all = torch.cat([cap_all[q * maxrows:q * maxrows + cap_counts[q]] for q in range(comm.world)], 0)
+        if timers is not None:
+            timers['scan_start'].record()
+        S = self._score(img, cap_all)
+        if timers is not None:
+            timers['scan_end'].record()
+        row0 = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)[0]
+        return S, finalize_ranks(comm, S, row0, n_img_total, im_div)
