@@ -245,3 +245,94 @@ class PooledModelEval:
             timers['scan_end'].record()
         row0 = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)[0]
         return S, finalize_ranks(comm, S, row0, n_img_total, im_div)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Real data: checkpointed model + precomp files -> sharded, device-resident evaluation (the bench's path on a dataset)
+def _features_to_device(arr, i0, i1, dev, chunk=512):
+    """Rows [i0, i1) of a memory-mapped .npy -> one HBM tensor; pinned staging + a side stream so that reading the
+    next chunk from the page cache / disk overlaps the copy of the previous one."""
+    out = torch.empty((i1 - i0,) + tuple(arr.shape[1:]), device=dev, dtype=torch.float32)
+    stream = torch.cuda.Stream(device=dev)
+    bufs = [torch.empty((chunk,) + tuple(arr.shape[1:]), dtype=torch.float32).pin_memory() for _ in range(2)]
+    evs = [None, None]
+    for k, r0 in enumerate(range(i0, i1, chunk)):
+        r1 = min(i1, r0 + chunk)
+        b = k & 1
+        if evs[b] is not None:
+            evs[b].synchronize()                  # the copy that last used this staging buffer is done
+        bufs[b][:r1 - r0].copy_(torch.from_numpy(np.ascontiguousarray(arr[r0:r1], dtype=np.float32)))
+        with torch.cuda.stream(stream):
+            out[r0 - i0:r1 - i0].copy_(bufs[b][:r1 - r0], non_blocking=True)
+            evs[b] = torch.cuda.Event()
+            evs[b].record(stream)
+    torch.cuda.current_stream(dev).wait_stream(stream)
+    return out
+
+
+def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1000):
+    """Recall ranks of `model` on a PrecompDataset (datamodule.data_loader), one process per GPU.
+
+    Unlike encode_data + cal_sims (the reference-shaped path: 5 x redundant image encodes, host numpy arrays, a Python
+    tile loop), every unique image is encoded once, nothing returns to the host but the rank vectors, the caption
+    axis is sharded over ranks and exchanged with ONE all-gather, and the row block of the similarity matrix is scored
+    by the fused kernels.  fold = (k, size) restricts to captions [k*size, (k+1)*size) (MS-COCO 1k folds,
+    evaluation.py:296-300).  Returns (i2t_rank, i2t_top1, t2i_rank, t2i_top1) as host int64 arrays."""
+    comm = comm or Comm()
+    cfg = model.config
+    name = cfg['name']
+    dev = torch.device('cuda', torch.cuda.current_device())
+    im_div = dataset.im_div
+    n_cap_all = len(dataset)
+    cap_lo, cap_hi = (0, n_cap_all) if fold is None else (fold[0] * fold[1], min(n_cap_all, (fold[0] + 1) * fold[1]))
+    n_cap = cap_hi - cap_lo
+    img_lo = cap_lo // im_div
+    n_img = -(-n_cap // im_div)
+    if im_div != 5 or n_cap % 5:
+        raise NotImplementedError("evaluate_precomp expects the 5-captions-per-image layout of the precomp test splits")
+    i0, i1 = block_range(n_img, comm.world, comm.rank, _IMG_ALIGN)
+    c0, c1 = block_range(n_cap, comm.world, comm.rank)
+    model.val_start()
+    feats = _features_to_device(dataset.images, img_lo + i0, img_lo + i1, dev)
+    with torch.no_grad():
+        if name in ('SCAN', 'SGRAF', 'VSE++', 'VSE_PP'):
+            ids = [dataset.token_ids(cap_lo + j) for j in range(c0, c1)]
+            lens = np.asarray([len(x) for x in ids], np.int64)
+            order = np.argsort(-lens, kind="stable")
+            lens_sorted = [int(lens[i]) for i in order]
+            packed = np.concatenate([np.asarray(ids[i], np.int64) for i in order]) if len(order) else np.zeros(0, np.int64)
+            tok_off = np.concatenate([[0], np.cumsum(lens_sorted)[:-1]]) if len(order) else np.zeros(0, np.int64)
+            toks, off = torch.from_numpy(packed).to(dev), torch.from_numpy(tok_off.astype(np.int64)).to(dev)
+            wi = {k: v.detach() for k, v in model.img_enc.state_dict().items()}
+            wt = {k: v.detach() for k, v in model.txt_enc.state_dict().items()}
+            ev = GruModelEval(wi, wt, dict(cfg, bi_gru=model.txt_enc.use_bi_gru, no_txtnorm=model.txt_enc.no_txtnorm,
+                                           no_imgnorm=model.img_enc.no_imgnorm), comm)
+            if name in ('VSE++', 'VSE_PP'):
+                img = ops.proj_l2norm(ops.mean_mid(feats), wi['fc.weight'], wi['fc.bias'], no_imgnorm=model.img_enc.no_imgnorm)
+                cap_sorted = ev.encode_captions(toks, off, lens_sorted, gather_last=True)
+                cap = torch.empty_like(cap_sorted)
+                cap[torch.from_numpy(np.ascontiguousarray(order)).to(dev)] = cap_sorted
+                counts = [block_range(n_cap, comm.world, q)[1] - block_range(n_cap, comm.world, q)[0] for q in range(comm.world)]
+                cap_all, maxrows = comm.all_gather_rows(cap, counts)
+                if comm.on and any(c != maxrows for c in counts):
+                    cap_all = torch.cat([cap_all[q * maxrows:q * maxrows + counts[q]] for q in range(comm.world)], 0)
+                S = ops.cosine_scores(img, cap_all)
+                return finalize_ranks(comm, S, i0, n_img, im_div)
+            sw = {k: v.detach() for k, v in model.sim_enc.state_dict().items()} if name == 'SGRAF' else None
+            _, ranks, _ = ev.scan_eval(feats, toks, off, lens_sorted, order, n_img, n_cap, im_div, sgraf_weights=sw)
+            return ranks
+        # ---- BERT models: one vector per caption
+        if name not in ('SAEM', 'CAMERA'):
+            raise NotImplementedError("evaluate_precomp: model %r" % name)
+        from .datamodule.data_loader import convert_to_feature
+        feat_rows = [convert_to_feature(dataset.captions[cap_lo + j], dataset.max_words, dataset.tokenizer) for j in range(c0, c1)]
+        ids = torch.tensor([f[1] for f in feat_rows], dtype=torch.long, device=dev).reshape(-1, dataset.max_words)
+        mask = torch.tensor([f[2] for f in feat_rows], dtype=torch.long, device=dev).reshape(-1, dataset.max_words)
+        types = torch.tensor([f[3] for f in feat_rows], dtype=torch.long, device=dev).reshape(-1, dataset.max_words)
+        boxes = wh = None
+        if name == 'CAMERA':
+            boxes = _features_to_device(dataset.boxes, img_lo + i0, img_lo + i1, dev)
+            wh = _features_to_device(dataset.img_wh, img_lo + i0, img_lo + i1, dev)
+        pe = PooledModelEval(model, comm, batch=batch)
+        _, ranks = pe.eval(feats, boxes, wh, ids, mask, types, [int(m.sum()) for m in mask.cpu()], n_img, n_cap, im_div)
+        return ranks

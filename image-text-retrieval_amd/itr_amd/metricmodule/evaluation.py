@@ -284,6 +284,45 @@ def _evalrank(model_paths, data_path, split, fold5, tag):
     return res_dic
 
 
+def _recall_dict(ranks):
+    """cal_recall's dict (evaluation.py:225-259) from rank vectors."""
+    i_rank, i_top, t_rank, t_top = [np.asarray(x, dtype=np.float64) for x in ranks]
+    r, ri = ops.recall_from_ranks(i_rank), ops.recall_from_ranks(t_rank)
+    ar, ari = (r[0] + r[1] + r[2]) / 3, (ri[0] + ri[1] + ri[2]) / 3
+    rsum = r[0] + r[1] + r[2] + ri[0] + ri[1] + ri[2]
+    return {'result': [list(r) + list(ri) + [ar, ari, rsum]], 'rsum': rsum, 'i2t_ave_r': ar, 'i2t_r1': r[0], 'i2t_r5': r[1],
+            'i2t_r10': r[2], 'i2t_medr': r[3], 'i2t_meanr': r[4], 'i2t_ranks': i_rank, 'i2t_top1': i_top, 't2i_ave_r': ari,
+            't2i_r1': ri[0], 't2i_r5': ri[1], 't2i_r10': ri[2], 't2i_medr': ri[3], 't2i_meanr': ri[4], 't2i_ranks': t_rank,
+            't2i_top1': t_top}
+
+
+def evalrank_fast(model_path, data_path=None, split='dev', fold5=False, comm=None):
+    """Same result dict / YAML as evalrank_single through the sharded device-resident pipeline
+    (itr_amd.evalpipe.evaluate_precomp): launch one process per GPU with torch.distributed.run; rank 0 writes
+    `<run dir>/<data_name>[_5fold]_single_result.yaml`."""
+    import os
+    import yaml
+    from .. import evalpipe
+    from ..datamodule import data_loader as data
+    model, _config = _load_for_eval(model_path, data_path)
+    dset = data.PrecompDataset(os.path.join(_config['data_path'], _config['data_name']), split, _config)
+    comm = comm or evalpipe.Comm()
+    if not fold5:
+        res_dic = _recall_dict(evalpipe.evaluate_precomp(model, dset, comm))
+    else:
+        res_dic = {'sum_result': []}
+        for i in range(5):
+            part = _recall_dict(evalpipe.evaluate_precomp(model, dset, comm, fold=(i, 5000)))
+            res_dic[f'PART_{i + 1}'] = part
+            res_dic['sum_result'] += part['result']
+        res_dic['Mean_metrics'] = _mean_metrics(res_dic)
+    res_dic['data_name'] = _config['data_name'] + ('_5fold' if fold5 else '')
+    if comm.rank == 0:
+        with open(os.path.join(os.path.dirname(model_path), f'{res_dic["data_name"]}_single_result.yaml'), 'w') as f:
+            yaml.safe_dump(_plain(res_dic), f)
+    return res_dic
+
+
 def evalrank_single(model_path, data_path=None, split='dev', fold5=False):
     """evaluation.py:262-335."""
     return _evalrank([model_path], data_path, split, fold5, 'single')

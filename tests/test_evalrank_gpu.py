@@ -92,6 +92,29 @@ def test_evalrank_single_and_ensemble(golden, dev, tmp_path):
     assert os.path.exists(os.path.join(os.path.dirname(paths[0]), '%s_ensemble_result.yaml' % name))
 
 
+def test_evalrank_fast_equals_reference_shaped_path(golden, dev, tmp_path):
+    """The sharded device-resident evaluator (unique images, packed captions, fused scoring) gives the ranks of the
+    encode_data + cal_sims path on the same checkpoint and files -- SCAN, SGRAF and VSE++."""
+    g = golden("g14_data_layer")
+    name, data_path, vdir = _materialise(g, tmp_path)
+    for model_name, extra in (('SCAN', []), ('SGRAF', ['module_name=SGR']), ('VSE_PP', [])):
+        save_dir = str(tmp_path / ('run_' + model_name))
+        os.makedirs(save_dir)
+        cfg = C.build_config(['with', model_name, 'data_name=%s' % name, 'bi_gru=True', 'seed=3'] + extra)
+        cfg.update(img_dim=8, embed_size=32, word_dim=16, vocab_size=int(g["vocab_len"]), data_path=data_path, vocab_path=vdir,
+                   batch_size=7, workers=0, save_dir=save_dir, word_tokenize=None, sim_dim=16, vocab_type='json')
+        torch.manual_seed(3)
+        model = get_model(cfg)
+        utils.save_checkpoint({'epoch': 0, 'model': model.state_dict(), 'best_rsum': 0.0, 'best_r1': 0.0, '_config': cfg, 'Eiters': 1},
+                              True, prefix=save_dir)
+        p = os.path.join(save_dir, 'model_best.pth.tar')
+        slow = evaluation.evalrank_single(p, split='test')
+        fast = evaluation.evalrank_fast(p, split='test')
+        for k in ('i2t_ranks', 't2i_ranks', 'i2t_top1', 't2i_top1'):
+            assert (np.asarray(slow[k]) == np.asarray(fast[k])).all(), (model_name, k)
+        assert fast['rsum'] == pytest.approx(slow['rsum'])
+
+
 def test_validate_step_and_resume(golden, dev, tmp_path):
     g = golden("g14_data_layer")
     name, data_path, vdir = _materialise(g, tmp_path)
