@@ -402,8 +402,9 @@ int gemm_nt_groupmax(const float *A, int64_t lda, const float *B, int64_t ldb, f
 extern "C" int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
                            float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
                            itr_stream_t stream) {
-    ITR_REQUIRE(A && B && C, "itr_gemm_nt: null pointer");
     ITR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "itr_gemm_nt: negative dimension");
+    if (M == 0 || N == 0) return ITR_OK;   // empty result: empty tensors carry null pointers
+    ITR_REQUIRE(A && B && C, "itr_gemm_nt: null pointer");
     // lda < K is allowed: overlapping A rows express a convolution over consecutive rows (SAEM conv head)
     ITR_REQUIRE(lda >= 1 && ldb >= K && ldc >= N, "itr_gemm_nt: leading dimension smaller than row");
     ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt: unknown activation %d", act);
@@ -420,15 +421,17 @@ extern "C" int itr_gemm_nt_acc(const float *A, int64_t lda, const float *B, int6
 
 extern "C" int itr_cosine_scores(const float *im, const float *s, float *S, int64_t Ni, int64_t Nc, int D,
                                  int64_t ldS, itr_stream_t stream) {
-    ITR_REQUIRE(im && s && S, "itr_cosine_scores: null pointer");
     ITR_REQUIRE(Ni >= 0 && Nc >= 0 && D > 0 && ldS >= Nc, "itr_cosine_scores: bad shape");
+    if (Ni == 0 || Nc == 0) return ITR_OK;
+    ITR_REQUIRE(im && s && S, "itr_cosine_scores: null pointer");
     return itr::gemm_nt(im, D, s, D, nullptr, S, ldS, Ni, Nc, D, 0, itr::as_stream(stream));
 }
 
 extern "C" int itr_mvm_scores(const float *imgs, const float *caps, float *S, int64_t Ni, int64_t Nc, int k,
                               int D, int64_t ldS, itr_stream_t stream) {
-    ITR_REQUIRE(imgs && caps && S, "itr_mvm_scores: null pointer");
     ITR_REQUIRE(Ni >= 0 && Nc >= 0 && D > 0 && ldS >= Nc, "itr_mvm_scores: bad shape");
+    if (Ni == 0 || Nc == 0) return ITR_OK;
+    ITR_REQUIRE(imgs && caps && S, "itr_mvm_scores: null pointer");
     ITR_REQUIRE(k >= 1 && k <= itr::BM, "itr_mvm_scores: number of views must be in [1, %d]", itr::BM);
     return itr::gemm_nt_groupmax(imgs, D, caps, D, S, ldS, Ni, k, Nc, D, itr::as_stream(stream));
 }

@@ -90,8 +90,9 @@ int norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, int ki
 
 extern "C" int itr_l2norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, int kind,
                                int take_abs, itr_stream_t stream) {
-    ITR_REQUIRE(x && y, "itr_l2norm_rows: null pointer");
     ITR_REQUIRE(rows >= 0 && dim > 0, "itr_l2norm_rows: bad shape rows=%lld dim=%d", (long long)rows, dim);
+    if (rows == 0) return ITR_OK;
+    ITR_REQUIRE(x && y, "itr_l2norm_rows: null pointer");
     ITR_REQUIRE(kind >= 0 && kind <= 3, "itr_l2norm_rows: unknown kind %d", kind);
     ITR_REQUIRE(rows < (int64_t)4 * 0x7fffffff, "itr_l2norm_rows: too many rows");
     return itr::norm_rows(x, y, rows, dim, eps, kind, take_abs, itr::as_stream(stream));

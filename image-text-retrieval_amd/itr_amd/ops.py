@@ -241,6 +241,8 @@ def scan_prepare(images, words, plan, cross_attn='t2i'):
     Ni, R, D = images.shape
     wsb = lib.itr_scan_workspace_bytes(Ni, R, words.shape[0], plan.Nc, plan.n_tiles, D)
     ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
+    if Ni == 0 or plan.Nc == 0:
+        return ws                      # nothing to prepare: the score matrix is empty
     _lib.check(lib.itr_scan_prepare(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
                                     _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc, words.shape[0], R, D,
                                     0 if cross_attn == 't2i' else 1, _p(ws), wsb, _stream()))
@@ -264,6 +266,8 @@ def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='c
     n_rows = words.shape[0]
     if out is None:
         out = torch.empty(Ni, plan.Nc, device=images.device, dtype=torch.float32)
+    if Ni == 0 or plan.Nc == 0:
+        return out
     ws = workspace if workspace is not None else scan_prepare(images, words, plan, cross_attn)
     _lib.check(lib.itr_scan_xattn_scores(
         _p(images), plan.n_tiles, Ni, plan.Nc, n_rows, R, D, 0 if cross_attn == 't2i' else 1,
@@ -477,6 +481,10 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
     len_dev = torch.from_numpy(len_host.copy()).to(dev)
     emb = _dev(weights['embed.weight'], name="embed.weight")
     V, E = emb.shape
+    if n_tok:
+        lo, hi = torch.aminmax(tokens_packed)          # nn.Embedding raises on ids outside [0, V) (TextEncoder.py:41)
+        if int(lo) < 0 or int(hi) >= V:
+            raise IndexError("index out of range in self")
     w_ih = _dev(weights['rnn.weight_ih_l0'])
     w_hh = _dev(weights['rnn.weight_hh_l0'])
     b_ih = _dev(weights['rnn.bias_ih_l0'])
