@@ -132,17 +132,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     const int64_t tiles_n = (g.N + BN - 1) / BN;
-    int64_t bid = blockIdx.x;
     const int64_t ntile = tiles_m * tiles_n;
-    {
-        const int64_t q = ntile / 8, r = ntile % 8;
-        const int64_t xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    // PERSISTENT: the grid is at most 2 workgroups per CU (8 XCDs x 64); XCD x owns a contiguous range of the tile order
+    // (consecutive tiles walk down a column of M tiles and share the B panel in that XCD's L2) and its resident
+    // workgroups stride through it.  A short-K tile lives ~25 us, and a fresh workgroup launch costs ~10 us of an idle
+    // slot (88 % slot occupancy measured on the SCAN kernel), which the loop removes.
+    // (Requesting the next tile's first chunk before the epilogue was tried and lost 15 %: the epilogue's own bias
+    // load makes hipcc wait for vmcnt(0), i.e. for the prefetch, before the first store.)
+    const int64_t q_ = ntile / 8, r_ = ntile % 8;
+    const int64_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8, nslots = gridDim.x / 8;
+    const int64_t t_begin = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_);
+    const int64_t t_count = q_ + (xcd < r_ ? 1 : 0);
+    const int ld_row = tid >> 3, ld_p = tid & 7;
+    const int nk = (int)(g.K / BK), klast = nk - 1;
+    char *const lbase = reinterpret_cast<char *>(&lds[0][0][0][0]);
+    constexpr unsigned OPER_BYTES = NPLANE * BM * 16u, BUF_BYTES = 2u * OPER_BYTES;
+    const unsigned ls0 = (unsigned)(ld_p * BM + (ld_row ^ ld_p)) * 16u;
+    const int fi = lane & 31, fg = lane >> 5;
+
+  for (int64_t tt = slot; tt < t_count; tt += nslots) {
+    const int64_t bid = t_begin + tt;
     const int64_t tm = bid % tiles_m, tn = bid / tiles_m;
     const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t m_end = (m0 + BM < g.M) ? m0 + BM : g.M;
-    const int ld_row = tid >> 3, ld_p = tid & 7;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -152,7 +164,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (int)(g.K / BK), klast = nk - 1;
     const char *abase = reinterpret_cast<const char *>(g.A + m0 * g.lda);
     const char *bbase = reinterpret_cast<const char *>(g.B + n0 * g.ldb);
     unsigned oa0, oa1, oa2, oa3, ob0, ob1, ob2, ob3;    // per-lane byte offsets (host checked: 128 rows * ld * 4 < 2^32)
@@ -170,10 +181,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
         oa0 = offa(0); oa1 = offa(1); oa2 = offa(2); oa3 = offa(3);
         ob0 = offb(0); ob1 = offb(1); ob2 = offb(2); ob3 = offb(3);
     }
-    char *const lbase = reinterpret_cast<char *>(&lds[0][0][0][0]);
-    constexpr unsigned OPER_BYTES = NPLANE * BM * 16u, BUF_BYTES = 2u * OPER_BYTES;
-    // LDS store byte addresses of this lane inside one operand of one buffer (row s: ld_row + 32 s; (r + 32 s) ^ p == (r ^ p) + 32 s)
-    const unsigned ls0 = (unsigned)(ld_p * BM + (ld_row ^ ld_p)) * 16u;
     f32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define GF_LDG(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 #define GF_GLOAD(KC)                                                                                \
@@ -199,7 +206,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
     GF_GLOAD((1 < klast ? 1 : klast))
     __syncthreads();
 
-    const int fi = lane & 31, fg = lane >> 5;
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
         GF_VMWAIT0
@@ -251,12 +257,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
         __syncthreads();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the unused tail prefetch
+    // (the loop ended on a barrier: nobody reads LDS any more, the next tile's prologue may overwrite it)
+    gemm_epilogue(g, acc, &lds[0][0][0][0], tid, lane, wm, wn, m0, n0, m_end);
+  }
 #undef GF_LDG
 #undef GF_GLOAD
 #undef GF_VMWAIT0
 #undef GF_STS
 #undef GF_LSTORE
-    gemm_epilogue(g, acc, &lds[0][0][0][0], tid, lane, wm, wn, m0, n0, m_end);
 }
 
 template <bool ALIGNED>
@@ -363,8 +371,11 @@ static int launch_gemm(const GemmArgs &g, hipStream_t st) {
                          ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
     const bool fast = aligned && g.group <= 1 && (g.K % BK == 0) && g.K >= BK && g.rows_per_tile == BM &&
                       (uint64_t)g.lda * 4u * BM < (1ull << 32) && (uint64_t)g.ldb * 4u * BN < (1ull << 32);
-    if (fast)
-        hipLaunchKernelGGL(gemm_nt_fast_kernel, dim3((unsigned)nblk), dim3(GEMM_THREADS), 0, st, g);
+    if (fast) {
+        const int64_t per_xcd = ceil_div(nblk, 8);
+        const unsigned grid = 8u * (unsigned)(per_xcd < 64 ? per_xcd : 64);     // <= 2 workgroups per CU, persistent
+        hipLaunchKernelGGL(gemm_nt_fast_kernel, dim3(grid), dim3(GEMM_THREADS), 0, st, g);
+    }
     else if (aligned)
         hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)nblk), dim3(GEMM_THREADS), 0, st, g);
     else
