@@ -6,6 +6,7 @@
 //   itr_mha_small       softmax(Q K^T / sqrt(dk) + (1 - mask) * -10000) V for short sequences (L <= 64), one wave
 //                       per (sequence, head), one lane per query row, online softmax       (bert.py:185-207; camera_.py:42-53)
 //   itr_relu_maxpool    max over time of relu(x) with a per-sequence valid length          (TextEncoder.py:148-149)
+#include <stdlib.h>
 #include "itr_common.h"
 
 namespace itr {
@@ -130,6 +131,177 @@ __global__ __launch_bounds__(64) void mha_small_kernel(const float *__restrict__
     for (int d = 0; d < DK; ++d) out[(row0 + lane) * ldo + h * DK + d] = ctx[d] * inv;
 }
 
+// Matrix-core attention for short sequences: one WAVE per (sequence b, head h), WPB waves per workgroup.
+//   S = Q K^T      (L x L, K = DK)   NT x NT tiles of v_mfma_f32_16x16x4_f32; Q and K staged in LDS in the plane layout
+//                                    lds[k / 4][row ^ (plane & 7)] (16-byte fragment reads, 4 k-steps per read)
+//   P = softmax(S * scale + mask)    in the accumulator layout: a row lives in the 16 lanes that share fg -> 4 xor-shuffles
+//   ctx = P V      (L x DK, K = L)   P goes through LDS (accumulator layout -> A-operand layout), V is read row-major
+// against the VALU kernel above (one lane per query row, half of the lanes idle at L = 32): 128 MFMAs = 4 096 cycles per
+// (sequence, head) at L = 32, DK = 64 instead of ~16 k FMAs per lane.  Waves never synchronise with each other.
+template <int DK, int NT, int WPB>
+__global__ __launch_bounds__(64 * WPB) void mha_mfma_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                            const float *__restrict__ v, int64_t ldq, int64_t ldk, int64_t ldv,
+                                                            const float *__restrict__ mask, float *__restrict__ out, int64_t ldo,
+                                                            int L, int heads, float scale, int64_t npairs) {
+    constexpr int LP = NT * 16, NPL = DK / 4, VST = DK + 16, PST = LP + 2, NDT = DK / 16;
+    constexpr int QK_F4 = NPL * LP;                                   // float4 per operand
+    constexpr int V_F4 = (LP * VST + 3) / 4, P_F4 = (LP * PST + 3) / 4;
+    constexpr int WAVE_F4 = 2 * QK_F4 + V_F4 + P_F4;
+    extern __shared__ float4 mha_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t pair = (int64_t)blockIdx.x * WPB + wave;
+    if (pair >= npairs) return;
+    const int b = (int)(pair / heads), h = (int)(pair % heads);
+    const int64_t row0 = (int64_t)b * L;
+    float4 *Qp = mha_smem + (size_t)wave * WAVE_F4;
+    float4 *Kp = Qp + QK_F4;
+    float *Vs = reinterpret_cast<float *>(Kp + QK_F4);
+    float *Ps = reinterpret_cast<float *>(Kp + QK_F4 + V_F4);
+    // ---- stage Q, K (plane layout) and V (row-major), zero rows beyond L
+    for (int idx = lane; idx < LP * NPL; idx += 64) {
+        const int row = idx / NPL, p = idx % NPL;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), kv = qv, vv = qv;
+        if (row < L) {
+            qv = *reinterpret_cast<const float4 *>(q + (row0 + row) * ldq + h * DK + 4 * p);
+            kv = *reinterpret_cast<const float4 *>(k + (row0 + row) * ldk + h * DK + 4 * p);
+            vv = *reinterpret_cast<const float4 *>(v + (row0 + row) * ldv + h * DK + 4 * p);
+        }
+        Qp[p * LP + (row ^ (p & 7))] = qv;
+        Kp[p * LP + (row ^ (p & 7))] = kv;
+        float *vd = Vs + row * VST + 4 * p;
+        vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+    }
+    const int fi = lane & 15, fg = lane >> 4;
+    // ---- S = Q K^T
+    f32x4 sacc[NT][NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) sacc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qq = 0; qq < NPL / 4; ++qq) {
+        const int pl = 4 * qq + fg;
+        float4 a[NT], bb[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            a[t] = Qp[pl * LP + ((t * 16 + fi) ^ (pl & 7))];
+            bb[t] = Kp[pl * LP + ((t * 16 + fi) ^ (pl & 7))];
+        }
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) sacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, bb[nt].x, sacc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) sacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, bb[nt].y, sacc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) sacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, bb[nt].z, sacc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) sacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, bb[nt].w, sacc[mt][nt], 0, 0, 0);
+    }
+    // ---- softmax over the keys: sacc[mt][nt][j] = S[mt*16 + 4 fg + j][nt*16 + fi]
+    float madd[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int key = nt * 16 + fi;
+        madd[nt] = key < L ? (mask ? (1.0f - mask[row0 + key]) * -10000.0f : 0.f) : -INFINITY;   // bert.py:340-341; padding keys drop out
+    }
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                sacc[mt][nt][j] = sacc[mt][nt][j] * scale + madd[nt];
+                mx = fmaxf(mx, sacc[mt][nt][j]);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float den = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                sacc[mt][nt][j] = expf(sacc[mt][nt][j] - mx);
+                den += sacc[mt][nt][j];
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
+            const float inv = 1.f / den;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) sacc[mt][nt][j] *= inv;
+        }
+    // ---- P -> LDS in [query][key] order
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Ps[(mt * 16 + 4 * fg + j) * PST + nt * 16 + fi] = sacc[mt][nt][j];
+    // ---- ctx = P V
+    f32x4 cacc[NT][NDT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) cacc[mt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < LP / 4; ++ks) {
+        float a[NT], bv[NDT];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) a[mt] = Ps[(mt * 16 + fi) * PST + 4 * ks + fg];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) bv[dt] = Vs[(4 * ks + fg) * VST + dt * 16 + fi];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) cacc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv[dt], cacc[mt][dt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mt * 16 + 4 * fg + j;
+            if (m < L) {
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) out[(row0 + m) * ldo + h * DK + dt * 16 + fi] = cacc[mt][dt][j];
+            }
+        }
+}
+
+template <int DK, int NT, int WPB>
+static int launch_mha_mfma(const float *q, const float *k, const float *v, int64_t ldq, int64_t ldk, int64_t ldv, const float *mask,
+                           float *out, int64_t ldo, int64_t B, int L, int heads, float scale, hipStream_t st) {
+    constexpr int LP = NT * 16, NPL = DK / 4, VST = DK + 16, PST = LP + 2;
+    constexpr size_t wave_bytes = (size_t)(2 * NPL * LP + (LP * VST + 3) / 4 + (LP * PST + 3) / 4) * 16;
+    constexpr size_t lds = wave_bytes * WPB;
+    static bool attr = false;
+    if (!attr) {
+        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mha_mfma_kernel<DK, NT, WPB>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int64_t npairs = B * heads;
+    hipLaunchKernelGGL((mha_mfma_kernel<DK, NT, WPB>), dim3((unsigned)ceil_div(npairs, (int64_t)WPB)), dim3(64 * WPB), lds, st, q, k, v, ldq,
+                       ldk, ldv, mask, out, ldo, L, heads, scale, npairs);
+    ITR_CHECK_LAUNCH("mha_mfma");
+    return ITR_OK;
+}
+
+template <int DK>
+static int dispatch_mha_mfma(const float *q, const float *k, const float *v, int64_t ldq, int64_t ldk, int64_t ldv, const float *mask,
+                             float *out, int64_t ldo, int64_t B, int L, int heads, float scale, hipStream_t st) {
+    const int nt = (L + 15) / 16;
+    if (nt == 1) return launch_mha_mfma<DK, 1, 4>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
+    if (nt == 2) return launch_mha_mfma<DK, 2, 4>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
+    if (nt == 3) return launch_mha_mfma<DK, 3, 2>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
+    return launch_mha_mfma<DK, 4, 2>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
+}
+
 // out[b, c] = max_{t < valid} relu(x[b, t, c])
 __global__ __launch_bounds__(256) void relu_maxpool_kernel(const float *__restrict__ x, int L, int C, int valid,
                                                            float *__restrict__ out, int64_t ldo) {
@@ -182,6 +354,14 @@ extern "C" int itr_mha_small(const float *q, const float *k, const float *v, int
     if (B == 0) return ITR_OK;
     const dim3 grid((unsigned)(B * heads));
     hipStream_t st = itr::as_stream(stream);
+    // matrix-core path: 16-byte aligned head slices (every fused-QKV / separate-projection layout of the path)
+    const bool al = (ldq % 4 == 0) && (ldk % 4 == 0) && (ldv % 4 == 0) && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+                     reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    if (al && !getenv("ITR_MHA_VALU")) {
+        if (dk == 16) return itr::dispatch_mha_mfma<16>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
+        if (dk == 32) return itr::dispatch_mha_mfma<32>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
+        return itr::dispatch_mha_mfma<64>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
+    }
     if (dk == 16) hipLaunchKernelGGL(itr::mha_small_kernel<16>, grid, dim3(64), 0, st, q, k, v, ldq, ldk, ldv, mask, out, ldo, L, heads, scale);
     else if (dk == 32) hipLaunchKernelGGL(itr::mha_small_kernel<32>, grid, dim3(64), 0, st, q, k, v, ldq, ldk, ldv, mask, out, ldo, L, heads, scale);
     else hipLaunchKernelGGL(itr::mha_small_kernel<64>, grid, dim3(64), 0, st, q, k, v, ldq, ldk, ldv, mask, out, ldo, L, heads, scale);

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from itr_amd import ops
 from itr_amd.modalmodule import bert, TextEncoder, ImgEncoder
 
 pytestmark = pytest.mark.gpu
@@ -133,3 +134,27 @@ def test_aux_losses_golden(golden, dev):
     assert abs(float(div) - float(g["div_reg"])) <= 1e-3 * max(1.0, abs(float(g["div_reg"])))
     ang = Objectives.AngularLoss()(T(g["ang_im"]).to(dev), T(g["ang_s"]).to(dev))
     assert abs(float(ang) - float(g["ang_loss"])) <= 1e-3 * max(1.0, abs(float(g["ang_loss"])))
+
+
+@pytest.mark.parametrize("dk", [16, 32, 64])
+@pytest.mark.parametrize("L", [1, 7, 16, 17, 32, 36, 49, 64])
+def test_attention_kernel_shapes(dev, L, dk):
+    """softmax(Q K^T / sqrt(dk) + (1 - mask) * -10000) V (bert.py:185-207) for every tile count / head width of the
+    matrix-core kernel, with a ragged key mask, fused-QKV strides, and an odd number of (sequence, head) pairs."""
+    torch.manual_seed(L * 100 + dk)
+    B, heads = 3, 3
+    H = heads * dk
+    qkv = torch.randn(B * L, 3 * H)
+    mask = torch.ones(B, L)
+    for b in range(B):
+        mask[b, max(1, L - 2 * b):] = 0
+    scale = 1.0 / dk ** 0.5
+    q, k, v = (qkv[:, i * H:(i + 1) * H].reshape(B, L, heads, dk).permute(0, 2, 1, 3) for i in range(3))
+    sc = q @ k.transpose(-1, -2) * scale + ((1.0 - mask) * -10000.0)[:, None, None, :]
+    want = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, H)
+    d = qkv.to(dev)
+    got = ops.mha_small(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], mask.to(dev), B, L, heads, dk, scale)
+    assert float((got.cpu() - want).abs().max()) <= 2e-6
+    got2 = ops.mha_small(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], None, B, L, heads, dk, scale)
+    want2 = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, H)
+    assert float((got2.cpu() - want2).abs().max()) <= 2e-6
