@@ -282,6 +282,41 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
                         "frac": flop / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                         "score_kernel_ms": float(np.mean(score_ms)), "algorithmic_flop_per_step": flop,
                         "note": "time = the whole step (the towers are hundreds of GEMM launches); flop = SURVEY 8d per-unit figures"}}
+    if world == 1 and not args.no_cpu_baseline:
+        # CPU oracle (kind "port") on the first ns images and their 5*ns captions: encode + score + rank, and max |diff|
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import itr_oracle as O
+        ns = min(args.cpu_sample_images, 40 if kind != "VSE++" else 200)
+        ncs = 5 * ns
+        wi = {k: v.detach().cpu() for k, v in model.img_enc.state_dict().items() if "num_batches_tracked" not in k}
+        wt = {k: v.detach().cpu() for k, v in model.txt_enc.state_dict().items() if "num_batches_tracked" not in k}
+        with torch.no_grad():
+            t0 = time.time()
+            if kind == "VSE++":
+                lens = lengths[:ncs]
+                order_s = np.argsort(-lens, kind="stable")
+                ids_s = torch.zeros(ncs, int(lens.max()), dtype=torch.long)
+                for r, i in enumerate(order_s):
+                    ids_s[r, :lens[i]] = torch.from_numpy(tokens[int(i)])
+                img_o = O.encoder_image_precomp(feats[:ns].cpu().mean(1), wi["fc.weight"], wi["fc.bias"])
+                cap_sorted, _ = O.encoder_text(ids_s, [int(lens[i]) for i in order_s], wt, True, False, False, "VSE++")
+                cap_o = torch.zeros_like(cap_sorted)
+                cap_o[torch.as_tensor(order_s)] = cap_sorted
+                S_o = O.cosine_sim(img_o, cap_o)
+            elif kind == "CAMERA":
+                img_o, _ = O.camera_image(wi, feats[:ns].cpu(), boxes[:ns].cpu(), imgs_wh[:ns].cpu(), cfg["head"])
+                cap_o = O.camera_text(wt, ids[:ncs].cpu(), mask[:ncs].cpu(), types[:ncs].cpu(), 12, 12, cfg["head"])
+                S_o = O.multi_view_matching(img_o, cap_o)
+            else:
+                img_o = O.saem_image(wi, feats[:ns].cpu(), 4)
+                cap_o = O.saem_text(wt, cfg["txt_stru"], ids[:ncs].cpu(), mask[:ncs].cpu(), types[:ncs].cpu(), 12, 12, 4)
+                S_o = O.pdist_cos(img_o, cap_o)
+            O.rank_counts(S_o.numpy())
+            dtc = time.time() - t0
+        out["cpu_baseline"] = dict(value=ns * ncs / dtc, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                                   sample="first %d images x %d captions of the same synthetic workload: encode+score+rank in %.1f s" % (ns, ncs, dtc),
+                                   max_abs_diff_vs_gpu=float((S[:ns, :ncs].cpu() - S_o).abs().max()))
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out), flush=True)
 
 
