@@ -393,46 +393,50 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
             }
         }
         __syncthreads();
-        // E2: one lane per region row, loop over the captions of the tile.  The attention
-        // weights overwrite the raw block row segment once the numerator has been taken.
+        // E2: one lane per region row, loop over the captions of the tile.  Per caption: the caption Gram H_c (W x W)
+        // is pulled into the part of the staging area that the parked block does not cover (19 KB free behind arawt),
+        // the un-normalised attention weights e = exp(ls b - max) overwrite the raw block row segment, and
+        //   num = sum e a / den,   ||ctx_r||^2 = e^T H_c e / den^2.
+        // The per-element code is specialised on the norm mode at compile time (see dispatch_norm).
+        float *hbuf = reinterpret_cast<float *>(smem_raw + sizeof(sm.arawt));
+        static_assert(sizeof(sm.arawt) + SC_NT * SC_NT * 4 <= sizeof(sm.stage), "caption Gram fits behind the parked block");
         for (int k = 0; k < ncap; ++k) {
             const int c0 = sm.meta.cap_start[k], c1 = sm.meta.cap_start[k + 1];
+            const int W = c1 - c0;
+            {
+                const float *H = g.cgram + g.cgram_off[sm.meta.cap_id[k]];
+                for (int idx = tid; idx < W * W; idx += SC_THREADS) hbuf[idx] = H[idx];
+            }
+            __syncthreads();
             if (tid < SC_MT) {
                 const int ii = tid / SC_R;
                 const int64_t img = img0 + ii;
-                float mx = -INFINITY;
-                for (int c = c0; c < c1; ++c) {
-                    const float b = norm_apply(AT(tid, c), norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
-                    mx = fmaxf(mx, b * ls);
-                }
-                float den = 0.f;
-                for (int c = c0; c < c1; ++c) {
-                    const float b = norm_apply(AT(tid, c), norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
-                    den += expf(b * ls - mx);
-                }
-                float num = 0.f;
-                for (int c = c0; c < c1; ++c) {
-                    const float a = AT(tid, c);
-                    const float b = norm_apply(a, norm, sm.colstat[ii][c][0], sm.colstat[ii][c][1]);
-                    const float pw = expf(b * ls - mx) / den;
-                    num += pw * a;
-                    AT(tid, c) = pw;  // own row, own caption segment: no other reader left
-                }
-                // ||ctx_r||^2 = p^T H_c p with the caption Gram H_c (uniform across lanes)
-                const int W = c1 - c0;
-                const float *H = g.cgram + g.cgram_off[sm.meta.cap_id[k]];
+                float mx = -INFINITY, den = 0.f, num = 0.f;
+                dispatch_norm(norm, [&](auto NC) {
+                    constexpr int NORM = decltype(NC)::value;
+                    for (int c = c0; c < c1; ++c)
+                        mx = fmaxf(mx, norm_apply_c<NORM>(AT(tid, c), sm.colstat[ii][c][0], sm.colstat[ii][c][1]) * ls);
+                    for (int c = c0; c < c1; ++c) {
+                        const float a = AT(tid, c);
+                        const float e = expf(norm_apply_c<NORM>(a, sm.colstat[ii][c][0], sm.colstat[ii][c][1]) * ls - mx);
+                        den += e;
+                        num += e * a;
+                        AT(tid, c) = e;  // own row, own caption segment: no other reader left
+                    }
+                });
                 float q = 0.f;
                 for (int u = 0; u < W; ++u) {
                     float t = 0.f;
-                    for (int v = 0; v < W; ++v) t += H[u * W + v] * AT(tid, c0 + v);
+                    for (int v = 0; v < W; ++v) t += hbuf[u * W + v] * AT(tid, c0 + v);
                     q += AT(tid, c0 + u) * t;
                 }
+                const float rden = 1.f / den;
                 const float w1 = img < g.Ni ? g.vnorm[img * SC_R + tid % SC_R] : 0.f;
-                const float w2 = sqrtf(fmaxf(q, 0.f));
-                sm.rsim2[tid][k] = num / fmaxf(w1 * w2, 1e-8f);
+                const float w2 = sqrtf(fmaxf(q, 0.f)) * rden;
+                sm.rsim2[tid][k] = (num * rden) / fmaxf(w1 * w2, 1e-8f);
             }
+            __syncthreads();   // hbuf is reloaded for the next caption
         }
-        __syncthreads();
         // E3: aggregate over the 36 regions
         if (tid < SC_IMGS * SC_MAXCAP) {
             const int ii = tid / SC_MAXCAP, k = tid % SC_MAXCAP;
