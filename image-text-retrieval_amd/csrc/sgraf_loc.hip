@@ -118,12 +118,15 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
     __syncthreads();
 
     const int fi = lane & 31, fg = lane >> 5;
+    // Branch-free K loop (one basic block per slice, so that the scheduler may overlap the phases): the tail iteration
+    // re-produces the last slice into the idle buffer.  Issue order requested from the scheduler: the global loads of
+    // the next slice go out first, one per stage-2 MFMA; then the fragment reads; the stage-1 MFMAs, the squared
+    // difference and the LDS stores of the next slice close the iteration.
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk) {
-            LOC_GLOAD_W(kc + 1)
-            LOC_LOAD_VZ(kc + 1)
-        }
+        const int kn = kc + 1 < nk ? kc + 1 : nk - 1;
+        LOC_GLOAD_W(kn)
+        LOC_LOAD_VZ(kn)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int p = 2 * q + fg;
@@ -135,18 +138,35 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
-        if (kc + 1 < nk) {
-            LOC_STAGE1(buf ^ 1)
-            LOC_LSTORE_W(buf ^ 1)
-            __syncthreads();
+        LOC_STAGE1(buf ^ 1)
+        LOC_LSTORE_W(buf ^ 1)
+#pragma unroll
+        for (int i_ = 0; i_ < 4; ++i_) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // first fragment reads
+#pragma unroll
+        for (int i_ = 0; i_ < 34; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 // VMEM read
         }
+#pragma unroll
+        for (int i_ = 0; i_ < 12; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 // DS read
+        }
+        __syncthreads();
     }
 
 #undef LOC_LOAD_VZ
