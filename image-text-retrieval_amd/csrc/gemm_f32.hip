@@ -38,6 +38,8 @@ struct GemmArgs {
     const float *Z;
     int64_t ldz;
     int accumulate;   // C = act(C + A*B^T + bias): sums the taps of a dilated Conv1d (camera_.py:100-103)
+    int64_t ksplit;   // > 0: blockIdx.y owns K range [y * ksplit, (y + 1) * ksplit) and writes the raw partial product to
+    float *part;      //      part + y * M * N  (row-major [M, N]); bias / activation are applied by the reduction kernel
 };
 
 template <bool ALIGNED>
@@ -291,6 +293,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
     const int64_t tm = bid % tiles_m, tn = bid / tiles_m;
     const int64_t m0 = tm * g.rows_per_tile, n0 = tn * BN;
     const int64_t m_end = (m0 + g.rows_per_tile < g.M) ? m0 + g.rows_per_tile : g.M;
+    if (g.ksplit > 0) {   // split-K slice of a skinny GEMM: shift the operands, shorten K, redirect the output
+        const int64_t koff = (int64_t)blockIdx.y * g.ksplit;
+        g.A += koff;
+        g.B += koff;
+        g.K = (g.K - koff < g.ksplit) ? g.K - koff : g.ksplit;
+        g.C = g.part + (int64_t)blockIdx.y * g.M * g.N;
+        g.ldc = g.N;
+        g.bias = nullptr;
+        g.act = 0;
+        g.accumulate = 0;
+    }
 
     const int ld_row = tid >> 3;  // 0..31
     const int ld_p = tid & 7;     // plane
@@ -384,27 +397,78 @@ static int launch_gemm(const GemmArgs &g, hipStream_t st) {
     return ITR_OK;
 }
 
+
+// ---- skinny GEMMs (the GRU recurrence of a training batch: M = 128 rows gives 24 tiles for 256 CUs) ------------------
+// The K range is cut into `splits` slices (grid.y), each slice writes its raw partial tile to the caller's scratch and a
+// second kernel adds the slices in a fixed order, the bias, the old C (accumulate) and the activation: deterministic.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, int splits, int64_t M, int64_t N,
+                                                            const float *__restrict__ bias, float *__restrict__ C, int64_t ldc, int act,
+                                                            int accumulate) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * N) return;
+    const int64_t m = idx / N, n = idx % N;
+    float v = accumulate ? C[m * ldc + n] : 0.f;
+    for (int s_ = 0; s_ < splits; ++s_) v += part[(int64_t)s_ * M * N + idx];
+    if (bias) v += bias[n];
+    C[m * ldc + n] = apply_act(v, act);
+}
+
+size_t gemm_splitk_scratch_bytes(int64_t M, int64_t N, int splits) { return (size_t)splits * (size_t)M * (size_t)N * 4; }
+
+// Picks the number of K slices so that the launch has >= ~256 workgroups; 1 = not worth it.
+int gemm_splitk_choice(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
+    if (tiles >= 128 || K < 256) return 1;
+    int s_ = (int)(256 / tiles);
+    while (s_ > 1 && K / s_ < 128) --s_;
+    return s_ < 1 ? 1 : (s_ > 16 ? 16 : s_);
+}
+
+int gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N,
+                   int64_t K, int act, int accumulate, int splits, float *scratch, hipStream_t st) {
+    if (M == 0 || N == 0) return ITR_OK;
+    if (splits <= 1) {
+        GemmArgs g1{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, accumulate, 0, nullptr};
+        return launch_gemm(g1, st);
+    }
+    const int64_t ksplit = ceil_div(ceil_div(K, (int64_t)splits), (int64_t)BK) * BK;       // slices start on chunk boundaries
+    const int ns = (int)ceil_div(K, ksplit);
+    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, M, N, K, 0, 1, BM, nullptr, nullptr, 0, 0, ksplit, scratch};
+    const int64_t nblk = ceil_div(M, BM) * ceil_div(N, BN);
+    const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    if (aligned)
+        hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)nblk, (unsigned)ns), dim3(GEMM_THREADS), 0, st, g);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3((unsigned)nblk, (unsigned)ns), dim3(GEMM_THREADS), 0, st, g);
+    ITR_CHECK_LAUNCH("gemm_nt(split-K)");
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(M * N, 256)), dim3(256), 0, st, scratch, ns, M, N, bias, C, ldc, act,
+                       accumulate);
+    ITR_CHECK_LAUNCH("splitk_reduce");
+    return ITR_OK;
+}
+
 int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
-    GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, 0};
+    GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, 0, 0, nullptr};
     return launch_gemm(g, st);
 }
 
 int gemm_nt_acc(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc,
                 int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
-    GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, 1};
+    GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, 1, 0, nullptr};
     return launch_gemm(g, st);
 }
 
 int gemm_nt_sqdiff(const float *A, int64_t lda, const float *B, int64_t ldb, const float *rowscale, const float *Z,
                    int64_t ldz, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t st) {
-    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, M, N, K, 0, 1, BM, rowscale, Z, ldz, 0};
+    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, M, N, K, 0, 1, BM, rowscale, Z, ldz, 0, 0, nullptr};
     return launch_gemm(g, st);
 }
 
 int gemm_nt_groupmax(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                      int64_t Mgroups, int group, int64_t N, int64_t K, hipStream_t st) {
-    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, Mgroups * group, N, K, 0, group, (BM / group) * group, nullptr, nullptr, 0, 0};
+    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, Mgroups * group, N, K, 0, group, (BM / group) * group, nullptr, nullptr, 0, 0, 0, nullptr};
     return launch_gemm(g, st);
 }
 

@@ -23,6 +23,11 @@ int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const floa
             int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
 int gemm_nt_acc(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc,
                 int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
+// skinny GEMMs of the recurrence (M = batch): split-K with a deterministic reduction (gemm_f32.hip)
+int gemm_splitk_choice(int64_t M, int64_t N, int64_t K);
+size_t gemm_splitk_scratch_bytes(int64_t M, int64_t N, int splits);
+int gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N,
+                   int64_t K, int act, int accumulate, int splits, float *scratch, hipStream_t st);
 
 __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
 
@@ -148,6 +153,7 @@ extern "C" size_t itr_gru_train_workspace_bytes(int64_t n_tok, int64_t B, int E,
     size_t b = al256(nt * E * 4) + 2 * al256(nt * d3 * 4) + al256(nt * D * 4) + al256((size_t)B * D * 4) + al256((size_t)B * d3 * 4) +
                al256(nt * E * 4) + al256(d3 * nt * 4) + al256((size_t)(E > D ? E : D) * nt * 4) + al256(d3 * D * 4) + al256(d3 * E * 4) +
                al256(((size_t)ceil_div(n_tok > 0 ? n_tok : 1, 256)) * d3 * 4) + 512;
+    b += al256(gemm_splitk_scratch_bytes(B, 3 * D, 16));      // split-K partials of the per-step GEMMs
     return b;
 }
 
@@ -172,6 +178,10 @@ extern "C" int itr_gru_fwd_train(const int64_t *tokens, const int64_t *tok_off, 
     float *gh = (float *)p; p += al256((size_t)n_tok * 3 * D * 4);   // only [B, 3D] used
     float *h = (float *)p; p += al256((size_t)n_tok * D * 4);        // only [B, D] used
     int *bad = (int *)p;
+    // the split-K scratch is the LAST region of the (shared forward / backward) workspace layout
+    float *skbuf = reinterpret_cast<float *>(static_cast<char *>(workspace) + itr_gru_train_workspace_bytes(n_tok, B, E, D) -
+                                             al256(gemm_splitk_scratch_bytes(B, 3 * D, 16)));
+    const int splits_h = gemm_splitk_choice(B, 3 * D, D);
     const int Lmax = len_host[0];
     ITR_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
     hipLaunchKernelGGL(embed_gather_train_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, x, bad);
@@ -186,7 +196,7 @@ extern "C" int itr_gru_fwd_train(const int64_t *tokens, const int64_t *tok_off, 
         int64_t n_act = B;
         for (int t = 0; t < Lmax; ++t) {
             while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
-            rc = gemm_nt(h, D, wh, D, bh, gh, 3 * D, n_act, 3 * D, D, 0, st);
+            rc = gemm_nt_splitk(h, D, wh, D, bh, gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, skbuf, st);
             if (rc != ITR_OK) return rc;
             hipLaunchKernelGGL(gru_gate_train_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, gi, gh, h, out, sv,
                                tok_off, len_dev, t, dir, dir, D, n_act);
@@ -225,6 +235,9 @@ extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const 
     float *wihT = (float *)p; p += al256(d3 * E * 4);
     float *cs = (float *)p; p += al256(((size_t)ceil_div(n_tok, 256)) * d3 * 4);
     int *bad = (int *)p;
+    float *skbuf = reinterpret_cast<float *>(static_cast<char *>(workspace) + itr_gru_train_workspace_bytes(n_tok, B, E, D) -
+                                             al256(gemm_splitk_scratch_bytes(B, 3 * D, 16)));
+    const int splits_c = gemm_splitk_choice(B, D, 3 * D);
     const int Lmax = len_host[0];
     const int64_t nparts = ceil_div(n_tok, 256);
     ITR_UNSUPPORTED(nparts > 65535, "itr_gru_bwd: more than 16M tokens");
@@ -247,7 +260,7 @@ extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const 
             hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, d_out, bi ? 0.5f : 1.f,
                                sv, carry, dgi, dgh, dgh_step, hprev, tok_off, len_dev, t, dir, D, n_act);
             ITR_CHECK_LAUNCH("gru_gate_bwd");
-            if (t > 0) GB_TRY(gemm_nt_acc(dgh_step, 3 * D, whhT, 3 * D, nullptr, carry, D, n_act, D, 3 * D, 0, st));
+            if (t > 0) GB_TRY(gemm_nt_splitk(dgh_step, 3 * D, whhT, 3 * D, nullptr, carry, D, n_act, D, 3 * D, 0, 1, splits_c, skbuf, st));
         }
         // weight gradients over all tokens
         GB_TRY(transpose(dgh, gT, n_tok, 3 * D, st));
