@@ -393,49 +393,145 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
             }
         }
         __syncthreads();
-        // E2: one lane per region row, loop over the captions of the tile.  Per caption: the caption Gram H_c (W x W)
-        // is pulled into the part of the staging area that the parked block does not cover (19 KB free behind arawt),
-        // the un-normalised attention weights e = exp(ls b - max) overwrite the raw block row segment, and
-        //   num = sum e a / den,   ||ctx_r||^2 = e^T H_c e / den^2.
-        // The per-element code is specialised on the norm mode at compile time (see dispatch_norm).
-        float *hbuf = reinterpret_cast<float *>(smem_raw + sizeof(sm.arawt));
+        float *hbuf = reinterpret_cast<float *>(smem_raw + sizeof(sm.arawt));     // 19 KB of the staging area behind the parked block
         static_assert(sizeof(sm.arawt) + SC_NT * SC_NT * 4 <= sizeof(sm.stage), "caption Gram fits behind the parked block");
-        for (int k = 0; k < ncap; ++k) {
-            const int c0 = sm.meta.cap_start[k], c1 = sm.meta.cap_start[k + 1];
-            const int W = c1 - c0;
-            {
+        const float *rsim = &sm.rsim2[0][0];
+        // Matrix-core path: every first norm that bounds |b| <= 1 (no max shift needed for exp(ls b), ls <= 60).
+        const bool mfma_path = (norm == 0 || norm == 1 || norm == 2 || norm == 5 || norm == 6) && fabsf(ls) <= 60.f;
+        if (mfma_path) {
+            // P0: block-diagonal Gram of the tile's captions, Hblk[v][w] = e_v . e_w for v, w in the same caption
+            for (int idx = tid; idx < SC_NT * SC_NT; idx += SC_THREADS) hbuf[idx] = 0.f;
+            __syncthreads();
+            for (int k = 0; k < ncap; ++k) {
+                const int c0 = sm.meta.cap_start[k], W = sm.meta.cap_start[k + 1] - c0;
                 const float *H = g.cgram + g.cgram_off[sm.meta.cap_id[k]];
-                for (int idx = tid; idx < W * W; idx += SC_THREADS) hbuf[idx] = H[idx];
+                for (int idx = tid; idx < W * W; idx += SC_THREADS) {
+                    const int u = idx / W, v = idx - u * W;
+                    hbuf[(c0 + u) * SC_NT + c0 + v] = H[idx];
+                }
+            }
+            float ind[16];   // indicator fragment: [word 16u + 4fg + j belongs to caption slot fi]
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ind[4 * u + j] = (sm.meta.col_cap[16 * u + 4 * fg + j] == fi) ? 1.f : 0.f;
+            // P1: e = exp(ls b) in place; den[row][k] = sum_{w in k} e, num[row][k] = sum e a as indicator products
+            dispatch_norm(norm, [&](auto NC) {
+                constexpr int NORM = decltype(NC)::value;
+                for (int mt = wave; mt < SC_MTILES; mt += 4) {
+                    const int row = mt * 16 + fi;
+                    const int ii = row / SC_R;
+                    f32x4 sden = f32x4{0.f, 0.f, 0.f, 0.f}, snum = sden;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int w = 16 * u + 4 * fg + j;
+                            const float av = AT(row, w);
+                            const float e = fast_exp(norm_apply_c<NORM>(av, sm.colstat[ii][w][0], sm.colstat[ii][w][1]) * ls);
+                            AT(row, w) = e;
+                            sden = __builtin_amdgcn_mfma_f32_16x16x4f32(e, ind[4 * u + j], sden, 0, 0, 0);
+                            snum = __builtin_amdgcn_mfma_f32_16x16x4f32(e * av, ind[4 * u + j], snum, 0, 0, 0);
+                        }
+                    *reinterpret_cast<f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]) = sden;     // [caption slot fi][rows 4fg..]
+                    *reinterpret_cast<f32x4 *>(&sm.stat[1][fi][mt * 16 + 4 * fg]) = snum;
+                }
+            });
+            __syncthreads();
+            // P3: T = E Hblk (64 MFMAs per row tile), then E o T in place: arawt[w][row] <- e[row][w] * T[row][w]
+            {
+                float hf[4][16];     // B fragments of Hblk, shared by every row tile of this wave
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) hf[nt][q] = hbuf[(4 * q + fg) * SC_NT + nt * 16 + fi];
+                for (int mt = wave; mt < SC_MTILES; mt += 4) {
+                    float ea[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) ea[q] = AT(mt * 16 + fi, 4 * q + fg);
+                    f32x4 tacc[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) tacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) tacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[q], hf[nt][q], tacc[nt], 0, 0, 0);
+                    // tacc[nt][j] = T[mt*16 + 4fg + j][nt*16 + fi]; the A fragments above were this wave's own rows only
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        f32x4 *ep = reinterpret_cast<f32x4 *>(&sm.arawt[nt * 16 + fi][mt * 16 + 4 * fg]);
+                        const f32x4 ev = *ep;
+                        *ep = f32x4{ev[0] * tacc[nt][0], ev[1] * tacc[nt][1], ev[2] * tacc[nt][2], ev[3] * tacc[nt][3]};
+                    }
+                }
             }
             __syncthreads();
-            if (tid < SC_MT) {
-                const int ii = tid / SC_R;
-                const int64_t img = img0 + ii;
-                float mx = -INFINITY, den = 0.f, num = 0.f;
-                dispatch_norm(norm, [&](auto NC) {
-                    constexpr int NORM = decltype(NC)::value;
-                    for (int c = c0; c < c1; ++c)
-                        mx = fmaxf(mx, norm_apply_c<NORM>(AT(tid, c), sm.colstat[ii][c][0], sm.colstat[ii][c][1]) * ls);
-                    for (int c = c0; c < c1; ++c) {
-                        const float a = AT(tid, c);
-                        const float e = expf(norm_apply_c<NORM>(a, sm.colstat[ii][c][0], sm.colstat[ii][c][1]) * ls - mx);
-                        den += e;
-                        num += e * a;
-                        AT(tid, c) = e;  // own row, own caption segment: no other reader left
-                    }
-                });
-                float q = 0.f;
-                for (int u = 0; u < W; ++u) {
-                    float t = 0.f;
-                    for (int v = 0; v < W; ++v) t += hbuf[u * W + v] * AT(tid, c0 + v);
-                    q += AT(tid, c0 + u) * t;
+            // P4: q[row][k] = sum_{w in k} (E o T) (indicator product), then the cosine term of every (region row, caption)
+            float *rs_out = hbuf;       // Hblk is dead: [144][16] similarity terms for the aggregation below
+            for (int mt = wave; mt < SC_MTILES; mt += 4) {
+                f32x4 sq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        sq = __builtin_amdgcn_mfma_f32_16x16x4f32(AT(mt * 16 + fi, 16 * u + 4 * fg + j), ind[4 * u + j], sq, 0, 0, 0);
+                const f32x4 dn = *reinterpret_cast<const f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]);
+                const f32x4 nm = *reinterpret_cast<const f32x4 *>(&sm.stat[1][fi][mt * 16 + 4 * fg]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = mt * 16 + 4 * fg + j;
+                    const int64_t img = img0 + row / SC_R;
+                    const float w1 = img < g.Ni ? g.vnorm[img * SC_R + row % SC_R] : 0.f;
+                    const float rden = dn[j] > 0.f ? 1.f / dn[j] : 0.f;     // caption slots >= ncap: never read
+                    const float w2 = sqrtf(fmaxf(sq[j], 0.f)) * rden;
+                    rs_out[row * SC_MAXCAP + fi] = (nm[j] * rden) / fmaxf(w1 * w2, 1e-8f);
                 }
-                const float rden = 1.f / den;
-                const float w1 = img < g.Ni ? g.vnorm[img * SC_R + tid % SC_R] : 0.f;
-                const float w2 = sqrtf(fmaxf(q, 0.f)) * rden;
-                sm.rsim2[tid][k] = (num * rden) / fmaxf(w1 * w2, 1e-8f);
             }
-            __syncthreads();   // hbuf is reloaded for the next caption
+            rsim = rs_out;
+            __syncthreads();
+        } else {
+            // E2: one lane per region row, loop over the captions of the tile.  Per caption: the caption Gram H_c (W x W)
+            // is pulled into the part of the staging area that the parked block does not cover (19 KB free behind arawt),
+            // the un-normalised attention weights e = exp(ls b - max) overwrite the raw block row segment, and
+            //   num = sum e a / den,   ||ctx_r||^2 = e^T H_c e / den^2.
+            // The per-element code is specialised on the norm mode at compile time (see dispatch_norm).
+            for (int k = 0; k < ncap; ++k) {
+                const int c0 = sm.meta.cap_start[k], c1 = sm.meta.cap_start[k + 1];
+                const int W = c1 - c0;
+                {
+                    const float *H = g.cgram + g.cgram_off[sm.meta.cap_id[k]];
+                    for (int idx = tid; idx < W * W; idx += SC_THREADS) hbuf[idx] = H[idx];
+                }
+                __syncthreads();
+                if (tid < SC_MT) {
+                    const int ii = tid / SC_R;
+                    const int64_t img = img0 + ii;
+                    float mx = -INFINITY, den = 0.f, num = 0.f;
+                    dispatch_norm(norm, [&](auto NC) {
+                        constexpr int NORM = decltype(NC)::value;
+                        for (int c = c0; c < c1; ++c)
+                            mx = fmaxf(mx, norm_apply_c<NORM>(AT(tid, c), sm.colstat[ii][c][0], sm.colstat[ii][c][1]) * ls);
+                        for (int c = c0; c < c1; ++c) {
+                            const float a = AT(tid, c);
+                            const float e = expf(norm_apply_c<NORM>(a, sm.colstat[ii][c][0], sm.colstat[ii][c][1]) * ls - mx);
+                            den += e;
+                            num += e * a;
+                            AT(tid, c) = e;  // own row, own caption segment: no other reader left
+                        }
+                    });
+                    float q = 0.f;
+                    for (int u = 0; u < W; ++u) {
+                        float t = 0.f;
+                        for (int v = 0; v < W; ++v) t += hbuf[u * W + v] * AT(tid, c0 + v);
+                        q += AT(tid, c0 + u) * t;
+                    }
+                    const float rden = 1.f / den;
+                    const float w1 = img < g.Ni ? g.vnorm[img * SC_R + tid % SC_R] : 0.f;
+                    const float w2 = sqrtf(fmaxf(q, 0.f)) * rden;
+                    sm.rsim2[tid][k] = (num * rden) / fmaxf(w1 * w2, 1e-8f);
+                }
+                __syncthreads();   // hbuf is reloaded for the next caption
+            }
         }
         // E3: aggregate over the 36 regions
         if (tid < SC_IMGS * SC_MAXCAP) {
@@ -445,14 +541,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                 float r;
                 if (g.agg == 0) {
                     r = 0.f;
-                    for (int t = 0; t < SC_R; ++t) r += expf(sm.rsim2[ii * SC_R + t][k] * g.lambda_lse);
+                    for (int t = 0; t < SC_R; ++t) r += expf(rsim[(ii * SC_R + t) * SC_MAXCAP + k] * g.lambda_lse);
                     r = logf(r) / g.lambda_lse;
                 } else if (g.agg == 1) {
                     r = -INFINITY;
-                    for (int t = 0; t < SC_R; ++t) r = fmaxf(r, sm.rsim2[ii * SC_R + t][k]);
+                    for (int t = 0; t < SC_R; ++t) r = fmaxf(r, rsim[(ii * SC_R + t) * SC_MAXCAP + k]);
                 } else {
                     r = 0.f;
-                    for (int t = 0; t < SC_R; ++t) r += sm.rsim2[ii * SC_R + t][k];
+                    for (int t = 0; t < SC_R; ++t) r += rsim[(ii * SC_R + t) * SC_MAXCAP + k];
                     if (g.agg == 3) r /= (float)SC_R;
                 }
                 g.S[img * g.ldS + sm.meta.cap_id[k]] = r;
