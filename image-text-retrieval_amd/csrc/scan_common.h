@@ -29,6 +29,12 @@ __device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.1f * v); }  
 // exp via v_exp_f32 (2^x): 2 VALU instructions instead of ~12; relative error ~|x| * 1e-7, far inside the
 // parity budget for the softmax / LogSumExp arguments here (|x| <= ~10).
 __device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+// single-instruction log / sqrt / reciprocal (v_log_f32, v_sqrt_f32, v_rcp_f32: 1 ulp) for the epilogue, where every
+// instruction of the wave waits for a slot next to the other workgroup's MFMA stream; the libm forms expand to 10-20
+// instructions each.  Relative error ~1e-7, far inside the 2e-5 parity budget of the scores.
+__device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.693147180559945309f; }
+__device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 
 #define SC_TICK(slot)                                                                              \
     if (g.dbg_cycles && tid == 0) {                                                                \

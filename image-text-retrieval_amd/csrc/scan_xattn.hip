@@ -217,7 +217,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                         }
                     f32x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = 1.f / ((NORM <= 1 ? sqrtf(sacc[j]) : sacc[j]) + 1e-8f);
+                    for (int j = 0; j < 4; ++j) o[j] = fast_rcp((NORM <= 1 ? fast_sqrt(sacc[j]) : sacc[j]) + 1e-8f);
                     if (fi < SC_MAXCAP) *reinterpret_cast<f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]) = o;   // caption slot fi
                 }
             });
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
 #pragma unroll
                 for (int r4 = 0; r4 < SC_R / 4; ++r4)
                     *reinterpret_cast<f32x4 *>(colp + 4 * r4) = f32x4{e[4 * r4], e[4 * r4 + 1], e[4 * r4 + 2], e[4 * r4 + 3]};
-                const float rden = 1.f / den;
+                const float rden = fast_rcp(den);
                 SC_TICK(5)   // E2a: weights
                 // T = G E.  B operand (k = region r2, n = word): lane (fi, fg) feeds E[16u + 4fg + j][nt*16 + fi].
                 // Only this wave touches rows ii*36 .. +35, and LDS operations of one wave are ordered.
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                     g.emit_cn[orow] = 1.f / (sqrtf(fmaxf(q, 0.f)) + 1e-8f);
                 }
                 const float w1 = wnorm_pre;
-                const float w2 = sqrtf(fmaxf(q, 0.f));
-                simv = num / fmaxf(w1 * w2, 1e-8f);   // cosine_similarity, Objectives.py:10-15
+                const float w2 = fast_sqrt(fmaxf(q, 0.f));
+                simv = num * fast_rcp(fmaxf(w1 * w2, 1e-8f));   // cosine_similarity, Objectives.py:10-15
             }
             sm.rowsim[ii][w] = simv;
         }
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                 float r;
                 if (g.agg == 0) {
                     r = 0.f;
-                    for (int c = c0; c < c1; ++c) r += expf(sm.rowsim[ii][c] * g.lambda_lse);
-                    r = logf(r) / g.lambda_lse;
+                    for (int c = c0; c < c1; ++c) r += fast_exp(sm.rowsim[ii][c] * g.lambda_lse);
+                    r = fast_log(r) / g.lambda_lse;
                 } else if (g.agg == 1) {
                     r = -INFINITY;
                     for (int c = c0; c < c1; ++c) r = fmaxf(r, sm.rowsim[ii][c]);
@@ -482,9 +482,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                     const int row = mt * 16 + 4 * fg + j;
                     const int64_t img = img0 + row / SC_R;
                     const float w1 = img < g.Ni ? g.vnorm[img * SC_R + row % SC_R] : 0.f;
-                    const float rden = dn[j] > 0.f ? 1.f / dn[j] : 0.f;     // caption slots >= ncap: never read
-                    const float w2 = sqrtf(fmaxf(sq[j], 0.f)) * rden;
-                    rs_out[row * SC_MAXCAP + fi] = (nm[j] * rden) / fmaxf(w1 * w2, 1e-8f);
+                    const float rden = dn[j] > 0.f ? fast_rcp(dn[j]) : 0.f;     // caption slots >= ncap: never read
+                    const float w2 = fast_sqrt(fmaxf(sq[j], 0.f)) * rden;
+                    rs_out[row * SC_MAXCAP + fi] = (nm[j] * rden) * fast_rcp(fmaxf(w1 * w2, 1e-8f));
                 }
             }
             rsim = rs_out;
@@ -541,8 +541,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                 float r;
                 if (g.agg == 0) {
                     r = 0.f;
-                    for (int t = 0; t < SC_R; ++t) r += expf(rsim[(ii * SC_R + t) * SC_MAXCAP + k] * g.lambda_lse);
-                    r = logf(r) / g.lambda_lse;
+                    for (int t = 0; t < SC_R; ++t) r += fast_exp(rsim[(ii * SC_R + t) * SC_MAXCAP + k] * g.lambda_lse);
+                    r = fast_log(r) / g.lambda_lse;
                 } else if (g.agg == 1) {
                     r = -INFINITY;
                     for (int t = 0; t < SC_R; ++t) r = fmaxf(r, rsim[(ii * SC_R + t) * SC_MAXCAP + k]);
