@@ -74,19 +74,23 @@ def build_config(argv):
 
 
 def config_hook(cfg, make_dirs=False):
-    """config.py:381-414: seed, name normalisation, save_dir, BERT file names, device selection."""
+    """config.py:381-414: seed, name normalisation, `<save_path>/<name>/<dataset>_<seed>_<timestamp>` run directory,
+    BERT file names, `hparams.yaml` (written when the directory is made)."""
     cfg = dict(cfg)
     if cfg['seed'] is None:
-        cfg['seed'] = random.randint(1, 100000)
+        cfg['seed'] = random.randint(0, 10000)
     display = 'VSE_PP' if cfg['name'] == 'VSE++' else cfg['name']   # the reference renames the model itself; get_model here accepts both
-    tail = ('_' + cfg['tail']) if cfg['tail'] else ''
-    cfg['save_dir'] = os.path.join(cfg['save_path'], display,
-                                   "%s_%s_%s%s" % (cfg['data_name'], cfg['seed'], time.strftime("%m%d%H%M"), tail))
+    stamp = '_'.join([cfg['data_name'].split('_')[0], str(cfg['seed']), time.strftime('%Y-%m-%d-%H-%M-%S', time.localtime())])
+    # the reference creates `<dir><tail>` but records `<dir>` (and then fails to write hparams.yaml); the tail is kept here
+    cfg['save_dir'] = os.path.join(cfg['save_path'], display, stamp + (cfg['tail'] if cfg['tail'] else ''))
     if cfg['text_encoder'] == 'bert':
         cfg['vocab_file'] = os.path.join(cfg['bert_path'], 'vocab.txt')
         cfg['bert_config_file'] = os.path.join(cfg['bert_path'], 'bert_config.json')
         cfg['init_checkpoint'] = os.path.join(cfg['bert_path'], 'pytorch_model.bin')
     if make_dirs:
+        import yaml
         os.makedirs(cfg['save_dir'], exist_ok=True)
+        with open(os.path.join(cfg['save_dir'], 'hparams.yaml'), 'w') as yaml_file:
+            yaml.safe_dump({k: v for k, v in cfg.items() if isinstance(v, (str, int, float, bool, type(None), list, dict))}, yaml_file)
     # one process per GPU: the device comes from LOCAL_RANK, `cuda` is kept for compatibility only
     return cfg

@@ -43,4 +43,4 @@ def train(_config):
 
 
 if __name__ == "__main__":
-    train(cfgmod.build_config(sys.argv[1:]))
+    train(cfgmod.config_hook(cfgmod.build_config(sys.argv[1:]), make_dirs=True))     # run directory + hparams.yaml

@@ -12,7 +12,18 @@ def test_defaults_and_named_layering():
     assert cfg['img_dim'] == 2048 and cfg['no_txtnorm'] is True and cfg['embed_size'] == 1024
     assert cfg['margin'] == 0.2 and cfg['word_dim'] == 300 and cfg['batch_size'] == 128
     assert cfg['lambda_lse'] == 6 and cfg['lambda_softmax'] == 9
-    assert 'coco_precomp_0_' in cfg['save_dir'] and '/SCAN/' in cfg['save_dir']
+    # <save_path>/<name>/<dataset>_<seed>_<%Y-%m-%d-%H-%M-%S> like the reference's hook (config.py:391-393)
+    import re
+    assert re.search(r'/SCAN/coco_0_\d{4}-\d{2}-\d{2}-\d{2}-\d{2}-\d{2}$', cfg['save_dir'])
+
+
+def test_hook_writes_hparams(tmp_path):
+    import yaml
+    cfg = C.build_config(['with', 'SCAN', 'save_path=%s' % tmp_path, 'tail=_x', 'seed=7'])
+    cfg = C.config_hook(cfg, make_dirs=True)
+    assert cfg['save_dir'].endswith('_x')
+    hp = yaml.safe_load(open(cfg['save_dir'] + '/hparams.yaml'))
+    assert hp['name'] == 'SCAN' and hp['seed'] == 7 and hp['learning_rate'] == cfg['learning_rate']
 
 
 def test_other_named_configs():
