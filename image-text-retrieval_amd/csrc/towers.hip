@@ -17,8 +17,10 @@ int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const floa
 int norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, int kind, int take_abs,
               hipStream_t st);
 
+// x rows are padded with zeros to Ep = E rounded up to 32 columns (300 -> 320) so that the input projection runs on
+// the branch-free GEMM path (K % 32 == 0); the matching zero-padded copy of W_ih is made by pad_cols_kernel.
 __global__ void embed_gather_kernel(const int64_t *__restrict__ tokens, int64_t n_tok, const float *__restrict__ embed,
-                                    int64_t V, int E, float *__restrict__ x, int *__restrict__ bad) {
+                                    int64_t V, int E, int Ep, float *__restrict__ x, int *__restrict__ bad) {
     const int64_t row = blockIdx.x;
     int64_t id = tokens[row];
     if (id < 0 || id >= V) {  // nn.Embedding would raise IndexError: flag it, keep memory safe
@@ -26,8 +28,13 @@ __global__ void embed_gather_kernel(const int64_t *__restrict__ tokens, int64_t 
         id = 0;
     }
     const float *src = embed + id * E;
-    float *dst = x + row * E;
-    for (int k = threadIdx.x; k < E; k += blockDim.x) dst[k] = src[k];
+    float *dst = x + row * Ep;
+    for (int k = threadIdx.x; k < Ep; k += blockDim.x) dst[k] = k < E ? src[k] : 0.f;
+}
+
+__global__ void pad_cols_kernel(const float *__restrict__ in, int64_t rows, int cols, int cols_p, float *__restrict__ out) {
+    const int64_t r = blockIdx.x;
+    for (int k = threadIdx.x; k < cols_p; k += blockDim.x) out[r * cols_p + k] = k < cols ? in[r * cols + k] : 0.f;
 }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
@@ -67,18 +74,21 @@ __global__ void gather_last_kernel(const float *__restrict__ out, const int64_t 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GruWs {
-    float *x, *gi, *gh, *h, *out_tmp;
+    float *x, *gi, *gh, *h, *out_tmp, *wpad;
     int *bad;
 };
+
+static inline int pad32(int E) { return (E + 31) / 32 * 32; }
 
 static GruWs carve(void *ws, int64_t n_tok, int64_t B, int E, int D) {
     char *p = static_cast<char *>(ws);
     GruWs w;
-    w.x = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * E * 4);
+    w.x = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * pad32(E) * 4);
     w.gi = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * 3 * D * 4);
     w.gh = reinterpret_cast<float *>(p); p += al256((size_t)B * 3 * D * 4);
     w.h = reinterpret_cast<float *>(p); p += al256((size_t)B * D * 4);
     w.out_tmp = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * D * 4);
+    w.wpad = reinterpret_cast<float *>(p); p += al256((size_t)3 * D * pad32(E) * 4);
     w.bad = reinterpret_cast<int *>(p);
     return w;
 }
@@ -104,8 +114,8 @@ extern "C" int itr_proj_l2norm(const float *x, const float *W, const float *b, f
 extern "C" size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional) {
     using itr::al256;
     (void)bidirectional;
-    return al256((size_t)n_tok * E * 4) + al256((size_t)n_tok * 3 * D * 4) + al256((size_t)B * 3 * D * 4) +
-           al256((size_t)B * D * 4) + al256((size_t)n_tok * D * 4) + 256;
+    return al256((size_t)n_tok * itr::pad32(E) * 4) + al256((size_t)n_tok * 3 * D * 4) + al256((size_t)B * 3 * D * 4) +
+           al256((size_t)B * D * 4) + al256((size_t)n_tok * D * 4) + al256((size_t)3 * D * itr::pad32(E) * 4) + 256;
 }
 
 extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev,
@@ -137,14 +147,21 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     const int Lmax = len_host[0];
 
     ITR_CHECK_HIP(hipMemsetAsync(w.bad, 0, sizeof(int), st));
-    hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, w.x,
+    const int Ep = pad32(E);
+    hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, Ep, w.x,
                        w.bad);
     ITR_CHECK_LAUNCH("embed_gather");
 
     for (int dir = 0; dir < (bi ? 2 : 1); ++dir) {
         const float *wi = dir ? w_ih_rev : w_ih, *wh = dir ? w_hh_rev : w_hh;
         const float *bi_ = dir ? b_ih_rev : b_ih, *bh = dir ? b_hh_rev : b_hh;
-        int rc = gemm_nt(w.x, E, wi, E, bi_, w.gi, 3 * D, n_tok, 3 * D, E, 0, st);
+        const float *wi_use = wi;
+        if (Ep != E) {   // zero-padded copy of W_ih: K = Ep is a multiple of 32 (zeros add nothing)
+            hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)(3 * D)), dim3(128), 0, st, wi, (int64_t)3 * D, E, Ep, w.wpad);
+            ITR_CHECK_LAUNCH("pad_cols");
+            wi_use = w.wpad;
+        }
+        int rc = gemm_nt(w.x, Ep, wi_use, Ep, bi_, w.gi, 3 * D, n_tok, 3 * D, Ep, 0, st);
         if (rc != ITR_OK) return rc;
         ITR_CHECK_HIP(hipMemsetAsync(w.h, 0, (size_t)B * D * 4, st));
         int64_t n_act = B;
