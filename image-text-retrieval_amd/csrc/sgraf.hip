@@ -1,16 +1,15 @@
 // SGRAF similarity: EncoderSimilarity.forward + VisualSA / TextSA / SCAN_attention / AttentionFiltration /
 // GraphReasoning (itr/modalmodule/Fusionmodule.py:373-664), eval mode (BatchNorm running statistics, no dropout).
 //
-// Round-1 structure ("v1": correct first, HBM round trips between stages, all heavy arithmetic on the fp32
-// matrix core).  Per block of IB images:
+// Structure (all heavy arithmetic on the fp32 matrix core), per block of 16 images (4 on the unfused path):
 //   1. SCAN kernel (scan_xattn.hip) in emit mode  -> attention weights P[i, word, 36] and 1/(||ctx||+eps)
 //      (SCAN_attention :632-664 is SCAN t2i with clipped_l2norm and smooth = 9)
-//   2. per image:  (P_i V_i * cn - E)^2          -> GEMM [words,36]x[36,D] with the squared-difference epilogue
-//   3. sim_loc = l2norm(W_loc (.) + b)            -> GEMM [IB*words, D] x [D, S] + row l2norm          (:427)
+//   2+3. sim_loc = l2norm(W_loc (l2norm(P V) - E)^2 + b)   fused, (ctx - E)^2 stays on chip: sgraf_loc.hip (:425-427)
+//        (sim_dim != 256: per image GEMM [words,36]x[36,D] with the squared-difference epilogue, GEMM [., D]x[D, S], l2norm)
 //   4. sim_glo = l2norm(W_glo (img_glo - cap_glo)^2 + b)  -> elementwise + GEMM + row l2norm          (:429-430)
-//   5. SAF (:615-619) or SGR x sgr_step (:581-587) + sigmoid(sim_eval_w)                                (:443-444)
+//   5. SAF (:615-619): one pair kernel;  SGR x sgr_step (:581-587): ONE folded query projection per node
+//      (q' = (Wk^T Wq) x + Wk^T bq, see below), MFMA pair kernel softmax(q' X^T) X, graph GEMM; sigmoid(sim_eval_w) (:443-444)
 // The global nodes img_glo / cap_glo (VisualSA :491-507, TextSA :543-559) are computed once per call.
-// A fused "flash" version that keeps (ctx - E)^2 on chip is the next step.
 #include "scan_common.h"
 
 namespace itr {
