@@ -327,7 +327,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="scan_t2i_coco5k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-images", type=int, default=120)
+    ap.add_argument("--cpu-sample-images", type=int, default=160)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
