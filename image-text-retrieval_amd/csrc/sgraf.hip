@@ -159,29 +159,31 @@ __global__ __launch_bounds__(256) void saf_pair_kernel(PairArgs p, const float *
     const int nn = p.cap_len[c] + 1, col0 = p.cap_col[c];
     const float bscale = bn_w[0] / sqrtf(bn_var[0] + BN_EPS);
     float asum = 0.f;
-    // pass 1: attention weights (kept per node in a register ring of the wave: recomputed in pass 2 instead)
-    for (int n = 0; n < nn; ++n) {
-        const float *x = node_row(p, p.xglo, p.xloc, ii, c, col0, n);
-        float s = 0.f;
-        for (int d = lane; d < p.S; d += 64) s += x[d] * saf_w[d];
-        s = wave_sum(s) + saf_b[0];
-        const float a = 1.f / (1.f + expf(-((s - bn_mean[0]) * bscale + bn_b[0])));
-        asum += fabsf(a);
-    }
-    const float inv = 1.f / (asum + 1e-8f);   // l1norm
-    // pass 2: filtered aggregate, this lane's columns d = lane, lane+64, ... (S <= 1024)
+    // ONE pass over the node rows (they are the HBM traffic of this kernel): the l1 normalisation of the attention
+    // weights is linear, so the un-normalised aggregate sum_n a_n x_n is divided by sum_n |a_n| at the end.
+    // This lane's columns: d = lane, lane + 64, ... (S <= 1024)
     float vec[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) vec[u] = 0.f;
     for (int n = 0; n < nn; ++n) {
         const float *x = node_row(p, p.xglo, p.xloc, ii, c, col0, n);
+        float xv[16];
         float s = 0.f;
-        for (int d = lane; d < p.S; d += 64) s += x[d] * saf_w[d];
-        s = wave_sum(s) + saf_b[0];
-        const float a = inv / (1.f + expf(-((s - bn_mean[0]) * bscale + bn_b[0])));
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int d = lane + 64 * u; if (d < p.S) vec[u] += a * x[d]; }
+        for (int u = 0; u < 16; ++u) {
+            const int d = lane + 64 * u;
+            xv[u] = d < p.S ? x[d] : 0.f;
+            s += d < p.S ? xv[u] * saf_w[d] : 0.f;
+        }
+        s = wave_sum(s) + saf_b[0];
+        const float a = 1.f / (1.f + expf(-((s - bn_mean[0]) * bscale + bn_b[0])));
+        asum += fabsf(a);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vec[u] += a * xv[u];
     }
+    const float inv = 1.f / (asum + 1e-8f);   // l1norm
+#pragma unroll
+    for (int u = 0; u < 16; ++u) vec[u] *= inv;
     float ss = 0.f, dot = 0.f;
 #pragma unroll
     for (int u = 0; u < 16; ++u) { const int d = lane + 64 * u; if (d < p.S) { ss += vec[u] * vec[u]; dot += vec[u] * eval_w[d]; } }
