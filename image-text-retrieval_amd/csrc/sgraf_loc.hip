@@ -65,17 +65,29 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) pa[q] = g.P[r * SC_R + 4 * q + sg] * sc;
     }
-    const float *vbase = g.img + ii * SC_R * (int64_t)D + si;                              // V[k][d]
-    const float *zbase = g.wtiled + (ct * SC_NT + 16 * wave + 4 * sg) * (int64_t)D + si;    // E rows 4 sg + j of this wave
+    // Loop-invariant addressing (the fp32 MFMA shares the vector ALU: the compiler's per-load 64-bit address arithmetic was
+    // 225 VALU instructions per slice, ~19 % of the matrix time): uniform 64-bit bases advanced by scalar adds + ONE fixed
+    // 32-bit per-lane byte offset per operand, loads issued through inline asm with our own s_waitcnt.
+    const char *vbase = reinterpret_cast<const char *>(g.img + ii * SC_R * (int64_t)D);                       // V[k][d]
+    const char *zbase = reinterpret_cast<const char *>(g.wtiled + (ct * SC_NT + 16 * wave) * (int64_t)D);    // E rows of this wave
+    const char *wbase = reinterpret_cast<const char *>(g.W);
+    const unsigned rowb = (unsigned)D * 4u;
+    const unsigned voff_v = (unsigned)sg * rowb + si * 4u;            // V[4q + sg][d0 + si]      (q via the base, +16 columns via offset:64)
+    const unsigned voff_z = 4u * sg * rowb + si * 4u;                 // E[4 sg + j][d0 + si]     (j via the base)
     float vb[2][9], zz[2][4];
-    // (macros, not lambdas; f32x4 = ext_vector_type, not HIP's float4 struct: an array of float4 that is loaded in one
-    // conditional block and consumed in another stayed in scratch memory here)
+#define LOC_LDG1(dst, base, voff, IMM) asm volatile("global_load_dword %0, %1, %2 offset:" #IMM : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+#define LOC_LDG4(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 #define LOC_LOAD_VZ(kc_)                                                                                        \
     {                                                                                                           \
-        const int d0_ = (kc_) * LK;                                                                             \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                      \
-            _Pragma("unroll") for (int q = 0; q < 9; ++q) vb[nt][q] = vbase[(int64_t)(4 * q + sg) * D + d0_ + nt * 16]; \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) zz[nt][j] = zbase[(int64_t)j * D + d0_ + nt * 16];    \
+        const char *vb_ = vbase + (int64_t)(kc_) * (LK * 4);                                                    \
+        const char *zb_ = zbase + (int64_t)(kc_) * (LK * 4);                                                    \
+        _Pragma("unroll") for (int q = 0; q < 9; ++q) {                                                         \
+            const char *b_ = vb_ + (int64_t)(4 * q) * rowb;                                                     \
+            LOC_LDG1(vb[0][q], b_, voff_v, 0) LOC_LDG1(vb[1][q], b_, voff_v, 64)                                \
+        }                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            const char *b_ = zb_ + (int64_t)j * rowb;                                                           \
+            LOC_LDG1(zz[0][j], b_, voff_z, 0) LOC_LDG1(zz[1][j], b_, voff_z, 64)                                \
         }                                                                                                       \
     }
 #define LOC_STAGE1(buf_)                                                                                        \
@@ -96,11 +108,19 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
     // ---- stage-2 operands
     const int ld_row = tid >> 3, ld_p = tid & 7;
     f32x4 rw[8];
+    const unsigned voff_w = (unsigned)ld_row * rowb + ld_p * 16u;     // W[ld_row + 32 s][kc*32 + 4 ld_p ..]  (s via the base)
 #define LOC_GLOAD_W(kc_)                                                                                        \
     {                                                                                                           \
-        const float *wp = g.W + (int64_t)ld_row * D + (kc_) * LK + ld_p * 4;                                    \
-        _Pragma("unroll") for (int s = 0; s < 8; ++s) rw[s] = *reinterpret_cast<const f32x4 *>(wp + (int64_t)(32 * s) * D); \
+        const char *wb_ = wbase + (int64_t)(kc_) * (LK * 4);                                                    \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) { const char *b_ = wb_ + (int64_t)(32 * s) * rowb; LOC_LDG4(rw[s], b_, voff_w) } \
     }
+// every asm load above has landed; the statements name the destination registers so that their consumers stay behind
+#define LOC_VMWAIT                                                                                              \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rw[0]), "+v"(rw[1]), "+v"(rw[2]), "+v"(rw[3]), "+v"(rw[4]), "+v"(rw[5]), "+v"(rw[6]), "+v"(rw[7]), \
+                 "+v"(zz[0][0]), "+v"(zz[0][1]), "+v"(zz[0][2]), "+v"(zz[0][3]), "+v"(zz[1][0]), "+v"(zz[1][1]), "+v"(zz[1][2]), "+v"(zz[1][3])::"memory"); \
+    asm volatile("" : "+v"(vb[0][0]), "+v"(vb[0][1]), "+v"(vb[0][2]), "+v"(vb[0][3]), "+v"(vb[0][4]), "+v"(vb[0][5]), "+v"(vb[0][6]), "+v"(vb[0][7]), \
+                 "+v"(vb[0][8]), "+v"(vb[1][0]), "+v"(vb[1][1]), "+v"(vb[1][2]), "+v"(vb[1][3]), "+v"(vb[1][4]), "+v"(vb[1][5]), "+v"(vb[1][6]), \
+                 "+v"(vb[1][7]), "+v"(vb[1][8])::"memory");
 #define LOC_LSTORE_W(buf_)                                                                                      \
     { _Pragma("unroll") for (int s = 0; s < 8; ++s) *reinterpret_cast<f32x4 *>(&sm.w[buf_][ld_p][(ld_row + 32 * s) ^ ld_p]) = rw[s]; }
     f32x16 acc[2][2];
@@ -113,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
 
     LOC_GLOAD_W(0)
     LOC_LOAD_VZ(0)
+    LOC_VMWAIT
     LOC_STAGE1(0)
     LOC_LSTORE_W(0)
     __syncthreads();
@@ -152,6 +173,7 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
+        LOC_VMWAIT
         LOC_STAGE1(buf ^ 1)
         LOC_LSTORE_W(buf ^ 1)
 #pragma unroll
@@ -169,6 +191,10 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
         __syncthreads();
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef LOC_LDG1
+#undef LOC_LDG4
+#undef LOC_VMWAIT
 #undef LOC_LOAD_VZ
 #undef LOC_STAGE1
 #undef LOC_GLOAD_W
