@@ -155,3 +155,45 @@ def test_feature_prefetcher_matches_plain_loader(golden, dev, tmp_path):
         assert list(a[4]) == list(b[4]) and list(a[5]) == list(b[5])
     with pytest.raises(RuntimeError):
         dl.FeaturePrefetcher(loader, 'cpu')
+
+
+def test_train_and_test_command_lines(golden, dev, tmp_path):
+    """`python train.py with SCAN k=v ...` for two short epochs on a toy precomp dataset (training step, validation,
+    checkpoints, hparams.yaml), then `python test.py` on the best checkpoint, reference-shaped and --fast."""
+    import glob
+    import subprocess
+    import sys
+    g = golden("g14_data_layer")
+    name = 'toy_precomp'
+    d = tmp_path / 'data' / name
+    d.mkdir(parents=True)
+    caps = bytes(g["caps_blob"]).split(b"\n")[:-1]
+    rng = np.random.RandomState(0)
+    for split, n_img in (('train', 40), ('dev', 1000), ('test', 6)):     # dev: PrecompDataset.__len__ is 5000 whatever the file holds
+        np.save(d / ('%s_ims.npy' % split), rng.randn(n_img, 36, 8).astype(np.float32))
+        lines = [caps[i % len(caps)] for i in range(5 * n_img)]
+        (d / ('%s_caps.txt' % split)).write_bytes(b"\n".join(lines) + b"\n")
+    vdir = tmp_path / 'vocab'
+    vdir.mkdir()
+    (vdir / ('%s_vocab.json' % name)).write_text(bytes(g["vocab_json"]).decode())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "image-text-retrieval_amd")
+    runs = str(tmp_path / 'runs')
+    cmd = [sys.executable, os.path.join(pkg, "train.py"), "with", "SCAN", "data_name=%s" % name, "data_path=%s" % (tmp_path / 'data'),
+           "vocab_path=%s" % vdir, "save_path=%s" % runs, "num_epochs=2", "batch_size=20", "val_step=7", "log_step=5", "workers=0",
+           "img_dim=8", "embed_size=32", "word_dim=16", "bi_gru=True", "max_violation=True", "seed=3", "learning_rate=0.002"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    run_dirs = glob.glob(os.path.join(runs, "SCAN", "toy_3_*"))
+    assert len(run_dirs) == 1
+    files = set(os.listdir(run_dirs[0]))
+    assert {'hparams.yaml', 'epo0_checkpoint.pth.tar', 'epo1_checkpoint.pth.tar', 'model_best.pth.tar'} <= files
+    ck = utils.load_checkpoint(os.path.join(run_dirs[0], 'epo1_checkpoint.pth.tar'))
+    assert ck['epoch'] == 1 and ck['Eiters'] == 2 * 10 and len(ck['model']) == 2 and ck['_config']['vocab_size'] == int(g["vocab_len"])
+    best = os.path.join(run_dirs[0], 'model_best.pth.tar')
+    for extra in ([], ['--fast']):
+        r = subprocess.run([sys.executable, os.path.join(pkg, "test.py"), best, "--split", "test"] + extra, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        y = yaml.safe_load(open(os.path.join(run_dirs[0], '%s_single_result.yaml' % name)))
+        assert y['data_name'] == name and len(y['i2t_ranks']) == 6 and 0.0 <= y['rsum'] <= 600.0
