@@ -197,3 +197,50 @@ def test_train_and_test_command_lines(golden, dev, tmp_path):
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
         y = yaml.safe_load(open(os.path.join(run_dirs[0], '%s_single_result.yaml' % name)))
         assert y['data_name'] == name and len(y['i2t_ranks']) == 6 and 0.0 <= y['rsum'] <= 600.0
+
+
+@pytest.mark.parametrize("model_name", ["CAMERA", "SAEM"])
+def test_evalrank_fast_bert_models(golden, dev, tmp_path, model_name):
+    """BERT-tower models through both evaluation paths on the toy dataset: word-piece features from the data layer,
+    boxes / image sizes for CAMERA, one vector per caption, cosine (pdist_cos) / multi-view matching."""
+    import json
+    from itr_amd.modalmodule import bert
+    g = golden("g14_data_layer")
+    name = 'toy_precomp'
+    d = tmp_path / 'data' / name
+    d.mkdir(parents=True)
+    np.save(d / 'test_ims.npy', g["ims"])
+    np.save(d / 'test_boxes.npy', g["boxes"])
+    np.save(d / 'test_img_sizes.npy', g["img_sizes"])
+    (d / 'test_caps.txt').write_bytes(bytes(g["caps_blob"]))
+    bdir = tmp_path / 'bert'
+    bdir.mkdir()
+    (bdir / 'vocab.txt').write_bytes(bytes(g["bert_vocab"]))
+    n_vocab = len(bytes(g["bert_vocab"]).decode().split("\n")) - 1
+    bcfg = dict(vocab_size=n_vocab, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    json.dump(bcfg, open(bdir / 'bert_config.json', 'w'))
+    json.dump(dict(bcfg, num_hidden_layers=1), open(bdir / 'trans_cfg.json', 'w'))
+    torch.manual_seed(4)
+    bm = bert.BertModel(bert.BertConfig.from_dict(bcfg))
+    for p_ in bm.parameters():
+        p_.data.normal_(0, 0.05)
+    torch.save(bm.state_dict(), bdir / 'pytorch_model.bin')
+    save_dir = str(tmp_path / 'run')
+    os.makedirs(save_dir)
+    cfg = C.build_config(['with', model_name, 'data_name=%s' % name, 'bert_path=%s' % bdir, 'seed=4'])
+    cfg.update(img_dim=8, embed_size=64, head=4, smry_k=12, max_words=12, final_dims=64, trans_cfg=str(bdir / 'trans_cfg.json'),
+               data_path=str(tmp_path / 'data'), batch_size=7, workers=0, save_dir=save_dir, vocab_size=n_vocab)
+    torch.manual_seed(5)
+    model = get_model(cfg)
+    for m in model.modules():                      # non-trivial BatchNorm statistics
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    utils.save_checkpoint({'epoch': 0, 'model': model.state_dict(), 'best_rsum': 0.0, 'best_r1': 0.0, '_config': cfg, 'Eiters': 1}, True,
+                          prefix=save_dir)
+    p = os.path.join(save_dir, 'model_best.pth.tar')
+    slow = evaluation.evalrank_single(p, split='test')
+    fast = evaluation.evalrank_fast(p, split='test')
+    for k in ('i2t_ranks', 't2i_ranks', 'i2t_top1', 't2i_top1'):
+        assert (np.asarray(slow[k]) == np.asarray(fast[k])).all(), k
