@@ -208,56 +208,58 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
     GF_GLOAD((1 < klast ? 1 : klast))
     __syncthreads();
 
+    // Two fragment sets per slice (F0 = planes 0..3, F1 = planes 4..7) and the barrier MID-WAY, as in the SCAN main loop:
+    //   park slice kc+1, request slice kc+2, read F1(kc);  MFMA F0(kc);  barrier;  read F0(kc+1) from the other buffer;
+    //   MFMA F1(kc)  -- after the barrier the matrix core works on registers while the first fragments of the next
+    //   slice arrive, so no LDS round trip is exposed.
+    float4 f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];     // [q within the half][tile]
+#define GF_FREAD(FA, FB, Q0, BUF)                                                                   \
+    {                                                                                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                          \
+            const int p_ = 2 * ((Q0) + q_) + fg;                                                    \
+            _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                      \
+                FA[q_][t_] = lds[BUF][0][p_][(wm * 64 + t_ * 32 + fi) ^ p_];                        \
+                FB[q_][t_] = lds[BUF][1][p_][(wn * 64 + t_ * 32 + fi) ^ p_];                        \
+            }                                                                                       \
+        }                                                                                           \
+    }
+#define GF_MFMA_C(FA, FB, C)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].C, FB[j].C, acc[i][j], 0, 0, 0);
+#define GF_FMFMA(FA, FB)                                                                            \
+    {                                                                                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                          \
+            GF_MFMA_C(FA[q_], FB[q_], x) GF_MFMA_C(FA[q_], FB[q_], y) GF_MFMA_C(FA[q_], FB[q_], z) GF_MFMA_C(FA[q_], FB[q_], w) \
+        }                                                                                           \
+    }
+#define GF_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+    GF_FREAD(f0a, f0b, 0, 0)
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
         GF_VMWAIT0
         GF_LSTORE(buf ^ 1)
         GF_GLOAD((kc + 2 < klast ? kc + 2 : klast))
+        GF_FREAD(f1a, f1b, 2, buf)
+        GF_FMFMA(f0a, f0b)
+        // first half: 32 MFMAs against 8 ds_write_b128 + 8 global loads + 8 ds_read_b128
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int p = 2 * q + fg;
-            float4 a[2], b[2];
+        for (int i_ = 0; i_ < 8; ++i_) { GF_SGB(0x008, 1) GF_SGB(0x200, 1) GF_SGB(0x008, 1) GF_SGB(0x020, 1) }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = lds[buf][0][p][(wm * 64 + i * 32 + fi) ^ p];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = lds[buf][1][p][(wn * 64 + j * 32 + fi) ^ p];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-        }
-        // 64 MFMAs per chunk against 16 ds_read_b128 + 8 ds_write_b128 + 8 global loads: one memory instruction per MFMA slot
-#pragma unroll
-        for (int i_ = 0; i_ < 4; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // first fragment reads before the first MFMA
-        }
-#pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-        }
-#pragma unroll
-        for (int i_ = 0; i_ < 12; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+        for (int i_ = 0; i_ < 8; ++i_) { GF_SGB(0x008, 1) GF_SGB(0x100, 1) }
+        GF_SGB(0x008, 8)
         __syncthreads();
+        GF_FREAD(f0a, f0b, 0, buf ^ 1)
+        GF_FMFMA(f1a, f1b)
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) { GF_SGB(0x008, 2) GF_SGB(0x100, 1) }
+        GF_SGB(0x008, 16)
     }
+    __syncthreads();      // every wave is done with LDS before the next tile's prologue overwrites it
+#undef GF_FREAD
+#undef GF_MFMA_C
+#undef GF_FMFMA
+#undef GF_SGB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the unused tail prefetch
     // (the loop ended on a barrier: nobody reads LDS any more, the next tile's prologue may overwrite it)
     gemm_epilogue(g, acc, &lds[0][0][0][0], tid, lane, wm, wn, m0, n0, m_end);
