@@ -213,7 +213,7 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
                                        dict(bi_gru=True, no_txtnorm=False, no_imgnorm=False), comm)
     else:
         feats, boxes, imgs_wh, ids, mask, types, lengths = pooled_inputs(n_img, n_cap, kind, dev)
-    pe = evalpipe.PooledModelEval(model, comm, batch=1000)
+    pe = evalpipe.PooledModelEval(model, comm, batch=1024)   # 1024 captions x 32 tokens = 256 M-tiles: whole rounds of the persistent GEMM
     timers = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
 
     def step(tm=None):

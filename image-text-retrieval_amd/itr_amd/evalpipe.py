@@ -197,7 +197,7 @@ class PooledModelEval:
     (cosine / pdist_cos / MultiViewMatching with its max-over-views epilogue) and the ranks are finished exactly as
     for SCAN (finalize_ranks)."""
 
-    def __init__(self, model, comm=None, batch=1000):
+    def __init__(self, model, comm=None, batch=1024):
         self.model, self.comm, self.batch = model, comm or Comm(), batch
         self.name = model.config['name']
 
@@ -270,7 +270,7 @@ def _features_to_device(arr, i0, i1, dev, chunk=512):
     return out
 
 
-def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1000):
+def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
     """Recall ranks of `model` on a PrecompDataset (datamodule.data_loader), one process per GPU.
 
     Unlike encode_data + cal_sims (the reference-shaped path: 5 x redundant image encodes, host numpy arrays, a Python
