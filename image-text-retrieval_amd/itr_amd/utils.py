@@ -114,18 +114,32 @@ def train_step(_config, train_loader, model, epoch, val_loader, best_rsum=0, bes
     return best_rsum, best_r1
 
 
-def validate_step(_config, val_loader, model):
-    """Encode the validation split, score, rank -> (r_sum, r1) (utils.py:144-186)."""
+def validate_step(_config, val_loader, model, fast=None):
+    """Encode the validation split, score, rank -> (r_sum, r1) (utils.py:144-186).
+    fast (default: _config.get('fast_eval', True) when the loader wraps a PrecompDataset): the device-resident pipeline
+    (evalpipe.evaluate_precomp: every unique image encoded once, packed captions, fused scoring) instead of
+    encode_data + cal_sims; the rank vectors are identical (tests/test_evalrank_gpu.py)."""
+    from .datamodule.data_loader import PrecompDataset
     start = time.time()
     model.val_start()
-    islength = _config['name'] in ['SGRAF', 'SCAN']
-    img_embs, cap_embs, cap_lens = eval.encode_data(model, val_loader, islength=islength)
-    img_embs = numpy.array([img_embs[i] for i in range(0, len(img_embs), 5)])   # 5 duplicated image rows -> 1
-    sims = eval.cal_sims(model, img_embs, cap_embs, lengths=cap_lens, shard_size=100)
-    print("Calculate similarity time:", time.time() - start)
-    (r1, r5, r10, medr, meanr) = eval.i2t(sims)
+    dset = getattr(val_loader, 'dataset', None)
+    if fast is None:
+        fast = bool(_config.get('fast_eval', True)) and isinstance(dset, PrecompDataset) and dset.im_div == 5 and len(dset) % 5 == 0
+    if fast:
+        from . import evalpipe
+        i_rank, _, t_rank, _ = evalpipe.evaluate_precomp(model, dset)
+        print("Calculate similarity time:", time.time() - start)
+        (r1, r5, r10, medr, meanr) = eval.ops.recall_from_ranks(i_rank)
+        (r1i, r5i, r10i, medri, meanri) = eval.ops.recall_from_ranks(t_rank)
+    else:
+        islength = _config['name'] in ['SGRAF', 'SCAN']
+        img_embs, cap_embs, cap_lens = eval.encode_data(model, val_loader, islength=islength)
+        img_embs = numpy.array([img_embs[i] for i in range(0, len(img_embs), 5)])   # 5 duplicated image rows -> 1
+        sims = eval.cal_sims(model, img_embs, cap_embs, lengths=cap_lens, shard_size=100)
+        print("Calculate similarity time:", time.time() - start)
+        (r1, r5, r10, medr, meanr) = eval.i2t(sims)
+        (r1i, r5i, r10i, medri, meanri) = eval.t2i(sims)
     logging.info("Image to text: r1 %.1f; r5 %.1f; r10 %.1f; medr %.1f; meanr %.1f" % (r1, r5, r10, medr, meanr))
-    (r1i, r5i, r10i, medri, meanri) = eval.t2i(sims)
     logging.info("Text to image: r1 %.1f; r5 %.1f; r10 %.1f; medr %.1f; meanr %.1f" % (r1i, r5i, r10i, medri, meanri))
     r_sum = r1 + r5 + r10 + r1i + r5i + r10i
     for k, v in (('r1_i2t', r1), ('r5_i2t', r5), ('r10_i2t', r10), ('medr_i2t', medr), ('meanr_i2t', meanr), ('r1_t2i', r1i),

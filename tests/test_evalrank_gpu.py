@@ -125,7 +125,9 @@ def test_validate_step_and_resume(golden, dev, tmp_path):
     torch.manual_seed(5)
     model = get_model(cfg)
     loader, _ = dl.get_test_loader('test', name, cfg['batch_size'], 0, cfg)
-    r_sum, r1 = utils.validate_step(cfg, loader, model)
+    r_sum, r1 = utils.validate_step(cfg, loader, model, fast=False)
+    r_sum_f, r1_f = utils.validate_step(cfg, loader, model)          # device-resident pipeline (default)
+    assert r_sum_f == pytest.approx(r_sum) and r1_f == pytest.approx(r1)
     want = O.rank_counts(_oracle_eval(model, cfg, name, data_path).numpy())
     ri, rt = O.recall_from_ranks(want[0]), O.recall_from_ranks(want[2])
     assert r1 == pytest.approx(ri[0]) and r_sum == pytest.approx(sum(ri[:3]) + sum(rt[:3]))
