@@ -99,18 +99,21 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float *__restri
     carry[b * D + j] = dh * z;
 }
 
-__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t rows, int64_t cols) {
+// out[c, r] = in[r, c] with out rows padded to `ldo` >= rows floats; the pad columns [rows, ldo) are written as zeros so
+// that the padded length can serve as a K % 32 == 0 contraction dimension of the branch-free GEMM.
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t rows, int64_t cols,
+                                                        int64_t ldo) {
     __shared__ float t[64][65];
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4)
-        if (r0 + i < rows && c0 + tx < cols) t[i][tx] = in[(r0 + i) * cols + c0 + tx];
+    for (int i = ty; i < 64; i += 4) t[i][tx] = (r0 + i < rows && c0 + tx < cols) ? in[(r0 + i) * cols + c0 + tx] : 0.f;
     __syncthreads();
     for (int i = ty; i < 64; i += 4)
-        if (c0 + i < cols && r0 + tx < rows) out[(c0 + i) * rows + r0 + tx] = t[tx][i];
+        if (c0 + i < cols && r0 + tx < ldo) out[(c0 + i) * ldo + r0 + tx] = t[tx][i];
 }
-static int transpose(const float *in, float *out, int64_t rows, int64_t cols, hipStream_t st) {
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(rows, 64)), dim3(256), 0, st, in, out, rows, cols);
+static int transpose(const float *in, float *out, int64_t rows, int64_t cols, int64_t ldo, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(ldo, 64)), dim3(256), 0, st, in, out, rows, cols,
+                       ldo);
     ITR_CHECK_LAUNCH("gru transpose");
     return ITR_OK;
 }
@@ -149,9 +152,9 @@ extern "C" size_t itr_gru_train_save_bytes(int64_t n_tok, int D, int bidirection
 extern "C" size_t itr_gru_train_workspace_bytes(int64_t n_tok, int64_t B, int E, int D) {
     // forward: x, gi, gh, h, bad.  backward: x, dgi, dgh, hprev, carry, dgh_step, dx, and the transposes
     // (dgi^T | dgh^T share one [3D, n_tok] buffer, x^T | hprev^T one [max(E, D), n_tok]), W_hh^T, W_ih^T, colsum partials.
-    const size_t nt = (size_t)n_tok, d3 = (size_t)3 * D;
+    const size_t nt = (size_t)n_tok, d3 = (size_t)3 * D, ntp = (size_t)ceil_div(n_tok > 0 ? n_tok : 1, 32) * 32;
     size_t b = al256(nt * E * 4) + 2 * al256(nt * d3 * 4) + al256(nt * D * 4) + al256((size_t)B * D * 4) + al256((size_t)B * d3 * 4) +
-               al256(nt * E * 4) + al256(d3 * nt * 4) + al256((size_t)(E > D ? E : D) * nt * 4) + al256(d3 * D * 4) + al256(d3 * E * 4) +
+               al256(nt * E * 4) + al256(d3 * ntp * 4) + al256((size_t)(E > D ? E : D) * ntp * 4) + al256(d3 * D * 4) + al256(d3 * E * 4) +
                al256(((size_t)ceil_div(n_tok > 0 ? n_tok : 1, 256)) * d3 * 4) + 512;
     b += al256(gemm_splitk_scratch_bytes(B, 3 * D, 16));      // split-K partials of the per-step GEMMs
     return b;
@@ -221,6 +224,7 @@ extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const 
     if (rc != ITR_OK) return rc;
     hipStream_t st = as_stream(stream);
     const size_t nt = (size_t)n_tok, d3 = (size_t)3 * D;
+    const int64_t ntp = ceil_div(n_tok, (int64_t)32) * 32;
     char *p = static_cast<char *>(workspace);
     float *x = (float *)p; p += al256(nt * E * 4);
     float *dgi = (float *)p; p += al256(nt * d3 * 4);
@@ -229,8 +233,8 @@ extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const 
     float *carry = (float *)p; p += al256((size_t)B * D * 4);
     float *dgh_step = (float *)p; p += al256((size_t)B * d3 * 4);
     float *dx = (float *)p; p += al256(nt * E * 4);
-    float *gT = (float *)p; p += al256(d3 * nt * 4);                       // dgi^T, then dgh^T
-    float *aT = (float *)p; p += al256((size_t)(E > D ? E : D) * nt * 4);   // x^T, then hprev^T
+    float *gT = (float *)p; p += al256(d3 * (size_t)ntp * 4);                       // dgi^T, then dgh^T
+    float *aT = (float *)p; p += al256((size_t)(E > D ? E : D) * (size_t)ntp * 4);   // x^T, then hprev^T
     float *whhT = (float *)p; p += al256(d3 * D * 4);
     float *wihT = (float *)p; p += al256(d3 * E * 4);
     float *cs = (float *)p; p += al256(((size_t)ceil_div(n_tok, 256)) * d3 * 4);
@@ -251,8 +255,8 @@ extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const 
         float *dwi = dir ? d_w_ih_rev : d_w_ih, *dwh = dir ? d_w_hh_rev : d_w_hh;
         float *dbi = dir ? d_b_ih_rev : d_b_ih, *dbh = dir ? d_b_hh_rev : d_b_hh;
         GruSave sv = save_planes(const_cast<void *>(save), dir, n_tok, D);
-        GB_TRY(transpose(wh, whhT, 3 * D, D, st));    // [3D, D] -> [D, 3D]:  carry += dgh_step . W_hh  ==  gemm_nt(dgh_step, W_hh^T)
-        GB_TRY(transpose(wi, wihT, 3 * D, E, st));    // [3D, E] -> [E, 3D]
+        GB_TRY(transpose(wh, whhT, 3 * D, D, 3 * D, st));    // [3D, D] -> [D, 3D]:  carry += dgh_step . W_hh  ==  gemm_nt(dgh_step, W_hh^T)
+        GB_TRY(transpose(wi, wihT, 3 * D, E, 3 * D, st));    // [3D, E] -> [E, 3D]
         ITR_CHECK_HIP(hipMemsetAsync(carry, 0, (size_t)B * D * 4, st));
         for (int t = Lmax - 1; t >= 0; --t) {
             int64_t n_act = 0;
@@ -263,12 +267,12 @@ extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const 
             if (t > 0) GB_TRY(gemm_nt_splitk(dgh_step, 3 * D, whhT, 3 * D, nullptr, carry, D, n_act, D, 3 * D, 0, 1, splits_c, skbuf, st));
         }
         // weight gradients over all tokens
-        GB_TRY(transpose(dgh, gT, n_tok, 3 * D, st));
-        GB_TRY(transpose(hprev, aT, n_tok, D, st));
-        GB_TRY(gemm_nt(gT, n_tok, aT, n_tok, nullptr, dwh, D, 3 * D, D, n_tok, 0, st));
-        GB_TRY(transpose(dgi, gT, n_tok, 3 * D, st));
-        GB_TRY(transpose(x, aT, n_tok, E, st));
-        GB_TRY(gemm_nt(gT, n_tok, aT, n_tok, nullptr, dwi, E, 3 * D, E, n_tok, 0, st));
+        GB_TRY(transpose(dgh, gT, n_tok, 3 * D, ntp, st));          // token axis zero-padded to ntp (K % 32 == 0)
+        GB_TRY(transpose(hprev, aT, n_tok, D, ntp, st));
+        GB_TRY(gemm_nt(gT, ntp, aT, ntp, nullptr, dwh, D, 3 * D, D, ntp, 0, st));
+        GB_TRY(transpose(dgi, gT, n_tok, 3 * D, ntp, st));
+        GB_TRY(transpose(x, aT, n_tok, E, ntp, st));
+        GB_TRY(gemm_nt(gT, ntp, aT, ntp, nullptr, dwi, E, 3 * D, E, ntp, 0, st));
         GB_TRY(itr_colsum(dgh, dbh, n_tok, 3 * D, 0, cs, al256((size_t)nparts * d3 * 4) + 256, stream));
         GB_TRY(itr_colsum(dgi, dbi, n_tok, 3 * D, 0, cs, al256((size_t)nparts * d3 * 4) + 256, stream));
         // input gradient: dx (+)= dgi . W_ih

@@ -238,6 +238,9 @@ def cosine_scores(im, s):
 
 
 class _ScanT2I(torch.autograd.Function):
+    """The word axis is zero-padded to a multiple of 32 (ntp) so that every GEMM whose contraction runs over the words
+    (dV = dA E) takes the branch-free kernel; padded columns of A / dA are zero and never read by the pair kernels."""
+
     @staticmethod
     def forward(ctx, V, E, cap_off, cap_len, max_len, norm, agg, ls, ll):
         lib = _lib.load()
@@ -247,37 +250,40 @@ class _ScanT2I(torch.autograd.Function):
         if E.dim() != 2 or E.shape[1] != D:
             raise ValueError("scan_t2i_scores: images (.., %d) vs words %s" % (D, tuple(E.shape)))
         n_tok = E.shape[0]
+        ntp = (n_tok + 31) // 32 * 32
         Bc = cap_len.numel()
         dev = V.device
         V2 = V.reshape(Bi * R, D)
-        A = _gemm_nt(V2, E)                                           # raw dot products of all pairs
+        Ep = torch.zeros(ntp, D, device=dev, dtype=torch.float32)
+        Ep[:n_tok] = E
+        A = _gemm_nt(V2, Ep)                                          # raw dot products of all pairs, [Bi*36, ntp]
         G = _f32(Bi, R, R, dev=dev)
-        enorm = _f32(n_tok, dev=dev)
-        _lib.check(lib.itr_scan_train_prepare(_p(V2), _p(E), Bi, n_tok, R, D, _p(G), _p(enorm), _stream()))
+        enorm = _f32(ntp, dev=dev)
+        _lib.check(lib.itr_scan_train_prepare(_p(V2), _p(Ep), Bi, ntp, R, D, _p(G), _p(enorm), _stream()))
         S = _f32(Bi, Bc, dev=dev)
-        _lib.check(lib.itr_scan_train_fwd(_p(A), n_tok, _p(G), _p(enorm), _p(cap_off), _p(cap_len), Bi, Bc, n_tok, R, D, max_len,
+        _lib.check(lib.itr_scan_train_fwd(_p(A), ntp, _p(G), _p(enorm), _p(cap_off), _p(cap_len), Bi, Bc, ntp, R, D, max_len,
                                           norm, agg, ls, ll, _p(S), _stream()))
-        ctx.save_for_backward(V2, E, A, G, enorm, cap_off, cap_len)
-        ctx.opts = (Bi, Bc, n_tok, R, D, max_len, norm, agg, ls, ll)
+        ctx.save_for_backward(V2, Ep, A, G, enorm, cap_off, cap_len)
+        ctx.opts = (Bi, Bc, n_tok, ntp, R, D, max_len, norm, agg, ls, ll)
         return S
 
     @staticmethod
     def backward(ctx, dS):
         lib = _lib.load()
-        V2, E, A, G, enorm, cap_off, cap_len = ctx.saved_tensors
-        Bi, Bc, n_tok, R, D, max_len, norm, agg, ls, ll = ctx.opts
+        V2, Ep, A, G, enorm, cap_off, cap_len = ctx.saved_tensors
+        Bi, Bc, n_tok, ntp, R, D, max_len, norm, agg, ls, ll = ctx.opts
         dev = V2.device
         dS = dS.contiguous()
         dA = torch.zeros_like(A)
         dGp = _f32(Bi, Bc, R, R, dev=dev)
-        denp = torch.zeros(Bi, n_tok, device=dev, dtype=torch.float32)
-        _lib.check(lib.itr_scan_train_bwd(_p(A), n_tok, _p(G), _p(enorm), _p(cap_off), _p(cap_len), Bi, Bc, n_tok, R, D, max_len, norm,
+        denp = torch.zeros(Bi, ntp, device=dev, dtype=torch.float32)
+        _lib.check(lib.itr_scan_train_bwd(_p(A), ntp, _p(G), _p(enorm), _p(cap_off), _p(cap_len), Bi, Bc, ntp, R, D, max_len, norm,
                                           agg, ls, ll, _p(dS), _p(dA), _p(dGp), _p(denp), _stream()))
-        dV = _gemm_nt(dA, transpose2d(E))                             # dA [Bi*36, n_tok] . E [n_tok, D]
-        dE = _gemm_nt(transpose2d(dA), transpose2d(V2))               # dA^T [n_tok, Bi*36] . V [Bi*36, D]
+        dV = _gemm_nt(dA, transpose2d(Ep))                            # dA [Bi*36, ntp] . E [ntp, D]
+        dE = _gemm_nt(transpose2d(dA), transpose2d(V2))               # dA^T [ntp, Bi*36] . V [Bi*36, D]
         den = colsum(denp)
-        _lib.check(lib.itr_scan_train_finish(_p(dGp), Bi, Bc, _p(V2), _p(E), _p(enorm), _p(den), n_tok, R, D, _p(dV), _p(dE), _stream()))
-        return dV.reshape(Bi, R, D), dE, None, None, None, None, None, None, None
+        _lib.check(lib.itr_scan_train_finish(_p(dGp), Bi, Bc, _p(V2), _p(Ep), _p(enorm), _p(den), ntp, R, D, _p(dV), _p(dE), _stream()))
+        return dV.reshape(Bi, R, D), dE[:n_tok], None, None, None, None, None, None, None
 
 
 def scan_t2i_scores(images, words_packed, cap_off, cap_lens, raw_feature_norm='clipped_l2norm', agg_func='LogSumExp',
