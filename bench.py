@@ -250,7 +250,7 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
         score_ms.append(timers["scan_start"].elapsed_time(timers["scan_end"]))
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    t = torch.tensor([dt], device="cpu" if os.environ.get("ITR_DIST_BACKEND") == "gloo" else dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -277,6 +277,7 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
                       "embed": dims, "parallelism": "row-shard x%d + 1 all-gather of caption embeddings" % world,
                       "step": "encode(image tower + text tower) + score + rank(i2t,t2i)"},
            "recall": {"i2t_r1": i2t[0], "i2t_r5": i2t[1], "i2t_r10": i2t[2], "t2i_r1": t2i[0], "t2i_r5": t2i[1], "t2i_r10": t2i[2]},
+           "rank_checksum": [int((np.asarray(r, np.int64) * (np.arange(len(r)) % 9973 + 1)).sum()) for r in ranks],
            "roofline": {"kernel": "gemm_nt_kernel (every dense layer of the towers + the score GEMM)", "bound": "mfma",
                         "achieved": flop / (ms_per_step * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flop / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
@@ -334,6 +335,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    backend = os.environ.get("ITR_DIST_BACKEND", "nccl")   # "gloo": several ranks on ONE GPU (tests); collectives staged through the host
+    if backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # ITR_FORCE_COLLECTIVES=1: run every RCCL call of the N>1 path with a single rank (1-GPU box smoke of the
@@ -342,7 +346,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from itr_amd import evalpipe, ops
     wl = WORKLOADS[args.workload]
@@ -400,7 +407,7 @@ def main():
         scan_ms.append(timers["scan_start"].elapsed_time(timers["scan_end"]))
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    t = torch.tensor([dt], device=dev if backend != "gloo" else "cpu", dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -441,6 +448,8 @@ def main():
                        "step": "encode(img proj + bi-GRU) + score + rank(i2t,t2i)"},
             "recall": {"i2t_r1": i2t[0], "i2t_r5": i2t[1], "i2t_r10": i2t[2], "t2i_r1": t2i[0], "t2i_r5": t2i[1],
                        "t2i_r10": t2i[2]},
+            # order-sensitive checksums of the four rank vectors: equal across GPU counts iff the sharded result is identical
+            "rank_checksum": [int((np.asarray(r, np.int64) * (np.arange(len(r)) % 9973 + 1)).sum()) for r in ranks],
             "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": alg_flop / (k_ms * 1e-3) / 1e12,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": alg_flop / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,

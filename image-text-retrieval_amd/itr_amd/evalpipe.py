@@ -42,6 +42,9 @@ class Comm:
         self.group = group
         self.rank = dist.get_rank(group) if self.on else 0
         self.world = dist.get_world_size(group) if self.on else 1
+        # gloo moves host memory: device tensors are staged through the host (tests: two ranks sharing ONE GPU, which
+        # RCCL refuses; production runs use backend nccl = RCCL over xGMI and never take this branch)
+        self.host_staged = self.on and dist.get_backend(group) == "gloo"
 
     def all_gather_rows(self, local, counts):
         """Concatenate row blocks of different heights.  Returns (buffer [world*maxrows, ...], maxrows):
@@ -52,7 +55,12 @@ class Comm:
         pad = torch.zeros((maxrows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         pad[:local.shape[0]] = local
         out = torch.empty((self.world * maxrows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, pad, group=self.group)
+        if self.host_staged and local.is_cuda:
+            parts = [torch.empty(pad.shape, dtype=pad.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, pad.cpu(), group=self.group)
+            out.copy_(torch.cat(parts, 0))
+        else:
+            dist.all_gather_into_tensor(out, pad, group=self.group)
         return out, maxrows
 
     def all_gather_list(self, obj_array):
@@ -68,7 +76,12 @@ class Comm:
 
     def all_reduce(self, t, op):
         if self.on:
-            dist.all_reduce(t, op=op, group=self.group)
+            if self.host_staged and t.is_cuda:
+                h = t.cpu()
+                dist.all_reduce(h, op=op, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=op, group=self.group)
         return t
 
 

@@ -191,3 +191,32 @@ def test_bench_collectives_single_rank():
         outs.append(json.loads(line[0]))
     assert outs[0]["recall"] == outs[1]["recall"]
     assert outs[1]["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,world", [("scan_t2i_f30k1k", 2), ("scan_t2i_f30k1k", 3), ("sgraf_saf_f30k1k", 2), ("vsepp_f30k1k", 2)])
+def test_sharded_eval_equals_single_process_on_one_gpu(workload, world):
+    """The WHOLE sharded pipeline (row-sharded images, caption slices, packed all-gather, max / sum / key reductions,
+    ragged rank gather) with real kernels: `world` ranks share this box's one GPU through the gloo backend (RCCL refuses
+    two ranks per device) and must reproduce the single-process rank vectors exactly."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [os.path.join(root, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+
+    def run(cmd, env):
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+        assert len(line) == 1, r.stdout[-2000:]
+        return json.loads(line[0])
+
+    single = run([sys.executable] + base, dict(os.environ))
+    env = dict(os.environ, ITR_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    multi = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                 "--master-port", str(29560 + world), base[0], "--gpus", str(world)] + base[1:], env)
+    assert multi["n_gpus"] == world
+    assert multi["rank_checksum"] == single["rank_checksum"]
+    assert multi["recall"] == single["recall"]
