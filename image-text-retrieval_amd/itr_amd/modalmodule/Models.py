@@ -237,6 +237,7 @@ class SAEM(base_module):
         self.img_enc.cuda()
         self.criterion = Objectives.ContrastiveLoss(config=config, margin=config['margin'], measure=config['measure'],
                                                     max_violation=config['max_violation'])
+        self.criterion_2 = Objectives.AngularLoss()
         self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters())
         self.calculate_params()
         self.no_decay = ['bias', 'gamma', 'beta']
@@ -247,11 +248,19 @@ class SAEM(base_module):
         return img_embs, cap_embs
 
     def forward_loss(self, epoch, img_emb, cap_emb, cap_len, ids):
-        """Ranking term only: the AngularLoss / weight-decay terms (Models.py:419-442) are training-time
-        auxiliaries and belong with the tower backward (8f-3)."""
+        """loss1 + alpha(epoch) * AngularLoss + 0.01 * sum ||W|| over the image tower's decayed parameters
+        (Models.py:419-442).  The ranking term runs on the HIP kernels; the two auxiliaries are training-time scalars
+        composed of torch GPU ops."""
+        alpha = 0 if epoch > 20 else 0.5 * (0.1 ** (epoch // 5))
         loss1 = self.criterion(img_emb, cap_emb, cap_len)
+        loss2 = self.criterion_2(img_emb, cap_emb, cap_len, ids)
         self._log('Loss1', loss1.item(), img_emb.size(0))
-        return loss1
+        self._log('Loss2', loss2.item(), img_emb.size(0))
+        l2_reg = torch.zeros((), device=img_emb.device)
+        for name, param in self.img_enc.named_parameters():
+            if name.split('.')[-1] not in self.no_decay:
+                l2_reg = l2_reg + torch.norm(param.detach())
+        return loss1 + alpha * loss2 + 0.01 * l2_reg
 
 
 class CAMERA(base_module):
@@ -268,6 +277,7 @@ class CAMERA(base_module):
         self.img_enc.cuda()       # one process per GPU: no nn.DataParallel wrapper (Models.py:561-562)
         self.txt_enc.cuda()
         self.crit_ranking = Objectives.TripletLoss(margin=config['margin'], max_violation=config['max_violation'])
+        self.crit_div = Objectives.DiversityRegularization(config['smry_k'], config['batch_size'])
         self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters())
         self.calculate_params()
 
@@ -277,8 +287,11 @@ class CAMERA(base_module):
         return img_emb, cap_emb, smry_mat
 
     def forward_loss(self, sim_mat, smry_mat):
-        """Ranking term; the diversity regulariser (Objectives.py:521-542, weight smry_lamda) is a training-time
-        auxiliary left with the tower backward (8f-3)."""
+        """ranking loss + smry_lamda * diversity regulariser (Models.py:598-611)."""
         ranking_loss = self.crit_ranking(sim_mat)
         self._log('Rank_Loss', ranking_loss.item(), len(sim_mat))
-        return ranking_loss
+        div_reg = self.crit_div(smry_mat)
+        self._log('Div_loss', div_reg.item(), len(sim_mat))
+        loss = ranking_loss + div_reg * self.config['smry_lamda']
+        self._log('Loss', loss.item(), len(sim_mat))
+        return loss

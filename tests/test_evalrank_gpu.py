@@ -246,3 +246,58 @@ def test_evalrank_fast_bert_models(golden, dev, tmp_path, model_name):
     fast = evaluation.evalrank_fast(p, split='test')
     for k in ('i2t_ranks', 't2i_ranks', 'i2t_top1', 't2i_top1'):
         assert (np.asarray(slow[k]) == np.asarray(fast[k])).all(), k
+
+
+@pytest.mark.parametrize("model_name", ["CAMERA", "SAEM"])
+def test_bert_model_wrappers_loss_vs_oracle(golden, dev, tmp_path, model_name):
+    """get_model('CAMERA' | 'SAEM'): forward_emb on a batch from the data layer -> forward_loss; the loss (ranking term +
+    diversity regulariser | + alpha * angular loss + weight-norm term) equals the oracle's on the same weights."""
+    import json
+    from itr_amd.modalmodule import bert
+    g = golden("g14_data_layer")
+    name = 'toy_precomp'
+    d = tmp_path / 'data' / name
+    d.mkdir(parents=True)
+    np.save(d / 'test_ims.npy', g["ims"])
+    np.save(d / 'test_boxes.npy', g["boxes"])
+    np.save(d / 'test_img_sizes.npy', g["img_sizes"])
+    (d / 'test_caps.txt').write_bytes(bytes(g["caps_blob"]))
+    bdir = tmp_path / 'bert'
+    bdir.mkdir()
+    (bdir / 'vocab.txt').write_bytes(bytes(g["bert_vocab"]))
+    n_vocab = len(bytes(g["bert_vocab"]).decode().split("\n")) - 1
+    bcfg = dict(vocab_size=n_vocab, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    json.dump(bcfg, open(bdir / 'bert_config.json', 'w'))
+    json.dump(dict(bcfg, num_hidden_layers=1), open(bdir / 'trans_cfg.json', 'w'))
+    torch.manual_seed(8)
+    bm = bert.BertModel(bert.BertConfig.from_dict(bcfg))
+    for p_ in bm.parameters():
+        p_.data.normal_(0, 0.05)
+    torch.save(bm.state_dict(), bdir / 'pytorch_model.bin')
+    cfg = C.build_config(['with', model_name, 'data_name=%s' % name, 'bert_path=%s' % bdir, 'seed=4', 'max_violation=True'])
+    cfg.update(img_dim=8, embed_size=64, head=4, smry_k=12, max_words=12, final_dims=64, trans_cfg=str(bdir / 'trans_cfg.json'),
+               data_path=str(tmp_path / 'data'), batch_size=6, workers=0, vocab_size=n_vocab, use_bbox=(model_name == 'CAMERA'))
+    torch.manual_seed(9)
+    model = get_model(cfg)
+    model.val_start()
+    model.logger = evaluation.LogCollector()
+    ds = dl.PrecompDataset(str(d), 'test', cfg)
+    batch = dl.collate_fn([ds[i] for i in (0, 5, 10, 15, 20, 25)])         # one caption of each of the 6 images
+    images, boxes, imgs_wh, ids, lengths, idx, mask, types = batch
+    wi = {k: v.detach().cpu() for k, v in model.img_enc.state_dict().items() if "num_batches_tracked" not in k}
+    wt = {k: v.detach().cpu() for k, v in model.txt_enc.state_dict().items() if "num_batches_tracked" not in k}
+    if model_name == 'CAMERA':
+        img_emb, cap_emb, smry = model.forward_emb(images, boxes, imgs_wh, ids, mask, types)
+        loss = model.forward_loss(model.mvm(img_emb, cap_emb), smry)
+        o_img, o_smry = O.camera_image(wi, images, boxes, imgs_wh, 4)
+        o_cap = O.camera_text(wt, ids, mask, types, 2, 4, 4)
+        want = O.hinge_loss(O.multi_view_matching(o_img, o_cap), cfg['margin'], True) + cfg['smry_lamda'] * O.diversity_regularization(o_smry)
+    else:
+        img_emb, cap_emb = model.forward_emb(images, ids, mask, types, lengths)
+        loss = model.forward_loss(3, img_emb, cap_emb, lengths, idx)
+        o_img = O.saem_image(wi, images, 4)
+        o_cap = O.saem_text(wt, cfg['txt_stru'], ids, mask, types, 2, 4, 4)
+        reg = sum(float(torch.norm(v)) for k, v in model.img_enc.named_parameters() if k.split('.')[-1] not in ('bias', 'gamma', 'beta'))
+        want = O.hinge_loss(O.pdist_cos(o_img, o_cap), cfg['margin'], True) + 0.5 * O.angular_loss(o_img, o_cap) + 0.01 * reg
+    assert abs(float(loss) - float(want)) <= 1e-4 * max(1.0, abs(float(want)))
