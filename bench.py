@@ -350,6 +350,11 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # build the communicator now (RCCL creates it lazily on the first collective): never inside the timed region,
+        # whatever --warmup is
+        _probe = torch.zeros(1, device=dev if backend != "gloo" else "cpu")
+        dist.all_reduce(_probe)
+        dist.barrier()
 
     from itr_amd import evalpipe, ops
     wl = WORKLOADS[args.workload]
