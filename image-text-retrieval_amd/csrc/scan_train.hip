@@ -29,7 +29,7 @@ struct ScanTrainArgs {
     const int64_t *cap_off;
     const int32_t *cap_len;
     int64_t Bi, Bc;
-    int norm, agg;         // norm: 0 clipped_l2norm, 1 l2norm, 3 no_norm, 4 clipped;  agg: 0 LSE, 1 Max, 2 Sum, 3 Mean
+    int norm, agg;         // norm: 0 clipped_l2norm, 1 l2norm, 2 softmax, 3 no_norm, 4 clipped, 5 l1norm, 6 clipped_l1norm;  agg: 0 LSE, 1 Max, 2 Sum, 3 Mean
     float ls, ll;
     float *S;              // [Bi, Bc]
     // backward only
@@ -59,25 +59,35 @@ __device__ __forceinline__ void pair_forward(const ScanTrainArgs &g, PairSmem &s
     }
     for (int idx = tid; idx < SC_R * SC_R; idx += 256) sm.g[idx / SC_R][idx % SC_R] = g.G[i * SC_R * SC_R + idx];
     __syncthreads();
-    const bool clip = (g.norm == 0 || g.norm == 4), l2 = (g.norm == 0 || g.norm == 1);
+    // first normalisation along the caption's words, one lane per region row: u[r][w] -> sm.p (Objectives.py:436-457)
+    const bool clip = (g.norm == 0 || g.norm == 4 || g.norm == 6), l2 = (g.norm == 0 || g.norm == 1), l1 = (g.norm == 5 || g.norm == 6);
     if (tid < SC_R) {
-        float ss = 0.f;
-        if (l2)
-            for (int w = 0; w < W; ++w) {
-                const float b = clip ? leaky(sm.a[tid][w]) : sm.a[tid][w];
-                ss += b * b;
-            }
-        const float rt = sqrtf(ss);
-        sm.rs[tid] = rt;
-        sm.rn[tid] = l2 ? 1.f / (rt + 1e-8f) : 1.f;
+        const int r = tid;
+        float st = 0.f, mxa = -INFINITY;
+        for (int w = 0; w < W; ++w) {
+            const float b = clip ? leaky(sm.a[r][w]) : sm.a[r][w];
+            st += l2 ? b * b : (l1 ? fabsf(b) : 0.f);
+            mxa = fmaxf(mxa, sm.a[r][w]);
+        }
+        if (l2) st = sqrtf(st);
+        if (g.norm == 2) {                       // softmax over the words
+            st = 0.f;
+            for (int w = 0; w < W; ++w) st += expf(sm.a[r][w] - mxa);
+        }
+        sm.rs[r] = (g.norm == 2) ? mxa : st;     // l2: ||b||, l1: sum |b|, softmax: the row maximum
+        const float rn = (l2 || l1) ? 1.f / (st + 1e-8f) : (g.norm == 2 ? 1.f / st : 1.f);
+        sm.rn[r] = rn;
+        for (int w = 0; w < W; ++w) {
+            const float araw = sm.a[r][w];
+            sm.p[r][w] = (g.norm == 2) ? expf(araw - mxa) * rn : (clip ? leaky(araw) : araw) * rn;
+        }
     }
     __syncthreads();
     if (tid < W) {   // one lane per word: softmax over the 36 regions
         const int w = tid;
         float mx = -INFINITY;
         for (int r = 0; r < SC_R; ++r) {
-            const float b = clip ? leaky(sm.a[r][w]) : sm.a[r][w];
-            const float u = b * sm.rn[r] * g.ls;
+            const float u = sm.p[r][w] * g.ls;
             sm.p[r][w] = u;
             mx = fmaxf(mx, u);
         }
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
         }
     }
     __syncthreads();
-    const bool clip = (g.norm == 0 || g.norm == 4), l2 = (g.norm == 0 || g.norm == 1);
+    const bool clip = (g.norm == 0 || g.norm == 4 || g.norm == 6), l2 = (g.norm == 0 || g.norm == 1), l1 = (g.norm == 5 || g.norm == 6);
     // ---- per word: cosine backward, attention backward through the softmax -> du (kept in da)
     if (tid < W) {
         const int w = tid;
@@ -195,18 +205,23 @@ __global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
     // ---- per region: first-norm backward  u = b * rn,  rn = 1 / (sqrt(sum b^2) + eps)
     if (tid < SC_R) {
         const int r = tid;
-        float dotb = 0.f;
-        if (l2)
-            for (int w = 0; w < W; ++w) {
-                const float b = clip ? leaky(sm.a[r][w]) : sm.a[r][w];
-                dotb += da[r][w] * b;
-            }
         const float rn = sm.rn[r], rt = sm.rs[r];
-        const float k = (l2 && rt > 0.f) ? dotb * rn * rn / rt : 0.f;
+        // dot = sum_w du u-like term of the normalisation's Jacobian
+        float dot = 0.f;
         for (int w = 0; w < W; ++w) {
             const float araw = sm.a[r][w];
             const float b = clip ? leaky(araw) : araw;
-            float db = da[r][w] * rn - b * k;
+            if (l2 || l1) dot += da[r][w] * b;
+            else if (g.norm == 2) dot += da[r][w] * expf(araw - rt) * rn;      // du . u
+        }
+        for (int w = 0; w < W; ++w) {
+            const float araw = sm.a[r][w];
+            const float b = clip ? leaky(araw) : araw;
+            float db;
+            if (l2) db = da[r][w] * rn - (rt > 0.f ? b * dot * rn * rn / rt : 0.f);       // u = b / (||b|| + eps)
+            else if (l1) db = da[r][w] * rn - (b > 0.f ? 1.f : (b < 0.f ? -1.f : 0.f)) * dot * rn * rn;   // u = b / (sum |b| + eps)
+            else if (g.norm == 2) { const float u = expf(araw - rt) * rn; db = u * (da[r][w] - dot); }    // u = softmax_w(a)
+            else db = da[r][w];
             if (clip) db *= (araw > 0.f) ? 1.f : 0.1f;    // LeakyReLU(0.1); slope at exactly 0 = 0.1 like torch
             da[r][w] = db + sm.num[w] * sm.p[r][w];        // + the direct path of num = sum p a
         }
@@ -290,8 +305,7 @@ static int check_train_args(const char *who, int64_t Bi, int64_t Bc, int64_t n_t
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && n_tok >= 1 && D > 0, "%s: bad shape", who);
     ITR_UNSUPPORTED(R != SC_R, "%s: built for %d regions, got %d", who, SC_R, R);
     ITR_UNSUPPORTED(max_len > ST_MAXW, "%s: captions of at most %d words are supported, got %d", who, ST_MAXW, max_len);
-    ITR_UNSUPPORTED(!(norm == 0 || norm == 1 || norm == 3 || norm == 4),
-                    "%s: training supports raw_feature_norm in {clipped_l2norm, l2norm, no_norm, clipped}", who);
+    ITR_REQUIRE(norm >= 0 && norm <= 6, "%s: unknown first norm %d", who, norm);
     ITR_REQUIRE(agg >= 0 && agg <= 3, "%s: unknown aggregation %d", who, agg);
     ITR_UNSUPPORTED(Bi > 65535, "%s: at most 65535 images per training batch", who);
     return ITR_OK;

@@ -132,7 +132,7 @@ def test_gru_backward_vs_oracle_autograd(dev, bi, last):
         assert md(wd[k].grad, wl[k].grad) <= 5e-6, k
 
 
-NORMS = ['clipped_l2norm', 'l2norm', 'no_norm', 'clipped']
+NORMS = ['clipped_l2norm', 'l2norm', 'no_norm', 'clipped', 'softmax', 'l1norm', 'clipped_l1norm']
 AGGS = ['LogSumExp', 'Mean', 'Sum', 'Max']
 
 
@@ -166,8 +166,6 @@ def test_scan_t2i_backward_vs_oracle_autograd(dev, norm, agg):
 
 def test_scan_train_rejects(dev):
     img, words = torch.zeros(2, 36, 32, device=dev), torch.zeros(5, 32, device=dev)
-    with pytest.raises(NotImplementedError):
-        ag.scan_t2i_scores(img, words, [0, 2], [2, 3], 'softmax')
     with pytest.raises(ValueError):
         ag.scan_t2i_scores(img, words, [0, 2], [2, 3], 'bogus')
     with pytest.raises(RuntimeError):
