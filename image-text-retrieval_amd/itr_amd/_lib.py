@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 i32, i64, f32, vp, sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -71,6 +71,10 @@ SIGNATURES = {
     "itr_scan_train_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, vp]),
     "itr_scan_train_bwd": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
     "itr_scan_train_finish": (i32, [vp, i64, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]),
+    "itr_scan_train_i2t_prepare": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, vp]),
+    "itr_scan_train_i2t_fwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, vp]),
+    "itr_scan_train_i2t_bwd": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
+    "itr_scan_train_i2t_finish": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]),
 }
 
 

@@ -300,6 +300,73 @@ def scan_t2i_scores(images, words_packed, cap_off, cap_lens, raw_feature_norm='c
                           _NORMS[raw_feature_norm], _AGGS[agg_func], float(lambda_softmax), float(lambda_lse))
 
 
+class _ScanI2T(torch.autograd.Function):
+    """xattn_score_i2t on a training batch (scan_train_i2t.hip); same padding of the word axis as _ScanT2I."""
+
+    @staticmethod
+    def forward(ctx, V, E, cap_off, cap_len, h_off, h_total, max_len, norm, agg, ls, ll):
+        lib = _lib.load()
+        V = _dev(V, name="images")
+        E = _dev(E, name="words")
+        Bi, R, D = V.shape
+        if E.dim() != 2 or E.shape[1] != D:
+            raise ValueError("scan_i2t_scores: images (.., %d) vs words %s" % (D, tuple(E.shape)))
+        n_tok = E.shape[0]
+        ntp = (n_tok + 31) // 32 * 32
+        Bc = cap_len.numel()
+        dev = V.device
+        V2 = V.reshape(Bi * R, D)
+        Ep = torch.zeros(ntp, D, device=dev, dtype=torch.float32)
+        Ep[:n_tok] = E
+        A = _gemm_nt(V2, Ep)
+        H = _f32(h_total, dev=dev)
+        vnorm = _f32(Bi * R, dev=dev)
+        _lib.check(lib.itr_scan_train_i2t_prepare(_p(V2), _p(Ep), _p(cap_off), _p(cap_len), _p(h_off), Bi, Bc, R, D, _p(H), _p(vnorm), _stream()))
+        S = _f32(Bi, Bc, dev=dev)
+        _lib.check(lib.itr_scan_train_i2t_fwd(_p(A), ntp, _p(H), _p(h_off), _p(vnorm), _p(cap_off), _p(cap_len), Bi, Bc, ntp, R, D, max_len,
+                                              norm, agg, ls, ll, _p(S), _stream()))
+        ctx.save_for_backward(V2, Ep, A, H, vnorm, cap_off, cap_len, h_off)
+        ctx.opts = (Bi, Bc, n_tok, ntp, R, D, max_len, norm, agg, ls, ll, h_total)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        lib = _lib.load()
+        V2, Ep, A, H, vnorm, cap_off, cap_len, h_off = ctx.saved_tensors
+        Bi, Bc, n_tok, ntp, R, D, max_len, norm, agg, ls, ll, h_total = ctx.opts
+        dev = V2.device
+        dS = dS.contiguous()
+        dA = torch.zeros_like(A)
+        dHp = _f32(Bi, h_total, dev=dev)
+        dvnp = _f32(Bc, Bi * R, dev=dev)
+        _lib.check(lib.itr_scan_train_i2t_bwd(_p(A), ntp, _p(H), _p(h_off), h_total, _p(vnorm), _p(cap_off), _p(cap_len), Bi, Bc, ntp, R, D,
+                                              max_len, norm, agg, ls, ll, _p(dS), _p(dA), _p(dHp), _p(dvnp), _stream()))
+        dV = _gemm_nt(dA, transpose2d(Ep))
+        dE = _gemm_nt(transpose2d(dA), transpose2d(V2))
+        dH = colsum(dHp)
+        dvn = colsum(dvnp)
+        _lib.check(lib.itr_scan_train_i2t_finish(_p(dH), _p(h_off), _p(cap_off), _p(cap_len), Bc, _p(Ep), _p(V2), _p(vnorm), _p(dvn), Bi, R, D,
+                                                 _p(dV), _p(dE), _stream()))
+        return (dV.reshape(Bi, R, D), dE[:n_tok]) + (None,) * 9
+
+
+def scan_i2t_scores(images, words_packed, cap_off, cap_lens, raw_feature_norm='clipped_l2norm', agg_func='LogSumExp',
+                    lambda_lse=6.0, lambda_softmax=9.0):
+    """xattn_score_i2t on a training batch -> (n_img, n_cap), differentiable w.r.t. images and words."""
+    if raw_feature_norm not in _NORMS:
+        raise ValueError("unknown first norm type:", raw_feature_norm)
+    if agg_func not in _AGGS:
+        raise ValueError("unknown aggfunc: {}".format(agg_func))
+    lens = _host_i32(cap_lens)
+    dev = images.device
+    off = cap_off if torch.is_tensor(cap_off) else torch.as_tensor(np.asarray(cap_off, np.int64), device=dev)
+    sq = lens.astype(np.int64) ** 2
+    h_off = np.concatenate([[0], np.cumsum(sq)[:-1]]).astype(np.int64)
+    return _ScanI2T.apply(images, words_packed, _dev(off, torch.int64, "cap_off"), torch.from_numpy(lens.copy()).to(dev),
+                          torch.from_numpy(h_off).to(dev), int(sq.sum()), int(lens.max()), _NORMS[raw_feature_norm], _AGGS[agg_func],
+                          float(lambda_softmax), float(lambda_lse))
+
+
 # ------------------------------------------------------------------------------------------ optimizer
 class Adam(object):
     """torch.optim.Adam(params, lr) as the reference builds it (betas (0.9, 0.999), eps 1e-8, no weight decay),

@@ -176,16 +176,16 @@ class SCAN(base_module):
         """One training step (Models.py:198-225)."""
         images, _, _, captions, lengths, _, _, _ = train_data
         cfg = self.config
-        if cfg['cross_attn'] != 't2i':
-            raise NotImplementedError("SCAN training is built for cross_attn='t2i' (the configured default); i2t is evaluation-only")
+        if cfg['cross_attn'] not in ('t2i', 'i2t'):
+            raise ValueError("unknown first norm type:", cfg['raw_feature_norm'])
         self.Eiters += 1
         self._log('Eit', self.Eiters)
         self._log('lr', self.optimizer.param_groups[0]['lr'])
         self.optimizer.zero_grad()
         with torch.enable_grad():
             img, words, off, lens = self._train_towers(images, captions, lengths, pooled_images=False, last_state=False)
-            scores = ag.scan_t2i_scores(img, words, off, lens, cfg['raw_feature_norm'], cfg['agg_func'], cfg['lambda_lse'],
-                                        cfg['lambda_softmax'])
+            score_fn = ag.scan_t2i_scores if cfg['cross_attn'] == 't2i' else ag.scan_i2t_scores
+            scores = score_fn(img, words, off, lens, cfg['raw_feature_norm'], cfg['agg_func'], cfg['lambda_lse'], cfg['lambda_softmax'])
             loss = ops.hinge_loss(scores, cfg['margin'], cfg['max_violation'])
             self._step(loss, img.size(0))
 

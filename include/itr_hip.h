@@ -287,6 +287,28 @@ int itr_scan_train_finish(const float *dG_pairs, int64_t Bi, int64_t Bc, const f
                           const float *enorm, const float *d_enorm, int64_t n_tok, int R, int D, float *dV, float *dE,
                           itr_stream_t stream);
 
+/* SCAN i2t similarity of a TRAINING batch (xattn_score_i2t, Objectives.py:376-417, under autograd): regions attend over
+ * the words of a caption.  A as above; H = packed caption Gram matrices (caption c: W_c x W_c floats at H + h_off[c],
+ * h_total = sum W_c^2) and vnorm[Bi*36] = ||v_r|| (itr_scan_train_i2t_prepare).  itr_scan_train_i2t_bwd writes dA,
+ * per-pair dH partials dH_pairs [Bi, h_total] and d||v|| partials d_vnorm_pairs [Bc, Bi*36]; the caller sums them over
+ * images / captions (itr_colsum), runs  dV = dA E,  dE = dA^T V  and itr_scan_train_i2t_finish, which ADDS
+ * (dH_c + dH_c^T) E_c to dE and  d||v|| v / ||v||  to dV. */
+int itr_scan_train_i2t_prepare(const float *V, const float *E, const int64_t *cap_off, const int32_t *cap_len,
+                               const int64_t *h_off, int64_t Bi, int64_t Bc, int R, int D, float *H, float *vnorm,
+                               itr_stream_t stream);
+int itr_scan_train_i2t_fwd(const float *A, int64_t ldA, const float *H, const int64_t *h_off, const float *vnorm,
+                           const int64_t *cap_off, const int32_t *cap_len, int64_t Bi, int64_t Bc, int64_t n_tok, int R,
+                           int D, int max_len, int norm, int agg, float lambda_softmax, float lambda_lse, float *S,
+                           itr_stream_t stream);
+int itr_scan_train_i2t_bwd(const float *A, int64_t ldA, const float *H, const int64_t *h_off, int64_t h_total,
+                           const float *vnorm, const int64_t *cap_off, const int32_t *cap_len, int64_t Bi, int64_t Bc,
+                           int64_t n_tok, int R, int D, int max_len, int norm, int agg, float lambda_softmax,
+                           float lambda_lse, const float *dS, float *dA, float *dH_pairs, float *d_vnorm_pairs,
+                           itr_stream_t stream);
+int itr_scan_train_i2t_finish(const float *dH, const int64_t *h_off, const int64_t *cap_off, const int32_t *cap_len,
+                              int64_t Bc, const float *E, const float *V, const float *vnorm, const float *d_vnorm,
+                              int64_t Bi, int R, int D, float *dV, float *dE, itr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

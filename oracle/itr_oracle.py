@@ -658,9 +658,7 @@ def gru_model_loss(kind, wi, wt, images, ids, lengths, cfg):
     if kind == 'SCAN':
         img = encoder_image_precomp(images, wi['fc.weight'], wi['fc.bias'], cfg.get('no_imgnorm', False))
         cap, cap_len = encoder_text(ids, lengths, wt, bi, cfg.get('no_txtnorm', False), False, None)
-        if cfg.get('cross_attn', 't2i') != 't2i':
-            raise NotImplementedError
-        scores = xattn_score(img, cap, cap_len, 't2i', cfg.get('raw_feature_norm', 'clipped_l2norm'),
+        scores = xattn_score(img, cap, cap_len, cfg.get('cross_attn', 't2i'), cfg.get('raw_feature_norm', 'clipped_l2norm'),
                              cfg.get('agg_func', 'LogSumExp'), cfg.get('lambda_lse', 6.0), cfg.get('lambda_softmax', 9.0))
     elif kind == 'VSE++':
         img = encoder_image_precomp(images.mean(1), wi['fc.weight'], wi['fc.bias'], cfg.get('no_imgnorm', False))

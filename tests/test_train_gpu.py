@@ -136,9 +136,10 @@ NORMS = ['clipped_l2norm', 'l2norm', 'no_norm', 'clipped', 'softmax', 'l1norm', 
 AGGS = ['LogSumExp', 'Mean', 'Sum', 'Max']
 
 
+@pytest.mark.parametrize("xa", ['t2i', 'i2t'])
 @pytest.mark.parametrize("norm", NORMS)
 @pytest.mark.parametrize("agg", AGGS)
-def test_scan_t2i_backward_vs_oracle_autograd(dev, norm, agg):
+def test_scan_backward_vs_oracle_autograd(dev, norm, agg, xa):
     rng = np.random.RandomState(6)
     torch.manual_seed(6)
     Bi, Bc, D = 5, 7, 64
@@ -149,13 +150,13 @@ def test_scan_t2i_backward_vs_oracle_autograd(dev, norm, agg):
     gS = torch.randn(Bi, Bc)
     a, c = img.clone().requires_grad_(True), cap.clone().requires_grad_(True)
     with torch.enable_grad():
-        S = O.xattn_score(a, c, lens, 't2i', norm, agg, 6.0, 9.0)
+        S = O.xattn_score(a, c, lens, xa, norm, agg, 6.0, 9.0)
         (S * gS).sum().backward()
     off = np.concatenate([[0], np.cumsum(lens)[:-1]])
     words = torch.cat([cap[k, :lens[k]] for k in range(Bc)], 0)
     ad, wd = img.to(dev).requires_grad_(True), words.to(dev).requires_grad_(True)
     with torch.enable_grad():
-        Sd = ag.scan_t2i_scores(ad, wd, off, lens, norm, agg, 6.0, 9.0)
+        Sd = (ag.scan_t2i_scores if xa == 't2i' else ag.scan_i2t_scores)(ad, wd, off, lens, norm, agg, 6.0, 9.0)
         (Sd * gS.to(dev)).sum().backward()
     assert md(Sd, S) <= 2e-5
     want_w = torch.cat([c.grad[k, :lens[k]] for k in range(Bc)], 0)
@@ -232,6 +233,31 @@ def test_scan_train_emb_matches_reference(golden, dev):
         assert model.Eiters == step
         assert abs(float(model.logger.meters['Loss'].val) - float(g["s%d_loss" % step])) <= 1e-4     # north_star: loss within 1e-4
         _check_step(model, g, 's%d_grad_' % step, 's%d_img_' % step, 's%d_txt_' % step, cfg['learning_rate'])
+
+
+def test_scan_i2t_train_emb_vs_oracle_step(golden, dev):
+    """cross_attn='i2t': one train_emb step from the G15 weights against the oracle's restated step (the oracle's step is
+    pinned by the reference's own train_emb for t2i, its i2t similarity by G5)."""
+    g = golden("g15_train_step")
+    cfg_ref = json.loads(bytes(g["cfg_json"]).decode())
+    cfg = C.build_config(['with', 'SCAN', 'data_name=f30k_precomp'])
+    cfg.update({k: v for k, v in cfg_ref.items() if k != "name"})
+    cfg.update(cross_attn='i2t', lambda_softmax=4.0, lambda_lse=5.0, agg_func='Mean')
+    model = get_model(cfg)
+    _load(model, g, 'w0_img_', 'w0_txt_')
+    model.train_start()
+    from itr_amd.metricmodule.evaluation import LogCollector
+    model.logger = LogCollector()
+    lens = [int(x) for x in g["s1_lens"]]
+    feats, ids = T(g["s1_feats"]), T(g["s1_ids"])
+    wi = {k[len('w0_img_'):]: T(g[k]) for k in g.files if k.startswith('w0_img_')}
+    wt = {k[len('w0_txt_'):]: T(g[k]) for k in g.files if k.startswith('w0_txt_')}
+    o_loss, o_grads, nwi, nwt, _ = O.gru_model_train_step('SCAN', wi, wt, feats, ids, lens, cfg, None)
+    model.train_emb((feats, None, None, ids, lens, list(range(len(lens))), None, None))
+    assert abs(float(model.logger.meters['Loss'].val) - float(o_loss)) <= 1e-4
+    coef = min(1.0, 2.0 / (float(model.optimizer.last_grad_norm[0]) + 1e-6))
+    for n, p in [('txt.' + n, p) for n, p in model.txt_enc.named_parameters()] + [('img.' + n, p) for n, p in model.img_enc.named_parameters()]:
+        assert md(p.grad * coef, o_grads[n]) <= 5e-6 * max(1.0, float(o_grads[n].abs().max())), n
 
 
 def test_vsepp_train_emb_matches_reference_components(golden, dev):
