@@ -19,7 +19,8 @@
 
 namespace itr {
 
-constexpr int ST_MAXW = 64;   // words per caption (same bound as the evaluation kernel's tile)
+constexpr int ST_MAXW = 96;   // words per caption: the longest Flickr30k caption has 82 tokens; 96 keeps the pair in 64 KB of static LDS.
+                              // Kernels are instantiated for 64 (3 workgroups per CU: every BASELINE batch) and 96.
 
 struct ScanTrainArgs {
     const float *A;        // [Bi*36, ldA]  raw dot products
@@ -39,19 +40,21 @@ struct ScanTrainArgs {
     float *den;            // [Bi, n_tok]        per (image, word) d||e_w||
 };
 
+template <int MAXW>
 struct PairSmem {
-    float a[SC_R][ST_MAXW + 1];   // raw
-    float p[SC_R][ST_MAXW + 1];   // attention weights
-    float g[SC_R][SC_R + 1];      // Gram
-    float gp[SC_R][ST_MAXW + 1];  // G p
-    float rn[SC_R];               // 1 / (||b[r,:]|| + eps)
-    float rs[SC_R];               // sqrt(sum_w b^2) per region (norm backward)
-    float s[ST_MAXW], num[ST_MAXW], q[ST_MAXW], ds[ST_MAXW];
+    float a[SC_R][MAXW + 1];   // raw
+    float p[SC_R][MAXW + 1];   // attention weights
+    float g[SC_R][SC_R + 1];   // Gram
+    float gp[SC_R][MAXW + 1];  // G p
+    float rn[SC_R];            // 1 / (||b[r,:]|| + eps)
+    float rs[SC_R];            // sqrt(sum_w b^2) per region (norm backward)
+    float s[MAXW], num[MAXW], q[MAXW], ds[MAXW];
     float red;
 };
 
 // everything up to s_w; returns with sm.{a,p,g,gp,rn,rs,s,num,q} valid
-__device__ __forceinline__ void pair_forward(const ScanTrainArgs &g, PairSmem &sm, int64_t i, int64_t c, int W, int64_t off) {
+template <int MAXW>
+__device__ __forceinline__ void pair_forward(const ScanTrainArgs &g, PairSmem<MAXW> &sm, int64_t i, int64_t c, int W, int64_t off) {
     const int tid = threadIdx.x;
     for (int idx = tid; idx < SC_R * W; idx += 256) {
         const int r = idx / W, w = idx - r * W;
@@ -118,8 +121,9 @@ __device__ __forceinline__ void pair_forward(const ScanTrainArgs &g, PairSmem &s
     __syncthreads();
 }
 
+template <int MAXW>
 __global__ __launch_bounds__(256) void scan_train_fwd_kernel(ScanTrainArgs g) {
-    __shared__ PairSmem sm;
+    __shared__ PairSmem<MAXW> sm;
     const int64_t c = blockIdx.x, i = blockIdx.y;
     const int W = g.cap_len[c];
     const int64_t off = g.cap_off[c];
@@ -144,10 +148,11 @@ __global__ __launch_bounds__(256) void scan_train_fwd_kernel(ScanTrainArgs g) {
     }
 }
 
+template <int MAXW>
 __global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
-    __shared__ PairSmem sm;
-    __shared__ float da[SC_R][ST_MAXW + 1];
-    __shared__ float dqs[ST_MAXW];
+    __shared__ PairSmem<MAXW> sm;
+    __shared__ float da[SC_R][MAXW + 1];
+    __shared__ float dqs[MAXW];
     const int tid = threadIdx.x;
     const int64_t c = blockIdx.x, i = blockIdx.y;
     const int W = g.cap_len[c];
@@ -337,7 +342,8 @@ extern "C" int itr_scan_train_fwd(const float *A, int64_t ldA, const float *G, c
     int rc = check_train_args("itr_scan_train_fwd", Bi, Bc, n_tok, R, D, norm, agg, max_len);
     if (rc != ITR_OK) return rc;
     ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, norm, agg, lambda_softmax, lambda_lse, S, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(scan_train_fwd_kernel, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
+    if (max_len <= 64) hipLaunchKernelGGL(scan_train_fwd_kernel<64>, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
+    else hipLaunchKernelGGL(scan_train_fwd_kernel<ST_MAXW>, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
     ITR_CHECK_LAUNCH("scan_train_fwd");
     return ITR_OK;
 }
@@ -350,7 +356,8 @@ extern "C" int itr_scan_train_bwd(const float *A, int64_t ldA, const float *G, c
     int rc = check_train_args("itr_scan_train_bwd", Bi, Bc, n_tok, R, D, norm, agg, max_len);
     if (rc != ITR_OK) return rc;
     ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, norm, agg, lambda_softmax, lambda_lse, nullptr, dS, dA, dG_pairs, d_enorm_pairs};
-    hipLaunchKernelGGL(scan_train_bwd_kernel, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
+    if (max_len <= 64) hipLaunchKernelGGL(scan_train_bwd_kernel<64>, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
+    else hipLaunchKernelGGL(scan_train_bwd_kernel<ST_MAXW>, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
     ITR_CHECK_LAUNCH("scan_train_bwd");
     return ITR_OK;
 }

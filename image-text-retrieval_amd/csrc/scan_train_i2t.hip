@@ -13,7 +13,7 @@
 
 namespace itr {
 
-constexpr int SI_MAXW = 64;
+constexpr int SI_MAXW = 96;    // as scan_train.hip; the W x W caption Gram makes the pair 80 KB -> dynamic LDS
 
 struct ScanI2TArgs {
     const float *A;        // [Bi*36, ldA] raw dot products
@@ -111,7 +111,8 @@ __device__ __forceinline__ void i2t_pair_forward(const ScanI2TArgs &g, I2TSmem &
 }
 
 __global__ __launch_bounds__(256) void scan_train_i2t_fwd_kernel(ScanI2TArgs g) {
-    __shared__ I2TSmem sm;
+    extern __shared__ __attribute__((aligned(16))) char i2t_smem[];
+    I2TSmem &sm = *reinterpret_cast<I2TSmem *>(i2t_smem);
     const int64_t c = blockIdx.x, i = blockIdx.y;
     const int W = g.cap_len[c];
     i2t_pair_forward(g, sm, i, c, W, g.cap_off[c]);
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(256) void scan_train_i2t_fwd_kernel(ScanI2TArgs g) 
 }
 
 __global__ __launch_bounds__(256) void scan_train_i2t_bwd_kernel(ScanI2TArgs g) {
-    __shared__ I2TSmem sm;
+    extern __shared__ __attribute__((aligned(16))) char i2t_smem[];
+    I2TSmem &sm = *reinterpret_cast<I2TSmem *>(i2t_smem);
     __shared__ float dqs[SC_R], dnums[SC_R];
     const int tid = threadIdx.x;
     const int64_t c = blockIdx.x, i = blockIdx.y;
@@ -269,8 +271,45 @@ __global__ __launch_bounds__(256) void rownorm_i2t_kernel(const float *__restric
     if (lane == 0) out[row] = sqrtf(s);
 }
 
-__global__ void gram_kernel(const float *__restrict__ X, const int64_t *__restrict__ row_off, const int32_t *__restrict__ row_cnt, int fixed_rows,
-                            int D, float *__restrict__ G, const int64_t *__restrict__ g_off);
+// H_c = E_c E_c^T for captions of up to SI_MAXW words (the evaluation path's gram_kernel stops at 64 rows):
+// one workgroup per caption, 32-wide slices of D through LDS, up to 36 (row, row) pairs per thread.
+__global__ __launch_bounds__(256) void caption_gram_kernel(const float *__restrict__ E, const int64_t *__restrict__ cap_off,
+                                                           const int32_t *__restrict__ cap_len, int D, float *__restrict__ H,
+                                                           const int64_t *__restrict__ h_off) {
+    __shared__ float xs[SI_MAXW][33];
+    const int64_t c = blockIdx.x;
+    const int W = cap_len[c];
+    const float *x = E + cap_off[c] * (int64_t)D;
+    constexpr int NP = (SI_MAXW * SI_MAXW + 255) / 256;
+    float acc[NP];
+#pragma unroll
+    for (int e = 0; e < NP; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < D; k0 += 32) {
+        for (int idx = threadIdx.x; idx < W * 32; idx += 256) {
+            const int r = idx >> 5, k = idx & 31;
+            xs[r][k] = (k0 + k < D) ? x[(int64_t)r * D + k0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NP; ++e) {
+            const int pidx = threadIdx.x + 256 * e;
+            if (pidx < W * W) {
+                const int r1 = pidx / W, r2 = pidx % W;
+                float s_ = 0.f;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) s_ += xs[r1][k] * xs[r2][k];
+                acc[e] += s_;
+            }
+        }
+        __syncthreads();
+    }
+    float *out = H + h_off[c];
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+        const int pidx = threadIdx.x + 256 * e;
+        if (pidx < W * W) out[pidx] = acc[e];
+    }
+}
 
 static int check_i2t(const char *who, int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int norm, int agg, int max_len) {
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && n_tok >= 1 && D > 0, "%s: bad shape", who);
@@ -292,7 +331,7 @@ extern "C" int itr_scan_train_i2t_prepare(const float *V, const float *E, const 
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && D > 0, "itr_scan_train_i2t_prepare: bad shape");
     ITR_UNSUPPORTED(R != SC_R, "itr_scan_train_i2t_prepare: built for %d regions", SC_R);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Bc), dim3(256), 0, st, E, cap_off, cap_len, 0, D, H, h_off);
+    hipLaunchKernelGGL(caption_gram_kernel, dim3((unsigned)Bc), dim3(256), 0, st, E, cap_off, cap_len, D, H, h_off);
     ITR_CHECK_LAUNCH("scan_train_i2t gram");
     hipLaunchKernelGGL(rownorm_i2t_kernel, dim3((unsigned)ceil_div(Bi * SC_R, 4)), dim3(256), 0, st, V, Bi * SC_R, D, vnorm);
     ITR_CHECK_LAUNCH("scan_train_i2t rownorm");
@@ -307,7 +346,13 @@ extern "C" int itr_scan_train_i2t_fwd(const float *A, int64_t ldA, const float *
     int rc = check_i2t("itr_scan_train_i2t_fwd", Bi, Bc, n_tok, R, D, norm, agg, max_len);
     if (rc != ITR_OK) return rc;
     ScanI2TArgs g{A, ldA, H, h_off, vnorm, cap_off, cap_len, Bi, Bc, 0, norm, agg, lambda_softmax, lambda_lse, S, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(scan_train_i2t_fwd_kernel, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
+    static bool attr_f = false;
+    if (!attr_f) {
+        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_train_i2t_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)sizeof(I2TSmem)));
+        attr_f = true;
+    }
+    hipLaunchKernelGGL(scan_train_i2t_fwd_kernel, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), sizeof(I2TSmem), as_stream(stream), g);
     ITR_CHECK_LAUNCH("scan_train_i2t_fwd");
     return ITR_OK;
 }
@@ -322,7 +367,13 @@ extern "C" int itr_scan_train_i2t_bwd(const float *A, int64_t ldA, const float *
     if (rc != ITR_OK) return rc;
     ScanI2TArgs g{A, ldA, H, h_off, vnorm, cap_off, cap_len, Bi, Bc, h_total, norm, agg, lambda_softmax, lambda_lse, nullptr, dS, dA, dH_pairs,
                   d_vnorm_pairs};
-    hipLaunchKernelGGL(scan_train_i2t_bwd_kernel, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
+    static bool attr_b = false;
+    if (!attr_b) {
+        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_train_i2t_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)sizeof(I2TSmem)));
+        attr_b = true;
+    }
+    hipLaunchKernelGGL(scan_train_i2t_bwd_kernel, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), sizeof(I2TSmem), as_stream(stream), g);
     ITR_CHECK_LAUNCH("scan_train_i2t_bwd");
     return ITR_OK;
 }

@@ -268,7 +268,7 @@ int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *le
 
 /* SCAN t2i similarity of a TRAINING batch (xattn_score_t2i, Objectives.py:329-372, under autograd).
  *   A [Bi*36, ldA] = V E^T  raw dot products (itr_gemm_nt), G [Bi, 36, 36] = V_i V_i^T and enorm[n_tok] = ||e_w||
- *   (itr_scan_train_prepare);  captions packed: cap_off[Bc], cap_len[Bc] (any order), at most 64 words.
+ *   (itr_scan_train_prepare);  captions packed: cap_off[Bc], cap_len[Bc] (any order), at most 96 words.
  *   norm in {0 clipped_l2norm, 1 l2norm, 2 softmax, 3 no_norm, 4 clipped, 5 l1norm, 6 clipped_l1norm};
  *   agg in {0 LogSumExp, 1 Max, 2 Sum, 3 Mean}.
  * itr_scan_train_bwd (dS [Bi, Bc]) writes dA [Bi*36, ldA], per-pair Gram gradients dG_pairs [Bi, Bc, 36, 36] and

@@ -165,6 +165,34 @@ def test_scan_backward_vs_oracle_autograd(dev, norm, agg, xa):
     assert md(wd.grad, want_w) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("xa", ['t2i', 'i2t'])
+def test_scan_train_long_captions(dev, xa):
+    """Training batches may hold captions of up to 96 tokens (the longest Flickr30k caption has 82)."""
+    torch.manual_seed(11)
+    Bi, D = 3, 32
+    lens = [96, 70, 3]
+    img = O.l2norm(torch.randn(Bi, 36, D), -1)
+    cap = torch.randn(len(lens), max(lens), D) * 0.5
+    gS = torch.randn(Bi, len(lens))
+    a, c = img.clone().requires_grad_(True), cap.clone().requires_grad_(True)
+    with torch.enable_grad():
+        S = O.xattn_score(a, c, lens, xa, 'clipped_l2norm', 'LogSumExp', 6.0, 9.0)
+        (S * gS).sum().backward()
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    words = torch.cat([cap[k, :lens[k]] for k in range(len(lens))], 0)
+    ad, wd = img.to(dev).requires_grad_(True), words.to(dev).requires_grad_(True)
+    fn = ag.scan_t2i_scores if xa == 't2i' else ag.scan_i2t_scores
+    with torch.enable_grad():
+        Sd = fn(ad, wd, off, lens, 'clipped_l2norm', 'LogSumExp', 6.0, 9.0)
+        (Sd * gS.to(dev)).sum().backward()
+    assert md(Sd, S) <= 2e-5
+    want_w = torch.cat([c.grad[k, :lens[k]] for k in range(len(lens))], 0)
+    scale = max(1.0, float(a.grad.abs().max()), float(want_w.abs().max()))
+    assert md(ad.grad, a.grad) <= 2e-5 * scale and md(wd.grad, want_w) <= 2e-5 * scale
+    with pytest.raises(NotImplementedError):
+        fn(ad, torch.zeros(97, D, device=dev), [0], [97])
+
+
 def test_scan_train_rejects(dev):
     img, words = torch.zeros(2, 36, 32, device=dev), torch.zeros(5, 32, device=dev)
     with pytest.raises(ValueError):
