@@ -212,24 +212,39 @@ def hinge_loss(scores, margin=0.2, max_violation=False):
 
 # ------------------------------------------------------------------------------------------
 class ScanPlan:
-    """Column-tile plan of a caption set for the SCAN kernel (host-side, cheap, reusable)."""
+    """Column-tile plan of a caption set for the SCAN kernel (host-side, cheap, reusable).
+
+    The fused kernel packs whole captions into 64-column tiles, so a caption of more than 64 words does not fit
+    (Flickr30k has a few, up to 82 tokens).  Such captions are planned separately: the kernel scores the others and
+    scan_xattn_scores fills their columns with the one-workgroup-per-pair forward of the training path
+    (csrc/scan_train*.hip, up to 96 words).  `Nc` is always the full caption count."""
 
     def __init__(self, cap_off, cap_len, n_rows, device):
         lib = _lib.load()
         self.len_host = _host_i32(cap_len)
+        self.off_host = np.asarray(cap_off, dtype=np.int64)
         self.Nc = len(self.len_host)
         self.n_rows = int(n_rows)
-        tb = np.zeros(self.Nc + 1, dtype=np.int32)
-        order = np.zeros(max(self.Nc, 1), dtype=np.int32)
+        self.device = device
+        long_mask = self.len_host > SCAN_NT
+        self.long_idx = np.nonzero(long_mask)[0] if long_mask.any() else None
+        if self.long_idx is None:
+            k_len, k_off = self.len_host, self.off_host
+        else:
+            self.short_idx = np.nonzero(~long_mask)[0]
+            k_len, k_off = np.ascontiguousarray(self.len_host[self.short_idx]), self.off_host[self.short_idx]
+        self.Nc_kernel = len(k_len)
+        tb = np.zeros(self.Nc_kernel + 1, dtype=np.int32)
+        order = np.zeros(max(self.Nc_kernel, 1), dtype=np.int32)
         nt = C.c_int64(0)
-        _lib.check(lib.itr_scan_plan_tiles(self.len_host.ctypes.data_as(C.c_void_p), self.Nc, SCAN_NT,
+        _lib.check(lib.itr_scan_plan_tiles(k_len.ctypes.data_as(C.c_void_p), self.Nc_kernel, SCAN_NT,
                                            tb.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p),
                                            C.byref(nt)))
         self.n_tiles = int(nt.value)
         self.tile_begin = torch.from_numpy(tb[:self.n_tiles + 1].copy()).to(device)
         self.cap_order = torch.from_numpy(order).to(device)
-        self.cap_len = torch.from_numpy(self.len_host.copy()).to(device)
-        self.cap_off = torch.as_tensor(np.asarray(cap_off, dtype=np.int64)).to(device)
+        self.cap_len = torch.from_numpy(k_len.copy()).to(device)
+        self.cap_off = torch.as_tensor(np.asarray(k_off, dtype=np.int64)).to(device)
 
 
 def scan_prepare(images, words, plan, cross_attn='t2i'):
@@ -239,12 +254,12 @@ def scan_prepare(images, words, plan, cross_attn='t2i'):
     images = _dev(images, name="images")
     words = _dev(words, name="words")
     Ni, R, D = images.shape
-    wsb = lib.itr_scan_workspace_bytes(Ni, R, words.shape[0], plan.Nc, plan.n_tiles, D)
+    wsb = lib.itr_scan_workspace_bytes(Ni, R, words.shape[0], plan.Nc_kernel, plan.n_tiles, D)
     ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
-    if Ni == 0 or plan.Nc == 0:
+    if Ni == 0 or plan.Nc_kernel == 0:
         return ws                      # nothing to prepare: the score matrix is empty
     _lib.check(lib.itr_scan_prepare(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
-                                    _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc, words.shape[0], R, D,
+                                    _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc_kernel, words.shape[0], R, D,
                                     0 if cross_attn == 't2i' else 1, _p(ws), wsb, _stream()))
     return ws
 
@@ -268,11 +283,37 @@ def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='c
         out = torch.empty(Ni, plan.Nc, device=images.device, dtype=torch.float32)
     if Ni == 0 or plan.Nc == 0:
         return out
+    if plan.long_idx is not None:
+        return _scan_scores_with_long_captions(images, words, plan, cross_attn, raw_feature_norm, agg_func, lambda_lse, lambda_softmax,
+                                               out, workspace)
     ws = workspace if workspace is not None else scan_prepare(images, words, plan, cross_attn)
     _lib.check(lib.itr_scan_xattn_scores(
         _p(images), plan.n_tiles, Ni, plan.Nc, n_rows, R, D, 0 if cross_attn == 't2i' else 1,
         _NORMS[raw_feature_norm], _AGGS[agg_func], float(lambda_softmax), float(lambda_lse), _p(out), out.stride(0),
         _p(ws), ws.numel(), _stream()))
+    return out
+
+
+def _scan_scores_with_long_captions(images, words, plan, cross_attn, norm, agg, lambda_lse, lambda_softmax, out, workspace):
+    """Captions of 65..96 words (ScanPlan docstring): fused kernel for the rest, pair kernels for these."""
+    from . import autograd
+    lib = _lib.load()
+    Ni, R, D = images.shape
+    dev = images.device
+    if plan.Nc_kernel:
+        ws = workspace if workspace is not None else scan_prepare(images, words, plan, cross_attn)
+        part = torch.empty(Ni, plan.Nc_kernel, device=dev, dtype=torch.float32)
+        _lib.check(lib.itr_scan_xattn_scores(
+            _p(images), plan.n_tiles, Ni, plan.Nc_kernel, words.shape[0], R, D, 0 if cross_attn == 't2i' else 1, _NORMS[norm],
+            _AGGS[agg], float(lambda_softmax), float(lambda_lse), _p(part), part.stride(0), _p(ws), ws.numel(), _stream()))
+        out[:, torch.from_numpy(plan.short_idx).to(dev)] = part
+    lens = plan.len_host[plan.long_idx]
+    rows = np.concatenate([np.arange(plan.off_host[c], plan.off_host[c] + plan.len_host[c]) for c in plan.long_idx])
+    w_long = words[torch.from_numpy(rows).to(dev)].contiguous()
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    fn = autograd.scan_t2i_scores if cross_attn == 't2i' else autograd.scan_i2t_scores
+    with torch.no_grad():
+        out[:, torch.from_numpy(plan.long_idx).to(dev)] = fn(images, w_long, off, lens, norm, agg, lambda_lse, lambda_softmax)
     return out
 
 
@@ -450,6 +491,8 @@ def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, ou
         out = torch.empty(Ni, plan.Nc, device=images.device, dtype=torch.float32)
     wsb = lib.itr_sgraf_workspace_bytes(Ni, plan.Nc, words.shape[0], plan.n_tiles, D, S_dim, mod)
     ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
+    if plan.long_idx is not None:
+        raise NotImplementedError("sgraf_scores: captions of at most 63 words are supported")
     max_len = int(plan.len_host.max()) if plan.Nc else 1
     _lib.check(lib.itr_sgraf_scores(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
                                     _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc, words.shape[0], max_len, R, D, S_dim,

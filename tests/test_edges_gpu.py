@@ -35,8 +35,14 @@ def test_longest_caption_and_exact_tile_fill(dev, xa):
     want = O.xattn_score(img, cap, lens, xa)
     got = ops.scan_xattn_padded(img.to(dev), cap.to(dev), lens, cross_attn=xa)
     assert float((got.cpu() - want).abs().max()) <= 2e-5
+    # 65..96 words: scored by the pair kernels of the training path (no 64-column tile holds them); 97 is rejected
+    lens2 = [82, 5, 96, 64, 65]
+    cap2 = torch.randn(len(lens2), 96, D) * 0.5
+    want2 = O.xattn_score(img, cap2, lens2, xa)
+    got2 = ops.scan_xattn_padded(img.to(dev), cap2.to(dev), lens2, cross_attn=xa)
+    assert float((got2.cpu() - want2).abs().max()) <= 2e-5
     with pytest.raises(NotImplementedError):
-        ops.scan_xattn_padded(img.to(dev), torch.randn(1, 65, D, device=dev), [65], cross_attn=xa)
+        ops.scan_xattn_padded(img.to(dev), torch.randn(1, 97, D, device=dev), [97], cross_attn=xa)
     with pytest.raises((ValueError, NotImplementedError)):
         ops.scan_xattn_padded(img.to(dev), cap.to(dev), [64, 16, 16, 16, 16, 0], cross_attn=xa)   # zero-length caption
 
