@@ -8,6 +8,7 @@
 // into one MFMA GEMM [n_tok, E] x [E, 3D]; each time step is then one MFMA GEMM on the active
 // prefix (h[0:n_t] x W_hh^T) plus one fused gate kernel (sigmoid / tanh / state update / output
 // write, direction average and last-step gather folded in).
+#include <stdlib.h>
 #include "itr_common.h"
 
 namespace itr {
@@ -16,6 +17,12 @@ int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const floa
             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
 int norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, int kind, int take_abs,
               hipStream_t st);
+// skinny GEMMs of the recurrence when the batch is small (the reference-shaped encode_data path feeds 128 captions at
+// a time): split-K with a deterministic reduction (gemm_f32.hip)
+int gemm_splitk_choice(int64_t M, int64_t N, int64_t K);
+size_t gemm_splitk_scratch_bytes(int64_t M, int64_t N, int splits);
+int gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N,
+                   int64_t K, int act, int accumulate, int splits, float *scratch, hipStream_t st);
 
 // x rows are padded with zeros to Ep = E rounded up to 32 columns (300 -> 320) so that the input projection runs on
 // the branch-free GEMM path (K % 32 == 0); the matching zero-padded copy of W_ih is made by pad_cols_kernel.
@@ -74,9 +81,12 @@ __global__ void gather_last_kernel(const float *__restrict__ out, const int64_t 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GruWs {
-    float *x, *gi, *gh, *h, *out_tmp, *wpad;
+    float *x, *gi, *gh, *h, *out_tmp, *wpad, *skbuf;
     int *bad;
 };
+
+// split-K scratch only for batches that need it (<= 1024 captions: 16 slices x B x 3D floats <= 200 MB)
+static inline size_t gru_splitk_bytes(int64_t B, int D) { return B <= 1024 ? gemm_splitk_scratch_bytes(B, 3 * D, 16) : 0; }
 
 static inline int pad32(int E) { return (E + 31) / 32 * 32; }
 
@@ -89,6 +99,7 @@ static GruWs carve(void *ws, int64_t n_tok, int64_t B, int E, int D) {
     w.h = reinterpret_cast<float *>(p); p += al256((size_t)B * D * 4);
     w.out_tmp = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * D * 4);
     w.wpad = reinterpret_cast<float *>(p); p += al256((size_t)3 * D * pad32(E) * 4);
+    w.skbuf = reinterpret_cast<float *>(p); p += al256(gru_splitk_bytes(B, D));
     w.bad = reinterpret_cast<int *>(p);
     return w;
 }
@@ -115,7 +126,8 @@ extern "C" size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D
     using itr::al256;
     (void)bidirectional;
     return al256((size_t)n_tok * itr::pad32(E) * 4) + al256((size_t)n_tok * 3 * D * 4) + al256((size_t)B * 3 * D * 4) +
-           al256((size_t)B * D * 4) + al256((size_t)n_tok * D * 4) + al256((size_t)3 * D * itr::pad32(E) * 4) + 256;
+           al256((size_t)B * D * 4) + al256((size_t)n_tok * D * 4) + al256((size_t)3 * D * itr::pad32(E) * 4) +
+           al256(itr::gru_splitk_bytes(B, D)) + 256;
 }
 
 extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev,
@@ -148,6 +160,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
 
     ITR_CHECK_HIP(hipMemsetAsync(w.bad, 0, sizeof(int), st));
     const int Ep = pad32(E);
+    const int splits_h = (B <= 1024 && !getenv("ITR_GRU_NO_SPLITK")) ? gemm_splitk_choice(B, 3 * D, D) : 1;   // env: A/B switch for tools/
     hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, Ep, w.x,
                        w.bad);
     ITR_CHECK_LAUNCH("embed_gather");
@@ -167,7 +180,8 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
         int64_t n_act = B;
         for (int t = 0; t < Lmax; ++t) {
             while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
-            rc = gemm_nt(w.h, D, wh, D, bh, w.gh, 3 * D, n_act, 3 * D, D, 0, st);
+            rc = (splits_h > 1) ? gemm_nt_splitk(w.h, D, wh, D, bh, w.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, w.skbuf, st)
+                                : gemm_nt(w.h, D, wh, D, bh, w.gh, 3 * D, n_act, 3 * D, D, 0, st);
             if (rc != ITR_OK) return rc;
             dim3 grid((unsigned)n_act, (unsigned)ceil_div(D, 256));
             hipLaunchKernelGGL(gru_gate_kernel, grid, dim3(256), 0, st, w.gi, w.gh, w.h, seq, tok_off, len_dev, t, dir,
