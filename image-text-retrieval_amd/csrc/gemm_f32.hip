@@ -450,6 +450,27 @@ int gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, con
     return ITR_OK;
 }
 
+// Slices only: scratch[s][m][n] (s < *n_slices) holds the raw partial products; the CONSUMER adds them (in slice order) --
+// the GRU gate kernels do, which saves one launch and one pass per time step.
+int gemm_nt_splitk_partials(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int64_t N, int64_t K, int splits, float *scratch,
+                            int *n_slices, hipStream_t st) {
+    *n_slices = 0;
+    if (M == 0 || N == 0) return ITR_OK;
+    const int64_t ksplit = ceil_div(ceil_div(K, (int64_t)(splits > 1 ? splits : 1)), (int64_t)BK) * BK;
+    const int ns = (int)ceil_div(K, ksplit);
+    GemmArgs g{A, B, nullptr, scratch, lda, ldb, N, M, N, K, 0, 1, BM, nullptr, nullptr, 0, 0, ksplit, scratch};
+    const int64_t nblk = ceil_div(M, BM) * ceil_div(N, BN);
+    const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    if (aligned)
+        hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3((unsigned)nblk, (unsigned)ns), dim3(GEMM_THREADS), 0, st, g);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3((unsigned)nblk, (unsigned)ns), dim3(GEMM_THREADS), 0, st, g);
+    ITR_CHECK_LAUNCH("gemm_nt(split-K partials)");
+    *n_slices = ns;
+    return ITR_OK;
+}
+
 int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
     GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, 0, 0, nullptr};

@@ -15,6 +15,7 @@
 // then, over ALL tokens at once (MFMA GEMMs on transposed operands):
 //     dW_hh = dgh^T H_prev    db_hh = colsum(dgh)    dW_ih = dgi^T X    db_ih = colsum(dgi)    dX (+)= dgi W_ih
 // and dE[token] += dX (atomic scatter; the only non-deterministic summation order of the step).
+#include <stdlib.h>
 #include "itr_common.h"
 
 namespace itr {
@@ -28,6 +29,8 @@ int gemm_splitk_choice(int64_t M, int64_t N, int64_t K);
 size_t gemm_splitk_scratch_bytes(int64_t M, int64_t N, int splits);
 int gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N,
                    int64_t K, int act, int accumulate, int splits, float *scratch, hipStream_t st);
+int gemm_nt_splitk_partials(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int64_t N, int64_t K, int splits, float *scratch,
+                            int *n_slices, hipStream_t st);
 
 __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
 
@@ -52,19 +55,26 @@ static GruSave save_planes(void *save, int dir, int64_t n_tok, int D) {
 }
 
 // forward step; mode 0: out[row] = h', mode 1: out[row] = (out[row] + h') / 2
+// ns > 0: `gh` holds ns split-K slices [ns][n_act][3D] of h W_hh^T (no bias): they are summed here, in slice order, + b_hh.
 __global__ __launch_bounds__(256) void gru_gate_train_kernel(const float *__restrict__ gi, const float *__restrict__ gh, float *__restrict__ h,
                                                              float *__restrict__ out, GruSave sv, const int64_t *__restrict__ tok_off,
                                                              const int32_t *__restrict__ len, int t, int reverse, int mode, int D,
-                                                             int64_t n_act) {
+                                                             int64_t n_act, int ns, const float *__restrict__ b_hh) {
     const int64_t b = blockIdx.x;
     const int j = blockIdx.y * blockDim.x + threadIdx.x;
     if (b >= n_act || j >= D) return;
     const int64_t row = tok_off[b] + (reverse ? (len[b] - 1 - t) : t);
     const float *gir = gi + row * 3 * D;
     const float *ghr = gh + b * 3 * D;
-    const float r = sigm(gir[j] + ghr[j]);
-    const float z = sigm(gir[D + j] + ghr[D + j]);
-    const float ghn = ghr[2 * D + j];
+    float g0 = ghr[j], g1 = ghr[D + j], g2 = ghr[2 * D + j];
+    if (ns > 0) {
+        const int64_t ss = n_act * 3 * (int64_t)D;
+        for (int s_ = 1; s_ < ns; ++s_) { g0 += ghr[s_ * ss + j]; g1 += ghr[s_ * ss + D + j]; g2 += ghr[s_ * ss + 2 * D + j]; }
+        g0 += b_hh[j]; g1 += b_hh[D + j]; g2 += b_hh[2 * D + j];
+    }
+    const float r = sigm(gir[j] + g0);
+    const float z = sigm(gir[D + j] + g1);
+    const float ghn = g2;
     const float n = tanhf(gir[2 * D + j] + r * ghn);
     const float hp = h[b * D + j];
     const float hn = (1.f - z) * n + z * hp;
@@ -77,7 +87,8 @@ __global__ __launch_bounds__(256) void gru_gate_train_kernel(const float *__rest
 __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float *__restrict__ d_out, float dscale, GruSave sv, float *__restrict__ carry,
                                                            float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dgh_step,
                                                            float *__restrict__ hprev_all, const int64_t *__restrict__ tok_off,
-                                                           const int32_t *__restrict__ len, int t, int reverse, int D, int64_t n_act) {
+                                                           const int32_t *__restrict__ len, int t, int reverse, int D, int64_t n_act,
+                                                           const float *__restrict__ part, int ns, int64_t prev_n) {
     const int64_t b = blockIdx.x;
     const int j = blockIdx.y * blockDim.x + threadIdx.x;
     if (b >= n_act || j >= D) return;
@@ -86,7 +97,12 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float *__restri
     const int64_t o = row * D + j;
     const float hp = (t > 0) ? sv.h[(row + (reverse ? 1 : -1)) * D + j] : 0.f;   // the state this step started from
     const float r = sv.r[o], z = sv.z[o], n = sv.n[o], ghn = sv.ghn[o];
-    const float dh = d_out[o] * dscale + carry[b * D + j];
+    float cin = carry[b * D + j];
+    if (ns > 0 && b < prev_n) {          // dgh W_hh of the step processed just before (time t + 1), still in split-K slices
+        const int64_t ss = prev_n * (int64_t)D;
+        for (int s_ = 0; s_ < ns; ++s_) cin += part[s_ * ss + b * D + j];
+    }
+    const float dh = d_out[o] * dscale + cin;
     const float dn = dh * (1.f - z) * (1.f - n * n);
     const float dz = dh * (hp - n) * z * (1.f - z);
     const float dr = dn * ghn * r * (1.f - r);
@@ -185,6 +201,7 @@ extern "C" int itr_gru_fwd_train(const int64_t *tokens, const int64_t *tok_off, 
     float *skbuf = reinterpret_cast<float *>(static_cast<char *>(workspace) + itr_gru_train_workspace_bytes(n_tok, B, E, D) -
                                              al256(gemm_splitk_scratch_bytes(B, 3 * D, 16)));
     const int splits_h = gemm_splitk_choice(B, 3 * D, D);
+    const bool fuse = getenv("ITR_GRU_REDUCE_KERNEL") == nullptr;   // tools/ A/B switch: separate reduction kernel
     const int Lmax = len_host[0];
     ITR_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
     hipLaunchKernelGGL(embed_gather_train_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, x, bad);
@@ -199,10 +216,12 @@ extern "C" int itr_gru_fwd_train(const int64_t *tokens, const int64_t *tok_off, 
         int64_t n_act = B;
         for (int t = 0; t < Lmax; ++t) {
             while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
-            rc = gemm_nt_splitk(h, D, wh, D, bh, gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, skbuf, st);
+            int ns = 0;
+            if (splits_h > 1 && fuse) rc = gemm_nt_splitk_partials(h, D, wh, D, n_act, 3 * D, D, splits_h, skbuf, &ns, st);
+            else rc = gemm_nt_splitk(h, D, wh, D, bh, gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, skbuf, st);
             if (rc != ITR_OK) return rc;
-            hipLaunchKernelGGL(gru_gate_train_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, gi, gh, h, out, sv,
-                               tok_off, len_dev, t, dir, dir, D, n_act);
+            hipLaunchKernelGGL(gru_gate_train_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, gi,
+                               ns > 0 ? skbuf : gh, h, out, sv, tok_off, len_dev, t, dir, dir, D, n_act, ns, bh);
             ITR_CHECK_LAUNCH("gru_gate(train)");
         }
     }
@@ -242,6 +261,7 @@ extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const 
     float *skbuf = reinterpret_cast<float *>(static_cast<char *>(workspace) + itr_gru_train_workspace_bytes(n_tok, B, E, D) -
                                              al256(gemm_splitk_scratch_bytes(B, 3 * D, 16)));
     const int splits_c = gemm_splitk_choice(B, D, 3 * D);
+    const bool fuse = getenv("ITR_GRU_REDUCE_KERNEL") == nullptr;
     const int Lmax = len_host[0];
     const int64_t nparts = ceil_div(n_tok, 256);
     ITR_UNSUPPORTED(nparts > 65535, "itr_gru_bwd: more than 16M tokens");
@@ -258,13 +278,23 @@ extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const 
         GB_TRY(transpose(wh, whhT, 3 * D, D, 3 * D, st));    // [3D, D] -> [D, 3D]:  carry += dgh_step . W_hh  ==  gemm_nt(dgh_step, W_hh^T)
         GB_TRY(transpose(wi, wihT, 3 * D, E, 3 * D, st));    // [3D, E] -> [E, 3D]
         ITR_CHECK_HIP(hipMemsetAsync(carry, 0, (size_t)B * D * 4, st));
+        int ns_pending = 0;
+        int64_t prev_n = 0;
         for (int t = Lmax - 1; t >= 0; --t) {
             int64_t n_act = 0;
             while (n_act < B && len_host[n_act] > t) ++n_act;
             hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, d_out, bi ? 0.5f : 1.f,
-                               sv, carry, dgi, dgh, dgh_step, hprev, tok_off, len_dev, t, dir, D, n_act);
+                               sv, carry, dgi, dgh, dgh_step, hprev, tok_off, len_dev, t, dir, D, n_act, skbuf, ns_pending, prev_n);
             ITR_CHECK_LAUNCH("gru_gate_bwd");
-            if (t > 0) GB_TRY(gemm_nt_splitk(dgh_step, 3 * D, whhT, 3 * D, nullptr, carry, D, n_act, D, 3 * D, 0, 1, splits_c, skbuf, st));
+            ns_pending = 0;
+            if (t > 0) {
+                if (splits_c > 1 && fuse) {   // slices of dgh W_hh stay in scratch: the next gate kernel adds them to carry
+                    GB_TRY(gemm_nt_splitk_partials(dgh_step, 3 * D, whhT, 3 * D, n_act, D, 3 * D, splits_c, skbuf, &ns_pending, st));
+                    prev_n = n_act;
+                } else {
+                    GB_TRY(gemm_nt_splitk(dgh_step, 3 * D, whhT, 3 * D, nullptr, carry, D, n_act, D, 3 * D, 0, 1, splits_c, skbuf, st));
+                }
+            }
         }
         // weight gradients over all tokens
         GB_TRY(transpose(dgh, gT, n_tok, 3 * D, ntp, st));          // token axis zero-padded to ntp (K % 32 == 0)

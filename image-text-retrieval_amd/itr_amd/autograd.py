@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .ops import _dev, _p, _stream, _host_i32, _NORMS, _AGGS
+from .ops import _dev, _p, _stream, _host_i32, _NORMS, _AGGS, h2d
 
 
 def _f32(*shape, dev):
@@ -207,7 +207,7 @@ def gru_sequence(tokens_packed, tok_off, lengths, embed, rnn_params, bidirection
     """Raw packed GRU outputs (n_tok, D) = (fwd + bwd) / 2 for a bi-GRU, differentiable w.r.t. the weights.
     rnn_params: dict of nn.GRU parameters (weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0[, *_reverse])."""
     len_host = _host_i32(lengths)
-    len_dev = torch.from_numpy(len_host.copy()).to(tokens_packed.device)
+    len_dev = h2d(len_host.copy(), tokens_packed.device)
     names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
     w = [rnn_params[n] for n in names]
     if bidirectional:
@@ -295,8 +295,8 @@ def scan_t2i_scores(images, words_packed, cap_off, cap_lens, raw_feature_norm='c
         raise ValueError("unknown aggfunc: {}".format(agg_func))
     lens = _host_i32(cap_lens)
     dev = images.device
-    off = cap_off if torch.is_tensor(cap_off) else torch.as_tensor(np.asarray(cap_off, np.int64), device=dev)
-    return _ScanT2I.apply(images, words_packed, _dev(off, torch.int64, "cap_off"), torch.from_numpy(lens.copy()).to(dev), int(lens.max()),
+    off = cap_off if torch.is_tensor(cap_off) else h2d(np.asarray(cap_off, np.int64), dev)
+    return _ScanT2I.apply(images, words_packed, _dev(off, torch.int64, "cap_off"), h2d(lens.copy(), dev), int(lens.max()),
                           _NORMS[raw_feature_norm], _AGGS[agg_func], float(lambda_softmax), float(lambda_lse))
 
 
@@ -359,11 +359,11 @@ def scan_i2t_scores(images, words_packed, cap_off, cap_lens, raw_feature_norm='c
         raise ValueError("unknown aggfunc: {}".format(agg_func))
     lens = _host_i32(cap_lens)
     dev = images.device
-    off = cap_off if torch.is_tensor(cap_off) else torch.as_tensor(np.asarray(cap_off, np.int64), device=dev)
+    off = cap_off if torch.is_tensor(cap_off) else h2d(np.asarray(cap_off, np.int64), dev)
     sq = lens.astype(np.int64) ** 2
     h_off = np.concatenate([[0], np.cumsum(sq)[:-1]]).astype(np.int64)
-    return _ScanI2T.apply(images, words_packed, _dev(off, torch.int64, "cap_off"), torch.from_numpy(lens.copy()).to(dev),
-                          torch.from_numpy(h_off).to(dev), int(sq.sum()), int(lens.max()), _NORMS[raw_feature_norm], _AGGS[agg_func],
+    return _ScanI2T.apply(images, words_packed, _dev(off, torch.int64, "cap_off"), h2d(lens.copy(), dev),
+                          h2d(h_off, dev), int(sq.sum()), int(lens.max()), _NORMS[raw_feature_norm], _AGGS[agg_func],
                           float(lambda_softmax), float(lambda_lse))
 
 

@@ -5,6 +5,7 @@ train_start / state_dict / load_state_dict.  Towers and losses run on the HIP ke
 `train_emb` (forward -> hinge -> backward -> clip_grad_norm_ -> Adam, Models.py:115-145, :198-225) is built for the
 GRU family with a pooled or SCAN t2i similarity (VSE++, SCAN): itr_amd/autograd.py wires the HIP forward / backward
 kernels into torch's tape.  SGRAF / SAEM / CAMERA training (backward through EncoderSimilarity / BERT) is not built."""
+import numpy as np
 import torch
 from torch import nn
 
@@ -83,7 +84,7 @@ class base_module(nn.Module):
         toks, off, lens, _ = TextEncoder.pack_tokens(captions, lengths)
         seq = ag.gru_sequence(toks, off, lens, te.embed.weight, dict(te.rnn.named_parameters()), te.use_bi_gru)
         if last_state:
-            last = off + torch.as_tensor(lens, device=off.device, dtype=torch.int64) - 1
+            last = off + ops.h2d(np.asarray(lens, np.int64), off.device) - 1
             seq = ag.gather_rows(seq, last)
         if not te.no_txtnorm:
             seq = ag.l2norm_rows(seq)
@@ -91,7 +92,7 @@ class base_module(nn.Module):
 
     def _step(self, loss, batch_size):
         """backward -> clip_grad_norm_(params, grad_clip) -> Adam (Models.py:139-144, :220-225)."""
-        self._log('Loss', float(loss.detach()), batch_size)
+        self._log('Loss', loss.detach(), batch_size)      # a device scalar like the reference's loss.data: no host sync here
         loss.backward()
         self.optimizer.step(max_norm=self.grad_clip if self.grad_clip > 0 else 0.0)
 

@@ -9,14 +9,17 @@ from .bert import BertConfig, BertModel
 
 
 def pack_tokens(x, lengths):
-    """(B, L) padded ids + descending lengths -> packed ids (n_tok,), tok_off (B,), host lengths."""
+    """(B, L) padded ids + descending lengths -> packed ids (n_tok,), tok_off (B,), host lengths, (B, L) validity mask.
+    The gather indices are built on the host from `lengths` (known there), so nothing waits for the GPU: a boolean-mask
+    gather would have to count its hits on the device and stall the launch queue."""
     lens = [int(l) for l in lengths]
     B, L = x.shape
+    flat = np.concatenate([b * L + np.arange(l, dtype=np.int64) for b, l in enumerate(lens)]) if B else np.zeros(0, np.int64)
+    idx = ops.h2d(flat, x.device)
+    toks = x.reshape(-1).index_select(0, idx)
+    off = ops.h2d(np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64), x.device)
     ar = torch.arange(L, device=x.device).unsqueeze(0)
-    lt = torch.as_tensor(lens, device=x.device).unsqueeze(1)
-    mask = ar < lt
-    toks = x[mask]                                   # row-major: caption by caption
-    off = torch.as_tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), dtype=torch.int64, device=x.device)
+    mask = ar < ops.h2d(np.asarray(lens, np.int64), x.device).unsqueeze(1)
     return toks.contiguous(), off, lens, mask
 
 

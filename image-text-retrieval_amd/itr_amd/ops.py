@@ -35,6 +35,18 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def h2d(arr, device, dtype=None):
+    """Small host array -> device tensor through PINNED staging with a non-blocking copy.  A copy from pageable memory
+    (torch.as_tensor(list, device=...), .to(device) of a numpy view) is synchronous: the host stops until the stream
+    has drained, which put the whole training step in lock-step with the GPU (1.8 ms per call measured)."""
+    t = torch.as_tensor(np.ascontiguousarray(arr)) if not torch.is_tensor(arr) else arr
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    if torch.device(device).type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _host_i32(a):
     arr = np.ascontiguousarray(np.asarray([int(x) for x in a] if not isinstance(a, np.ndarray) else a, dtype=np.int32))
     return arr
@@ -241,10 +253,10 @@ class ScanPlan:
                                            tb.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p),
                                            C.byref(nt)))
         self.n_tiles = int(nt.value)
-        self.tile_begin = torch.from_numpy(tb[:self.n_tiles + 1].copy()).to(device)
-        self.cap_order = torch.from_numpy(order).to(device)
-        self.cap_len = torch.from_numpy(k_len.copy()).to(device)
-        self.cap_off = torch.as_tensor(np.asarray(k_off, dtype=np.int64)).to(device)
+        self.tile_begin = h2d(tb[:self.n_tiles + 1].copy(), device)
+        self.cap_order = h2d(order, device)
+        self.cap_len = h2d(k_len.copy(), device)
+        self.cap_off = h2d(np.asarray(k_off, dtype=np.int64), device)
 
 
 def scan_prepare(images, words, plan, cross_attn='t2i'):
@@ -521,7 +533,7 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
     n_tok = int(tokens_packed.numel())
     dev = tokens_packed.device
     tok_off = _dev(tok_off, torch.int64, "tok_off")
-    len_dev = torch.from_numpy(len_host.copy()).to(dev)
+    len_dev = h2d(len_host.copy(), dev)
     emb = _dev(weights['embed.weight'], name="embed.weight")
     V, E = emb.shape
     if n_tok:
