@@ -11,6 +11,7 @@ There is no CPU path: tensors must live on the GPU.
     cosine_scores(im, s)         im s^T                                 Objectives.py:18-21
     scan_t2i_scores(...)         SCAN t2i similarity matrix             Objectives.py:329-372
     Adam / clip_grad_norm        torch.optim.Adam + clip_grad_norm_     Models.py:98, :178, :223-225
+    dp_gather_rows(...)          rank-major all-gather of row blocks    data-parallel train_emb
 """
 import ctypes as C
 
@@ -368,6 +369,40 @@ def scan_i2t_scores(images, words_packed, cap_off, cap_lens, raw_feature_norm='c
 
 
 # ------------------------------------------------------------------------------------------ optimizer
+class _DPGatherRows(torch.autograd.Function):
+    """Row blocks of every rank concatenated rank-major (one RCCL all-gather).  Two kinds of backward:
+    reduce=True   the gathered rows feed a computation that DIFFERS per rank (every rank scores its own image rows
+                  against all caption embeddings): each rank holds a partial gradient for all rows -> sum all-reduce,
+                  then the rank's own rows;
+    reduce=False  the gathered rows feed a computation REPLICATED on every rank (the hinge over the gathered score
+                  matrix): the gradient is already complete -> the rank's own rows, no exchange."""
+
+    @staticmethod
+    def forward(ctx, local, comm, counts, reduce):
+        counts = [int(c) for c in counts]
+        if local.shape[0] != counts[comm.rank]:
+            raise ValueError("dp_gather_rows: %d local rows, counts[%d] = %d" % (local.shape[0], comm.rank, counts[comm.rank]))
+        buf, maxrows = comm.all_gather_rows(local.contiguous(), counts)
+        ctx.comm, ctx.counts, ctx.reduce = comm, counts, reduce
+        if all(c == maxrows for c in counts):
+            return buf
+        return torch.cat([buf[q * maxrows:q * maxrows + counts[q]] for q in range(comm.world)], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        comm, counts = ctx.comm, ctx.counts
+        lo = sum(counts[:comm.rank])
+        if ctx.reduce:
+            g = g.clone()
+            comm.all_reduce(g, dist.ReduceOp.SUM)
+        return g[lo:lo + counts[comm.rank]].contiguous(), None, None, None
+
+
+def dp_gather_rows(local, comm, counts, reduce):
+    return _DPGatherRows.apply(local, comm, counts, reduce)
+
+
 class Adam(object):
     """torch.optim.Adam(params, lr) as the reference builds it (betas (0.9, 0.999), eps 1e-8, no weight decay),
     one fused kernel per tensor; `step(max_norm)` folds clip_grad_norm_(params, max_norm) into the update."""
@@ -378,10 +413,27 @@ class Adam(object):
         self.state = {}
         self.t = 0
         self.last_grad_norm = None
+        self.comm = None       # evalpipe.Comm of a data-parallel run: step() sums the gradients over the ranks first
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+
+    def _sync_grads(self):
+        """Data parallel: ONE sum all-reduce of all gradients as a flat bucket (the loss is a sum over the global batch,
+        so the global gradient is the sum of the ranks' -- no averaging); p.grad become views of the reduced bucket."""
+        import torch.distributed as dist
+        ps = [p for p in self.params if p.requires_grad]
+        for p in ps:
+            if p.grad is None:       # a rank whose shard never touched p still has to take part in the collective
+                p.grad = torch.zeros_like(p.data)
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        self.comm.all_reduce(flat, dist.ReduceOp.SUM)
+        o = 0
+        for p in ps:
+            n = p.numel()
+            p.grad = flat[o:o + n].view(p.shape)
+            o += n
 
     def _coef(self, max_norm):
         lib = _lib.load()
@@ -403,6 +455,8 @@ class Adam(object):
         self.t += 1
         g0 = self.param_groups[0]
         coef = None
+        if self.comm is not None and self.comm.on:
+            self._sync_grads()
         if any(p.grad is not None for p in self.params):
             coef = self._coef(max_norm)
             self.last_grad_norm = coef[1:]

@@ -24,6 +24,7 @@ import pickle
 
 import numpy as np
 import torch
+import torch.distributed
 import torch.utils.data as data
 
 from . import tokenization
@@ -132,8 +133,14 @@ def get_precomp_loader(data_path, data_split, config, batch_size=100, shuffle=Tr
     """data_loader.py:181-196 -> (loader, vocab_size)."""
     dset = PrecompDataset(data_path, data_split, config)
     vocab_size = len(dset.tokenizer.vocab) if config.get('text_encoder') == 'bert' else len(dset.vocab)
+    gen = None
+    if shuffle and config.get('seed') is not None:
+        # the permutations come from the run's seed alone: a data-parallel run (which shards every GLOBAL batch inside
+        # train_emb) draws the same batches on every rank, and the same ones as the single-process run
+        gen = torch.Generator()
+        gen.manual_seed(int(config.get('seed', 0)))
     loader = torch.utils.data.DataLoader(dataset=dset, batch_size=batch_size, shuffle=shuffle, pin_memory=torch.cuda.is_available(),
-                                         collate_fn=collate_fn, num_workers=num_workers)
+                                         collate_fn=collate_fn, num_workers=num_workers, generator=gen)
     return loader, vocab_size
 
 

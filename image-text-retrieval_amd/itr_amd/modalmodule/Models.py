@@ -3,8 +3,15 @@ txt_enc, sim_enc, criterion, optimizer, Eiters, logger; methods forward_emb / fo
 train_start / state_dict / load_state_dict.  Towers and losses run on the HIP kernels.
 
 `train_emb` (forward -> hinge -> backward -> clip_grad_norm_ -> Adam, Models.py:115-145, :198-225) is built for the
-GRU family with a pooled or SCAN t2i similarity (VSE++, SCAN): itr_amd/autograd.py wires the HIP forward / backward
-kernels into torch's tape.  SGRAF / SAEM / CAMERA training (backward through EncoderSimilarity / BERT) is not built."""
+GRU family with a pooled or SCAN similarity (VSE++, SCAN): itr_amd/autograd.py wires the HIP forward / backward
+kernels into torch's tape.  SGRAF / SAEM / CAMERA training (backward through EncoderSimilarity / BERT) is not built.
+
+Data-parallel training (the reference has none): with torch.distributed initialised and world > 1,
+every rank receives the SAME global batch (loaders share the seed), keeps the strided shard rank::world of it, runs
+the towers on the shard, all-gathers the caption (word) embeddings, scores its image rows against ALL captions,
+all-gathers the score rows and evaluates the hinge on the full B x B matrix -- so the hardest negatives are searched
+in the GLOBAL batch and the step equals the single-GPU one up to fp32 summation order.  Gradients: caption
+embeddings sum-all-reduced inside the gather's backward, parameters in one flat bucket inside Adam.step."""
 import numpy as np
 import torch
 from torch import nn
@@ -67,6 +74,33 @@ class base_module(nn.Module):
     def train_emb(self, train_data, *a, **k):
         raise NotImplementedError("train_emb of %s needs backward kernels that are not built (SURVEY.md 8f-3); "
                                   "forward_emb / forward_loss are available" % type(self).__name__)
+
+    # ---- data-parallel sharding of one global batch
+    def _dp_comm(self):
+        from ..evalpipe import Comm
+        comm = Comm()
+        if self.optimizer is not None:
+            self.optimizer.comm = comm if comm.on else None
+        return comm
+
+    @staticmethod
+    def _dp_shard(comm, images, captions, lengths):
+        """Strided shard rank::world of a length-sorted batch (every shard stays sorted and gets the same mix of
+        lengths).  Returns the shard + the rank-major global bookkeeping every rank can derive without communication:
+        rows per rank, lengths of all captions in gathered order."""
+        B = len(lengths)
+        if B < comm.world:
+            raise ValueError("data-parallel train_emb: batch of %d on %d ranks" % (B, comm.world))
+        sel = [list(range(q, B, comm.world)) for q in range(comm.world)]
+        mine = sel[comm.rank]
+        idx = torch.as_tensor(mine, dtype=torch.long)
+        lens_all = [int(lengths[i]) for q in range(comm.world) for i in sel[q]]
+        rows = [len(x) for x in sel]
+        toks = [sum(int(lengths[i]) for i in x) for x in sel]
+        lens = [int(lengths[i]) for i in mine]
+        images = images[idx.to(images.device)]
+        captions = captions[idx.to(captions.device)][:, :max(lens)]
+        return images, captions, lens, rows, toks, lens_all
 
     # ---- shared by the GRU-family training steps
     def _train_towers(self, images, captions, lengths, pooled_images, last_state):
@@ -137,10 +171,18 @@ class VSE_PP(base_module):
         self._log('Eit', self.Eiters)
         self._log('lr', self.optimizer.param_groups[0]['lr'])
         self.optimizer.zero_grad()
+        comm = self._dp_comm()
+        if comm.on:
+            images, captions, lengths, rows, _, _ = self._dp_shard(comm, images, captions, lengths)
         with torch.enable_grad():
             img, cap, _, _ = self._train_towers(images, captions, lengths, pooled_images=True, last_state=True)
-            loss = ops.hinge_loss(ag.cosine_scores(img, cap), self.config['margin'], self.config['max_violation'])
-            self._step(loss, img.size(0))
+            if comm.on:
+                cap = ag.dp_gather_rows(cap, comm, rows, reduce=True)
+                scores = ag.dp_gather_rows(ag.cosine_scores(img, cap), comm, rows, reduce=False)
+            else:
+                scores = ag.cosine_scores(img, cap)
+            loss = ops.hinge_loss(scores, self.config['margin'], self.config['max_violation'])
+            self._step(loss, scores.size(0))
 
     def forward_loss(self, img_emb, cap_emb):
         loss = self.criterion(img_emb, cap_emb)
@@ -183,12 +225,21 @@ class SCAN(base_module):
         self._log('Eit', self.Eiters)
         self._log('lr', self.optimizer.param_groups[0]['lr'])
         self.optimizer.zero_grad()
+        comm = self._dp_comm()
+        if comm.on:
+            images, captions, lengths, rows, toks, lens_all = self._dp_shard(comm, images, captions, lengths)
         with torch.enable_grad():
             img, words, off, lens = self._train_towers(images, captions, lengths, pooled_images=False, last_state=False)
+            if comm.on:
+                words = ag.dp_gather_rows(words, comm, toks, reduce=True)
+                lens = lens_all
+                off = np.concatenate([[0], np.cumsum(lens_all)[:-1]]).astype(np.int64)
             score_fn = ag.scan_t2i_scores if cfg['cross_attn'] == 't2i' else ag.scan_i2t_scores
             scores = score_fn(img, words, off, lens, cfg['raw_feature_norm'], cfg['agg_func'], cfg['lambda_lse'], cfg['lambda_softmax'])
+            if comm.on:
+                scores = ag.dp_gather_rows(scores, comm, rows, reduce=False)
             loss = ops.hinge_loss(scores, cfg['margin'], cfg['max_violation'])
-            self._step(loss, img.size(0))
+            self._step(loss, scores.size(0))
 
     def forward_loss(self, img_emb, cap_emb, cap_lens):
         loss = self.criterion(img_emb, cap_emb, cap_lens)

@@ -61,8 +61,16 @@ def load_resume(models, _config, reload=False):
     return model, start_epoch, best_rsum, best_r1
 
 
+def is_main_process():
+    """Rank 0 of a data-parallel run (or the only process): the one that logs and writes checkpoints."""
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
 def save_checkpoint(state, is_best, filename='checkpoint.pth.tar', prefix='', is_epo_end=False):
-    """utils.py:58-62."""
+    """utils.py:58-62.  Data parallel: the replicas are identical, rank 0 writes."""
+    if not is_main_process():
+        return
     if is_epo_end:
         torch.save(state, os.path.join(prefix, 'epo' + str(state['epoch']) + '_' + filename))
     if is_best:

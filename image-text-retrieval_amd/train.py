@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """`python train.py with <MODEL> key=value ...` -- the reference's sacred command line (train.py:20-72, itr/config.py)
 on the MI355X-native package: config -> precomp loaders -> model -> epochs of train_step / validate_step ->
-checkpoints in the reference's layout.  One process per GPU (LOCAL_RANK selects the device)."""
+checkpoints in the reference's layout.  One process per GPU (LOCAL_RANK selects the device); under
+torch.distributed.run with N > 1 ranks the step is data parallel (modalmodule/Models.py) and validation row-sharded
+(evalpipe.py); rank 0 alone logs and writes checkpoints."""
 import copy
 import logging
 import os
 import sys
 
 import torch
+import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from itr_amd import config as cfgmod, utils                # noqa: E402
@@ -17,12 +20,12 @@ from itr_amd.datamodule import data_loader as data         # noqa: E402
 
 def train(_config):
     _config = copy.deepcopy(_config)
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     utils.setup_seed(_config['seed'])
-    logging.basicConfig(format='%(asctime)s %(message)s', level=logging.INFO)
+    logging.basicConfig(format='%(asctime)s %(message)s', level=logging.INFO if utils.is_main_process() else logging.WARNING)
     os.makedirs(_config['save_dir'], exist_ok=True)
-    utils.tb_logger.configure(_config['save_dir'], flush_secs=5)
-    utils.print_options(_config)
+    if utils.is_main_process():
+        utils.tb_logger.configure(_config['save_dir'], flush_secs=5)
+        utils.print_options(_config)
     train_loader, val_loader, vocab_size = data.get_loaders(_config['data_name'], _config['batch_size'], _config['workers'], _config)
     _config['vocab_size'] = vocab_size
     if _config['resume']:
@@ -42,5 +45,27 @@ def train(_config):
                               prefix=_config['save_dir'], is_epo_end=True)
 
 
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv):
+    # one process per GPU; several ranks may share a device only under the gloo test backend
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    cfg = cfgmod.build_config(argv)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # data-parallel training: `python -m torch.distributed.run --nproc-per-node N train.py with ...`.  Every rank
+        # builds the same loaders (same seed => same global batches) and train_emb shards each batch; rank 0 makes the
+        # run directory and tells the others its name and the seed (a random one when seed=None)
+        dist.init_process_group(os.environ.get("ITR_DIST_BACKEND", "nccl"))
+        box = [cfgmod.config_hook(cfg, make_dirs=True) if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        cfg = box[0]
+    else:
+        cfg = cfgmod.config_hook(cfg, make_dirs=True)      # run directory + hparams.yaml
+    train(cfg)
+
+
 if __name__ == "__main__":
-    train(cfgmod.config_hook(cfgmod.build_config(sys.argv[1:]), make_dirs=True))     # run directory + hparams.yaml
+    main(sys.argv[1:])

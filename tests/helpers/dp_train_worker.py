@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Worker of tests/test_dp_train_gpu.py: a few `model.train_emb` steps on seeded global batches, alone or as one rank of
+a torch.distributed job (backend from ITR_DIST_BACKEND; gloo = several ranks on ONE GPU, host-staged collectives).
+Rank 0 writes the per-step losses, gradient norms and the final parameters to --out (npz)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "image-text-retrieval_amd"))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="SCAN")
+ap.add_argument("--cross-attn", default="t2i")
+ap.add_argument("--batch", type=int, default=24)
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--out", required=True)
+a = ap.parse_args()
+
+world = int(os.environ.get("WORLD_SIZE", "1"))
+backend = os.environ.get("ITR_DIST_BACKEND", "nccl")
+local = 0 if backend == "gloo" else int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local)
+if world > 1:
+    dist.init_process_group(backend)
+
+from itr_amd import config as C                                   # noqa: E402
+from itr_amd.modalmodule import get_model                         # noqa: E402
+from itr_amd.metricmodule.evaluation import LogCollector          # noqa: E402
+
+over = ['with', a.model, 'data_name=coco_precomp', 'bi_gru=True', 'max_violation=True', 'embed_size=256', 'word_dim=64']
+if a.model == 'SCAN':
+    over.append('cross_attn=' + a.cross_attn)
+cfg = C.build_config(over)
+cfg['vocab_size'] = 500
+cfg['img_dim'] = 128
+torch.manual_seed(1234)
+model = get_model(cfg)
+model.train_start()
+model.logger = LogCollector()
+rng = np.random.RandomState(7)
+B = a.batch
+losses, gnorms = [], []
+for step in range(a.steps):
+    lens = sorted([int(x) for x in rng.randint(3, 15, size=B)], reverse=True)
+    ids = torch.zeros(B, max(lens), dtype=torch.long)
+    for b, l in enumerate(lens):
+        ids[b, :l] = torch.from_numpy(rng.randint(4, 500, size=l))
+    feats = torch.from_numpy(rng.randn(B, 36, 128).astype(np.float32))
+    feats = feats / feats.norm(dim=-1, keepdim=True)
+    model.train_emb((feats, None, None, ids, lens, list(range(B)), None, None))
+    losses.append(float(model.logger.meters['Loss'].val))
+    gnorms.append(float(model.optimizer.last_grad_norm[0]))
+torch.cuda.synchronize()
+if world == 1 or dist.get_rank() == 0:
+    flat = torch.cat([p.detach().reshape(-1) for p in model.params]).cpu().numpy()
+    np.savez(a.out, dp_world=(model.optimizer.comm.world if model.optimizer.comm is not None else 1), params=flat, losses=np.asarray(losses), gnorms=np.asarray(gnorms), lr=cfg['learning_rate'])
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()

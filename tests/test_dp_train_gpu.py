@@ -1,0 +1,93 @@
+"""Data-parallel `train_emb`: `world` ranks share this box's one GPU through the gloo backend (RCCL
+refuses two ranks per device; the collectives are host-staged, everything else is the production path) and must
+reproduce the single-process training steps: same losses, same clipped gradient norm, same parameters after Adam --
+up to fp32 summation order (the loss is a sum over the GLOBAL batch with GLOBAL hardest negatives)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "helpers", "dp_train_worker.py")
+
+
+def _run(tmp_path, tag, world, extra):
+    out = str(tmp_path / ("%s_%d.npz" % (tag, world)))
+    args = [WORKER, "--out", out] + extra
+    if world == 1:
+        cmd, env = [sys.executable] + args, dict(os.environ)
+    else:
+        env = dict(os.environ, ITR_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(29610 + world)] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,world", [
+    (["--model", "SCAN", "--cross-attn", "t2i"], 2),
+    (["--model", "SCAN", "--cross-attn", "t2i", "--batch", "25"], 3),     # ragged shards: 9 / 8 / 8 rows
+    (["--model", "SCAN", "--cross-attn", "i2t"], 2),
+    (["--model", "VSE_PP"], 2),
+])
+def test_dp_train_step_equals_single_process(tmp_path, extra, world):
+    one = _run(tmp_path, "one", 1, extra)
+    dp = _run(tmp_path, "dp", world, extra)
+    assert int(one["dp_world"]) == 1 and int(dp["dp_world"]) == world      # the sharded step really ran
+    lr = float(one["lr"])
+    np.testing.assert_allclose(dp["losses"], one["losses"], rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(dp["gnorms"], one["gnorms"], rtol=1e-4)
+    d = np.abs(dp["params"] - one["params"])
+    # Adam turns a 1e-7 difference of a gradient with |g| ~ eps into a difference of up to lr per step
+    assert d.max() <= 3 * lr + 1e-7 and d.mean() <= 2e-6, (d.max(), d.mean())
+
+
+@pytest.mark.gpu
+def test_dp_train_command_line(golden, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 train.py with SCAN ...` (gloo, both ranks on this GPU): same
+    global batches, sharded step, row-sharded validation, rank 0 writes ONE run directory -- and the checkpoint after
+    an epoch matches the single-process run's."""
+    import glob
+    import torch
+    g = golden("g14_data_layer")
+    name = 'toy_precomp'
+    d = tmp_path / 'data' / name
+    d.mkdir(parents=True)
+    caps = bytes(g["caps_blob"]).split(b"\n")[:-1]
+    rng = np.random.RandomState(0)
+    for split, n_img in (('train', 40), ('dev', 1000)):
+        np.save(d / ('%s_ims.npy' % split), rng.randn(n_img, 36, 8).astype(np.float32))
+        lines = [caps[i % len(caps)] for i in range(5 * n_img)]
+        (d / ('%s_caps.txt' % split)).write_bytes(b"\n".join(lines) + b"\n")
+    vdir = tmp_path / 'vocab'
+    vdir.mkdir()
+    (vdir / ('%s_vocab.json' % name)).write_text(bytes(g["vocab_json"]).decode())
+    train_py = os.path.join(ROOT, "image-text-retrieval_amd", "train.py")
+    cks = {}
+    for world in (1, 2):
+        runs = str(tmp_path / ('runs%d' % world))
+        args = [train_py, "with", "SCAN", "data_name=%s" % name, "data_path=%s" % (tmp_path / 'data'), "vocab_path=%s" % vdir,
+                "save_path=%s" % runs, "num_epochs=1", "batch_size=20", "val_step=100", "log_step=5", "workers=0", "img_dim=8",
+                "embed_size=32", "word_dim=16", "bi_gru=True", "max_violation=True", "seed=3", "learning_rate=0.002"]
+        if world == 1:
+            cmd, env = [sys.executable] + args, dict(os.environ)
+        else:
+            env = dict(os.environ, ITR_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                   "--master-addr", "127.0.0.1", "--master-port", "29633"] + args
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        run_dirs = glob.glob(os.path.join(runs, "SCAN", "toy_3_*"))
+        assert len(run_dirs) == 1, run_dirs
+        cks[world] = torch.load(os.path.join(run_dirs[0], 'epo0_checkpoint.pth.tar'), map_location='cpu', weights_only=False)
+    assert cks[1]['Eiters'] == cks[2]['Eiters'] == 10
+    assert cks[1]['best_rsum'] == pytest.approx(cks[2]['best_rsum'], abs=1.0)
+    for a, b in zip(cks[1]['model'], cks[2]['model']):
+        for k in a:
+            dmax = (a[k] - b[k]).abs().max().item()
+            assert dmax <= 10 * 3 * 0.002, (k, dmax)       # 10 Adam steps, each may move a |g| ~ eps weight by up to lr
+            assert (a[k] - b[k]).abs().mean().item() <= 2e-4, k
