@@ -44,6 +44,8 @@ WORKLOADS = {
     "sgraf_sgr_f30k1k": dict(n_img=1000, vocab=8481, sgraf="SGR"),
     # BASELINE.json configs[1]: VSE++ f30k 1k x 5k cosine; configs[3]: SAEM / CAMERA with the BERT-base text tower
     "vsepp_f30k1k": dict(n_img=1000, vocab=8481, pooled="VSE++"),
+    "vsrn_coco5k": dict(n_img=5000, vocab=11353, pooled="VSRN"),
+    "vsrn_f30k1k": dict(n_img=1000, vocab=8481, pooled="VSRN"),
     "saem_coco5k": dict(n_img=5000, pooled="SAEM"),
     "camera_coco5k": dict(n_img=5000, pooled="CAMERA"),
     "camera_f30k1k": dict(n_img=1000, pooled="CAMERA"),
@@ -191,16 +193,29 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
     i0, i1 = evalpipe.block_range(n_img, comm.world, comm.rank, 4)
     c0, c1 = evalpipe.block_range(n_cap, comm.world, comm.rank)
     torch.manual_seed(0)
+    gru_text = kind in ("VSE++", "VSRN")
     if kind == "VSE++":
         cfg = C.build_config(['with', 'VSE_PP', 'data_name=f30k_precomp', 'bi_gru=True', 'max_violation=True'])
         cfg.update(img_dim=2048, vocab_size=wl["vocab"])
+    elif kind == "VSRN":
+        cfg = C.build_config(['with', 'VSRN', 'data_name=%s_precomp' % ("coco" if wl["n_img"] == 5000 else "f30k")])
+        cfg.update(vocab_size=wl["vocab"])
     else:
         cfg_file, ckpt, trans = bert_files(os.path.join("/tmp", "itr_bench_bert"))
         cfg = C.build_config(['with', kind, 'data_name=coco_precomp'])
         cfg.update(bert_config_file=cfg_file, init_checkpoint=ckpt, trans_cfg=trans, vocab_size=30522)
     model = get_model(cfg)
+    if kind == "VSRN":
+        # Rs_GCN initialises its BatchNorm to gamma = beta = 0 (an identity layer): trained-like statistics instead
+        gbn = torch.Generator().manual_seed(1)
+        for mod in model.img_enc.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=gbn) * 0.6 + 0.2)
+                mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=gbn) * 0.05)
+                mod.running_mean.data.copy_(torch.randn(mod.running_mean.shape, generator=gbn) * 0.1)
+                mod.running_var.data.copy_(torch.rand(mod.running_var.shape, generator=gbn) + 0.5)
     model.val_start()
-    if kind == "VSE++":
+    if gru_text:
         # packed captions of this rank, sorted by length once (like the SCAN workload): ONE GRU call per step
         lengths, tokens = make_captions(n_cap, wl["vocab"])
         g = torch.Generator(device=dev)
@@ -210,15 +225,19 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
         order_dev = torch.from_numpy(np.ascontiguousarray(order)).to(dev)
         towers = evalpipe.GruModelEval({k: v.detach() for k, v in model.img_enc.state_dict().items()},
                                        {k: v.detach() for k, v in model.txt_enc.state_dict().items()},
-                                       dict(bi_gru=True, no_txtnorm=False, no_imgnorm=False), comm)
+                                       dict(bi_gru=kind == "VSE++", no_txtnorm=False, no_imgnorm=False), comm)
     else:
         feats, boxes, imgs_wh, ids, mask, types, lengths = pooled_inputs(n_img, n_cap, kind, dev)
     pe = evalpipe.PooledModelEval(model, comm, batch=1024)   # 1024 captions x 32 tokens = 256 M-tiles: whole rounds of the persistent GEMM
     timers = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
 
     def step(tm=None):
-        if kind == "VSE++":
-            img = ops.proj_l2norm(ops.mean_mid(feats[i0:i1]), towers.wi['fc.weight'], towers.wi['fc.bias'])
+        if gru_text:
+            if kind == "VSRN":
+                with torch.no_grad():
+                    img = torch.cat([model.img_enc(feats[b0:min(b0 + 1024, i1)])[0] for b0 in range(i0, i1, 1024)], 0)
+            else:
+                img = ops.proj_l2norm(ops.mean_mid(feats[i0:i1]), towers.wi['fc.weight'], towers.wi['fc.bias'])
             cap_sorted = towers.encode_captions(toks, tok_off, lens_sorted, gather_last=True)
             cap = torch.empty_like(cap_sorted)
             cap[order_dev] = cap_sorted                      # back to the dataset order
@@ -263,6 +282,12 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
         n_tok = float(lengths[c0:c1].sum())
         flop = (i1 - i0) * 2 * 2048 * 1024 + n_tok * 16.27e6 + float(i1 - i0) * n_cap * 2 * 1024
         model_name, dims = "VSE++ bi-GRU (mean-pooled regions)", 1024
+    elif kind == "VSRN":
+        n_tok = float(lengths[c0:c1].sum())
+        D = 2048      # per image: fc + 4 x (theta, phi, g, W convolutions + the two N x N x D relation products) + GRU over 36 regions
+        flop_img = 36 * 2 * 2048 * D + 4 * (4 * 36 * 2 * D * D + 2 * 2 * 36 * 36 * D) + 36 * 2 * 3 * D * (D + D)
+        flop = (i1 - i0) * float(flop_img) + n_tok * 2 * 3 * D * (300 + D) + float(i1 - i0) * n_cap * 2 * D
+        model_name, dims = "VSRN (4 x Rs_GCN + region GRU image tower, uni-GRU text tower)", D
     elif kind == "SAEM":
         flop = (c1 - c0) * 5.47e9 + float(i1 - i0) * n_cap * 512
         model_name, dims = "SAEM (BERT-base + cnn head, transformer image tower)", 256
@@ -287,20 +312,23 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
         # CPU oracle (kind "port") on the first ns images and their 5*ns captions: encode + score + rank, and max |diff|
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import itr_oracle as O
-        ns = min(args.cpu_sample_images, 40 if kind != "VSE++" else 200)
+        ns = min(args.cpu_sample_images, 40 if not gru_text else 200)
         ncs = 5 * ns
         wi = {k: v.detach().cpu() for k, v in model.img_enc.state_dict().items() if "num_batches_tracked" not in k}
         wt = {k: v.detach().cpu() for k, v in model.txt_enc.state_dict().items() if "num_batches_tracked" not in k}
         with torch.no_grad():
             t0 = time.time()
-            if kind == "VSE++":
+            if gru_text:
                 lens = lengths[:ncs]
                 order_s = np.argsort(-lens, kind="stable")
                 ids_s = torch.zeros(ncs, int(lens.max()), dtype=torch.long)
                 for r, i in enumerate(order_s):
                     ids_s[r, :lens[i]] = torch.from_numpy(tokens[int(i)])
-                img_o = O.encoder_image_precomp(feats[:ns].cpu().mean(1), wi["fc.weight"], wi["fc.bias"])
-                cap_sorted, _ = O.encoder_text(ids_s, [int(lens[i]) for i in order_s], wt, True, False, False, "VSE++")
+                if kind == "VSRN":
+                    img_o, _ = O.vsrn_image(wi, feats[:ns].cpu(), cfg["data_name"])
+                else:
+                    img_o = O.encoder_image_precomp(feats[:ns].cpu().mean(1), wi["fc.weight"], wi["fc.bias"])
+                cap_sorted, _ = O.encoder_text(ids_s, [int(lens[i]) for i in order_s], wt, kind == "VSE++", False, False, "VSE++")
                 cap_o = torch.zeros_like(cap_sorted)
                 cap_o[torch.as_tensor(order_s)] = cap_sorted
                 S_o = O.cosine_sim(img_o, cap_o)

@@ -79,6 +79,23 @@ class PrecompDataset(data.Dataset):
         tokens = self.word_tokenize(self.caption_text(self.captions[index]).lower())
         return [self.vocab('<start>')] + [self.vocab(t) for t in tokens] + [self.vocab('<end>')]
 
+    def vsrn_ids(self, index):
+        """The caption layout the reference feeds VSRN (data_loader.py:117-125), as written: more than max_len tokens ->
+        the last id moves to position max_len and the list is cut to max_len; then zeros (<pad>) up to max_len + 1 ids.
+        EVERY caption therefore reaches collate_fn with length max_len + 1, `lengths` is [max_len + 1] * B and the text
+        GRU runs over the padding too (its "last state" is the state after the <pad> tail) -- this is what a reference
+        VSRN checkpoint was trained and evaluated with, so it is reproduced.  The mask is computed AFTER the padding
+        (min(len, max_len) == max_len ones)."""
+        ids = list(self.token_ids(index))
+        max_len = int(self.config['max_len'])
+        if len(ids) > max_len:
+            ids[max_len] = ids[-1]
+            ids = ids[:max_len]
+        ids = ids + [0] * (max_len + 1 - len(ids))
+        mask = [0.0] * (max_len + 1)
+        mask[:min(len(ids), max_len)] = [1.0] * min(len(ids), max_len)
+        return ids, mask
+
     def __getitem__(self, index):
         img_id = index // self.im_div
         image = torch.from_numpy(np.array(self.images[img_id], dtype=np.float32))
@@ -91,10 +108,12 @@ class PrecompDataset(data.Dataset):
             _, ids, mask, types = convert_to_feature(self.captions[index], self.max_words, self.tokenizer)
             captions_ids, captions_mask, captions_type_ids = (torch.tensor(v, dtype=torch.long) for v in (ids, mask, types))
         else:
-            captions_ids = torch.tensor(self.token_ids(index), dtype=torch.long)
             if self.config.get('name') == 'VSRN':
-                raise NotImplementedError("VSRN caption layout (SURVEY 8(f)-4) is not built")
-            captions_mask, captions_type_ids = None, None
+                ids, mask = self.vsrn_ids(index)
+                captions_ids, captions_mask, captions_type_ids = torch.tensor(ids, dtype=torch.long), torch.tensor(mask), None
+            else:
+                captions_ids = torch.tensor(self.token_ids(index), dtype=torch.long)
+                captions_mask, captions_type_ids = None, None
         return image, boxes, img_wh, captions_ids, index, img_id, captions_mask, captions_type_ids
 
     def __len__(self):

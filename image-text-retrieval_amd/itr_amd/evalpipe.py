@@ -308,8 +308,9 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
     model.val_start()
     feats = _features_to_device(dataset.images, img_lo + i0, img_lo + i1, dev)
     with torch.no_grad():
-        if name in ('SCAN', 'SGRAF', 'VSE++', 'VSE_PP'):
-            ids = [dataset.token_ids(cap_lo + j) for j in range(c0, c1)]
+        if name in ('SCAN', 'SGRAF', 'VSE++', 'VSE_PP', 'VSRN'):
+            # VSRN: the reference's padded caption layout (every caption max_len + 1 ids, PrecompDataset.vsrn_ids)
+            ids = [dataset.vsrn_ids(cap_lo + j)[0] if name == 'VSRN' else dataset.token_ids(cap_lo + j) for j in range(c0, c1)]
             lens = np.asarray([len(x) for x in ids], np.int64)
             order = np.argsort(-lens, kind="stable")
             lens_sorted = [int(lens[i]) for i in order]
@@ -320,8 +321,12 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
             wt = {k: v.detach() for k, v in model.txt_enc.state_dict().items()}
             ev = GruModelEval(wi, wt, dict(cfg, bi_gru=model.txt_enc.use_bi_gru, no_txtnorm=model.txt_enc.no_txtnorm,
                                            no_imgnorm=model.img_enc.no_imgnorm), comm)
-            if name in ('VSE++', 'VSE_PP'):
-                img = ops.proj_l2norm(ops.mean_mid(feats), wi['fc.weight'], wi['fc.bias'], no_imgnorm=model.img_enc.no_imgnorm)
+            if name in ('VSE++', 'VSE_PP', 'VSRN'):
+                if name == 'VSRN':       # GCN + region GRU tower (ImgEncoder.py:199-231), `batch` images per pass
+                    img = torch.cat([model.img_enc(feats[b0:b0 + batch])[0] for b0 in range(0, feats.shape[0], batch)], 0) \
+                        if feats.shape[0] else torch.zeros(0, cfg['embed_size'], device=dev)
+                else:
+                    img = ops.proj_l2norm(ops.mean_mid(feats), wi['fc.weight'], wi['fc.bias'], no_imgnorm=model.img_enc.no_imgnorm)
                 cap_sorted = ev.encode_captions(toks, off, lens_sorted, gather_last=True)
                 cap = torch.empty_like(cap_sorted)
                 cap[torch.from_numpy(np.ascontiguousarray(order)).to(dev)] = cap_sorted

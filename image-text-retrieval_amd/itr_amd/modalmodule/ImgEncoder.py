@@ -63,6 +63,68 @@ class EncoderImagePooledPrecomp(EncoderImagePrecomp):
         return super().forward(images)
 
 
+from .vsrn_ import Rs_GCN  # noqa: E402
+
+
+class EncoderImagePrecompAttn(nn.Module):
+    """VSRN image tower (ImgEncoder.py:166-231): fc -> l2norm -> 4 x Rs_GCN -> l2norm -> GRU over the 36 regions ->
+    last hidden state -> [BatchNorm1d on f30k] -> l2norm.  NB the two l2norm calls on region tensors use the reference's
+    DEFAULT dim=1, i.e. they normalise across the regions (utils.py:11; :204, :216) -- reproduced.
+    Returns (features (B, D), GCN_img_emd (B, N, D))."""
+
+    def __init__(self, img_dim, embed_size, data_name, use_abs=False, no_imgnorm=False):
+        super().__init__()
+        self.embed_size = embed_size
+        self.no_imgnorm = no_imgnorm
+        self.use_abs = use_abs
+        self.data_name = data_name
+        self.fc = nn.Linear(img_dim, embed_size)
+        self.init_weights()
+        self.img_rnn = nn.GRU(embed_size, embed_size, 1, batch_first=True)
+        self.Rs_GCN_1 = Rs_GCN(in_channels=embed_size, inter_channels=embed_size)
+        self.Rs_GCN_2 = Rs_GCN(in_channels=embed_size, inter_channels=embed_size)
+        self.Rs_GCN_3 = Rs_GCN(in_channels=embed_size, inter_channels=embed_size)
+        self.Rs_GCN_4 = Rs_GCN(in_channels=embed_size, inter_channels=embed_size)
+        if self.data_name == 'f30k_precomp':
+            self.bn = nn.BatchNorm1d(embed_size)
+
+    def init_weights(self):
+        r = np.sqrt(6.) / np.sqrt(self.fc.in_features + self.fc.out_features)
+        self.fc.weight.data.uniform_(-r, r)
+        self.fc.bias.data.fill_(0)
+
+    def forward(self, images):
+        if self.training:
+            raise NotImplementedError("EncoderImagePrecompAttn: training mode is not built (SURVEY.md 8(f)-4)")
+        x = ops.linear(images, self.fc.weight.detach(), self.fc.bias.detach())
+        if self.data_name != 'f30k_precomp':
+            x = ops.l2norm(x, dim=1)
+        for gcn in (self.Rs_GCN_1, self.Rs_GCN_2, self.Rs_GCN_3, self.Rs_GCN_4):
+            x = gcn(x)
+        gcn_emb = ops.l2norm(x, dim=1)
+        B, N, D = gcn_emb.shape
+        # the region GRU is the caption GRU kernel fed with a dense "embedding table": row r of the table IS region r,
+        # every sequence is N long, the last state is what VSRN keeps (hidden_state[0], :219-222)
+        w = {'embed.weight': gcn_emb.view(B * N, D)}
+        for k, v in self.img_rnn.named_parameters():
+            w['rnn.' + k] = v.detach()
+        dev = gcn_emb.device
+        tokens = torch.arange(B * N, device=dev, dtype=torch.int64)
+        tok_off = torch.arange(B, device=dev, dtype=torch.int64) * N
+        plain_tail = self.data_name != 'f30k_precomp'
+        feat = ops.gru_encode(tokens, tok_off, [N] * B, w, False, no_txtnorm=not (plain_tail and not self.no_imgnorm),
+                              use_abs=plain_tail and self.use_abs and not self.no_imgnorm, gather_last=True)
+        if not plain_tail:
+            bn = self.bn
+            s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+            feat = ops.affine_cols(feat, s, (bn.bias - bn.running_mean * s).detach())
+            if not self.no_imgnorm:
+                feat = ops.l2norm(feat, dim=1)
+        if self.use_abs and (not plain_tail or self.no_imgnorm):
+            feat = feat.abs()
+        return feat, gcn_emb
+
+
 class TransformerMapping(nn.Module):
     """SAEM image tower: Linear(img_dim -> final_dims) -> one BERTLayer -> mean over regions -> F.normalize
     (ImgEncoder.py:324-350).  `trans_cfg` is not shipped with the reference: hidden_size must equal

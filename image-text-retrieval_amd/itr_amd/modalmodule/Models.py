@@ -247,6 +247,49 @@ class SCAN(base_module):
         return loss
 
 
+class VSRN(base_module):
+    """Visual Semantic Reasoning Network (Models.py:229-365), retrieval side: region-relationship GCN + region GRU image
+    tower, last-state GRU text tower, cosine similarity.  The reference's checkpoints hold [img_enc, txt_enc] only
+    (Models.py:37-45: the captioning model is never saved), so they load and evaluate here.  The captioning branch
+    (EncoderRNN / DecoderRNN / S2VTAttModel, training only) and train_emb are not built."""
+
+    def __init__(self, config, use_txt_emb=True):
+        super().__init__(config)
+        if not config['data_name'].endswith('_precomp'):
+            raise NotImplementedError("raw-image VSRN (EncoderImageFull: torchvision CNN) is out of scope")
+        if use_txt_emb:
+            self.img_enc = ImgEncoder.EncoderImagePrecompAttn(config['img_dim'], config['embed_size'], config['data_name'],
+                                                              use_abs=config['use_abs'], no_imgnorm=config['no_imgnorm'])
+        else:
+            self.img_enc = ImgEncoder.EncoderImagePrecomp(config['img_dim'], config['embed_size'], use_abs=config['use_abs'],
+                                                          no_imgnorm=config['no_imgnorm'])
+        self.txt_enc = TextEncoder.EncoderText(config['vocab_size'], config['word_dim'], config['embed_size'],
+                                               config['num_layers'], use_abs=config['use_abs'],
+                                               no_txtnorm=config['no_txtnorm'], method_name=config['name'])
+        self.img_enc.cuda()
+        self.txt_enc.cuda()
+        self.criterion = Objectives.ContrastiveLoss(config=config, margin=config['margin'], measure=config['measure'],
+                                                    max_violation=config['max_violation'])
+        self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters())
+        self.calculate_params()
+
+    def forward_emb(self, images, captions, lengths, *args, **kwargs):
+        out = self.img_enc(self._dev(images))
+        img_emb, gcn_emb = out if isinstance(out, tuple) else (out, None)
+        cap_emb, _ = self.txt_enc(self._dev(captions), lengths)
+        return img_emb, cap_emb, gcn_emb
+
+    def forward_loss(self, img_emb, cap_emb, GCN_img_emd=None, captions=None, captions_mask=None):
+        """Retrieval loss (Models.py:337).  The reference adds the captioning loss of S2VTAttModel on GCN_img_emd
+        (:334, training only): passing captions asks for it and raises."""
+        if captions is not None:
+            raise NotImplementedError("VSRN captioning loss (Fusionmodule.py:10-367) is not built; call forward_loss(img_emb, cap_emb)")
+        loss = self.criterion(img_emb, cap_emb)
+        self._log('Loss_retrieval', loss.data, img_emb.size(0))
+        self._log('Loss', loss.data, img_emb.size(0))
+        return loss
+
+
 class SGRAF(base_module):
     """Similarity Reasoning and Filtration network (Models.py:468-546)."""
 

@@ -427,6 +427,18 @@ def gemm_acc(x2d, lda, M, K, weight, bias, out, act=None):
     return out
 
 
+def gcn_relation(tpg, n_img, n_regions, channels):
+    """Rs_GCN between its convolutions (vsrn_.py:50-67): tpg [n_img*N, 3C] rows = theta | phi | g ->
+    y [n_img*N, C] = (theta phi^T / N) g per image."""
+    lib = _lib.load()
+    tpg = _dev(tpg, name="tpg")
+    if tpg.dim() != 2 or tpg.shape[0] != n_img * n_regions or tpg.shape[1] != 3 * channels:
+        raise ValueError("gcn_relation: tpg %s for %d images x %d regions x 3*%d" % (tuple(tpg.shape), n_img, n_regions, channels))
+    y = torch.empty(n_img * n_regions, channels, device=tpg.device, dtype=torch.float32)
+    _lib.check(lib.itr_gcn_relation(_p(tpg), tpg.shape[1], _p(y), channels, n_img, n_regions, channels, _stream()))
+    return y
+
+
 def camera_posenc(boxes, imgs_wh):
     lib = _lib.load()
     boxes = _dev(boxes.to(torch.float32), name="boxes")

@@ -50,6 +50,14 @@ int itr_l2norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, 
  * ImgEncoder.py:348; the VSE++ region pooling of SURVEY Q3). */
 int itr_mean_mid(const float *x, float *y, int64_t B, int R, int F, itr_stream_t stream);
 
+/* ---- VSRN region-relationship reasoning: Rs_GCN.forward between its 1x1 convolutions
+ * (itr/modalmodule/vsrn_.py:50-71).  tpg [n_img*N, ld]: per region row the three convolution outputs side by side,
+ * theta at columns [0, D), phi at [D, 2D), g at [2D, 3D) (one GEMM with the stacked weight).  For every image
+ *   y[n, :] = sum_m (theta[n,:] . phi[m,:] / N) g[m, :]           (R = theta_v phi_v^T; R_div_C = R / N; y = R_div_C g_v)
+ * y [n_img*N, ldy].  N <= 36 regions, D and ld multiples of 4. */
+int itr_gcn_relation(const float *tpg, int64_t ld, float *y, int64_t ldy, int64_t n_img, int N, int D,
+                     itr_stream_t stream);
+
 /* ---- generic fp32 MFMA GEMM used by the towers ----------------------------------------
  * C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]);  lda/ldb/ldc are row strides in elements.
  * bias may be NULL.  lda < K is allowed (overlapping A rows = a convolution over consecutive rows).  act: 0 none, 1 relu, 2 tanh, 3 sigmoid, 4 gelu(erf), 5 leaky_relu(0.1).

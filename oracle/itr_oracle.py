@@ -56,6 +56,47 @@ def encoder_image_precomp(images, fc_weight, fc_bias, no_imgnorm=False, use_abs=
 
 
 # --------------------------------------------------------------------------------------
+# f4  VSRN image tower: fc -> l2norm -> 4 x Rs_GCN -> l2norm -> GRU over the regions -> last hidden state -> [BN] -> l2norm
+#     (itr/modalmodule/ImgEncoder.py:166-231, itr/modalmodule/vsrn_.py:50-71)
+# --------------------------------------------------------------------------------------
+
+
+def rs_gcn(w, p, v):
+    """Rs_GCN.forward on v (B, N, D) (the reference works on the (B, D, N) transpose; a Conv1d with kernel size 1 is a
+    Linear over the channel axis): R = theta(v) phi(v)^T / N, y = R g(v), v* = BN(W y) + v  (vsrn_.py:50-71)."""
+    def conv(name, x):
+        return x @ w[p + name + '.weight'][:, :, 0].t() + w[p + name + '.bias']
+    g_v, theta_v, phi_v = conv('g', v), conv('theta', v), conv('phi', v)
+    R = theta_v @ phi_v.transpose(1, 2)
+    y = (R / R.shape[-1]) @ g_v
+    wy = conv('W.0', y)
+    return _bn_eval(wy, w, p + 'W.1', channel_dim=2) + v
+
+
+def vsrn_image(w, images, data_name='coco_precomp', no_imgnorm=False, use_abs=False):
+    """EncoderImagePrecompAttn.forward (ImgEncoder.py:199-231) -> (features (B, D), GCN_img_emd (B, N, D)).
+    NB both l2norm calls on the region tensors use the reference's DEFAULT dim=1: they normalise ACROSS the regions
+    (utils.py:11), not across the features -- restated as written."""
+    x = images @ w['fc.weight'].t() + w['fc.bias']
+    if data_name != 'f30k_precomp':
+        x = l2norm(x, dim=1)
+    for i in (1, 2, 3, 4):
+        x = rs_gcn(w, 'Rs_GCN_%d.' % i, x)
+    gcn = l2norm(x, dim=1)
+    B, N, _ = gcn.shape
+    seq = gru_direction(gcn, [N] * B, w['img_rnn.weight_ih_l0'], w['img_rnn.weight_hh_l0'], w['img_rnn.bias_ih_l0'],
+                        w['img_rnn.bias_hh_l0'])
+    feat = seq[:, N - 1]
+    if data_name == 'f30k_precomp':
+        feat = _bn_eval(feat, w, 'bn', channel_dim=1)
+    if not no_imgnorm:
+        feat = l2norm(feat, dim=1)
+    if use_abs:
+        feat = feat.abs()
+    return feat, gcn
+
+
+# --------------------------------------------------------------------------------------
 # a3  text tower: Embedding -> packed (bi)GRU -> dir-average -> [last step] -> [l2norm]
 #     (itr/modalmodule/TextEncoder.py:38-70)
 # --------------------------------------------------------------------------------------

@@ -600,6 +600,12 @@ def g14():
     batch = rdl.collate_fn([ds[i] for i in pick])
     out.update(pick=np.array(pick), col_images=batch[0], col_ids=batch[3], col_lengths=np.array(batch[4]), col_index=np.array(batch[5]))
     assert batch[1] == (None,) * len(pick) and batch[6] == (None,) * len(pick)
+    # -- VSRN caption layout (data_loader.py:117-125): max_len small enough that some captions take the truncation branch
+    dsv = rdl.PrecompDataset(d, 'test', dict(cfg, name='VSRN', max_len=9))
+    out['vsrn_ids'] = np.stack([dsv[i][3].numpy() for i in range(len(dsv))]).astype(np.int64)
+    out['vsrn_mask'] = np.stack([dsv[i][6].numpy() for i in range(len(dsv))])
+    vb = rdl.collate_fn([dsv[i] for i in pick])
+    out.update(vcol_ids=vb[3], vcol_lengths=np.array(vb[4]), vcol_mask=vb[6], vcol_index=np.array(vb[5]))
     # -- BERT tokenizer + features (+ bbox branch of collate_fn)
     vfile = os.path.join(root, 'bert_vocab.txt')
     open(vfile, 'w').write("\n".join(G14_BERT_VOCAB) + "\n")
@@ -714,9 +720,69 @@ def g15():
     save('g15_train_step', **out)
 
 
+# ------------------------------------------------------------------ G16 VSRN image tower + model forward_emb
+def _randomise_bn(module, gen_seed):
+    g = torch.Generator().manual_seed(gen_seed)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data = torch.rand(m.weight.shape, generator=g) * 0.6 + 0.2     # Rs_GCN initialises gamma = beta = 0
+            m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.05             # (an identity layer): trained-like values
+            m.running_mean.data = torch.randn(m.running_mean.shape, generator=g) * 0.1
+            m.running_var.data = torch.rand(m.running_var.shape, generator=g) + 0.5
+
+
+def g16():
+    out = {}
+    for data_name in ('coco_precomp', 'f30k_precomp'):
+        tag = data_name.split('_')[0]
+        torch.manual_seed(160)
+        enc = ImgEncoder.EncoderImagePrecompAttn(48, 64, data_name, use_abs=False, no_imgnorm=False).eval()
+        enc.fc.bias.data.uniform_(-0.05, 0.05)
+        _randomise_bn(enc, 161)
+        x = mutils.l2norm(torch.randn(5, 36, 48), dim=-1)
+        feat, gcn = enc(x)
+        w = sd(enc)
+        of, og = O.vsrn_image(w, x, data_name)
+        check('vsrn_img_%s feat' % tag, of, feat, 2e-6)
+        check('vsrn_img_%s gcn' % tag, og, gcn, 2e-6)
+        out.update({'%s_images' % tag: x, '%s_feat' % tag: feat, '%s_gcn' % tag: gcn})
+        for k, v in w.items():
+            out['%s_w_%s' % (tag, k)] = v
+    # the model wrapper: forward_emb of `get_model` VSRN (Models.py:229-324) on a ragged batch, eval mode
+    rng = np.random.RandomState(16)
+    cfg = dict(name='VSRN', data_name='coco_precomp', img_dim=48, embed_size=64, use_abs=False, no_imgnorm=False, vocab_size=70,
+               word_dim=24, num_layers=1, no_txtnorm=False, dim_vid=64, dim_hidden=32, bidirectional=False, input_dropout_p=0.2,
+               rnn_type='gru', rnn_dropout_p=0.5, max_len=20, dim_word=16, margin=0.2, measure='cosine', max_violation=True,
+               finetune=False, learning_rate=2e-4, grad_clip=2.0)
+    torch.manual_seed(162)
+    model = Models.VSRN(cfg)
+    _randomise_bn(model.img_enc, 163)
+    model.val_start()
+    B = 7
+    lengths = ragged_lengths(rng, B, 2, 9)
+    ids = torch.zeros(B, max(lengths), dtype=torch.long)
+    for b, l in enumerate(lengths):
+        ids[b, :l] = torch.from_numpy(rng.randint(4, 70, size=l))
+    x = mutils.l2norm(torch.randn(B, 36, 48), dim=-1)
+    img_emb, cap_emb, gcn = model.forward_emb(x, ids, lengths)
+    loss = model.criterion(img_emb, cap_emb)
+    wi, wt = sd(model.img_enc), sd(model.txt_enc)
+    of, og = O.vsrn_image(wi, x, 'coco_precomp')
+    oc, _ = O.encoder_text(ids, lengths, wt, False, False, False, 'VSRN')
+    check('vsrn model img', of, img_emb, 2e-6)
+    check('vsrn model cap', oc, cap_emb, 2e-6)
+    check('vsrn model loss', O.hinge_loss(O.cosine_sim(of, oc), 0.2, True), loss, 1e-5)
+    out.update(m_images=x, m_ids=ids, m_lengths=np.array(lengths), m_img_emb=img_emb, m_cap_emb=cap_emb, m_gcn=gcn, m_loss=float(loss))
+    for k, v in wi.items():
+        out['m_img_' + k] = v
+    for k, v in wt.items():
+        out['m_txt_' + k] = v
+    save('g16_vsrn', **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16']
     for name in which:
         print("== " + name)
         globals()[name]()

@@ -122,3 +122,17 @@ def test_loader_contract(toy):
     assert sorted(seen) == list(range(30))
     with pytest.raises(NotImplementedError):
         dl.get_loaders('coco', 8, 0, dict(cfg, data_name='coco'))
+
+
+def test_vsrn_caption_layout_matches_reference(toy):
+    """data_loader.py:117-125 as written: every caption max_len + 1 ids (truncation drops <end>, <pad> tail), a mask
+    computed after the padding, collate_fn lengths all max_len + 1."""
+    g, root, d, vdir, vfile, name = toy
+    ds = dl.PrecompDataset(d, 'test', dict(_cfg(vdir, name, max_len=9, ref_quirk_bytes_repr=True), name='VSRN'))
+    ids = np.stack([ds[i][3].numpy() for i in range(len(ds))])
+    mask = np.stack([ds[i][6].numpy() for i in range(len(ds))])
+    assert ids.dtype == np.int64 and (ids == g["vsrn_ids"]).all() and (mask == g["vsrn_mask"]).all()
+    pick = [int(i) for i in g["pick"]]
+    b = dl.collate_fn([ds[i] for i in pick])
+    assert (b[3].numpy() == g["vcol_ids"]).all() and list(b[4]) == list(g["vcol_lengths"]) and list(b[5]) == list(g["vcol_index"])
+    assert (b[6].numpy() == g["vcol_mask"]).all() and b[7] == (None,) * len(pick)

@@ -94,10 +94,10 @@ def test_evalrank_single_and_ensemble(golden, dev, tmp_path):
 
 def test_evalrank_fast_equals_reference_shaped_path(golden, dev, tmp_path):
     """The sharded device-resident evaluator (unique images, packed captions, fused scoring) gives the ranks of the
-    encode_data + cal_sims path on the same checkpoint and files -- SCAN, SGRAF and VSE++."""
+    encode_data + cal_sims path on the same checkpoint and files -- SCAN, SGRAF, VSE++ and VSRN."""
     g = golden("g14_data_layer")
     name, data_path, vdir = _materialise(g, tmp_path)
-    for model_name, extra in (('SCAN', []), ('SGRAF', ['module_name=SGR']), ('VSE_PP', [])):
+    for model_name, extra in (('SCAN', []), ('SGRAF', ['module_name=SGR']), ('VSE_PP', []), ('VSRN', [])):
         save_dir = str(tmp_path / ('run_' + model_name))
         os.makedirs(save_dir)
         cfg = C.build_config(['with', model_name, 'data_name=%s' % name, 'bi_gru=True', 'seed=3'] + extra)
@@ -105,6 +105,12 @@ def test_evalrank_fast_equals_reference_shaped_path(golden, dev, tmp_path):
                    batch_size=7, workers=0, save_dir=save_dir, word_tokenize=None, sim_dim=16, vocab_type='json')
         torch.manual_seed(3)
         model = get_model(cfg)
+        if model_name == 'VSRN':          # Rs_GCN starts as an identity layer (BatchNorm gamma = beta = 0): trained-like values
+            for m in model.img_enc.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.weight.data.uniform_(0.2, 0.8)
+                    m.running_mean.data.normal_(0, 0.1)
+                    m.running_var.data.uniform_(0.5, 1.5)
         utils.save_checkpoint({'epoch': 0, 'model': model.state_dict(), 'best_rsum': 0.0, 'best_r1': 0.0, '_config': cfg, 'Eiters': 1},
                               True, prefix=save_dir)
         p = os.path.join(save_dir, 'model_best.pth.tar')

@@ -194,7 +194,8 @@ def test_bench_collectives_single_rank():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload,world", [("scan_t2i_f30k1k", 2), ("scan_t2i_f30k1k", 3), ("sgraf_saf_f30k1k", 2), ("vsepp_f30k1k", 2)])
+@pytest.mark.parametrize("workload,world", [("scan_t2i_f30k1k", 2), ("scan_t2i_f30k1k", 3), ("sgraf_saf_f30k1k", 2), ("vsepp_f30k1k", 2),
+                                            ("vsrn_f30k1k", 2)])
 def test_sharded_eval_equals_single_process_on_one_gpu(workload, world):
     """The WHOLE sharded pipeline (row-sharded images, caption slices, packed all-gather, max / sum / key reductions,
     ragged rank gather) with real kernels: `world` ranks share this box's one GPU through the gloo backend (RCCL refuses
