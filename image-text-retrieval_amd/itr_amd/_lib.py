@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 i32, i64, f32, vp, sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -23,6 +23,10 @@ SIGNATURES = {
     "itr_l2norm_rows": (i32, [vp, vp, i64, i32, f32, i32, i32, vp]),
     "itr_mean_mid": (i32, [vp, vp, i64, i32, i32, vp]),
     "itr_gcn_relation": (i32, [vp, i64, vp, i64, i64, i32, i32, vp]),
+    "itr_order_scores": (i32, [vp, vp, vp, i64, i64, i32, vp]),
+    "itr_order_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, vp]),
+    "itr_row_sqnorm": (i32, [vp, vp, i64, i32, vp]),
+    "itr_pdist_finish": (i32, [vp, vp, vp, i64, i64, vp]),
     "itr_gemm_nt": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "itr_proj_l2norm": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "itr_gru_workspace_bytes": (sz, [i64, i64, i32, i32, i32]),

@@ -238,6 +238,30 @@ def cosine_scores(im, s):
     return _Cosine.apply(im, s)
 
 
+class _Order(torch.autograd.Function):
+    """order_sim (Objectives.py:24-30) under autograd."""
+
+    @staticmethod
+    def forward(ctx, im, s):
+        from . import ops
+        S = ops.order_scores(im, s)
+        ctx.save_for_backward(_dev(im, name="im"), _dev(s, name="s"), S)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        lib = _lib.load()
+        im, s, S = ctx.saved_tensors
+        dS = dS.contiguous()
+        d_im, d_s = torch.empty_like(im), torch.empty_like(s)
+        _lib.check(lib.itr_order_bwd(_p(im), _p(s), _p(S), _p(dS), _p(d_im), _p(d_s), im.shape[0], s.shape[0], im.shape[1], _stream()))
+        return d_im, d_s
+
+
+def order_scores(im, s):
+    return _Order.apply(im, s)
+
+
 class _ScanT2I(torch.autograd.Function):
     """The word axis is zero-padded to a multiple of 32 (ntp) so that every GEMM whose contraction runs over the words
     (dV = dA E) takes the branch-free kernel; padded columns of A / dA are zero and never read by the pair kernels."""

@@ -115,6 +115,8 @@ class base_module(nn.Module):
         img = ag.linear(x, ie._weight(), ie.fc.bias)
         if not ie.no_imgnorm:
             img = ag.l2norm_rows(img)
+        if getattr(ie, 'use_abs', False):      # order embeddings (ImgEncoder.py:143-145); elementwise glue on the tape
+            img = img.abs()
         toks, off, lens, _ = TextEncoder.pack_tokens(captions, lengths)
         seq = ag.gru_sequence(toks, off, lens, te.embed.weight, dict(te.rnn.named_parameters()), te.use_bi_gru)
         if last_state:
@@ -122,6 +124,8 @@ class base_module(nn.Module):
             seq = ag.gather_rows(seq, last)
         if not te.no_txtnorm:
             seq = ag.l2norm_rows(seq)
+        if getattr(te, 'use_abs', False):      # TextEncoder.py:66-68
+            seq = seq.abs()
         return img, seq, off, lens
 
     def _step(self, loss, batch_size):
@@ -165,8 +169,9 @@ class VSE_PP(base_module):
     def train_emb(self, train_data, *args, **kwargs):
         """One training step (Models.py:115-145)."""
         images, _, _, captions, lengths, _, _, _ = train_data
-        if self.config['measure'] != 'cosine':
-            raise NotImplementedError("training with measure='order' is not built")
+        if self.config['measure'] not in ('cosine', 'order'):
+            raise ValueError("unknown measure:", self.config['measure'])
+        pair_scores = ag.order_scores if self.config['measure'] == 'order' else ag.cosine_scores
         self.Eiters += 1
         self._log('Eit', self.Eiters)
         self._log('lr', self.optimizer.param_groups[0]['lr'])
@@ -178,9 +183,9 @@ class VSE_PP(base_module):
             img, cap, _, _ = self._train_towers(images, captions, lengths, pooled_images=True, last_state=True)
             if comm.on:
                 cap = ag.dp_gather_rows(cap, comm, rows, reduce=True)
-                scores = ag.dp_gather_rows(ag.cosine_scores(img, cap), comm, rows, reduce=False)
+                scores = ag.dp_gather_rows(pair_scores(img, cap), comm, rows, reduce=False)
             else:
-                scores = ag.cosine_scores(img, cap)
+                scores = pair_scores(img, cap)
             loss = ops.hinge_loss(scores, self.config['margin'], self.config['max_violation'])
             self._step(loss, scores.size(0))
 

@@ -21,7 +21,13 @@ def cosine_sim(im, s, *args):
 
 
 def order_sim(im, s, *args):
-    raise NotImplementedError("measure='order' (Objectives.py:24-30) is not on the BASELINE path; see DESIGN.md")
+    """Order-embedding similarity -|max(0, s - im)|_2 (Objectives.py:24-30)."""
+    return ops.order_scores(im, s)
+
+
+def pdist(x1, x2, *args):
+    """SAEM's euclidean distance, used as the "similarity" when measure='order' (Objectives.py:54-56, :297-307)."""
+    return ops.pdist(x1, x2)
 
 
 def pdist_cos(x1, x2, *args):
@@ -62,10 +68,7 @@ class ContrastiveLoss(nn.Module):
         else:
             raise ValueError("unknown measure:", measure)
         if self.config['name'] == 'SAEM':
-            if measure == 'cosine':
-                self.sim = pdist_cos
-            else:
-                raise NotImplementedError("SAEM pdist (order) is not on the BASELINE path")
+            self.sim = pdist if measure == 'order' else pdist_cos
         elif self.config['name'] == 'SCAN':
             if self.config['cross_attn'] == 't2i':
                 self.sim = xattn_score_t2i

@@ -161,6 +161,30 @@ def pdist_cos(x1, x2):
     return torch.nan_to_num_(res, nan=0.0, posinf=float('inf'), neginf=float('-inf'))
 
 
+def order_scores(im, s):
+    """order_sim (Objectives.py:24-30): -sqrt(sum_d max(0, s - im)^2) for every (image, sentence) pair."""
+    lib = _lib.load()
+    im, s = _dev(im, name="im"), _dev(s, name="s")
+    if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
+        raise ValueError("order_scores: im %s vs s %s" % (tuple(im.shape), tuple(s.shape)))
+    out = torch.empty(im.shape[0], s.shape[0], device=im.device, dtype=torch.float32)
+    _lib.check(lib.itr_order_scores(_p(im), _p(s), _p(out), im.shape[0], s.shape[0], im.shape[1], _stream()))
+    return out
+
+
+def pdist(x1, x2):
+    """SAEM's euclidean `pdist` (Objectives.py:297-307): sqrt(|x1|^2 - 2 x1.x2 + |x2|^2 + 1e-4)."""
+    lib = _lib.load()
+    x1, x2 = _dev(x1, name="x1"), _dev(x2, name="x2")
+    S = cosine_scores(x1, x2)
+    n1 = torch.empty(x1.shape[0], device=x1.device, dtype=torch.float32)
+    n2 = torch.empty(x2.shape[0], device=x1.device, dtype=torch.float32)
+    _lib.check(lib.itr_row_sqnorm(_p(x1), _p(n1), x1.shape[0], x1.shape[1], _stream()))
+    _lib.check(lib.itr_row_sqnorm(_p(x2), _p(n2), x2.shape[0], x2.shape[1], _stream()))
+    _lib.check(lib.itr_pdist_finish(_p(S), _p(n1), _p(n2), S.shape[0], S.shape[1], _stream()))
+    return S
+
+
 def mvm_scores(imgs, caps):
     """MultiViewMatching.forward (Fusionmodule.py:674-692)."""
     lib = _lib.load()

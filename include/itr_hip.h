@@ -50,6 +50,19 @@ int itr_l2norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, 
  * ImgEncoder.py:348; the VSE++ region pooling of SURVEY Q3). */
 int itr_mean_mid(const float *x, float *y, int64_t B, int R, int F, itr_stream_t stream);
 
+/* ---- measure='order' (config.py:74): order_sim, Objectives.py:24-30 ----------------------
+ * out[i, c] = -sqrt( sum_d max(0, s[c, d] - im[i, d])^2 ), out [Ni, Nc] row-major.  D a multiple of 4. */
+int itr_order_scores(const float *im, const float *s, float *out, int64_t Ni, int64_t Nc, int D, itr_stream_t stream);
+/* Gradient of itr_order_scores for train_emb: S = its output, dS [Ni, Nc] -> d_im [Ni, D], d_s [Nc, D].  A pair with
+ * S == 0 (no violated dimension) carries no gradient (torch propagates sqrt'(0) * 0 = NaN there). */
+int itr_order_bwd(const float *im, const float *s, const float *S, const float *dS, float *d_im, float *d_s, int64_t Ni,
+                  int64_t Nc, int D, itr_stream_t stream);
+/* SAEM with measure='order' uses the euclidean distance `pdist` as its "similarity" (Objectives.py:54-56, :297-307):
+ * S <- sqrt(n1[i] - 2 S[i, c] + n2[c] + 1e-4) in place on S = x1 x2^T (itr_gemm_nt), n1 / n2 = squared row norms
+ * (itr_row_sqnorm: out[r] = sum_d x[r, d]^2). */
+int itr_row_sqnorm(const float *x, float *out, int64_t rows, int D, itr_stream_t stream);
+int itr_pdist_finish(float *S, const float *n1, const float *n2, int64_t Ni, int64_t Nc, itr_stream_t stream);
+
 /* ---- VSRN region-relationship reasoning: Rs_GCN.forward between its 1x1 convolutions
  * (itr/modalmodule/vsrn_.py:50-71).  tpg [n_img*N, ld]: per region row the three convolution outputs side by side,
  * theta at columns [0, D), phi at [D, 2D), g at [2D, 3D) (one GEMM with the stacked weight).  For every image

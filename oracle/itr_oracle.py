@@ -176,6 +176,13 @@ def order_sim(im, s):
     return -d.pow(2).sum(2).sqrt().t()
 
 
+def pdist(x1, x2):
+    """SAEM euclidean distance, its "similarity" under measure='order' (Objectives.py:297-307)."""
+    x1_square = torch.sum(x1 * x1, 1).view(-1, 1)
+    x2_square = torch.sum(x2 * x2, 1).view(1, -1)
+    return torch.sqrt(x1_square - 2 * torch.mm(x1, x2.t()) + x2_square + 1e-4)
+
+
 def pdist_cos(x1, x2):
     """rows renormalised by their plain L2 norm (no eps), mm, NaN -> 0 (Objectives.py:310-323)."""
     a = x1 / x1.norm(dim=1)[:, None]

@@ -780,9 +780,36 @@ def g16():
     save('g16_vsrn', **out)
 
 
+# ------------------------------------------------------------------ G17 measure='order': order_sim, SAEM pdist, hinge on top
+def g17():
+    torch.manual_seed(17)
+    im = mutils.l2norm(torch.randn(9, 40), dim=-1).abs()          # order embeddings are used with use_abs
+    s = mutils.l2norm(torch.randn(13, 40), dim=-1).abs()
+    S = Objectives.order_sim(im, s)
+    P = Objectives.pdist(im, s)
+    check('order_sim', O.order_sim(im, s), S, 1e-6)
+    check('pdist', O.pdist(im, s), P, 1e-6)
+    out = dict(im=im, s=s, order=S, pdist=P)
+    # ContrastiveLoss(measure='order') value and gradients on a square batch (VSE++ dispatch)
+    with torch.enable_grad():
+        a = im[:8].clone().requires_grad_(True)
+        b = s[:8].clone().requires_grad_(True)
+        for mv in (False, True):
+            crit = Objectives.ContrastiveLoss(config={'name': 'VSE++'}, margin=0.2, measure='order', max_violation=mv)
+            a.grad = b.grad = None
+            loss = crit(a, b)
+            loss.backward()
+            tag = 'maxviol' if mv else 'sum'
+            out.update({'loss_' + tag: float(loss), 'd_im_' + tag: a.grad.clone(), 'd_s_' + tag: b.grad.clone()})
+            check('order loss ' + tag, O.hinge_loss(O.order_sim(a.detach(), b.detach()), 0.2, mv), float(loss), 1e-5)
+    crit_saem = Objectives.ContrastiveLoss(config={'name': 'SAEM'}, margin=0.2, measure='order', max_violation=True)
+    out['saem_order_loss'] = float(crit_saem(im[:8], s[:8]))
+    save('g17_order', **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17']
     for name in which:
         print("== " + name)
         globals()[name]()
