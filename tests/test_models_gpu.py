@@ -129,8 +129,8 @@ def test_vsepp_cfg1_toy_batch(golden, dev):
 def test_get_model_errors(dev):
     with pytest.raises(KeyError):
         get_model({'name': 'nope'})
-    with pytest.raises(NotImplementedError):
-        get_model({'name': 'VSRN'})
+    with pytest.raises(NotImplementedError):          # raw-image towers (torchvision CNNs) are out of scope
+        get_model(dict(C.build_config(['with', 'VSRN']), data_name='coco', vocab_size=10))
 
 
 def test_state_dict_round_trip(golden, dev):
