@@ -24,7 +24,13 @@ world = int(os.environ.get("WORLD_SIZE", "1"))
 backend = os.environ.get("ITR_DIST_BACKEND", "nccl")
 local = 0 if backend == "gloo" else int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(local)
-if world > 1:
+forced = os.environ.get("ITR_FORCE_COLLECTIVES") == "1"      # a 1-rank group whose collectives still run (RCCL on a 1-GPU box)
+if world > 1 or forced:
+    if forced and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     dist.init_process_group(backend)
 
 from itr_amd import config as C                                   # noqa: E402
@@ -57,7 +63,7 @@ for step in range(a.steps):
 torch.cuda.synchronize()
 if world == 1 or dist.get_rank() == 0:
     flat = torch.cat([p.detach().reshape(-1) for p in model.params]).cpu().numpy()
-    np.savez(a.out, dp_world=(model.optimizer.comm.world if model.optimizer.comm is not None else 1), params=flat, losses=np.asarray(losses), gnorms=np.asarray(gnorms), lr=cfg['learning_rate'])
-if world > 1:
+    np.savez(a.out, dp_on=int(model.optimizer.comm is not None), dp_world=(model.optimizer.comm.world if model.optimizer.comm is not None else 1), params=flat, losses=np.asarray(losses), gnorms=np.asarray(gnorms), lr=cfg['learning_rate'])
+if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()

@@ -47,6 +47,24 @@ def test_dp_train_step_equals_single_process(tmp_path, extra, world):
 
 
 @pytest.mark.gpu
+def test_dp_train_step_over_rccl_single_rank(tmp_path):
+    """The same sharded step with backend nccl (= RCCL) and ITR_FORCE_COLLECTIVES=1: one rank, but every collective of
+    the data-parallel path (row all-gathers, the gradient all-reduce of the gather's backward, the flat parameter-gradient
+    bucket) really goes through RCCL on device buffers -- the only way to touch it on a 1-GPU box."""
+    extra = ["--model", "SCAN", "--cross-attn", "t2i"]
+    one = _run(tmp_path, "one", 1, extra)
+    out = str(tmp_path / "rccl.npz")
+    env = dict(os.environ, ITR_FORCE_COLLECTIVES="1", ITR_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29657",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, WORKER, "--out", out] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    assert int(got["dp_on"]) == 1 and int(one["dp_on"]) == 0
+    np.testing.assert_allclose(got["losses"], one["losses"], rtol=2e-5, atol=1e-5)
+    assert np.abs(got["params"] - one["params"]).max() <= 3 * float(one["lr"]) + 1e-7
+
+
+@pytest.mark.gpu
 def test_dp_train_command_line(golden, tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 train.py with SCAN ...` (gloo, both ranks on this GPU): same
     global batches, sharded step, row-sharded validation, rank 0 writes ONE run directory -- and the checkpoint after
