@@ -4,6 +4,7 @@ torch is plumbing here: it owns device memory and the current HIP stream; every 
 raw device pointers + sizes to libitr_hip.so.  CPU tensors are rejected -- there is no fallback.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -91,6 +92,23 @@ def mean_mid(x):
     return y
 
 
+# STUDY switch: ITR_GEMM_BF16X3=1 routes the plain tower / score GEMMs (linear, linear_strided,
+# cosine_scores) through the split-bf16 kernel (terms = 3, ~1e-6 of fp32).  Default off: the product GEMM is exact fp32.
+BF16X3 = os.environ.get("ITR_GEMM_BF16X3") == "1"
+_PLANES = {}
+
+
+def _weight_planes(w):
+    """hi / lo planes of a weight tensor, cached until the tensor changes (its version counter or storage)."""
+    key = (w.data_ptr(), tuple(w.shape))
+    hit = _PLANES.get(key)
+    if hit is None or hit[0] != w._version:
+        if len(_PLANES) > 512:
+            _PLANES.clear()
+        hit = _PLANES[key] = (w._version, split_bf16(w))
+    return hit[1]
+
+
 def linear(x, weight, bias=None, act=None):
     """act(x @ weight^T + bias) on the fp32 MFMA GEMM.  x (..., K), weight (N, K)."""
     lib = _lib.load()
@@ -103,6 +121,9 @@ def linear(x, weight, bias=None, act=None):
     N = weight.shape[0]
     b = _dev(bias, name="bias") if bias is not None else None
     out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+    if BF16X3 and M and N and K % 32 == 0:
+        gemm_nt_bf16(split_bf16(x.reshape(M, K)), _weight_planes(weight), b, 3, act, out=out.view(M, N))
+        return out
     _lib.check(lib.itr_gemm_nt(_p(x), K, _p(weight), K, _p(b), _p(out), N, M, N, K, _ACTS[act], _stream()))
     return out
 
@@ -121,6 +142,8 @@ def linear_strided(base, lda, M, K, weight, bias=None, act=None, out=None):
     b = _dev(bias, name="bias") if bias is not None else None
     if out is None:
         out = torch.empty(M, N, device=base.device, dtype=torch.float32)
+    if BF16X3 and M and N and K % 32 == 0 and lda % 8 == 0:
+        return gemm_nt_bf16(split_bf16(base), _weight_planes(weight), b, 3, act, M=M, K=K, lda=lda, out=out)
     _lib.check(lib.itr_gemm_nt(_p(base), lda, _p(weight), K, _p(b), _p(out), out.stride(0), M, N, K, _ACTS[act], _stream()))
     return out
 
@@ -148,6 +171,8 @@ def cosine_scores(im, s):
     s = _dev(s, name="s")
     if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
         raise ValueError("cosine_scores: expected (Ni, D) and (Nc, D), got %s and %s" % (tuple(im.shape), tuple(s.shape)))
+    if BF16X3 and im.shape[0] and s.shape[0] and im.shape[1] % 32 == 0:
+        return gemm_nt_bf16(split_bf16(im), split_bf16(s), None, 3)
     S = torch.empty(im.shape[0], s.shape[0], device=im.device, dtype=torch.float32)
     _lib.check(lib.itr_cosine_scores(_p(im), _p(s), _p(S), im.shape[0], s.shape[0], im.shape[1], s.shape[0], _stream()))
     return S
@@ -159,6 +184,37 @@ def pdist_cos(x1, x2):
     b = _norm(x2, -1, 0.0, 3)
     res = cosine_scores(a, b)
     return torch.nan_to_num_(res, nan=0.0, posinf=float('inf'), neginf=float('-inf'))
+
+
+def split_bf16(x, with_lo=True):
+    """fp32 -> (hi, lo) bf16 planes (int16 storage), x = hi + lo + O(2^-17 |x|); lo is None for plain bf16."""
+    lib = _lib.load()
+    x = _dev(x, name="x")
+    hi = torch.empty(x.shape, device=x.device, dtype=torch.int16)
+    lo = torch.empty(x.shape, device=x.device, dtype=torch.int16) if with_lo else None
+    _lib.check(lib.itr_split_bf16(_p(x), _p(hi), _p(lo), x.numel(), _stream()))
+    return hi, lo
+
+
+def gemm_nt_bf16(a_planes, b_planes, bias=None, terms=3, act=None, M=None, K=None, lda=None, out=None):
+    """STUDY / opt-in: A B^T on the bf16 matrix core from split planes (split_bf16), fp32 accumulation.
+    terms = 3: hi.hi + hi.lo + lo.hi; terms = 1: hi.hi.  The product GEMM (linear / cosine_scores) is exact fp32."""
+    lib = _lib.load()
+    ah, al = a_planes
+    bh, bl = b_planes
+    if bh.dim() != 2 or (M is None and (ah.dim() != 2 or ah.shape[1] != bh.shape[1])) or (K is not None and K != bh.shape[1]):
+        raise ValueError("gemm_nt_bf16: A %s vs B %s" % (tuple(ah.shape), tuple(bh.shape)))
+    if terms == 3 and (al is None or bl is None):
+        raise ValueError("gemm_nt_bf16: terms=3 needs the lo planes")
+    if M is None:
+        M, K, lda = ah.shape[0], ah.shape[1], ah.shape[1]       # (M, K, lda given: strided / overlapping rows of a flat plane)
+    N = bh.shape[0]
+    b = _dev(bias, name="bias") if bias is not None else None
+    if out is None:
+        out = torch.empty(M, N, device=ah.device, dtype=torch.float32)
+    _lib.check(lib.itr_gemm_nt_bf16(_p(ah), _p(al), lda, _p(bh), _p(bl), bh.shape[1], _p(b), _p(out), out.stride(0), M, N, K,
+                                    _ACTS[act], int(terms), _stream()))
+    return out
 
 
 def order_scores(im, s):

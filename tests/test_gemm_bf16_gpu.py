@@ -1,0 +1,83 @@
+"""GPU: the split-bf16 GEMM study kernel (csrc/gemm_bf16x3.hip; opt-in, not on any default path): fragment / C-layout
+correctness with asymmetric operands, ragged M / N, bias, and the error bounds that DESIGN.md 9 quotes."""
+import numpy as np
+import pytest
+import torch
+
+from itr_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def test_split_bf16_planes(dev):
+    torch.manual_seed(0)
+    x = torch.randn(1000, device=dev) * torch.logspace(-3, 3, 1000, device=dev)
+    hi, lo = ops.split_bf16(x)
+    f = lambda p: (p.to(torch.int32) << 16).view(torch.float32)      # bf16 bits -> fp32
+    assert torch.equal(f(hi), x.to(torch.bfloat16).float())          # round to nearest even, like torch
+    assert ((x - f(hi) - f(lo)).abs() <= x.abs() * 2.0 ** -16).all()
+    assert ops.split_bf16(x, with_lo=False)[1] is None
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 77, 64), (1, 1, 32), (300, 513, 1024)])
+def test_gemm_bf16x3_vs_fp64(dev, M, N, K):
+    torch.manual_seed(M + N)
+    a = torch.randn(M, K) * (1.0 + torch.arange(M).float()[:, None] / M)        # asymmetric: a row / column swap fails
+    b = torch.randn(N, K) * (0.5 + torch.arange(N).float()[:, None] / N)
+    bias = torch.randn(N)
+    want = a.double() @ b.double().t() + bias.double()
+    scale = (a.abs().double() @ b.abs().double().t())                            # sum_k |a_k b_k|: the natural error scale
+    pa, pb = ops.split_bf16(a.to(dev)), ops.split_bf16(b.to(dev))
+    got3 = ops.gemm_nt_bf16(pa, pb, bias.to(dev), terms=3).cpu().double()
+    got1 = ops.gemm_nt_bf16(pa, pb, bias.to(dev), terms=1).cpu().double()
+    assert ((got3 - want).abs() / scale).max().item() <= 3e-5                   # worst case 3 * 2^-17 per product
+    assert ((got3 - want).abs() / scale).mean().item() <= 1e-6
+    assert ((got1 - want).abs() / scale).max().item() <= 8e-3                   # plain bf16: 2^-8 per product
+    fp32 = ops.linear(a.to(dev), b.to(dev), bias.to(dev)).cpu().double()
+    assert (got3 - fp32).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
+
+
+def test_gemm_bf16_argument_errors(dev):
+    pa = ops.split_bf16(torch.randn(4, 48, device=dev))
+    pb = ops.split_bf16(torch.randn(4, 48, device=dev))
+    with pytest.raises(Exception):
+        ops.gemm_nt_bf16(pa, pb)                                   # K not a multiple of 32
+    pa = ops.split_bf16(torch.randn(4, 32, device=dev), with_lo=False)
+    with pytest.raises(ValueError):
+        ops.gemm_nt_bf16(pa, pa, terms=3)
+    assert ops.gemm_nt_bf16(pa, pa, terms=1).shape == (4, 4)
+
+
+@pytest.mark.parametrize("act", [None, 'relu', 'tanh', 'sigmoid', 'gelu', 'leaky_relu'])
+def test_gemm_bf16x3_activation_epilogue(dev, act):
+    torch.manual_seed(3)
+    a, b, bias = torch.randn(70, 96, device=dev), torch.randn(45, 96, device=dev), torch.randn(45, device=dev)
+    got = ops.gemm_nt_bf16(ops.split_bf16(a), ops.split_bf16(b), bias, terms=3, act=act)
+    want = ops.linear(a, b, bias, act=act)
+    scale = (a.abs() @ b.abs().t()).max().item()               # sum_k |a_k b_k|; activations here are 1-Lipschitz or flatter
+    assert (got - want).abs().max().item() <= 4e-6 * scale
+
+
+def test_gemm_bf16x3_overlapping_rows_and_env_switch(dev):
+    """lda < K (SAEM's Conv2d over consecutive tokens as a GEMM) and the ITR_GEMM_BF16X3 routing of ops.linear /
+    linear_strided / cosine_scores."""
+    torch.manual_seed(4)
+    base = torch.randn(40, 64, device=dev)                      # 40 tokens x 64
+    w = torch.randn(24, 3 * 64, device=dev)
+    want = ops.linear_strided(base, 64, 38, 192, w, None, act='relu')
+    ops.BF16X3 = True
+    try:
+        got = ops.linear_strided(base, 64, 38, 192, w, None, act='relu')
+        x = torch.randn(5, 7, 64, device=dev)
+        w2, b2 = torch.randn(33, 64, device=dev), torch.randn(33, device=dev)
+        y = ops.linear(x, w2, b2, act='gelu')
+        s = ops.cosine_scores(base, base[:9].contiguous())
+        w2.mul_(2.0)                                            # in-place update -> the cached planes must be rebuilt
+        y2 = ops.linear(x, w2, b2)
+    finally:
+        ops.BF16X3 = False
+    tol = 4e-6 * 3 * 64 * 4.0        # 4e-6 of sum_k |a_k b_k| (K = 192 at most, |a_k b_k| rarely above 4)
+    assert (got - want).abs().max().item() <= tol
+    assert (y - ops.linear(x, w2 / 2.0, b2, act='gelu')).abs().max().item() <= tol and y.shape == (5, 7, 33)
+    assert (s - ops.cosine_scores(base, base[:9].contiguous())).abs().max().item() <= tol
+    assert (y2 - ops.linear(x, w2, b2)).abs().max().item() <= 2 * tol
