@@ -27,6 +27,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16 / 16x16x32)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* peak = fp32 vector peak
 
 WORKLOADS = {
@@ -37,6 +38,12 @@ WORKLOADS = {
                             lambda_softmax=9.0, raw_feature_norm="clipped_l2norm"),
     "scan_i2t_coco5k": dict(n_img=5000, vocab=11353, cross_attn="i2t", agg_func="LogSumExp", lambda_lse=20.0,
                             lambda_softmax=4.0, raw_feature_norm="clipped_l2norm"),
+    # reported SEPARATELY: the same workloads with the region x word dot products on the bf16 matrix
+    # core from split operands (hi.hi + hi.lo + lo.hi, fp32 accumulation); never the default, never the headline value
+    "scan_t2i_coco5k_bf16x3": dict(n_img=5000, vocab=11353, cross_attn="t2i", agg_func="LogSumExp", lambda_lse=6.0,
+                                   lambda_softmax=9.0, raw_feature_norm="clipped_l2norm", scan_precision="bf16x3"),
+    "scan_i2t_coco5k_bf16x3": dict(n_img=5000, vocab=11353, cross_attn="i2t", agg_func="LogSumExp", lambda_lse=20.0,
+                                   lambda_softmax=4.0, raw_feature_norm="clipped_l2norm", scan_precision="bf16x3"),
     # BASELINE.json configs[4]: SGRAF (EncoderSimilarity), sim_dim 256, l2-normalised bi-GRU words
     "sgraf_saf_coco5k": dict(n_img=5000, vocab=11353, sgraf="SAF"),
     "sgraf_sgr_coco5k": dict(n_img=5000, vocab=11353, sgraf="SGR"),
@@ -467,6 +474,12 @@ def main():
             model_name = "SGRAF-%s bi-GRU" % wl["sgraf"]
             kernel_name = "sgraf pair stage (scan_xattn_kernel emit + gemm_nt chain + pair kernels)"
             note = "time = the whole itr_sgraf_scores call (global nodes + per-4-image pair stage); flop = SURVEY 8d K8"
+        dtype, peak = "f32", FP32_MFMA_PEAK_TFLOPS
+        if wl.get("scan_precision") == "bf16x3":
+            dtype, peak = "f32 inputs split into bf16 hi+lo planes, 3 bf16 MFMA products, f32 accumulate (bf16x3)", BF16_MFMA_PEAK_TFLOPS
+            exe_flop = float(i1 - i0) * n_words * (3 * 2 * 36 * D + 36 * 37)
+            note = ("STUDY VARIANT, reported separately: region x word dot products as hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 "
+                    "(peak = dense bf16 MFMA); the fp32 epilogue is unchanged.  " + note)
         from itr_amd import ops as _ops
         i2t = _ops.recall_from_ranks(ranks[0])
         t2i = _ops.recall_from_ranks(ranks[2])
@@ -474,7 +487,7 @@ def main():
             "metric": "pairs/sec scored (5k img x 25k cap) + Recall@1 parity, 1/2/4/8 MI355X",
             "value": pairs / (dt / args.steps), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": args.workload, "model": model_name,
                        "n_img": n_img, "n_cap": n_cap, "regions": R, "feat_dim": F_, "embed": D,
                        "n_words": n_words, "parallelism": "row-shard x%d + 1 all-gather" % world,
@@ -484,14 +497,14 @@ def main():
             # order-sensitive checksums of the four rank vectors: equal across GPU counts iff the sharded result is identical
             "rank_checksum": [int((np.asarray(r, np.int64) * (np.arange(len(r)) % 9973 + 1)).sum()) for r in ranks],
             "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": alg_flop / (k_ms * 1e-3) / 1e12,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": alg_flop / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "peak": peak, "unit": "TFLOP/s",
+                         "frac": alg_flop / (k_ms * 1e-3) / 1e12 / peak,
                          "traffic": pmc_traffic(args.workload, world)[0],
                          "traffic_source": pmc_traffic(args.workload, world)[1],
                          "kernel_ms": k_ms, "algorithmic_flop_per_launch": alg_flop,
                          "executed_flop_per_launch": exe_flop,
                          "executed_tflops": exe_flop / (k_ms * 1e-3) / 1e12,
-                         "executed_frac": exe_flop / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "executed_frac": exe_flop / (k_ms * 1e-3) / 1e12 / peak,
                          "note": note},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -38,6 +38,8 @@ namespace itr {
 struct ScanArgs {
     const float *img;        // [Ni, 36, D]
     const float *wtiled;     // [n_tiles * 64, D]   words re-packed tile by tile (zero rows = padding)
+    const uint16_t *img_bf;  // bf16x3 variant: split planes of img,    [Ni * 36][hi | lo][D] bf16 (scan_split_rows_kernel)
+    const uint16_t *wt_bf;   //                 split planes of wtiled, [n_tiles * 64][hi | lo][D]
     const ScanTileMeta *meta;  // [n_tiles]
     const float *gram;       // [Ni, 36, 36]        (t2i)   V_i V_i^T
     const float *wnorm;      // [n_tiles * 64]      (t2i)   ||E_w|| per tiled column
@@ -134,6 +136,11 @@ struct NormAcc {
     }
 };
 
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+
+// PREC 0: exact fp32 main loop (scan_mainloop.inc).  PREC 1: split-bf16 "bf16x3" main loop (scan_mainloop_bf16.inc; opt-in,
+// reported separately -- DESIGN.md 9).  The epilogue is shared.
+template <int PREC>
 __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ScanSmem &sm = *reinterpret_cast<ScanSmem *>(smem_raw);
@@ -163,7 +170,12 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
     // ---- tile metadata: needed by the epilogue only, so its load overlaps the main loop
     if (tid < 64) reinterpret_cast<int32_t *>(&sm.meta)[tid] = reinterpret_cast<const int32_t *>(g.meta + ct)[tid];
 
+    const int fi = lane & 15, fg = lane >> 4;
+    if constexpr (PREC == 0) {
 #include "scan_mainloop.inc"
+    } else {
+#include "scan_mainloop_bf16.inc"
+    }
 
     const int norm = g.norm;
     const float ls = g.lambda_softmax;
@@ -698,6 +710,30 @@ __global__ __launch_bounds__(256) void scan_pack_kernel(const float *__restrict_
     }
 }
 
+// bf16x3 variant: rows of an fp32 matrix [rows, D] -> interleaved split planes [rows][hi | lo][D] bf16
+// (hi = bf16(x), lo = bf16(x - hi), round to nearest even): x = hi + lo + O(2^-17 |x|)
+__global__ __launch_bounds__(256) void scan_split_rows_kernel(const float *__restrict__ x, uint16_t *__restrict__ out, int64_t rows,
+                                                              int D) {
+    const int64_t row = blockIdx.y;
+    const int d = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (d >= D) return;
+    const float4 v = *reinterpret_cast<const float4 *>(x + row * D + d);
+    auto rne = [](float f) -> uint32_t {
+        const uint32_t u = __float_as_uint(f);
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = rne(in[i]);
+        l[i] = rne(in[i] - __uint_as_float(h[i] << 16));
+    }
+    uint16_t *o = out + row * 2 * (int64_t)D + d;
+    *reinterpret_cast<uint2 *>(o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    *reinterpret_cast<uint2 *>(o + D) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static_assert(sizeof(ScanSmem) <= 80 * 1024, "two workgroups per CU need <= 80 KiB of LDS each");
 
@@ -830,10 +866,28 @@ extern "C" int itr_scan_prepare(const float *img, const float *words, const int6
 namespace itr {
 // emit_p / emit_cn != null: also write the normalised attention weights [Ni, n_tiles*64, 36] and
 // 1 / (||ctx|| + eps) [Ni, n_tiles*64] (SGRAF); S may then be null-free scratch of the usual shape.
+static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
+                             int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
+                             void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
+                             int64_t img_count, void *bf16_ws, itr_stream_t stream);
+
 int scan_scores_impl(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
                      int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
                      void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
                      int64_t img_count, itr_stream_t stream) {
+    return scan_scores_impl2(img, n_tiles, Ni, Nc, n_rows, R, D, mode, norm, agg, lambda_softmax, lambda_lse, S, ldS, workspace,
+                             workspace_bytes, emit_p, emit_cn, img_index0, img_count, nullptr, stream);
+}
+
+static size_t scan_bf16_ws_bytes(int64_t Ni, int R, int64_t n_tiles, int D) {
+    return align256((size_t)Ni * R * D * 4) + align256((size_t)n_tiles * SC_NT * D * 4);
+}
+
+// bf16_ws != null: the split-bf16 ("bf16x3") main loop; img and the packed word tiles are split into bf16_ws first
+static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
+                             int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
+                             void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
+                             int64_t img_count, void *bf16_ws, itr_stream_t stream) {
     ITR_REQUIRE(img && S && workspace, "itr_scan_xattn_scores: null pointer");
     ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && n_tiles >= 0 && ldS >= Nc, "itr_scan_xattn_scores: bad shape");
     if (mode != 0 && mode != 1) { set_error("unknown cross_attn mode %d", mode); return ITR_ERR_BADARG; }
@@ -877,13 +931,34 @@ int scan_scores_impl(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, 
     ITR_UNSUPPORTED(nblk > 0x7fffffffLL, "itr_scan_xattn_scores: grid too large; shard the call");
     static bool attr_set = false;
     if (!attr_set) {
-        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel),
+        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     size_t lds = sizeof(ScanSmem);
     if (const char *ex = getenv("ITR_SCAN_LDS_EXTRA")) lds += (size_t)atoi(ex);   // occupancy experiments only
-    hipLaunchKernelGGL(scan_xattn_kernel, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+    if (bf16_ws) {
+        ITR_UNSUPPORTED((uint64_t)Ni * R * D * 4 >= (1ull << 32) || (uint64_t)SC_NT * D * 4 >= (1ull << 32),
+                        "itr_scan_xattn_scores_bf16x3: per-launch operand offsets must fit 32 bits; shard the images");
+        uint16_t *img_bf = static_cast<uint16_t *>(bf16_ws);
+        uint16_t *wt_bf = reinterpret_cast<uint16_t *>(static_cast<char *>(bf16_ws) + align256((size_t)Ni * R * D * 4));
+        const dim3 sg((unsigned)ceil_div(D / 4, 256), 1);
+        ITR_REQUIRE(Ni * R <= 0x7fffffff / 1 && n_tiles * SC_NT <= 0x7fffffff, "scan split: too many rows");
+        for (int64_t r0 = 0; r0 < Ni * R; r0 += 65535)
+            hipLaunchKernelGGL(scan_split_rows_kernel, dim3(sg.x, (unsigned)min((int64_t)65535, Ni * R - r0)), dim3(256), 0, st,
+                               a.img + r0 * D, img_bf + r0 * 2 * D, Ni * R - r0, D);
+        for (int64_t r0 = 0; r0 < n_tiles * SC_NT; r0 += 65535)
+            hipLaunchKernelGGL(scan_split_rows_kernel, dim3(sg.x, (unsigned)min((int64_t)65535, n_tiles * SC_NT - r0)), dim3(256), 0,
+                               st, w.wtiled + r0 * D, wt_bf + r0 * 2 * D, n_tiles * SC_NT - r0, D);
+        ITR_CHECK_LAUNCH("scan split");
+        a.img_bf = img_bf;
+        a.wt_bf = wt_bf;
+        hipLaunchKernelGGL(scan_xattn_kernel<1>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(scan_xattn_kernel<0>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+    }
     ITR_CHECK_LAUNCH("scan_xattn");
     return ITR_OK;
 }
@@ -897,13 +972,27 @@ extern "C" int itr_scan_xattn_scores(const float *img, int64_t n_tiles, int64_t 
                                  ldS, workspace, workspace_bytes, nullptr, nullptr, 0, -1, stream);
 }
 
+extern "C" size_t itr_scan_bf16_workspace_bytes(int64_t Ni, int R, int64_t n_tiles, int D) {
+    return itr::scan_bf16_ws_bytes(Ni, R, n_tiles, D);
+}
+
+extern "C" int itr_scan_xattn_scores_bf16x3(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
+                                            int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S,
+                                            int64_t ldS, void *workspace, size_t workspace_bytes, void *bf16_workspace,
+                                            size_t bf16_workspace_bytes, itr_stream_t stream) {
+    ITR_REQUIRE(bf16_workspace && bf16_workspace_bytes >= itr::scan_bf16_ws_bytes(Ni, R, n_tiles, D),
+                "itr_scan_xattn_scores_bf16x3: bf16 workspace missing or too small");
+    return itr::scan_scores_impl2(img, n_tiles, Ni, Nc, n_rows, R, D, mode, norm, agg, lambda_softmax, lambda_lse, S, ldS, workspace,
+                                  workspace_bytes, nullptr, nullptr, 0, -1, bf16_workspace, stream);
+}
+
 // Diagnostics for tools/: resident workgroups per CU of the SCAN kernel as the runtime sees it.
 extern "C" int itr_debug_scan_occupancy(int *blocks_per_cu, int *lds_bytes) {
     using namespace itr;
     ITR_REQUIRE(blocks_per_cu && lds_bytes, "itr_debug_scan_occupancy: null pointer");
-    ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel),
+    ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanSmem)));
-    ITR_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(scan_xattn_kernel),
+    ITR_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(scan_xattn_kernel<0>),
                                                                SC_THREADS, sizeof(ScanSmem)));
     *lds_bytes = (int)sizeof(ScanSmem);
     return ITR_OK;

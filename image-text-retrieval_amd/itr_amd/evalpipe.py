@@ -194,7 +194,8 @@ class GruModelEval:
         S = ops.scan_xattn_scores(img, words_all, plan, cross_attn=xa,
                                   raw_feature_norm=cfg.get('raw_feature_norm', 'clipped_l2norm'),
                                   agg_func=cfg.get('agg_func', 'LogSumExp'), lambda_lse=cfg.get('lambda_lse', 6.0),
-                                  lambda_softmax=cfg.get('lambda_softmax', 9.0), workspace=ws)
+                                  lambda_softmax=cfg.get('lambda_softmax', 9.0), workspace=ws,
+                                  precision=cfg.get('scan_precision', 'fp32'))    # 'bf16x3': opt-in study variant
         if timers is not None:
             timers['scan_end'].record()
         # -- step 4

@@ -357,9 +357,11 @@ def scan_prepare(images, words, plan, cross_attn='t2i'):
 
 
 def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='clipped_l2norm',
-                      agg_func='LogSumExp', lambda_lse=6.0, lambda_softmax=9.0, out=None, workspace=None):
+                      agg_func='LogSumExp', lambda_lse=6.0, lambda_softmax=9.0, out=None, workspace=None, precision='fp32'):
     """xattn_score_t2i / _i2t (Objectives.py:329-417).  images (Ni, 36, D); words (n_rows, D) with the
-    caption layout described by `plan` (ScanPlan).  -> (Ni, Nc)."""
+    caption layout described by `plan` (ScanPlan).  -> (Ni, Nc).
+    precision='bf16x3' (opt-in study variant): the region x word dot products run on the bf16 matrix core
+    from split operands (hi.hi + hi.lo + lo.hi, fp32 accumulation); everything else is unchanged."""
     lib = _lib.load()
     if cross_attn not in ('t2i', 'i2t'):
         raise ValueError("unknown first norm type:", raw_feature_norm)  # the reference's message (Objectives.py:71)
@@ -376,9 +378,21 @@ def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='c
     if Ni == 0 or plan.Nc == 0:
         return out
     if plan.long_idx is not None:
+        if precision != 'fp32':
+            raise NotImplementedError("scan_xattn_scores: precision=%r with captions of more than %d words" % (precision, SCAN_NT))
         return _scan_scores_with_long_captions(images, words, plan, cross_attn, raw_feature_norm, agg_func, lambda_lse, lambda_softmax,
                                                out, workspace)
     ws = workspace if workspace is not None else scan_prepare(images, words, plan, cross_attn)
+    if precision == 'bf16x3':
+        bsz = lib.itr_scan_bf16_workspace_bytes(Ni, R, plan.n_tiles, D)
+        bws = torch.empty(bsz, device=images.device, dtype=torch.uint8)
+        _lib.check(lib.itr_scan_xattn_scores_bf16x3(
+            _p(images), plan.n_tiles, Ni, plan.Nc, n_rows, R, D, 0 if cross_attn == 't2i' else 1,
+            _NORMS[raw_feature_norm], _AGGS[agg_func], float(lambda_softmax), float(lambda_lse), _p(out), out.stride(0),
+            _p(ws), ws.numel(), _p(bws), bsz, _stream()))
+        return out
+    if precision != 'fp32':
+        raise ValueError("scan_xattn_scores: precision must be 'fp32' or 'bf16x3'")
     _lib.check(lib.itr_scan_xattn_scores(
         _p(images), plan.n_tiles, Ni, plan.Nc, n_rows, R, D, 0 if cross_attn == 't2i' else 1,
         _NORMS[raw_feature_norm], _AGGS[agg_func], float(lambda_softmax), float(lambda_lse), _p(out), out.stride(0),
