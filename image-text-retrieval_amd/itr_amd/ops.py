@@ -95,18 +95,13 @@ def mean_mid(x):
 # STUDY switch: ITR_GEMM_BF16X3=1 routes the plain tower / score GEMMs (linear, linear_strided,
 # cosine_scores) through the split-bf16 kernel (terms = 3, ~1e-6 of fp32).  Default off: the product GEMM is exact fp32.
 BF16X3 = os.environ.get("ITR_GEMM_BF16X3") == "1"
-_PLANES = {}
 
 
 def _weight_planes(w):
-    """hi / lo planes of a weight tensor, cached until the tensor changes (its version counter or storage)."""
-    key = (w.data_ptr(), tuple(w.shape))
-    hit = _PLANES.get(key)
-    if hit is None or hit[0] != w._version:
-        if len(_PLANES) > 512:
-            _PLANES.clear()
-        hit = _PLANES[key] = (w._version, split_bf16(w))
-    return hit[1]
+    """hi / lo planes of a weight tensor.  Not cached: call sites hand over detached views and temporaries whose address
+    and version counter do not identify their contents (a cached plane of a recycled temporary gave wrong CAMERA scores);
+    splitting costs one read + one write of the weight, ~1 % of the GEMM it feeds."""
+    return split_bf16(w)
 
 
 def linear(x, weight, bias=None, act=None):

@@ -72,7 +72,7 @@ def test_gemm_bf16x3_overlapping_rows_and_env_switch(dev):
         w2, b2 = torch.randn(33, 64, device=dev), torch.randn(33, device=dev)
         y = ops.linear(x, w2, b2, act='gelu')
         s = ops.cosine_scores(base, base[:9].contiguous())
-        w2.mul_(2.0)                                            # in-place update -> the cached planes must be rebuilt
+        w2.mul_(2.0)                                            # in-place update: the planes are rebuilt on every call
         y2 = ops.linear(x, w2, b2)
     finally:
         ops.BF16X3 = False
