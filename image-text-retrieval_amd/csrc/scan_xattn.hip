@@ -38,8 +38,8 @@ namespace itr {
 struct ScanArgs {
     const float *img;        // [Ni, 36, D]
     const float *wtiled;     // [n_tiles * 64, D]   words re-packed tile by tile (zero rows = padding)
-    const uint16_t *img_bf;  // bf16x3 variant: split planes of img,    [Ni * 36][hi | lo][D] bf16 (scan_split_rows_kernel)
-    const uint16_t *wt_bf;   //                 split planes of wtiled, [n_tiles * 64][hi | lo][D]
+    const uint16_t *img_bf;  // bf16x3 variant: split planes of img,    [Ni * 36][D / 32][hi | lo][32] bf16 (scan_split_rows_kernel)
+    const uint16_t *wt_bf;   //                 split planes of wtiled, [n_tiles * 64][D / 32][hi | lo][32]
     const ScanTileMeta *meta;  // [n_tiles]
     const float *gram;       // [Ni, 36, 36]        (t2i)   V_i V_i^T
     const float *wnorm;      // [n_tiles * 64]      (t2i)   ||E_w|| per tiled column
@@ -710,8 +710,8 @@ __global__ __launch_bounds__(256) void scan_pack_kernel(const float *__restrict_
     }
 }
 
-// bf16x3 variant: rows of an fp32 matrix [rows, D] -> interleaved split planes [rows][hi | lo][D] bf16
-// (hi = bf16(x), lo = bf16(x - hi), round to nearest even): x = hi + lo + O(2^-17 |x|)
+// bf16x3 variant: rows of an fp32 matrix [rows, D] -> split planes interleaved per 32-wide K chunk,
+// [rows][D / 32][hi (32 bf16) | lo (32 bf16)]  (hi = bf16(x), lo = bf16(x - hi), round to nearest even): x = hi + lo + O(2^-17 |x|)
 __global__ __launch_bounds__(256) void scan_split_rows_kernel(const float *__restrict__ x, uint16_t *__restrict__ out, int64_t rows,
                                                               int D) {
     const int64_t row = blockIdx.y;
@@ -729,9 +729,9 @@ __global__ __launch_bounds__(256) void scan_split_rows_kernel(const float *__res
         h[i] = rne(in[i]);
         l[i] = rne(in[i] - __uint_as_float(h[i] << 16));
     }
-    uint16_t *o = out + row * 2 * (int64_t)D + d;
+    uint16_t *o = out + row * 2 * (int64_t)D + (d >> 5) * 64 + (d & 31);
     *reinterpret_cast<uint2 *>(o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    *reinterpret_cast<uint2 *>(o + D) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    *reinterpret_cast<uint2 *>(o + 32) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -955,7 +955,16 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
         ITR_CHECK_LAUNCH("scan split");
         a.img_bf = img_bf;
         a.wt_bf = wt_bf;
-        hipLaunchKernelGGL(scan_xattn_kernel<1>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+        // ablation builds of the main loop (tools/scan_ablate2.py bf16x3): 5 = no global loads, 9 = no MFMAs -- results are garbage
+        const int abl = getenv("ITR_SCAN_BF16_ABLATE") ? atoi(getenv("ITR_SCAN_BF16_ABLATE")) : 0;
+        if (abl == 5) {
+            ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL(scan_xattn_kernel<5>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+        } else if (abl == 9) {
+            ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL(scan_xattn_kernel<9>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+        } else
+            hipLaunchKernelGGL(scan_xattn_kernel<1>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
     } else {
         hipLaunchKernelGGL(scan_xattn_kernel<0>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
     }

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "image-text-retrieval_amd"))
 import numpy as np, torch
 from itr_amd import ops
 dev = torch.device("cuda:0")
+PREC = sys.argv[1] if len(sys.argv) > 1 else "fp32"      # "bf16x3": the opt-in split-bf16 main loop
 Ni = 1000
 Nc, D = 5 * Ni, 1024
 rng = np.random.RandomState(0)
@@ -22,12 +23,12 @@ for extra in (0, 4000):
     for name, flag in (("full", 0), ("no_epilogue", 1), ("no_gload_no_epi", 3), ("no_mfma_no_epi", 5)):
         os.environ["ITR_SCAN_DEBUG"] = str(flag)
         for _ in range(2):
-            ops.scan_xattn_scores(img, words, plan, workspace=ws)
+            ops.scan_xattn_scores(img, words, plan, workspace=ws, precision=PREC)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
-            ops.scan_xattn_scores(img, words, plan, workspace=ws)
+            ops.scan_xattn_scores(img, words, plan, workspace=ws, precision=PREC)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
         print("blocks/CU=%d %-18s %8.2f ms   %6.1f TF/s" % (2 if extra == 0 else 1, name, ms, flop / ms / 1e9))
@@ -39,7 +40,7 @@ for extra in (0, 4000):
         out = torch.zeros(Ni, Nc + 64, device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ops.scan_xattn_scores(img, words, plan, workspace=ws, out=out)
+        ops.scan_xattn_scores(img, words, plan, workspace=ws, out=out, precision=PREC)
         e1.record()
         torch.cuda.synchronize()
         wall_ms = e0.elapsed_time(e1)
