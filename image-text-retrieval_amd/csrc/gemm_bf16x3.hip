@@ -6,6 +6,9 @@
 // fp32-equivalent work against 157 for v_mfma_f32_32x32x2_f32.  NOT wired into any default path: the product GEMM
 // (gemm_f32.hip) is exact fp32; this kernel is reported separately and opt-in.
 //
+// Operand format: per row and 32-wide K chunk the 64 B of hi are followed by the 64 B of lo ([rows][K / 32][hi | lo][32] bf16),
+// so one chunk of one row is one full 128-byte line (separate whole-row planes made every load use half a line; the vector
+// L1 path then limits -- found on the SCAN loop).
 // Tiling: 128 x 128 per workgroup, 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs);
 // K chunks of 32 staged through LDS (row stride 80 B: 16 consecutive rows hit 16 different 16-byte bank groups), the next
 // chunk's global loads are in flight in registers while the current one is multiplied.
@@ -15,12 +18,12 @@ namespace itr {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;   // (arrays of HIP uint4 that live across blocks go to scratch)
 
 constexpr int GB_T = 128, GB_BK = 32, GB_ROWB = 80, GB_PLANE = GB_T * GB_ROWB;   // 10 240 B per operand plane
 
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict__ x, uint16_t *__restrict__ hi,
-                                                         uint16_t *__restrict__ lo, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict__ x, uint16_t *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // K % 32 == 0, so chunks never straddle rows
     if (i >= n) return;
     auto rne = [](float v) -> uint32_t {       // fp32 -> bf16 bits, round to nearest even (finite inputs)
         const uint32_t u = __float_as_uint(v);
@@ -28,13 +31,13 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict
     };
     const float v = x[i];
     const uint32_t h = rne(v);
-    hi[i] = (uint16_t)h;
-    if (lo) lo[i] = (uint16_t)rne(v - __uint_as_float(h << 16));
+    const int64_t o = (i >> 5) * 64 + (i & 31);
+    out[o] = (uint16_t)h;
+    out[o + 32] = (uint16_t)rne(v - __uint_as_float(h << 16));
 }
 
 template <int TERMS>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t *__restrict__ Ah, const uint16_t *__restrict__ Al,
-                                                           const uint16_t *__restrict__ Bh, const uint16_t *__restrict__ Bl,
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ B,
                                                            const float *__restrict__ bias, float *__restrict__ C, int64_t ldc,
                                                            int64_t M, int64_t N, int K, int64_t lda, int64_t ldb, int act,
                                                            int tiles_m, int tiles_n) {
@@ -57,23 +60,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t *__res
     const int64_t m0 = (int64_t)tm * GB_T, n0 = (int64_t)tn * GB_T;
 
     // global -> register staging: thread = (row r, 16-byte granule gq of the 64-byte chunk row); rows r and r + 64
-    const int r = tid >> 2, gq = tid & 3;
-    const int64_t ra0 = min(m0 + r, M - 1) * lda + gq * 8, ra1 = min(m0 + r + 64, M - 1) * lda + gq * 8;
-    const int64_t rb0 = min(n0 + r, N - 1) * ldb + gq * 8, rb1 = min(n0 + r + 64, N - 1) * ldb + gq * 8;
-    const unsigned ls0 = (unsigned)r * GB_ROWB + gq * 16, ls1 = (unsigned)(r + 64) * GB_ROWB + gq * 16;
-    uint4 sah0, sah1, sbh0, sbh1, sal0, sal1, sbl0, sbl1;
+    // TERMS == 3: 8 lanes cover the whole 128-byte line of one row chunk (granule p: hi for p < 4, lo otherwise), 32 rows per
+    // pass, 4 passes per operand.  TERMS == 1: only the hi half is needed -- 4 lanes per row, 64 rows per pass, 2 passes.
+    constexpr int LPR = TERMS == 3 ? 8 : 4, PASS = TERMS == 3 ? 4 : 2, RPP = 256 / LPR;
+    const int r = tid / LPR, p = tid % LPR;
+    int64_t ga[PASS], gb[PASS];
+    unsigned la[PASS];
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+        ga[i] = min(m0 + r + RPP * i, M - 1) * lda + p * 8;
+        gb[i] = min(n0 + r + RPP * i, N - 1) * ldb + p * 8;
+        la[i] = (unsigned)(p >> 2) * GB_PLANE + (unsigned)(r + RPP * i) * GB_ROWB + (p & 3) * 16;
+    }
+    u32x4 sa[PASS], sb[PASS];
 #define GB_LOAD(kc)                                                                                  \
     {                                                                                                \
-        const int64_t ko = (int64_t)(kc) * GB_BK;                                                    \
-        sah0 = *reinterpret_cast<const uint4 *>(Ah + ra0 + ko);                                      \
-        sah1 = *reinterpret_cast<const uint4 *>(Ah + ra1 + ko);                                      \
-        sbh0 = *reinterpret_cast<const uint4 *>(Bh + rb0 + ko);                                      \
-        sbh1 = *reinterpret_cast<const uint4 *>(Bh + rb1 + ko);                                      \
-        if (TERMS == 3) {                                                                            \
-            sal0 = *reinterpret_cast<const uint4 *>(Al + ra0 + ko);                                  \
-            sal1 = *reinterpret_cast<const uint4 *>(Al + ra1 + ko);                                  \
-            sbl0 = *reinterpret_cast<const uint4 *>(Bl + rb0 + ko);                                  \
-            sbl1 = *reinterpret_cast<const uint4 *>(Bl + rb1 + ko);                                  \
+        const int64_t ko = (int64_t)(kc) * (2 * GB_BK);                                              \
+        _Pragma("unroll") for (int i = 0; i < PASS; ++i) {                                           \
+            sa[i] = *reinterpret_cast<const u32x4 *>(A + ga[i] + ko);                                \
+            sb[i] = *reinterpret_cast<const u32x4 *>(B + gb[i] + ko);                                \
         }                                                                                            \
     }
     f32x16 acc[2][2];
@@ -90,15 +95,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t *__res
     const int nk = K / GB_BK;
     GB_LOAD(0)
     for (int kc = 0; kc < nk; ++kc) {
-        *reinterpret_cast<uint4 *>(lds + ls0) = sah0;
-        *reinterpret_cast<uint4 *>(lds + ls1) = sah1;
-        *reinterpret_cast<uint4 *>(lds + 2 * GB_PLANE + ls0) = sbh0;
-        *reinterpret_cast<uint4 *>(lds + 2 * GB_PLANE + ls1) = sbh1;
-        if (TERMS == 3) {
-            *reinterpret_cast<uint4 *>(lds + GB_PLANE + ls0) = sal0;
-            *reinterpret_cast<uint4 *>(lds + GB_PLANE + ls1) = sal1;
-            *reinterpret_cast<uint4 *>(lds + 3 * GB_PLANE + ls0) = sbl0;
-            *reinterpret_cast<uint4 *>(lds + 3 * GB_PLANE + ls1) = sbl1;
+#pragma unroll
+        for (int i = 0; i < PASS; ++i) {
+            *reinterpret_cast<u32x4 *>(lds + la[i]) = sa[i];
+            *reinterpret_cast<u32x4 *>(lds + 2 * GB_PLANE + la[i]) = sb[i];
         }
         __syncthreads();
         if (kc + 1 < nk) GB_LOAD(kc + 1)
@@ -146,38 +146,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t *__res
 
 }  // namespace itr
 
-extern "C" int itr_split_bf16(const float *x, uint16_t *hi, uint16_t *lo, int64_t n, itr_stream_t stream) {
-    ITR_REQUIRE(n >= 0, "itr_split_bf16: bad size");
-    if (n == 0) return ITR_OK;
-    ITR_REQUIRE(x && hi, "itr_split_bf16: null pointer");
-    ITR_REQUIRE(itr::ceil_div(n, (int64_t)256) <= 0x7fffffff, "itr_split_bf16: too many elements for one call");
-    hipLaunchKernelGGL(itr::split_bf16_kernel, dim3((unsigned)itr::ceil_div(n, (int64_t)256)), dim3(256), 0, itr::as_stream(stream), x,
-                       hi, lo, n);
+extern "C" int itr_split_bf16(const float *x, uint16_t *out, int64_t rows, int64_t K, itr_stream_t stream) {
+    ITR_REQUIRE(rows >= 0 && K >= 32 && K % 32 == 0, "itr_split_bf16: K must be a positive multiple of 32");
+    if (rows == 0) return ITR_OK;
+    ITR_REQUIRE(x && out, "itr_split_bf16: null pointer");
+    ITR_REQUIRE(itr::ceil_div(rows * K, (int64_t)256) <= 0x7fffffff, "itr_split_bf16: too many elements for one call");
+    hipLaunchKernelGGL(itr::split_bf16_kernel, dim3((unsigned)itr::ceil_div(rows * K, (int64_t)256)), dim3(256), 0, itr::as_stream(stream),
+                       x, out, rows * K);
     ITR_CHECK_LAUNCH("split_bf16");
     return ITR_OK;
 }
 
-extern "C" int itr_gemm_nt_bf16(const uint16_t *Ah, const uint16_t *Al, int64_t lda, const uint16_t *Bh, const uint16_t *Bl,
-                                int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
-                                int terms, itr_stream_t stream) {
-    ITR_REQUIRE(M >= 0 && N >= 0 && K >= 32 && K % 32 == 0 && K <= 0x7fffffff, "itr_gemm_nt_bf16: K must be a positive multiple of 32");
+extern "C" int itr_gemm_nt_bf16(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb, const float *bias, float *C,
+                                int64_t ldc, int64_t M, int64_t N, int64_t K, int act, int terms, itr_stream_t stream) {
+    ITR_REQUIRE(M >= 0 && N >= 0 && K >= 32 && K % 32 == 0 && K <= 0x3fffffff, "itr_gemm_nt_bf16: K must be a positive multiple of 32");
     ITR_REQUIRE(terms == 1 || terms == 3, "itr_gemm_nt_bf16: terms must be 1 (bf16) or 3 (bf16x3)");
     if (M == 0 || N == 0) return ITR_OK;
-    ITR_REQUIRE(Ah && Bh && C && (terms == 1 || (Al && Bl)), "itr_gemm_nt_bf16: null pointer");
-    ITR_REQUIRE(ldc >= N && lda >= 8 && ldb >= 8 && lda % 8 == 0 && ldb % 8 == 0, "itr_gemm_nt_bf16: ldc >= N, lda / ldb multiples of 8");
+    ITR_REQUIRE(A && B && C, "itr_gemm_nt_bf16: null pointer");
+    ITR_REQUIRE(ldc >= N && lda >= 64 && ldb >= 64 && lda % 64 == 0 && ldb % 64 == 0,
+                "itr_gemm_nt_bf16: ldc >= N; lda / ldb count interleaved bf16 elements (2 x the fp32 stride), multiples of 64");
     ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt_bf16: unknown activation");
-    const uintptr_t al = reinterpret_cast<uintptr_t>(Ah) | reinterpret_cast<uintptr_t>(Bh) | reinterpret_cast<uintptr_t>(Al) |
-                         reinterpret_cast<uintptr_t>(Bl);
-    ITR_REQUIRE((al & 15) == 0, "itr_gemm_nt_bf16: operands must be 16-byte aligned");
+    ITR_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0, "itr_gemm_nt_bf16: operands must be 16-byte aligned");
     const int64_t tm = itr::ceil_div(M, (int64_t)itr::GB_T), tn = itr::ceil_div(N, (int64_t)itr::GB_T);
     ITR_REQUIRE(tm * tn <= 0x7fffffff, "itr_gemm_nt_bf16: too many tiles");
     const dim3 grid((unsigned)(tm * tn));
     if (terms == 3)
-        hipLaunchKernelGGL(itr::gemm_bf16_kernel<3>, grid, dim3(256), 0, itr::as_stream(stream), Ah, Al, Bh, Bl, bias, C, ldc, M, N,
-                           (int)K, lda, ldb, act, (int)tm, (int)tn);
+        hipLaunchKernelGGL(itr::gemm_bf16_kernel<3>, grid, dim3(256), 0, itr::as_stream(stream), A, B, bias, C, ldc, M, N, (int)K, lda, ldb,
+                           act, (int)tm, (int)tn);
     else
-        hipLaunchKernelGGL(itr::gemm_bf16_kernel<1>, grid, dim3(256), 0, itr::as_stream(stream), Ah, Al, Bh, Bl, bias, C, ldc, M, N,
-                           (int)K, lda, ldb, act, (int)tm, (int)tn);
+        hipLaunchKernelGGL(itr::gemm_bf16_kernel<1>, grid, dim3(256), 0, itr::as_stream(stream), A, B, bias, C, ldc, M, N, (int)K, lda, ldb,
+                           act, (int)tm, (int)tn);
     ITR_CHECK_LAUNCH("gemm_bf16");
     return ITR_OK;
 }

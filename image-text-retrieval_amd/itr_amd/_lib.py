@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 i32, i64, f32, vp, sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -22,8 +22,8 @@ SIGNATURES = {
     "itr_abi_version": (i32, []),
     "itr_l2norm_rows": (i32, [vp, vp, i64, i32, f32, i32, i32, vp]),
     "itr_mean_mid": (i32, [vp, vp, i64, i32, i32, vp]),
-    "itr_split_bf16": (i32, [vp, vp, vp, i64, vp]),
-    "itr_gemm_nt_bf16": (i32, [vp, vp, i64, vp, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, vp]),
+    "itr_split_bf16": (i32, [vp, vp, i64, i64, vp]),
+    "itr_gemm_nt_bf16": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, vp]),
     "itr_gcn_relation": (i32, [vp, i64, vp, i64, i64, i32, i32, vp]),
     "itr_order_scores": (i32, [vp, vp, vp, i64, i64, i32, vp]),
     "itr_order_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, vp]),

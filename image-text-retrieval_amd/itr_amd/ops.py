@@ -137,7 +137,7 @@ def linear_strided(base, lda, M, K, weight, bias=None, act=None, out=None):
     b = _dev(bias, name="bias") if bias is not None else None
     if out is None:
         out = torch.empty(M, N, device=base.device, dtype=torch.float32)
-    if BF16X3 and M and N and K % 32 == 0 and lda % 8 == 0:
+    if BF16X3 and M and N and K % 32 == 0 and lda % 32 == 0:
         return gemm_nt_bf16(split_bf16(base), _weight_planes(weight), b, 3, act, M=M, K=K, lda=lda, out=out)
     _lib.check(lib.itr_gemm_nt(_p(base), lda, _p(weight), K, _p(b), _p(out), out.stride(0), M, N, K, _ACTS[act], _stream()))
     return out
@@ -181,33 +181,32 @@ def pdist_cos(x1, x2):
     return torch.nan_to_num_(res, nan=0.0, posinf=float('inf'), neginf=float('-inf'))
 
 
-def split_bf16(x, with_lo=True):
-    """fp32 -> (hi, lo) bf16 planes (int16 storage), x = hi + lo + O(2^-17 |x|); lo is None for plain bf16."""
+def split_bf16(x):
+    """fp32 [..., K] -> split-bf16 operand [rows, 2 K] (int16 storage): per row and 32-wide chunk 32 hi values then 32 lo values,
+    x = hi + lo + O(2^-17 |x|).  K must be a multiple of 32."""
     lib = _lib.load()
     x = _dev(x, name="x")
-    hi = torch.empty(x.shape, device=x.device, dtype=torch.int16)
-    lo = torch.empty(x.shape, device=x.device, dtype=torch.int16) if with_lo else None
-    _lib.check(lib.itr_split_bf16(_p(x), _p(hi), _p(lo), x.numel(), _stream()))
-    return hi, lo
+    K = x.shape[-1]
+    rows = x.numel() // K if K else 0
+    out = torch.empty(rows, 2 * K, device=x.device, dtype=torch.int16)
+    _lib.check(lib.itr_split_bf16(_p(x), _p(out), rows, K, _stream()))
+    return out
 
 
-def gemm_nt_bf16(a_planes, b_planes, bias=None, terms=3, act=None, M=None, K=None, lda=None, out=None):
-    """STUDY / opt-in: A B^T on the bf16 matrix core from split planes (split_bf16), fp32 accumulation.
-    terms = 3: hi.hi + hi.lo + lo.hi; terms = 1: hi.hi.  The product GEMM (linear / cosine_scores) is exact fp32."""
+def gemm_nt_bf16(a_il, b_il, bias=None, terms=3, act=None, M=None, K=None, lda=None, out=None):
+    """STUDY / opt-in: A B^T on the bf16 matrix core from split operands (split_bf16), fp32 accumulation.
+    terms = 3: hi.hi + hi.lo + lo.hi; terms = 1: hi.hi.  The product GEMM (linear / cosine_scores) is exact fp32.
+    M, K, lda (fp32 elements) describe strided / overlapping rows of a flat operand (linear_strided)."""
     lib = _lib.load()
-    ah, al = a_planes
-    bh, bl = b_planes
-    if bh.dim() != 2 or (M is None and (ah.dim() != 2 or ah.shape[1] != bh.shape[1])) or (K is not None and K != bh.shape[1]):
-        raise ValueError("gemm_nt_bf16: A %s vs B %s" % (tuple(ah.shape), tuple(bh.shape)))
-    if terms == 3 and (al is None or bl is None):
-        raise ValueError("gemm_nt_bf16: terms=3 needs the lo planes")
+    if b_il.dim() != 2 or (M is None and (a_il.dim() != 2 or a_il.shape[1] != b_il.shape[1])) or (K is not None and 2 * K != b_il.shape[1]):
+        raise ValueError("gemm_nt_bf16: A %s vs B %s" % (tuple(a_il.shape), tuple(b_il.shape)))
     if M is None:
-        M, K, lda = ah.shape[0], ah.shape[1], ah.shape[1]       # (M, K, lda given: strided / overlapping rows of a flat plane)
-    N = bh.shape[0]
+        M, K, lda = a_il.shape[0], a_il.shape[1] // 2, a_il.shape[1] // 2
+    N = b_il.shape[0]
     b = _dev(bias, name="bias") if bias is not None else None
     if out is None:
-        out = torch.empty(M, N, device=ah.device, dtype=torch.float32)
-    _lib.check(lib.itr_gemm_nt_bf16(_p(ah), _p(al), lda, _p(bh), _p(bl), bh.shape[1], _p(b), _p(out), out.stride(0), M, N, K,
+        out = torch.empty(M, N, device=a_il.device, dtype=torch.float32)
+    _lib.check(lib.itr_gemm_nt_bf16(_p(a_il), 2 * lda, _p(b_il), b_il.shape[1], _p(b), _p(out), out.stride(0), M, N, K,
                                     _ACTS[act], int(terms), _stream()))
     return out
 

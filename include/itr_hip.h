@@ -81,14 +81,15 @@ int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const 
                 itr_stream_t stream);
 
 /* ---- split-bf16 GEMM (study, opt-in; SURVEY.md 8d "bf16-in / fp32-acc variant reported separately") -------------
- * itr_split_bf16: x = hi + lo + O(2^-17 |x|), hi = bf16(x), lo = bf16(x - hi), both round-to-nearest-even; lo may be
- * NULL (plain bf16).  itr_gemm_nt_bf16: C[M,N] = act(A B^T + bias) (lda / ldb / act as itr_gemm_nt) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation,
- * terms = 3: hi.hi + hi.lo + lo.hi ("bf16x3"), terms = 1: hi.hi.  K a multiple of 32; the planes are [rows, K] bf16
- * row-major, 16-byte aligned.  No default path calls these: itr_gemm_nt (exact fp32) is the product GEMM. */
-int itr_split_bf16(const float *x, uint16_t *hi, uint16_t *lo, int64_t n, itr_stream_t stream);
-int itr_gemm_nt_bf16(const uint16_t *Ah, const uint16_t *Al, int64_t lda, const uint16_t *Bh, const uint16_t *Bl, int64_t ldb,
-                     const float *bias, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, int terms,
-                     itr_stream_t stream);
+ * itr_split_bf16: x [rows, K] fp32 -> out [rows][K / 32][hi (32 bf16) | lo (32 bf16)], hi = bf16(x), lo = bf16(x - hi), both
+ * round-to-nearest-even: x = hi + lo + O(2^-17 |x|).  K a multiple of 32; one 32-wide chunk of one row is one 128-byte line.
+ * itr_gemm_nt_bf16: C[M,N] = act(A B^T + bias) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation from such operands;
+ * terms = 3: hi.hi + hi.lo + lo.hi ("bf16x3"), terms = 1: hi.hi (plain bf16).  lda / ldb count interleaved bf16 elements
+ * (2 x the fp32 row stride; lda < 2 K = overlapping rows as in itr_gemm_nt).  No default path calls these: itr_gemm_nt
+ * (exact fp32) is the product GEMM. */
+int itr_split_bf16(const float *x, uint16_t *out, int64_t rows, int64_t K, itr_stream_t stream);
+int itr_gemm_nt_bf16(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb, const float *bias, float *C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, int act, int terms, itr_stream_t stream);
 
 /* ---- a2: EncoderImagePrecomp.forward (itr/modalmodule/ImgEncoder.py:133-147) -----------
  * out[rows, D] = l2norm(x[rows, F] * W[D, F]^T + b[D]) [abs]; rows = n_img * n_regions.

@@ -11,12 +11,16 @@ pytestmark = pytest.mark.gpu
 
 def test_split_bf16_planes(dev):
     torch.manual_seed(0)
-    x = torch.randn(1000, device=dev) * torch.logspace(-3, 3, 1000, device=dev)
-    hi, lo = ops.split_bf16(x)
+    x = torch.randn(5, 64, device=dev) * torch.logspace(-3, 3, 64, device=dev)
+    il = ops.split_bf16(x)                                            # [5, 128]: per 32-chunk 32 hi then 32 lo
+    assert il.shape == (5, 128) and il.dtype == torch.int16
     f = lambda p: (p.to(torch.int32) << 16).view(torch.float32)      # bf16 bits -> fp32
-    assert torch.equal(f(hi), x.to(torch.bfloat16).float())          # round to nearest even, like torch
-    assert ((x - f(hi) - f(lo)).abs() <= x.abs() * 2.0 ** -16).all()
-    assert ops.split_bf16(x, with_lo=False)[1] is None
+    v = il.view(5, 2, 2, 32)                                          # [row][chunk][hi | lo][32]
+    hi, lo = f(v[:, :, 0]).reshape(5, 64), f(v[:, :, 1]).reshape(5, 64)
+    assert torch.equal(hi, x.to(torch.bfloat16).float())             # round to nearest even, like torch
+    assert ((x - hi - lo).abs() <= x.abs() * 2.0 ** -16).all()
+    with pytest.raises(Exception):
+        ops.split_bf16(torch.randn(4, 48, device=dev))               # K not a multiple of 32
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 77, 64), (1, 1, 32), (300, 513, 1024)])
@@ -38,13 +42,12 @@ def test_gemm_bf16x3_vs_fp64(dev, M, N, K):
 
 
 def test_gemm_bf16_argument_errors(dev):
-    pa = ops.split_bf16(torch.randn(4, 48, device=dev))
-    pb = ops.split_bf16(torch.randn(4, 48, device=dev))
-    with pytest.raises(Exception):
-        ops.gemm_nt_bf16(pa, pb)                                   # K not a multiple of 32
-    pa = ops.split_bf16(torch.randn(4, 32, device=dev), with_lo=False)
+    pa = ops.split_bf16(torch.randn(4, 32, device=dev))
+    pb = ops.split_bf16(torch.randn(6, 64, device=dev))
     with pytest.raises(ValueError):
-        ops.gemm_nt_bf16(pa, pa, terms=3)
+        ops.gemm_nt_bf16(pa, pb)                                   # K mismatch
+    with pytest.raises(Exception):
+        ops.gemm_nt_bf16(pa, pa, terms=2)
     assert ops.gemm_nt_bf16(pa, pa, terms=1).shape == (4, 4)
 
 
