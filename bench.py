@@ -138,7 +138,7 @@ def pmc_traffic(workload, world):
     PMC counters itself; null when no matching profile is committed."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "scan_pmc.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "scan_pmc.json"), recursive=True)):
         try:
             d = json.load(open(f))
         except Exception:
