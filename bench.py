@@ -44,6 +44,8 @@ WORKLOADS = {
                                    lambda_softmax=9.0, raw_feature_norm="clipped_l2norm", scan_precision="bf16x3"),
     "scan_i2t_coco5k_bf16x3": dict(n_img=5000, vocab=11353, cross_attn="i2t", agg_func="LogSumExp", lambda_lse=20.0,
                                    lambda_softmax=4.0, raw_feature_norm="clipped_l2norm", scan_precision="bf16x3"),
+    "scan_t2i_coco5k_fp16x3": dict(n_img=5000, vocab=11353, cross_attn="t2i", agg_func="LogSumExp", lambda_lse=6.0,
+                                   lambda_softmax=9.0, raw_feature_norm="clipped_l2norm", scan_precision="fp16x3"),
     # BASELINE.json configs[4]: SGRAF (EncoderSimilarity), sim_dim 256, l2-normalised bi-GRU words
     "sgraf_saf_coco5k": dict(n_img=5000, vocab=11353, sgraf="SAF"),
     "sgraf_sgr_coco5k": dict(n_img=5000, vocab=11353, sgraf="SGR"),
@@ -475,11 +477,12 @@ def main():
             kernel_name = "sgraf pair stage (scan_xattn_kernel emit + gemm_nt chain + pair kernels)"
             note = "time = the whole itr_sgraf_scores call (global nodes + per-4-image pair stage); flop = SURVEY 8d K8"
         dtype, peak = "f32", FP32_MFMA_PEAK_TFLOPS
-        if wl.get("scan_precision") == "bf16x3":
-            dtype, peak = "f32 inputs split into bf16 hi+lo planes, 3 bf16 MFMA products, f32 accumulate (bf16x3)", BF16_MFMA_PEAK_TFLOPS
+        if wl.get("scan_precision") in ("bf16x3", "fp16x3"):
+            half = "bf16" if wl["scan_precision"] == "bf16x3" else "fp16"
+            dtype, peak = "f32 inputs split into %s hi+lo planes, 3 %s MFMA products, f32 accumulate (%s)" % (half, half, wl["scan_precision"]), BF16_MFMA_PEAK_TFLOPS
             exe_flop = float(i1 - i0) * n_words * (3 * 2 * 36 * D + 36 * 37)
-            note = ("STUDY VARIANT, reported separately: region x word dot products as hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 "
-                    "(peak = dense bf16 MFMA); the fp32 epilogue is unchanged.  " + note)
+            note = ("STUDY VARIANT, reported separately: region x word dot products as hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_%s "
+                    "(peak = dense bf16 / fp16 MFMA); the fp32 epilogue is unchanged.  " % ("bf16" if half == "bf16" else "f16") + note)
         from itr_amd import ops as _ops
         i2t = _ops.recall_from_ranks(ranks[0])
         t2i = _ops.recall_from_ranks(ranks[2])

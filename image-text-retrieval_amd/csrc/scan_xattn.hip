@@ -137,9 +137,10 @@ struct NormAcc {
 };
 
 using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8_t = __attribute__((ext_vector_type(8))) _Float16;
 
-// PREC 0: exact fp32 main loop (scan_mainloop.inc).  PREC 1: split-bf16 "bf16x3" main loop (scan_mainloop_bf16.inc; opt-in,
-// reported separately -- DESIGN.md 9).  The epilogue is shared.
+// PREC 0: exact fp32 main loop (scan_mainloop.inc).  PREC 1: split-bf16 "bf16x3", PREC 3: split-fp16 "fp16x3" main loop
+// (scan_mainloop_bf16.inc; opt-in, reported separately -- DESIGN.md 9); bits 2 / 3: ablation builds.  The epilogue is shared.
 template <int PREC>
 __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256) void scan_pack_kernel(const float *__restrict_
 // bf16x3 variant: rows of an fp32 matrix [rows, D] -> split planes interleaved per 32-wide K chunk,
 // [rows][D / 32][hi (32 bf16) | lo (32 bf16)]  (hi = bf16(x), lo = bf16(x - hi), round to nearest even): x = hi + lo + O(2^-17 |x|)
 __global__ __launch_bounds__(256) void scan_split_rows_kernel(const float *__restrict__ x, uint16_t *__restrict__ out, int64_t rows,
-                                                              int D) {
+                                                              int D, int f16) {
     const int64_t row = blockIdx.y;
     const int d = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (d >= D) return;
@@ -726,8 +727,18 @@ __global__ __launch_bounds__(256) void scan_split_rows_kernel(const float *__res
     uint32_t h[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        h[i] = rne(in[i]);
-        l[i] = rne(in[i] - __uint_as_float(h[i] << 16));
+        if (f16) {       // fp16 planes of x' = 2^12 x: hi = half(x'), lo' = half((x' - hi) * 2^11).  The matrix core flushes fp16
+                         // subnormals, so both planes are kept normal by exact power-of-two scales (undone at the park):
+                         // |x| >= 1.5e-8 stays normal, |x| <= 15.99 does not overflow -- unit-norm rows on this path
+            const float xs = in[i] * 4096.f;
+            const _Float16 hh = (_Float16)xs;
+            const _Float16 ll = (_Float16)((xs - (float)hh) * 2048.f);
+            h[i] = __builtin_bit_cast(uint16_t, hh);
+            l[i] = __builtin_bit_cast(uint16_t, ll);
+        } else {
+            h[i] = rne(in[i]);
+            l[i] = rne(in[i] - __uint_as_float(h[i] << 16));
+        }
     }
     uint16_t *o = out + row * 2 * (int64_t)D + (d >> 5) * 64 + (d & 31);
     *reinterpret_cast<uint2 *>(o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
@@ -869,14 +880,14 @@ namespace itr {
 static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
                              int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
                              void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
-                             int64_t img_count, void *bf16_ws, itr_stream_t stream);
+                             int64_t img_count, void *bf16_ws, int f16, itr_stream_t stream);
 
 int scan_scores_impl(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
                      int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
                      void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
                      int64_t img_count, itr_stream_t stream) {
     return scan_scores_impl2(img, n_tiles, Ni, Nc, n_rows, R, D, mode, norm, agg, lambda_softmax, lambda_lse, S, ldS, workspace,
-                             workspace_bytes, emit_p, emit_cn, img_index0, img_count, nullptr, stream);
+                             workspace_bytes, emit_p, emit_cn, img_index0, img_count, nullptr, 0, stream);
 }
 
 static size_t scan_bf16_ws_bytes(int64_t Ni, int R, int64_t n_tiles, int D) {
@@ -887,7 +898,7 @@ static size_t scan_bf16_ws_bytes(int64_t Ni, int R, int64_t n_tiles, int D) {
 static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
                              int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
                              void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
-                             int64_t img_count, void *bf16_ws, itr_stream_t stream) {
+                             int64_t img_count, void *bf16_ws, int f16, itr_stream_t stream) {
     ITR_REQUIRE(img && S && workspace, "itr_scan_xattn_scores: null pointer");
     ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && n_tiles >= 0 && ldS >= Nc, "itr_scan_xattn_scores: bad shape");
     if (mode != 0 && mode != 1) { set_error("unknown cross_attn mode %d", mode); return ITR_ERR_BADARG; }
@@ -948,10 +959,10 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
         ITR_REQUIRE(Ni * R <= 0x7fffffff / 1 && n_tiles * SC_NT <= 0x7fffffff, "scan split: too many rows");
         for (int64_t r0 = 0; r0 < Ni * R; r0 += 65535)
             hipLaunchKernelGGL(scan_split_rows_kernel, dim3(sg.x, (unsigned)min((int64_t)65535, Ni * R - r0)), dim3(256), 0, st,
-                               a.img + r0 * D, img_bf + r0 * 2 * D, Ni * R - r0, D);
+                               a.img + r0 * D, img_bf + r0 * 2 * D, Ni * R - r0, D, f16);
         for (int64_t r0 = 0; r0 < n_tiles * SC_NT; r0 += 65535)
             hipLaunchKernelGGL(scan_split_rows_kernel, dim3(sg.x, (unsigned)min((int64_t)65535, n_tiles * SC_NT - r0)), dim3(256), 0,
-                               st, w.wtiled + r0 * D, wt_bf + r0 * 2 * D, n_tiles * SC_NT - r0, D);
+                               st, w.wtiled + r0 * D, wt_bf + r0 * 2 * D, n_tiles * SC_NT - r0, D, f16);
         ITR_CHECK_LAUNCH("scan split");
         a.img_bf = img_bf;
         a.wt_bf = wt_bf;
@@ -963,6 +974,13 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
         } else if (abl == 9) {
             ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipLaunchKernelGGL(scan_xattn_kernel<9>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+        } else if (f16) {
+            static bool attr3 = false;
+            if (!attr3) {
+                ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr3 = true;
+            }
+            hipLaunchKernelGGL(scan_xattn_kernel<3>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
         } else
             hipLaunchKernelGGL(scan_xattn_kernel<1>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
     } else {
@@ -988,11 +1006,12 @@ extern "C" size_t itr_scan_bf16_workspace_bytes(int64_t Ni, int R, int64_t n_til
 extern "C" int itr_scan_xattn_scores_bf16x3(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
                                             int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S,
                                             int64_t ldS, void *workspace, size_t workspace_bytes, void *bf16_workspace,
-                                            size_t bf16_workspace_bytes, itr_stream_t stream) {
+                                            size_t bf16_workspace_bytes, int split_format, itr_stream_t stream) {
     ITR_REQUIRE(bf16_workspace && bf16_workspace_bytes >= itr::scan_bf16_ws_bytes(Ni, R, n_tiles, D),
-                "itr_scan_xattn_scores_bf16x3: bf16 workspace missing or too small");
+                "itr_scan_xattn_scores_bf16x3: split workspace missing or too small");
+    ITR_REQUIRE(split_format == 0 || split_format == 1, "itr_scan_xattn_scores_bf16x3: split_format 0 (bf16) or 1 (fp16)");
     return itr::scan_scores_impl2(img, n_tiles, Ni, Nc, n_rows, R, D, mode, norm, agg, lambda_softmax, lambda_lse, S, ldS, workspace,
-                                  workspace_bytes, nullptr, nullptr, 0, -1, bf16_workspace, stream);
+                                  workspace_bytes, nullptr, nullptr, 0, -1, bf16_workspace, split_format, stream);
 }
 
 // Diagnostics for tools/: resident workgroups per CU of the SCAN kernel as the runtime sees it.

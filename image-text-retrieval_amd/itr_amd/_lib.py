@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 i32, i64, f32, vp, sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -43,7 +43,7 @@ SIGNATURES = {
     "itr_scan_prepare": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, sz, vp]),
     "itr_scan_xattn_scores": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp, sz, vp]),
     "itr_scan_bf16_workspace_bytes": (sz, [i64, i32, i64, i32]),
-    "itr_scan_xattn_scores_bf16x3": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp, sz, vp, sz, vp]),
+    "itr_scan_xattn_scores_bf16x3": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp, sz, vp, sz, i32, vp]),
     "itr_bert_embed_ln": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, i32, i32, f32, vp]),
     "itr_add_layernorm": (i32, [vp, vp, vp, vp, vp, i64, i32, f32, vp]),
     "itr_mha_small": (i32, [vp, vp, vp, i64, i64, i64, vp, vp, i64, i64, i32, i32, i32, f32, vp]),

@@ -354,8 +354,9 @@ def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='c
                       agg_func='LogSumExp', lambda_lse=6.0, lambda_softmax=9.0, out=None, workspace=None, precision='fp32'):
     """xattn_score_t2i / _i2t (Objectives.py:329-417).  images (Ni, 36, D); words (n_rows, D) with the
     caption layout described by `plan` (ScanPlan).  -> (Ni, Nc).
-    precision='bf16x3' (opt-in study variant): the region x word dot products run on the bf16 matrix core
-    from split operands (hi.hi + hi.lo + lo.hi, fp32 accumulation); everything else is unchanged."""
+    precision='bf16x3' / 'fp16x3' (opt-in study variants): the region x word dot products run on the 16-bit
+    matrix core from split operands (hi.hi + hi.lo + lo.hi, fp32 accumulation; bf16 planes: ~3e-6, fp16 planes: ~1e-7 of the
+    fp32 result, fp16 needs |x| <= 65504); everything else is unchanged."""
     lib = _lib.load()
     if cross_attn not in ('t2i', 'i2t'):
         raise ValueError("unknown first norm type:", raw_feature_norm)  # the reference's message (Objectives.py:71)
@@ -377,16 +378,16 @@ def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='c
         return _scan_scores_with_long_captions(images, words, plan, cross_attn, raw_feature_norm, agg_func, lambda_lse, lambda_softmax,
                                                out, workspace)
     ws = workspace if workspace is not None else scan_prepare(images, words, plan, cross_attn)
-    if precision == 'bf16x3':
+    if precision in ('bf16x3', 'fp16x3'):
         bsz = lib.itr_scan_bf16_workspace_bytes(Ni, R, plan.n_tiles, D)
         bws = torch.empty(bsz, device=images.device, dtype=torch.uint8)
         _lib.check(lib.itr_scan_xattn_scores_bf16x3(
             _p(images), plan.n_tiles, Ni, plan.Nc, n_rows, R, D, 0 if cross_attn == 't2i' else 1,
             _NORMS[raw_feature_norm], _AGGS[agg_func], float(lambda_softmax), float(lambda_lse), _p(out), out.stride(0),
-            _p(ws), ws.numel(), _p(bws), bsz, _stream()))
+            _p(ws), ws.numel(), _p(bws), bsz, 1 if precision == 'fp16x3' else 0, _stream()))
         return out
     if precision != 'fp32':
-        raise ValueError("scan_xattn_scores: precision must be 'fp32' or 'bf16x3'")
+        raise ValueError("scan_xattn_scores: precision must be 'fp32', 'bf16x3' or 'fp16x3'")
     _lib.check(lib.itr_scan_xattn_scores(
         _p(images), plan.n_tiles, Ni, plan.Nc, n_rows, R, D, 0 if cross_attn == 't2i' else 1,
         _NORMS[raw_feature_norm], _AGGS[agg_func], float(lambda_softmax), float(lambda_lse), _p(out), out.stride(0),

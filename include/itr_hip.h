@@ -170,12 +170,14 @@ int itr_scan_xattn_scores(const float *img, int64_t n_tiles, int64_t Ni, int64_t
 /* Opt-in study variant (SURVEY.md 8d "bf16-in / fp32-acc variant reported separately"): the same scores
  * with the region x word dot products on the bf16 matrix core from split operands, x = hi + lo, hi.hi + hi.lo + lo.hi,
  * fp32 accumulation ("bf16x3", ~1e-6 of the fp32 result on the unit-norm operands of this path); the epilogue is the
- * fp32 one.  bf16_workspace: itr_scan_bf16_workspace_bytes(Ni, R, n_tiles, D) bytes of scratch for the split planes. */
+ * fp32 one.  bf16_workspace: itr_scan_bf16_workspace_bytes(Ni, R, n_tiles, D) bytes of scratch for the split planes.
+ * split_format 0: bf16 planes (8 + 8 mantissa bits).  split_format 1 ("fp16x3"): fp16 planes (11 + 11 bits, lo scaled by 2^11,
+ * cross terms in a second accumulator): ~1e-7 of the fp32 result, needs |x| <= 65504 (unit-norm rows on this path). */
 size_t itr_scan_bf16_workspace_bytes(int64_t Ni, int R, int64_t n_tiles, int D);
 int itr_scan_xattn_scores_bf16x3(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
                                  int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S,
                                  int64_t ldS, void *workspace, size_t workspace_bytes, void *bf16_workspace,
-                                 size_t bf16_workspace_bytes, itr_stream_t stream);
+                                 size_t bf16_workspace_bytes, int split_format, itr_stream_t stream);
 
 /* ---- a11: BERT building blocks (itr/modalmodule/bert.py:113-358); the dense layers use itr_gemm_nt (act 4 =
  * erf-GELU :29-34, act 2 = tanh pooler :299-302).
