@@ -46,6 +46,8 @@ WORKLOADS = {
                                    lambda_softmax=4.0, raw_feature_norm="clipped_l2norm", scan_precision="bf16x3"),
     "scan_t2i_coco5k_fp16x3": dict(n_img=5000, vocab=11353, cross_attn="t2i", agg_func="LogSumExp", lambda_lse=6.0,
                                    lambda_softmax=9.0, raw_feature_norm="clipped_l2norm", scan_precision="fp16x3"),
+    "scan_i2t_coco5k_fp16x3": dict(n_img=5000, vocab=11353, cross_attn="i2t", agg_func="LogSumExp", lambda_lse=20.0,
+                                   lambda_softmax=4.0, raw_feature_norm="clipped_l2norm", scan_precision="fp16x3"),
     # BASELINE.json configs[4]: SGRAF (EncoderSimilarity), sim_dim 256, l2-normalised bi-GRU words
     "sgraf_saf_coco5k": dict(n_img=5000, vocab=11353, sgraf="SAF"),
     "sgraf_sgr_coco5k": dict(n_img=5000, vocab=11353, sgraf="SGR"),
