@@ -11,9 +11,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
-i32, i64, f32, vp, sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
 # name -> (restype, argtypes).  Kept in one table so tests can check that every symbol the
 # header declares is exported with the arity the binding expects.
@@ -24,6 +24,15 @@ SIGNATURES = {
     "itr_mean_mid": (i32, [vp, vp, i64, i32, i32, vp]),
     "itr_split_bf16": (i32, [vp, vp, i64, i64, vp]),
     "itr_gemm_nt_bf16": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, vp]),
+    "itr_dropout": (i32, [vp, vp, i64, f32, u64, u64, vp]),
+    "itr_add_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]),
+    "itr_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "itr_gelu": (i32, [vp, vp, vp, i64, vp]),
+    "itr_mha_train_fwd": (i32, [vp, vp, vp, i64, vp, i64, i32, i32, i32, f32, f32, u64, vp, vp, i64, vp]),
+    "itr_mha_train_bwd": (i32, [vp, vp, vp, i64, vp, i64, i32, i32, i32, f32, f32, u64, vp, vp, i64, vp, vp, vp, i64, vp]),
+    "itr_relu_maxpool_arg": (i32, [vp, i64, i32, i32, vp, vp, vp]),
+    "itr_relu_maxpool_bwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+    "itr_bcast_mid": (i32, [vp, vp, i64, i32, i32, f32, vp]),
     "itr_gcn_relation": (i32, [vp, i64, vp, i64, i64, i32, i32, vp]),
     "itr_order_scores": (i32, [vp, vp, vp, i64, i64, i32, vp]),
     "itr_order_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i32, vp]),

@@ -393,6 +393,201 @@ def scan_i2t_scores(images, words_packed, cap_off, cap_lens, raw_feature_norm='c
 
 
 # ------------------------------------------------------------------------------------------ optimizer
+# ---------------------------------------------------------------------------------------------------------------------
+# transformer towers (SAEM): dropout, residual LayerNorm, gelu, short-sequence attention, relu + max-pool, mean over regions
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        lib = _lib.load()
+        x = _dev(x, name="x")
+        y = torch.empty_like(x)
+        _lib.check(lib.itr_dropout(_p(x), _p(y), x.numel(), float(p), int(seed), 0, _stream()))
+        ctx.p, ctx.seed = float(p), int(seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.check(lib.itr_dropout(_p(dy), _p(dx), dy.numel(), ctx.p, ctx.seed, 0, _stream()))
+        return dx, None, None
+
+
+class DropoutSeeds(object):
+    """Per-step seeds of the dropout sites: torch's generator supplies one base seed per training step (so
+    torch.manual_seed makes runs repeatable), every call site takes the next counter value."""
+
+    def __init__(self):
+        self.base, self.n = 0, 0
+
+    def new_step(self):
+        self.base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        self.n = 0
+
+    def next(self):
+        self.n += 1
+        return self.base * 4096 + self.n
+
+
+def dropout(x, p, seeds, training=True):
+    """nn.Dropout(p)(x): identity when not training or p == 0."""
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, p, seeds.next())
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """BERTLayerNorm(x + residual) (bert.py:113-126)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps):
+        lib = _lib.load()
+        x = _dev(x, name="x")
+        H = x.shape[-1]
+        rows = x.numel() // H
+        res = _dev(residual, name="residual") if residual is not None else None
+        g, b = _dev(gamma, name="gamma"), _dev(beta, name="beta")
+        z, out = torch.empty_like(x), torch.empty_like(x)
+        mean, rstd = _f32(rows, dev=x.device), _f32(rows, dev=x.device)
+        _lib.check(lib.itr_add_ln_fwd(_p(x), _p(res), _p(g), _p(b), _p(z), _p(out), _p(mean), _p(rstd), rows, H, float(eps), _stream()))
+        ctx.save_for_backward(z, mean, rstd, g)
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        z, mean, rstd, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        H = z.shape[-1]
+        rows = z.numel() // H
+        dz, t = torch.empty_like(z), torch.empty_like(z)
+        _lib.check(lib.itr_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(g), _p(dz), _p(t), rows, H, _stream()))
+        dgamma = colsum(t.view(rows, H)) if ctx.needs_input_grad[2] else None
+        dbeta = colsum(dy.view(rows, H)) if ctx.needs_input_grad[3] else None
+        return dz, (dz if ctx.has_res else None), dgamma, dbeta, None
+
+
+def add_layernorm(x, residual, gamma, beta, eps=1e-12):
+    return _AddLayerNorm.apply(x, residual, gamma, beta, eps)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _dev(x, name="x")
+        y = torch.empty_like(x)
+        _lib.check(lib.itr_gelu(_p(x), None, _p(y), x.numel(), _stream()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(lib.itr_gelu(_p(x), _p(dy), _p(dx), x.numel(), _stream()))
+        return dx
+
+
+def gelu(x):
+    return _Gelu.apply(x)
+
+
+class _Mha(torch.autograd.Function):
+    """BERTSelfAttention core (bert.py:175-215) on the fused QKV projection output qkv [B*L, 3A] (thirds Q | K | V)."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask01, B, L, heads, p_drop, seed):
+        lib = _lib.load()
+        qkv = _dev(qkv, name="qkv")
+        A = qkv.shape[1] // 3
+        dk = A // heads
+        m = _dev(mask01.to(torch.float32), name="mask") if mask01 is not None else None
+        P = _f32(B, heads, L, L, dev=qkv.device)
+        out = _f32(B * L, A, dev=qkv.device)
+        base = qkv.data_ptr()
+        scale = 1.0 / float(np.sqrt(dk))
+        _lib.check(lib.itr_mha_train_fwd(C.c_void_p(base), C.c_void_p(base + 4 * A), C.c_void_p(base + 8 * A), 3 * A, _p(m), B, L, heads, dk,
+                                         scale, float(p_drop), int(seed), _p(P), _p(out), A, _stream()))
+        ctx.save_for_backward(qkv, P, m if m is not None else torch.empty(0, device=qkv.device))
+        ctx.cfg = (B, L, heads, dk, A, scale, float(p_drop), int(seed), m is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        lib = _lib.load()
+        qkv, P, m = ctx.saved_tensors
+        B, L, heads, dk, A, scale, p_drop, seed, has_mask = ctx.cfg
+        dctx = dctx.contiguous()
+        dqkv = torch.empty_like(qkv)
+        base, gb = qkv.data_ptr(), dqkv.data_ptr()
+        _lib.check(lib.itr_mha_train_bwd(C.c_void_p(base), C.c_void_p(base + 4 * A), C.c_void_p(base + 8 * A), 3 * A, _p(m) if has_mask else None,
+                                         B, L, heads, dk, scale, p_drop, seed, _p(P), _p(dctx), A, C.c_void_p(gb), C.c_void_p(gb + 4 * A),
+                                         C.c_void_p(gb + 8 * A), 3 * A, _stream()))
+        return dqkv, None, None, None, None, None, None
+
+
+def mha(qkv, mask01, B, L, heads, p_drop=0.0, seed=0):
+    return _Mha.apply(qkv, mask01, B, L, heads, p_drop, seed)
+
+
+class _ReluMaxpool(torch.autograd.Function):
+    """max over positions of relu(x), x [B, npos, C] (TextEncoder.py:122-124)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _dev(x, name="x")
+        B, npos, Cc = x.shape
+        out = _f32(B, Cc, dev=x.device)
+        arg = torch.empty(B, Cc, device=x.device, dtype=torch.int32)
+        _lib.check(lib.itr_relu_maxpool_arg(_p(x), B, npos, Cc, _p(out), _p(arg), _stream()))
+        ctx.save_for_backward(arg)
+        ctx.npos = npos
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        arg, = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Cc = dy.shape
+        dx = _f32(B, ctx.npos, Cc, dev=dy.device)
+        _lib.check(lib.itr_relu_maxpool_bwd(_p(dy), _p(arg), B, ctx.npos, Cc, _p(dx), _stream()))
+        return dx
+
+
+def relu_maxpool(x):
+    return _ReluMaxpool.apply(x)
+
+
+class _MeanMid(torch.autograd.Function):
+    """torch.mean(x, 1) of x [B, R, F]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import ops
+        ctx.R = x.shape[1]
+        return ops.mean_mid(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = dy.contiguous()
+        B, F = dy.shape
+        dx = _f32(B, ctx.R, F, dev=dy.device)
+        _lib.check(lib.itr_bcast_mid(_p(dy), _p(dx), B, ctx.R, F, 1.0 / ctx.R, _stream()))
+        return dx
+
+
+def mean_mid(x):
+    return _MeanMid.apply(x)
+
+
 class _DPGatherRows(torch.autograd.Function):
     """Row blocks of every rank concatenated rank-major (one RCCL all-gather).  Two kinds of backward:
     reduce=True   the gathered rows feed a computation that DIFFERS per rank (every rank scores its own image rows

@@ -293,6 +293,36 @@ int itr_clip_coef(const float *partials, int64_t nparts, float max_norm, float *
 int itr_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
                   int64_t step, const float *grad_scale_dev, itr_stream_t stream);
 
+/* ---- transformer towers under autograd (SAEM: TransformerMapping / BertMapping, ImgEncoder.py:324-350, TextEncoder.py:75-152,
+ * bert.py:113-300); the dense layers are itr_gemm_nt on transposed operands as for every other backward pass ----------------
+ * nn.Dropout: y = x * keep / (1 - p), keep(i) from a counter-based hash of (seed, offset + i).  Stateless: the backward pass
+ * is the same call on dy.  (The random stream is not torch's; only the distribution is the reference's.) */
+int itr_dropout(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset, itr_stream_t stream);
+/* BERTLayerNorm(x + residual) (bert.py:113-126; residual may be NULL) keeping z = x + residual, the row means and
+ * 1 / sqrt(var + eps); backward: dz (for x and for the residual) and t = dy * xhat (dgamma = column sums of t, dbeta of dy). */
+int itr_add_ln_fwd(const float *x, const float *residual, const float *gamma, const float *beta, float *z, float *out,
+                   float *mean, float *rstd, int64_t rows, int H, float eps, itr_stream_t stream);
+int itr_ln_bwd(const float *dy, const float *z, const float *mean, const float *rstd, const float *gamma, float *dz, float *t,
+               int64_t rows, int H, itr_stream_t stream);
+/* gelu (bert.py:104-110): dy == NULL -> out = gelu(x);  else out = dy * gelu'(x). */
+int itr_gelu(const float *x, const float *dy, float *out, int64_t n, itr_stream_t stream);
+/* BERTSelfAttention (bert.py:175-215) for short sequences (L <= 64, head size <= 64): per (sequence, head)
+ *   P = softmax(Q K^T * scale + (1 - mask01) * -10000);  ctx = dropout(P) V.
+ * q / k / v: row b * L + i, column head * dk + d, row stride ld (the three thirds of one fused QKV GEMM output).
+ * P [B, heads, L, L] keeps the probabilities for the backward pass, which returns dq / dk / dv with row stride ldg. */
+int itr_mha_train_fwd(const float *q, const float *k, const float *v, int64_t ld, const float *mask01, int64_t B, int L,
+                      int heads, int dk, float scale, float p_drop, uint64_t seed, float *P, float *ctx, int64_t ldc,
+                      itr_stream_t stream);
+int itr_mha_train_bwd(const float *q, const float *k, const float *v, int64_t ld, const float *mask01, int64_t B, int L,
+                      int heads, int dk, float scale, float p_drop, uint64_t seed, const float *P, const float *dctx,
+                      int64_t ldc, float *dq, float *dk_out, float *dv, int64_t ldg, itr_stream_t stream);
+/* F.relu + F.max_pool1d over all positions (TextEncoder.py:122-124): x [B, npos, C] -> out [B, C], arg [B, C] (first position of
+ * the maximum, -1 when it is 0); backward scatters dy to the arg-max position. */
+int itr_relu_maxpool_arg(const float *x, int64_t B, int npos, int C, float *out, int32_t *arg, itr_stream_t stream);
+int itr_relu_maxpool_bwd(const float *dy, const int32_t *arg, int64_t B, int npos, int C, float *dx, itr_stream_t stream);
+/* backward of torch.mean(x, 1): dx[b, r, :] = scale * dy[b, :]. */
+int itr_bcast_mid(const float *dy, float *dx, int64_t B, int R, int F, float scale, itr_stream_t stream);
+
 /* EncoderText (bi)GRU under autograd (TextEncoder.py:38-70): training forward that keeps the gate activations, and
  * backpropagation through time.  Same packed layout / sorting contract as itr_gru_fwd.  `out` [n_tok, D] is the RAW
  * sequence output ((fwd + bwd) / 2 for a bi-GRU); l2norm / last-step gather are separate differentiable steps.
