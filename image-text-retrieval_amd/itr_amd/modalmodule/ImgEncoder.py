@@ -143,6 +143,14 @@ class TransformerMapping(nn.Module):
         embed = ops.mean_mid(hidden_states)
         return ops.normalize(embed, dim=1)
 
+    def forward_train(self, x, seeds):
+        """The same tower on the autograd tape with the layer's dropout sites live (SAEM.train_emb)."""
+        from .. import autograd as ag
+        B, R, _ = x.shape
+        h = ag.linear(x.reshape(B * R, -1), self.mapping.weight, self.mapping.bias).view(B, R, -1)
+        h = self.layer.forward_train(h, None, seeds, training=self.training)
+        return ag.l2norm_rows(ag.mean_mid(h), eps=1e-12)          # F.normalize: x / max(||x||, 1e-12)
+
 
 from .camera_ import AGSA, Summarization, PositionEncoder  # noqa: E402
 

@@ -2,9 +2,10 @@
 txt_enc, sim_enc, criterion, optimizer, Eiters, logger; methods forward_emb / forward_loss / train_emb / val_start /
 train_start / state_dict / load_state_dict.  Towers and losses run on the HIP kernels.
 
-`train_emb` (forward -> hinge -> backward -> clip_grad_norm_ -> Adam, Models.py:115-145, :198-225) is built for the
-GRU family with a pooled or SCAN similarity (VSE++, SCAN): itr_amd/autograd.py wires the HIP forward / backward
-kernels into torch's tape.  SGRAF / SAEM / CAMERA training (backward through EncoderSimilarity / BERT) is not built.
+`train_emb` (forward -> loss -> backward -> clip_grad_norm_ -> Adam, Models.py:115-145, :198-225, :444-464) is built for the
+GRU family with a pooled or SCAN similarity (VSE++, SCAN) and for SAEM (frozen BERT in training mode, cnn / pooling / trans
+head and the image transformer layer on the tape, live dropout): itr_amd/autograd.py wires the HIP forward / backward
+kernels into torch's tape.  SGRAF / CAMERA training (backward through EncoderSimilarity / AGSA + summarisation) is not built.
 
 Data-parallel training (the reference has none): with torch.distributed initialised and world > 1,
 every rank receives the SAME global batch (loaders share the seed), keeps the strided shard rank::world of it, runs
@@ -340,6 +341,9 @@ class SAEM(base_module):
         self.criterion_2 = Objectives.AngularLoss()
         self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters())
         self.calculate_params()
+        # Adam over the parameters that receive gradients (the reference hands the frozen BERT weights to Adam as well; they
+        # never get a gradient there either)
+        self.optimizer = ag.Adam([p_ for p_ in self.params if p_.requires_grad], lr=config['learning_rate'])
         self.no_decay = ['bias', 'gamma', 'beta']
 
     def forward_emb(self, images, captions, captions_mask, captions_type_ids, lengths, *args, **kwargs):
@@ -361,6 +365,35 @@ class SAEM(base_module):
             if name.split('.')[-1] not in self.no_decay:
                 l2_reg = l2_reg + torch.norm(param.detach())
         return loss1 + alpha * loss2 + 0.01 * l2_reg
+
+    def train_emb(self, train_data, epoch=0):
+        """One training step (Models.py:444-464): towers on the autograd tape (frozen BERT forward in training mode, head
+        and image transformer layer differentiable), loss1 + alpha(epoch) * AngularLoss + 0.01 * sum ||W||, backward,
+        clip_grad_norm_, Adam.  utils.train_step never passes the epoch, so alpha is 0.5 there, as in the reference."""
+        images, _, _, captions, lengths, ids, captions_mask, captions_type_ids = train_data
+        self.Eiters += 1
+        self._log('Eit', self.Eiters)
+        self._log('lr', self.optimizer.param_groups[0]['lr'])
+        if not hasattr(self, '_seeds'):
+            self._seeds = ag.DropoutSeeds()
+        self._seeds.new_step()
+        self.optimizer.zero_grad()
+        with torch.enable_grad():
+            cap = self.txt_enc.forward_train(self._dev(captions), self._dev(captions_mask), self._dev(captions_type_ids), lengths, self._seeds)
+            img = self.img_enc.forward_train(self._dev(images), self._seeds)
+            # criterion = hinge on pdist_cos (Objectives.py:310-323: rows renormalised, no eps), on the tape
+            scores = ag.cosine_scores(ag.l2norm_rows(img, eps=0.0), ag.l2norm_rows(cap, eps=0.0))
+            loss1 = ops.hinge_loss(scores, self.config['margin'], self.config['max_violation'])
+            alpha = 0 if epoch > 20 else 0.5 * (0.1 ** (epoch // 5))
+            loss2 = self.criterion_2(img, cap, lengths, ids)
+            l2_reg = torch.zeros((), device=img.device)
+            for name, param in self.img_enc.named_parameters():
+                if name.split('.')[-1] not in self.no_decay:
+                    l2_reg = l2_reg + torch.norm(param)
+            loss = loss1 + alpha * loss2 + 0.01 * l2_reg
+            self._log('Loss1', loss1.detach(), img.size(0))
+            self._log('Loss2', loss2.detach(), img.size(0))
+            self._step(loss, img.size(0))
 
 
 class CAMERA(base_module):

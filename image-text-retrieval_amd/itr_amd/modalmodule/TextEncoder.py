@@ -126,6 +126,35 @@ class BertMapping(nn.Module):
         code = ops.linear(output, self.mapping.weight.detach(), self.mapping.bias.detach())
         return ops.normalize(code, dim=1)
 
+    def forward_train(self, input_ids, attention_mask, token_type_ids, lengths, seeds):
+        """SAEM.train_emb: frozen BERT in training mode (no gradient, live dropout) -> head on the autograd tape ->
+        nn.Dropout(hidden_dropout_prob) -> mapping -> F.normalize (TextEncoder.py:115-152)."""
+        from .. import autograd as ag
+        last = self.bert.forward_frozen_train(input_ids, token_type_ids, attention_mask, seeds)
+        B, L, H = last.shape
+        p_drop = float(self.bert.config.hidden_dropout_prob)
+        if self.txt_stru == 'pooling':
+            output = ag.mean_mid(ag.linear(last.reshape(B * L, H), self.mapping_0.weight, self.mapping_0.bias).view(B, L, -1))
+        elif self.txt_stru == 'cnn':
+            pooled = []
+            for conv in self.convs1:
+                K = conv.kernel_size[0]
+                if L < K:
+                    raise ValueError("sequence shorter than the conv window")
+                npos = L - K + 1
+                # Conv2d(1, C, (K, H)) on the frozen features: unfold K consecutive token rows (a copy), then one GEMM
+                unf = torch.cat([last[:, k:k + npos] for k in range(K)], 2).reshape(B * npos, K * H)
+                y = ag.linear(unf, conv.weight.reshape(conv.out_channels, K * H), conv.bias)
+                pooled.append(ag.relu_maxpool(y.view(B, npos, conv.out_channels)))
+            output = torch.cat(pooled, 1)
+        else:  # trans
+            hidden = ag.linear(last.reshape(B * L, H), self.mapping_0.weight, self.mapping_0.bias).view(B, L, -1)
+            hidden = self.layer.forward_train(hidden, attention_mask.to(last.device).to(torch.float32), seeds, training=self.training)
+            output = ag.mean_mid(hidden)
+        output = ag.dropout(output, p_drop if self.txt_stru != 'trans' else float(self.layer.p_hidden), seeds, self.training)
+        code = ag.linear(output, self.mapping.weight, self.mapping.bias)
+        return ag.l2norm_rows(code, eps=1e-12)
+
     def freeze_layers(self, model):
         for child in model.children():
             for param in child.parameters():

@@ -155,6 +155,26 @@ class BERTLayer(nn.Module):
         self.attention = BERTAttention(config)
         self.intermediate = BERTIntermediate(config)
         self.output = BERTOutput(config)
+        # nn.Dropout sites of the reference (bert.py:174, :221, :255); used by forward_train only
+        self.p_attn, self.p_hidden = float(config.attention_probs_dropout_prob), float(config.hidden_dropout_prob)
+
+    def forward_train(self, hidden_states, mask01, seeds, training=True):
+        """The layer on the autograd tape (train_emb): hidden_states (B, L, H) -> (B, L, H).  Same arithmetic as forward plus
+        the reference's three dropout sites when `training`; under torch.no_grad() this is the frozen-tower forward in
+        training mode (the reference keeps BERT's dropout active although its weights are frozen, TextEncoder.py:83 + model.train())."""
+        from .. import autograd as ag
+        B, L, H = hidden_states.shape
+        at, so, io, oo = self.attention.self, self.attention.output, self.intermediate, self.output
+        x2 = hidden_states.reshape(B * L, H)
+        w = torch.cat([at.query.weight, at.key.weight, at.value.weight], 0)
+        b = torch.cat([at.query.bias, at.key.bias, at.value.bias], 0)
+        qkv = ag.linear(x2, w, b)
+        ctx = ag.mha(qkv, mask01, B, L, at.num_attention_heads, self.p_attn if training else 0.0, seeds.next())
+        h = ag.dropout(ag.linear(ctx, so.dense.weight, so.dense.bias), self.p_hidden, seeds, training)
+        att = ag.add_layernorm(h, x2, so.LayerNorm.gamma, so.LayerNorm.beta, so.LayerNorm.variance_epsilon)
+        inter = ag.gelu(ag.linear(att, io.dense.weight, io.dense.bias))
+        h2 = ag.dropout(ag.linear(inter, oo.dense.weight, oo.dense.bias), self.p_hidden, seeds, training)
+        return ag.add_layernorm(h2, att, oo.LayerNorm.gamma, oo.LayerNorm.beta, oo.LayerNorm.variance_epsilon).view(B, L, H)
 
     def forward(self, hidden_states, attention_mask):
         mask01 = attention_mask
@@ -192,6 +212,7 @@ class BertModel(nn.Module):
 
     def __init__(self, config):
         super().__init__()
+        self.config = config
         self.embeddings = BERTEmbeddings(config)
         self.encoder = BERTEncoder(config)
         self.pooler = BERTPooler(config)
@@ -207,3 +228,18 @@ class BertModel(nn.Module):
         all_encoder_layers = self.encoder(embedding_output, mask01)
         pooled_output = self.pooler(all_encoder_layers[-1])
         return all_encoder_layers, pooled_output
+
+    def forward_frozen_train(self, input_ids, token_type_ids, attention_mask, seeds):
+        """Last encoder layer of the FROZEN tower in training mode (SAEM / CAMERA text towers under model.train(): the
+        weights receive no gradient but the dropout sites are live -- embeddings :151-158, every layer :174/:221/:255)."""
+        from .. import autograd as ag
+        input_ids = input_ids.cuda() if not input_ids.is_cuda else input_ids
+        mask01 = attention_mask.to(input_ids.device).to(torch.float32) if attention_mask is not None else None
+        if token_type_ids is not None:
+            token_type_ids = token_type_ids.to(input_ids.device)
+        with torch.no_grad():
+            h = self.embeddings(input_ids, token_type_ids)
+            h = ag.dropout(h, float(self.config.hidden_dropout_prob), seeds)
+            for layer in self.encoder.layer:
+                h = layer.forward_train(h, mask01, seeds, training=True)
+        return h

@@ -807,9 +807,85 @@ def g17():
     save('g17_order', **out)
 
 
+# ------------------------------------------------------------------ G18 SAEM.train_emb (a14), dropout probabilities 0
+def g18():
+    """The reference's own SAEM.train_emb (Models.py:444-464) run twice on CPU with every dropout probability set to 0 (the
+    reference draws its masks from torch's generator; the build uses a counter-based hash, so only p = 0 is comparable
+    value by value): losses, gradients of the trainable parameters and all parameters after each Adam step."""
+    import json
+    import tempfile
+    from itr.modalmodule import bert as rbert
+    rng = np.random.RandomState(18)
+    out = {}
+    tmp = tempfile.mkdtemp()
+    cfg_d = dict(vocab_size=100, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                 max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    trans_d = dict(vocab_size=10, hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                   max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(180)
+    bm = rbert.BertModel(rbert.BertConfig.from_dict(cfg_d))
+    for name, p_ in bm.named_parameters():
+        p_.data.normal_(0, 0.05)
+        if name.endswith('gamma'):
+            p_.data.uniform_(0.8, 1.2)
+    json.dump(cfg_d, open(os.path.join(tmp, 'bert_config.json'), 'w'))
+    json.dump(trans_d, open(os.path.join(tmp, 'trans_cfg.json'), 'w'))
+    torch.save(bm.state_dict(), os.path.join(tmp, 'pytorch_model.bin'))
+    out.update(bert_cfg=json.dumps(cfg_d), trans_cfg=json.dumps(trans_d))
+    for k, v in sd(bm).items():
+        out['wbert_' + k] = v
+    B, L, F_ = 6, 12, 40
+    for stru in ('cnn', 'trans', 'pooling'):
+        cfg = dict(name='SAEM', bert_config_file=os.path.join(tmp, 'bert_config.json'), init_checkpoint=os.path.join(tmp, 'pytorch_model.bin'),
+                   trans_cfg=os.path.join(tmp, 'trans_cfg.json'), txt_stru=stru, final_dims=32, img_dim=F_, bi_gru=False, embed_size=32,
+                   num_layers=1, margin=0.2, measure='cosine', max_violation=True, learning_rate=1e-3, grad_clip=2.0)
+        with torch.enable_grad():
+            torch.manual_seed(181)
+            model = Models.SAEM(cfg)
+            for name, p_ in list(model.txt_enc.named_parameters()) + list(model.img_enc.named_parameters()):
+                if not name.startswith('bert.'):
+                    p_.data.normal_(0, 0.08)
+                    if name.endswith('gamma'):
+                        p_.data.uniform_(0.8, 1.2)
+            model.train_start()
+            model.logger = evaluation.LogCollector()
+            for k, v in sd(model.img_enc).items():
+                out['%s_w0_img_%s' % (stru, k)] = v
+            for k, v in sd(model.txt_enc).items():
+                if not k.startswith('bert.'):
+                    out['%s_w0_txt_%s' % (stru, k)] = v
+            for step in (1, 2):
+                lens = sorted([int(x) for x in rng.randint(3, L + 1, size=B)], reverse=True)
+                ids = torch.from_numpy(rng.randint(1, 100, size=(B, L)))
+                mask = torch.zeros(B, L, dtype=torch.long)
+                for b, l in enumerate(lens):
+                    mask[b, :l] = 1
+                    ids[b, l:] = 0
+                types = torch.zeros(B, L, dtype=torch.long)
+                feats = mutils.l2norm(torch.randn(B, 36, F_), dim=-1)
+                model.train_emb((feats, None, None, ids, lens, list(range(B)), mask, types), epoch=step - 1)
+                out.update({'%s_s%d_feats' % (stru, step): feats, '%s_s%d_ids' % (stru, step): ids, '%s_s%d_mask' % (stru, step): mask,
+                            '%s_s%d_types' % (stru, step): types, '%s_s%d_lens' % (stru, step): np.array(lens),
+                            '%s_s%d_loss1' % (stru, step): float(model.logger.meters['Loss1'].val),
+                            '%s_s%d_loss2' % (stru, step): float(model.logger.meters['Loss2'].val)})
+                for n, p_ in list(('txt.' + n, p_) for n, p_ in model.txt_enc.named_parameters()) + \
+                        list(('img.' + n, p_) for n, p_ in model.img_enc.named_parameters()):
+                    if p_.grad is not None:
+                        out['%s_s%d_grad_%s' % (stru, step, n)] = p_.grad.detach().clone()
+                if step == 2:          # parameters after both Adam steps (the step-1 state is implied by the step-1 gradients)
+                    for k, v in sd(model.img_enc).items():
+                        out['%s_s%d_img_%s' % (stru, step, k)] = v
+                    for k, v in sd(model.txt_enc).items():
+                        if not k.startswith('bert.'):
+                            out['%s_s%d_txt_%s' % (stru, step, k)] = v
+            print("   %s: loss1 %.5f / %.5f  loss2 %.5f / %.5f" % (stru, out[stru + '_s1_loss1'], out[stru + '_s2_loss1'],
+                                                                   out[stru + '_s1_loss2'], out[stru + '_s2_loss2']))
+    save('g18_saem_train', **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18']
     for name in which:
         print("== " + name)
         globals()[name]()
