@@ -377,10 +377,31 @@ class SAEM(base_module):
         if not hasattr(self, '_seeds'):
             self._seeds = ag.DropoutSeeds()
         self._seeds.new_step()
+        comm = self._dp_comm()
+        rows = None
+        if comm.on:
+            # data parallel: strided shard of the global batch through the towers, both embedding sets all-gathered; every
+            # loss term is then evaluated replicated on the full batch, so the gathers' backward is a plain slice and only the
+            # parameter gradients are summed (Adam.step).  The regulariser depends on the parameters alone: 1 / world of it
+            # per rank.
+            B = len(lengths)
+            if B < comm.world:
+                raise ValueError("data-parallel train_emb: batch of %d on %d ranks" % (B, comm.world))
+            sel = torch.arange(comm.rank, B, comm.world)
+            rows = [len(range(q, B, comm.world)) for q in range(comm.world)]
+            order = [i for q in range(comm.world) for i in range(q, B, comm.world)]          # rank-major global order
+            images, captions, captions_mask, captions_type_ids = (t[sel.to(t.device)] for t in (images, captions, captions_mask, captions_type_ids))
+            lengths_all, ids_all = [lengths[i] for i in order], [ids[i] for i in order]
+            lengths = [lengths[i] for i in sel.tolist()]
+            self._seeds.base += comm.rank * 7919                                                # other masks on other shards
         self.optimizer.zero_grad()
         with torch.enable_grad():
             cap = self.txt_enc.forward_train(self._dev(captions), self._dev(captions_mask), self._dev(captions_type_ids), lengths, self._seeds)
             img = self.img_enc.forward_train(self._dev(images), self._seeds)
+            if comm.on:
+                img = ag.dp_gather_rows(img, comm, rows, reduce=False)
+                cap = ag.dp_gather_rows(cap, comm, rows, reduce=False)
+                lengths, ids = lengths_all, ids_all
             # criterion = hinge on pdist_cos (Objectives.py:310-323: rows renormalised, no eps), on the tape
             scores = ag.cosine_scores(ag.l2norm_rows(img, eps=0.0), ag.l2norm_rows(cap, eps=0.0))
             loss1 = ops.hinge_loss(scores, self.config['margin'], self.config['max_violation'])
@@ -390,7 +411,7 @@ class SAEM(base_module):
             for name, param in self.img_enc.named_parameters():
                 if name.split('.')[-1] not in self.no_decay:
                     l2_reg = l2_reg + torch.norm(param)
-            loss = loss1 + alpha * loss2 + 0.01 * l2_reg
+            loss = loss1 + alpha * loss2 + (0.01 / comm.world) * l2_reg
             self._log('Loss1', loss1.detach(), img.size(0))
             self._log('Loss2', loss2.detach(), img.size(0))
             self._step(loss, img.size(0))

@@ -43,6 +43,23 @@ if a.model == 'SCAN':
 cfg = C.build_config(over)
 cfg['vocab_size'] = 500
 cfg['img_dim'] = 128
+if a.model == 'SAEM':
+    # a tiny random BERT + transformer config (dropout 0: the shards of a data-parallel run draw other masks than one process)
+    import json
+    from itr_amd.modalmodule import bert
+    d = a.out + ".files_rank%s" % os.environ.get("RANK", "0")
+    os.makedirs(d, exist_ok=True)
+    bc = dict(vocab_size=500, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64, max_position_embeddings=40,
+              type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    json.dump(bc, open(os.path.join(d, 'bert_config.json'), 'w'))
+    json.dump(dict(bc, num_hidden_layers=1, vocab_size=10), open(os.path.join(d, 'trans_cfg.json'), 'w'))
+    torch.manual_seed(99)
+    bm = bert.BertModel(bert.BertConfig.from_dict(bc))
+    for p_ in bm.parameters():
+        p_.data.normal_(0, 0.05)
+    torch.save(bm.state_dict(), os.path.join(d, 'pytorch_model.bin'))
+    cfg.update(bert_config_file=os.path.join(d, 'bert_config.json'), init_checkpoint=os.path.join(d, 'pytorch_model.bin'),
+               trans_cfg=os.path.join(d, 'trans_cfg.json'), final_dims=32, embed_size=32, learning_rate=1e-3)
 torch.manual_seed(1234)
 model = get_model(cfg)
 model.train_start()
@@ -57,12 +74,23 @@ for step in range(a.steps):
         ids[b, :l] = torch.from_numpy(rng.randint(4, 500, size=l))
     feats = torch.from_numpy(rng.randn(B, 36, 128).astype(np.float32))
     feats = feats / feats.norm(dim=-1, keepdim=True)
+    if a.model == 'SAEM':
+        L = 14
+        ids = torch.from_numpy(rng.randint(1, 500, size=(B, L)))
+        mask = torch.zeros(B, L, dtype=torch.long)
+        for b, l in enumerate(lens):
+            mask[b, :l] = 1
+            ids[b, l:] = 0
+        model.train_emb((feats, None, None, ids, lens, list(range(B)), mask, torch.zeros(B, L, dtype=torch.long)))
+        losses.append(float(model.logger.meters['Loss1'].val) + float(model.logger.meters['Loss2'].val))
+        gnorms.append(float(model.optimizer.last_grad_norm[0]))
+        continue
     model.train_emb((feats, None, None, ids, lens, list(range(B)), None, None))
     losses.append(float(model.logger.meters['Loss'].val))
     gnorms.append(float(model.optimizer.last_grad_norm[0]))
 torch.cuda.synchronize()
 if world == 1 or dist.get_rank() == 0:
-    flat = torch.cat([p.detach().reshape(-1) for p in model.params]).cpu().numpy()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.params if p.requires_grad]).cpu().numpy()
     np.savez(a.out, dp_on=int(model.optimizer.comm is not None), dp_world=(model.optimizer.comm.world if model.optimizer.comm is not None else 1), params=flat, losses=np.asarray(losses), gnorms=np.asarray(gnorms), lr=cfg['learning_rate'])
 if dist.is_initialized():
     dist.barrier()

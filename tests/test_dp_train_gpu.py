@@ -33,6 +33,7 @@ def _run(tmp_path, tag, world, extra):
     (["--model", "SCAN", "--cross-attn", "t2i", "--batch", "25"], 3),     # ragged shards: 9 / 8 / 8 rows
     (["--model", "SCAN", "--cross-attn", "i2t"], 2),
     (["--model", "VSE_PP"], 2),
+    (["--model", "SAEM", "--batch", "11"], 2),                            # both embedding sets gathered, losses replicated
 ])
 def test_dp_train_step_equals_single_process(tmp_path, extra, world):
     one = _run(tmp_path, "one", 1, extra)
