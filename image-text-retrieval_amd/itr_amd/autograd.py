@@ -588,6 +588,220 @@ def mean_mid(x):
     return _MeanMid.apply(x)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# CAMERA towers: elementwise product, activations, attention gate, training-mode BatchNorm, l2norm across regions,
+# multi-view summarisation, multi-view matching
+def _ew_mul(a, b):
+    lib = _lib.load()
+    out = torch.empty_like(a)
+    _lib.check(lib.itr_ew_mul(_p(a), _p(b), _p(out), a.numel(), _stream()))
+    return out
+
+
+class _Mul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _dev(a, name="a"), _dev(b, name="b")
+        if a.shape != b.shape:
+            raise ValueError("mul: shapes %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        ctx.save_for_backward(a, b)
+        return _ew_mul(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        return _ew_mul(dy, b), _ew_mul(dy, a)
+
+
+def mul(a, b):
+    return _Mul.apply(a, b)
+
+
+_ACT_CODE = {'relu': 1, 'tanh': 2, 'sigmoid': 3}
+
+
+class _Act(torch.autograd.Function):
+    """relu / tanh / sigmoid; the derivative is taken from the output."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        from . import ops
+        y = ops.affine_cols(_dev(x, name="x"), act=kind)
+        ctx.save_for_backward(y)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        y, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        _lib.check(lib.itr_act_bwd(_p(y), _p(dy), _p(dx), y.numel(), _ACT_CODE[ctx.kind], _stream()))
+        return dx, None
+
+
+def act(x, kind):
+    return _Act.apply(x, kind)
+
+
+class _GateApply(torch.autograd.Function):
+    """q' = q * M[:, :dk], k' = k * M[:, dk:]  (camera_.py:41-44); q, k [rows, dk], M [rows, 2 dk]."""
+
+    @staticmethod
+    def forward(ctx, q, k, M):
+        lib = _lib.load()
+        q, k, M = _dev(q, name="q"), _dev(k, name="k"), _dev(M, name="M")
+        rows, dk = q.shape
+        qo, ko = torch.empty_like(q), torch.empty_like(k)
+        _lib.check(lib.itr_gate_apply(_p(q), _p(k), _p(M), _p(qo), _p(ko), rows, dk, _stream()))
+        ctx.save_for_backward(q, k, M)
+        return qo, ko
+
+    @staticmethod
+    def backward(ctx, dqo, dko):
+        lib = _lib.load()
+        q, k, M = ctx.saved_tensors
+        rows, dk = q.shape
+        dq, dkk, dM = torch.empty_like(q), torch.empty_like(k), torch.empty_like(M)
+        _lib.check(lib.itr_gate_apply_bwd(_p(q), _p(k), _p(M), _p(dqo.contiguous()), _p(dko.contiguous()), _p(dq), _p(dkk), _p(dM), rows, dk,
+                                          _stream()))
+        return dq, dkk, dM
+
+
+def gate_apply(q, k, M):
+    return _GateApply.apply(q, k, M)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, stats_out):
+        lib = _lib.load()
+        x = _dev(x, name="x")
+        N, Cc = x.shape
+        g, b = _dev(gamma, name="gamma"), _dev(beta, name="beta")
+        y = torch.empty_like(x)
+        mean, invstd = _f32(Cc, dev=x.device), _f32(Cc, dev=x.device)
+        _lib.check(lib.itr_bn_train_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(invstd), N, Cc, float(eps), _stream()))
+        ctx.save_for_backward(x, mean, invstd, g)
+        stats_out.append((mean, invstd))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, mean, invstd, g = ctx.saved_tensors
+        N, Cc = x.shape
+        dx, dg, db = torch.empty_like(x), _f32(Cc, dev=x.device), _f32(Cc, dev=x.device)
+        _lib.check(lib.itr_bn_train_bwd(_p(dy.contiguous()), _p(x), _p(mean), _p(invstd), _p(g), _p(dx), _p(dg), _p(db), N, Cc, _stream()))
+        return dx, dg, db, None, None
+
+
+def batch_norm_train(x2d, bn):
+    """nn.BatchNorm1d(x2d [N, C]) in training mode: batch statistics, and the module's running statistics updated like torch
+    (momentum, unbiased variance, num_batches_tracked)."""
+    stats = []
+    y = _BatchNormTrain.apply(x2d, bn.weight, bn.bias, bn.eps, stats)
+    mean, invstd = stats[0]
+    with torch.no_grad():
+        N = x2d.shape[0]
+        var_b = 1.0 / (invstd * invstd) - bn.eps
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+        bn.running_var.mul_(1 - mom).add_(var_b * (N / max(N - 1, 1)), alpha=mom)
+        bn.num_batches_tracked += 1
+    return y
+
+
+class _L2NormMid(torch.autograd.Function):
+    """utils.l2norm(x) with the reference's default dim=1 on x [B, R, D]."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib = _lib.load()
+        x = _dev(x, name="x")
+        B, R, D = x.shape
+        z, n = torch.empty_like(x), _f32(B, D, dev=x.device)
+        _lib.check(lib.itr_l2norm_mid_fwd(_p(x), _p(z), _p(n), B, R, D, float(eps), _stream()))
+        ctx.save_for_backward(z, n)
+        ctx.eps = float(eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        z, n = ctx.saved_tensors
+        B, R, D = z.shape
+        dx = torch.empty_like(z)
+        _lib.check(lib.itr_l2norm_mid_bwd(_p(dz.contiguous()), _p(z), _p(n), _p(dx), B, R, D, ctx.eps, _stream()))
+        return dx, None
+
+
+def l2norm_mid(x, eps=1e-8):
+    return _L2NormMid.apply(x, eps)
+
+
+class _Smry(torch.autograd.Function):
+    """softmax(smry_mat, dim=1)^T x  (ImgEncoder.py:386-387): smry [B, R, K], x [B, R, D] -> [B, K, D]."""
+
+    @staticmethod
+    def forward(ctx, smry, x):
+        lib = _lib.load()
+        smry, x = _dev(smry, name="smry"), _dev(x, name="x")
+        B, R, K = smry.shape
+        D = x.shape[2]
+        L, out = torch.empty_like(smry), _f32(B, K, D, dev=x.device)
+        _lib.check(lib.itr_smry_fwd(_p(smry), _p(x), _p(L), _p(out), B, R, K, D, _stream()))
+        ctx.save_for_backward(x, L)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, L = ctx.saved_tensors
+        B, R, K = L.shape
+        D = x.shape[2]
+        dx, dsm, scratch = torch.empty_like(x), torch.empty_like(L), torch.empty_like(L)
+        _lib.check(lib.itr_smry_bwd(_p(x), _p(L), _p(dout.contiguous()), _p(dx), _p(dsm), _p(scratch), B, R, K, D, _stream()))
+        return dsm, dx
+
+
+def summarize(smry, x):
+    return _Smry.apply(smry, x)
+
+
+class _GroupMax(torch.autograd.Function):
+    """max over the k view rows of every image: T [Ni * k, Nc] -> [Ni, Nc]."""
+
+    @staticmethod
+    def forward(ctx, T, k):
+        lib = _lib.load()
+        T = _dev(T, name="T")
+        Ni, Nc = T.shape[0] // k, T.shape[1]
+        S = _f32(Ni, Nc, dev=T.device)
+        arg = torch.empty(Ni, Nc, device=T.device, dtype=torch.int32)
+        _lib.check(lib.itr_groupmax_fwd(_p(T), Ni, k, Nc, _p(S), _p(arg), _stream()))
+        ctx.save_for_backward(arg)
+        ctx.k = k
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        lib = _lib.load()
+        arg, = ctx.saved_tensors
+        Ni, Nc = arg.shape
+        dT = _f32(Ni * ctx.k, Nc, dev=dS.device)
+        _lib.check(lib.itr_groupmax_bwd(_p(dS.contiguous()), _p(arg), Ni, ctx.k, Nc, _p(dT), _stream()))
+        return dT, None
+
+
+def mvm_scores(img_views, caps):
+    """MultiViewMatching (Fusionmodule.py:674-692) on the tape: img_views [Ni, k, D], caps [Nc, D] -> [Ni, Nc]."""
+    Ni, k, D = img_views.shape
+    return _GroupMax.apply(cosine_scores(img_views.reshape(Ni * k, D), caps), k)
+
+
 class _DPGatherRows(torch.autograd.Function):
     """Row blocks of every rank concatenated rank-major (one RCCL all-gather).  Two kinds of backward:
     reduce=True   the gathered rows feed a computation that DIFFERS per rank (every rank scores its own image rows

@@ -323,6 +323,33 @@ int itr_relu_maxpool_bwd(const float *dy, const int32_t *arg, int64_t B, int npo
 /* backward of torch.mean(x, 1): dx[b, r, :] = scale * dy[b, :]. */
 int itr_bcast_mid(const float *dy, float *dx, int64_t B, int R, int F, float scale, itr_stream_t stream);
 
+/* ---- CAMERA towers under autograd (camera_.py:14-114, ImgEncoder.py:355-389, TextEncoder.py:162-192, Fusionmodule.py:674-692):
+ * the pieces between the dense layers ---------------------------------------------------------------------------------------
+ * out = a * b (backward: two more calls). */
+int itr_ew_mul(const float *a, const float *b, float *out, int64_t n, itr_stream_t stream);
+/* dx = dy * act'(.) from the OUTPUT y of the activation: act 1 relu, 2 tanh, 3 sigmoid. */
+int itr_act_bwd(const float *y, const float *dy, float *dx, int64_t n, int act, itr_stream_t stream);
+/* GatedQueryAttLayer gate (camera_.py:41-44): q' = q * M[:, :dk], k' = k * M[:, dk:] on [rows, dk] operands, M [rows, 2 dk]. */
+int itr_gate_apply(const float *q, const float *k, const float *M, float *qo, float *ko, int64_t rows, int dk, itr_stream_t stream);
+int itr_gate_apply_bwd(const float *q, const float *k, const float *M, const float *dqo, const float *dko, float *dq, float *dk_out,
+                       float *dM, int64_t rows, int dk, itr_stream_t stream);
+/* nn.BatchNorm1d in training mode on x [N, C]: batch mean / biased variance per column; keeps mean and 1 / sqrt(var + eps). */
+int itr_bn_train_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *invstd, int64_t N, int C,
+                     float eps, itr_stream_t stream);
+int itr_bn_train_bwd(const float *dy, const float *x, const float *mean, const float *invstd, const float *gamma, float *dx,
+                     float *dgamma, float *dbeta, int64_t N, int C, itr_stream_t stream);
+/* utils.l2norm with its default dim=1 on [B, R, D] (normalises ACROSS the R regions, ImgEncoder.py:378,384). */
+int itr_l2norm_mid_fwd(const float *x, float *z, float *norms, int64_t B, int R, int D, float eps, itr_stream_t stream);
+int itr_l2norm_mid_bwd(const float *dz, const float *z, const float *norms, float *dx, int64_t B, int R, int D, float eps,
+                       itr_stream_t stream);
+/* Multi-view summarisation (ImgEncoder.py:386-387): L = softmax(smry [B, R, K], dim=1); out [B, K, D] = L^T x.  scratch: B*R*K floats. */
+int itr_smry_fwd(const float *smry, const float *x, float *L, float *out, int64_t B, int R, int K, int D, itr_stream_t stream);
+int itr_smry_bwd(const float *x, const float *L, const float *dout, float *dx, float *dsmry, float *scratch, int64_t B, int R, int K,
+                 int D, itr_stream_t stream);
+/* MultiViewMatching (Fusionmodule.py:674-692) on top of the [Ni * k, Nc] view scores: S[i, c] = max_v T[i * k + v, c]. */
+int itr_groupmax_fwd(const float *T, int64_t Ni, int k, int64_t Nc, float *S, int32_t *arg, itr_stream_t stream);
+int itr_groupmax_bwd(const float *dS, const int32_t *arg, int64_t Ni, int k, int64_t Nc, float *dT, itr_stream_t stream);
+
 /* EncoderText (bi)GRU under autograd (TextEncoder.py:38-70): training forward that keeps the gate activations, and
  * backpropagation through time.  Same packed layout / sorting contract as itr_gru_fwd.  `out` [n_tok, D] is the RAW
  * sequence output ((fwd + bwd) / 2 for a bi-GRU); l2norm / last-step gather are separate differentiable steps.

@@ -1,0 +1,96 @@
+"""GPU: training primitives of the CAMERA towers (csrc/train_camera.hip, itr_amd/autograd.py) against torch autograd on the CPU in
+float64: elementwise product, activations, attention gate, training-mode BatchNorm1d (incl. running statistics), l2norm across
+the regions, multi-view summarisation, multi-view matching."""
+import numpy as np
+import pytest
+import torch
+
+from itr_amd import autograd as ag
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(got, want, tol):
+    assert float((got.detach().cpu().double() - want.detach()).abs().max()) <= tol
+
+
+def test_mul_act_gate(dev):
+    torch.manual_seed(0)
+    a, b, dy = torch.randn(50, 33), torch.randn(50, 33), torch.randn(50, 33)
+    A, B_ = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    (A * B_).backward(dy.double())
+    ga, gb = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ag.mul(ga, gb)
+    y.backward(dy.to(dev))
+    _cmp(y, (A * B_), 1e-6); _cmp(ga.grad, A.grad, 1e-6); _cmp(gb.grad, B_.grad, 1e-6)
+    for kind, fn in (('relu', torch.relu), ('tanh', torch.tanh), ('sigmoid', torch.sigmoid)):
+        X = a.double().requires_grad_(True)
+        fn(X).backward(dy.double())
+        gx = a.to(dev).requires_grad_(True)
+        out = ag.act(gx, kind)
+        out.backward(dy.to(dev))
+        _cmp(out, fn(X), 2e-6); _cmp(gx.grad, X.grad, 2e-6)
+    rows, dk = 77, 32
+    q, k, M = torch.randn(rows, dk), torch.randn(rows, dk), torch.rand(rows, 2 * dk)
+    d1, d2 = torch.randn(rows, dk), torch.randn(rows, dk)
+    Q, K, MM = (t.double().requires_grad_(True) for t in (q, k, M))
+    ((Q * MM[:, :dk]) * d1.double()).sum().backward(retain_graph=True)
+    ((K * MM[:, dk:]) * d2.double()).sum().backward()
+    gq, gk, gm = (t.to(dev).requires_grad_(True) for t in (q, k, M))
+    qo, ko = ag.gate_apply(gq, gk, gm)
+    ((qo * d1.to(dev)).sum() + (ko * d2.to(dev)).sum()).backward()
+    _cmp(qo, Q * MM[:, :dk], 1e-6); _cmp(ko, K * MM[:, dk:], 1e-6)
+    _cmp(gq.grad, Q.grad, 1e-6); _cmp(gk.grad, K.grad, 1e-6); _cmp(gm.grad, MM.grad, 1e-6)
+
+
+def test_batch_norm_train(dev):
+    torch.manual_seed(1)
+    for N, Cc in ((200, 70), (9, 130)):
+        x, dy = torch.randn(N, Cc) * 2 + 0.5, torch.randn(N, Cc)
+        ref = torch.nn.BatchNorm1d(Cc).double()
+        ref.weight.data.uniform_(0.5, 1.5); ref.bias.data.normal_(0, 0.1)
+        ref.running_mean.normal_(0, 0.1); ref.running_var.uniform_(0.5, 1.5)
+        mine = torch.nn.BatchNorm1d(Cc)
+        mine.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+        mine.to(dev)
+        X = x.double().requires_grad_(True)
+        ref.train()
+        want = ref(X)
+        want.backward(dy.double())
+        gx = x.to(dev).requires_grad_(True)
+        y = ag.batch_norm_train(gx, mine)
+        y.backward(dy.to(dev))
+        _cmp(y, want, 2e-5); _cmp(gx.grad, X.grad, 5e-5)
+        _cmp(mine.weight.grad, ref.weight.grad, 2e-4); _cmp(mine.bias.grad, ref.bias.grad, 2e-4)
+        _cmp(mine.running_mean, ref.running_mean, 1e-5); _cmp(mine.running_var, ref.running_var, 1e-4)
+        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+
+
+def test_l2norm_mid_summarize_mvm(dev):
+    torch.manual_seed(2)
+    B, R, D, K = 4, 36, 70, 12
+    x, dz = torch.randn(B, R, D), torch.randn(B, R, D)
+    X = x.double().requires_grad_(True)
+    want = X / (X.pow(2).sum(1, keepdim=True).sqrt() + 1e-8)
+    want.backward(dz.double())
+    gx = x.to(dev).requires_grad_(True)
+    z = ag.l2norm_mid(gx)
+    z.backward(dz.to(dev))
+    _cmp(z, want, 1e-6); _cmp(gx.grad, X.grad, 2e-6)
+    sm, dout = torch.randn(B, R, K), torch.randn(B, K, D)
+    S_, X2 = sm.double().requires_grad_(True), x.double().requires_grad_(True)
+    want = torch.softmax(S_, 1).transpose(1, 2) @ X2
+    want.backward(dout.double())
+    gs, gx2 = sm.to(dev).requires_grad_(True), x.to(dev).requires_grad_(True)
+    out = ag.summarize(gs, gx2)
+    out.backward(dout.to(dev))
+    _cmp(out, want, 2e-6); _cmp(gs.grad, S_.grad, 2e-5); _cmp(gx2.grad, X2.grad, 2e-6)
+    Ni, Nc = 7, 9
+    img, cap, dS = torch.randn(Ni, K, D), torch.randn(Nc, D), torch.randn(Ni, Nc)
+    I, Cc = img.double().requires_grad_(True), cap.double().requires_grad_(True)
+    want = (I.reshape(Ni * K, D) @ Cc.t()).view(Ni, K, Nc).max(1).values
+    want.backward(dS.double())
+    gi, gc = img.to(dev).requires_grad_(True), cap.to(dev).requires_grad_(True)
+    Sg = ag.mvm_scores(gi, gc)
+    Sg.backward(dS.to(dev))
+    _cmp(Sg, want, 2e-5); _cmp(gi.grad, I.grad, 2e-5); _cmp(gc.grad, Cc.grad, 2e-5)
