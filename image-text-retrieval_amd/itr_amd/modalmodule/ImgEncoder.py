@@ -182,6 +182,17 @@ class EncoderImagePrecompSelfAttn(nn.Module):
         smry_mat = self.mvs(self_att_emb)
         return ops.camera_summarize(smry_mat, self_att_emb), smry_mat
 
+    def forward_train(self, images, boxes, imgs_wh, seeds):
+        """The tower on the autograd tape (CAMERA.train_emb): BatchNorm batch statistics, dropout sites live."""
+        from .. import autograd as ag
+        B, R, _ = images.shape
+        fc = ag.l2norm_mid(ag.linear(images.reshape(B * R, -1), self.fc.weight, self.fc.bias).view(B, R, -1))
+        pos = self.position_enc.forward_train(boxes, imgs_wh)
+        att = ag.l2norm_mid(self.agsa.forward_train(fc, pos, seeds, self.training))
+        smry_mat = self.mvs.forward_train(att)
+        views = ag.summarize(smry_mat, att)                                       # softmax(smry, dim=1)^T att  -> (B, k, D)
+        return ag.l2norm_rows(views, eps=1e-12), smry_mat                         # F.normalize(dim=-1)
+
     def load_state_dict(self, state_dict):
         own_state = self.state_dict()
         new_state = OrderedDict((k, v) for k, v in state_dict.items() if k in own_state)

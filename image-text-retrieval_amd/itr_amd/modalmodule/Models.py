@@ -4,8 +4,9 @@ train_start / state_dict / load_state_dict.  Towers and losses run on the HIP ke
 
 `train_emb` (forward -> loss -> backward -> clip_grad_norm_ -> Adam, Models.py:115-145, :198-225, :444-464) is built for the
 GRU family with a pooled or SCAN similarity (VSE++, SCAN) and for SAEM (frozen BERT in training mode, cnn / pooling / trans
-head and the image transformer layer on the tape, live dropout): itr_amd/autograd.py wires the HIP forward / backward
-kernels into torch's tape.  SGRAF / CAMERA training (backward through EncoderSimilarity / AGSA + summarisation) is not built.
+head and the image transformer layer on the tape, live dropout) and CAMERA (AGSA with BatchNorm batch statistics,
+dilated-convolution summarisation, multi-view matching): itr_amd/autograd.py wires the HIP forward / backward kernels into
+torch's tape.  SGRAF training (backward through EncoderSimilarity) is not built.
 
 Data-parallel training (the reference has none): with torch.distributed initialised and world > 1,
 every rank receives the SAME global batch (loaders share the seed), keeps the strided shard rank::world of it, runs
@@ -434,6 +435,7 @@ class CAMERA(base_module):
         self.crit_div = Objectives.DiversityRegularization(config['smry_k'], config['batch_size'])
         self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters())
         self.calculate_params()
+        self.optimizer = ag.Adam([p_ for p_ in self.params if p_.requires_grad], lr=config['learning_rate'])   # (frozen BERT: no gradients)
 
     def forward_emb(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, *args, **kwargs):
         cap_emb = self.txt_enc(self._dev(captions), self._dev(captions_mask), self._dev(captions_type_ids))
@@ -449,3 +451,26 @@ class CAMERA(base_module):
         loss = ranking_loss + div_reg * self.config['smry_lamda']
         self._log('Loss', loss.item(), len(sim_mat))
         return loss
+
+    def train_emb(self, train_data, *args, **kwargs):
+        """One training step (Models.py:613-645): towers on the autograd tape (frozen BERT forward in training mode, AGSA with
+        BatchNorm batch statistics, dilated-convolution summarisation), multi-view matching, bidirectional hinge + smry_lamda *
+        diversity regulariser, backward, clip_grad_norm_, Adam."""
+        images, boxes, imgs_wh, captions, _, _, captions_mask, captions_type_ids = train_data
+        self.Eiters += 1
+        self._log('Eit', self.Eiters)
+        self._log('lr', self.optimizer.param_groups[0]['lr'])
+        if not hasattr(self, '_seeds'):
+            self._seeds = ag.DropoutSeeds()
+        self._seeds.new_step()
+        self.optimizer.zero_grad()
+        with torch.enable_grad():
+            cap = self.txt_enc.forward_train(self._dev(captions), self._dev(captions_mask), self._dev(captions_type_ids), self._seeds)
+            img, smry_mat = self.img_enc.forward_train(self._dev(images), self._dev(boxes), self._dev(imgs_wh), self._seeds)
+            sim_mat = ag.mvm_scores(img, cap)
+            ranking_loss = ops.hinge_loss(sim_mat, self.config['margin'], self.config['max_violation'])
+            div_reg = self.crit_div(smry_mat)
+            loss = ranking_loss + div_reg * self.config['smry_lamda']
+            self._log('Rank_Loss', ranking_loss.detach(), len(sim_mat))
+            self._log('Div_loss', div_reg.detach(), len(sim_mat))
+            self._step(loss, len(sim_mat))

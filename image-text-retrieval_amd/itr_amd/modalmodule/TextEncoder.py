@@ -179,6 +179,7 @@ class CAMERAEncoderText(nn.Module):
         self.fc1 = nn.Linear(embed_size, embed_size)
         self.fc2 = nn.Linear(embed_size, embed_size)
         self.bn = nn.BatchNorm1d(embed_size)
+        self.drop = float(drop or 0.0)
 
     def forward(self, input_ids, attention_mask, token_type_ids, lengths=None):
         all_encoder_layers, _ = self.bert(input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask)
@@ -189,6 +190,21 @@ class CAMERAEncoderText(nn.Module):
         sc, sh = bn_affine(self.bn)
         x = ops.affine_cols(h, sc, sh, residual=agsa_emb)
         return ops.normalize(ops.mean_mid(x), dim=-1)
+
+    def forward_train(self, input_ids, attention_mask, token_type_ids, seeds):
+        """CAMERA.train_emb: frozen BERT in training mode -> mapping -> AGSA -> MLP + BatchNorm residual -> mean -> F.normalize
+        on the autograd tape (TextEncoder.py:181-192)."""
+        from .. import autograd as ag
+        last = self.bert.forward_frozen_train(input_ids, token_type_ids, attention_mask, seeds)
+        B, L, H = last.shape
+        x = ag.linear(last.reshape(B * L, H), self.mapping.weight, self.mapping.bias).view(B, L, -1)
+        agsa_emb = self.agsa.forward_train(x, None, seeds, self.training)
+        E = agsa_emb.shape[-1]
+        h = ag.act(ag.linear(agsa_emb.reshape(B * L, E), self.fc1.weight, self.fc1.bias), 'relu')
+        h = ag.linear(ag.dropout(h, self.drop, seeds, self.training), self.fc2.weight, self.fc2.bias)
+        h = ag.batch_norm_train(h, self.bn).view(B, L, E)
+        x = agsa_emb + ag.dropout(h, self.drop, seeds, self.training)
+        return ag.l2norm_rows(ag.mean_mid(x), eps=1e-12)
 
     def freeze_layers(self, model):
         for child in model.children():

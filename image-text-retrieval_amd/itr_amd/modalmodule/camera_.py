@@ -58,6 +58,21 @@ class GatedQueryAttLayer(nn.Module):
         x = ops.mha_small(q2.view(B * L, D), k2.view(B * L, D), v, None, B, L, self.h, dk, 1.0 / math.sqrt(dk))
         return x.view(B, L, D)
 
+    def forward_train(self, inp, seeds, training=True):
+        """The layer on the autograd tape (CAMERA.train_emb); dropout on the attention probabilities when drop > 0 (:49-50)."""
+        from .. import autograd as ag
+        B, L, D = inp.shape
+        dk = self.d_k
+        x2 = inp.reshape(B * L, D)
+        q, k, v = [ag.linear(x2, l.weight, l.bias) for l in self.linears]
+        q2, k2 = q.view(-1, dk), k.view(-1, dk)
+        G = ag.mul(ag.linear(q2, self.fc_q.weight, self.fc_q.bias), ag.linear(k2, self.fc_k.weight, self.fc_k.bias))
+        M = ag.act(ag.linear(G, self.fc_g.weight, self.fc_g.bias), 'sigmoid')
+        qg, kg = ag.gate_apply(q2, k2, M)
+        qkv = torch.cat([qg.view(B * L, D), kg.view(B * L, D), v], 1)
+        p = float(self.drop_p or 0.0)
+        return ag.mha(qkv, None, B, L, self.h, p if training else 0.0, seeds.next()).view(B, L, D)
+
 
 class AGSA(nn.Module):
     """Adaptive Gating Self-Attention (camera_.py:57-89)."""
@@ -66,6 +81,7 @@ class AGSA(nn.Module):
         super().__init__()
         self.num_layers = num_layers
         self.bns = clones(nn.BatchNorm1d(embed_size), num_layers)
+        self.drop = float(drop or 0.0)          # nn.Dropout(drop) after every BatchNorm (camera_.py:63, :82, :88)
         self.is_share = is_share
         self.h = h
         self.embed_size = embed_size
@@ -79,6 +95,18 @@ class AGSA(nn.Module):
             x = self.att_layers[i](x if i == 0 else agsa_emb, mask)
             sc, sh = bn_affine(self.bns[i])
             agsa_emb = ops.affine_cols(x, sc, sh, residual=agsa_emb)          # rgn + bn(att)
+        return agsa_emb
+
+    def forward_train(self, rgn_emb, pos_emb, seeds, training=True):
+        """AGSA on the autograd tape with BatchNorm batch statistics and the dropout sites live (camera_.py:69-89)."""
+        from .. import autograd as ag
+        bs, num_r, emb_dim = rgn_emb.shape
+        x = rgn_emb if pos_emb is None else ag.mul(rgn_emb, pos_emb)
+        agsa_emb = rgn_emb
+        for i in range(self.num_layers):
+            x = self.att_layers[i].forward_train(x if i == 0 else agsa_emb, seeds, training)
+            x = ag.batch_norm_train(x.reshape(bs * num_r, emb_dim), self.bns[i]).view(bs, num_r, emb_dim)
+            agsa_emb = agsa_emb + ag.dropout(x, self.drop, seeds, training)
         return agsa_emb
 
 
@@ -124,6 +152,22 @@ class Summarization(nn.Module):
         smry = _lin(cat, self.convs_fc)                                          # (B*Rp, k)
         return smry.view(B, Rp, -1)[:, P:P + R].contiguous()
 
+    def forward_train(self, rgn_emb):
+        """On the autograd tape: every dilated convolution is an unfold copy of its taps (zero padded) + ONE GEMM + relu."""
+        from .. import autograd as ag
+        B, R, D = rgn_emb.shape
+        P = self.PAD
+        xp = torch.nn.functional.pad(rgn_emb, (0, 0, P, P))                      # zero rows before / after the regions
+        outs = []
+        for conv in self.convs_dilate:
+            ks, dil, oc = conv.kernel_size[0], conv.dilation[0], conv.out_channels
+            taps = [xp[:, P + (j - (ks - 1) // 2) * dil:P + (j - (ks - 1) // 2) * dil + R] for j in range(ks)]
+            unf = torch.cat(taps, 2).reshape(B * R, ks * D)
+            w2 = conv.weight.permute(0, 2, 1).reshape(oc, ks * D)                # [oc, D, ks] -> [oc, ks * D]
+            outs.append(ag.act(ag.linear(unf, w2, conv.bias), 'relu'))
+        cat = torch.cat(outs, 1)                                                 # (B*R, 1024)
+        return ag.linear(cat, self.convs_fc.weight, self.convs_fc.bias).view(B, R, -1)
+
 
 class PositionEncoder(nn.Module):
     """camera_.py:131-147."""
@@ -135,3 +179,9 @@ class PositionEncoder(nn.Module):
     def forward(self, boxes, imgs_wh):
         posi = ops.camera_posenc(boxes, imgs_wh)                                 # (bs, num_r, 6)
         return _lin(posi, self.proj, act='sigmoid')
+
+    def forward_train(self, boxes, imgs_wh):
+        from .. import autograd as ag
+        posi = ops.camera_posenc(boxes, imgs_wh)
+        B, R, _ = posi.shape
+        return ag.act(ag.linear(posi.reshape(B * R, -1), self.proj.weight, self.proj.bias), 'sigmoid').view(B, R, -1)

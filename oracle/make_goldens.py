@@ -883,9 +883,84 @@ def g18():
     save('g18_saem_train', **out)
 
 
+# ------------------------------------------------------------------ G19 CAMERA.train_emb (a14), drop = 0, BERT dropout 0
+def g19():
+    """The reference's own CAMERA.train_emb (Models.py:613-645) run twice on CPU (drop = 0 and BERT dropout probabilities 0, see
+    g18): Rank_Loss / Div_loss, the gradients of the trainable parameters after step 1 and all parameters / BatchNorm running
+    statistics after step 2."""
+    import json
+    import tempfile
+    from itr.modalmodule import bert as rbert
+    rng = np.random.RandomState(19)
+    out = {}
+    tmp = tempfile.mkdtemp()
+    cfg_d = dict(vocab_size=100, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                 max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(190)
+    bm = rbert.BertModel(rbert.BertConfig.from_dict(cfg_d))
+    for name, p_ in bm.named_parameters():
+        p_.data.normal_(0, 0.05)
+        if name.endswith('gamma'):
+            p_.data.uniform_(0.8, 1.2)
+    json.dump(cfg_d, open(os.path.join(tmp, 'bert_config.json'), 'w'))
+    torch.save(bm.state_dict(), os.path.join(tmp, 'pytorch_model.bin'))
+    out['bert_cfg'] = json.dumps(cfg_d)
+    for k, v in sd(bm).items():
+        out['wbert_' + k] = v
+    B, L, F_, E = 6, 10, 24, 32
+    cfg = dict(name='CAMERA', bert_config_file=os.path.join(tmp, 'bert_config.json'), init_checkpoint=os.path.join(tmp, 'pytorch_model.bin'),
+               img_dim=F_, embed_size=E, head=2, smry_k=12, drop=0.0, margin=0.2, max_violation=True, batch_size=B, learning_rate=1e-3,
+               grad_clip=2.0, smry_lamda=0.01)
+    with torch.enable_grad():
+        torch.manual_seed(191)
+        model = Models.CAMERA(cfg)
+        for name, p_ in list(model.txt_enc.named_parameters()) + list(model.img_enc.named_parameters()):
+            if 'bert.' not in name:
+                p_.data.normal_(0, 0.1)
+                if '.bns.' in name and name.endswith('weight') or name.endswith('bn.weight'):
+                    p_.data.uniform_(0.6, 1.4)
+        model.train_start()
+        model.logger = evaluation.LogCollector()
+        for k, v in sd(model.img_enc).items():
+            out['w0_img_' + k] = v
+        for k, v in sd(model.txt_enc).items():
+            if 'bert.' not in k:
+                out['w0_txt_' + k] = v
+        for step in (1, 2):
+            lens = sorted([int(x) for x in rng.randint(3, L + 1, size=B)], reverse=True)
+            ids = torch.from_numpy(rng.randint(1, 100, size=(B, L)))
+            mask = torch.zeros(B, L, dtype=torch.long)
+            for b, l in enumerate(lens):
+                mask[b, :l] = 1
+                ids[b, l:] = 0
+            types = torch.zeros(B, L, dtype=torch.long)
+            feats = mutils.l2norm(torch.randn(B, 36, F_), dim=-1)
+            x1y1 = torch.rand(B, 36, 2) * 300
+            boxes = torch.cat([x1y1, x1y1 + 20 + torch.rand(B, 36, 2) * 150], 2)
+            wh = torch.tensor([[640., 480.]]).repeat(B, 1)
+            model.train_emb((feats, boxes, wh, ids, lens, list(range(B)), mask, types))
+            pre = 's%d_' % step
+            out.update({pre + 'feats': feats, pre + 'boxes': boxes, pre + 'wh': wh, pre + 'ids': ids, pre + 'mask': mask, pre + 'types': types,
+                        pre + 'lens': np.array(lens), pre + 'rank_loss': float(model.logger.meters['Rank_Loss'].val),
+                        pre + 'div_loss': float(model.logger.meters['Div_loss'].val)})
+            if step == 1:
+                for n, p_ in list(('txt.' + n, p_) for n, p_ in model.txt_enc.named_parameters()) + \
+                        list(('img.' + n, p_) for n, p_ in model.img_enc.named_parameters()):
+                    if p_.grad is not None:
+                        out[pre + 'grad_' + n] = p_.grad.detach().clone()
+            else:
+                for k, v in sd(model.img_enc).items():
+                    out[pre + 'img_' + k] = v
+                for k, v in sd(model.txt_enc).items():
+                    if 'bert.' not in k:
+                        out[pre + 'txt_' + k] = v
+        print("   rank loss %.5f / %.5f   div %.5f / %.5f" % (out['s1_rank_loss'], out['s2_rank_loss'], out['s1_div_loss'], out['s2_div_loss']))
+    save('g19_camera_train', **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19']
     for name in which:
         print("== " + name)
         globals()[name]()

@@ -1,0 +1,93 @@
+"""GPU: CAMERA.train_emb (a14) against G19 -- the reference's own CAMERA.train_emb run twice on CPU (drop 0): Rank_Loss / Div_loss of
+both steps, every (clipped) gradient of the trainable parameters after step 1, the parameters and BatchNorm running statistics
+after the second Adam step."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from itr_amd import config as C
+from itr_amd.metricmodule.evaluation import LogCollector
+from itr_amd.modalmodule import get_model, bert
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_camera_train_emb_matches_reference(golden, dev, tmp_path):
+    g = golden("g19_camera_train")
+    bcfg = json.loads(str(g["bert_cfg"]))
+    json.dump(bcfg, open(tmp_path / 'bert_config.json', 'w'))
+    bm = bert.BertModel(bert.BertConfig.from_dict(bcfg))
+    bm.load_state_dict({k[6:]: T(g[k]) for k in g.files if k.startswith('wbert_')})
+    torch.save(bm.state_dict(), tmp_path / 'pytorch_model.bin')
+    cfg = C.build_config(['with', 'CAMERA', 'data_name=coco_precomp', 'max_violation=True', 'learning_rate=0.001', 'batch_size=6'])
+    cfg.update(bert_config_file=str(tmp_path / 'bert_config.json'), init_checkpoint=str(tmp_path / 'pytorch_model.bin'), img_dim=24, embed_size=32,
+               head=2, smry_k=12, drop=0.0, smry_lamda=0.01, vocab_size=100)
+    model = get_model(cfg)
+    # (the reference wraps both towers in nn.DataParallel: its names carry a "module." prefix)
+    strip = lambda k: k.replace('module.', '', 1)
+    sd_txt = model.txt_enc.state_dict()
+    sd_txt.update({strip(k[7:]): T(g[k]) for k in g.files if k.startswith('w0_txt_')})
+    model.load_state_dict([{strip(k[7:]): T(g[k]) for k in g.files if k.startswith('w0_img_')}, sd_txt])
+    model.train_start()
+    model.logger = LogCollector()
+    for step in (1, 2):
+        pre = 's%d_' % step
+        lens = [int(x) for x in g[pre + 'lens']]
+        batch = (T(g[pre + 'feats']), T(g[pre + 'boxes']), T(g[pre + 'wh']), T(g[pre + 'ids']), lens, list(range(len(lens))), T(g[pre + 'mask']),
+                 T(g[pre + 'types']))
+        model.train_emb(batch)
+        assert float(model.logger.meters['Rank_Loss'].val) == pytest.approx(float(g[pre + 'rank_loss']), abs=5e-5)
+        assert float(model.logger.meters['Div_loss'].val) == pytest.approx(float(g[pre + 'div_loss']), rel=2e-5)
+        if step == 1:
+            gn = float(model.optimizer.last_grad_norm[0])
+            coef = min(1.0, model.grad_clip / (gn + 1e-6))         # the reference stores the gradients after clip_grad_norm_
+            report = []
+            named = [('txt.' + n, p) for n, p in model.txt_enc.named_parameters()] + [('img.' + n, p) for n, p in model.img_enc.named_parameters()]
+            n_checked = 0
+            for n, p in named:
+                key = pre + 'grad_' + n.replace('.', '.module.', 1)
+                if key in g.files:
+                    want = T(g[key])
+                    d = float((p.grad.detach().cpu() * coef - want).norm() / (want.norm() + 1e-12))
+                    report.append((n, d, float(want.abs().max())))
+                    n_checked += 1
+                else:
+                    assert 'bert.' in n and p.grad is None, n
+            assert n_checked >= 30
+            # relative L2 error per tensor.  In this fixture two pre-activations of mvs.convs_dilate.3 lie within 5e-7 of the relu
+            # kink (measured), fp32 rounding flips their sign against the CPU run, and that convolution's gradient and everything
+            # upstream of it (fc, AGSA value projection, position encoder, BatchNorm) moves by up to ~1 %: every tensor must be
+            # within 2 %, the tensors that do not depend on the kink (and biases with a ~1e-7 gradient aside) within 1e-4
+            assert max(d for n, d, m in report if m > 1e-5) <= 2e-2, sorted(report, key=lambda r: -r[1])[:5]
+            tight = [d for n, d, m in report if m > 1e-5 and d <= 1e-4]
+            assert len(tight) >= 0.55 * len(report), (len(tight), len(report))
+    lr = 1e-3
+    for which, mod in (('img', model.img_enc), ('txt', model.txt_enc)):
+        for k, v in mod.state_dict().items():
+            key = 's2_%s_module.%s' % (which, k)
+            if key in g.files:
+                want = T(g[key])
+                if not v.is_floating_point():
+                    assert int(v) == int(want), k                  # num_batches_tracked
+                    continue
+                d = (v.cpu().float() - want.float()).abs()
+                if 'running_' in k:
+                    # (step-2 activations already see parameters that moved by up to lr through Adam's amplification)
+                    assert float(d.max()) <= 2e-3 * max(1.0, float(want.abs().max())), (k, float(d.max()))
+                else:
+                    # Adam turns gradient noise into steps of up to lr where |g| ~ eps: a parameter whose true gradient vanishes
+                    # (the value-projection bias in front of a BatchNorm: ~1e-6 in the reference run) random-walks by +-lr per step
+                    # in BOTH runs; everything else stays within 2 lr and 2e-4 on average (the relu-kink flip above moves a few
+                    # gradients by ~1 %)
+                    gkey = 's1_grad_%s.module.%s' % (which, k)
+                    noise_only = gkey in g.files and float(np.abs(g[gkey]).max()) < 1e-5
+                    if noise_only:
+                        assert float(d.max()) <= 4 * lr + 1e-7, (k, float(d.max()))
+                    else:
+                        assert float(d.max()) <= 2 * lr + 1e-7 and float(d.mean()) <= 2e-4, (k, float(d.max()), float(d.mean()))
