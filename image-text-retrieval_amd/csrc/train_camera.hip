@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
     float d;
     if (act == 1) d = v > 0.f ? 1.f : 0.f;            // relu
     else if (act == 2) d = 1.f - v * v;               // tanh
+    else if (act == 4) d = v > 0.f ? 1.f : 0.1f;      // LeakyReLU(0.1)
     else d = v * (1.f - v);                           // sigmoid
     dx[i] = dy[i] * d;
 }
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void l2norm_mid_bwd_kernel(const float *__rest
 }
 
 // ---- multi-view summarisation: L = softmax over the R regions of smry [B, R, K]; out[b, v, d] = sum_r L[b, r, v] x[b, r, d]
-constexpr int SM_R = 64, SM_K = 16;
+constexpr int SM_R = 64, SM_K = 64;      // (SGRAF: K = words of a caption / graph nodes)
 __global__ __launch_bounds__(256) void smry_fwd_kernel(const float *__restrict__ smry, const float *__restrict__ x, float *__restrict__ Lout,
                                                        float *__restrict__ out, int R, int K, int D) {
     __shared__ float sl[SM_R][SM_K];
@@ -223,6 +224,21 @@ __global__ __launch_bounds__(256) void groupmax_bwd_kernel(const float *__restri
     for (int v = 0; v < k; ++v) dT[(i * k + v) * Nc + c] = v == am ? dS[i * Nc + c] : 0.f;
 }
 
+// ---- batched small matrix products (SGRAF graph reasoning: n <= 64 nodes, 256-wide similarity vectors):
+//   C[b] (M x N) = op(A[b]) op(B[b]),  op = identity or transpose, all operands row-major and dense per batch item
+__global__ __launch_bounds__(256) void bmm_small_kernel(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M,
+                                                        int N, int K, int ta, int tb) {
+    const int64_t b = blockIdx.y;
+    const float *a = A + b * (int64_t)M * K, *bb = B + b * (int64_t)K * N;
+    float *c = C + b * (int64_t)M * N;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < M * N; e += gridDim.x * 256) {
+        const int m = e / N, n = e % N;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s = fmaf(ta ? a[k * M + m] : a[m * K + k], tb ? bb[n * K + k] : bb[k * N + n], s);
+        c[e] = s;
+    }
+}
+
 }  // namespace itr
 
 #define EW_GRID(n) dim3((unsigned)itr::ceil_div((int64_t)(n), (int64_t)256)), dim3(256), 0, itr::as_stream(stream)
@@ -237,7 +253,7 @@ extern "C" int itr_ew_mul(const float *a, const float *b, float *out, int64_t n,
 }
 
 extern "C" int itr_act_bwd(const float *y, const float *dy, float *dx, int64_t n, int act, itr_stream_t stream) {
-    ITR_REQUIRE(n >= 0 && itr::ceil_div(n, (int64_t)256) <= 0x7fffffff && act >= 1 && act <= 3, "itr_act_bwd: bad size or activation (1 relu, 2 tanh, 3 sigmoid)");
+    ITR_REQUIRE(n >= 0 && itr::ceil_div(n, (int64_t)256) <= 0x7fffffff && act >= 1 && act <= 4, "itr_act_bwd: bad size or activation (1 relu, 2 tanh, 3 sigmoid, 4 leaky_relu(0.1))");
     if (n == 0) return ITR_OK;
     ITR_REQUIRE(y && dy && dx, "itr_act_bwd: null pointer");
     hipLaunchKernelGGL(itr::act_bwd_kernel, EW_GRID(n), y, dy, dx, n, act);
@@ -306,7 +322,7 @@ extern "C" int itr_l2norm_mid_bwd(const float *dz, const float *z, const float *
 }
 
 extern "C" int itr_smry_fwd(const float *smry, const float *x, float *L, float *out, int64_t B, int R, int K, int D, itr_stream_t stream) {
-    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_fwd: at most 64 regions, 16 views, 65535 images");
+    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_fwd: at most 64 rows, 64 columns, 65535 groups");
     if (B == 0) return ITR_OK;
     ITR_REQUIRE(smry && x && L && out, "itr_smry_fwd: null pointer");
     hipLaunchKernelGGL(itr::smry_fwd_kernel, dim3((unsigned)itr::ceil_div(D, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), smry, x, L, out,
@@ -317,7 +333,7 @@ extern "C" int itr_smry_fwd(const float *smry, const float *x, float *L, float *
 
 extern "C" int itr_smry_bwd(const float *x, const float *L, const float *dout, float *dx, float *dsmry, float *scratch, int64_t B, int R, int K,
                             int D, itr_stream_t stream) {
-    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_bwd: at most 64 regions, 16 views, 65535 images");
+    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_bwd: at most 64 rows, 64 columns, 65535 groups");
     if (B == 0) return ITR_OK;
     ITR_REQUIRE(x && L && dout && dx && dsmry && scratch, "itr_smry_bwd: null pointer (scratch: B * R * K floats)");
     ITR_REQUIRE(B * R <= 0x7fffffff, "itr_smry_bwd: too many rows");
@@ -346,5 +362,17 @@ extern "C" int itr_groupmax_bwd(const float *dS, const int32_t *arg, int64_t Ni,
     hipLaunchKernelGGL(itr::groupmax_bwd_kernel, dim3((unsigned)itr::ceil_div(Nc, (int64_t)256), (unsigned)Ni), dim3(256), 0, itr::as_stream(stream), dS,
                        arg, k, Nc, dT);
     ITR_CHECK_LAUNCH("groupmax_bwd");
+    return ITR_OK;
+}
+
+extern "C" int itr_bmm_small(const float *A, const float *B, float *C, int64_t batch, int M, int N, int K, int trans_a, int trans_b,
+                             itr_stream_t stream) {
+    ITR_REQUIRE(batch >= 0 && batch <= 65535 && M >= 1 && N >= 1 && K >= 1, "itr_bmm_small: bad shape (at most 65535 batch items)");
+    if (batch == 0) return ITR_OK;
+    ITR_REQUIRE(A && B && C, "itr_bmm_small: null pointer");
+    const int64_t gq = itr::ceil_div((int64_t)M * N, (int64_t)256);
+    const unsigned gx = (unsigned)(gq < 64 ? gq : 64);
+    hipLaunchKernelGGL(itr::bmm_small_kernel, dim3(gx, (unsigned)batch), dim3(256), 0, itr::as_stream(stream), A, B, C, M, N, K, trans_a, trans_b);
+    ITR_CHECK_LAUNCH("bmm_small");
     return ITR_OK;
 }

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -43,6 +43,7 @@ SIGNATURES = {
     "itr_l2norm_mid_bwd": (i32, [vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "itr_smry_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "itr_smry_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "itr_bmm_small": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "itr_groupmax_fwd": (i32, [vp, i64, i32, i64, vp, vp, vp]),
     "itr_groupmax_bwd": (i32, [vp, vp, i64, i32, i64, vp, vp]),
     "itr_gcn_relation": (i32, [vp, i64, vp, i64, i64, i32, i32, vp]),

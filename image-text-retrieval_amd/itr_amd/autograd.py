@@ -618,7 +618,7 @@ def mul(a, b):
     return _Mul.apply(a, b)
 
 
-_ACT_CODE = {'relu': 1, 'tanh': 2, 'sigmoid': 3}
+_ACT_CODE = {'relu': 1, 'tanh': 2, 'sigmoid': 3, 'leaky_relu': 4}
 
 
 class _Act(torch.autograd.Function):
@@ -769,6 +769,38 @@ class _Smry(torch.autograd.Function):
 
 def summarize(smry, x):
     return _Smry.apply(smry, x)
+
+
+def _bmm(A, B, ta, tb, M, N, K):
+    lib = _lib.load()
+    out = _f32(A.shape[0], M, N, dev=A.device)
+    _lib.check(lib.itr_bmm_small(_p(A), _p(B), _p(out), A.shape[0], M, N, K, int(ta), int(tb), _stream()))
+    return out
+
+
+class _BmmNT(torch.autograd.Function):
+    """C[b] = A[b] B[b]^T for small operands: A [Bn, M, K], B [Bn, N, K] -> [Bn, M, N]  (torch.bmm(q, k.permute(0, 2, 1)))."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        A, B = _dev(A, name="A"), _dev(B, name="B")
+        if A.dim() != 3 or B.dim() != 3 or A.shape[0] != B.shape[0] or A.shape[2] != B.shape[2]:
+            raise ValueError("bmm_nt: A %s vs B %s" % (tuple(A.shape), tuple(B.shape)))
+        ctx.save_for_backward(A, B)
+        return _bmm(A, B, 0, 1, A.shape[1], B.shape[1], A.shape[2])
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        dC = dC.contiguous()
+        M, N, K = A.shape[1], B.shape[1], A.shape[2]
+        dA = _bmm(dC, B, 0, 0, M, K, N)            # dC [M, N] . B [N, K]
+        dB = _bmm(dC, A, 1, 0, N, K, M)            # dC^T [N, M] . A [M, K]
+        return dA, dB
+
+
+def bmm_nt(A, B):
+    return _BmmNT.apply(A, B)
 
 
 class _GroupMax(torch.autograd.Function):

@@ -103,6 +103,102 @@ class EncoderSimilarity(nn.Module):
         return ops.sgraf_scores(img_emb, words, plan, self.state_dict(), self.module_name, self.sgr_step)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Training-mode forward of EncoderSimilarity on the autograd tape (SGRAF.train_emb).  Unlike the fused evaluation kernels
+# (csrc/sgraf*.hip) this follows the reference's own structure -- a loop over the captions of the batch (Fusionmodule.py:415-447)
+# -- because training mode is per-caption by construction: TextSA and AttentionFiltration see one caption at a time, and
+# AttentionFiltration's BatchNorm1d(1) takes its batch statistics (and updates its running statistics) once per caption.
+# Every dense contraction is a HIP kernel (MFMA GEMM, the small batched products, the softmax-weighted sums); the remaining
+# elementwise glue of this training-only path ((a - b)^2, the l1 normalisation, concatenations) are torch ops on the tape.
+def _seq_linear(x2d, seq, idx=0):
+    from .. import autograd as ag
+    return ag.linear(x2d, seq[idx].weight, seq[idx].bias)
+
+
+def _sa_train(mod, local, raw_global, seeds, training):
+    """VisualSA / TextSA.forward (Fusionmodule.py:497-512 / :549-564) on local [B, n, D], raw_global [B, D]."""
+    from .. import autograd as ag
+    B, n, D = local.shape
+    le = _seq_linear(local.reshape(B * n, D), mod.embedding_local)
+    ge = _seq_linear(raw_global, mod.embedding_global)
+    if isinstance(mod.embedding_local[1], nn.BatchNorm1d):          # VisualSA: BatchNorm1d(num_region) on (B, 36, D): channel = region
+        bn_l, bn_g = mod.embedding_local[1], mod.embedding_global[1]
+        if training:
+            t = le.view(B, n, D).permute(0, 2, 1).reshape(B * D, n)        # rows = (image, feature), columns = regions
+            le = ag.batch_norm_train(t, bn_l).view(B, D, n).permute(0, 2, 1).reshape(B * n, D)
+            ge = ag.batch_norm_train(ge, bn_g)
+        else:
+            raise NotImplementedError("evaluation mode runs on the fused kernels (EncoderSimilarity.forward)")
+    p = float(mod.embedding_local[-1].p)
+    le = ag.dropout(ag.act(le, 'tanh'), p, seeds, training).view(B, n, D)
+    ge = ag.dropout(ag.act(ge, 'tanh'), p, seeds, training)
+    common = ag.mul(le, ge.unsqueeze(1).expand(B, n, D).contiguous())
+    w = _seq_linear(common.reshape(B * n, D), mod.embedding_common).view(B, n, 1)      # logits over the n rows
+    new_global = ag.summarize(w, local).view(B, D)                                        # softmax over dim=1, weighted sum
+    return ag.l2norm_rows(new_global, eps=1e-8)
+
+
+def _scan_attention_train(cap_i, img_emb, smooth=9.0):
+    """SCAN_attention(cap_i_expand, img_emb, smooth) (Fusionmodule.py:632-664): cap_i [W, D], img_emb [B, 36, D] -> [B, W, D]."""
+    from .. import autograd as ag
+    B, R, D = img_emb.shape
+    W = cap_i.shape[0]
+    attn = ag.cosine_scores(img_emb.reshape(B * R, D), cap_i)                  # (B*36, W): bmm(context, query^T)
+    attn = ag.l2norm_rows(ag.act(attn, 'leaky_relu'), eps=1e-8)                  # LeakyReLU(0.1), l2norm over the words
+    ctx = ag.summarize((attn * smooth).view(B, R, W), img_emb)                   # softmax over the regions, weighted sum
+    return ag.l2norm_rows(ctx, eps=1e-8)                                         # (B, W, D)
+
+
+def _graph_step_train(gr, x):
+    """GraphReasoning.forward (Fusionmodule.py:579-586) on x [B, n, S]."""
+    from .. import autograd as ag
+    B, n, S = x.shape
+    x2 = x.reshape(B * n, S)
+    q = ag.linear(x2, gr.graph_query_w.weight, gr.graph_query_w.bias).view(B, n, S)
+    k = ag.linear(x2, gr.graph_key_w.weight, gr.graph_key_w.bias).view(B, n, S)
+    scores_t = ag.bmm_nt(k, q)                                                   # [b, r, v] = k_r . q_v  (edge logits, transposed)
+    sgr = ag.summarize(scores_t, x)                                              # softmax over r for every query v, times x
+    return ag.act(ag.linear(sgr.reshape(B * n, S), gr.sim_graph_w.weight, gr.sim_graph_w.bias), 'relu').view(B, n, S)
+
+
+def _saf_train(saf, x, training):
+    """AttentionFiltration.forward (Fusionmodule.py:613-618) on x [B, n, S]."""
+    from .. import autograd as ag
+    B, n, S = x.shape
+    a = ag.linear(x.reshape(B * n, S), saf.attn_sim_w.weight, saf.attn_sim_w.bias)       # (B*n, 1)
+    a = ag.batch_norm_train(a, saf.bn) if training else a
+    a = ag.act(a, 'sigmoid').view(B, n)
+    a = a / (a.abs().sum(1, keepdim=True) + 1e-8)                                # l1norm over the nodes
+    sim_saf = (a.unsqueeze(2) * x).sum(1)
+    return ag.l2norm_rows(sim_saf, eps=1e-8)
+
+
+def encoder_similarity_train(sim_enc, img_emb, words, tok_off, lens, seeds, training=True):
+    """EncoderSimilarity.forward in training mode: img_emb [B, 36, D], packed word embeddings words [n_tok, D] with caption c at
+    rows tok_off[c] .. tok_off[c] + lens[c] -> sims [B, n_caption]."""
+    from .. import autograd as ag
+    B = img_emb.shape[0]
+    img_glo = _sa_train(sim_enc.v_global_w, img_emb, ag.mean_mid(img_emb), seeds, training)
+    cols = []
+    for c, n_word in enumerate(lens):
+        o = int(tok_off[c])
+        cap_i = words[o:o + n_word]                                              # (W, D)
+        cap_glo = _sa_train(sim_enc.t_global_w, cap_i.unsqueeze(0), cap_i.mean(0, keepdim=True), seeds, training)     # (1, D)
+        ctx = _scan_attention_train(cap_i, img_emb)                              # (B, W, D)
+        sim_loc = (ctx - cap_i.unsqueeze(0)) ** 2
+        sim_loc = ag.l2norm_rows(ag.linear(sim_loc.reshape(B * n_word, -1), sim_enc.sim_tranloc_w.weight, sim_enc.sim_tranloc_w.bias), eps=1e-8)
+        sim_glo = ag.l2norm_rows(ag.linear((img_glo - cap_glo) ** 2, sim_enc.sim_tranglo_w.weight, sim_enc.sim_tranglo_w.bias), eps=1e-8)
+        sim_emb = torch.cat([sim_glo.unsqueeze(1), sim_loc.view(B, n_word, -1)], 1)            # (B, W + 1, S)
+        if sim_enc.module_name == 'SGR':
+            for gr in sim_enc.SGR_module:
+                sim_emb = _graph_step_train(gr, sim_emb)
+            sim_vec = sim_emb[:, 0, :]
+        else:
+            sim_vec = _saf_train(sim_enc.SAF_module, sim_emb, training)
+        cols.append(ag.act(ag.linear(sim_vec, sim_enc.sim_eval_w.weight, sim_enc.sim_eval_w.bias), 'sigmoid'))
+    return torch.cat(cols, 1)
+
+
 class MultiViewMatching(nn.Module):
     """CAMERA: max over the k views (Fusionmodule.py:670-692)."""
 

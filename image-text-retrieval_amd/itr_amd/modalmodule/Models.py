@@ -6,7 +6,8 @@ train_start / state_dict / load_state_dict.  Towers and losses run on the HIP ke
 GRU family with a pooled or SCAN similarity (VSE++, SCAN) and for SAEM (frozen BERT in training mode, cnn / pooling / trans
 head and the image transformer layer on the tape, live dropout) and CAMERA (AGSA with BatchNorm batch statistics,
 dilated-convolution summarisation, multi-view matching): itr_amd/autograd.py wires the HIP forward / backward kernels into
-torch's tape.  SGRAF training (backward through EncoderSimilarity) is not built.
+torch's tape.  SGRAF trains too: its similarity module runs the reference's per-caption structure on the tape in training
+mode (Fusionmodule.encoder_similarity_train) and the fused kernels in evaluation mode.
 
 Data-parallel training (the reference has none): with torch.distributed initialised and world > 1,
 every rank receives the SAME global batch (loaders share the seed), keeps the strided shard rank::world of it, runs
@@ -111,8 +112,6 @@ class base_module(nn.Module):
         images = self._dev(images)
         captions = self._dev(captions)
         ie, te = self.img_enc, self.txt_enc
-        if getattr(te, 'dropout_p', 0.) > 0:
-            raise NotImplementedError("training-mode dropout on the word embeddings is not built")
         x = ops.mean_mid(images) if pooled_images else images
         img = ag.linear(x, ie._weight(), ie.fc.bias)
         if not ie.no_imgnorm:
@@ -120,7 +119,17 @@ class base_module(nn.Module):
         if getattr(ie, 'use_abs', False):      # order embeddings (ImgEncoder.py:143-145); elementwise glue on the tape
             img = img.abs()
         toks, off, lens, _ = TextEncoder.pack_tokens(captions, lengths)
-        seq = ag.gru_sequence(toks, off, lens, te.embed.weight, dict(te.rnn.named_parameters()), te.use_bi_gru)
+        if getattr(te, 'dropout_p', 0.) > 0 and te.training:
+            # nn.Dropout on the word embeddings (TextEncoder.py:42; SGRAF: p = 0.4): gather the rows on the tape, drop, and feed the
+            # GRU kernels the dropped rows as a dense "embedding table" indexed by arange (the VSRN region-GRU trick)
+            if not hasattr(self, '_seeds'):
+                self._seeds = ag.DropoutSeeds()
+                self._seeds.new_step()
+            emb = ag.dropout(ag.gather_rows(te.embed.weight, toks), te.dropout_p, self._seeds)
+            toks = torch.arange(emb.shape[0], device=emb.device, dtype=torch.int64)
+            seq = ag.gru_sequence(toks, off, lens, emb, dict(te.rnn.named_parameters()), te.use_bi_gru)
+        else:
+            seq = ag.gru_sequence(toks, off, lens, te.embed.weight, dict(te.rnn.named_parameters()), te.use_bi_gru)
         if last_state:
             last = off + ops.h2d(np.asarray(lens, np.int64), off.device) - 1
             seq = ag.gather_rows(seq, last)
@@ -326,6 +335,27 @@ class SGRAF(base_module):
         loss = self.criterion(sims)
         self._log('Loss', loss.item(), sims.size(0))
         return loss
+
+    def train_emb(self, train_data, *args, **kwargs):
+        """One training step (Models.py:524-546): towers and the similarity module on the autograd tape (word-embedding and
+        self-attention dropout live, BatchNorm batch statistics), hinge on the B x B similarity matrix, backward,
+        clip_grad_norm_, Adam.  The similarity module follows the reference's per-caption structure in training mode
+        (Fusionmodule.encoder_similarity_train); evaluation uses the fused kernels."""
+        images, _, _, captions, lengths, _, _, _ = train_data
+        self.Eiters += 1
+        self._log('Eit', self.Eiters)
+        self._log('lr', self.optimizer.param_groups[0]['lr'])
+        if not hasattr(self, '_seeds'):
+            self._seeds = ag.DropoutSeeds()
+        self._seeds.new_step()
+        self.optimizer.zero_grad()
+        with torch.enable_grad():
+            img, words, off, lens = self._train_towers(images, captions, lengths, pooled_images=False, last_state=False)
+            off_host = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            sims = Fusionmodule.encoder_similarity_train(self.sim_enc, img, words, off_host, [int(x) for x in lens], self._seeds,
+                                                         self.sim_enc.training)
+            loss = ops.hinge_loss(sims, self.config['margin'], self.config['max_violation'])
+            self._step(loss, sims.size(0))
 
 
 class SAEM(base_module):

@@ -327,7 +327,7 @@ int itr_bcast_mid(const float *dy, float *dx, int64_t B, int R, int F, float sca
  * the pieces between the dense layers ---------------------------------------------------------------------------------------
  * out = a * b (backward: two more calls). */
 int itr_ew_mul(const float *a, const float *b, float *out, int64_t n, itr_stream_t stream);
-/* dx = dy * act'(.) from the OUTPUT y of the activation: act 1 relu, 2 tanh, 3 sigmoid. */
+/* dx = dy * act'(.) from the OUTPUT y of the activation: act 1 relu, 2 tanh, 3 sigmoid, 4 LeakyReLU(0.1). */
 int itr_act_bwd(const float *y, const float *dy, float *dx, int64_t n, int act, itr_stream_t stream);
 /* GatedQueryAttLayer gate (camera_.py:41-44): q' = q * M[:, :dk], k' = k * M[:, dk:] on [rows, dk] operands, M [rows, 2 dk]. */
 int itr_gate_apply(const float *q, const float *k, const float *M, float *qo, float *ko, int64_t rows, int dk, itr_stream_t stream);
@@ -342,10 +342,16 @@ int itr_bn_train_bwd(const float *dy, const float *x, const float *mean, const f
 int itr_l2norm_mid_fwd(const float *x, float *z, float *norms, int64_t B, int R, int D, float eps, itr_stream_t stream);
 int itr_l2norm_mid_bwd(const float *dz, const float *z, const float *norms, float *dx, int64_t B, int R, int D, float eps,
                        itr_stream_t stream);
-/* Multi-view summarisation (ImgEncoder.py:386-387): L = softmax(smry [B, R, K], dim=1); out [B, K, D] = L^T x.  scratch: B*R*K floats. */
+/* Multi-view summarisation (ImgEncoder.py:386-387): L = softmax(smry [B, R, K], dim=1); out [B, K, D] = L^T x.  scratch: B*R*K floats.
+ * R, K <= 64.  The same contraction is SGRAF's SCAN_attention weighting (K = words, Fusionmodule.py:649-661) and the edge
+ * aggregation of its graph reasoning (R = K = nodes, :581-584). */
 int itr_smry_fwd(const float *smry, const float *x, float *L, float *out, int64_t B, int R, int K, int D, itr_stream_t stream);
 int itr_smry_bwd(const float *x, const float *L, const float *dout, float *dx, float *dsmry, float *scratch, int64_t B, int R, int K,
                  int D, itr_stream_t stream);
+/* C[b] (M x N) = op(A[b]) op(B[b]) for small dense row-major operands, op = identity / transpose (torch.bmm in GraphReasoning,
+ * Fusionmodule.py:582-584, and its backward). */
+int itr_bmm_small(const float *A, const float *B, float *C, int64_t batch, int M, int N, int K, int trans_a, int trans_b,
+                  itr_stream_t stream);
 /* MultiViewMatching (Fusionmodule.py:674-692) on top of the [Ni * k, Nc] view scores: S[i, c] = max_v T[i * k + v, c]. */
 int itr_groupmax_fwd(const float *T, int64_t Ni, int k, int64_t Nc, float *S, int32_t *arg, itr_stream_t stream);
 int itr_groupmax_bwd(const float *dS, const int32_t *arg, int64_t Ni, int k, int64_t Nc, float *dT, itr_stream_t stream);

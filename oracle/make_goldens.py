@@ -958,9 +958,53 @@ def g19():
     save('g19_camera_train', **out)
 
 
+# ------------------------------------------------------------------ G20 SGRAF.train_emb (a14), dropout modules set to p = 0
+def g20():
+    """The reference's own SGRAF.train_emb (Models.py:524-546) run twice on CPU for SAF and SGR.  Its dropout probabilities are
+    hard-coded (0.4 in VisualSA / TextSA / EncoderText) and drawn from torch's generator, so every nn.Dropout of the reference
+    model is switched to p = 0 here (see g18); BatchNorm runs in training mode: batch statistics, running statistics updated
+    (AttentionFiltration's BatchNorm1d(1) once per caption)."""
+    rng = np.random.RandomState(20)
+    out = {}
+    V, F_, D, E, S, B = 60, 24, 32, 16, 16, 6
+    for mod in ('SAF', 'SGR'):
+        cfg = dict(name='SGRAF', img_dim=F_, embed_size=D, no_imgnorm=False, vocab_size=V, word_dim=E, num_layers=1, bi_gru=True,
+                   no_txtnorm=False, sim_dim=S, module_name=mod, sgr_step=3, margin=0.2, measure='cosine', max_violation=True,
+                   learning_rate=2e-3, grad_clip=2.0)
+        with torch.enable_grad():
+            torch.manual_seed(200)
+            model = Models.SGRAF(cfg)
+            for m in list(model.txt_enc.modules()) + list(model.sim_enc.modules()):
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+            if hasattr(model.txt_enc, 'dropout') and not isinstance(model.txt_enc.dropout, torch.nn.Module):
+                model.txt_enc.dropout = 0.0
+            model.train_start()
+            model.logger = evaluation.LogCollector()
+            for which, m in (('img', model.img_enc), ('txt', model.txt_enc), ('sim', model.sim_enc)):
+                for k, v in sd(m).items():
+                    out['%s_w0_%s_%s' % (mod, which, k)] = v
+            for step in (1, 2):
+                feats, ids, lens = _train_batch(rng, B, V, F_)
+                model.train_emb((feats, None, None, ids, lens, list(range(B)), None, None))
+                pre = '%s_s%d_' % (mod, step)
+                out.update({pre + 'feats': feats, pre + 'ids': ids, pre + 'lens': np.array(lens), pre + 'loss': float(model.logger.meters['Loss'].val)})
+                if step == 1:
+                    for which, m in (('img', model.img_enc), ('txt', model.txt_enc), ('sim', model.sim_enc)):
+                        for n, p_ in m.named_parameters():
+                            if p_.grad is not None:
+                                out[pre + 'grad_%s.%s' % (which, n)] = p_.grad.detach().clone()
+                else:
+                    for which, m in (('img', model.img_enc), ('txt', model.txt_enc), ('sim', model.sim_enc)):
+                        for k, v in sd(m).items():
+                            out[pre + '%s_%s' % (which, k)] = v
+            print("   %s: loss %.5f / %.5f" % (mod, out[mod + '_s1_loss'], out[mod + '_s2_loss']))
+    save('g20_sgraf_train', **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20']
     for name in which:
         print("== " + name)
         globals()[name]()

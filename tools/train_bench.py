@@ -15,14 +15,21 @@ from itr_amd.modalmodule import get_model
 from itr_amd.metricmodule.evaluation import LogCollector
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--model", default="SCAN", choices=["SCAN", "VSE_PP"])
+ap.add_argument("--model", default="SCAN", choices=["SCAN", "VSE_PP", "SGRAF", "SAEM", "CAMERA"])
+ap.add_argument("--module", default="SAF", choices=["SAF", "SGR"])
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--steps", type=int, default=10)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-cfg = C.build_config(['with', a.model, 'data_name=coco_precomp', 'bi_gru=True', 'max_violation=True'])
+cfg = C.build_config(['with', a.model, 'data_name=coco_precomp', 'bi_gru=True', 'max_violation=True'] + (['module_name=' + a.module] if a.model == 'SGRAF' else []))
 cfg['vocab_size'] = 11353
 cfg['img_dim'] = 2048        # precomp region features
+BERT = a.model in ('SAEM', 'CAMERA')
+if BERT:
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg_file, ckpt, trans = bench.bert_files(os.path.join("/tmp", "itr_bench_bert"))
+    cfg.update(bert_config_file=cfg_file, init_checkpoint=ckpt, trans_cfg=trans, vocab_size=30522, batch_size=a.batch)
 torch.manual_seed(0)
 model = get_model(cfg)
 model.train_start()
@@ -37,6 +44,17 @@ def batch():
     for b, l in enumerate(lens):
         ids[b, :l] = torch.from_numpy(rng.randint(4, 11353, size=l))
     feats = ops.l2norm(torch.randn(B, 36, 2048, device=dev))
+    if BERT:
+        L = 32
+        bid = torch.from_numpy(rng.randint(1000, 30522, size=(B, L)))
+        mask = torch.zeros(B, L, dtype=torch.long)
+        for b, l in enumerate(lens):
+            mask[b, :l] = 1
+            bid[b, l:] = 0
+        x1y1 = torch.rand(B, 36, 2) * 300
+        boxes = torch.cat([x1y1, x1y1 + 20 + torch.rand(B, 36, 2) * 150], 2)
+        return (feats, boxes.to(dev), torch.tensor([[640., 480.]]).repeat(B, 1).to(dev), bid.to(dev), lens, list(range(B)), mask.to(dev),
+                torch.zeros(B, L, dtype=torch.long, device=dev))
     return (feats, None, None, ids.to(dev), lens, list(range(B)), None, None)
 
 
@@ -51,4 +69,5 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 n_tok = sum(batches[0][4])
 print("%s train_emb  batch %d (%d words): %.2f ms/step  (%.0f pairs/s, %.0f img-cap pairs scored per step); loss %.4f" % (
-    a.model, B, n_tok, dt * 1e3, B * B / dt, B * B, float(model.logger.meters['Loss'].val)))
+    a.model + ("-" + a.module if a.model == 'SGRAF' else ""), B, n_tok, dt * 1e3, B * B / dt, B * B,
+    float(model.logger.meters['Loss' if 'Loss' in model.logger.meters else 'Loss1'].val)))
