@@ -165,7 +165,8 @@ def test_feature_prefetcher_matches_plain_loader(golden, dev, tmp_path):
         dl.FeaturePrefetcher(loader, 'cpu')
 
 
-def test_train_and_test_command_lines(golden, dev, tmp_path):
+@pytest.mark.parametrize("model_name,extra", [("SCAN", []), ("SGRAF", ["module_name=SAF", "sim_dim=16"])])
+def test_train_and_test_command_lines(golden, dev, tmp_path, model_name, extra):
     """`python train.py with SCAN k=v ...` for two short epochs on a toy precomp dataset (training step, validation,
     checkpoints, hparams.yaml), then `python test.py` on the best checkpoint, reference-shaped and --fast."""
     import glob
@@ -187,17 +188,18 @@ def test_train_and_test_command_lines(golden, dev, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg = os.path.join(root, "image-text-retrieval_amd")
     runs = str(tmp_path / 'runs')
-    cmd = [sys.executable, os.path.join(pkg, "train.py"), "with", "SCAN", "data_name=%s" % name, "data_path=%s" % (tmp_path / 'data'),
+    cmd = [sys.executable, os.path.join(pkg, "train.py"), "with", model_name] + extra + ["data_name=%s" % name, "data_path=%s" % (tmp_path / 'data'),
            "vocab_path=%s" % vdir, "save_path=%s" % runs, "num_epochs=2", "batch_size=20", "val_step=7", "log_step=5", "workers=0",
            "img_dim=8", "embed_size=32", "word_dim=16", "bi_gru=True", "max_violation=True", "seed=3", "learning_rate=0.002"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    run_dirs = glob.glob(os.path.join(runs, "SCAN", "toy_3_*"))
+    run_dirs = glob.glob(os.path.join(runs, model_name, "toy_3_*"))
     assert len(run_dirs) == 1
     files = set(os.listdir(run_dirs[0]))
     assert {'hparams.yaml', 'epo0_checkpoint.pth.tar', 'epo1_checkpoint.pth.tar', 'model_best.pth.tar'} <= files
     ck = utils.load_checkpoint(os.path.join(run_dirs[0], 'epo1_checkpoint.pth.tar'))
-    assert ck['epoch'] == 1 and ck['Eiters'] == 2 * 10 and len(ck['model']) == 2 and ck['_config']['vocab_size'] == int(g["vocab_len"])
+    assert ck['epoch'] == 1 and ck['Eiters'] == 2 * 10 and len(ck['model']) == (3 if model_name == 'SGRAF' else 2)
+    assert ck['_config']['vocab_size'] == int(g["vocab_len"])
     best = os.path.join(run_dirs[0], 'model_best.pth.tar')
     for extra in ([], ['--fast']):
         r = subprocess.run([sys.executable, os.path.join(pkg, "test.py"), best, "--split", "test"] + extra, capture_output=True, text=True,
@@ -252,6 +254,26 @@ def test_evalrank_fast_bert_models(golden, dev, tmp_path, model_name):
     fast = evaluation.evalrank_fast(p, split='test')
     for k in ('i2t_ranks', 't2i_ranks', 'i2t_top1', 't2i_top1'):
         assert (np.asarray(slow[k]) == np.asarray(fast[k])).all(), k
+    # ---- one epoch of utils.train_step on the same files: loader 8-tuple -> model.train_emb (word-piece features, boxes for
+    #      CAMERA) -> backward / clip / Adam; the trainable parameters move, the frozen BERT does not, evaluation still runs
+    cfg2 = dict(cfg, val_step=10 ** 9, log_step=10 ** 9)
+    for f in ('ims', 'boxes', 'img_sizes'):
+        np.save(d / ('train_%s.npy' % f), g[f])
+    (d / 'train_caps.txt').write_bytes(bytes(g["caps_blob"]))
+    train_loader, _ = dl.get_precomp_loader(str(d), 'train', cfg2, batch_size=7, shuffle=True, num_workers=0)
+    before = {k: v.detach().clone() for k, v in model.txt_enc.state_dict().items()}
+    img_before = model.img_enc.fc.weight.detach().clone() if hasattr(model.img_enc, 'fc') else model.img_enc.mapping.weight.detach().clone()
+    utils.train_step(cfg2, train_loader, model, 0, None)
+    assert model.Eiters == len(train_loader)
+    after = model.txt_enc.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before if k.startswith('bert.'))
+    assert not torch.equal(before['mapping.weight'], after['mapping.weight'])
+    img_after = model.img_enc.fc.weight if hasattr(model.img_enc, 'fc') else model.img_enc.mapping.weight
+    assert not torch.equal(img_before, img_after) and bool(torch.isfinite(img_after).all())
+    model.val_start()
+    utils.save_checkpoint({'epoch': 1, 'model': model.state_dict(), 'best_rsum': 0.0, 'best_r1': 0.0, '_config': cfg, 'Eiters': model.Eiters}, True,
+                          prefix=save_dir)
+    assert 0.0 <= evaluation.evalrank_fast(p, split='test')['rsum'] <= 600.0
 
 
 @pytest.mark.parametrize("model_name", ["CAMERA", "SAEM"])
