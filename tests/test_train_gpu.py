@@ -304,8 +304,9 @@ def test_vsepp_train_emb_matches_reference_components(golden, dev):
 
 
 def test_untrainable_models_say_so(dev):
-    cfg = C.build_config(['with', 'SGRAF', 'data_name=f30k_precomp'])
-    cfg.update(img_dim=16, embed_size=32, word_dim=8, vocab_size=20, sim_dim=16)
+    """Every wrapper of the reference trains (G15 / G18 / G19 / G20); only VSRN, whose step needs the captioning branch, does not."""
+    cfg = C.build_config(['with', 'VSRN', 'data_name=f30k_precomp'])
+    cfg.update(img_dim=16, embed_size=32, word_dim=8, vocab_size=20)
     model = get_model(cfg)
     assert model.optimizer is not None and model.optimizer.param_groups[0]['lr'] == cfg['learning_rate']
     with pytest.raises(NotImplementedError):
