@@ -2,6 +2,9 @@
 // split into bf16 planes,  x = hi + lo + O(2^-17 |x|):
 //   TERMS = 3   hi.hi + hi.lo + lo.hi   ("bf16x3": dropped terms ~ 2^-17 per product, fp32 accumulation)
 //   TERMS = 1   hi.hi                   (plain bf16 inputs, fp32 accumulation)
+//   TERMS = 4   "fp16x3": fp16 planes of x' = s x (s a power of two from the tensor's absmax, so hi stays normal -- the matrix core
+//               flushes fp16 subnormals), lo stored scaled by 2^11, hi.hi in one accumulator set and hi.lo' + lo'.hi in a second
+//               one, folded back with exact powers of two in the epilogue: 11 + 11 mantissa bits, error at the fp32 rounding level
 // v_mfma_f32_32x32x16_bf16 runs 16x the fp32 MFMA rate, so bf16x3 has a ceiling of 2.5 PF / 3 = 833 TFLOP/s of
 // fp32-equivalent work against 157 for v_mfma_f32_32x32x2_f32.  NOT wired into any default path: the product GEMM
 // (gemm_f32.hip) is exact fp32; this kernel is reported separately and opt-in.
@@ -36,11 +39,45 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict
     out[o + 32] = (uint16_t)rne(v - __uint_as_float(h << 16));
 }
 
+// ---- fp16x3 operand preparation: absmax -> power-of-two scale -> fp16 hi | scaled fp16 lo planes
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    __shared__ float red[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup (16 k same-address atomics cost more than the split itself); non-negative floats order like their bits
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+__device__ __forceinline__ float f16_scale(unsigned absmax_bits) {
+    const float m = __uint_as_float(absmax_bits);
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
+    return ldexpf(1.f, 14 - ilogbf(m));                                    // m * s in [2^14, 2^15): far from 65 504, tiny values stay normal
+}
+__global__ __launch_bounds__(256) void split_f16_kernel(const float *__restrict__ x, uint16_t *__restrict__ out, int64_t n,
+                                                        const unsigned *__restrict__ absmax, float *__restrict__ inv_scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float s = f16_scale(*absmax);
+    if (i == 0) *inv_scale = 1.f / s;
+    if (i >= n) return;
+    const float xs = x[i] * s;
+    const _Float16 hh = (_Float16)xs;
+    const _Float16 ll = (_Float16)((xs - (float)hh) * 2048.f);
+    const int64_t o = (i >> 5) * 64 + (i & 31);
+    out[o] = __builtin_bit_cast(uint16_t, hh);
+    out[o + 32] = __builtin_bit_cast(uint16_t, ll);
+}
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
 template <int TERMS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ B,
                                                            const float *__restrict__ bias, float *__restrict__ C, int64_t ldc,
                                                            int64_t M, int64_t N, int K, int64_t lda, int64_t ldb, int act,
-                                                           int tiles_m, int tiles_n) {
+                                                           int tiles_m, int tiles_n, const float *__restrict__ inv_sa,
+                                                           const float *__restrict__ inv_sb) {
+    constexpr bool F16 = TERMS == 4, SPLIT = TERMS >= 3;
     __shared__ __attribute__((aligned(16))) char lds[4 * GB_PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -62,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t *__res
     // global -> register staging: thread = (row r, 16-byte granule gq of the 64-byte chunk row); rows r and r + 64
     // TERMS == 3: 8 lanes cover the whole 128-byte line of one row chunk (granule p: hi for p < 4, lo otherwise), 32 rows per
     // pass, 4 passes per operand.  TERMS == 1: only the hi half is needed -- 4 lanes per row, 64 rows per pass, 2 passes.
-    constexpr int LPR = TERMS == 3 ? 8 : 4, PASS = TERMS == 3 ? 4 : 2, RPP = 256 / LPR;
+    constexpr int LPR = SPLIT ? 8 : 4, PASS = SPLIT ? 4 : 2, RPP = 256 / LPR;
     const int r = tid / LPR, p = tid % LPR;
     int64_t ga[PASS], gb[PASS];
     unsigned la[PASS];
@@ -81,13 +118,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t *__res
             sb[i] = *reinterpret_cast<const u32x4 *>(B + gb[i] + ko);                                \
         }                                                                                            \
     }
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], acx[2][2];             // acx: the scaled cross terms of fp16x3 (unused otherwise)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+            for (int v = 0; v < 16; ++v) { acc[i][j][v] = 0.f; acx[i][j][v] = 0.f; }
 
     // fragment addresses: lane -> (row lane & 31, k group lane >> 5) of a 32-row tile; planes Ah | Al | Bh | Bl
     const unsigned fa = (unsigned)(wm * 64 + (lane & 31)) * GB_ROWB + (lane >> 5) * 16;
@@ -109,21 +146,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t *__res
             for (int i = 0; i < 2; ++i) {
                 ah[i] = *reinterpret_cast<const bf16x8 *>(lds + fa + i * 32 * GB_ROWB + ks * 32);
                 bh[i] = *reinterpret_cast<const bf16x8 *>(lds + 2 * GB_PLANE + fb + i * 32 * GB_ROWB + ks * 32);
-                if (TERMS == 3) {
+                if (SPLIT) {
                     al[i] = *reinterpret_cast<const bf16x8 *>(lds + GB_PLANE + fa + i * 32 * GB_ROWB + ks * 32);
                     bl[i] = *reinterpret_cast<const bf16x8 *>(lds + 3 * GB_PLANE + fb + i * 32 * GB_ROWB + ks * 32);
                 }
             }
+#define GB_H(v) __builtin_bit_cast(f16x8, (v))
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (TERMS == 3) {       // small terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if constexpr (F16) {
+                        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(GB_H(al[i]), GB_H(bh[j]), acx[i][j], 0, 0, 0);
+                        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(GB_H(ah[i]), GB_H(bl[j]), acx[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(GB_H(ah[i]), GB_H(bh[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        if (TERMS == 3) {       // small terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
+#undef GB_H
         }
         __syncthreads();
     }
@@ -136,10 +181,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t *__res
             const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
             if (col >= N) continue;
             const float bv = bias ? bias[col] : 0.f;
+            const float unscale = F16 ? *inv_sa * *inv_sb : 1.f;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int64_t row = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-                if (row < M) C[row * ldc + col] = apply_act(acc[i][j][v] + bv, act);
+                const float r = F16 ? (acc[i][j][v] + acx[i][j][v] * (1.f / 2048.f)) * unscale : acc[i][j][v];
+                if (row < M) C[row * ldc + col] = apply_act(r + bv, act);
             }
         }
 }
@@ -172,10 +219,45 @@ extern "C" int itr_gemm_nt_bf16(const uint16_t *A, int64_t lda, const uint16_t *
     const dim3 grid((unsigned)(tm * tn));
     if (terms == 3)
         hipLaunchKernelGGL(itr::gemm_bf16_kernel<3>, grid, dim3(256), 0, itr::as_stream(stream), A, B, bias, C, ldc, M, N, (int)K, lda, ldb,
-                           act, (int)tm, (int)tn);
+                           act, (int)tm, (int)tn, (const float *)nullptr, (const float *)nullptr);
     else
         hipLaunchKernelGGL(itr::gemm_bf16_kernel<1>, grid, dim3(256), 0, itr::as_stream(stream), A, B, bias, C, ldc, M, N, (int)K, lda, ldb,
-                           act, (int)tm, (int)tn);
+                           act, (int)tm, (int)tn, (const float *)nullptr, (const float *)nullptr);
     ITR_CHECK_LAUNCH("gemm_bf16");
+    return ITR_OK;
+}
+
+extern "C" int itr_split_f16(const float *x, uint16_t *out, float *scale_state, int64_t rows, int64_t K, itr_stream_t stream) {
+    ITR_REQUIRE(rows >= 0 && K >= 32 && K % 32 == 0, "itr_split_f16: K must be a positive multiple of 32");
+    ITR_REQUIRE(scale_state, "itr_split_f16: scale_state (2 floats: absmax bits, 1 / scale) missing");
+    if (rows == 0) return ITR_OK;
+    ITR_REQUIRE(x && out, "itr_split_f16: null pointer");
+    const int64_t n = rows * K;
+    ITR_REQUIRE(itr::ceil_div(n, (int64_t)256) <= 0x7fffffff, "itr_split_f16: too many elements for one call");
+    ITR_CHECK_HIP(hipMemsetAsync(scale_state, 0, 4, itr::as_stream(stream)));
+    const int64_t gb = itr::ceil_div(n, (int64_t)256);
+    hipLaunchKernelGGL(itr::absmax_kernel, dim3((unsigned)(gb < 1024 ? gb : 1024)), dim3(256), 0, itr::as_stream(stream), x, n,
+                       reinterpret_cast<unsigned *>(scale_state));
+    hipLaunchKernelGGL(itr::split_f16_kernel, dim3((unsigned)gb), dim3(256), 0, itr::as_stream(stream), x, out, n,
+                       reinterpret_cast<const unsigned *>(scale_state), scale_state + 1);
+    ITR_CHECK_LAUNCH("split_f16");
+    return ITR_OK;
+}
+
+extern "C" int itr_gemm_nt_f16x3(const uint16_t *A, int64_t lda, const float *scale_state_a, const uint16_t *B, int64_t ldb,
+                                 const float *scale_state_b, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
+                                 itr_stream_t stream) {
+    ITR_REQUIRE(M >= 0 && N >= 0 && K >= 32 && K % 32 == 0 && K <= 0x3fffffff, "itr_gemm_nt_f16x3: K must be a positive multiple of 32");
+    if (M == 0 || N == 0) return ITR_OK;
+    ITR_REQUIRE(A && B && C && scale_state_a && scale_state_b, "itr_gemm_nt_f16x3: null pointer");
+    ITR_REQUIRE(ldc >= N && lda >= 64 && ldb >= 64 && lda % 64 == 0 && ldb % 64 == 0,
+                "itr_gemm_nt_f16x3: ldc >= N; lda / ldb count interleaved fp16 elements (2 x the fp32 stride), multiples of 64");
+    ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt_f16x3: unknown activation");
+    ITR_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0, "itr_gemm_nt_f16x3: operands must be 16-byte aligned");
+    const int64_t tm = itr::ceil_div(M, (int64_t)itr::GB_T), tn = itr::ceil_div(N, (int64_t)itr::GB_T);
+    ITR_REQUIRE(tm * tn <= 0x7fffffff, "itr_gemm_nt_f16x3: too many tiles");
+    hipLaunchKernelGGL(itr::gemm_bf16_kernel<4>, dim3((unsigned)(tm * tn)), dim3(256), 0, itr::as_stream(stream), A, B, bias, C, ldc, M, N, (int)K,
+                       lda, ldb, act, (int)tm, (int)tn, scale_state_a + 1, scale_state_b + 1);
+    ITR_CHECK_LAUNCH("gemm_f16x3");
     return ITR_OK;
 }

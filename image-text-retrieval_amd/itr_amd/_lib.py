@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -23,6 +23,8 @@ SIGNATURES = {
     "itr_l2norm_rows": (i32, [vp, vp, i64, i32, f32, i32, i32, vp]),
     "itr_mean_mid": (i32, [vp, vp, i64, i32, i32, vp]),
     "itr_split_bf16": (i32, [vp, vp, i64, i64, vp]),
+    "itr_split_f16": (i32, [vp, vp, vp, i64, i64, vp]),
+    "itr_gemm_nt_f16x3": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, i64, i64, i64, i32, vp]),
     "itr_gemm_nt_bf16": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, vp]),
     "itr_dropout": (i32, [vp, vp, i64, f32, u64, u64, vp]),
     "itr_add_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]),

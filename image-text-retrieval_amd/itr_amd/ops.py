@@ -95,6 +95,7 @@ def mean_mid(x):
 # STUDY switch: ITR_GEMM_BF16X3=1 routes the plain tower / score GEMMs (linear, linear_strided,
 # cosine_scores) through the split-bf16 kernel (terms = 3, ~1e-6 of fp32).  Default off: the product GEMM is exact fp32.
 BF16X3 = os.environ.get("ITR_GEMM_BF16X3") == "1"
+FP16X3 = os.environ.get("ITR_GEMM_FP16X3") == "1"      # the fp16-plane variant: fp32-rounding-level error, same speed
 
 
 def _weight_planes(w):
@@ -116,6 +117,9 @@ def linear(x, weight, bias=None, act=None):
     N = weight.shape[0]
     b = _dev(bias, name="bias") if bias is not None else None
     out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+    if FP16X3 and M and N and K % 32 == 0:
+        gemm_nt_f16x3(split_f16(x.reshape(M, K)), split_f16(weight), b, act, out=out.view(M, N))
+        return out
     if BF16X3 and M and N and K % 32 == 0:
         gemm_nt_bf16(split_bf16(x.reshape(M, K)), _weight_planes(weight), b, 3, act, out=out.view(M, N))
         return out
@@ -137,6 +141,8 @@ def linear_strided(base, lda, M, K, weight, bias=None, act=None, out=None):
     b = _dev(bias, name="bias") if bias is not None else None
     if out is None:
         out = torch.empty(M, N, device=base.device, dtype=torch.float32)
+    if FP16X3 and M and N and K % 32 == 0 and lda % 32 == 0:
+        return gemm_nt_f16x3(split_f16(base), split_f16(weight), b, act, M=M, K=K, lda=lda, out=out)
     if BF16X3 and M and N and K % 32 == 0 and lda % 32 == 0:
         return gemm_nt_bf16(split_bf16(base), _weight_planes(weight), b, 3, act, M=M, K=K, lda=lda, out=out)
     _lib.check(lib.itr_gemm_nt(_p(base), lda, _p(weight), K, _p(b), _p(out), out.stride(0), M, N, K, _ACTS[act], _stream()))
@@ -166,6 +172,8 @@ def cosine_scores(im, s):
     s = _dev(s, name="s")
     if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
         raise ValueError("cosine_scores: expected (Ni, D) and (Nc, D), got %s and %s" % (tuple(im.shape), tuple(s.shape)))
+    if FP16X3 and im.shape[0] and s.shape[0] and im.shape[1] % 32 == 0:
+        return gemm_nt_f16x3(split_f16(im), split_f16(s), None)
     if BF16X3 and im.shape[0] and s.shape[0] and im.shape[1] % 32 == 0:
         return gemm_nt_bf16(split_bf16(im), split_bf16(s), None, 3)
     S = torch.empty(im.shape[0], s.shape[0], device=im.device, dtype=torch.float32)
@@ -208,6 +216,37 @@ def gemm_nt_bf16(a_il, b_il, bias=None, terms=3, act=None, M=None, K=None, lda=N
         out = torch.empty(M, N, device=a_il.device, dtype=torch.float32)
     _lib.check(lib.itr_gemm_nt_bf16(_p(a_il), 2 * lda, _p(b_il), b_il.shape[1], _p(b), _p(out), out.stride(0), M, N, K,
                                     _ACTS[act], int(terms), _stream()))
+    return out
+
+
+def split_f16(x):
+    """fp32 [..., K] -> (fp16x3 operand [rows, 2 K] int16, scale_state [2] float32 on the device): per row and 32-wide chunk 32 hi then
+    32 scaled-lo fp16 values of x * s, s = the power of two that puts the tensor's absmax in [2^14, 2^15)."""
+    lib = _lib.load()
+    x = _dev(x, name="x")
+    K = x.shape[-1]
+    rows = x.numel() // K if K else 0
+    out = torch.empty(rows, 2 * K, device=x.device, dtype=torch.int16)
+    state = torch.empty(2, device=x.device, dtype=torch.float32)
+    _lib.check(lib.itr_split_f16(_p(x), _p(out), _p(state), rows, K, _stream()))
+    return out, state
+
+
+def gemm_nt_f16x3(a, b, bias=None, act=None, M=None, K=None, lda=None, out=None):
+    """STUDY / opt-in: A B^T from split_f16 operands on the fp16 matrix core, fp32 accumulation, error at the fp32
+    rounding level.  M, K, lda (fp32 elements) describe strided / overlapping rows of a flat operand (linear_strided)."""
+    lib = _lib.load()
+    (a_il, sa), (b_il, sb) = a, b
+    if b_il.dim() != 2 or (M is None and (a_il.dim() != 2 or a_il.shape[1] != b_il.shape[1])) or (K is not None and 2 * K != b_il.shape[1]):
+        raise ValueError("gemm_nt_f16x3: A %s vs B %s" % (tuple(a_il.shape), tuple(b_il.shape)))
+    if M is None:
+        M, K, lda = a_il.shape[0], a_il.shape[1] // 2, a_il.shape[1] // 2
+    N = b_il.shape[0]
+    bb = _dev(bias, name="bias") if bias is not None else None
+    if out is None:
+        out = torch.empty(M, N, device=a_il.device, dtype=torch.float32)
+    _lib.check(lib.itr_gemm_nt_f16x3(_p(a_il), 2 * lda, _p(sa), _p(b_il), b_il.shape[1], _p(sb), _p(bb), _p(out), out.stride(0), M, N, K,
+                                     _ACTS[act], _stream()))
     return out
 
 

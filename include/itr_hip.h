@@ -91,6 +91,16 @@ int itr_split_bf16(const float *x, uint16_t *out, int64_t rows, int64_t K, itr_s
 int itr_gemm_nt_bf16(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb, const float *bias, float *C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, int act, int terms, itr_stream_t stream);
 
+/* "fp16x3" variant of the study GEMM: fp16 planes (11 + 11 mantissa bits) of x' = s x with s the power of two that puts the
+ * tensor's absmax in [2^14, 2^15) (the matrix core flushes fp16 subnormals, so hi must stay normal), lo scaled by 2^11, cross
+ * terms in a second accumulator set, everything folded back with exact powers of two: error at the fp32 rounding level for
+ * ANY finite operands.  itr_split_f16 computes absmax and the planes; scale_state (2 floats, device) receives the absmax
+ * bits and 1 / s and is handed to the GEMM.  Same operand layout as itr_split_bf16. */
+int itr_split_f16(const float *x, uint16_t *out, float *scale_state, int64_t rows, int64_t K, itr_stream_t stream);
+int itr_gemm_nt_f16x3(const uint16_t *A, int64_t lda, const float *scale_state_a, const uint16_t *B, int64_t ldb,
+                      const float *scale_state_b, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
+                      itr_stream_t stream);
+
 /* ---- a2: EncoderImagePrecomp.forward (itr/modalmodule/ImgEncoder.py:133-147) -----------
  * out[rows, D] = l2norm(x[rows, F] * W[D, F]^T + b[D]) [abs]; rows = n_img * n_regions.
  * no_imgnorm / use_abs as in the reference constructor. */

@@ -84,3 +84,36 @@ def test_gemm_bf16x3_overlapping_rows_and_env_switch(dev):
     assert (y - ops.linear(x, w2 / 2.0, b2, act='gelu')).abs().max().item() <= tol and y.shape == (5, 7, 33)
     assert (s - ops.cosine_scores(base, base[:9].contiguous())).abs().max().item() <= tol
     assert (y2 - ops.linear(x, w2, b2)).abs().max().item() <= 2 * tol
+
+
+@pytest.mark.parametrize("M,N,K,scale", [(200, 77, 64, 1.0), (300, 513, 1024, 1.0), (130, 140, 96, 3000.0), (64, 64, 32, 1e-6)])
+def test_gemm_f16x3_fp32_level_accuracy(dev, M, N, K, scale):
+    """fp16 planes with absmax scaling: error at the fp32 rounding level for operands of any magnitude (no fp16 overflow, no flushed
+    subnormals), compared with the bf16x3 bound of 4e-6 and with the exact fp32 GEMM."""
+    torch.manual_seed(M + K)
+    a = torch.randn(M, K) * scale * (1.0 + torch.arange(M).float()[:, None] / M)
+    b = torch.randn(N, K) * (0.5 + torch.arange(N).float()[:, None] / N)
+    a[0, :5] = torch.tensor([1e-12, -3e-9, 7e-7, 0.0, 2e-15]) * scale           # tiny components next to large ones
+    bias = torch.randn(N) * scale
+    want = a.double() @ b.double().t() + bias.double()
+    nat = (a.abs().double() @ b.abs().double().t())
+    got = ops.gemm_nt_f16x3(ops.split_f16(a.to(dev)), ops.split_f16(b.to(dev)), bias.to(dev)).cpu().double()
+    fp32 = ops.linear(a.to(dev), b.to(dev), bias.to(dev)).cpu().double()
+    e16, e32 = ((got - want).abs() / nat).max().item(), ((fp32 - want).abs() / nat).max().item()
+    assert bool(torch.isfinite(got).all())
+    assert e16 <= 1e-6 and e16 <= 8 * e32 + 3e-7, (e16, e32)       # (bf16x3: 4e-6)
+    act = ops.gemm_nt_f16x3(ops.split_f16(a.to(dev)), ops.split_f16(b.to(dev)), bias.to(dev), act='tanh').cpu().double()
+    assert (act - torch.tanh(want)).abs().max().item() <= 1e-6 * max(1.0, nat.max().item())      # tanh is 1-Lipschitz
+
+
+def test_fp16x3_env_switch(dev):
+    torch.manual_seed(8)
+    x, w, b = torch.randn(5, 7, 64, device=dev) * 30, torch.randn(33, 64, device=dev) * 0.05, torch.randn(33, device=dev)
+    want = ops.linear(x, w, b, act='gelu')
+    ops.FP16X3 = True
+    try:
+        got = ops.linear(x, w, b, act='gelu')
+        s = ops.cosine_scores(w, w[:9].contiguous())
+    finally:
+        ops.FP16X3 = False
+    assert (got - want).abs().max().item() <= 2e-5 and (s - ops.cosine_scores(w, w[:9].contiguous())).abs().max().item() <= 1e-7

@@ -46,13 +46,14 @@ def timed():
 
 ops.BF16X3 = False
 S0, r0, t0 = timed()
-ops.BF16X3 = True
+which = os.environ.get("STUDY_VARIANT", "bf16x3")          # or fp16x3
+setattr(ops, "FP16X3" if which == "fp16x3" else "BF16X3", True)
 S1, r1, t1 = timed()
 d = (S1 - S0).abs()
 agree_i = float((np.asarray(r0[0]) == np.asarray(r1[0])).mean())
 agree_t = float((np.asarray(r0[2]) == np.asarray(r1[2])).mean())
 rec0 = ops.recall_from_ranks(r0[0])[:3] + ops.recall_from_ranks(r0[2])[:3]
 rec1 = ops.recall_from_ranks(r1[0])[:3] + ops.recall_from_ranks(r1[2])[:3]
-print("%s %d x %d: fp32 %.1f ms, bf16x3 %.1f ms (x%.2f); max|dS| %.2e mean|dS| %.2e (|S| max %.3f); identical ranks i2t %.2f%% t2i %.2f%%; "
-      "max |dRecall@K| %.3f" % (kind, n_img, n_cap, t0 * 1e3, t1 * 1e3, t0 / t1, d.max().item(), d.mean().item(), S0.abs().max().item(),
+print(("%s %d x %d: fp32 %.1f ms, " + which + " %.1f ms (x%.2f); max|dS| %.2e mean|dS| %.2e (|S| max %.3f); identical ranks i2t %.2f%% t2i %.2f%%; "
+      "max |dRecall@K| %.3f") % (kind, n_img, n_cap, t0 * 1e3, t1 * 1e3, t0 / t1, d.max().item(), d.mean().item(), S0.abs().max().item(),
                                100 * agree_i, 100 * agree_t, max(abs(a - b) for a, b in zip(rec0, rec1))))

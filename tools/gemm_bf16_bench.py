@@ -39,6 +39,9 @@ for name, M, N, K in shapes:
     t3 = timed(lambda: ops.gemm_nt_bf16(pa, pb, terms=3))
     t1 = timed(lambda: ops.gemm_nt_bf16(pa, pb, terms=1))
     ts = timed(lambda: (ops.split_bf16(a), ops.split_bf16(b)))
+    qa, qb = ops.split_f16(a), ops.split_f16(b)
+    t16 = timed(lambda: ops.gemm_nt_f16x3(qa, qb))
+    ts16 = timed(lambda: (ops.split_f16(a), ops.split_f16(b)))
     ref = ops.linear(a, b)
     e3 = (ops.gemm_nt_bf16(pa, pb, terms=3) - ref).abs().max().item()
     e1 = (ops.gemm_nt_bf16(pa, pb, terms=1) - ref).abs().max().item()
@@ -48,6 +51,8 @@ for name, M, N, K in shapes:
     w64 = a[rows].double() @ b[cols].double().t()
     e32_64 = (ref[rows][:, cols].double() - w64).abs().max().item()
     e3_64 = (ops.gemm_nt_bf16(pa, pb, terms=3)[rows][:, cols].double() - w64).abs().max().item()
+    e16_64 = (ops.gemm_nt_f16x3(qa, qb)[rows][:, cols].double() - w64).abs().max().item()
+    print("   fp16x3 %7.2f ms %6.1f TF/s (x%.2f vs fp32), split %.2f ms, max|d| vs fp64 %.1e" % (t16 * 1e3, flop / t16 / 1e12, t32 / t16, ts16 * 1e3, e16_64))
     print("%s | fp32 %7.2f ms %6.1f TF/s | bf16x3 %7.2f ms %6.1f TF/s (x%.2f) | bf16 %7.2f ms %6.1f TF/s | split %.2f ms | "
           "max|d| vs fp64 (unit rows): fp32 %.1e, bf16x3 %.1e; vs fp32: bf16x3 %.1e, bf16 %.1e"
           % (name, t32 * 1e3, flop / t32 / 1e12, t3 * 1e3, flop / t3 / 1e12, t32 / t3, t1 * 1e3, flop / t1 / 1e12, ts * 1e3,
