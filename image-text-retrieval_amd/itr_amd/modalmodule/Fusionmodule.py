@@ -138,15 +138,17 @@ def _sa_train(mod, local, raw_global, seeds, training):
     return ag.l2norm_rows(new_global, eps=1e-8)
 
 
-def _scan_attention_train(cap_i, img_emb, smooth=9.0):
-    """SCAN_attention(cap_i_expand, img_emb, smooth) (Fusionmodule.py:632-664): cap_i [W, D], img_emb [B, 36, D] -> [B, W, D]."""
+def _scan_attention_train(caps, img_emb, smooth=9.0):
+    """SCAN_attention(cap_i_expand, img_emb, smooth) (Fusionmodule.py:632-664) for a GROUP of G captions of the same length:
+    caps [G, W, D], img_emb [B, 36, D] -> [G*B, W, D] (caption-major)."""
     from .. import autograd as ag
     B, R, D = img_emb.shape
-    W = cap_i.shape[0]
-    attn = ag.cosine_scores(img_emb.reshape(B * R, D), cap_i)                  # (B*36, W): bmm(context, query^T)
-    attn = ag.l2norm_rows(ag.act(attn, 'leaky_relu'), eps=1e-8)                  # LeakyReLU(0.1), l2norm over the words
-    ctx = ag.summarize((attn * smooth).view(B, R, W), img_emb)                   # softmax over the regions, weighted sum
-    return ag.l2norm_rows(ctx, eps=1e-8)                                         # (B, W, D)
+    G, W, _ = caps.shape
+    attn = ag.cosine_scores(img_emb.reshape(B * R, D), caps.reshape(G * W, D))       # (B*36, G*W): bmm(context, query^T), one GEMM
+    attn = ag.l2norm_rows(ag.act(attn, 'leaky_relu').view(B * R * G, W), eps=1e-8)      # LeakyReLU(0.1), l2norm over the words of a caption
+    smry = (attn * smooth).view(B, R, G, W).permute(2, 0, 1, 3).reshape(G * B, R, W)   # caption-major copy
+    x = img_emb.unsqueeze(0).expand(G, B, R, D).reshape(G * B, R, D)
+    return ag.l2norm_rows(ag.summarize(smry, x), eps=1e-8)                              # softmax over the regions, weighted sum
 
 
 def _graph_step_train(gr, x):
@@ -161,41 +163,68 @@ def _graph_step_train(gr, x):
     return ag.act(ag.linear(sgr.reshape(B * n, S), gr.sim_graph_w.weight, gr.sim_graph_w.bias), 'relu').view(B, n, S)
 
 
-def _saf_train(saf, x, training):
-    """AttentionFiltration.forward (Fusionmodule.py:613-618) on x [B, n, S]."""
+def _saf_train(saf, x, G, training):
+    """AttentionFiltration.forward (Fusionmodule.py:613-618) on x [G*B, n, S] (caption-major).  The reference calls it once per
+    caption, so its BatchNorm1d(1) normalises with the statistics of ONE caption's B * n logits and updates its running statistics
+    once per caption, in caption order: the G captions become G channels of one column BatchNorm with the shared gamma / beta."""
     from .. import autograd as ag
-    B, n, S = x.shape
-    a = ag.linear(x.reshape(B * n, S), saf.attn_sim_w.weight, saf.attn_sim_w.bias)       # (B*n, 1)
-    a = ag.batch_norm_train(a, saf.bn) if training else a
-    a = ag.act(a, 'sigmoid').view(B, n)
+    GB, n, S = x.shape
+    B = GB // G
+    a = ag.linear(x.reshape(GB * n, S), saf.attn_sim_w.weight, saf.attn_sim_w.bias)       # (G*B*n, 1)
+    if training:
+        bn = saf.bn
+        stats = []
+        t = a.view(G, B * n).t().contiguous()                                             # rows = (image, node), columns = captions
+        y = ag._BatchNormTrain.apply(t, bn.weight.expand(G).contiguous(), bn.bias.expand(G).contiguous(), bn.eps, stats)
+        a = y.t().contiguous().view(GB * n, 1)
+        mean, invstd = stats[0]
+        with torch.no_grad():
+            N = B * n
+            var_u = (1.0 / (invstd * invstd) - bn.eps) * (N / max(N - 1, 1))
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            for gi in range(G):                                                           # sequential momentum updates, caption order
+                bn.running_mean.mul_(1 - mom).add_(mean[gi:gi + 1], alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var_u[gi:gi + 1], alpha=mom)
+            bn.num_batches_tracked += G
+    a = ag.act(a, 'sigmoid').view(GB, n)
     a = a / (a.abs().sum(1, keepdim=True) + 1e-8)                                # l1norm over the nodes
     sim_saf = (a.unsqueeze(2) * x).sum(1)
     return ag.l2norm_rows(sim_saf, eps=1e-8)
 
 
-def encoder_similarity_train(sim_enc, img_emb, words, tok_off, lens, seeds, training=True):
+def encoder_similarity_train(sim_enc, img_emb, words, tok_off, lens, seeds, training=True, max_group=32):
     """EncoderSimilarity.forward in training mode: img_emb [B, 36, D], packed word embeddings words [n_tok, D] with caption c at
-    rows tok_off[c] .. tok_off[c] + lens[c] -> sims [B, n_caption]."""
+    rows tok_off[c] .. tok_off[c] + lens[c] -> sims [B, n_caption].  Consecutive captions of the same length (collate_fn sorts by
+    length) are processed as one group: the arithmetic per caption is the reference's, the launches are shared."""
     from .. import autograd as ag
-    B = img_emb.shape[0]
+    B, R, D = img_emb.shape
     img_glo = _sa_train(sim_enc.v_global_w, img_emb, ag.mean_mid(img_emb), seeds, training)
     cols = []
-    for c, n_word in enumerate(lens):
+    c = 0
+    while c < len(lens):
+        n_word = lens[c]
+        G = 1
+        while c + G < len(lens) and lens[c + G] == n_word and G < max_group and int(tok_off[c + G]) == int(tok_off[c]) + G * n_word:
+            G += 1
         o = int(tok_off[c])
-        cap_i = words[o:o + n_word]                                              # (W, D)
-        cap_glo = _sa_train(sim_enc.t_global_w, cap_i.unsqueeze(0), cap_i.mean(0, keepdim=True), seeds, training)     # (1, D)
-        ctx = _scan_attention_train(cap_i, img_emb)                              # (B, W, D)
-        sim_loc = (ctx - cap_i.unsqueeze(0)) ** 2
-        sim_loc = ag.l2norm_rows(ag.linear(sim_loc.reshape(B * n_word, -1), sim_enc.sim_tranloc_w.weight, sim_enc.sim_tranloc_w.bias), eps=1e-8)
-        sim_glo = ag.l2norm_rows(ag.linear((img_glo - cap_glo) ** 2, sim_enc.sim_tranglo_w.weight, sim_enc.sim_tranglo_w.bias), eps=1e-8)
-        sim_emb = torch.cat([sim_glo.unsqueeze(1), sim_loc.view(B, n_word, -1)], 1)            # (B, W + 1, S)
+        caps = words[o:o + G * n_word].view(G, n_word, D)                        # (G, W, D)
+        cap_glo = _sa_train(sim_enc.t_global_w, caps, caps.mean(1), seeds, training)          # (G, D); TextSA has no BatchNorm
+        ctx = _scan_attention_train(caps, img_emb)                               # (G*B, W, D)
+        cap_exp = caps.unsqueeze(1).expand(G, B, n_word, D).reshape(G * B, n_word, D)
+        sim_loc = (ctx - cap_exp) ** 2
+        sim_loc = ag.l2norm_rows(ag.linear(sim_loc.reshape(G * B * n_word, D), sim_enc.sim_tranloc_w.weight, sim_enc.sim_tranloc_w.bias), eps=1e-8)
+        glo_diff = (img_glo.unsqueeze(0) - cap_glo.unsqueeze(1)).reshape(G * B, D) ** 2
+        sim_glo = ag.l2norm_rows(ag.linear(glo_diff, sim_enc.sim_tranglo_w.weight, sim_enc.sim_tranglo_w.bias), eps=1e-8)
+        sim_emb = torch.cat([sim_glo.unsqueeze(1), sim_loc.view(G * B, n_word, -1)], 1)        # (G*B, W + 1, S)
         if sim_enc.module_name == 'SGR':
             for gr in sim_enc.SGR_module:
                 sim_emb = _graph_step_train(gr, sim_emb)
             sim_vec = sim_emb[:, 0, :]
         else:
-            sim_vec = _saf_train(sim_enc.SAF_module, sim_emb, training)
-        cols.append(ag.act(ag.linear(sim_vec, sim_enc.sim_eval_w.weight, sim_enc.sim_eval_w.bias), 'sigmoid'))
+            sim_vec = _saf_train(sim_enc.SAF_module, sim_emb, G, training)
+        sims = ag.act(ag.linear(sim_vec, sim_enc.sim_eval_w.weight, sim_enc.sim_eval_w.bias), 'sigmoid')     # (G*B, 1)
+        cols.append(sims.view(G, B).t())
+        c += G
     return torch.cat(cols, 1)
 
 
