@@ -1,0 +1,124 @@
+// Training-step primitives of VSRN's captioning branch (itr/modalmodule/Fusionmodule.py:10-367, Objectives.py:138-158): the decoder
+// is a per-step loop (attention over the 36 encoder outputs -> GRU cell -> vocabulary projection -> log-softmax / NLL), so the pieces
+// are single-step kernels; the dense layers are gemm_nt_kernel.
+//   itr_gru_cell_fwd / _bwd     one nn.GRU step from the two projections gi = W_ih x + b_ih, gh = W_hh h + b_hh (gate order r, z, n):
+//                               r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (1 - z) n + z h
+//   itr_nll_logsoftmax_fwd/_bwd F.log_softmax + nn.NLLLoss(reduce=False) * mask per row: loss[b] = -mask[b] log_softmax(logits[b])[target[b]]
+#include "itr_common.h"
+
+namespace itr {
+
+__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const float *__restrict__ gi, const float *__restrict__ gh, const float *__restrict__ h,
+                                                           float *__restrict__ hn, float *__restrict__ gates, int64_t B, int H) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int64_t b = i / H;
+    const int j = (int)(i - b * H);
+    const float *a = gi + b * 3 * H, *c = gh + b * 3 * H;
+    const float r = 1.f / (1.f + expf(-(a[j] + c[j])));
+    const float z = 1.f / (1.f + expf(-(a[H + j] + c[H + j])));
+    const float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+    hn[i] = (1.f - z) * n + z * h[i];
+    gates[b * 3 * H + j] = r;
+    gates[b * 3 * H + H + j] = z;
+    gates[b * 3 * H + 2 * H + j] = n;
+}
+
+__global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float *__restrict__ dhn, const float *__restrict__ gates,
+                                                           const float *__restrict__ gh, const float *__restrict__ h, float *__restrict__ dgi,
+                                                           float *__restrict__ dgh, float *__restrict__ dh, int64_t B, int H) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int64_t b = i / H;
+    const int j = (int)(i - b * H);
+    const float r = gates[b * 3 * H + j], z = gates[b * 3 * H + H + j], n = gates[b * 3 * H + 2 * H + j];
+    const float g = dhn[i];
+    const float dn_pre = g * (1.f - z) * (1.f - n * n);
+    const float dz_pre = g * (h[i] - n) * z * (1.f - z);
+    const float dr_pre = dn_pre * gh[b * 3 * H + 2 * H + j] * r * (1.f - r);
+    dgi[b * 3 * H + j] = dr_pre; dgi[b * 3 * H + H + j] = dz_pre; dgi[b * 3 * H + 2 * H + j] = dn_pre;
+    dgh[b * 3 * H + j] = dr_pre; dgh[b * 3 * H + H + j] = dz_pre; dgh[b * 3 * H + 2 * H + j] = dn_pre * r;
+    dh[i] = g * z;
+}
+
+// one workgroup per row
+__global__ __launch_bounds__(256) void nll_logsoftmax_fwd_kernel(const float *__restrict__ logits, const int64_t *__restrict__ target,
+                                                                 const float *__restrict__ mask, float *__restrict__ loss, float *__restrict__ lse,
+                                                                 int V) {
+    __shared__ float red[4];
+    const int64_t b = blockIdx.x;
+    const float *x = logits + b * V;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) m = fmaxf(m, x[v]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) s += expf(x[v] - m);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l = m + logf(red[0] + red[1] + red[2] + red[3]);
+        lse[b] = l;
+        const int64_t t = target[b];
+        loss[b] = (t >= 0 && t < V) ? -(x[t] - l) * mask[b] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void nll_logsoftmax_bwd_kernel(const float *__restrict__ logits, const int64_t *__restrict__ target,
+                                                                 const float *__restrict__ mask, const float *__restrict__ lse,
+                                                                 const float *__restrict__ dloss, float *__restrict__ dlogits, int V) {
+    const int64_t b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float g = dloss[b] * mask[b];
+    dlogits[b * V + v] = g * (expf(logits[b * V + v] - lse[b]) - (v == target[b] ? 1.f : 0.f));
+}
+
+}  // namespace itr
+
+extern "C" int itr_gru_cell_fwd(const float *gi, const float *gh, const float *h, float *h_next, float *gates, int64_t B, int H,
+                                itr_stream_t stream) {
+    ITR_REQUIRE(B >= 0 && H >= 1, "itr_gru_cell_fwd: bad shape");
+    if (B == 0) return ITR_OK;
+    ITR_REQUIRE(gi && gh && h && h_next && gates, "itr_gru_cell_fwd: null pointer");
+    hipLaunchKernelGGL(itr::gru_cell_fwd_kernel, dim3((unsigned)itr::ceil_div(B * H, (int64_t)256)), dim3(256), 0, itr::as_stream(stream), gi, gh, h,
+                       h_next, gates, B, H);
+    ITR_CHECK_LAUNCH("gru_cell_fwd");
+    return ITR_OK;
+}
+
+extern "C" int itr_gru_cell_bwd(const float *dh_next, const float *gates, const float *gh, const float *h, float *dgi, float *dgh, float *dh,
+                                int64_t B, int H, itr_stream_t stream) {
+    ITR_REQUIRE(B >= 0 && H >= 1, "itr_gru_cell_bwd: bad shape");
+    if (B == 0) return ITR_OK;
+    ITR_REQUIRE(dh_next && gates && gh && h && dgi && dgh && dh, "itr_gru_cell_bwd: null pointer");
+    hipLaunchKernelGGL(itr::gru_cell_bwd_kernel, dim3((unsigned)itr::ceil_div(B * H, (int64_t)256)), dim3(256), 0, itr::as_stream(stream), dh_next,
+                       gates, gh, h, dgi, dgh, dh, B, H);
+    ITR_CHECK_LAUNCH("gru_cell_bwd");
+    return ITR_OK;
+}
+
+extern "C" int itr_nll_logsoftmax_fwd(const float *logits, const int64_t *target, const float *mask, float *loss, float *lse, int64_t B, int V,
+                                      itr_stream_t stream) {
+    ITR_REQUIRE(B >= 0 && B <= 0x7fffffff && V >= 1, "itr_nll_logsoftmax_fwd: bad shape");
+    if (B == 0) return ITR_OK;
+    ITR_REQUIRE(logits && target && mask && loss && lse, "itr_nll_logsoftmax_fwd: null pointer");
+    hipLaunchKernelGGL(itr::nll_logsoftmax_fwd_kernel, dim3((unsigned)B), dim3(256), 0, itr::as_stream(stream), logits, target, mask, loss, lse, V);
+    ITR_CHECK_LAUNCH("nll_logsoftmax_fwd");
+    return ITR_OK;
+}
+
+extern "C" int itr_nll_logsoftmax_bwd(const float *logits, const int64_t *target, const float *mask, const float *lse, const float *dloss,
+                                      float *dlogits, int64_t B, int V, itr_stream_t stream) {
+    ITR_REQUIRE(B >= 0 && B <= 65535 && V >= 1, "itr_nll_logsoftmax_bwd: bad shape (at most 65535 rows)");
+    if (B == 0) return ITR_OK;
+    ITR_REQUIRE(logits && target && mask && lse && dloss && dlogits, "itr_nll_logsoftmax_bwd: null pointer");
+    hipLaunchKernelGGL(itr::nll_logsoftmax_bwd_kernel, dim3((unsigned)itr::ceil_div(V, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), logits,
+                       target, mask, lse, dloss, dlogits, V);
+    ITR_CHECK_LAUNCH("nll_logsoftmax_bwd");
+    return ITR_OK;
+}

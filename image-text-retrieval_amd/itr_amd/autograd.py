@@ -803,6 +803,90 @@ def bmm_nt(A, B):
     return _BmmNT.apply(A, B)
 
 
+class _BmmNN(torch.autograd.Function):
+    """C[b] = A[b] B[b] for small operands: A [Bn, M, K], B [Bn, K, N] -> [Bn, M, N]."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        A, B = _dev(A, name="A"), _dev(B, name="B")
+        if A.dim() != 3 or B.dim() != 3 or A.shape[0] != B.shape[0] or A.shape[2] != B.shape[1]:
+            raise ValueError("bmm_nn: A %s vs B %s" % (tuple(A.shape), tuple(B.shape)))
+        ctx.save_for_backward(A, B)
+        return _bmm(A, B, 0, 0, A.shape[1], B.shape[2], A.shape[2])
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        dC = dC.contiguous()
+        M, K, N = A.shape[1], A.shape[2], B.shape[2]
+        dA = _bmm(dC, B, 0, 1, M, K, N)            # dC [M, N] . B^T [N, K]
+        dB = _bmm(A, dC, 1, 0, K, N, M)            # A^T [K, M] . dC [M, N]
+        return dA, dB
+
+
+def bmm_nn(A, B):
+    return _BmmNN.apply(A, B)
+
+
+class _GruCell(torch.autograd.Function):
+    """One nn.GRU step from the two projections (gate order r, z, n)."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        lib = _lib.load()
+        gi, gh, h = _dev(gi, name="gi"), _dev(gh, name="gh"), _dev(h, name="h")
+        B, H = h.shape
+        hn, gates = torch.empty_like(h), torch.empty_like(gi)
+        _lib.check(lib.itr_gru_cell_fwd(_p(gi), _p(gh), _p(h), _p(hn), _p(gates), B, H, _stream()))
+        ctx.save_for_backward(gates, gh, h)
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        lib = _lib.load()
+        gates, gh, h = ctx.saved_tensors
+        B, H = h.shape
+        dgi, dgh, dh = torch.empty_like(gates), torch.empty_like(gates), torch.empty_like(h)
+        _lib.check(lib.itr_gru_cell_bwd(_p(dhn.contiguous()), _p(gates), _p(gh), _p(h), _p(dgi), _p(dgh), _p(dh), B, H, _stream()))
+        return dgi, dgh, dh
+
+
+def gru_cell(x, h, rnn):
+    """h' = nn.GRU step (single layer, `rnn` supplies weight_ih_l0 / weight_hh_l0 / bias_ih_l0 / bias_hh_l0)."""
+    gi = linear(x, rnn.weight_ih_l0, rnn.bias_ih_l0)
+    gh = linear(h, rnn.weight_hh_l0, rnn.bias_hh_l0)
+    return _GruCell.apply(gi, gh, h)
+
+
+class _NllLogSoftmax(torch.autograd.Function):
+    """-mask[b] * log_softmax(logits[b])[target[b]] per row."""
+
+    @staticmethod
+    def forward(ctx, logits, target, mask):
+        lib = _lib.load()
+        logits = _dev(logits, name="logits")
+        target = _dev(target, torch.int64, "target")
+        mask = _dev(mask.to(torch.float32), name="mask")
+        B, V = logits.shape
+        loss, lse = _f32(B, dev=logits.device), _f32(B, dev=logits.device)
+        _lib.check(lib.itr_nll_logsoftmax_fwd(_p(logits), _p(target), _p(mask), _p(loss), _p(lse), B, V, _stream()))
+        ctx.save_for_backward(logits, target, mask, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        logits, target, mask, lse = ctx.saved_tensors
+        B, V = logits.shape
+        dlogits = torch.empty_like(logits)
+        _lib.check(lib.itr_nll_logsoftmax_bwd(_p(logits), _p(target), _p(mask), _p(lse), _p(dloss.contiguous()), _p(dlogits), B, V, _stream()))
+        return dlogits, None, None
+
+
+def nll_logsoftmax(logits, target, mask):
+    return _NllLogSoftmax.apply(logits, target, mask)
+
+
 class _GroupMax(torch.autograd.Function):
     """max over the k view rows of every image: T [Ni * k, Nc] -> [Ni, Nc]."""
 

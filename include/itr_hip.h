@@ -366,6 +366,19 @@ int itr_bmm_small(const float *A, const float *B, float *C, int64_t batch, int M
 int itr_groupmax_fwd(const float *T, int64_t Ni, int k, int64_t Nc, float *S, int32_t *arg, itr_stream_t stream);
 int itr_groupmax_bwd(const float *dS, const int32_t *arg, int64_t Ni, int k, int64_t Nc, float *dT, itr_stream_t stream);
 
+/* ---- VSRN captioning branch under autograd (Fusionmodule.py:10-367, Objectives.py:138-158): single decoder steps ---------------
+ * One nn.GRU step from gi = W_ih x + b_ih and gh = W_hh h + b_hh ([B, 3H], gate order r, z, n); gates [B, 3H] keeps r, z, n. */
+int itr_gru_cell_fwd(const float *gi, const float *gh, const float *h, float *h_next, float *gates, int64_t B, int H,
+                     itr_stream_t stream);
+int itr_gru_cell_bwd(const float *dh_next, const float *gates, const float *gh, const float *h, float *dgi, float *dgh, float *dh,
+                     int64_t B, int H, itr_stream_t stream);
+/* loss[b] = -mask[b] * log_softmax(logits[b, :])[target[b]]  (F.log_softmax + NLLLoss(reduce=False) * mask); lse keeps the row
+ * log-sum-exp for the backward pass dlogits = dloss[b] mask[b] (softmax - onehot). */
+int itr_nll_logsoftmax_fwd(const float *logits, const int64_t *target, const float *mask, float *loss, float *lse, int64_t B, int V,
+                           itr_stream_t stream);
+int itr_nll_logsoftmax_bwd(const float *logits, const int64_t *target, const float *mask, const float *lse, const float *dloss,
+                           float *dlogits, int64_t B, int V, itr_stream_t stream);
+
 /* EncoderText (bi)GRU under autograd (TextEncoder.py:38-70): training forward that keeps the gate activations, and
  * backpropagation through time.  Same packed layout / sorting contract as itr_gru_fwd.  `out` [n_tok, D] is the RAW
  * sequence output ((fwd + bwd) / 2 for a bi-GRU); l2norm / last-step gather are separate differentiable steps.

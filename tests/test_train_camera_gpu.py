@@ -94,3 +94,38 @@ def test_l2norm_mid_summarize_mvm(dev):
     Sg = ag.mvm_scores(gi, gc)
     Sg.backward(dS.to(dev))
     _cmp(Sg, want, 2e-5); _cmp(gi.grad, I.grad, 2e-5); _cmp(gc.grad, Cc.grad, 2e-5)
+
+
+def test_gru_cell_nll_bmm_nn(dev):
+    """Single-step pieces of VSRN's captioning decoder: nn.GRU cell, log-softmax + masked NLL, small batched product."""
+    torch.manual_seed(4)
+    B, E, H, V = 7, 20, 24, 57
+    rnn = torch.nn.GRU(E, H, 1, batch_first=True).double()
+    x, h, dy = torch.randn(B, E), torch.randn(B, H), torch.randn(B, H)
+    X, Hh = x.double().requires_grad_(True), h.double().requires_grad_(True)
+    out, hn = rnn(X.unsqueeze(1), Hh.unsqueeze(0))
+    hn[0].backward(dy.double())
+    mine = torch.nn.GRU(E, H, 1, batch_first=True)
+    mine.load_state_dict({k: v.float() for k, v in rnn.state_dict().items()})
+    mine.to(dev)
+    gx, gh = x.to(dev).requires_grad_(True), h.to(dev).requires_grad_(True)
+    y = ag.gru_cell(gx, gh, mine)
+    y.backward(dy.to(dev))
+    _cmp(y, hn[0], 2e-6); _cmp(gx.grad, X.grad, 5e-6); _cmp(gh.grad, Hh.grad, 5e-6)
+    for n, p in mine.named_parameters():
+        _cmp(p.grad, dict(rnn.named_parameters())[n].grad, 2e-5)
+    logits, tgt, mask, dl = torch.randn(B, V) * 3, torch.randint(0, V, (B,)), torch.tensor([1., 1, 0, 1, 1, 0, 1]), torch.randn(B)
+    Lg = logits.double().requires_grad_(True)
+    want = torch.nn.functional.nll_loss(torch.log_softmax(Lg, 1), tgt, reduction='none') * mask.double()
+    want.backward(dl.double())
+    gl = logits.to(dev).requires_grad_(True)
+    loss = ag.nll_logsoftmax(gl, tgt.to(dev), mask.to(dev))
+    loss.backward(dl.to(dev))
+    _cmp(loss, want, 2e-6); _cmp(gl.grad, Lg.grad, 2e-6)
+    a, b, dc = torch.randn(3, 9, 14), torch.randn(3, 14, 11), torch.randn(3, 9, 11)
+    A, Bm = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    (A @ Bm).backward(dc.double())
+    ga, gb = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    c = ag.bmm_nn(ga, gb)
+    c.backward(dc.to(dev))
+    _cmp(c, A @ Bm, 5e-6); _cmp(ga.grad, A.grad, 5e-6); _cmp(gb.grad, Bm.grad, 5e-6)
