@@ -228,6 +228,89 @@ def encoder_similarity_train(sim_enc, img_emb, words, tok_off, lens, seeds, trai
     return torch.cat(cols, 1)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# VSRN captioning branch (Fusionmodule.py:10-367), training only: parameter containers with the reference's names + the
+# teacher-forced forward on the autograd tape.  (The reference never stores these modules in its checkpoints, Models.py:37-45.)
+class Attention(nn.Module):
+    """Fusionmodule.py:115-146."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.linear1 = nn.Linear(dim * 2, dim)
+        self.linear2 = nn.Linear(dim, 1, bias=False)
+
+
+class EncoderRNN(nn.Module):
+    """Fusionmodule.py:149-206 (GRU cell, one layer, unidirectional)."""
+
+    def __init__(self, dim_vid, dim_hidden, input_dropout_p=0.2, rnn_dropout_p=0.5, n_layers=1, bidirectional=False, rnn_cell='gru'):
+        super().__init__()
+        if str(rnn_cell).lower() != 'gru' or n_layers != 1 or bidirectional:
+            raise NotImplementedError("VSRN captioning encoder: one unidirectional GRU layer (the reference's configuration)")
+        self.dim_vid, self.dim_hidden, self.input_dropout_p = dim_vid, dim_hidden, float(input_dropout_p)
+        self.vid2hid = nn.Linear(dim_vid, dim_hidden)
+        nn.init.xavier_normal_(self.vid2hid.weight)
+        self.rnn = nn.GRU(dim_hidden, dim_hidden, 1, batch_first=True)      # (nn.GRU's own dropout acts between layers only)
+
+
+class DecoderRNN(nn.Module):
+    """Fusionmodule.py:209-365 (GRU cell, one layer)."""
+
+    def __init__(self, vocab_size, max_len, dim_hidden, dim_word, n_layers=1, rnn_cell='gru', bidirectional=False, input_dropout_p=0.1,
+                 rnn_dropout_p=0.1):
+        super().__init__()
+        if str(rnn_cell).lower() != 'gru' or n_layers != 1 or bidirectional:
+            raise NotImplementedError("VSRN captioning decoder: one unidirectional GRU layer (the reference's configuration)")
+        self.dim_output, self.dim_hidden, self.dim_word, self.max_length = vocab_size, dim_hidden, dim_word, max_len
+        self.input_dropout_p = float(input_dropout_p)
+        self.embedding = nn.Embedding(vocab_size, dim_word)
+        self.attention = Attention(dim_hidden)
+        self.rnn = nn.GRU(dim_hidden + dim_word, dim_hidden, 1, batch_first=True)
+        self.out = nn.Linear(dim_hidden, vocab_size)
+        nn.init.xavier_normal_(self.out.weight)
+
+
+class S2VTAttModel(nn.Module):
+    """Fusionmodule.py:10-35."""
+
+    def __init__(self, encoder, decoder):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+
+    def caption_loss_train(self, vid_feats, labels, masks, seeds, training=True):
+        """LanguageModelCriterion(caption_model(vid_feats, labels, 'train'), labels[:, 1:], masks[:, 1:])  (Models.py:303-313,
+        Objectives.py:138-158) on the autograd tape: encoder GRU over the regions, then max_len - 1 teacher-forced decoder steps of
+        attention -> GRU cell -> vocabulary projection -> log-softmax / masked NLL; sum over steps and rows / batch size."""
+        from .. import autograd as ag
+        enc, dec = self.encoder, self.decoder
+        B, N, Dv = vid_feats.shape
+        H = enc.dim_hidden
+        x = ag.dropout(ag.linear(vid_feats.reshape(B * N, Dv), enc.vid2hid.weight, enc.vid2hid.bias), enc.input_dropout_p, seeds, training)
+        dev = x.device
+        tokens = torch.arange(B * N, device=dev, dtype=torch.int64)
+        off = torch.arange(B, device=dev, dtype=torch.int64) * N
+        enc_out = ag.gru_sequence(tokens, off, [N] * B, x, dict(enc.rnn.named_parameters()), False)          # (B*N, H)
+        h = ag.gather_rows(enc_out, off + (N - 1))                                                             # encoder_hidden
+        enc_out3 = enc_out.view(B, N, H)
+        labels = labels.to(dev)
+        masks = masks.to(dev).to(torch.float32)
+        steps = min(dec.max_length - 1, labels.shape[1] - 1)
+        total = torch.zeros((), device=dev)
+        att = dec.attention
+        for i in range(steps):
+            cur = ag.gather_rows(dec.embedding.weight, labels[:, i].contiguous())
+            inputs = torch.cat([enc_out3, h.unsqueeze(1).expand(B, N, H)], 2).reshape(B * N, 2 * H)
+            e = ag.linear(ag.act(ag.linear(inputs, att.linear1.weight, att.linear1.bias), 'tanh'), att.linear2.weight, None)
+            context = ag.summarize(e.view(B, N, 1), enc_out3).view(B, H)                                      # softmax over the regions
+            dec_in = ag.dropout(torch.cat([cur, context], 1), dec.input_dropout_p, seeds, training)
+            h = ag.gru_cell(dec_in, h, dec.rnn)
+            logits = ag.linear(h, dec.out.weight, dec.out.bias)
+            total = total + ag.nll_logsoftmax(logits, labels[:, i + 1].contiguous(), masks[:, i + 1].contiguous()).sum()
+        return total / B
+
+
 class MultiViewMatching(nn.Module):
     """CAMERA: max over the k views (Fusionmodule.py:670-692)."""
 

@@ -124,6 +124,31 @@ class EncoderImagePrecompAttn(nn.Module):
             feat = feat.abs()
         return feat, gcn_emb
 
+    def forward_train(self, images):
+        """The tower on the autograd tape (VSRN.train_emb): GCN BatchNorms with batch statistics, region GRU through the caption
+        GRU kernels with the GCN output as a dense table -> (features (B, D), GCN_img_emd (B, N, D))."""
+        from .. import autograd as ag
+        B, N, _ = images.shape
+        x = ag.linear(images.reshape(B * N, -1), self.fc.weight, self.fc.bias).view(B, N, -1)
+        if self.data_name != 'f30k_precomp':
+            x = ag.l2norm_mid(x)
+        for gcn in (self.Rs_GCN_1, self.Rs_GCN_2, self.Rs_GCN_3, self.Rs_GCN_4):
+            x = gcn.forward_train(x)
+        gcn_emb = ag.l2norm_mid(x)
+        D = gcn_emb.shape[2]
+        dev = gcn_emb.device
+        tokens = torch.arange(B * N, device=dev, dtype=torch.int64)
+        off = torch.arange(B, device=dev, dtype=torch.int64) * N
+        seq = ag.gru_sequence(tokens, off, [N] * B, gcn_emb.reshape(B * N, D), dict(self.img_rnn.named_parameters()), False)
+        feat = ag.gather_rows(seq, off + (N - 1))                                # hidden_state[0]: the state after the last region
+        if self.data_name == 'f30k_precomp':
+            feat = ag.batch_norm_train(feat, self.bn)
+        if not self.no_imgnorm:
+            feat = ag.l2norm_rows(feat, eps=1e-8)
+        if self.use_abs:
+            feat = feat.abs()
+        return feat, gcn_emb
+
 
 class TransformerMapping(nn.Module):
     """SAEM image tower: Linear(img_dim -> final_dims) -> one BERTLayer -> mean over regions -> F.normalize

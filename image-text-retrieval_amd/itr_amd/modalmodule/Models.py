@@ -7,7 +7,7 @@ GRU family with a pooled or SCAN similarity (VSE++, SCAN) and for SAEM (frozen B
 head and the image transformer layer on the tape, live dropout) and CAMERA (AGSA with BatchNorm batch statistics,
 dilated-convolution summarisation, multi-view matching): itr_amd/autograd.py wires the HIP forward / backward kernels into
 torch's tape.  SGRAF trains too: its similarity module runs the reference's per-caption structure on the tape in training
-mode (Fusionmodule.encoder_similarity_train) and the fused kernels in evaluation mode.
+mode (Fusionmodule.encoder_similarity_train) and the fused kernels in evaluation mode; VSRN trains with its captioning branch.
 
 Data-parallel training (the reference has none): with torch.distributed initialised and world > 1,
 every rank receives the SAME global batch (loaders share the seed), keeps the strided shard rank::world of it, runs
@@ -264,10 +264,10 @@ class SCAN(base_module):
 
 
 class VSRN(base_module):
-    """Visual Semantic Reasoning Network (Models.py:229-365), retrieval side: region-relationship GCN + region GRU image
-    tower, last-state GRU text tower, cosine similarity.  The reference's checkpoints hold [img_enc, txt_enc] only
-    (Models.py:37-45: the captioning model is never saved), so they load and evaluate here.  The captioning branch
-    (EncoderRNN / DecoderRNN / S2VTAttModel, training only) and train_emb are not built."""
+    """Visual Semantic Reasoning Network (Models.py:229-365): region-relationship GCN + region GRU image tower, last-state GRU text
+    tower, cosine similarity, plus the training-only captioning branch (EncoderRNN / attention DecoderRNN over the GCN region
+    features, LanguageModelCriterion).  The reference's checkpoints hold [img_enc, txt_enc] only (Models.py:37-45: the captioning
+    model is never saved) -- the same here."""
 
     def __init__(self, config, use_txt_emb=True):
         super().__init__(config)
@@ -282,12 +282,28 @@ class VSRN(base_module):
         self.txt_enc = TextEncoder.EncoderText(config['vocab_size'], config['word_dim'], config['embed_size'],
                                                config['num_layers'], use_abs=config['use_abs'],
                                                no_txtnorm=config['no_txtnorm'], method_name=config['name'])
+        self.encoder = Fusionmodule.EncoderRNN(config['dim_vid'], config['dim_hidden'], bidirectional=config['bidirectional'],
+                                               input_dropout_p=config['input_dropout_p'], rnn_cell=config['rnn_type'],
+                                               rnn_dropout_p=config['rnn_dropout_p'])
+        self.decoder = Fusionmodule.DecoderRNN(config['vocab_size'], config['max_len'], config['dim_hidden'], config['dim_word'],
+                                               input_dropout_p=config['input_dropout_p'], rnn_cell=config['rnn_type'],
+                                               rnn_dropout_p=config['rnn_dropout_p'], bidirectional=config['bidirectional'])
+        self.caption_model = Fusionmodule.S2VTAttModel(self.encoder, self.decoder)
         self.img_enc.cuda()
         self.txt_enc.cuda()
+        self.caption_model.cuda()
         self.criterion = Objectives.ContrastiveLoss(config=config, margin=config['margin'], measure=config['measure'],
                                                     max_violation=config['max_violation'])
-        self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters())
+        self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters()) + list(self.caption_model.parameters())
         self.calculate_params()
+
+    def train_start(self):
+        super().train_start()
+        self.caption_model.train()
+
+    def val_start(self):
+        super().val_start()
+        self.caption_model.eval()
 
     def forward_emb(self, images, captions, lengths, *args, **kwargs):
         out = self.img_enc(self._dev(images))
@@ -296,14 +312,48 @@ class VSRN(base_module):
         return img_emb, cap_emb, gcn_emb
 
     def forward_loss(self, img_emb, cap_emb, GCN_img_emd=None, captions=None, captions_mask=None):
-        """Retrieval loss (Models.py:337).  The reference adds the captioning loss of S2VTAttModel on GCN_img_emd
-        (:334, training only): passing captions asks for it and raises."""
+        """Retrieval loss (Models.py:337) on evaluation-mode embeddings.  The captioning term needs the autograd tape through the
+        towers: it is part of train_emb (passing captions here raises)."""
         if captions is not None:
-            raise NotImplementedError("VSRN captioning loss (Fusionmodule.py:10-367) is not built; call forward_loss(img_emb, cap_emb)")
+            raise NotImplementedError("the captioning loss is evaluated inside train_emb (the towers must be on the autograd tape)")
         loss = self.criterion(img_emb, cap_emb)
         self._log('Loss_retrieval', loss.data, img_emb.size(0))
         self._log('Loss', loss.data, img_emb.size(0))
         return loss
+
+    def train_emb(self, train_data, *args, **kwargs):
+        """One training step (Models.py:343-365): towers on the autograd tape -> retrieval hinge + captioning loss
+        (calcualte_caption_loss :303-313) -> backward, clip_grad_norm_, Adam."""
+        images, _, _, captions, lengths, _, captions_mask, _ = train_data
+        if not isinstance(self.img_enc, ImgEncoder.EncoderImagePrecompAttn):
+            raise NotImplementedError("VSRN.train_emb with use_txt_emb=False")
+        if self.config['measure'] not in ('cosine', 'order'):
+            raise ValueError("unknown measure:", self.config['measure'])
+        self.Eiters += 1
+        self._log('Eit', self.Eiters)
+        self._log('lr', self.optimizer.param_groups[0]['lr'])
+        if not hasattr(self, '_seeds'):
+            self._seeds = ag.DropoutSeeds()
+        self._seeds.new_step()
+        self.optimizer.zero_grad()
+        with torch.enable_grad():
+            images, captions = self._dev(images), self._dev(captions)
+            img, gcn_emb = self.img_enc.forward_train(images)
+            te = self.txt_enc
+            toks, off, lens, _ = TextEncoder.pack_tokens(captions, lengths)
+            seq = ag.gru_sequence(toks, off, lens, te.embed.weight, dict(te.rnn.named_parameters()), te.use_bi_gru)
+            cap = ag.gather_rows(seq, off + ops.h2d(np.asarray(lens, np.int64), off.device) - 1)
+            if not te.no_txtnorm:
+                cap = ag.l2norm_rows(cap)
+            if te.use_abs:
+                cap = cap.abs()
+            scores = (ag.order_scores if self.config['measure'] == 'order' else ag.cosine_scores)(img, cap)
+            retrieval_loss = ops.hinge_loss(scores, self.config['margin'], self.config['max_violation'])
+            caption_loss = self.caption_model.caption_loss_train(gcn_emb, captions, self._dev(captions_mask), self._seeds,
+                                                                 self.caption_model.training)
+            self._log('Loss_caption', caption_loss.detach(), img.size(0))
+            self._log('Loss_retrieval', retrieval_loss.detach(), img.size(0))
+            self._step(retrieval_loss + caption_loss, img.size(0))
 
 
 class SGRAF(base_module):

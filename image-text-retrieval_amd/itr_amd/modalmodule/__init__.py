@@ -3,7 +3,7 @@ renames 'VSE++' to 'VSE_PP' while get_model only matches 'VSE++' (KeyError, SURV
 from . import Models, ImgEncoder, TextEncoder, Objectives, Fusionmodule, utils  # noqa: F401
 
 _BUILT = {'VSE++': 'VSE_PP', 'VSE_PP': 'VSE_PP', 'SCAN': 'SCAN', 'SGRAF': 'SGRAF', 'SAEM': 'SAEM', 'CAMERA': 'CAMERA',
-          'VSRN': 'VSRN'}      # VSRN: retrieval side (towers + cosine); its training-only captioning branch is not built
+          'VSRN': 'VSRN'}
 
 
 def get_model(config):

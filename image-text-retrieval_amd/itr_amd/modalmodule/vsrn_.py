@@ -65,3 +65,20 @@ class Rs_GCN(nn.Module):
         out = v.reshape(B * N, D).clone()
         ops.gemm_acc(y, y.shape[1], B * N, self.inter_channels, ww, wb, out)  # + BN(W y)
         return out.view(B, N, D)
+
+    def forward_train(self, v):
+        """The layer on the autograd tape (VSRN.train_emb): BatchNorm with batch statistics (channel = feature, rows = B * N)."""
+        from .. import autograd as ag
+        B, N, D = v.shape
+        C = self.inter_channels
+        v2 = v.reshape(B * N, D)
+        theta = ag.linear(v2, self.theta.weight[:, :, 0], self.theta.bias).view(B, N, C)
+        phi = ag.linear(v2, self.phi.weight[:, :, 0], self.phi.bias).view(B, N, C)
+        g = ag.linear(v2, self.g.weight[:, :, 0], self.g.bias).view(B, N, C)
+        R = ag.bmm_nt(theta, phi) * (1.0 / N)                                   # R_div_C = theta phi^T / N
+        y = ag.bmm_nn(R, g).reshape(B * N, C)
+        if isinstance(self.W, nn.Sequential):
+            wy = ag.batch_norm_train(ag.linear(y, self.W[0].weight[:, :, 0], self.W[0].bias), self.W[1])
+        else:
+            wy = ag.linear(y, self.W.weight[:, :, 0], self.W.bias)
+        return (wy + v2).view(B, N, D)

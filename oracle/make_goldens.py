@@ -1002,9 +1002,67 @@ def g20():
     save('g20_sgraf_train', **out)
 
 
+# ------------------------------------------------------------------ G21 VSRN.train_emb (f4), dropout modules set to p = 0
+def g21():
+    """The reference's own VSRN.train_emb (Models.py:343-365) run twice on CPU: retrieval + captioning losses, gradients of all
+    parameters (towers and captioning model) after step 1, parameters after step 2.  nn.Dropout modules switched to p = 0 (see g18);
+    captions in the loader's VSRN layout (max_len + 1 ids, data_loader.py:117-125)."""
+    rng = np.random.RandomState(21)
+    out = {}
+    V, F_, D, E, B, max_len = 40, 20, 32, 12, 5, 8
+    cfg = dict(name='VSRN', data_name='coco_precomp', img_dim=F_, embed_size=D, use_abs=False, no_imgnorm=False, vocab_size=V, word_dim=E,
+               num_layers=1, no_txtnorm=False, dim_vid=D, dim_hidden=16, bidirectional=False, input_dropout_p=0.2, rnn_type='gru',
+               rnn_dropout_p=0.0, max_len=max_len, dim_word=10, margin=0.2, measure='cosine', max_violation=True, finetune=False,
+               learning_rate=2e-3, grad_clip=2.0)
+    with torch.enable_grad():
+        torch.manual_seed(210)
+        model = Models.VSRN(cfg)
+        _randomise_bn(model.img_enc, 211)
+        for m in list(model.caption_model.modules()) + list(model.txt_enc.modules()):
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        model.train_start()
+        model.caption_model.train()
+        model.logger = evaluation.LogCollector()
+        mods = (('img', model.img_enc), ('txt', model.txt_enc), ('cap', model.caption_model))
+        for which, m in mods:
+            for k, v in sd(m).items():
+                out['w0_%s_%s' % (which, k)] = v
+        for step in (1, 2):
+            feats = mutils.l2norm(torch.randn(B, 36, F_), dim=-1)
+            true_len = [int(x) for x in rng.randint(3, max_len + 3, size=B)]
+            ids = torch.zeros(B, max_len + 1, dtype=torch.long)
+            mask = torch.zeros(B, max_len + 1)
+            for b, l in enumerate(true_len):
+                toks = [1] + [int(x) for x in rng.randint(4, V, size=l - 2)] + [2]
+                if len(toks) > max_len:
+                    toks[max_len] = toks[-1]
+                    toks = toks[:max_len]
+                ids[b, :len(toks)] = torch.tensor(toks)
+                mask[b, :max_len] = 1            # the reference's mask is computed after the padding (data_loader.py:123-124)
+            lens = [max_len + 1] * B
+            model.train_emb((feats, None, None, ids, lens, list(range(B)), mask, None))
+            pre = 's%d_' % step
+            out.update({pre + 'feats': feats, pre + 'ids': ids, pre + 'mask': mask, pre + 'lens': np.array(lens),
+                        pre + 'loss_caption': float(model.logger.meters['Loss_caption'].val),
+                        pre + 'loss_retrieval': float(model.logger.meters['Loss_retrieval'].val)})
+            if step == 1:
+                for which, m in mods:
+                    for n, p_ in m.named_parameters():
+                        if p_.grad is not None:
+                            out[pre + 'grad_%s.%s' % (which, n)] = p_.grad.detach().clone()
+            else:
+                for which, m in mods:
+                    for k, v in sd(m).items():
+                        out[pre + '%s_%s' % (which, k)] = v
+        print("   caption loss %.5f / %.5f   retrieval %.5f / %.5f" % (out['s1_loss_caption'], out['s2_loss_caption'], out['s1_loss_retrieval'],
+                                                                       out['s2_loss_retrieval']))
+    save('g21_vsrn_train', **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20', 'g21']
     for name in which:
         print("== " + name)
         globals()[name]()

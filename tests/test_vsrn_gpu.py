@@ -72,9 +72,7 @@ def test_vsrn_model_golden(golden, dev):
     assert np.abs(gcn.cpu().numpy() - g["m_gcn"]).max() <= 2e-6
     assert float(model.forward_loss(img_emb, cap_emb)) == pytest.approx(float(g["m_loss"]), abs=1e-5)
     with pytest.raises(NotImplementedError):
-        model.forward_loss(img_emb, cap_emb, gcn, T(g["m_ids"]), None)      # the captioning branch
-    with pytest.raises(NotImplementedError):
-        model.train_emb(None)
+        model.forward_loss(img_emb, cap_emb, gcn, T(g["m_ids"]), None)      # the captioning term lives in train_emb (tests/test_vsrn_train_gpu.py)
     sd = model.state_dict()
     assert len(sd) == 2 and 'Rs_GCN_1.W.1.running_mean' in sd[0] and 'img_rnn.weight_ih_l0' in sd[0] and 'rnn.weight_hh_l0' in sd[1]
     m2 = get_model(cfg)
