@@ -15,7 +15,7 @@ from itr_amd.modalmodule import get_model
 from itr_amd.metricmodule.evaluation import LogCollector
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--model", default="SCAN", choices=["SCAN", "VSE_PP", "SGRAF", "SAEM", "CAMERA"])
+ap.add_argument("--model", default="SCAN", choices=["SCAN", "VSE_PP", "SGRAF", "SAEM", "CAMERA", "VSRN"])
 ap.add_argument("--module", default="SAF", choices=["SAF", "SGR"])
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--steps", type=int, default=10)
@@ -44,6 +44,13 @@ def batch():
     for b, l in enumerate(lens):
         ids[b, :l] = torch.from_numpy(rng.randint(4, 11353, size=l))
     feats = ops.l2norm(torch.randn(B, 36, 2048, device=dev))
+    if a.model == 'VSRN':          # the loader's VSRN layout: every caption max_len + 1 = 61 ids (data_loader.py:117-125)
+        vid = torch.zeros(B, 61, dtype=torch.long)
+        for b, l in enumerate(lens):
+            vid[b, :l] = ids[b, :l]
+        vmask = torch.zeros(B, 61)
+        vmask[:, :60] = 1
+        return (feats, None, None, vid.to(dev), [61] * B, list(range(B)), vmask.to(dev), None)
     if BERT:
         L = 32
         bid = torch.from_numpy(rng.randint(1000, 30522, size=(B, L)))
