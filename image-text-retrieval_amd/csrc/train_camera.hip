@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void l2norm_mid_bwd_kernel(const float *__rest
 }
 
 // ---- multi-view summarisation: L = softmax over the R regions of smry [B, R, K]; out[b, v, d] = sum_r L[b, r, v] x[b, r, d]
-constexpr int SM_R = 64, SM_K = 64;      // (SGRAF: K = words of a caption / graph nodes)
+constexpr int SM_R = 96, SM_K = 96;      // (SGRAF: K = words of a caption / graph nodes; the longest Flickr30k caption has 82 tokens)
 __global__ __launch_bounds__(256) void smry_fwd_kernel(const float *__restrict__ smry, const float *__restrict__ x, float *__restrict__ Lout,
                                                        float *__restrict__ out, int R, int K, int D) {
     __shared__ float sl[SM_R][SM_K];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void smry_bwd_l_kernel(const float *__restrict
     }
 }
 // softmax backward over the R axis: dsmry[b, r, v] = L (dLraw - sum_r dLraw L)
-__global__ __launch_bounds__(64) void smry_bwd_softmax_kernel(const float *__restrict__ L, const float *__restrict__ dLraw,
+__global__ __launch_bounds__(128) void smry_bwd_softmax_kernel(const float *__restrict__ L, const float *__restrict__ dLraw,
                                                               float *__restrict__ dsmry, int R, int K) {
     const int64_t b = blockIdx.x;
     const int v = threadIdx.x;
@@ -322,7 +322,7 @@ extern "C" int itr_l2norm_mid_bwd(const float *dz, const float *z, const float *
 }
 
 extern "C" int itr_smry_fwd(const float *smry, const float *x, float *L, float *out, int64_t B, int R, int K, int D, itr_stream_t stream) {
-    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_fwd: at most 64 rows, 64 columns, 65535 groups");
+    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_fwd: at most 96 rows, 96 columns, 65535 groups");
     if (B == 0) return ITR_OK;
     ITR_REQUIRE(smry && x && L && out, "itr_smry_fwd: null pointer");
     hipLaunchKernelGGL(itr::smry_fwd_kernel, dim3((unsigned)itr::ceil_div(D, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), smry, x, L, out,
@@ -333,14 +333,14 @@ extern "C" int itr_smry_fwd(const float *smry, const float *x, float *L, float *
 
 extern "C" int itr_smry_bwd(const float *x, const float *L, const float *dout, float *dx, float *dsmry, float *scratch, int64_t B, int R, int K,
                             int D, itr_stream_t stream) {
-    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_bwd: at most 64 rows, 64 columns, 65535 groups");
+    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_bwd: at most 96 rows, 96 columns, 65535 groups");
     if (B == 0) return ITR_OK;
     ITR_REQUIRE(x && L && dout && dx && dsmry && scratch, "itr_smry_bwd: null pointer (scratch: B * R * K floats)");
     ITR_REQUIRE(B * R <= 0x7fffffff, "itr_smry_bwd: too many rows");
     hipLaunchKernelGGL(itr::smry_bwd_x_kernel, dim3((unsigned)itr::ceil_div(D, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), L, dout, dx, R,
                        K, D);
     hipLaunchKernelGGL(itr::smry_bwd_l_kernel, dim3((unsigned)(B * R)), dim3(256), 0, itr::as_stream(stream), x, dout, scratch, R, K, D);
-    hipLaunchKernelGGL(itr::smry_bwd_softmax_kernel, dim3((unsigned)B), dim3(64), 0, itr::as_stream(stream), L, scratch, dsmry, R, K);
+    hipLaunchKernelGGL(itr::smry_bwd_softmax_kernel, dim3((unsigned)B), dim3(128), 0, itr::as_stream(stream), L, scratch, dsmry, R, K);
     ITR_CHECK_LAUNCH("smry_bwd");
     return ITR_OK;
 }

@@ -71,8 +71,8 @@ class AttentionFiltration(nn.Module):
 
 class EncoderSimilarity(nn.Module):
     """Image-text similarity by SGR / SAF (Fusionmodule.py:373-451).  img_emb (n_img, 36, D), cap_emb
-    (n_cap, L, D) padded, cap_lens -> (n_img, n_cap).  Evaluation mode only (BatchNorm running statistics, no
-    dropout): the training-mode forward / backward is SURVEY.md 8(f)-3."""
+    (n_cap, L, D) padded, cap_lens -> (n_img, n_cap).  This forward is the evaluation mode (BatchNorm running statistics, no
+    dropout) on the fused kernels; the training mode is encoder_similarity_train below."""
 
     def __init__(self, embed_size, sim_dim, module_name='AVE', sgr_step=3):
         super().__init__()
@@ -96,7 +96,7 @@ class EncoderSimilarity(nn.Module):
 
     def forward(self, img_emb, cap_emb, cap_lens, *args, **kwargs):
         if self.training:
-            raise NotImplementedError("EncoderSimilarity is built for evaluation mode; call val_start()")
+            raise NotImplementedError("training mode runs inside SGRAF.train_emb (Fusionmodule.encoder_similarity_train); call val_start()")
         return ops.sgraf_padded(img_emb, cap_emb, cap_lens, self.state_dict(), self.module_name, self.sgr_step)
 
     def forward_packed(self, img_emb, words, plan):
@@ -127,8 +127,15 @@ def _sa_train(mod, local, raw_global, seeds, training):
             t = le.view(B, n, D).permute(0, 2, 1).reshape(B * D, n)        # rows = (image, feature), columns = regions
             le = ag.batch_norm_train(t, bn_l).view(B, D, n).permute(0, 2, 1).reshape(B * n, D)
             ge = ag.batch_norm_train(ge, bn_g)
-        else:
-            raise NotImplementedError("evaluation mode runs on the fused kernels (EncoderSimilarity.forward)")
+        else:        # evaluation mode (the long-caption fallback of ops.sgraf_scores): running statistics as a folded affine
+            def fold(bn):
+                sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+                return sc.contiguous(), (bn.bias - bn.running_mean * sc).detach().contiguous()
+            sc, sh = fold(bn_l)
+            t = le.view(B, n, D).permute(0, 2, 1).reshape(B * D, n).contiguous()
+            le = ops.affine_cols(t, sc, sh).view(B, D, n).permute(0, 2, 1).reshape(B * n, D).contiguous()
+            sc, sh = fold(bn_g)
+            ge = ops.affine_cols(ge, sc, sh)
     p = float(mod.embedding_local[-1].p)
     le = ag.dropout(ag.act(le, 'tanh'), p, seeds, training).view(B, n, D)
     ge = ag.dropout(ag.act(ge, 'tanh'), p, seeds, training)
@@ -186,6 +193,10 @@ def _saf_train(saf, x, G, training):
                 bn.running_mean.mul_(1 - mom).add_(mean[gi:gi + 1], alpha=mom)
                 bn.running_var.mul_(1 - mom).add_(var_u[gi:gi + 1], alpha=mom)
             bn.num_batches_tracked += G
+    else:
+        bn = saf.bn
+        sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+        a = ops.affine_cols(a, sc.contiguous(), (bn.bias - bn.running_mean * sc).detach().contiguous())
     a = ag.act(a, 'sigmoid').view(GB, n)
     a = a / (a.abs().sum(1, keepdim=True) + 1e-8)                                # l1norm over the nodes
     sim_saf = (a.unsqueeze(2) * x).sum(1)

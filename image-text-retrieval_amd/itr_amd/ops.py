@@ -344,14 +344,14 @@ class ScanPlan:
     scan_xattn_scores fills their columns with the one-workgroup-per-pair forward of the training path
     (csrc/scan_train*.hip, up to 96 words).  `Nc` is always the full caption count."""
 
-    def __init__(self, cap_off, cap_len, n_rows, device):
+    def __init__(self, cap_off, cap_len, n_rows, device, max_kernel_len=None):
         lib = _lib.load()
         self.len_host = _host_i32(cap_len)
         self.off_host = np.asarray(cap_off, dtype=np.int64)
         self.Nc = len(self.len_host)
         self.n_rows = int(n_rows)
         self.device = device
-        long_mask = self.len_host > SCAN_NT
+        long_mask = self.len_host > (SCAN_NT if max_kernel_len is None else max_kernel_len)      # (SGRAF: 63 words + the global node)
         self.long_idx = np.nonzero(long_mask)[0] if long_mask.any() else None
         if self.long_idx is None:
             k_len, k_off = self.len_host, self.off_host
@@ -609,6 +609,9 @@ _SAF_MAP = {"saf_w": "SAF_module.attn_sim_w.weight", "saf_b": "SAF_module.attn_s
             "saf_bn_mean": "SAF_module.bn.running_mean", "saf_bn_var": "SAF_module.bn.running_var"}
 
 
+SGRAF_MAX_WORDS = 63      # fused pair kernels: 63 words + the global node = one 64-row tile
+
+
 def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, out=None):
     """EncoderSimilarity.forward (Fusionmodule.py:406-451), eval mode.  images (Ni, 36, D); words (n_rows, D)
     with the caption layout of `plan` (ScanPlan on the WORD lengths); weights: the module's state_dict."""
@@ -643,8 +646,37 @@ def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, ou
         out = torch.empty(Ni, plan.Nc, device=images.device, dtype=torch.float32)
     wsb = lib.itr_sgraf_workspace_bytes(Ni, plan.Nc, words.shape[0], plan.n_tiles, D, S_dim, mod)
     ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
+    if plan.Nc and int(plan.len_host.max()) > SGRAF_MAX_WORDS:
+        plan = ScanPlan(plan.off_host, plan.len_host, plan.n_rows, plan.device, max_kernel_len=SGRAF_MAX_WORDS)
     if plan.long_idx is not None:
-        raise NotImplementedError("sgraf_scores: captions of at most 63 words are supported")
+        # Captions of more than 63 words (Flickr30k has a few, up to 82 tokens) do not fit the 64-node tiles of the fused pair
+        # kernels: the others are scored by the fused path, these by the per-caption composition of the training path run in
+        # evaluation mode (Fusionmodule.encoder_similarity_train(training=False): same arithmetic, HIP kernels, up to 95 words).
+        from .modalmodule import Fusionmodule
+        dev = images.device
+        if plan.Nc_kernel:
+            part = torch.empty(Ni, plan.Nc_kernel, device=dev, dtype=torch.float32)
+            wsb = lib.itr_sgraf_workspace_bytes(Ni, plan.Nc_kernel, words.shape[0], plan.n_tiles, D, S_dim, mod)
+            ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+            max_len = int(plan.len_host[plan.short_idx].max())
+            _lib.check(lib.itr_sgraf_scores(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
+                                            _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc_kernel, words.shape[0], max_len, R, D, S_dim,
+                                            mod, int(sgr_step), C.byref(st), _p(part), part.stride(0), _p(ws), wsb, _stream()))
+            out[:, torch.from_numpy(plan.short_idx).to(dev)] = part
+        sim_enc = Fusionmodule.EncoderSimilarity(D, S_dim, module_name, sgr_step)
+        own = sim_enc.state_dict()
+        sim_enc.load_state_dict({k: (weights[k].detach() if k in weights else own[k]) for k in own if k in weights or k.endswith('num_batches_tracked')})
+        sim_enc.to(dev).eval()
+        lens = [int(plan.len_host[c]) for c in plan.long_idx]
+        if max(lens) > 95:
+            raise NotImplementedError("sgraf_scores: captions of at most 95 words are supported")
+        rows = np.concatenate([np.arange(plan.off_host[c], plan.off_host[c] + plan.len_host[c]) for c in plan.long_idx])
+        w_long = words[torch.from_numpy(rows).to(dev)].contiguous()
+        off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        with torch.no_grad():
+            out[:, torch.from_numpy(plan.long_idx).to(dev)] = Fusionmodule.encoder_similarity_train(sim_enc, images, w_long, off, lens, None,
+                                                                                                   training=False)
+        return out
     max_len = int(plan.len_host.max()) if plan.Nc else 1
     _lib.check(lib.itr_sgraf_scores(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
                                     _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc, words.shape[0], max_len, R, D, S_dim,

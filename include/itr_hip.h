@@ -353,7 +353,7 @@ int itr_l2norm_mid_fwd(const float *x, float *z, float *norms, int64_t B, int R,
 int itr_l2norm_mid_bwd(const float *dz, const float *z, const float *norms, float *dx, int64_t B, int R, int D, float eps,
                        itr_stream_t stream);
 /* Multi-view summarisation (ImgEncoder.py:386-387): L = softmax(smry [B, R, K], dim=1); out [B, K, D] = L^T x.  scratch: B*R*K floats.
- * R, K <= 64.  The same contraction is SGRAF's SCAN_attention weighting (K = words, Fusionmodule.py:649-661) and the edge
+ * R, K <= 96.  The same contraction is SGRAF's SCAN_attention weighting (K = words, Fusionmodule.py:649-661) and the edge
  * aggregation of its graph reasoning (R = K = nodes, :581-584). */
 int itr_smry_fwd(const float *smry, const float *x, float *L, float *out, int64_t B, int R, int K, int D, itr_stream_t stream);
 int itr_smry_bwd(const float *x, const float *L, const float *dout, float *dx, float *dsmry, float *scratch, int64_t B, int R, int K,
