@@ -56,56 +56,106 @@ __global__ __launch_bounds__(256) void gate_apply_bwd_kernel(const float *__rest
     dM[r * 2 * dk + dk + d] = dko[i] * k[i];
 }
 
-// ---- BatchNorm1d, training mode: one workgroup per 64 columns, 4 row lanes per column
-__global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
-                                                           const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ mean,
-                                                           float *__restrict__ invstd, int64_t N, int C, float eps) {
+// ---- BatchNorm1d, training mode.  Grid = (column blocks of 64, row slices): with few columns and many rows (VisualSA's
+// BatchNorm1d(36) over B * D = 131 072 rows) one workgroup per column block would leave the chip idle, so the column statistics are
+// reduced in two stages: every (column block, row slice) workgroup writes partial sums, the consumers add the <= 64 partials of
+// their columns in a fixed order (deterministic).  Two passes for the variance (mean first), like torch.
+constexpr int BN_MAXSLICES = 64;
+__device__ __forceinline__ void bn_rows(int64_t N, int slices, int64_t *r0, int64_t *r1) {
+    const int64_t per = (N + slices - 1) / slices;
+    *r0 = (int64_t)blockIdx.y * per;
+    *r1 = *r0 + per < N ? *r0 + per : N;
+}
+// mode 0: part[slice][c] = sum x;  mode 1: sum (x - mean)^2 with mean from the mode-0 partials (sum0 / N)
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ sum0, float *__restrict__ part,
+                                                         int64_t N, int C, int slices, int mode) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     const bool ok = c < C;
-    float s = 0.f;
-    if (ok) for (int64_t r = rl; r < N; r += 4) s += x[r * C + c];
-    red[rl][cl] = s;
+    int64_t r0, r1;
+    bn_rows(N, slices, &r0, &r1);
+    float u = 0.f;
+    if (mode == 1 && ok) {
+        for (int s = 0; s < slices; ++s) u += sum0[(int64_t)s * C + c];
+        u /= (float)N;
+    }
+    float a = 0.f;
+    if (ok) for (int64_t r = r0 + rl; r < r1; r += 4) {
+        const float d = x[r * C + c] - u;
+        a += mode == 0 ? d : d * d;
+    }
+    red[rl][cl] = a;
     __syncthreads();
-    const float u = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)N;
-    __syncthreads();
-    float q = 0.f;
-    if (ok) for (int64_t r = rl; r < N; r += 4) { const float d = x[r * C + c] - u; q += d * d; }
-    red[rl][cl] = q;
-    __syncthreads();
-    const float var = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)N;      // biased, as the normalisation uses
-    const float is = 1.f / sqrtf(var + eps);
-    if (!ok) return;
-    const float g = gamma[c], b = beta[c];
-    for (int64_t r = rl; r < N; r += 4) y[r * C + c] = (x[r * C + c] - u) * is * g + b;
-    if (rl == 0) { mean[c] = u; invstd[c] = is; }
+    if (rl == 0 && ok) part[(int64_t)blockIdx.y * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
-__global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                           const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                           const float *__restrict__ gamma, float *__restrict__ dx, float *__restrict__ dgamma,
-                                                           float *__restrict__ dbeta, int64_t N, int C) {
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, const float *__restrict__ sum0,
+                                                             const float *__restrict__ sum1, float *__restrict__ y, float *__restrict__ mean,
+                                                             float *__restrict__ invstd, int64_t N, int C, int slices, float eps) {
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    if (c >= C) return;
+    float u = 0.f, q = 0.f;
+    for (int s = 0; s < slices; ++s) { u += sum0[(int64_t)s * C + c]; q += sum1[(int64_t)s * C + c]; }
+    u /= (float)N;
+    const float is = 1.f / sqrtf(q / (float)N + eps);      // biased variance, as the normalisation uses
+    int64_t r0, r1;
+    bn_rows(N, slices, &r0, &r1);
+    const float g = gamma[c], b = beta[c];
+    for (int64_t r = r0 + rl; r < r1; r += 4) y[r * C + c] = (x[r * C + c] - u) * is * g + b;
+    if (blockIdx.y == 0 && rl == 0) { mean[c] = u; invstd[c] = is; }
+}
+// backward partials: pa = sum dy, pb = sum dy * xhat per (row slice, column)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                             float *__restrict__ pa, float *__restrict__ pb, int64_t N, int C, int slices) {
     __shared__ float ra[4][64], rb[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     const bool ok = c < C;
     const float u = ok ? mean[c] : 0.f, is = ok ? invstd[c] : 0.f;
+    int64_t r0, r1;
+    bn_rows(N, slices, &r0, &r1);
     float a = 0.f, b = 0.f;
-    if (ok) for (int64_t r = rl; r < N; r += 4) {
+    if (ok) for (int64_t r = r0 + rl; r < r1; r += 4) {
         const float g = dy[r * C + c];
         a += g;
         b += g * (x[r * C + c] - u) * is;
     }
     ra[rl][cl] = a; rb[rl][cl] = b;
     __syncthreads();
-    const float sa = ra[0][cl] + ra[1][cl] + ra[2][cl] + ra[3][cl], sb = rb[0][cl] + rb[1][cl] + rb[2][cl] + rb[3][cl];
-    if (!ok) return;
-    const float g = gamma[c], ma = sa / (float)N, mb = sb / (float)N;
-    for (int64_t r = rl; r < N; r += 4) {
+    if (rl == 0 && ok) {
+        pa[(int64_t)blockIdx.y * C + c] = ra[0][cl] + ra[1][cl] + ra[2][cl] + ra[3][cl];
+        pb[(int64_t)blockIdx.y * C + c] = rb[0][cl] + rb[1][cl] + rb[2][cl] + rb[3][cl];
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                           const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                           const float *__restrict__ gamma, const float *__restrict__ pa,
+                                                           const float *__restrict__ pb, float *__restrict__ dx, float *__restrict__ dgamma,
+                                                           float *__restrict__ dbeta, int64_t N, int C, int slices) {
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    if (c >= C) return;
+    float sa = 0.f, sb = 0.f;
+    for (int s = 0; s < slices; ++s) { sa += pa[(int64_t)s * C + c]; sb += pb[(int64_t)s * C + c]; }
+    const float u = mean[c], is = invstd[c], g = gamma[c], ma = sa / (float)N, mb = sb / (float)N;
+    int64_t r0, r1;
+    bn_rows(N, slices, &r0, &r1);
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
         const float xh = (x[r * C + c] - u) * is;
         dx[r * C + c] = g * is * (dy[r * C + c] - ma - xh * mb);
     }
-    if (rl == 0) { dgamma[c] = sb; dbeta[c] = sa; }
+    if (blockIdx.y == 0 && rl == 0) { dgamma[c] = sb; dbeta[c] = sa; }
+}
+static int bn_slices(int64_t N, int C) {
+    const int64_t col_blocks = ceil_div((int64_t)C, (int64_t)64);
+    int64_t s = ceil_div((int64_t)1024, col_blocks);            // aim at ~1024 workgroups
+    const int64_t by_rows = ceil_div(N, (int64_t)256);          // at least 256 rows per slice
+    if (s > by_rows) s = by_rows;
+    if (s > BN_MAXSLICES) s = BN_MAXSLICES;
+    return (int)(s < 1 ? 1 : s);
 }
 
 // ---- l2norm across the middle axis of [B, R, D]: one thread per (b, d)
@@ -280,22 +330,33 @@ extern "C" int itr_gate_apply_bwd(const float *q, const float *k, const float *M
     return ITR_OK;
 }
 
+extern "C" size_t itr_bn_train_scratch_bytes(int64_t N, int C) { return (size_t)2 * itr::BN_MAXSLICES * (size_t)C * sizeof(float); }
+
 extern "C" int itr_bn_train_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *invstd, int64_t N, int C,
-                                float eps, itr_stream_t stream) {
+                                float eps, void *scratch, itr_stream_t stream) {
     ITR_REQUIRE(N >= 1 && C >= 1, "itr_bn_train_fwd: bad shape");
-    ITR_REQUIRE(x && gamma && beta && y && mean && invstd, "itr_bn_train_fwd: null pointer");
-    hipLaunchKernelGGL(itr::bn_train_fwd_kernel, dim3((unsigned)itr::ceil_div(C, 64)), dim3(256), 0, itr::as_stream(stream), x, gamma, beta, y, mean,
-                       invstd, N, C, eps);
+    ITR_REQUIRE(x && gamma && beta && y && mean && invstd && scratch, "itr_bn_train_fwd: null pointer (scratch: itr_bn_train_scratch_bytes)");
+    const int slices = itr::bn_slices(N, C);
+    float *s0 = static_cast<float *>(scratch), *s1 = s0 + (size_t)itr::BN_MAXSLICES * C;
+    const dim3 grid((unsigned)itr::ceil_div(C, 64), (unsigned)slices);
+    hipLaunchKernelGGL(itr::bn_partial_kernel, grid, dim3(256), 0, itr::as_stream(stream), x, (const float *)nullptr, s0, N, C, slices, 0);
+    hipLaunchKernelGGL(itr::bn_partial_kernel, grid, dim3(256), 0, itr::as_stream(stream), x, (const float *)s0, s1, N, C, slices, 1);
+    hipLaunchKernelGGL(itr::bn_train_apply_kernel, grid, dim3(256), 0, itr::as_stream(stream), x, gamma, beta, (const float *)s0, (const float *)s1, y,
+                       mean, invstd, N, C, slices, eps);
     ITR_CHECK_LAUNCH("bn_train_fwd");
     return ITR_OK;
 }
 
 extern "C" int itr_bn_train_bwd(const float *dy, const float *x, const float *mean, const float *invstd, const float *gamma, float *dx,
-                                float *dgamma, float *dbeta, int64_t N, int C, itr_stream_t stream) {
+                                float *dgamma, float *dbeta, int64_t N, int C, void *scratch, itr_stream_t stream) {
     ITR_REQUIRE(N >= 1 && C >= 1, "itr_bn_train_bwd: bad shape");
-    ITR_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta, "itr_bn_train_bwd: null pointer");
-    hipLaunchKernelGGL(itr::bn_train_bwd_kernel, dim3((unsigned)itr::ceil_div(C, 64)), dim3(256), 0, itr::as_stream(stream), dy, x, mean, invstd,
-                       gamma, dx, dgamma, dbeta, N, C);
+    ITR_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && scratch, "itr_bn_train_bwd: null pointer (scratch: itr_bn_train_scratch_bytes)");
+    const int slices = itr::bn_slices(N, C);
+    float *pa = static_cast<float *>(scratch), *pb = pa + (size_t)itr::BN_MAXSLICES * C;
+    const dim3 grid((unsigned)itr::ceil_div(C, 64), (unsigned)slices);
+    hipLaunchKernelGGL(itr::bn_bwd_partial_kernel, grid, dim3(256), 0, itr::as_stream(stream), dy, x, mean, invstd, pa, pb, N, C, slices);
+    hipLaunchKernelGGL(itr::bn_bwd_apply_kernel, grid, dim3(256), 0, itr::as_stream(stream), dy, x, mean, invstd, gamma, (const float *)pa,
+                       (const float *)pb, dx, dgamma, dbeta, N, C, slices);
     ITR_CHECK_LAUNCH("bn_train_bwd");
     return ITR_OK;
 }

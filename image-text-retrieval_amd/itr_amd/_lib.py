@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -39,8 +39,9 @@ SIGNATURES = {
     "itr_act_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
     "itr_gate_apply": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
     "itr_gate_apply_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
-    "itr_bn_train_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]),
-    "itr_bn_train_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "itr_bn_train_scratch_bytes": (sz, [i64, i32]),
+    "itr_bn_train_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp]),
+    "itr_bn_train_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
     "itr_l2norm_mid_fwd": (i32, [vp, vp, vp, i64, i32, i32, f32, vp]),
     "itr_l2norm_mid_bwd": (i32, [vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "itr_smry_fwd": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, vp]),

@@ -683,7 +683,8 @@ class _BatchNormTrain(torch.autograd.Function):
         g, b = _dev(gamma, name="gamma"), _dev(beta, name="beta")
         y = torch.empty_like(x)
         mean, invstd = _f32(Cc, dev=x.device), _f32(Cc, dev=x.device)
-        _lib.check(lib.itr_bn_train_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(invstd), N, Cc, float(eps), _stream()))
+        scratch = torch.empty(lib.itr_bn_train_scratch_bytes(N, Cc), device=x.device, dtype=torch.uint8)
+        _lib.check(lib.itr_bn_train_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(invstd), N, Cc, float(eps), _p(scratch), _stream()))
         ctx.save_for_backward(x, mean, invstd, g)
         stats_out.append((mean, invstd))
         return y
@@ -694,7 +695,9 @@ class _BatchNormTrain(torch.autograd.Function):
         x, mean, invstd, g = ctx.saved_tensors
         N, Cc = x.shape
         dx, dg, db = torch.empty_like(x), _f32(Cc, dev=x.device), _f32(Cc, dev=x.device)
-        _lib.check(lib.itr_bn_train_bwd(_p(dy.contiguous()), _p(x), _p(mean), _p(invstd), _p(g), _p(dx), _p(dg), _p(db), N, Cc, _stream()))
+        scratch = torch.empty(lib.itr_bn_train_scratch_bytes(N, Cc), device=x.device, dtype=torch.uint8)
+        _lib.check(lib.itr_bn_train_bwd(_p(dy.contiguous()), _p(x), _p(mean), _p(invstd), _p(g), _p(dx), _p(dg), _p(db), N, Cc, _p(scratch),
+                                        _stream()))
         return dx, dg, db, None, None
 
 

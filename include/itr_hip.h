@@ -343,11 +343,13 @@ int itr_act_bwd(const float *y, const float *dy, float *dx, int64_t n, int act, 
 int itr_gate_apply(const float *q, const float *k, const float *M, float *qo, float *ko, int64_t rows, int dk, itr_stream_t stream);
 int itr_gate_apply_bwd(const float *q, const float *k, const float *M, const float *dqo, const float *dko, float *dq, float *dk_out,
                        float *dM, int64_t rows, int dk, itr_stream_t stream);
-/* nn.BatchNorm1d in training mode on x [N, C]: batch mean / biased variance per column; keeps mean and 1 / sqrt(var + eps). */
+/* nn.BatchNorm1d in training mode on x [N, C]: batch mean / biased variance per column; keeps mean and 1 / sqrt(var + eps).
+ * scratch: itr_bn_train_scratch_bytes(N, C) bytes (partial sums of the row slices; fixed summation order). */
+size_t itr_bn_train_scratch_bytes(int64_t N, int C);
 int itr_bn_train_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *invstd, int64_t N, int C,
-                     float eps, itr_stream_t stream);
+                     float eps, void *scratch, itr_stream_t stream);
 int itr_bn_train_bwd(const float *dy, const float *x, const float *mean, const float *invstd, const float *gamma, float *dx,
-                     float *dgamma, float *dbeta, int64_t N, int C, itr_stream_t stream);
+                     float *dgamma, float *dbeta, int64_t N, int C, void *scratch, itr_stream_t stream);
 /* utils.l2norm with its default dim=1 on [B, R, D] (normalises ACROSS the R regions, ImgEncoder.py:378,384). */
 int itr_l2norm_mid_fwd(const float *x, float *z, float *norms, int64_t B, int R, int D, float eps, itr_stream_t stream);
 int itr_l2norm_mid_bwd(const float *dz, const float *z, const float *norms, float *dx, int64_t B, int R, int D, float eps,
