@@ -308,8 +308,8 @@ class S2VTAttModel(nn.Module):
         labels = labels.to(dev)
         masks = masks.to(dev).to(torch.float32)
         steps = min(dec.max_length - 1, labels.shape[1] - 1)
-        total = torch.zeros((), device=dev)
         att = dec.attention
+        hs = []
         for i in range(steps):
             cur = ag.gather_rows(dec.embedding.weight, labels[:, i].contiguous())
             inputs = torch.cat([enc_out3, h.unsqueeze(1).expand(B, N, H)], 2).reshape(B * N, 2 * H)
@@ -317,9 +317,13 @@ class S2VTAttModel(nn.Module):
             context = ag.summarize(e.view(B, N, 1), enc_out3).view(B, H)                                      # softmax over the regions
             dec_in = ag.dropout(torch.cat([cur, context], 1), dec.input_dropout_p, seeds, training)
             h = ag.gru_cell(dec_in, h, dec.rnn)
-            logits = ag.linear(h, dec.out.weight, dec.out.bias)
-            total = total + ag.nll_logsoftmax(logits, labels[:, i + 1].contiguous(), masks[:, i + 1].contiguous()).sum()
-        return total / B
+            hs.append(h)
+        # teacher forcing: the logits never feed back into the recurrence, so the vocabulary projection and the log-softmax / NLL of
+        # ALL steps are one GEMM and one kernel (rows step-major) instead of max_len - 1 small ones -- the same sum
+        logits = ag.linear(torch.cat(hs, 0), dec.out.weight, dec.out.bias)
+        tgt = labels[:, 1:steps + 1].t().reshape(-1)
+        msk = masks[:, 1:steps + 1].t().reshape(-1)
+        return ag.nll_logsoftmax(logits, tgt, msk).sum() / B
 
 
 class MultiViewMatching(nn.Module):
