@@ -367,6 +367,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="scan_t2i_coco5k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the separately reported fp16x3 variant of the SCAN workloads")
     ap.add_argument("--cpu-sample-images", type=int, default=160)
     args = ap.parse_args()
 
@@ -512,6 +513,29 @@ def main():
                          "executed_frac": exe_flop / (k_ms * 1e-3) / 1e12 / peak,
                          "note": note},
         }
+        if world == 1 and not is_sgraf and "scan_precision" not in wl and not args.no_variants:
+            # Reported NEXT TO the exact-fp32 metric, never instead of it: the same step with the region x word dot
+            # products from split fp16 operands (hi.hi + hi.lo' + lo'.hi, fp32 accumulation) -- outside the timed region above
+            vmodel = evalpipe.GruModelEval(model.wi, model.wt, dict(cfg, scan_precision="fp16x3"), comm)
+            vt = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
+            vstep = lambda tm=None: vmodel.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm)
+            vstep()
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            vk = []
+            for _ in range(2):
+                Sv, ranks_v, _ = vstep(vt)
+                vk.append(vt["scan_start"].elapsed_time(vt["scan_end"]))
+            torch.cuda.synchronize()
+            dtv = (time.perf_counter() - tv) / 2
+            iv, tvv = _ops.recall_from_ranks(ranks_v[0]), _ops.recall_from_ranks(ranks_v[2])
+            out["variant_fp16x3"] = {
+                "value": pairs / dtv, "unit": "pairs/s", "ms_per_step": 1e3 * dtv, "kernel_ms": float(np.mean(vk)),
+                "max_abs_diff_vs_fp32_scores": float((Sv - S).abs().max()), "mean_abs_diff_vs_fp32_scores": float((Sv - S).abs().mean()),
+                "recall": {"i2t_r1": iv[0], "i2t_r5": iv[1], "i2t_r10": iv[2], "t2i_r1": tvv[0], "t2i_r5": tvv[1], "t2i_r10": tvv[2]},
+                "note": "opt-in study variant, reported separately: fp32 inputs split into scaled fp16 hi + lo planes, 3 fp16 MFMA products, "
+                        "fp32 accumulate; against a float64 oracle it is not further from the truth than the fp32 kernel (DESIGN.md 9)"}
+            del Sv
         if world == 1 and not args.no_cpu_baseline:
             base, S_cpu, ranks_cpu = cpu_baseline(wl, wi, wt, feats_head, lengths, tokens, args.cpu_sample_images)
             ns, ncs = args.cpu_sample_images, 5 * args.cpu_sample_images
