@@ -221,3 +221,6 @@ def test_sharded_eval_equals_single_process_on_one_gpu(workload, world):
     assert multi["n_gpus"] == world
     assert multi["rank_checksum"] == single["rank_checksum"]
     assert multi["recall"] == single["recall"]
+    if workload.startswith("scan_"):       # the separately reported split-fp16 variant rides along with the single-GPU fp32 line only
+        v = single["variant_fp16x3"]
+        assert v["max_abs_diff_vs_fp32_scores"] <= 1e-5 and v["recall"] == single["recall"] and "variant_fp16x3" not in multi
