@@ -51,9 +51,17 @@ class base_module(nn.Module):
             sd.append(self.sim_enc.state_dict())
         return sd
 
+    @staticmethod
+    def _strip_dp(sd):
+        """The reference wraps CAMERA's towers in nn.DataParallel (Models.py:561-562), so its checkpoints name their tensors
+        'module.<name>'; accepted for every model."""
+        if isinstance(sd, dict) and sd and all(k.startswith('module.') for k in sd):
+            return type(sd)((k[len('module.'):], v) for k, v in sd.items())
+        return sd
+
     def load_state_dict(self, state_dict):
-        self.img_enc.load_state_dict(state_dict[0])
-        self.txt_enc.load_state_dict(state_dict[1])
+        self.img_enc.load_state_dict(self._strip_dp(state_dict[0]))
+        self.txt_enc.load_state_dict(self._strip_dp(state_dict[1]))
         if self.sim_enc is not None:
             third = state_dict[2]
             self.sim_enc.load_state_dict(third.state_dict() if isinstance(third, nn.Module) else third)
@@ -516,6 +524,12 @@ class CAMERA(base_module):
         self.params = list(self.txt_enc.parameters()) + list(self.img_enc.parameters())
         self.calculate_params()
         self.optimizer = ag.Adam([p_ for p_ in self.params if p_.requires_grad], lr=config['learning_rate'])   # (frozen BERT: no gradients)
+
+    def state_dict(self):
+        """[img_enc, txt_enc] with the 'module.' prefix of the reference's nn.DataParallel wrappers (Models.py:561-562), so that a
+        checkpoint written here loads in the reference on a GPU host and vice versa (load_state_dict accepts both spellings)."""
+        from collections import OrderedDict
+        return [OrderedDict(('module.' + k, v) for k, v in m.state_dict().items()) for m in (self.img_enc, self.txt_enc)]
 
     def forward_emb(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, *args, **kwargs):
         cap_emb = self.txt_enc(self._dev(captions), self._dev(captions_mask), self._dev(captions_type_ids))

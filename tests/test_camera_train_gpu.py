@@ -29,11 +29,12 @@ def test_camera_train_emb_matches_reference(golden, dev, tmp_path):
     cfg.update(bert_config_file=str(tmp_path / 'bert_config.json'), init_checkpoint=str(tmp_path / 'pytorch_model.bin'), img_dim=24, embed_size=32,
                head=2, smry_k=12, drop=0.0, smry_lamda=0.01, vocab_size=100)
     model = get_model(cfg)
-    # (the reference wraps both towers in nn.DataParallel: its names carry a "module." prefix)
-    strip = lambda k: k.replace('module.', '', 1)
-    sd_txt = model.txt_enc.state_dict()
-    sd_txt.update({strip(k[7:]): T(g[k]) for k in g.files if k.startswith('w0_txt_')})
-    model.load_state_dict([{strip(k[7:]): T(g[k]) for k in g.files if k.startswith('w0_img_')}, sd_txt])
+    # the reference wraps both towers in nn.DataParallel: its state_dicts carry a "module." prefix, which CAMERA.state_dict() emits and
+    # load_state_dict accepts (the frozen BERT weights of the fixture's checkpoint files are already in the model)
+    sd_txt = {'module.' + k: v for k, v in model.txt_enc.state_dict().items()}
+    sd_txt.update({k[7:]: T(g[k]) for k in g.files if k.startswith('w0_txt_')})
+    model.load_state_dict([{k[7:]: T(g[k]) for k in g.files if k.startswith('w0_img_')}, sd_txt])
+    assert all(k.startswith('module.') for k in model.state_dict()[0]) and all(k.startswith('module.') for k in model.state_dict()[1])
     model.train_start()
     model.logger = LogCollector()
     for step in (1, 2):
