@@ -73,8 +73,9 @@ class EncoderText(nn.Module):
 
 class BertMapping(nn.Module):
     """SAEM text tower: frozen BERT + conv / pooling / transformer head + Linear + F.normalize
-    (TextEncoder.py:74-157).  txt_stru='rnn' divides tensor sizes by a float in the reference
-    (TextEncoder.py:135) and cannot run there either: not built."""
+    (TextEncoder.py:74-157).  txt_stru='rnn' cannot run in the reference either and is not built: with bi_gru it slices
+    by a float (TextEncoder.py:135), and without it pack_padded_sequence (TextEncoder.py:128) rejects the batch,
+    because the BERT collate leaves the mask-sum lengths unsorted (every id row has max_words entries, data_loader.py:146-157)."""
 
     def __init__(self, config):
         super().__init__()
@@ -96,7 +97,8 @@ class BertMapping(nn.Module):
             self.mapping_0 = nn.Linear(bert_config.hidden_size, trans_config.hidden_size)
             self.mapping = nn.Linear(trans_config.hidden_size, config['final_dims'])
         elif config['txt_stru'] == 'rnn':
-            raise NotImplementedError("txt_stru='rnn' is broken in the reference (float slicing, TextEncoder.py:135)")
+            raise NotImplementedError("txt_stru='rnn' is broken in the reference (float slicing, TextEncoder.py:135; "
+                                      "unsorted lengths into pack_padded_sequence, TextEncoder.py:128)")
         else:
             raise ValueError("Unknown txt_stru: {}".format(config['txt_stru']))
 
