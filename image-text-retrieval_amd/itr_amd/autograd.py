@@ -701,14 +701,94 @@ class _BatchNormTrain(torch.autograd.Function):
         return dx, dg, db, None, None
 
 
+class _SyncBatchNormTrain(torch.autograd.Function):
+    """_BatchNormTrain on a row shard of the batch: the statistics of the GLOBAL batch from one all-reduce of the per-rank
+    (count, sum, sum of squares) in the forward and one of (sum dy, sum dy*xhat) in the backward, so that a data-parallel step
+    normalises exactly like one process on the whole batch.  The local kernels do the row reductions; gamma / beta keep their
+    LOCAL gradients (Adam.step sums parameter gradients over the ranks)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, stats_out, comm):
+        import torch.distributed as dist
+        from . import ops
+        lib = _lib.load()
+        x = _dev(x, name="x")
+        N, Cc = x.shape
+        g, b = _dev(gamma, name="gamma"), _dev(beta, name="beta")
+        mean, invstd = _f32(Cc, dev=x.device), _f32(Cc, dev=x.device)
+        scratch = torch.empty(lib.itr_bn_train_scratch_bytes(N, Cc), device=x.device, dtype=torch.uint8)
+        _lib.check(lib.itr_bn_train_fwd(_p(x), _p(g), _p(b), _p(torch.empty_like(x)), _p(mean), _p(invstd), N, Cc, float(eps), _p(scratch),
+                                        _stream()))
+        m64 = mean.double()
+        var64 = 1.0 / (invstd.double() * invstd.double()) - eps                  # biased variance of the local rows
+        acc = torch.cat([torch.full((1,), float(N), device=x.device, dtype=torch.float64), m64 * N, (var64 + m64 * m64) * N])
+        comm.all_reduce(acc, dist.ReduceOp.SUM)
+        n_glob = float(acc[0])
+        gm = acc[1:1 + Cc] / n_glob
+        gvar = (acc[1 + Cc:] / n_glob - gm * gm).clamp_min(0.0)
+        ginv = torch.rsqrt(gvar + eps)
+        mean, invstd = gm.float(), ginv.float()
+        scale = (g.double() * ginv).float()
+        y = ops.affine_cols(x, scale=scale, shift=(b.double() - gm * g.double() * ginv).float())
+        ctx.save_for_backward(x, mean, invstd, g)
+        ctx.comm, ctx.n_glob = comm, n_glob
+        stats_out.append((mean, invstd, n_glob))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        from . import ops
+        lib = _lib.load()
+        x, mean, invstd, g = ctx.saved_tensors
+        N, Cc = x.shape
+        dy = dy.contiguous()
+        dg, db = _f32(Cc, dev=x.device), _f32(Cc, dev=x.device)
+        scratch = torch.empty(lib.itr_bn_train_scratch_bytes(N, Cc), device=x.device, dtype=torch.uint8)
+        # the kernel's row sums with the GLOBAL mean / invstd: dg = sum dy*xhat, db = sum dy over the local rows (its dx, which
+        # would close the formula with local sums only, is discarded)
+        _lib.check(lib.itr_bn_train_bwd(_p(dy), _p(x), _p(mean), _p(invstd), _p(g), _p(torch.empty_like(x)), _p(dg), _p(db), N, Cc, _p(scratch),
+                                        _stream()))
+        tot = torch.cat([dg, db]).double()
+        ctx.comm.all_reduce(tot, dist.ReduceOp.SUM)
+        dg_g, db_g = tot[:Cc] / ctx.n_glob, tot[Cc:] / ctx.n_glob
+        gi = g.double() * invstd.double()
+        # dx = gamma*invstd * (dy - mean(dy) - xhat * mean(dy*xhat)),  xhat = (x - mean) * invstd
+        s_x = -gi * invstd.double() * dg_g
+        c = gi * (mean.double() * invstd.double() * dg_g - db_g)
+        dx = ops.affine_cols(x, scale=s_x.float(), shift=c.float(), residual=ops.affine_cols(dy, scale=gi.float(), shift=torch.zeros_like(g)))
+        return dx, dg, db, None, None, None
+
+
+_BN_SYNC = [None]
+
+
+class bn_sync:
+    """`with bn_sync(comm):` -- batch_norm_train inside normalises over the rows of ALL ranks (data-parallel train_emb)."""
+
+    def __init__(self, comm):
+        self.comm = comm if (comm is not None and comm.on) else None
+
+    def __enter__(self):
+        self.prev, _BN_SYNC[0] = _BN_SYNC[0], self.comm
+        return self
+
+    def __exit__(self, *exc):
+        _BN_SYNC[0] = self.prev
+        return False
+
+
 def batch_norm_train(x2d, bn):
     """nn.BatchNorm1d(x2d [N, C]) in training mode: batch statistics, and the module's running statistics updated like torch
-    (momentum, unbiased variance, num_batches_tracked)."""
+    (momentum, unbiased variance, num_batches_tracked).  Inside `bn_sync(comm)` the batch is the rows of all ranks."""
     stats = []
-    y = _BatchNormTrain.apply(x2d, bn.weight, bn.bias, bn.eps, stats)
-    mean, invstd = stats[0]
+    if _BN_SYNC[0] is not None:
+        y = _SyncBatchNormTrain.apply(x2d, bn.weight, bn.bias, bn.eps, stats, _BN_SYNC[0])
+        mean, invstd, N = stats[0]
+    else:
+        y = _BatchNormTrain.apply(x2d, bn.weight, bn.bias, bn.eps, stats)
+        (mean, invstd), N = stats[0], x2d.shape[0]
     with torch.no_grad():
-        N = x2d.shape[0]
         var_b = 1.0 / (invstd * invstd) - bn.eps
         mom = bn.momentum if bn.momentum is not None else 0.1
         bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)

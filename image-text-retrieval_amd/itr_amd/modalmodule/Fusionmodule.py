@@ -290,7 +290,7 @@ class S2VTAttModel(nn.Module):
         self.encoder = encoder
         self.decoder = decoder
 
-    def caption_loss_train(self, vid_feats, labels, masks, seeds, training=True):
+    def caption_loss_train(self, vid_feats, labels, masks, seeds, training=True, batch_total=None):
         """LanguageModelCriterion(caption_model(vid_feats, labels, 'train'), labels[:, 1:], masks[:, 1:])  (Models.py:303-313,
         Objectives.py:138-158) on the autograd tape: encoder GRU over the regions, then max_len - 1 teacher-forced decoder steps of
         attention -> GRU cell -> vocabulary projection -> log-softmax / masked NLL; sum over steps and rows / batch size."""
@@ -323,7 +323,8 @@ class S2VTAttModel(nn.Module):
         logits = ag.linear(torch.cat(hs, 0), dec.out.weight, dec.out.bias)
         tgt = labels[:, 1:steps + 1].t().reshape(-1)
         msk = masks[:, 1:steps + 1].t().reshape(-1)
-        return ag.nll_logsoftmax(logits, tgt, msk).sum() / B
+        # (data parallel: these rows are a shard, the divisor stays the size of the whole batch)
+        return ag.nll_logsoftmax(logits, tgt, msk).sum() / (B if batch_total is None else batch_total)
 
 
 class MultiViewMatching(nn.Module):

@@ -147,9 +147,10 @@ class base_module(nn.Module):
             seq = seq.abs()
         return img, seq, off, lens
 
-    def _step(self, loss, batch_size):
-        """backward -> clip_grad_norm_(params, grad_clip) -> Adam (Models.py:139-144, :220-225)."""
-        self._log('Loss', loss.detach(), batch_size)      # a device scalar like the reference's loss.data: no host sync here
+    def _step(self, loss, batch_size, logged=None):
+        """backward -> clip_grad_norm_(params, grad_clip) -> Adam (Models.py:139-144, :220-225).  `logged`: the value of the
+        whole batch when `loss` holds only this rank's part of a term (data parallel)."""
+        self._log('Loss', loss.detach() if logged is None else logged, batch_size)      # a device scalar like the reference's loss.data: no host sync here
         loss.backward()
         self.optimizer.step(max_norm=self.grad_clip if self.grad_clip > 0 else 0.0)
 
@@ -343,8 +344,21 @@ class VSRN(base_module):
         if not hasattr(self, '_seeds'):
             self._seeds = ag.DropoutSeeds()
         self._seeds.new_step()
+        comm = self._dp_comm()
+        n_batch = len(lengths)
+        if comm.on:
+            # data parallel: a strided shard through the towers (the BatchNorms of the GCN and of the image tower take their
+            # statistics over the rows of all ranks, ag.bn_sync), embeddings all-gathered, retrieval hinge replicated on the full
+            # batch; the captioning loss is a sum over rows / batch size, so every rank adds its shard's part of it
+            if n_batch < comm.world:
+                raise ValueError("data-parallel train_emb: batch of %d on %d ranks" % (n_batch, comm.world))
+            sel = torch.arange(comm.rank, n_batch, comm.world)
+            rows = [len(range(q, n_batch, comm.world)) for q in range(comm.world)]
+            images, captions, captions_mask = (t[sel.to(t.device)] for t in (images, captions, captions_mask))
+            lengths = [lengths[i] for i in sel.tolist()]
+            self._seeds.base += comm.rank * 7919                                                # other masks on other shards
         self.optimizer.zero_grad()
-        with torch.enable_grad():
+        with torch.enable_grad(), ag.bn_sync(comm):
             images, captions = self._dev(images), self._dev(captions)
             img, gcn_emb = self.img_enc.forward_train(images)
             te = self.txt_enc
@@ -355,13 +369,20 @@ class VSRN(base_module):
                 cap = ag.l2norm_rows(cap)
             if te.use_abs:
                 cap = cap.abs()
+            if comm.on:
+                img = ag.dp_gather_rows(img, comm, rows, reduce=False)
+                cap = ag.dp_gather_rows(cap, comm, rows, reduce=False)
             scores = (ag.order_scores if self.config['measure'] == 'order' else ag.cosine_scores)(img, cap)
             retrieval_loss = ops.hinge_loss(scores, self.config['margin'], self.config['max_violation'])
             caption_loss = self.caption_model.caption_loss_train(gcn_emb, captions, self._dev(captions_mask), self._seeds,
-                                                                 self.caption_model.training)
-            self._log('Loss_caption', caption_loss.detach(), img.size(0))
+                                                                 self.caption_model.training, batch_total=n_batch)
+            caption_total = caption_loss.detach()
+            if comm.on:
+                import torch.distributed as dist
+                caption_total = comm.all_reduce(caption_total.clone(), dist.ReduceOp.SUM)          # for the log only
+            self._log('Loss_caption', caption_total, img.size(0))
             self._log('Loss_retrieval', retrieval_loss.detach(), img.size(0))
-            self._step(retrieval_loss + caption_loss, img.size(0))
+            self._step(retrieval_loss + caption_loss, img.size(0), logged=retrieval_loss.detach() + caption_total)
 
 
 class SGRAF(base_module):
@@ -557,10 +578,28 @@ class CAMERA(base_module):
         if not hasattr(self, '_seeds'):
             self._seeds = ag.DropoutSeeds()
         self._seeds.new_step()
+        comm = self._dp_comm()
+        if comm.on:
+            # data parallel (like SAEM): a strided shard of the global batch through the towers -- every BatchNorm inside takes
+            # its statistics over the rows of ALL ranks (ag.bn_sync: one small all-reduce each way) -- then the multi-view
+            # embeddings, caption embeddings and summarisation matrices are all-gathered and the loss is evaluated replicated on
+            # the full batch, so the gathers' backward is a slice and only the parameter gradients are summed (Adam.step)
+            B = len(captions)
+            if B < comm.world:
+                raise ValueError("data-parallel train_emb: batch of %d on %d ranks" % (B, comm.world))
+            sel = torch.arange(comm.rank, B, comm.world)
+            rows = [len(range(q, B, comm.world)) for q in range(comm.world)]
+            images, boxes, imgs_wh, captions, captions_mask, captions_type_ids = (
+                t[sel.to(t.device)] for t in (images, boxes, imgs_wh, captions, captions_mask, captions_type_ids))
+            self._seeds.base += comm.rank * 7919                                                # other masks on other shards
         self.optimizer.zero_grad()
-        with torch.enable_grad():
+        with torch.enable_grad(), ag.bn_sync(comm):
             cap = self.txt_enc.forward_train(self._dev(captions), self._dev(captions_mask), self._dev(captions_type_ids), self._seeds)
             img, smry_mat = self.img_enc.forward_train(self._dev(images), self._dev(boxes), self._dev(imgs_wh), self._seeds)
+            if comm.on:
+                img = ag.dp_gather_rows(img, comm, rows, reduce=False)
+                cap = ag.dp_gather_rows(cap, comm, rows, reduce=False)
+                smry_mat = ag.dp_gather_rows(smry_mat, comm, rows, reduce=False)
             sim_mat = ag.mvm_scores(img, cap)
             ranking_loss = ops.hinge_loss(sim_mat, self.config['margin'], self.config['max_violation'])
             div_reg = self.crit_div(smry_mat)

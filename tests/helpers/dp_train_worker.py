@@ -43,7 +43,7 @@ if a.model == 'SCAN':
 cfg = C.build_config(over)
 cfg['vocab_size'] = 500
 cfg['img_dim'] = 128
-if a.model == 'SAEM':
+if a.model in ('SAEM', 'CAMERA'):
     # a tiny random BERT + transformer config (dropout 0: the shards of a data-parallel run draw other masks than one process)
     import json
     from itr_amd.modalmodule import bert
@@ -60,13 +60,28 @@ if a.model == 'SAEM':
     torch.save(bm.state_dict(), os.path.join(d, 'pytorch_model.bin'))
     cfg.update(bert_config_file=os.path.join(d, 'bert_config.json'), init_checkpoint=os.path.join(d, 'pytorch_model.bin'),
                trans_cfg=os.path.join(d, 'trans_cfg.json'), final_dims=32, embed_size=32, learning_rate=1e-3)
+    if a.model == 'CAMERA':
+        cfg.update(img_dim=24, head=2, smry_k=12, drop=0.0, smry_lamda=0.01)
+if a.model == 'VSRN':
+    cfg.update(img_dim=20, embed_size=32, word_dim=12, vocab_size=40, dim_vid=32, dim_hidden=16, dim_word=10, max_len=8, input_dropout_p=0.0,
+               rnn_dropout_p=0.0, learning_rate=2e-3)
 torch.manual_seed(1234)
 model = get_model(cfg)
+if a.model == 'VSRN':
+    model.caption_model.cuda()
 model.train_start()
 model.logger = LogCollector()
 rng = np.random.RandomState(7)
 B = a.batch
-losses, gnorms = [], []
+losses, gnorms, grads1 = [], [], []
+
+
+def keep_grads():
+    if not grads1:     # the (summed, unclipped) gradient of the first step, as Adam.step saw it
+        grads1.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().reshape(-1) for p in model.params
+                                 if p.requires_grad]).cpu().numpy())
+
+
 for step in range(a.steps):
     lens = sorted([int(x) for x in rng.randint(3, 15, size=B)], reverse=True)
     ids = torch.zeros(B, max(lens), dtype=torch.long)
@@ -74,6 +89,38 @@ for step in range(a.steps):
         ids[b, :l] = torch.from_numpy(rng.randint(4, 500, size=l))
     feats = torch.from_numpy(rng.randn(B, 36, 128).astype(np.float32))
     feats = feats / feats.norm(dim=-1, keepdim=True)
+    if a.model == 'VSRN':
+        # the VSRN loader's layout: every caption padded to max_len + 1 ids, all "lengths" equal (data_loader.py:100-121)
+        L = cfg['max_len'] + 1
+        ids = torch.zeros(B, L, dtype=torch.long)
+        mask = torch.zeros(B, L, dtype=torch.long)
+        for b in range(B):
+            l = int(rng.randint(3, L))
+            ids[b, :l] = torch.from_numpy(rng.randint(1, 40, size=l))
+            mask[b, :l] = 1
+        feats = torch.from_numpy(rng.randn(B, 36, 20).astype(np.float32))
+        model.train_emb((feats, None, None, ids, [L] * B, list(range(B)), mask, None))
+        losses.append(float(model.logger.meters['Loss'].val))
+        gnorms.append(float(model.optimizer.last_grad_norm[0]))
+        keep_grads()
+        continue
+    if a.model == 'CAMERA':
+        L = 14
+        ids = torch.from_numpy(rng.randint(1, 500, size=(B, L)))
+        mask = torch.zeros(B, L, dtype=torch.long)
+        for b, l in enumerate(lens):
+            mask[b, :l] = 1
+            ids[b, l:] = 0
+        feats = torch.from_numpy(rng.randn(B, 36, 24).astype(np.float32))
+        wh = torch.from_numpy(rng.randint(200, 640, size=(B, 2)).astype(np.float32))
+        xy = rng.rand(B, 36, 2, 2).astype(np.float32)
+        xy.sort(axis=2)                                                  # x0 <= x1, y0 <= y1 as fractions of the image
+        boxes = torch.from_numpy(np.concatenate([xy[:, :, 0], xy[:, :, 1]], -1)) * torch.cat([wh, wh], 1)[:, None, :]
+        model.train_emb((feats, boxes, wh, ids, lens, list(range(B)), mask, torch.zeros(B, L, dtype=torch.long)))
+        losses.append(float(model.logger.meters['Loss'].val))
+        gnorms.append(float(model.optimizer.last_grad_norm[0]))
+        keep_grads()
+        continue
     if a.model == 'SAEM':
         L = 14
         ids = torch.from_numpy(rng.randint(1, 500, size=(B, L)))
@@ -84,14 +131,16 @@ for step in range(a.steps):
         model.train_emb((feats, None, None, ids, lens, list(range(B)), mask, torch.zeros(B, L, dtype=torch.long)))
         losses.append(float(model.logger.meters['Loss1'].val) + float(model.logger.meters['Loss2'].val))
         gnorms.append(float(model.optimizer.last_grad_norm[0]))
+        keep_grads()
         continue
     model.train_emb((feats, None, None, ids, lens, list(range(B)), None, None))
     losses.append(float(model.logger.meters['Loss'].val))
     gnorms.append(float(model.optimizer.last_grad_norm[0]))
+    keep_grads()
 torch.cuda.synchronize()
 if world == 1 or dist.get_rank() == 0:
     flat = torch.cat([p.detach().reshape(-1) for p in model.params if p.requires_grad]).cpu().numpy()
-    np.savez(a.out, dp_on=int(model.optimizer.comm is not None), dp_world=(model.optimizer.comm.world if model.optimizer.comm is not None else 1), params=flat, losses=np.asarray(losses), gnorms=np.asarray(gnorms), lr=cfg['learning_rate'])
+    np.savez(a.out, dp_on=int(model.optimizer.comm is not None), dp_world=(model.optimizer.comm.world if model.optimizer.comm is not None else 1), params=flat, grads1=grads1[0], losses=np.asarray(losses), gnorms=np.asarray(gnorms), lr=cfg['learning_rate'])
 if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()

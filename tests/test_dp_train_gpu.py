@@ -34,15 +34,35 @@ def _run(tmp_path, tag, world, extra):
     (["--model", "SCAN", "--cross-attn", "i2t"], 2),
     (["--model", "VSE_PP"], 2),
     (["--model", "SAEM", "--batch", "11"], 2),                            # both embedding sets gathered, losses replicated
+    (["--model", "CAMERA", "--batch", "13"], 2),                          # + BatchNorm statistics over the rows of all ranks
+    (["--model", "CAMERA", "--batch", "10"], 3),
+    (["--model", "VSRN", "--batch", "13"], 2),                            # + the captioning loss: every rank its rows' part
 ])
 def test_dp_train_step_equals_single_process(tmp_path, extra, world):
     one = _run(tmp_path, "one", 1, extra)
     dp = _run(tmp_path, "dp", world, extra)
     assert int(one["dp_world"]) == 1 and int(dp["dp_world"]) == world      # the sharded step really ran
     lr = float(one["lr"])
+    # the gradient of the first step (identical parameters on both sides): the sharded towers, the gathers' backward, the
+    # all-rank BatchNorm statistics and the parameter-gradient all-reduce together reproduce the single-process gradient
+    g1, g2 = one["grads1"], dp["grads1"]
+    # CAMERA: BatchNorm divides by a batch std of ~0.1 and fp32 rounding grows to 4e-5 .. 8e-5 (measured; the synchronised
+    # BatchNorm itself is checked exactly in test_train_camera_gpu.py).  With --batch 11 the data sit on a non-smooth point of
+    # the summarisation (relu / max over views) and 2 and 3 ranks alike differ by 2e-4 from one process, so other sizes are used.
+    tol = 2e-4 if ("CAMERA" in extra or "VSRN" in extra) else 2e-5
+    assert g1.shape == g2.shape and np.linalg.norm(g1 - g2) <= tol * np.linalg.norm(g1), np.linalg.norm(g1 - g2) / np.linalg.norm(g1)
+    d = np.abs(dp["params"] - one["params"])
+    if "CAMERA" in extra or "VSRN" in extra:
+        # Adam moves a parameter whose gradient is ~0 at the initial point (|g| ~ 1e-8: ~0.1 % of CAMERA's) by +-lr, the sign
+        # decided by rounding; from the second step on those parameters do matter, so later losses agree to ~1e-3 only
+        np.testing.assert_allclose(dp["losses"][:1], one["losses"][:1], rtol=2e-5)
+        np.testing.assert_allclose(dp["gnorms"][:1], one["gnorms"][:1], rtol=1e-4)
+        np.testing.assert_allclose(dp["losses"], one["losses"], rtol=3e-3)
+        # (the first-step gradient above is the sharp check; three Adam steps later most parameters still agree to 1e-6)
+        assert d.max() <= 2 * len(one["losses"]) * lr + 1e-7 and np.median(d) <= 2e-6 and d.mean() <= 5e-5, (d.max(), np.median(d), d.mean())
+        return
     np.testing.assert_allclose(dp["losses"], one["losses"], rtol=2e-5, atol=1e-5)
     np.testing.assert_allclose(dp["gnorms"], one["gnorms"], rtol=1e-4)
-    d = np.abs(dp["params"] - one["params"])
     # Adam turns a 1e-7 difference of a gradient with |g| ~ eps into a difference of up to lr per step
     assert d.max() <= 3 * lr + 1e-7 and d.mean() <= 2e-6, (d.max(), d.mean())
 

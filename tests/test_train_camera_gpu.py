@@ -66,6 +66,67 @@ def test_batch_norm_train(dev):
         assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1
 
 
+class _ReplayComm:
+    """One rank of a data-parallel BatchNorm, the other ranks' contributions replayed: pass `record` collects what this rank
+    adds to each all-reduce, pass `replay` returns the recorded sum over all ranks (the forward contribution depends on the local
+    rows only, the backward one on the global statistics and the local dy, so three passes give the exact distributed result)."""
+    on = True
+
+    def __init__(self, log, totals=None):
+        self.log, self.totals, self.i = log, totals, 0
+
+    def all_reduce(self, t, op):
+        self.log.append(t.clone())
+        if self.totals is not None and self.i < len(self.totals):
+            t.copy_(self.totals[self.i])
+        self.i += 1
+        return t
+
+
+def test_batch_norm_train_over_row_shards_of_several_ranks(dev):
+    """ag.bn_sync: BatchNorm on ragged row shards (7 / 4 / 9 rows) with the statistics of all rows == one BatchNorm on the whole
+    batch: y, dx, the SUM of the ranks' local gamma / beta gradients, and the running statistics."""
+    torch.manual_seed(5)
+    N, Cc, cuts = 20, 70, (0, 7, 11, 20)
+    x, dy = torch.randn(N, Cc) * 2 + 0.5, torch.randn(N, Cc)
+    ref = torch.nn.BatchNorm1d(Cc).double()
+    ref.weight.data.uniform_(0.5, 1.5); ref.bias.data.normal_(0, 0.1)
+    X = x.double().requires_grad_(True)
+    ref.train()
+    want = ref(X)
+    want.backward(dy.double())
+    sd = {k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()}
+    init = {k: v.clone() for k, v in torch.nn.BatchNorm1d(Cc).state_dict().items()}
+    init.update(weight=sd['weight'], bias=sd['bias'])
+
+    def run_all(totals_f, totals_b):
+        out = []
+        for q in range(3):
+            bn = torch.nn.BatchNorm1d(Cc)
+            bn.load_state_dict(init)
+            bn.to(dev)
+            log = []
+            gx = x[cuts[q]:cuts[q + 1]].to(dev).requires_grad_(True)
+            with ag.bn_sync(_ReplayComm(log, None if totals_f is None else [totals_f] + ([totals_b] if totals_b is not None else []))):
+                y = ag.batch_norm_train(gx, bn)
+                y.backward(dy[cuts[q]:cuts[q + 1]].to(dev))
+            out.append((y, gx.grad, bn, log))
+        return out
+
+    p1 = run_all(None, None)                                             # records the forward contributions
+    tf = sum(o[3][0] for o in p1)
+    p2 = run_all(tf, None)                                               # right statistics; records the backward contributions
+    tb = sum(o[3][1] for o in p2)
+    p3 = run_all(tf, tb)
+    _cmp(torch.cat([o[0] for o in p3]), want, 2e-5)
+    _cmp(torch.cat([o[1] for o in p3]), X.grad, 5e-5)
+    _cmp(sum(o[2].weight.grad for o in p3), ref.weight.grad, 2e-4)
+    _cmp(sum(o[2].bias.grad for o in p3), ref.bias.grad, 2e-4)
+    for o in p3:
+        _cmp(o[2].running_mean, ref.running_mean, 1e-5); _cmp(o[2].running_var, ref.running_var, 1e-4)
+        assert int(o[2].num_batches_tracked) == 1
+
+
 def test_l2norm_mid_summarize_mvm(dev):
     torch.manual_seed(2)
     B, R, D, K = 4, 36, 70, 12
