@@ -203,13 +203,14 @@ def _saf_train(saf, x, G, training):
     return ag.l2norm_rows(sim_saf, eps=1e-8)
 
 
-def encoder_similarity_train(sim_enc, img_emb, words, tok_off, lens, seeds, training=True, max_group=32):
+def encoder_similarity_train(sim_enc, img_emb, words, tok_off, lens, seeds, training=True, max_group=32, seeds_global=None):
     """EncoderSimilarity.forward in training mode: img_emb [B, 36, D], packed word embeddings words [n_tok, D] with caption c at
     rows tok_off[c] .. tok_off[c] + lens[c] -> sims [B, n_caption].  Consecutive captions of the same length (collate_fn sorts by
     length) are processed as one group: the arithmetic per caption is the reference's, the launches are shared."""
     from .. import autograd as ag
     B, R, D = img_emb.shape
-    img_glo = _sa_train(sim_enc.v_global_w, img_emb, ag.mean_mid(img_emb), seeds, training)
+    # (data parallel: every rank computes the global image vectors of the whole batch, with the same dropout masks -- seeds_global)
+    img_glo = _sa_train(sim_enc.v_global_w, img_emb, ag.mean_mid(img_emb), seeds_global or seeds, training)
     cols = []
     c = 0
     while c < len(lens):

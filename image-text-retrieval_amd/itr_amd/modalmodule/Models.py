@@ -428,11 +428,27 @@ class SGRAF(base_module):
             self._seeds = ag.DropoutSeeds()
         self._seeds.new_step()
         self.optimizer.zero_grad()
+        comm = self._dp_comm()
+        shared = None
+        if comm.on:
+            # data parallel by CAPTION (the similarity module works caption by caption, each against all images): towers on a
+            # strided shard, region embeddings all-gathered (every rank holds a partial gradient for all of them: summed in the
+            # gather's backward), this rank's columns of the B x B matrix, columns all-gathered, hinge replicated.  The global
+            # image vectors (VisualSA: BatchNorm over the image batch) are computed replicated on the gathered embeddings with the
+            # same dropout masks everywhere; all other dropout sites draw other masks on other shards.
+            images, captions, lengths, rows, _, _ = self._dp_shard(comm, images, captions, lengths)
+            shared = ag.DropoutSeeds()
+            shared.base, shared.n = self._seeds.base, 2048
+            self._seeds.base += comm.rank * 7919
         with torch.enable_grad():
             img, words, off, lens = self._train_towers(images, captions, lengths, pooled_images=False, last_state=False)
+            if comm.on:
+                img = ag.dp_gather_rows(img, comm, rows, reduce=True)
             off_host = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
             sims = Fusionmodule.encoder_similarity_train(self.sim_enc, img, words, off_host, [int(x) for x in lens], self._seeds,
-                                                         self.sim_enc.training)
+                                                         self.sim_enc.training, seeds_global=shared)
+            if comm.on:
+                sims = ag.dp_gather_rows(sims.t().contiguous(), comm, rows, reduce=False).t()      # (images, captions), both rank-major
             loss = ops.hinge_loss(sims, self.config['margin'], self.config['max_violation'])
             self._step(loss, sims.size(0))
 

@@ -15,6 +15,7 @@ import torch.distributed as dist
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="SCAN")
 ap.add_argument("--cross-attn", default="t2i")
+ap.add_argument("--module-name", default="SAF")
 ap.add_argument("--batch", type=int, default=24)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--out", required=True)
@@ -40,9 +41,13 @@ from itr_amd.metricmodule.evaluation import LogCollector          # noqa: E402
 over = ['with', a.model, 'data_name=coco_precomp', 'bi_gru=True', 'max_violation=True', 'embed_size=256', 'word_dim=64']
 if a.model == 'SCAN':
     over.append('cross_attn=' + a.cross_attn)
+if a.model == 'SGRAF':
+    over.append('module_name=' + a.module_name)
 cfg = C.build_config(over)
 cfg['vocab_size'] = 500
 cfg['img_dim'] = 128
+if a.model == 'SGRAF':
+    cfg.update(embed_size=32, word_dim=16, sim_dim=16, sgr_step=3, learning_rate=2e-3)
 if a.model in ('SAEM', 'CAMERA'):
     # a tiny random BERT + transformer config (dropout 0: the shards of a data-parallel run draw other masks than one process)
     import json
@@ -69,6 +74,12 @@ torch.manual_seed(1234)
 model = get_model(cfg)
 if a.model == 'VSRN':
     model.caption_model.cuda()
+if a.model == 'SGRAF':
+    # the reference hard-codes p = 0.4 dropout sites; the shards of a data-parallel run draw other masks than one process
+    model.txt_enc.dropout_p = 0.0
+    for m_ in model.sim_enc.modules():
+        if isinstance(m_, torch.nn.Dropout):
+            m_.p = 0.0
 model.train_start()
 model.logger = LogCollector()
 rng = np.random.RandomState(7)
