@@ -89,7 +89,12 @@ def test_dp_train_step_over_rccl_single_rank(tmp_path):
 
 
 @pytest.mark.gpu
-def test_dp_train_command_line(golden, tmp_path):
+@pytest.mark.parametrize("model_name,model_args", [
+    ("SCAN", ["bi_gru=True"]),
+    # a BatchNorm model: statistics over the rows of both ranks, captioning loss split by rows
+    ("VSRN", ["dim_vid=32", "dim_hidden=16", "dim_word=10", "max_len=8", "input_dropout_p=0.0", "rnn_dropout_p=0.0"]),
+])
+def test_dp_train_command_line(golden, tmp_path, model_name, model_args):
     """`python -m torch.distributed.run --nproc-per-node 2 train.py with SCAN ...` (gloo, both ranks on this GPU): same
     global batches, sharded step, row-sharded validation, rank 0 writes ONE run directory -- and the checkpoint after
     an epoch matches the single-process run's."""
@@ -112,9 +117,9 @@ def test_dp_train_command_line(golden, tmp_path):
     cks = {}
     for world in (1, 2):
         runs = str(tmp_path / ('runs%d' % world))
-        args = [train_py, "with", "SCAN", "data_name=%s" % name, "data_path=%s" % (tmp_path / 'data'), "vocab_path=%s" % vdir,
+        args = [train_py, "with", model_name, "data_name=%s" % name, "data_path=%s" % (tmp_path / 'data'), "vocab_path=%s" % vdir,
                 "save_path=%s" % runs, "num_epochs=1", "batch_size=20", "val_step=100", "log_step=5", "workers=0", "img_dim=8",
-                "embed_size=32", "word_dim=16", "bi_gru=True", "max_violation=True", "seed=3", "learning_rate=0.002"]
+                "embed_size=32", "word_dim=16", "max_violation=True", "seed=3", "learning_rate=0.002"] + model_args
         if world == 1:
             cmd, env = [sys.executable] + args, dict(os.environ)
         else:
@@ -123,13 +128,18 @@ def test_dp_train_command_line(golden, tmp_path):
                    "--master-addr", "127.0.0.1", "--master-port", "29633"] + args
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-        run_dirs = glob.glob(os.path.join(runs, "SCAN", "toy_3_*"))
+        run_dirs = glob.glob(os.path.join(runs, model_name, "toy_3_*"))
         assert len(run_dirs) == 1, run_dirs
         cks[world] = torch.load(os.path.join(run_dirs[0], 'epo0_checkpoint.pth.tar'), map_location='cpu', weights_only=False)
     assert cks[1]['Eiters'] == cks[2]['Eiters'] == 10
     assert cks[1]['best_rsum'] == pytest.approx(cks[2]['best_rsum'], abs=1.0)
     for a, b in zip(cks[1]['model'], cks[2]['model']):
         for k in a:
+            if not a[k].is_floating_point():
+                assert int(a[k]) == int(b[k]), k               # num_batches_tracked
+                continue
             dmax = (a[k] - b[k]).abs().max().item()
             assert dmax <= 10 * 3 * 0.002, (k, dmax)       # 10 Adam steps, each may move a |g| ~ eps weight by up to lr
-            assert (a[k] - b[k]).abs().mean().item() <= 2e-4, k
+            # (a convolution bias directly in front of a BatchNorm -- the GCN's W.0.bias -- has a vanishing true gradient: Adam
+            # random-walks it by +-lr per step in both runs, and BatchNorm removes it again -- its running mean follows the bias)
+            assert k.endswith(('W.0.bias', 'W.1.running_mean')) or (a[k] - b[k]).abs().mean().item() <= 2e-4, k
