@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -35,6 +35,10 @@ SIGNATURES = {
     "itr_relu_maxpool_arg": (i32, [vp, i64, i32, i32, vp, vp, vp]),
     "itr_relu_maxpool_bwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "itr_bcast_mid": (i32, [vp, vp, i64, i32, i32, f32, vp]),
+    "itr_angular_fwd": (i32, [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp]),
+    "itr_angular_bwd": (i32, [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "itr_diversity_fwd": (i32, [vp, i64, i32, i32, vp, vp, vp]),
+    "itr_diversity_bwd": (i32, [vp, i64, i32, i32, vp, vp, vp]),
     "itr_ew_mul": (i32, [vp, vp, vp, i64, vp]),
     "itr_act_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
     "itr_gate_apply": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),

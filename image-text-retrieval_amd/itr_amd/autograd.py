@@ -588,6 +588,68 @@ def mean_mid(x):
     return _MeanMid.apply(x)
 
 
+class _Angular(torch.autograd.Function):
+    """AngularLoss.angular_loss on M1 = anchors others^T, M2 = positives others^T, Q = anchors positives^T (Objectives.py:262-290)."""
+
+    @staticmethod
+    def forward(ctx, M1, M2, Q, angle_bound, max_violation):
+        lib = _lib.load()
+        M1, M2, Q = _dev(M1, name="M1"), _dev(M2, name="M2"), _dev(Q, name="Q")
+        n = M1.shape[0]
+        if not (tuple(M1.shape) == tuple(M2.shape) == tuple(Q.shape) == (n, n)):
+            raise ValueError("angular_loss: needs three n x n matrices, got %s %s %s" % (tuple(M1.shape), tuple(M2.shape), tuple(Q.shape)))
+        dev = M1.device
+        loss, row, stat, den = _f32(1, dev=dev), _f32(n, dev=dev), _f32(n, dev=dev), _f32(n, dev=dev)
+        arg = torch.empty(n, device=dev, dtype=torch.int32)
+        _lib.check(lib.itr_angular_fwd(_p(M1), _p(M2), _p(Q), n, float(angle_bound), int(bool(max_violation)), _p(loss), _p(row), _p(stat),
+                                       _p(den), _p(arg), _stream()))
+        ctx.save_for_backward(M1, M2, Q, stat, den, arg)
+        ctx.cfg = (float(angle_bound), int(bool(max_violation)))
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        M1, M2, Q, stat, den, arg = ctx.saved_tensors
+        n = M1.shape[0]
+        dM, dQ = torch.empty_like(M1), torch.empty_like(Q)
+        _lib.check(lib.itr_angular_bwd(_p(M1), _p(M2), _p(Q), n, ctx.cfg[0], ctx.cfg[1], _p(stat), _p(den), _p(arg),
+                                       _p(g.contiguous().reshape(1).float()), _p(dM), _p(dQ), _stream()))
+        return dM, dM, dQ, None, None
+
+
+def angular_loss(anchors, positives, others, angle_bound=1.0, max_violation=True):
+    """One direction of SAEM's AngularLoss: three GEMMs + the row kernel, differentiable w.r.t. all three inputs."""
+    return _Angular.apply(linear(anchors, others), linear(positives, others), linear(anchors, positives), angle_bound, max_violation)
+
+
+class _Diversity(torch.autograd.Function):
+    """DiversityRegularization (Objectives.py:521-542) of smry [B, R, K]."""
+
+    @staticmethod
+    def forward(ctx, smry):
+        lib = _lib.load()
+        smry = _dev(smry, name="smry_mat")
+        B, R, K = smry.shape
+        part, loss = _f32(max(B, 1), dev=smry.device), _f32(1, dev=smry.device)
+        _lib.check(lib.itr_diversity_fwd(_p(smry), B, R, K, _p(part), _p(loss), _stream()))
+        ctx.save_for_backward(smry)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        smry, = ctx.saved_tensors
+        B, R, K = smry.shape
+        d = torch.empty_like(smry)
+        _lib.check(lib.itr_diversity_bwd(_p(smry), B, R, K, _p(g.contiguous().reshape(1).float()), _p(d), _stream()))
+        return d
+
+
+def diversity_reg(smry_mat):
+    return _Diversity.apply(smry_mat)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # CAMERA towers: elementwise product, activations, attention gate, training-mode BatchNorm, l2norm across regions,
 # multi-view summarisation, multi-view matching

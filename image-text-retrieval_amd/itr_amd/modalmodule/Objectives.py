@@ -97,8 +97,8 @@ class TripletLoss(nn.Module):
 
 
 class DiversityRegularization(nn.Module):
-    """CAMERA diversity regulariser (Objectives.py:521-542).  Training-time auxiliary (torch
-    composition accepted): runs as torch ops on the GPU, not as a dedicated kernel."""
+    """CAMERA diversity regulariser (Objectives.py:521-542): sum over images of || Sn^T Sn - I ||_F^2 with the columns of the
+    summarisation matrix l2-normalised over the regions -- one HIP kernel each way (csrc/aux_loss.hip)."""
 
     def __init__(self, smry_k, batch_size):
         super().__init__()
@@ -106,13 +106,16 @@ class DiversityRegularization(nn.Module):
         self.batch_size = batch_size
 
     def forward(self, smry_mat):
-        s = torch.nn.functional.normalize(smry_mat, dim=1)
-        d = torch.matmul(s.transpose(1, 2), s) - torch.eye(self.smry_k, device=s.device).unsqueeze(0)
-        return (d ** 2).sum()
+        from .. import autograd as ag
+        if smry_mat.shape[-1] != self.smry_k:
+            raise RuntimeError("DiversityRegularization: %d views, built for %d" % (smry_mat.shape[-1], self.smry_k))
+        return ag.diversity_reg(smry_mat)
 
 
 class AngularLoss(nn.Module):
-    """SAEM angular loss (Objectives.py:238-290); training-time auxiliary composed of torch GPU ops."""
+    """SAEM angular loss (Objectives.py:238-290): per anchor, x_j = 4 ab (a + p).n_j - 2 (1 + ab) a.p over the other rows of the
+    batch as negatives; soft-plus of the hardest (max_violation) or log(1 + sum exp).  Three GEMMs + a row kernel each way
+    (csrc/aux_loss.hip)."""
 
     def __init__(self, l2_reg=0.02, angle_bound=1., lambda_ang=2, max_violation=True):
         super().__init__()
@@ -125,15 +128,5 @@ class AngularLoss(nn.Module):
         return self.angular_loss(im, s, s) + self.angular_loss(s, im, im)
 
     def angular_loss(self, anchors, positives, others):
-        n = anchors.shape[0]
-        idx = torch.tensor([[j for j in range(n) if j != i] for i in range(n)], dtype=torch.long, device=anchors.device)
-        neg = others[idx]
-        a, p = anchors.unsqueeze(1), positives.unsqueeze(1)
-        ab = self.angle_bound
-        x = 4. * ab * torch.matmul(a + p, neg.transpose(1, 2)) - 2. * (1. + ab) * torch.matmul(a, p.transpose(1, 2))
-        if self.max_violation:
-            return torch.log(1 + torch.exp(x.max(2)[0])).sum()
-        with torch.no_grad():
-            t = torch.max(x, dim=2)[0]
-        x = torch.exp(x - t.unsqueeze(dim=1))
-        return torch.mean(t + torch.log(torch.exp(-t) + torch.sum(x, 2)))
+        from .. import autograd as ag
+        return ag.angular_loss(anchors, positives, others, self.angle_bound, self.max_violation)

@@ -333,6 +333,22 @@ int itr_relu_maxpool_bwd(const float *dy, const int32_t *arg, int64_t B, int npo
 /* backward of torch.mean(x, 1): dx[b, r, :] = scale * dy[b, :]. */
 int itr_bcast_mid(const float *dy, float *dx, int64_t B, int R, int F, float scale, itr_stream_t stream);
 
+/* ---- a18: training-only auxiliary losses (csrc/aux_loss.hip) ---------------------------------------------------------------
+ * AngularLoss.angular_loss (Objectives.py:262-290) on its three n x n products M1 = anchors others^T, M2 = positives others^T,
+ * Q = anchors positives^T (row-major, ld = n):  x[i][j] = 4 ab (M1 + M2)[i][j] - 2 (1 + ab) Q[i][i] over the j != i;
+ *   max_violation:  loss = sum_i log(1 + exp(max_j x[i][j]))                 (stat = max, arg = its first column)
+ *   otherwise:      loss = mean_i log(1 + sum_j exp(x[i][j])), evaluated as t + log(exp(-t) + sum exp(x - t))   (stat = t, den)
+ * row / stat / den / arg are [n] scratch the backward reads; loss and grad_loss are device scalars.  The backward writes the
+ * gradient of M1 (== that of M2) to dM and that of Q (its diagonal) to dQ, both dense [n, n]. */
+int itr_angular_fwd(const float *M1, const float *M2, const float *Q, int n, float angle_bound, int max_violation, float *loss,
+                    float *row, float *stat, float *den, int32_t *arg, itr_stream_t stream);
+int itr_angular_bwd(const float *M1, const float *M2, const float *Q, int n, float angle_bound, int max_violation, const float *stat,
+                    const float *den, const int32_t *arg, const float *grad_loss, float *dM, float *dQ, itr_stream_t stream);
+/* DiversityRegularization (Objectives.py:521-542): smry [B, R, K] -> sum_b || Sn_b^T Sn_b - I ||_F^2 with Sn = F.normalize(S, dim=1)
+ * (columns over the R regions, eps 1e-12).  part: [B] scratch; loss / grad_loss device scalars; R*K + K*K + K <= 15360. */
+int itr_diversity_fwd(const float *smry, int64_t B, int R, int K, float *part, float *loss, itr_stream_t stream);
+int itr_diversity_bwd(const float *smry, int64_t B, int R, int K, const float *grad_loss, float *d_smry, itr_stream_t stream);
+
 /* ---- CAMERA towers under autograd (camera_.py:14-114, ImgEncoder.py:355-389, TextEncoder.py:162-192, Fusionmodule.py:674-692):
  * the pieces between the dense layers ---------------------------------------------------------------------------------------
  * out = a * b (backward: two more calls). */
