@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="SCAN")
 ap.add_argument("--cross-attn", default="t2i")
 ap.add_argument("--module-name", default="SAF")
+ap.add_argument("--live-dropout", action="store_true")
 ap.add_argument("--batch", type=int, default=24)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--out", required=True)
@@ -74,7 +75,7 @@ torch.manual_seed(1234)
 model = get_model(cfg)
 if a.model == 'VSRN':
     model.caption_model.cuda()
-if a.model == 'SGRAF':
+if a.model == 'SGRAF' and not a.live_dropout:
     # the reference hard-codes p = 0.4 dropout sites; the shards of a data-parallel run draw other masks than one process
     model.txt_enc.dropout_p = 0.0
     for m_ in model.sim_enc.modules():

@@ -71,6 +71,19 @@ def test_dp_train_step_equals_single_process(tmp_path, extra, world):
 
 
 @pytest.mark.gpu
+def test_dp_train_step_with_live_dropout(tmp_path):
+    """SGRAF with its hard-coded p = 0.4 dropout sites on two ranks: the shards draw their own masks (the replicated global image
+    vectors share one), so the numbers differ from one process -- but the step runs, stays finite and the loss is of the same size."""
+    extra = ["--model", "SGRAF", "--module-name", "SAF", "--batch", "12", "--live-dropout"]
+    one = _run(tmp_path, "one", 1, extra)
+    dp = _run(tmp_path, "dp", 2, extra)
+    assert int(dp["dp_world"]) == 2
+    assert np.isfinite(dp["losses"]).all() and np.isfinite(dp["params"]).all() and np.isfinite(dp["gnorms"]).all()
+    assert np.abs(dp["losses"] - one["losses"]).max() > 1e-6                  # really other masks
+    np.testing.assert_allclose(dp["losses"], one["losses"], rtol=0.2)
+
+
+@pytest.mark.gpu
 def test_dp_train_step_over_rccl_single_rank(tmp_path):
     """The same sharded step with backend nccl (= RCCL) and ITR_FORCE_COLLECTIVES=1: one rank, but every collective of
     the data-parallel path (row all-gathers, the gradient all-reduce of the gather's backward, the flat parameter-gradient
