@@ -84,11 +84,15 @@ def test_dp_train_step_with_live_dropout(tmp_path):
 
 
 @pytest.mark.gpu
-def test_dp_train_step_over_rccl_single_rank(tmp_path):
+@pytest.mark.parametrize("extra", [
+    ["--model", "SCAN", "--cross-attn", "t2i"],
+    ["--model", "CAMERA", "--batch", "12"],                 # + the float64 statistics all-reduces of the all-rank BatchNorm
+    ["--model", "SGRAF", "--module-name", "SAF", "--batch", "12"],
+])
+def test_dp_train_step_over_rccl_single_rank(tmp_path, extra):
     """The same sharded step with backend nccl (= RCCL) and ITR_FORCE_COLLECTIVES=1: one rank, but every collective of
     the data-parallel path (row all-gathers, the gradient all-reduce of the gather's backward, the flat parameter-gradient
     bucket) really goes through RCCL on device buffers -- the only way to touch it on a 1-GPU box."""
-    extra = ["--model", "SCAN", "--cross-attn", "t2i"]
     one = _run(tmp_path, "one", 1, extra)
     out = str(tmp_path / "rccl.npz")
     env = dict(os.environ, ITR_FORCE_COLLECTIVES="1", ITR_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29657",
@@ -97,8 +101,12 @@ def test_dp_train_step_over_rccl_single_rank(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     got = np.load(out)
     assert int(got["dp_on"]) == 1 and int(one["dp_on"]) == 0
-    np.testing.assert_allclose(got["losses"], one["losses"], rtol=2e-5, atol=1e-5)
-    assert np.abs(got["params"] - one["params"]).max() <= 3 * float(one["lr"]) + 1e-7
+    g1, g2 = one["grads1"], got["grads1"]
+    assert np.linalg.norm(g1 - g2) <= 2e-4 * np.linalg.norm(g1)
+    np.testing.assert_allclose(got["losses"][:1], one["losses"][:1], rtol=2e-5, atol=1e-5)
+    if "SCAN" in extra:
+        np.testing.assert_allclose(got["losses"], one["losses"], rtol=2e-5, atol=1e-5)
+    assert np.abs(got["params"] - one["params"]).max() <= 2 * len(one["losses"]) * float(one["lr"]) + 1e-7
 
 
 @pytest.mark.gpu
