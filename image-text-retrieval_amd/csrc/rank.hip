@@ -147,7 +147,212 @@ __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__r
         }
 }
 
+// ---- float64 similarity matrices ------------------------------------------------------------
+// The reference ranks the float64 matrix cal_sims returns (evaluation.py:169, :209), and the
+// ensemble path averages two models in float64 first (evaluation.py:380, :398): scores that differ
+// in float64 may collapse in fp32, so those matrices are counted in float64.  Same scheme as above
+// with 16-byte double2 loads; the arg-max key (64-bit ordered score) no longer fits next to the
+// index, so t2i's top-1 takes a second pass: max key per column first, then the highest row
+// holding it.
+__device__ __forceinline__ unsigned long long double_order_key(double d) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__global__ void gather_gt_f64_kernel(const double *__restrict__ S, int64_t ldS, int64_t row0, int64_t nrows,
+                                     int64_t Nc, int im_div, double *__restrict__ s_gt) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Nc) return;
+    const int64_t g = j / im_div - row0;
+    if (g >= 0 && g < nrows) s_gt[j] = S[g * ldS + j];
+}
+
+__global__ __launch_bounds__(RANK_THREADS) void i2t_rank_f64_kernel(const double *__restrict__ S, int64_t ldS,
+                                                                    int64_t row0, int64_t Nc, int im_div,
+                                                                    int32_t *__restrict__ rank_out,
+                                                                    int32_t *__restrict__ top1_out) {
+    __shared__ int s_cnt[RANK_THREADS / 64][MAX_IMDIV];
+    __shared__ unsigned long long s_key[RANK_THREADS / 64];
+    __shared__ int s_idx[RANK_THREADS / 64];
+    const int64_t r = blockIdx.x;
+    const double *row = S + r * ldS;
+    const int64_t gi = row0 + r;
+    double gt[MAX_IMDIV];
+    int64_t gidx[MAX_IMDIV];
+    int cnt[MAX_IMDIV];
+#pragma unroll
+    for (int g = 0; g < MAX_IMDIV; ++g) {
+        gidx[g] = gi * im_div + g;
+        const bool ok = g < im_div && gidx[g] < Nc;
+        gt[g] = ok ? row[gidx[g]] : (double)INFINITY;
+        cnt[g] = 0;
+    }
+    unsigned long long bkey = 0;
+    int bidx = -1;  // columns are visited in increasing order per lane: >= keeps the highest index
+    const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+    const int64_t nvec = vec ? (Nc >> 1) : 0;
+    for (int64_t c = threadIdx.x; c < nvec; c += RANK_THREADS) {
+        const double2 v = reinterpret_cast<const double2 *>(row)[c];
+        const double e[2] = {v.x, v.y};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t k = c * 2 + u;
+            const unsigned long long key = double_order_key(e[u]);
+            if (key >= bkey) { bkey = key; bidx = (int)k; }
+#pragma unroll
+            for (int g = 0; g < MAX_IMDIV; ++g)
+                cnt[g] += (e[u] > gt[g]) || (e[u] == gt[g] && k > gidx[g]);
+        }
+    }
+    for (int64_t k = nvec * 2 + threadIdx.x; k < Nc; k += RANK_THREADS) {
+        const double e = row[k];
+        const unsigned long long key = double_order_key(e);
+        if (key >= bkey) { bkey = key; bidx = (int)k; }
+#pragma unroll
+        for (int g = 0; g < MAX_IMDIV; ++g) cnt[g] += (e > gt[g]) || (e == gt[g] && k > gidx[g]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int g = 0; g < MAX_IMDIV; ++g) cnt[g] = wave_sum_i(cnt[g]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long okey = __shfl_xor(bkey, o, 64);
+        const int oidx = __shfl_xor(bidx, o, 64);
+        if (okey > bkey || (okey == bkey && oidx > bidx)) { bkey = okey; bidx = oidx; }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < MAX_IMDIV; ++g) s_cnt[wave][g] = cnt[g];
+        s_key[wave] = bkey;
+        s_idx[wave] = bidx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int rank = 0x7fffffff;
+        for (int g = 0; g < im_div; ++g) {
+            if (gi * im_div + g >= Nc) break;
+            int t = 0;
+            for (int w = 0; w < RANK_THREADS / 64; ++w) t += s_cnt[w][g];
+            rank = t < rank ? t : rank;
+        }
+        unsigned long long k = 0;
+        int b = -1;
+        for (int w = 0; w < RANK_THREADS / 64; ++w)
+            if (s_key[w] > k || (s_key[w] == k && s_idx[w] > b)) { k = s_key[w]; b = s_idx[w]; }
+        rank_out[r] = rank;
+        top1_out[r] = b;
+    }
+}
+
+// PASS 0: counts + max key per column; PASS 1: highest global row whose key equals best_key.
+template <int PASS>
+__global__ __launch_bounds__(RANK_THREADS) void t2i_rank_f64_kernel(const double *__restrict__ S, int64_t ldS,
+                                                                    int64_t row0, int64_t nrows, int64_t Nc,
+                                                                    int im_div, const double *__restrict__ s_gt,
+                                                                    int32_t *__restrict__ rank_acc,
+                                                                    unsigned long long *__restrict__ best_key,
+                                                                    int32_t *__restrict__ best_row) {
+    const int64_t c0 = ((int64_t)blockIdx.x * RANK_THREADS + threadIdx.x) * 2;
+    if (c0 >= Nc) return;
+    const int64_t r_begin = (int64_t)blockIdx.y * T2I_ROWS;
+    const int64_t r_end = (r_begin + T2I_ROWS < nrows) ? r_begin + T2I_ROWS : nrows;
+    const int ncol = (Nc - c0 >= 2) ? 2 : 1;
+    double gt[2];
+    int64_t gimg[2];
+    int cnt[2] = {0, 0};
+    unsigned long long best[2] = {0, 0};
+    int brow[2] = {-1, -1};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        gt[u] = (PASS == 0 && u < ncol) ? s_gt[c0 + u] : (double)INFINITY;
+        gimg[u] = (c0 + u) / im_div;
+        if (PASS == 1 && u < ncol) best[u] = best_key[c0 + u];
+    }
+    const bool vec = (ncol == 2) && ((ldS & 1) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
+    for (int64_t r = r_begin; r < r_end; ++r) {
+        const double *p = S + r * ldS + c0;
+        double e[2];
+        if (vec) {
+            const double2 v = *reinterpret_cast<const double2 *>(p);
+            e[0] = v.x; e[1] = v.y;
+        } else {
+            e[0] = p[0];
+            e[1] = ncol == 2 ? p[1] : -(double)INFINITY;
+        }
+        const int64_t gr = row0 + r;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned long long key = double_order_key(e[u]);
+            if (PASS == 0) {
+                cnt[u] += (e[u] > gt[u]) || (e[u] == gt[u] && gr > gimg[u]);
+                best[u] = key > best[u] ? key : best[u];
+            } else if (key == best[u]) {
+                brow[u] = (int)gr;  // rows ascend: the last match is the highest
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (u < ncol) {
+            if (PASS == 0) {
+                if (cnt[u]) atomicAdd(&rank_acc[c0 + u], cnt[u]);
+                atomicMax(&best_key[c0 + u], best[u]);
+            } else if (brow[u] >= 0) {
+                atomicMax(&best_row[c0 + u], brow[u]);
+            }
+        }
+}
+
 }  // namespace itr
+
+extern "C" int itr_rank_gather_gt_f64(const double *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
+                                      int im_div, double *s_gt, itr_stream_t stream) {
+    ITR_REQUIRE(S && s_gt, "itr_rank_gather_gt_f64: null pointer");
+    ITR_REQUIRE(im_div >= 1 && Nc >= 0 && ldS >= Nc && row0 >= 0 && n_rows_local >= 0,
+                "itr_rank_gather_gt_f64: bad shape");
+    if (Nc == 0) return ITR_OK;
+    hipLaunchKernelGGL(itr::gather_gt_f64_kernel, dim3((unsigned)itr::ceil_div(Nc, 256)), dim3(256), 0,
+                       itr::as_stream(stream), S, ldS, row0, n_rows_local, Nc, im_div, s_gt);
+    ITR_CHECK_LAUNCH("gather_gt_f64");
+    return ITR_OK;
+}
+
+extern "C" int itr_rank_counts_f64(const double *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
+                                   int im_div, const double *s_gt, int32_t *i2t_rank, int32_t *i2t_top1,
+                                   int32_t *t2i_rank, uint64_t *t2i_best_key, itr_stream_t stream) {
+    ITR_REQUIRE(S && s_gt && i2t_rank && i2t_top1 && t2i_rank && t2i_best_key, "itr_rank_counts_f64: null pointer");
+    ITR_REQUIRE(im_div >= 1 && im_div <= itr::MAX_IMDIV, "itr_rank_counts_f64: im_div must be in [1, %d]",
+                itr::MAX_IMDIV);
+    ITR_REQUIRE(Nc >= 0 && ldS >= Nc && row0 >= 0 && n_rows_local >= 0, "itr_rank_counts_f64: bad shape");
+    ITR_REQUIRE(Nc < 0x7fffffffLL && row0 + n_rows_local < 0x7fffffffLL, "itr_rank_counts_f64: index overflow");
+    if (Nc == 0 || n_rows_local == 0) return ITR_OK;
+    hipStream_t st = itr::as_stream(stream);
+    hipLaunchKernelGGL(itr::i2t_rank_f64_kernel, dim3((unsigned)n_rows_local), dim3(itr::RANK_THREADS), 0, st, S,
+                       ldS, row0, Nc, im_div, i2t_rank, i2t_top1);
+    ITR_CHECK_LAUNCH("i2t_rank_f64");
+    dim3 grid((unsigned)itr::ceil_div(Nc, (int64_t)itr::RANK_THREADS * 2),
+              (unsigned)itr::ceil_div(n_rows_local, itr::T2I_ROWS));
+    hipLaunchKernelGGL(itr::t2i_rank_f64_kernel<0>, grid, dim3(itr::RANK_THREADS), 0, st, S, ldS, row0,
+                       n_rows_local, Nc, im_div, s_gt, t2i_rank,
+                       reinterpret_cast<unsigned long long *>(t2i_best_key), (int32_t *)nullptr);
+    ITR_CHECK_LAUNCH("t2i_rank_f64");
+    return ITR_OK;
+}
+
+extern "C" int itr_rank_t2i_top1_f64(const double *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
+                                     const uint64_t *t2i_best_key, int32_t *t2i_top1, itr_stream_t stream) {
+    ITR_REQUIRE(S && t2i_best_key && t2i_top1, "itr_rank_t2i_top1_f64: null pointer");
+    ITR_REQUIRE(Nc >= 0 && ldS >= Nc && row0 >= 0 && n_rows_local >= 0, "itr_rank_t2i_top1_f64: bad shape");
+    ITR_REQUIRE(Nc < 0x7fffffffLL && row0 + n_rows_local < 0x7fffffffLL, "itr_rank_t2i_top1_f64: index overflow");
+    if (Nc == 0 || n_rows_local == 0) return ITR_OK;
+    dim3 grid((unsigned)itr::ceil_div(Nc, (int64_t)itr::RANK_THREADS * 2),
+              (unsigned)itr::ceil_div(n_rows_local, itr::T2I_ROWS));
+    hipLaunchKernelGGL(itr::t2i_rank_f64_kernel<1>, grid, dim3(itr::RANK_THREADS), 0, itr::as_stream(stream), S, ldS,
+                       row0, n_rows_local, Nc, 1, (const double *)nullptr, (int32_t *)nullptr,
+                       reinterpret_cast<unsigned long long *>(const_cast<uint64_t *>(t2i_best_key)), t2i_top1);
+    ITR_CHECK_LAUNCH("t2i_top1_f64");
+    return ITR_OK;
+}
 
 extern "C" int itr_rank_gather_gt(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
                                   int im_div, float *s_gt, itr_stream_t stream) {

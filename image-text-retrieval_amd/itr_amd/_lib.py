@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -91,6 +91,9 @@ SIGNATURES = {
     "itr_debug_scan_occupancy": (i32, [vp, vp]),
     "itr_rank_gather_gt": (i32, [vp, i64, i64, i64, i64, i32, vp, vp]),
     "itr_rank_counts": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
+    "itr_rank_gather_gt_f64": (i32, [vp, i64, i64, i64, i64, i32, vp, vp]),
+    "itr_rank_counts_f64": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
+    "itr_rank_t2i_top1_f64": (i32, [vp, i64, i64, i64, i64, vp, vp, vp]),
     "itr_recall_from_ranks": (i32, [vp, i64, vp]),
     # ---- training step
     "itr_l2norm_fwd_save": (i32, [vp, vp, vp, i64, i32, f32, vp]),

@@ -138,10 +138,27 @@ def cal_sims(model, img_embs, cap_embs, lengths=None, shard_size=128, ref_quirk_
 
 
 def _ranks(sims):
-    S = torch.from_numpy(np.ascontiguousarray(np.asarray(sims, dtype=np.float32))).cuda()
-    i_rank, i_top, t_rank, t_best, _ = ops.rank_counts(S, 5)
+    """Rank vectors of a similarity matrix in the arithmetic the caller holds it in: float64 input (cal_sims' output,
+    an ensemble average -- what the reference argsorts, evaluation.py:169, :209, :380) is counted in float64, so the
+    indices equal the reference's even where two scores differ by less than an fp32 ulp; float32 input is counted in
+    float32; anything else is widened to float64 (exact for every narrower type)."""
+    if torch.is_tensor(sims):
+        S = sims.detach()
+        if S.dtype not in (torch.float32, torch.float64):
+            S = S.to(torch.float64)
+        S = S.contiguous().cuda()
+    else:
+        a = np.asarray(sims)
+        if a.dtype != np.float32:
+            a = a.astype(np.float64, copy=False)
+        S = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    if S.dtype == torch.float64:
+        i_rank, i_top, t_rank, t_top = ops.rank_counts_f64(S, 5)
+    else:
+        i_rank, i_top, t_rank, t_best, _ = ops.rank_counts(S, 5)
+        t_top = t_best & 0xffffffff
     return (i_rank.cpu().numpy().astype(np.float64), i_top.cpu().numpy().astype(np.float64),
-            t_rank.cpu().numpy().astype(np.float64), (t_best & 0xffffffff).cpu().numpy().astype(np.float64))
+            t_rank.cpu().numpy().astype(np.float64), t_top.cpu().numpy().astype(np.float64))
 
 
 def i2t(sims, return_ranks=False):

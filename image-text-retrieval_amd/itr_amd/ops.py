@@ -736,7 +736,8 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
 def rank_counts(S, im_div=5, row0=0, s_gt=None, t2i_rank=None, t2i_best=None):
     """Sort-free ranks of a (local row block of a) similarity matrix.
     -> (i2t_rank int32[n_rows], i2t_top1 int32[n_rows], t2i_rank int32[Nc], t2i_best uint64-as-int64[Nc], s_gt)
-    For a single GPU (row0 = 0, all rows local) t2i_rank is final and t2i_top1 = t2i_best & 0xffffffff."""
+    For a single GPU (row0 = 0, all rows local) t2i_rank is final and t2i_top1 = t2i_best & 0xffffffff.
+    A float64 matrix (the reference's cal_sims output, an ensemble average) is ranked in float64: `rank_counts_f64`."""
     lib = _lib.load()
     S = _dev(S, name="S")
     n_rows, Nc = S.shape
@@ -753,6 +754,27 @@ def rank_counts(S, im_div=5, row0=0, s_gt=None, t2i_rank=None, t2i_best=None):
     _lib.check(lib.itr_rank_counts(_p(S), S.stride(0), row0, n_rows, Nc, im_div, _p(s_gt), _p(i2t_rank), _p(i2t_top1),
                                    _p(t2i_rank), _p(t2i_best), _stream()))
     return i2t_rank, i2t_top1, t2i_rank, t2i_best, s_gt
+
+
+def rank_counts_f64(S, im_div=5):
+    """The same counts on a float64 similarity matrix (all rows local): index-exact against the reference's argsort of
+    float64 rows / columns (evaluation.py:169, :209; ensemble averages: :380, :398).
+    -> (i2t_rank, i2t_top1, t2i_rank, t2i_top1) int32."""
+    lib = _lib.load()
+    S = _dev(S, dtype=torch.float64, name="S")
+    n_rows, Nc = S.shape
+    dev = S.device
+    s_gt = torch.full((Nc,), float('-inf'), device=dev, dtype=torch.float64)
+    _lib.check(lib.itr_rank_gather_gt_f64(_p(S), S.stride(0), 0, n_rows, Nc, im_div, _p(s_gt), _stream()))
+    i2t_rank = torch.empty(n_rows, device=dev, dtype=torch.int32)
+    i2t_top1 = torch.empty(n_rows, device=dev, dtype=torch.int32)
+    t2i_rank = torch.zeros(Nc, device=dev, dtype=torch.int32)
+    t2i_key = torch.zeros(Nc, device=dev, dtype=torch.int64)
+    t2i_top1 = torch.full((Nc,), -1, device=dev, dtype=torch.int32)
+    _lib.check(lib.itr_rank_counts_f64(_p(S), S.stride(0), 0, n_rows, Nc, im_div, _p(s_gt), _p(i2t_rank), _p(i2t_top1),
+                                       _p(t2i_rank), _p(t2i_key), _stream()))
+    _lib.check(lib.itr_rank_t2i_top1_f64(_p(S), S.stride(0), 0, n_rows, Nc, _p(t2i_key), _p(t2i_top1), _stream()))
+    return i2t_rank, i2t_top1, t2i_rank, t2i_top1
 
 
 def gather_gt(S, im_div=5, row0=0, s_gt=None):

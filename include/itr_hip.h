@@ -268,6 +268,20 @@ int itr_rank_gather_gt(const float *S, int64_t ldS, int64_t row0, int64_t n_rows
 int itr_rank_counts(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
                     int im_div, const float *s_gt, int32_t *i2t_rank, int32_t *i2t_top1,
                     int32_t *t2i_rank, uint64_t *t2i_best, itr_stream_t stream);
+/* float64 matrices.  The reference ranks the float64 array cal_sims returns (evaluation.py:169, :209), and
+ * evalrank_ensemble averages two models' matrices in float64 before ranking (evaluation.py:380, :398): such
+ * scores are not fp32-representable, so they are counted in float64 -- same counts, same tie rule, index-exact.
+ * t2i_best_key[Nc] (zero it first) is max-reduced to the 64-bit ordered key of every column's best score;
+ * itr_rank_t2i_top1_f64 then max-reduces t2i_top1[Nc] (int32, pre-filled with -1) to the highest global row
+ * holding that key (second pass over S; with several ranks: max all-reduce the keys between the two calls and
+ * t2i_top1 after). */
+int itr_rank_gather_gt_f64(const double *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
+                           int im_div, double *s_gt, itr_stream_t stream);
+int itr_rank_counts_f64(const double *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
+                        int im_div, const double *s_gt, int32_t *i2t_rank, int32_t *i2t_top1,
+                        int32_t *t2i_rank, uint64_t *t2i_best_key, itr_stream_t stream);
+int itr_rank_t2i_top1_f64(const double *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
+                          const uint64_t *t2i_best_key, int32_t *t2i_top1, itr_stream_t stream);
 /* host-side summary (evaluation.py:181-185): out5 = r1, r5, r10, medr, meanr. */
 int itr_recall_from_ranks(const int32_t *ranks_host, int64_t n, double *out5);
 

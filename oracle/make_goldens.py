@@ -362,6 +362,36 @@ def g12():
          tie_t2i=np.array(trt), zeros_i2t_ranks=zr_i, zeros_t2i_ranks=zr_t)
 
 
+# ------------------------------------------------------------------ G22 ranker on float64 (ensemble) matrices
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'helpers'))
+from rank_matrices import ensemble_sigmoid_matrix, half_ulp_matrix  # noqa: E402  (one recipe for generator and tests)
+
+
+def g22():
+    import rank_matrices
+    out = {}
+    # seeds 35 / 26: the fp32 cast of these two changes one i2t / one t2i rank (most seeds change none at this size)
+    for name, make in rank_matrices.CASES.items():
+        S = make()
+        assert S.dtype == np.float64
+        (ri, (ranks_i, top_i)) = evaluation.i2t(S, True)
+        (rt, (ranks_t, top_t)) = evaluation.t2i(S, True)
+        c = O.rank_counts(S)
+        assert (c[0] == ranks_i).all() and (c[2] == ranks_t).all(), "oracle counts != reference argsort (float64)"
+        assert (c[1] == top_i).all() and (c[3] == top_t).all()
+        # how much an fp32 cast of the same matrix would change (documents that the fixture is sensitive)
+        c32 = O.rank_counts(S.astype(np.float32))
+        n_i, n_t = int((c32[0] != ranks_i).sum()), int((c32[2] != ranks_t).sum())
+        print("   %s: fp32 truncation would change %d/%d i2t and %d/%d t2i ranks" % (name, n_i, len(ranks_i), n_t, len(ranks_t)))
+        assert n_i + n_t > 0, "fixture does not separate float64 from float32 ranking"
+        out.update({name + '_sha256': rank_matrices.sha256_u8(S),
+                    name + '_shape': np.array(S.shape), name + '_i2t': np.array(ri), name + '_t2i': np.array(rt),
+                    name + '_i2t_ranks': ranks_i.astype(np.int32), name + '_i2t_top1': top_i.astype(np.int32),
+                    name + '_t2i_ranks': ranks_t.astype(np.int32), name + '_t2i_top1': top_t.astype(np.int32),
+                    name + '_fp32_changed': np.array([n_i, n_t])})
+    save('g22_ranker_f64', **out)
+
+
 # ------------------------------------------------------------------ G10 BERT + SAEM towers
 def g10():
     import json
@@ -1062,7 +1092,7 @@ def g21():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20', 'g21']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g78', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20', 'g21', 'g22']
     for name in which:
         print("== " + name)
         globals()[name]()

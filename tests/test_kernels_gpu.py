@@ -164,6 +164,62 @@ def test_ranker_ties_and_zeros(golden, dev):
     assert (z[0] == g["zeros_i2t_ranks"]).all() and (z[2] == g["zeros_t2i_ranks"]).all()
 
 
+def run_ranker_f64(sims64, dev, im_div=5):
+    S = torch.from_numpy(np.ascontiguousarray(sims64, dtype=np.float64)).to(dev)
+    return [x.cpu().numpy().astype(np.int64) for x in ops.rank_counts_f64(S, im_div)]
+
+
+@pytest.mark.parametrize("case", ["sig35", "sig26", "ulp"])
+def test_ranker_float64_golden(golden, dev, case):
+    """Ensemble-style float64 matrices (two fp32 matrices averaged in float64, 1k x 5k; a half-ulp Latin rectangle):
+    i2t / t2i(return_ranks=True) through the package equal the reference's vectors bit for bit
+    (evaluation.py:156-222, :380).  An fp32 ranker gets them wrong (`*_fp32_changed` in the fixture)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    import rank_matrices
+    from itr_amd.metricmodule import evaluation as E
+    g = golden("g22_ranker_f64")
+    S = rank_matrices.CASES[case]()
+    got = run_ranker_f64(S, dev)
+    want = O.rank_counts(S)                      # always: HIP == float64 oracle on the same bytes
+    for a, b in zip(got, want):
+        assert (a == b).all()
+    if (rank_matrices.sha256_u8(S) == g[case + "_sha256"]).all():
+        (ri, (ranks_i, top_i)) = E.i2t(S, return_ranks=True)
+        (rt, (ranks_t, top_t)) = E.t2i(S, return_ranks=True)
+        assert (ranks_i == g[case + "_i2t_ranks"]).all() and (top_i == g[case + "_i2t_top1"]).all()
+        assert (ranks_t == g[case + "_t2i_ranks"]).all() and (top_t == g[case + "_t2i_top1"]).all()
+        assert ri == pytest.approx(tuple(g[case + "_i2t"])) and rt == pytest.approx(tuple(g[case + "_t2i"]))
+        # the fp32 ranker on the truncated matrix does differ: the float64 path is what makes this exact
+        got32 = run_ranker(S.astype(np.float32), dev)
+        assert [int((got32[0] != got[0]).sum()), int((got32[2] != got[2]).sum())] == list(g[case + "_fp32_changed"])
+    else:
+        assert case != "ulp", "integer-exact recipe changed"
+
+
+@pytest.mark.parametrize("shape", [(1, 5), (7, 35), (41, 205), (257, 1285), (64, 319)])
+def test_ranker_float64_ragged_and_ties(dev, shape):
+    rng = np.random.RandomState(shape[0])
+    sims = rng.randn(*shape)
+    for S in (sims, np.round(sims * 2) / 2, np.zeros(shape)):      # plain, many exact ties, all equal
+        got = run_ranker_f64(S, dev)
+        want = O.rank_counts(S)
+        for a, b in zip(got, want):
+            assert (a == b).all()
+
+
+def test_i2t_t2i_dtype_dispatch(golden, dev):
+    """float64 in -> float64 counts; float32 in -> float32 counts; both equal the oracle on their own input."""
+    from itr_amd.metricmodule import evaluation as E
+    g = golden("g12_ranker")
+    for sims in (g["sims"], g["sims"].astype(np.float32), torch.from_numpy(g["sims"])):
+        (_, (ranks_i, top_i)) = E.i2t(sims, return_ranks=True)
+        (_, (ranks_t, top_t)) = E.t2i(sims, return_ranks=True)
+        assert (ranks_i == g["i2t_ranks"]).all() and (top_i == g["i2t_top1"]).all()
+        assert (ranks_t == g["t2i_ranks"]).all() and (top_t == g["t2i_top1"]).all()
+
+
 @pytest.mark.parametrize("Ni", [1, 7, 41, 257])
 def test_ranker_ragged_shapes(dev, Ni):
     rng = np.random.RandomState(Ni)
