@@ -137,9 +137,10 @@ def cpu_baseline(wl, wi, wt, feats_cpu, lengths, tokens, n_img_s, seconds_cap=60
 
 
 def pmc_traffic(workload, world):
-    """HBM bytes per launch of the dominant kernel as measured by the committed rocprofv3 PMC passes
-    (profiles/rNN/scan_pmc.json; FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md).  bench.py cannot collect
-    PMC counters itself; null when no matching profile is committed."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN/scan_pmc.json;
+    FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md).  bench.py cannot collect PMC counters itself (they need their own
+    rocprofv3 --pmc runs), so this number is REPLAYED from the newest committed profile of the same workload, and the
+    line says so: `traffic_source` = "replayed: <file> @ <commit the profile was taken at>".  null when none matches."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "scan_pmc.json"), recursive=True)):
@@ -148,8 +149,10 @@ def pmc_traffic(workload, world):
         except Exception:
             continue
         if d.get("workload") == workload and d.get("n_gpus") == world:
-            best = d
-    return (best["hbm_bytes_per_launch"], best["source"]) if best else (None, None)
+            best = (d, os.path.relpath(f, ROOT))
+    if not best:
+        return None, None
+    return best[0]["hbm_bytes_per_launch"], "replayed: %s @ %s (not measured in this run)" % (best[1], best[0].get("commit", "unknown commit"))
 
 
 # ------------------------------------------------------------------------------------------ pooled models
@@ -467,8 +470,9 @@ def main():
         exe_flop = float(i1 - i0) * n_words * (2 * 36 * D + 36 * 37)
         k_ms = float(np.mean(scan_ms))
         model_name = "SCAN %s %s bi-GRU" % (wl.get("cross_attn"), wl.get("agg_func"))
-        kernel_name, note = "scan_xattn_kernel", ("achieved uses SURVEY 8d's algorithmic (4*36+6)*W*D flop/pair; the kernel "
-                                                  "executes about half of it (Gram-matrix identity, DESIGN.md)")
+        kernel_name, note = "scan_xattn_kernel", ("achieved/frac count the flop the kernel executes (2*36*W*D dot products + the 36x36 quadratic "
+                                                  "form per word); SURVEY 8d's algorithmic (4*36+6)*W*D flop/pair, about twice that because the "
+                                                  "context bmm is replaced by the Gram identity (DESIGN.md 4.3), is in algorithmic_equiv_*")
         if is_sgraf:
             # 4*36*W*D + 2*W*D*s + 2*D*s + T*(6*(W+1)*s^2 + 4*(W+1)^2*s) + 2s per pair (T = 0 for SAF)
             s_, T_ = 256, (3 if wl["sgraf"] == "SGR" else 0)
@@ -489,6 +493,7 @@ def main():
         from itr_amd import ops as _ops
         i2t = _ops.recall_from_ranks(ranks[0])
         t2i = _ops.recall_from_ranks(ranks[2])
+        traffic, traffic_src = pmc_traffic(args.workload, world)
         out = {
             "metric": "pairs/sec scored (5k img x 25k cap) + Recall@1 parity, 1/2/4/8 MI355X",
             "value": pairs / (dt / args.steps), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -502,15 +507,16 @@ def main():
                        "t2i_r10": t2i[2]},
             # order-sensitive checksums of the four rank vectors: equal across GPU counts iff the sharded result is identical
             "rank_checksum": [int((np.asarray(r, np.int64) * (np.arange(len(r)) % 9973 + 1)).sum()) for r in ranks],
-            "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": alg_flop / (k_ms * 1e-3) / 1e12,
+            # achieved / frac = what the matrix core EXECUTES per launch / HIP-event kernel time (a hardware fraction, <= 1);
+            # SURVEY 8d's algorithmic flop (which includes the context bmm this design never runs) is reported next to it
+            "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": exe_flop / (k_ms * 1e-3) / 1e12,
                          "peak": peak, "unit": "TFLOP/s",
-                         "frac": alg_flop / (k_ms * 1e-3) / 1e12 / peak,
-                         "traffic": pmc_traffic(args.workload, world)[0],
-                         "traffic_source": pmc_traffic(args.workload, world)[1],
-                         "kernel_ms": k_ms, "algorithmic_flop_per_launch": alg_flop,
-                         "executed_flop_per_launch": exe_flop,
-                         "executed_tflops": exe_flop / (k_ms * 1e-3) / 1e12,
-                         "executed_frac": exe_flop / (k_ms * 1e-3) / 1e12 / peak,
+                         "frac": exe_flop / (k_ms * 1e-3) / 1e12 / peak,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_ms": k_ms, "executed_flop_per_launch": exe_flop,
+                         "algorithmic_flop_per_launch": alg_flop,
+                         "algorithmic_equiv_tflops": alg_flop / (k_ms * 1e-3) / 1e12,
+                         "algorithmic_equiv_frac": alg_flop / (k_ms * 1e-3) / 1e12 / peak,
                          "note": note},
         }
         if world == 1 and not is_sgraf and "scan_precision" not in wl and not args.no_variants:

@@ -132,11 +132,12 @@ class GruModelEval:
     # -- step 1
     def encode_images(self, feats_local):
         return ops.proj_l2norm(feats_local, self.wi['fc.weight'], self.wi['fc.bias'],
-                               no_imgnorm=self.cfg.get('no_imgnorm', False))
+                               no_imgnorm=self.cfg.get('no_imgnorm', False), use_abs=self.cfg.get('img_use_abs', False))
 
     def encode_captions(self, tokens_packed, tok_off, lengths_sorted, gather_last=False):
         return ops.gru_encode(tokens_packed, tok_off, lengths_sorted, self.wt, self.cfg.get('bi_gru', False),
-                              no_txtnorm=self.cfg.get('no_txtnorm', False), gather_last=gather_last)
+                              no_txtnorm=self.cfg.get('no_txtnorm', False), use_abs=self.cfg.get('txt_use_abs', False),
+                              gather_last=gather_last)
 
     # -- whole step for SCAN.  Local inputs:
     #   feats_local [n_img_local, 36, F]          unique images rows [i0, i1)
@@ -268,6 +269,9 @@ def _features_to_device(arr, i0, i1, dev, chunk=512):
     next chunk from the page cache / disk overlaps the copy of the previous one."""
     out = torch.empty((i1 - i0,) + tuple(arr.shape[1:]), device=dev, dtype=torch.float32)
     stream = torch.cuda.Stream(device=dev)
+    # `out` may be a block the caching allocator just recycled from kernels still queued on the current stream (validation
+    # right after an asynchronous training step): the copies must not overtake them
+    stream.wait_stream(torch.cuda.current_stream(dev))
     bufs = [torch.empty((chunk,) + tuple(arr.shape[1:]), dtype=torch.float32).pin_memory() for _ in range(2)]
     evs = [None, None]
     for k, r0 in enumerate(range(i0, i1, chunk)):
@@ -319,15 +323,19 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
             tok_off = np.concatenate([[0], np.cumsum(lens_sorted)[:-1]]) if len(order) else np.zeros(0, np.int64)
             toks, off = torch.from_numpy(packed).to(dev), torch.from_numpy(tok_off.astype(np.int64)).to(dev)
             wi = {k: v.detach() for k, v in model.img_enc.state_dict().items()}
+            if hasattr(model.img_enc, '_weight'):      # precomp_enc_type='weight_norm' stores fc.weight_g / fc.weight_v only
+                wi['fc.weight'] = model.img_enc._weight().detach()
             wt = {k: v.detach() for k, v in model.txt_enc.state_dict().items()}
+            # the towers' own switches (order embeddings: use_abs on both towers, ImgEncoder.py:143-145, TextEncoder.py:66-68)
             ev = GruModelEval(wi, wt, dict(cfg, bi_gru=model.txt_enc.use_bi_gru, no_txtnorm=model.txt_enc.no_txtnorm,
-                                           no_imgnorm=model.img_enc.no_imgnorm), comm)
+                                           no_imgnorm=model.img_enc.no_imgnorm, img_use_abs=getattr(model.img_enc, 'use_abs', False),
+                                           txt_use_abs=getattr(model.txt_enc, 'use_abs', False)), comm)
             if name in ('VSE++', 'VSE_PP', 'VSRN'):
                 if name == 'VSRN':       # GCN + region GRU tower (ImgEncoder.py:199-231), `batch` images per pass
                     img = torch.cat([model.img_enc(feats[b0:b0 + batch])[0] for b0 in range(0, feats.shape[0], batch)], 0) \
                         if feats.shape[0] else torch.zeros(0, cfg['embed_size'], device=dev)
                 else:
-                    img = ops.proj_l2norm(ops.mean_mid(feats), wi['fc.weight'], wi['fc.bias'], no_imgnorm=model.img_enc.no_imgnorm)
+                    img = ev.encode_images(ops.mean_mid(feats))
                 cap_sorted = ev.encode_captions(toks, off, lens_sorted, gather_last=True)
                 cap = torch.empty_like(cap_sorted)
                 cap[torch.from_numpy(np.ascontiguousarray(order)).to(dev)] = cap_sorted
@@ -335,7 +343,14 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
                 cap_all, maxrows = comm.all_gather_rows(cap, counts)
                 if comm.on and any(c != maxrows for c in counts):
                     cap_all = torch.cat([cap_all[q * maxrows:q * maxrows + counts[q]] for q in range(comm.world)], 0)
-                S = ops.cosine_scores(img, cap_all)
+                # ranked with the similarity the model was trained for: criterion.sim = cosine_sim or order_sim
+                # (Objectives.py:45-50; the reference's cal_sims calls model.criterion.sim, evaluation.py:128-131)
+                if cfg.get('measure', 'cosine') == 'order':
+                    S = ops.order_scores(img, cap_all)
+                elif cfg.get('measure', 'cosine') == 'cosine':
+                    S = ops.cosine_scores(img, cap_all)
+                else:
+                    raise ValueError("unknown measure:", cfg.get('measure'))
                 return finalize_ranks(comm, S, i0, n_img, im_div)
             sw = {k: v.detach() for k, v in model.sim_enc.state_dict().items()} if name == 'SGRAF' else None
             _, ranks, _ = ev.scan_eval(feats, toks, off, lens_sorted, order, n_img, n_cap, im_div, sgraf_weights=sw)

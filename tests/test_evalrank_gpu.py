@@ -97,8 +97,12 @@ def test_evalrank_fast_equals_reference_shaped_path(golden, dev, tmp_path):
     encode_data + cal_sims path on the same checkpoint and files -- SCAN, SGRAF, VSE++ and VSRN."""
     g = golden("g14_data_layer")
     name, data_path, vdir = _materialise(g, tmp_path)
-    for model_name, extra in (('SCAN', []), ('SGRAF', ['module_name=SGR']), ('VSE_PP', []), ('VSRN', [])):
-        save_dir = str(tmp_path / ('run_' + model_name))
+    # + the towers' / criterion's own switches: order embeddings (measure='order' ranks with order_sim, use_abs on both towers)
+    # and SCAN's weight-normalised projection (state_dict holds fc.weight_g / fc.weight_v, no fc.weight)
+    for case, (model_name, extra) in enumerate((('SCAN', []), ('SGRAF', ['module_name=SGR']), ('VSE_PP', []), ('VSRN', []),
+                                                ('VSE_PP', ['measure=order', 'use_abs=True']), ('VSRN', ['measure=order', 'use_abs=True']),
+                                                ('SCAN', ['precomp_enc_type=weight_norm']))):
+        save_dir = str(tmp_path / ('run%d_%s' % (case, model_name)))
         os.makedirs(save_dir)
         cfg = C.build_config(['with', model_name, 'data_name=%s' % name, 'bi_gru=True', 'seed=3'] + extra)
         cfg.update(img_dim=8, embed_size=32, word_dim=16, vocab_size=int(g["vocab_len"]), data_path=data_path, vocab_path=vdir,
@@ -117,8 +121,18 @@ def test_evalrank_fast_equals_reference_shaped_path(golden, dev, tmp_path):
         slow = evaluation.evalrank_single(p, split='test')
         fast = evaluation.evalrank_fast(p, split='test')
         for k in ('i2t_ranks', 't2i_ranks', 'i2t_top1', 't2i_top1'):
-            assert (np.asarray(slow[k]) == np.asarray(fast[k])).all(), (model_name, k)
+            assert (np.asarray(slow[k]) == np.asarray(fast[k])).all(), (model_name, extra, k)
         assert fast['rsum'] == pytest.approx(slow['rsum'])
+        if 'measure=order' in extra:       # and the order similarity does rank differently from the cosine on these embeddings
+            cos = evaluation._recall_dict(__import__('itr_amd.evalpipe', fromlist=['x']).evaluate_precomp(
+                _with_measure(model, 'cosine'), dl.PrecompDataset(os.path.join(data_path, name), 'test', cfg)))
+            model.config['measure'] = 'order'
+            assert any((np.asarray(cos[k]) != np.asarray(fast[k])).any() for k in ('i2t_ranks', 't2i_ranks'))
+
+
+def _with_measure(model, measure):
+    model.config['measure'] = measure
+    return model
 
 
 def test_validate_step_and_resume(golden, dev, tmp_path):
