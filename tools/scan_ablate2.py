@@ -20,7 +20,7 @@ ws = ops.scan_prepare(img, words, plan)
 flop = Ni * n_rows * (2 * 36 * D)
 for extra in (0, 4000):
     os.environ["ITR_SCAN_LDS_EXTRA"] = str(extra)
-    for name, flag in (("full", 0), ("no_epilogue", 1), ("no_gload_no_epi", 3), ("no_mfma_no_epi", 5)):
+    for name, flag in (("full", 0), ("no_epilogue", 1)):      # (the load / MFMA ablation switches of round 1 are gone from the loop)
         os.environ["ITR_SCAN_DEBUG"] = str(flag)
         for _ in range(2):
             ops.scan_xattn_scores(img, words, plan, workspace=ws, precision=PREC)
