@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void enorm_bwd_kernel(const float *__restrict_
 
 // LDS-tiled Gram kernel of the evaluation path (scan_xattn.hip): G[n] = X_n X_n^T
 __global__ void gram_kernel(const float *__restrict__ X, const int64_t *__restrict__ row_off, const int32_t *__restrict__ row_cnt, int fixed_rows,
-                            int D, float *__restrict__ G, const int64_t *__restrict__ g_off);
+                            int D, float *__restrict__ G, const int64_t *__restrict__ g_off, int upper2);
 
 static int check_train_args(const char *who, int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int norm, int agg, int max_len) {
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && n_tok >= 1 && D > 0, "%s: bad shape", who);
@@ -327,7 +327,7 @@ extern "C" int itr_scan_train_prepare(const float *V, const float *E, int64_t Bi
     ITR_UNSUPPORTED(R != SC_R, "itr_scan_train_prepare: built for %d regions", SC_R);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Bi), dim3(256), 0, st, V, (const int64_t *)nullptr, (const int32_t *)nullptr, SC_R, D, G,
-                       (const int64_t *)nullptr);
+                       (const int64_t *)nullptr, 0);
     ITR_CHECK_LAUNCH("scan_train_gram");
     hipLaunchKernelGGL(rownorm_train_kernel, dim3((unsigned)ceil_div(n_tok, 4)), dim3(256), 0, st, E, n_tok, D, enorm);
     ITR_CHECK_LAUNCH("scan_train_rownorm");

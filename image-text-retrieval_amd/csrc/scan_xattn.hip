@@ -41,7 +41,7 @@ struct ScanArgs {
     const uint16_t *img_bf;  // bf16x3 variant: split planes of img,    [Ni * 36][D / 32][hi | lo][32] bf16 (scan_split_rows_kernel)
     const uint16_t *wt_bf;   //                 split planes of wtiled, [n_tiles * 64][D / 32][hi | lo][32]
     const ScanTileMeta *meta;  // [n_tiles]
-    const float *gram;       // [Ni, 36, 36]        (t2i)   V_i V_i^T
+    const float *gram;       // [Ni, 36, 36]        (t2i)   V_i V_i^T in upper-triangular form (diagonal + 2 x upper part)
     const float *wnorm;      // [n_tiles * 64]      (t2i)   ||E_w|| per tiled column
     const float *vnorm;      // [Ni * 36]           (i2t)   ||V_r||
     const float *cgram;      // [sum W_c^2]         (i2t)   E_c E_c^T, caption c at cgram_off[c]
@@ -54,6 +54,7 @@ struct ScanArgs {
     float lambda_softmax, lambda_lse;
     float *emit_p;    // [Ni, n_tiles*64, 36] normalised attention weights (SGRAF: SCAN_attention), or null
     float *emit_cn;   // [Ni, n_tiles*64]     1 / (||ctx|| + eps)
+    int tpw;    // tiles per workgroup (see the work mapping in the kernel)
     int debug;  // ablation switches for tools/scan_ablate.py (env ITR_SCAN_DEBUG); 0 in production
     unsigned long long *dbg_cycles;  // [8] phase cycle sums (debug & 16), normally null
 };
@@ -142,27 +143,37 @@ using f16x8_t = __attribute__((ext_vector_type(8))) _Float16;
 // PREC 0: exact fp32 main loop (scan_mainloop.inc).  PREC 1: split-bf16 "bf16x3", PREC 3: split-fp16 "fp16x3" main loop
 // (scan_mainloop_bf16.inc; opt-in, reported separately -- DESIGN.md 9); bits 2 / 3: ablation builds.  The epilogue is shared.
 template <int PREC>
-__global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
+__device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ScanSmem &sm = *reinterpret_cast<ScanSmem *>(smem_raw);
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // ---- XCD-aware work mapping: each XCD walks 8 x 8 patches of (image tile, column tile) so
-    // that the ~64 workgroups resident on one XCD share operand panels in its private L2.
+    // ---- XCD-aware work mapping, `tpw` tiles per workgroup.  Workgroup b lives on XCD b % 8 (round-robin dispatch); each XCD
+    // walks 8 x 8 patches of (image tile, column tile) so that the ~64 workgroups resident on it share operand panels in its
+    // private L2.  A workgroup handles the SAME position of `tpw` consecutive patches of its XCD, one after the other: the
+    // resident workgroups still sit on one patch at a time, while the cost of launching a workgroup (its slot stays empty for
+    // several microseconds; residency 0.90 with one 75 us tile per workgroup) is spread over tpw tiles.  Workgroups are still
+    // launched as slots free up, so the two workgroups of a CU stay out of phase -- one multiplies while the other runs its
+    // epilogue; a fully persistent grid (all workgroups started together) locks them in phase and measured 7 % slower.
     const int64_t img_tiles = (g.Ni + SC_IMGS - 1) / SC_IMGS;
     const int64_t PI = (img_tiles + 7) / 8, PJ = (g.n_tiles + 7) / 8;
-    const int64_t bid = blockIdx.x;
-    const int64_t xcd = bid & 7, seq = bid >> 3;
-    const int64_t patch = (seq >> 6) * 8 + xcd;
-    const int within = (int)(seq & 63);
-    if (patch >= PI * PJ) return;
+    const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int64_t pgroup = slot >> 6;
+    const int within = (int)(slot & 63);
+    int tid_ = threadIdx.x;
+  for (int rep = 0; rep < g.tpw; ++rep) {
+    const int64_t patch = (pgroup * g.tpw + rep) * 8 + xcd;
+    if (patch >= PI * PJ) break;
     const int64_t it = (patch / PJ) * 8 + (within & 7);
     const int64_t ct = (patch % PJ) * 8 + (within >> 3);
-    if (it >= img_tiles || ct >= g.n_tiles) return;
+    if (it >= img_tiles || ct >= g.n_tiles) continue;
     const int64_t img0 = it * SC_IMGS;
+    // everything per-lane is re-derived from this opaque copy each tile: otherwise hipcc hoists the (loop-invariant) address
+    // arithmetic out of the tile loop and its live ranges then span main loop AND epilogue -- spills at this VGPR budget
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __syncthreads();   // the previous tile's epilogue is done with the LDS block (meta, parked scores)
 
     unsigned long long tick_ = g.dbg_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long real0_ = g.dbg_cycles ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
     const int ncap = sm.meta.ncap;
     if (g.debug & 1) {  // ablation: no epilogue
         if (tid < SC_IMGS && img0 + tid < g.Ni) g.S[(img0 + tid) * g.ldS + sm.meta.cap_id[0]] = sm.arawt[0][tid * SC_R];
-        return;
+        continue;
     }
 #define AT(row, col) sm.arawt[col][row]
 
@@ -201,60 +212,72 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
             for (int mt = 0; mt < 3; ++mt) {
                 int row = mt * 16 + fi;
                 row = row < SC_R ? row : SC_R - 1;       // rows 36..47 of the last tile: their outputs are ignored
-                gfa[mt][0] = *reinterpret_cast<const float4 *>(G + row * SC_R + 4 * fg);
-                gfa[mt][1] = *reinterpret_cast<const float4 *>(G + row * SC_R + 16 + 4 * fg);
+                // G is stored upper-triangular (gram_kernel, upper2): k-blocks left of row tile mt are zero and are skipped
+                if (mt < 1) gfa[mt][0] = *reinterpret_cast<const float4 *>(G + row * SC_R + 4 * fg);
+                if (mt < 2) gfa[mt][1] = *reinterpret_cast<const float4 *>(G + row * SC_R + 16 + 4 * fg);
                 gfb[mt] = G[row * SC_R + 32 + fg];
             }
         }
         // E1: statistics of the first normalisation, along each caption's words, per (region row, caption).
-        if (norm == 0 || norm == 1 || norm == 5 || norm == 6) {
-            // sum_w f(a[row][w]) * [w in caption k]  =  (f(A) [144 x 64]) x (indicator [64 x 16]) on the matrix
-            // core; f = leaky^2 | a^2 | |a| | |leaky|.  Wave w owns row tiles w, w+4 (and 8 for wave 0).
-            float ind[16];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ind[4 * u + j] = (sm.meta.col_cap[16 * u + 4 * fg + j] == fi) ? 1.f : 0.f;
-            dispatch_norm(norm, [&](auto NC) {
-                constexpr int NORM = decltype(NC)::value;
-                for (int mt = wave; mt < SC_MTILES; mt += 4) {
-                    f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float v = AT(mt * 16 + fi, 16 * u + 4 * fg + j);
-                            if (NORM == 0 || NORM == 6) v = leaky(v);
-                            v = (NORM <= 1) ? v * v : fabsf(v);
-                            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, ind[4 * u + j], sacc, 0, 0, 0);
+        // From here on the epilogue is WAVE-LOCAL: wave ii owns image img0 + ii -- its 36 rows of the parked block, its
+        // statistics, its similarity terms -- so E1 -> E2 -> E3 need no workgroup barrier (LDS operations of one wave
+        // execute in order), and the four waves carry the same load.  That matters more than the instruction count: a
+        // main-loop wave of the co-resident workgroup that shares its SIMD with a busy epilogue wave falls behind, and
+        // its three sibling waves then idle at their per-chunk barrier -- unbalanced epilogue work is paid four times.
+        // E1: statistics of the first normalisation, along each caption's words, per (region row, caption):
+        // sum_w f(a[row][w]), f = leaky^2 | a^2 | |a| | |leaky|.  One lane per region row (36 of 64) walks the tile's columns
+        // caption by caption (bounds are wave-uniform: scalar loop control), ~3 vector instructions per element.  (Round 1
+        // ran this as an MFMA product with a [64 x 16] indicator matrix: 6 % of its multiply-adds useful.)
+        // The reciprocal is stored multiplied by lambda_softmax * log2(e): E2a needs nothing else (see there).
+        const bool img_ok = img0 + wave < g.Ni;      // wave-uniform
+        if (img_ok && lane < SC_R) {
+            const int row = wave * SC_R + lane;
+            const float *colbase = &sm.arawt[0][row];          // (row, column c) at colbase[c * SC_LDT]
+            if (norm == 0 || norm == 1 || norm == 5 || norm == 6) {
+                const float ls_log2e = ls * 1.44269504088896341f;
+                dispatch_norm(norm, [&](auto NC) {
+                    constexpr int NORM = decltype(NC)::value;
+                    for (int k = 0; k < ncap; ++k) {
+                        const int c0 = __builtin_amdgcn_readfirstlane(sm.meta.cap_start[k]);
+                        const int c1 = __builtin_amdgcn_readfirstlane(sm.meta.cap_start[k + 1]);
+                        float s0 = 0.f, s1 = 0.f;
+                        int c = c0;
+                        for (; c + 1 < c1; c += 2) {
+                            float v0 = colbase[c * SC_LDT], v1 = colbase[(c + 1) * SC_LDT];
+                            if (NORM == 0 || NORM == 6) { v0 = leaky(v0); v1 = leaky(v1); }
+                            s0 += (NORM <= 1) ? v0 * v0 : fabsf(v0);
+                            s1 += (NORM <= 1) ? v1 * v1 : fabsf(v1);
                         }
-                    f32x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = fast_rcp((NORM <= 1 ? fast_sqrt(sacc[j]) : sacc[j]) + 1e-8f);
-                    if (fi < SC_MAXCAP) *reinterpret_cast<f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]) = o;   // caption slot fi
+                        if (c < c1) {
+                            float v0 = colbase[c * SC_LDT];
+                            if (NORM == 0 || NORM == 6) v0 = leaky(v0);
+                            s0 += (NORM <= 1) ? v0 * v0 : fabsf(v0);
+                        }
+                        const float sum = s0 + s1;
+                        sm.stat[0][k][row] = fast_rcp((NORM <= 1 ? fast_sqrt(sum) : sum) + 1e-8f) * ls_log2e;
+                    }
+                });
+            } else if (norm == 2) {
+                for (int k = 0; k < ncap; ++k) {
+                    const int c0 = __builtin_amdgcn_readfirstlane(sm.meta.cap_start[k]);
+                    const int c1 = __builtin_amdgcn_readfirstlane(sm.meta.cap_start[k + 1]);
+                    NormAcc na;
+                    na.init(norm);
+                    for (int c = c0; c < c1; ++c) na.pass1(colbase[c * SC_LDT], norm);
+                    for (int c = c0; c < c1; ++c) na.pass2(colbase[c * SC_LDT], norm);
+                    na.finish(norm);
+                    sm.stat[0][k][row] = na.s0;
+                    sm.stat[1][k][row] = na.s1;
                 }
-            });
-        } else if (norm == 2) {
-            for (int idx = tid; idx < SC_MT * ncap; idx += SC_THREADS) {
-                const int k = idx / SC_MT, row = idx - k * SC_MT;
-                const int c0 = sm.meta.cap_start[k], c1 = sm.meta.cap_start[k + 1];
-                NormAcc na;
-                na.init(norm);
-                for (int c = c0; c < c1; ++c) na.pass1(AT(row, c), norm);
-                for (int c = c0; c < c1; ++c) na.pass2(AT(row, c), norm);
-                na.finish(norm);
-                sm.stat[0][k][row] = na.s0;
-                sm.stat[1][k][row] = na.s1;
             }
         }
-        __syncthreads();
         SC_TICK(2)   // E1
         // E2: one wave per image, one lane per word column.
         //   (a) attention weights e = exp(lambda_s * b [- max]); the max shift is skipped whenever the first
         //       normalisation bounds |b| <= 1 (all l2 / l1 / softmax forms; exp(+-lambda_s) is harmless in fp32);
         //       e overwrites the raw dot products of this lane's column;
-        //   (b) ||ctx||^2 = e^T G e / den^2:  T = G E on the matrix core (3 x 4 tiles, K = 36 -> 108 MFMAs per
-        //       wave), then a 12-term dot per lane and a 4-lane reduction.
+        //   (b) ||ctx||^2 = e^T G e / den^2:  T = G' E on the matrix core (G' = upper-triangular form of G: 60 MFMAs per wave
+        //       instead of the 108 of the full 3 x 4 tiles x K = 36), then a 12-term dot per lane and a 4-lane reduction.
         {
             const int ii = wave;
             const int w = lane;
@@ -265,9 +288,13 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                 const int kk = k < 0 ? 0 : k;
                 float *colp = &sm.arawt[w][ii * SC_R];
                 float a[SC_R], e[SC_R];
-                float mx = 0.f;
+                float den = 0.f, num = 0.f;
                 dispatch_norm(norm, [&](auto NC) {
                     constexpr int NORM = decltype(NC)::value;
+                    // l2 / l1 first norms: E1 stored 1/(norm + eps) already multiplied by lambda_softmax * log2(e), so the
+                    // attention weight is one v_exp_f32 of (leaky(a) | a) * stat -- two multiplies fewer per element
+                    constexpr bool FOLDED = (NORM == 0 || NORM == 1 || NORM == 5 || NORM == 6);
+                    float mx = 0.f;
 #pragma unroll
                     for (int r4 = 0; r4 < SC_R / 4; ++r4) {
                         const f32x4 av = *reinterpret_cast<const f32x4 *>(colp + 4 * r4);
@@ -277,7 +304,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             a[4 * r4 + j] = av[j];
-                            e[4 * r4 + j] = norm_apply_c<NORM>(av[j], s0[j], s1[j]) * ls;
+                            e[4 * r4 + j] = FOLDED ? norm_apply_c<NORM>(av[j], s0[j], s1[j]) : norm_apply_c<NORM>(av[j], s0[j], s1[j]) * ls;
                         }
                     }
                     if (NORM == 3 || NORM == 4) {
@@ -285,14 +312,13 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
 #pragma unroll
                         for (int r = 1; r < SC_R; ++r) mx = fmaxf(mx, e[r]);
                     }
-                });
-                float den = 0.f, num = 0.f;
 #pragma unroll
-                for (int r = 0; r < SC_R; ++r) {
-                    e[r] = fast_exp(e[r] - mx);
-                    den += e[r];
-                    num += e[r] * a[r];
-                }
+                    for (int r = 0; r < SC_R; ++r) {
+                        e[r] = FOLDED ? __builtin_amdgcn_exp2f(e[r]) : fast_exp(e[r] - mx);
+                        den += e[r];
+                        num += e[r] * a[r];
+                    }
+                });
 #pragma unroll
                 for (int r4 = 0; r4 < SC_R / 4; ++r4)
                     *reinterpret_cast<f32x4 *>(colp + 4 * r4) = f32x4{e[4 * r4], e[4 * r4 + 1], e[4 * r4 + 2], e[4 * r4 + 3]};
@@ -311,14 +337,15 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const f32x4 bv = *reinterpret_cast<const f32x4 *>(ec + 16 * u + 4 * fg);
+                        // row tile mt only meets k-blocks u >= mt (upper-triangular G): 60 MFMAs per wave instead of 108
 #pragma unroll
-                        for (int mt = 0; mt < 3; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].x, bv[0], tacc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt <= u; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].x, bv[0], tacc[mt][nt], 0, 0, 0);
 #pragma unroll
-                        for (int mt = 0; mt < 3; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].y, bv[1], tacc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt <= u; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].y, bv[1], tacc[mt][nt], 0, 0, 0);
 #pragma unroll
-                        for (int mt = 0; mt < 3; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].z, bv[2], tacc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt <= u; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].z, bv[2], tacc[mt][nt], 0, 0, 0);
 #pragma unroll
-                        for (int mt = 0; mt < 3; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].w, bv[3], tacc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt <= u; ++mt) tacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[mt][u].w, bv[3], tacc[mt][nt], 0, 0, 0);
                     }
                     const float b4 = ec[32 + fg];
 #pragma unroll
@@ -361,33 +388,28 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
                 const float w2 = fast_sqrt(fmaxf(q, 0.f));
                 simv = num * fast_rcp(fmaxf(w1 * w2, 1e-8f));   // cosine_similarity, Objectives.py:10-15
             }
-            sm.rowsim[ii][w] = simv;
-        }
-        __syncthreads();
-        SC_TICK(3)   // E2
-        if (g.dbg_cycles && tid == 0) atomicAdd(&g.dbg_cycles[7], __builtin_amdgcn_s_memrealtime() - real0_);
-        // E3: aggregate over the words of each caption (Objectives.py:355-366)
-        if (tid < SC_IMGS * SC_MAXCAP) {
-            const int ii = tid / SC_MAXCAP, k = tid % SC_MAXCAP;
-            const int64_t img = img0 + ii;
-            if (k < ncap && img < g.Ni) {
-                const int c0 = sm.meta.cap_start[k], c1 = sm.meta.cap_start[k + 1];
-                float r;
-                if (g.agg == 0) {
-                    r = 0.f;
-                    for (int c = c0; c < c1; ++c) r += fast_exp(sm.rowsim[ii][c] * g.lambda_lse);
-                    r = fast_log(r) / g.lambda_lse;
-                } else if (g.agg == 1) {
-                    r = -INFINITY;
-                    for (int c = c0; c < c1; ++c) r = fmaxf(r, sm.rowsim[ii][c]);
-                } else {
-                    r = 0.f;
-                    for (int c = c0; c < c1; ++c) r += sm.rowsim[ii][c];
-                    if (g.agg == 3) r /= (float)(c1 - c0);
+            // E3: aggregate over the words of each caption (Objectives.py:355-366), still inside the wave: every lane turns
+            // its word's term into the summand (one exp per lane for LogSumExp), lanes 0..15 then fold their caption's words
+            if (img < g.Ni) {
+                sm.rowsim[ii][w] = (g.agg == 0) ? fast_exp(simv * g.lambda_lse) : simv;
+                if (lane < ncap) {
+                    const int c0 = sm.meta.cap_start[lane], c1 = sm.meta.cap_start[lane + 1];
+                    float r;
+                    if (g.agg == 1) {
+                        r = -INFINITY;
+                        for (int c = c0; c < c1; ++c) r = fmaxf(r, sm.rowsim[ii][c]);
+                    } else {
+                        r = 0.f;
+                        for (int c = c0; c < c1; ++c) r += sm.rowsim[ii][c];
+                        if (g.agg == 0) r = fast_log(r) / g.lambda_lse;
+                        else if (g.agg == 3) r /= (float)(c1 - c0);
+                    }
+                    g.S[img * g.ldS + sm.meta.cap_id[lane]] = r;
                 }
-                g.S[img * g.ldS + sm.meta.cap_id[k]] = r;
             }
         }
+        SC_TICK(3)   // E2 + E3
+        if (g.dbg_cycles && tid == 0) atomicAdd(&g.dbg_cycles[7], __builtin_amdgcn_s_memrealtime() - real0_);
     } else {
         // ================= i2t: regions attend over the words of every caption ============
         // E1: first normalisation runs along the 36 regions (query axis), per (image, word)
@@ -568,13 +590,21 @@ __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
             }
         }
     }
+  }   // tile loop
+}
+
+template <int PREC>
+__global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
+    scan_xattn_body<PREC>(g);
 }
 
 // ---- precompute kernels -------------------------------------------------------------------
 // G[n] = X_n X_n^T for X_n [rows, D] (rows <= 64): one workgroup per matrix.
+// upper2: write the upper-triangular form G'[r][s] = G[r][s] (r == s), 2 G[r][s] (r < s), 0 (r > s): e^T G' e == e^T G e
+// (G is symmetric bit for bit: the same products in the same order), and the consumer skips the all-zero blocks.
 __global__ __launch_bounds__(256) void gram_kernel(const float *__restrict__ X, const int64_t *__restrict__ row_off,
                                                    const int32_t *__restrict__ row_cnt, int fixed_rows, int D,
-                                                   float *__restrict__ G, const int64_t *__restrict__ g_off) {
+                                                   float *__restrict__ G, const int64_t *__restrict__ g_off, int upper2) {
     __shared__ float xs[64][33];
     const int64_t n = blockIdx.x;
     const int rows = row_cnt ? row_cnt[n] : fixed_rows;
@@ -606,7 +636,14 @@ __global__ __launch_bounds__(256) void gram_kernel(const float *__restrict__ X, 
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int pidx = threadIdx.x + 256 * e;
-        if (pidx < npair) out[pidx] = acc[e];
+        if (pidx < npair) {
+            float v = acc[e];
+            if (upper2) {
+                const int r1 = pidx / rows, r2 = pidx % rows;
+                v = r2 > r1 ? 2.f * v : (r2 == r1 ? v : 0.f);
+            }
+            out[pidx] = v;
+        }
     }
 }
 
@@ -850,7 +887,7 @@ int scan_prepare_impl(const float *img, const float *words, const int64_t *cap_o
     ITR_CHECK_LAUNCH("scan pack");
     if (mode == 0) {
         hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Ni), dim3(256), 0, st, img, (const int64_t *)nullptr,
-                           (const int32_t *)nullptr, R, D, w.gram, (const int64_t *)nullptr);
+                           (const int32_t *)nullptr, R, D, w.gram, (const int64_t *)nullptr, 1);
         ITR_CHECK_LAUNCH("scan gram");
     } else {
         hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)ceil_div(Ni * R, 4)), dim3(256), 0, st, img, Ni * R, D, w.vnorm);
@@ -858,7 +895,7 @@ int scan_prepare_impl(const float *img, const float *words, const int64_t *cap_o
         hipLaunchKernelGGL(sq_prefix_kernel, dim3(1), dim3(1024), 0, st, cap_len, Nc, w.coff);
         ITR_CHECK_LAUNCH("scan cgram offsets");
         hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Nc), dim3(256), 0, st, words, cap_off, cap_len, 0, D, w.cgram,
-                           (const int64_t *)w.coff);
+                           (const int64_t *)w.coff, 0);
         ITR_CHECK_LAUNCH("scan caption gram");
     }
     return ITR_OK;
@@ -950,6 +987,11 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
     }
     size_t lds = sizeof(ScanSmem);
     if (const char *ex = getenv("ITR_SCAN_LDS_EXTRA")) lds += (size_t)atoi(ex);   // occupancy experiments only
+    // tiles per workgroup (ITR_SCAN_TPW overrides, tools/scan_ablate2.py).  Measured at 1k x 5k: 37.13 / 36.89 / 36.94 / 36.85 ms
+    // for 1 / 2 / 4 / 8 -- the launch gaps of one-tile workgroups are already covered by the co-resident workgroup.
+    a.tpw = 2;
+    if (const char *te = getenv("ITR_SCAN_TPW")) a.tpw = atoi(te) > 0 ? atoi(te) : 1;
+    const int64_t grid = ceil_div(ceil_div(PI * PJ, 8), (int64_t)a.tpw) * 64 * 8;
     if (bf16_ws) {
         ITR_UNSUPPORTED((uint64_t)Ni * R * D * 4 >= (1ull << 32) || (uint64_t)SC_NT * D * 4 >= (1ull << 32),
                         "itr_scan_xattn_scores_bf16x3: per-launch operand offsets must fit 32 bits; shard the images");
@@ -970,21 +1012,21 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
         const int abl = getenv("ITR_SCAN_BF16_ABLATE") ? atoi(getenv("ITR_SCAN_BF16_ABLATE")) : 0;
         if (abl == 5) {
             ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            hipLaunchKernelGGL(scan_xattn_kernel<5>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+            hipLaunchKernelGGL(scan_xattn_kernel<5>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
         } else if (abl == 9) {
             ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            hipLaunchKernelGGL(scan_xattn_kernel<9>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+            hipLaunchKernelGGL(scan_xattn_kernel<9>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
         } else if (f16) {
             static bool attr3 = false;
             if (!attr3) {
                 ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr3 = true;
             }
-            hipLaunchKernelGGL(scan_xattn_kernel<3>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+            hipLaunchKernelGGL(scan_xattn_kernel<3>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
         } else
-            hipLaunchKernelGGL(scan_xattn_kernel<1>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+            hipLaunchKernelGGL(scan_xattn_kernel<1>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
     } else {
-        hipLaunchKernelGGL(scan_xattn_kernel<0>, dim3((unsigned)nblk), dim3(SC_THREADS), lds, st, a);
+        hipLaunchKernelGGL(scan_xattn_kernel<0>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
     }
     ITR_CHECK_LAUNCH("scan_xattn");
     return ITR_OK;
