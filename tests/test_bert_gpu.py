@@ -75,11 +75,13 @@ def test_saem_image_golden(golden, dev, tmp_path):
     assert maxdiff(im(T(g["saem_img_x"]).to(dev)), g["saem_img_y"]) <= 2e-5
 
 
-def test_bert_base_shape_vs_oracle(dev):
-    """BERT-base geometry (768 hidden, 12 heads of 64, 3072 intermediate), 2 layers, 32 tokens."""
+@pytest.mark.parametrize("n_layers", [2, 12])
+def test_bert_base_shape_vs_oracle(dev, n_layers):
+    """BERT-base geometry (768 hidden, 12 heads of 64, 3072 intermediate), 32 tokens; 12 layers = the full stack of
+    BASELINE config 4 (bert.py:305-358), EVERY layer's output against the oracle."""
     import itr_oracle as O
     torch.manual_seed(0)
-    cfg = bert.BertConfig(vocab_size=500, hidden_size=768, num_hidden_layers=2, num_attention_heads=12,
+    cfg = bert.BertConfig(vocab_size=500, hidden_size=768, num_hidden_layers=n_layers, num_attention_heads=12,
                           intermediate_size=3072, max_position_embeddings=64, type_vocab_size=2)
     model = bert.BertModel(cfg)
     for p in model.parameters():
@@ -92,8 +94,10 @@ def test_bert_base_shape_vs_oracle(dev):
     for b, l in enumerate([32, 20, 11, 7, 3, 1]):
         mask[b, l:] = 0
     layers, pooled = model(ids.to(dev), None, mask.to(dev))
-    ol, op = O.bert_model(w, ids, None, mask, 2, 12)
-    assert maxdiff(layers[-1], ol[-1]) <= 5e-5
+    ol, op = O.bert_model(w, ids, None, mask, n_layers, 12)
+    assert len(layers) == len(ol) == n_layers
+    for a, b in zip(layers, ol):
+        assert maxdiff(a, b) <= 5e-5
     assert maxdiff(pooled, op) <= 5e-5
 
 

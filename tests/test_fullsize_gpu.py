@@ -98,3 +98,119 @@ def test_ranker_full_size(dev):
     greater = int((S > gt[None, :]).sum().item())            # continuous random scores: no exact ties
     assert int(t_rank.astype(np.int64).sum()) == greater
     assert ops.recall_from_ranks(i_rank)[:3] == tuple(100.0 * int((i_rank < k).sum()) / n_img for k in (1, 5, 10))
+
+
+def test_scan_repeated_launches_are_bit_identical(dev):
+    """Stress for the hand-counted loads of the main loop (two workgroups per CU, 8 launches back to back): a load that
+    lands in a register after it was reused shows up as a launch-to-launch difference or a non-finite score."""
+    img, words, lens, off = _problem(1000, 23, dev)
+    plan = ops.ScanPlan(off, lens, words.shape[0], dev)
+    ws = ops.scan_prepare(img, words, plan)
+    ref = ops.scan_xattn_scores(img, words, plan, workspace=ws).clone()
+    assert bool(torch.isfinite(ref).all())
+    for _ in range(8):
+        again = ops.scan_xattn_scores(img, words, plan, workspace=ws)
+        assert torch.equal(again, ref)
+
+
+@pytest.mark.parametrize("mod", ['SAF', 'SGR'])
+def test_sgraf_full_size(dev, mod):
+    """BASELINE config 5 shape (embed 1024, sim_dim 256, sgr_step 3) on the f30k-size problem 1k x 5k: oracle spot check on
+    24 scattered images x 40 scattered captions (a pair's score depends on that pair only: BatchNorms run on running
+    statistics), and row-shard invariance (the multi-GPU contract of SURVEY 8e) -- Fusionmodule.py:406-451."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    import sgraf_weights
+    n_img, D, S_ = 1000, 1024, 256
+    img, words, lens, off = _problem(n_img, 17, dev, D)
+    words = ops.l2norm(words)                               # SGRAF's text tower normalises the word vectors
+    n_cap = len(lens)
+    w = sgraf_weights.make(D, S_)
+    wd = {k: v.to(dev) for k, v in w.items()}
+    plan = ops.ScanPlan(off, lens, words.shape[0], dev)
+    S = ops.sgraf_scores(img, words, plan, wd, mod, 3)
+    assert S.shape == (n_img, n_cap) and bool(torch.isfinite(S).all())
+    assert float(S.min()) > 0.0 and float(S.max()) < 1.0   # sigmoid outputs
+    rng = np.random.RandomState(7)
+    ri = np.sort(rng.choice(n_img, 24, replace=False))
+    ci = np.sort(rng.choice(n_cap, 40, replace=False))
+    L = int(lens[ci].max())
+    cap = torch.zeros(len(ci), L, D)
+    for k, c in enumerate(ci):
+        cap[k, :lens[c]] = words[off[c]:off[c] + lens[c]].cpu()
+    want = O.sgraf_similarity(w, img[ri].cpu(), cap, [int(lens[c]) for c in ci], mod, 3)
+    got = S[ri][:, ci].cpu()
+    assert float((got - want).abs().max()) <= 5e-6         # the tolerance of the small-size SGRAF parity tests
+    # row block scored alone (a multiple of the 16-image block): identical rows
+    r0, r1 = 112, 240
+    Sb = ops.sgraf_scores(img[r0:r1].contiguous(), words, plan, wd, mod, 3)
+    assert torch.equal(Sb, S[r0:r1])
+
+
+@pytest.mark.parametrize("kind", ["SAEM", "CAMERA"])
+def test_pooled_bert_models_full_size(dev, kind):
+    """BASELINE config 4 at MS-COCO size: SAEM (BERT-base + cnn head, D = 256, pdist_cos) and CAMERA (BERT-base + AGSA,
+    12 views x 2048, MultiViewMatching) through the sharded evaluator (evalpipe.PooledModelEval) on 5 000 images x
+    25 000 captions -- Models.py:600-645, Fusionmodule.py:674-692, Objectives.py:310-323.  Checked: the towers + scorer
+    against the CPU oracle on the first 6 images / 30 captions (the 12-layer BERT stack included), scattered rows /
+    columns of the rank vectors against a host argsort of the same matrix, row-block invariance."""
+    import os
+    import bench
+    from itr_amd import config as C, evalpipe
+    from itr_amd.modalmodule import get_model
+    n_img, n_cap = 5000, 25000
+    cfg_file, ckpt, trans = bench.bert_files(os.path.join("/tmp", "itr_bench_bert"))
+    cfg = C.build_config(['with', kind, 'data_name=coco_precomp'])
+    cfg.update(bert_config_file=cfg_file, init_checkpoint=ckpt, trans_cfg=trans, vocab_size=30522)
+    torch.manual_seed(0)
+    model = get_model(cfg)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    model.val_start()
+    feats, boxes, imgs_wh, ids, mask, types, lengths = bench.pooled_inputs(n_img, n_cap, kind, dev)
+    pe = evalpipe.PooledModelEval(model, evalpipe.Comm(), batch=1024)
+    lens = [int(x) for x in lengths]
+    S, ranks = pe.eval(feats, boxes, imgs_wh, ids, mask, types, lens, n_img, n_cap)
+    assert S.shape == (n_img, n_cap) and bool(torch.isfinite(S).all())
+    # ---- oracle: towers + scorer on a corner of the problem
+    ns, ncs = 6, 30
+    wi = {k: v.detach().cpu() for k, v in model.img_enc.state_dict().items() if "num_batches_tracked" not in k}
+    wt = {k: v.detach().cpu() for k, v in model.txt_enc.state_dict().items() if "num_batches_tracked" not in k}
+    with torch.no_grad():
+        if kind == "CAMERA":
+            img_o, _ = O.camera_image(wi, feats[:ns].cpu(), boxes[:ns].cpu(), imgs_wh[:ns].cpu(), cfg["head"])
+            cap_o = O.camera_text(wt, ids[:ncs].cpu(), mask[:ncs].cpu(), types[:ncs].cpu(), 12, 12, cfg["head"])
+            S_o = O.multi_view_matching(img_o, cap_o)
+        else:
+            img_o = O.saem_image(wi, feats[:ns].cpu(), 4)
+            cap_o = O.saem_text(wt, cfg["txt_stru"], ids[:ncs].cpu(), mask[:ncs].cpu(), types[:ncs].cpu(), 12, 12, 4)
+            S_o = O.pdist_cos(img_o, cap_o)
+    assert float((S[:ns, :ncs].cpu() - S_o).abs().max()) <= 2e-5
+    # ---- rank vectors vs a host argsort of the same matrix (evaluation.py:156-222)
+    i_rank, i_top, t_rank, t_top = [np.asarray(r) for r in ranks]
+    rng = np.random.RandomState(1)
+    for i in rng.choice(n_img, 24, replace=False):
+        row = S[i].cpu().numpy()
+        order = np.argsort(row, kind="stable")[::-1]
+        pos = np.empty(n_cap, np.int64)
+        pos[order] = np.arange(n_cap)
+        lo = min(int((row > row[g_]).sum()) for g_ in range(5 * i, 5 * i + 5))       # exact ties (random-init BERT: near-identical
+        hi = min(int((row >= row[g_]).sum()) - 1 for g_ in range(5 * i, 5 * i + 5))  # captions): the rank lies in the tie band
+        assert lo <= i_rank[i] <= hi
+    for j in rng.choice(n_cap, 24, replace=False):
+        col = S[:, j].cpu().numpy()
+        assert int((col > col[j // 5]).sum()) <= t_rank[j] <= int((col >= col[j // 5]).sum()) - 1
+    want = ops.rank_counts(S)
+    assert (want[0].cpu().numpy() == i_rank).all() and (want[2].cpu().numpy() == t_rank).all()
+    # ---- a row block of images encoded and scored alone gives the same rows
+    r0, r1 = 1024, 1024 + 256
+    img_b, _ = pe.encode(feats[r0:r1], None if boxes is None else boxes[r0:r1], None if imgs_wh is None else imgs_wh[r0:r1],
+                         ids[:8], mask[:8], types[:8], lens[:8])
+    img_all, cap_all = pe.encode(feats[r0:r1], None if boxes is None else boxes[r0:r1], None if imgs_wh is None else imgs_wh[r0:r1],
+                                 ids[:2048], mask[:2048], types[:2048], lens[:2048])
+    assert torch.equal(img_b, img_all)
+    Sb = pe._score(img_all, cap_all)
+    assert float((Sb - S[r0:r1, :2048]).abs().max()) <= 1e-6

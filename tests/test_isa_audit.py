@@ -58,3 +58,10 @@ def test_audit_detects_a_touched_register():
     assert any("v32, v15" in r for r in rep)            # second load never covered
     assert not any("v31, v10" in r for r in rep)        # covered by the wait
     assert any("in flight at s_endpgm" in r for r in rep)
+
+
+def test_generated_main_loop_is_current():
+    """csrc/scan_mainloop_asm.inc is generated (tools/gen_scan_mainloop.py); the committed file must be what the generator emits."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_scan_mainloop.py"), "--check"])
+    assert r.returncode == 0, "regenerate: python tools/gen_scan_mainloop.py"

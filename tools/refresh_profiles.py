@@ -26,14 +26,14 @@ def counter(kernel, cname):
     """value 'per dispatch' of `cname` in the block of `kernel`"""
     blocks = re.split(r"\n   (?=\S)", summary)
     for b in blocks:
-        if b.lstrip().startswith(kernel):
+        if b.lstrip().startswith(kernel) or b.lstrip().startswith("void " + kernel):
             mm = re.search(r"%s\s+per dispatch ([0-9.e+]+)" % re.escape(cname), b)
             if mm:
                 return float(mm.group(1))
     return None
 
 
-kern = "itr::scan_xattn_kernel"
+kern = "itr::scan_xattn_kernel<0>"
 f, w = counter(kern, "FETCH_SIZE"), counter(kern, "WRITE_SIZE")
 out = {"kernel": kern, "workload": workload, "n_gpus": 1,
        "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
@@ -41,7 +41,9 @@ out = {"kernel": kern, "workload": workload, "n_gpus": 1,
        "TCC_HIT_sum": counter(kern, "TCC_HIT_sum"), "TCC_MISS_sum": counter(kern, "TCC_MISS_sum"),
        "SQ_INSTS_MFMA": counter(kern, "SQ_INSTS_MFMA"), "SQ_VALU_MFMA_BUSY_CYCLES": counter(kern, "SQ_VALU_MFMA_BUSY_CYCLES"),
        "SQ_BUSY_CYCLES": counter(kern, "SQ_BUSY_CYCLES"), "GRBM_GUI_ACTIVE": counter(kern, "GRBM_GUI_ACTIVE"),
-       "source": "%s/%s (separate --pmc passes)" % (dst.rstrip("/"), name)}
+       "source": "%s/%s (separate --pmc passes)" % (dst.rstrip("/"), name),
+       # the commit the profiled tree was built from (bench.py prints it next to the replayed traffic figure)
+       "commit": __import__("subprocess").run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"}
 json.dump(out, open(os.path.join(dst, "scan_pmc.json"), "w"), indent=1)
 if len(sys.argv) > 3:
     shutil.copy(sys.argv[3], os.path.join(dst, "bench_n1.json"))
