@@ -914,7 +914,7 @@ def g18():
 
 
 # ------------------------------------------------------------------ G19 CAMERA.train_emb (a14), drop = 0, BERT dropout 0
-def g19():
+def _g19_try(model_seed):
     """The reference's own CAMERA.train_emb (Models.py:613-645) run twice on CPU (drop = 0 and BERT dropout probabilities 0, see
     g18): Rank_Loss / Div_loss, the gradients of the trainable parameters after step 1 and all parameters / BatchNorm running
     statistics after step 2."""
@@ -937,12 +937,12 @@ def g19():
     out['bert_cfg'] = json.dumps(cfg_d)
     for k, v in sd(bm).items():
         out['wbert_' + k] = v
-    B, L, F_, E = 6, 10, 24, 32
+    B, L, F_, E = 3, 10, 24, 32       # 3 images: half as many relu inputs as 6 -- see g19 on why that matters
     cfg = dict(name='CAMERA', bert_config_file=os.path.join(tmp, 'bert_config.json'), init_checkpoint=os.path.join(tmp, 'pytorch_model.bin'),
                img_dim=F_, embed_size=E, head=2, smry_k=12, drop=0.0, margin=0.2, max_violation=True, batch_size=B, learning_rate=1e-3,
                grad_clip=2.0, smry_lamda=0.01)
     with torch.enable_grad():
-        torch.manual_seed(191)
+        torch.manual_seed(model_seed)
         model = Models.CAMERA(cfg)
         for name, p_ in list(model.txt_enc.named_parameters()) + list(model.img_enc.named_parameters()):
             if 'bert.' not in name:
@@ -985,7 +985,38 @@ def g19():
                     if 'bert.' not in k:
                         out[pre + 'txt_' + k] = v
         print("   rank loss %.5f / %.5f   div %.5f / %.5f" % (out['s1_rank_loss'], out['s2_rank_loss'], out['s1_div_loss'], out['s2_div_loss']))
-    save('g19_camera_train', **out)
+    return out
+
+
+def g19():
+    """G19 with a fixture that is NOT ill-conditioned: a pre-activation within fp32 rounding of a relu kink flips its sign
+    between the CPU run and any other fp32 evaluation order, and the gradients upstream then differ by percents (round 1's
+    fixture had two such values within 5e-7).  The model seed is searched until every relu input of both steps (the dilated
+    summarisation convolutions camera_.py:110 with their 1 024 channels x 36 regions per image, the text head
+    TextEncoder.py:187 -- 223 000 pre-activations at batch 3) is at least 1e-6 away from zero, several times the absolute
+    difference two fp32 evaluation orders produce on values of this size.  (A 1e-4 margin cannot exist: with that many values
+    of scale ~0.1 about a hundred fall inside it for every seed; even 1e-6 takes tens of seeds to find.)"""
+    import torch.nn.functional as F
+    real_relu = F.relu
+    for model_seed in range(191, 791):
+        seen = []
+
+        def spy(x, *a, **k):
+            seen.append(float(x.detach().abs().min()))
+            return real_relu(x, *a, **k)
+        F.relu = spy
+        try:
+            out = _g19_try(model_seed)
+        finally:
+            F.relu = real_relu
+        margin = min(seen)
+        print("   model seed %d: %d relu calls, min |pre-activation| = %.2e" % (model_seed, len(seen), margin))
+        if margin >= 1e-6:
+            out['relu_margin'] = np.array(margin)
+            out['model_seed'] = np.array(model_seed)
+            save('g19_camera_train', **out)
+            return
+    raise RuntimeError("no well-conditioned seed found")
 
 
 # ------------------------------------------------------------------ G20 SGRAF.train_emb (a14), dropout modules set to p = 0

@@ -25,7 +25,7 @@ def test_camera_train_emb_matches_reference(golden, dev, tmp_path):
     bm = bert.BertModel(bert.BertConfig.from_dict(bcfg))
     bm.load_state_dict({k[6:]: T(g[k]) for k in g.files if k.startswith('wbert_')})
     torch.save(bm.state_dict(), tmp_path / 'pytorch_model.bin')
-    cfg = C.build_config(['with', 'CAMERA', 'data_name=coco_precomp', 'max_violation=True', 'learning_rate=0.001', 'batch_size=6'])
+    cfg = C.build_config(['with', 'CAMERA', 'data_name=coco_precomp', 'max_violation=True', 'learning_rate=0.001', 'batch_size=3'])
     cfg.update(bert_config_file=str(tmp_path / 'bert_config.json'), init_checkpoint=str(tmp_path / 'pytorch_model.bin'), img_dim=24, embed_size=32,
                head=2, smry_k=12, drop=0.0, smry_lamda=0.01, vocab_size=100)
     model = get_model(cfg)
@@ -61,13 +61,12 @@ def test_camera_train_emb_matches_reference(golden, dev, tmp_path):
                 else:
                     assert 'bert.' in n and p.grad is None, n
             assert n_checked >= 30
-            # relative L2 error per tensor.  In this fixture two pre-activations of mvs.convs_dilate.3 lie within 5e-7 of the relu
-            # kink (measured), fp32 rounding flips their sign against the CPU run, and that convolution's gradient and everything
-            # upstream of it (fc, AGSA value projection, position encoder, BatchNorm) moves by up to ~1 %: every tensor must be
-            # within 2 %, the tensors that do not depend on the kink (and biases with a ~1e-7 gradient aside) within 1e-4
-            assert max(d for n, d, m in report if m > 1e-5) <= 2e-2, sorted(report, key=lambda r: -r[1])[:5]
-            tight = [d for n, d, m in report if m > 1e-5 and d <= 1e-4]
-            assert len(tight) >= 0.55 * len(report), (len(tight), len(report))
+            # relative L2 error per tensor: EVERY gradient tensor within 1e-4 (biases with a ~1e-7 gradient aside).  The fixture is
+            # generated so that no relu input lies within 1e-6 of the kink (oracle/make_goldens.py g19, `relu_margin` in the
+            # fixture): round 1's fixture had two pre-activations within 5e-7 of zero, whose sign flipped against the CPU run and
+            # moved everything upstream by ~1 %
+            assert float(g["relu_margin"]) >= 1e-6
+            assert max(d for n, d, m in report if m > 1e-5) <= 1e-4, sorted(report, key=lambda r: -r[1])[:5]
     lr = 1e-3
     for which, mod in (('img', model.img_enc), ('txt', model.txt_enc)):
         for k, v in mod.state_dict().items():
@@ -84,8 +83,7 @@ def test_camera_train_emb_matches_reference(golden, dev, tmp_path):
                 else:
                     # Adam turns gradient noise into steps of up to lr where |g| ~ eps: a parameter whose true gradient vanishes
                     # (the value-projection bias in front of a BatchNorm: ~1e-6 in the reference run) random-walks by +-lr per step
-                    # in BOTH runs; everything else stays within 2 lr and 2e-4 on average (the relu-kink flip above moves a few
-                    # gradients by ~1 %)
+                    # in BOTH runs; everything else stays within 2 lr and 2e-4 on average
                     gkey = 's1_grad_%s.module.%s' % (which, k)
                     noise_only = gkey in g.files and float(np.abs(g[gkey]).max()) < 1e-5
                     if noise_only:
