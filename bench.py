@@ -232,6 +232,8 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
     if gru_text:
         # packed captions of this rank, sorted by length once (like the SCAN workload): ONE GRU call per step
         lengths, tokens = make_captions(n_cap, wl["vocab"])
+        cap_ranges = evalpipe.caption_ranges(n_cap, comm.world, lengths)      # near-equal token sums per rank
+        c0, c1 = cap_ranges[comm.rank]
         g = torch.Generator(device=dev)
         g.manual_seed(0)
         feats = ops.l2norm(torch.randn(n_img, 36, 2048, device=dev, generator=g))
@@ -255,7 +257,7 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
             cap_sorted = towers.encode_captions(toks, tok_off, lens_sorted, gather_last=True)
             cap = torch.empty_like(cap_sorted)
             cap[order_dev] = cap_sorted                      # back to the dataset order
-            cap_counts = [evalpipe.block_range(n_cap, comm.world, q)[1] - evalpipe.block_range(n_cap, comm.world, q)[0] for q in range(comm.world)]
+            cap_counts = [hi - lo for lo, hi in cap_ranges]
             cap_all, maxrows = comm.all_gather_rows(cap, cap_counts)
             if comm.on and any(c != maxrows for c in cap_counts):
                 cap_all = torch.cat([cap_all[q * maxrows:q * maxrows + cap_counts[q]] for q in range(comm.world)], 0)
@@ -426,7 +428,8 @@ def main():
     lengths, tokens = make_captions(n_cap, wl["vocab"])
     comm = evalpipe.Comm()
     i0, i1 = evalpipe.block_range(n_img, comm.world, comm.rank, 4)
-    c0, c1 = evalpipe.block_range(n_cap, comm.world, comm.rank)
+    cap_ranges = evalpipe.caption_ranges(n_cap, comm.world, lengths)      # near-equal TOKEN sums per rank
+    c0, c1 = cap_ranges[comm.rank]
     feats_local = feats[i0:i1].contiguous()
     feats_head = feats[:args.cpu_sample_images].cpu() if rank == 0 else None
     del feats
@@ -437,7 +440,8 @@ def main():
     timers = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
 
     def step(tm=None):
-        return model.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm, sgraf_weights=sim_w)
+        return model.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm, sgraf_weights=sim_w,
+                               cap_ranges=cap_ranges)
 
     def barrier():
         if use_dist:
@@ -451,8 +455,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         S, ranks, plan = step(timers)
-        # the step already synchronised the stream when it copied the ranks to the host
-        scan_ms.append(timers["scan_start"].elapsed_time(timers["scan_end"]))
+        # the step already synchronised the stream when it copied the ranks to the host; with several ranks the row block is
+        # scored in up to three launches (own captions while the exchange is in flight, then the others): their sum
+        scan_ms.append(sum(a.elapsed_time(b) for a, b in timers["segments"]))
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev if backend != "gloo" else "cpu", dtype=torch.float64)
@@ -524,14 +529,14 @@ def main():
             # products from split fp16 operands (hi.hi + hi.lo' + lo'.hi, fp32 accumulation) -- outside the timed region above
             vmodel = evalpipe.GruModelEval(model.wi, model.wt, dict(cfg, scan_precision="fp16x3"), comm)
             vt = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
-            vstep = lambda tm=None: vmodel.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm)
+            vstep = lambda tm=None: vmodel.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm, cap_ranges=cap_ranges)
             vstep()
             torch.cuda.synchronize()
             tv = time.perf_counter()
             vk = []
             for _ in range(2):
                 Sv, ranks_v, _ = vstep(vt)
-                vk.append(vt["scan_start"].elapsed_time(vt["scan_end"]))
+                vk.append(sum(a.elapsed_time(b) for a, b in vt["segments"]))
             torch.cuda.synchronize()
             dtv = (time.perf_counter() - tv) / 2
             iv, tvv = _ops.recall_from_ranks(ranks_v[0]), _ops.recall_from_ranks(ranks_v[2])

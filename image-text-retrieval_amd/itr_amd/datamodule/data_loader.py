@@ -79,6 +79,52 @@ class PrecompDataset(data.Dataset):
         tokens = self.word_tokenize(self.caption_text(self.captions[index]).lower())
         return [self.vocab('<start>')] + [self.vocab(t) for t in tokens] + [self.vocab('<end>')]
 
+    def token_ids_range(self, lo, hi):
+        """token_ids of captions lo .. hi-1 at once -> (packed int64 ids, int64 lengths); the whole split is tokenised on the
+        first call and kept (evaluation asks for the same captions every epoch; every rank of a sharded evaluation needs all
+        lengths to balance its caption ranges by token count).  Uses the one-pass regex tokeniser when that is the
+        tokeniser in effect; any other `word_tokenize` goes caption by caption."""
+        if getattr(self, '_tok_all', None) is None:
+            n = len(self.captions)
+            default_regex = self.word_tokenize is tokenization.word_tokenize and not tokenization.nltk_available()
+            if default_regex or self.word_tokenize is tokenization.regex_word_tokenize:
+                flat, counts = tokenization.regex_word_tokenize_lines([self.caption_text(c).lower() for c in self.captions])
+                w2i, unk = self.vocab.word2idx, self.vocab('<unk>')
+                ids = np.fromiter((w2i.get(t, unk) for t in flat), dtype=np.int64, count=len(flat))
+                counts = np.asarray(counts, dtype=np.int64)
+                lens = counts + 2
+                off = np.concatenate([[0], np.cumsum(lens)])
+                packed = np.empty(int(off[-1]), dtype=np.int64)
+                packed[off[:-1]] = self.vocab('<start>')
+                packed[off[1:] - 1] = self.vocab('<end>')
+                body = np.ones(int(off[-1]), dtype=bool)
+                body[off[:-1]] = False
+                body[off[1:] - 1] = False
+                packed[body] = ids
+            else:
+                rows = [np.asarray(self.token_ids(i), dtype=np.int64) for i in range(n)]
+                lens = np.asarray([len(r) for r in rows], dtype=np.int64)
+                off = np.concatenate([[0], np.cumsum(lens)])
+                packed = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+            self._tok_all = (packed, lens, off)
+        packed, lens, off = self._tok_all
+        return packed[off[lo]:off[hi]], lens[lo:hi]
+
+    def bert_features_range(self, lo, hi):
+        """convert_to_feature of captions lo .. hi-1 -> (ids, mask, type_ids) int64 arrays [hi - lo, max_words]; rows are
+        computed once and kept (a validation pass asks for the same captions every epoch)."""
+        cache = self.__dict__.setdefault('_bert_rows', {})
+        miss = [i for i in range(lo, hi) if i not in cache]
+        for i in miss:
+            _, ids, mask, types = convert_to_feature(self.captions[i], self.max_words, self.tokenizer)
+            cache[i] = (ids, mask, types)
+        n = hi - lo
+        out = [np.zeros((n, self.max_words), np.int64) for _ in range(3)]
+        for r, i in enumerate(range(lo, hi)):
+            for k in range(3):
+                out[k][r] = cache[i][k]
+        return tuple(out)
+
     def vsrn_ids(self, index):
         """The caption layout the reference feeds VSRN (data_loader.py:117-125), as written: more than max_len tokens ->
         the last id moves to position max_len and the list is cut to max_len; then zeros (<pad>) up to max_len + 1 ids.

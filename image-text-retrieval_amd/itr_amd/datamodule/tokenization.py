@@ -19,6 +19,39 @@ def regex_word_tokenize(text):
     return _WORD_RE.findall(text)
 
 
+_WORD_OR_EOL_RE = re.compile(r"\w+|[^\w\s]|\n", re.UNICODE)
+
+
+def regex_word_tokenize_lines(texts):
+    """regex_word_tokenize of many one-line texts in ONE pass of the regex engine over their concatenation (a Python-level
+    loop over 25 000 captions costs ~0.4 s, this ~40 ms).  -> (flat token list, token count per text).  Texts must not
+    contain a newline (caption files hold one caption per line)."""
+    if not texts:
+        return [], []
+    blob = "\n".join(texts) + "\n"
+    toks = _WORD_OR_EOL_RE.findall(blob)
+    flat, counts, n = [], [], 0
+    for t in toks:
+        if t == "\n":
+            counts.append(n)
+            n = 0
+        else:
+            flat.append(t)
+            n += 1
+    if len(counts) != len(texts):
+        raise ValueError("regex_word_tokenize_lines: a text contains a newline")
+    return flat, counts
+
+
+def nltk_available():
+    try:
+        import nltk
+        nltk.tokenize.word_tokenize("a")
+        return True
+    except (ImportError, AttributeError, LookupError):
+        return False
+
+
 def word_tokenize(text):
     try:
         import nltk

@@ -32,6 +32,24 @@ def block_range(n, world, rank, align=1):
     return lo, min(n, lo + per)
 
 
+def caption_ranges(n_cap, world, weights=None):
+    """Contiguous caption range of every rank.  With `weights` (token count of every caption) the ranges carry near-equal
+    token sums -- the text towers' cost is per token and captions are ragged (SURVEY 8e: "balance shards by token count");
+    without, near-equal counts (BERT models: every caption is max_words ids, so counts ARE token counts)."""
+    if weights is None or world == 1:
+        return [block_range(n_cap, world, q) for q in range(world)]
+    w = np.asarray(weights, dtype=np.float64)
+    if len(w) != n_cap:
+        raise ValueError("caption_ranges: %d weights for %d captions" % (len(w), n_cap))
+    cs = np.concatenate([[0.0], np.cumsum(w)])
+    bounds = [0]
+    for q in range(1, world):
+        b = int(np.searchsorted(cs, cs[-1] * q / world, side='left'))
+        bounds.append(max(bounds[-1], min(n_cap, b)))
+    bounds.append(n_cap)
+    return [(bounds[q], bounds[q + 1]) for q in range(world)]
+
+
 class Comm:
     """Minimal collective layer: torch.distributed (backend nccl == RCCL over xGMI on ROCm, gloo in
     the CPU tests) or a no-op for a single process."""
@@ -62,6 +80,26 @@ class Comm:
         else:
             dist.all_gather_into_tensor(out, pad, group=self.group)
         return out, maxrows
+
+    def all_gather_rows_async(self, local, counts):
+        """all_gather_rows that returns at once: (buffer, maxrows, wait).  With RCCL the collective runs on the backend's
+        own stream; kernels launched on the current stream before `wait()` overlap it (the caller scores the captions
+        it already holds meanwhile).  gloo (tests) and a single process complete immediately."""
+        maxrows = int(max(counts))
+        if not self.on:
+            return local, maxrows, (lambda: None)
+        if self.host_staged and local.is_cuda or dist.get_backend(self.group) != "nccl":
+            out, maxrows = self.all_gather_rows(local, counts)
+            return out, maxrows, (lambda: None)
+        pad = torch.zeros((maxrows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+        out = torch.empty((self.world * maxrows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
+        keep = (pad,)            # the send buffer must outlive the collective
+
+        def wait(_w=work, _k=keep):
+            _w.wait()            # current stream waits for the collective; the host does not block
+        return out, maxrows, wait
 
     def all_gather_list(self, obj_array):
         """all-gather a small host int array (same length on every rank)."""
@@ -151,54 +189,80 @@ class GruModelEval:
                               n_cap_total, im_div, timers, sgraf_weights=sim_weights)
 
     def scan_eval(self, feats_local, tokens_packed, tok_off, lengths_sorted, order_local, n_img_total,
-                  n_cap_total, im_div=5, timers=None, sgraf_weights=None):
+                  n_cap_total, im_div=5, timers=None, sgraf_weights=None, cap_ranges=None):
+        """cap_ranges: the caption range of EVERY rank (caption_ranges(); default: equal counts); this rank's inputs hold
+        its own range.  Order of work with several ranks: host metadata exchange (lengths) -> towers -> the all-gather of
+        the packed word embeddings is started -> the columns of the captions this rank encoded itself are scored while the
+        exchange is in flight -> the other ranks' columns.  A pair's score depends on that pair only (whatever tile the
+        caption shares with others), so the matrix is bit-identical to the single-process one."""
         comm = self.comm
         cfg = self.cfg
         dev = feats_local.device
-        img = self.encode_images(feats_local)
-        words = self.encode_captions(tokens_packed, tok_off, lengths_sorted)
-        # -- step 2: one all-gather of packed word embeddings (+ tiny host metadata)
-        n_tok_local = int(words.shape[0])
+        ranges = cap_ranges or [block_range(n_cap_total, comm.world, q) for q in range(comm.world)]
+        cap_counts = [hi - lo for lo, hi in ranges]
+        # -- host metadata first: lengths / offsets of this rank's captions in their original order, token count
         lens_sorted = np.asarray(lengths_sorted, dtype=np.int64)
         off_sorted = np.concatenate([[0], np.cumsum(lens_sorted)[:-1]]) if len(lens_sorted) else np.zeros(0, np.int64)
         n_loc = len(lens_sorted)
+        if n_loc != cap_counts[comm.rank]:
+            raise ValueError("scan_eval: %d local captions, range of rank %d holds %d" % (n_loc, comm.rank, cap_counts[comm.rank]))
         len_loc = np.zeros(n_loc, np.int64)
         off_loc = np.zeros(n_loc, np.int64)
         len_loc[np.asarray(order_local)] = lens_sorted       # back to the original caption order
         off_loc[np.asarray(order_local)] = off_sorted
-        cap_counts = [block_range(n_cap_total, comm.world, q)[1] - block_range(n_cap_total, comm.world, q)[0]
-                      for q in range(comm.world)]
         maxcap = max(cap_counts)
         meta = np.zeros(2 * maxcap + 1, np.int64)
-        meta[0] = n_tok_local
+        meta[0] = int(lens_sorted.sum())
         meta[1:1 + n_loc] = len_loc
         meta[1 + maxcap:1 + maxcap + n_loc] = off_loc
         metas = comm.all_gather_list(meta)
         tok_counts = [int(m[0]) for m in metas]
-        words_all, maxtok = comm.all_gather_rows(words, tok_counts)
+        # -- step 1: towers
+        img = self.encode_images(feats_local)
+        words = self.encode_captions(tokens_packed, tok_off, lengths_sorted)
+        # -- step 2: start the one exchange
+        words_all, maxtok, wait = comm.all_gather_rows_async(words, tok_counts)
         cap_len = np.concatenate([m[1:1 + cap_counts[q]] for q, m in enumerate(metas)])
         cap_off = np.concatenate([m[1 + maxcap:1 + maxcap + cap_counts[q]] + q * maxtok for q, m in enumerate(metas)])
-        plan = ops.ScanPlan(cap_off, cap_len, words_all.shape[0], dev)
-        # -- step 3: local row block
         xa = cfg.get('cross_attn', 't2i')
-        if sgraf_weights is not None:
-            if timers is not None:
-                timers['scan_start'].record()
-            S = ops.sgraf_scores(img, words_all, plan, sgraf_weights, cfg.get('module_name', 'SAF'), cfg.get('sgr_step', 3))
-            if timers is not None:
-                timers['scan_end'].record()
-            row0 = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)[0]
-            return S, finalize_ranks(comm, S, row0, n_img_total, im_div), plan
-        ws = ops.scan_prepare(img, words_all, plan, xa)
+
         if timers is not None:
-            timers['scan_start'].record()
-        S = ops.scan_xattn_scores(img, words_all, plan, cross_attn=xa,
-                                  raw_feature_norm=cfg.get('raw_feature_norm', 'clipped_l2norm'),
-                                  agg_func=cfg.get('agg_func', 'LogSumExp'), lambda_lse=cfg.get('lambda_lse', 6.0),
-                                  lambda_softmax=cfg.get('lambda_softmax', 9.0), workspace=ws,
-                                  precision=cfg.get('scan_precision', 'fp32'))    # 'bf16x3': opt-in study variant
-        if timers is not None:
-            timers['scan_end'].record()
+            timers['segments'] = []      # (start, end) HIP events around every scoring launch of this step
+
+        def score(words_t, off, lens, out):
+            plan_ = ops.ScanPlan(off, lens, words_t.shape[0], dev)
+            ws = None if sgraf_weights is not None else ops.scan_prepare(img, words_t, plan_, xa)   # tile packing, Gram matrices: not the kernel timed
+            if timers is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            if sgraf_weights is not None:
+                ops.sgraf_scores(img, words_t, plan_, sgraf_weights, cfg.get('module_name', 'SAF'), cfg.get('sgr_step', 3), out=out)
+            else:
+                ops.scan_xattn_scores(img, words_t, plan_, cross_attn=xa, raw_feature_norm=cfg.get('raw_feature_norm', 'clipped_l2norm'),
+                                      agg_func=cfg.get('agg_func', 'LogSumExp'), lambda_lse=cfg.get('lambda_lse', 6.0),
+                                      lambda_softmax=cfg.get('lambda_softmax', 9.0), out=out, workspace=ws,
+                                      precision=cfg.get('scan_precision', 'fp32'))    # 'bf16x3': opt-in study variant (DESIGN.md 9)
+            if timers is not None:
+                ev[1].record()
+                timers['segments'].append(ev)
+            return plan_
+
+        # -- step 3: local row block.  One launch when there is nothing to wait for; else own columns first
+        S = torch.empty(img.shape[0], n_cap_total, device=dev, dtype=torch.float32)
+        if comm.world == 1:
+            wait()
+            plan = score(words_all, cap_off, cap_len, S)
+        else:
+            c0, c1 = ranges[comm.rank]
+            plan = None
+            if c1 > c0:
+                plan = score(words, off_loc, len_loc, S[:, c0:c1])
+            wait()
+            for lo, hi in ((0, c0), (c1, n_cap_total)):
+                if hi > lo:
+                    plan = score(words_all, cap_off[lo:hi], cap_len[lo:hi], S[:, lo:hi])
+        if timers is not None and timers['segments']:
+            timers['scan_start'], timers['scan_end'] = timers['segments'][-1]    # (one launch: the kernel; several: the last one)
         # -- step 4
         row0 = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)[0]
         ranks = finalize_ranks(comm, S, row0, n_img_total, im_div)
@@ -309,19 +373,38 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
     if im_div != 5 or n_cap % 5:
         raise NotImplementedError("evaluate_precomp expects the 5-captions-per-image layout of the precomp test splits")
     i0, i1 = block_range(n_img, comm.world, comm.rank, _IMG_ALIGN)
-    c0, c1 = block_range(n_cap, comm.world, comm.rank)
     model.val_start()
     feats = _features_to_device(dataset.images, img_lo + i0, img_lo + i1, dev)
     with torch.no_grad():
         if name in ('SCAN', 'SGRAF', 'VSE++', 'VSE_PP', 'VSRN'):
-            # VSRN: the reference's padded caption layout (every caption max_len + 1 ids, PrecompDataset.vsrn_ids)
-            ids = [dataset.vsrn_ids(cap_lo + j)[0] if name == 'VSRN' else dataset.token_ids(cap_lo + j) for j in range(c0, c1)]
-            lens = np.asarray([len(x) for x in ids], np.int64)
+            if name == 'VSRN':
+                # VSRN: the reference's padded caption layout (every caption max_len + 1 ids, PrecompDataset.vsrn_ids): equal lengths
+                ranges = caption_ranges(n_cap, comm.world)
+                c0, c1 = ranges[comm.rank]
+                ids = [dataset.vsrn_ids(cap_lo + j)[0] for j in range(c0, c1)]
+                lens = np.asarray([len(x) for x in ids], np.int64)
+                flat = np.concatenate([np.asarray(x, np.int64) for x in ids]) if len(ids) else np.zeros(0, np.int64)
+            else:
+                # every rank tokenises the split once (one regex pass, cached in the dataset) and so knows ALL lengths: the
+                # caption ranges are balanced by token count without any exchange
+                flat_all, lens_all = dataset.token_ids_range(cap_lo, cap_hi)
+                ranges = caption_ranges(n_cap, comm.world, lens_all)
+                c0, c1 = ranges[comm.rank]
+                offs_all = np.concatenate([[0], np.cumsum(lens_all)])
+                lens = lens_all[c0:c1]
+                flat = flat_all[offs_all[c0]:offs_all[c1]]
+            # sort this rank's captions by length (descending, stable -- pack_padded_sequence's order) and re-pack
             order = np.argsort(-lens, kind="stable")
             lens_sorted = [int(lens[i]) for i in order]
-            packed = np.concatenate([np.asarray(ids[i], np.int64) for i in order]) if len(order) else np.zeros(0, np.int64)
+            src_off = np.concatenate([[0], np.cumsum(lens)[:-1]]) if len(lens) else np.zeros(0, np.int64)
+            if len(order):
+                ls = lens[order]
+                dst_off = np.cumsum(ls) - ls
+                packed = flat[np.repeat(src_off[order] - dst_off, ls) + np.arange(int(ls.sum()))]
+            else:
+                packed = np.zeros(0, np.int64)
             tok_off = np.concatenate([[0], np.cumsum(lens_sorted)[:-1]]) if len(order) else np.zeros(0, np.int64)
-            toks, off = torch.from_numpy(packed).to(dev), torch.from_numpy(tok_off.astype(np.int64)).to(dev)
+            toks, off = ops.h2d(packed, dev, torch.int64), ops.h2d(tok_off.astype(np.int64), dev, torch.int64)
             wi = {k: v.detach() for k, v in model.img_enc.state_dict().items()}
             if hasattr(model.img_enc, '_weight'):      # precomp_enc_type='weight_norm' stores fc.weight_g / fc.weight_v only
                 wi['fc.weight'] = model.img_enc._weight().detach()
@@ -339,7 +422,7 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
                 cap_sorted = ev.encode_captions(toks, off, lens_sorted, gather_last=True)
                 cap = torch.empty_like(cap_sorted)
                 cap[torch.from_numpy(np.ascontiguousarray(order)).to(dev)] = cap_sorted
-                counts = [block_range(n_cap, comm.world, q)[1] - block_range(n_cap, comm.world, q)[0] for q in range(comm.world)]
+                counts = [hi - lo for lo, hi in ranges]
                 cap_all, maxrows = comm.all_gather_rows(cap, counts)
                 if comm.on and any(c != maxrows for c in counts):
                     cap_all = torch.cat([cap_all[q * maxrows:q * maxrows + counts[q]] for q in range(comm.world)], 0)
@@ -353,20 +436,18 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
                     raise ValueError("unknown measure:", cfg.get('measure'))
                 return finalize_ranks(comm, S, i0, n_img, im_div)
             sw = {k: v.detach() for k, v in model.sim_enc.state_dict().items()} if name == 'SGRAF' else None
-            _, ranks, _ = ev.scan_eval(feats, toks, off, lens_sorted, order, n_img, n_cap, im_div, sgraf_weights=sw)
+            _, ranks, _ = ev.scan_eval(feats, toks, off, lens_sorted, order, n_img, n_cap, im_div, sgraf_weights=sw, cap_ranges=ranges)
             return ranks
         # ---- BERT models: one vector per caption
         if name not in ('SAEM', 'CAMERA'):
             raise NotImplementedError("evaluate_precomp: model %r" % name)
-        from .datamodule.data_loader import convert_to_feature
-        feat_rows = [convert_to_feature(dataset.captions[cap_lo + j], dataset.max_words, dataset.tokenizer) for j in range(c0, c1)]
-        ids = torch.tensor([f[1] for f in feat_rows], dtype=torch.long, device=dev).reshape(-1, dataset.max_words)
-        mask = torch.tensor([f[2] for f in feat_rows], dtype=torch.long, device=dev).reshape(-1, dataset.max_words)
-        types = torch.tensor([f[3] for f in feat_rows], dtype=torch.long, device=dev).reshape(-1, dataset.max_words)
+        c0, c1 = block_range(n_cap, comm.world, comm.rank)     # every caption is max_words ids: equal counts = equal tokens
+        ids_np, mask_np, types_np = dataset.bert_features_range(cap_lo + c0, cap_lo + c1)
+        ids, mask, types = (ops.h2d(a, dev, torch.long).reshape(-1, dataset.max_words) for a in (ids_np, mask_np, types_np))
         boxes = wh = None
         if name == 'CAMERA':
             boxes = _features_to_device(dataset.boxes, img_lo + i0, img_lo + i1, dev)
             wh = _features_to_device(dataset.img_wh, img_lo + i0, img_lo + i1, dev)
         pe = PooledModelEval(model, comm, batch=batch)
-        _, ranks = pe.eval(feats, boxes, wh, ids, mask, types, [int(m.sum()) for m in mask.cpu()], n_img, n_cap, im_div)
+        _, ranks = pe.eval(feats, boxes, wh, ids, mask, types, [int(v) for v in mask_np.sum(1)], n_img, n_cap, im_div)
         return ranks

@@ -100,3 +100,24 @@ def test_block_range_partition():
                 for (a0, a1), (b0, b1) in zip(spans[:-1], spans[1:]):
                     assert a1 == b0 and a0 <= a1
                 assert all(lo % align == 0 or lo == n for lo, _ in spans)
+
+
+def test_caption_ranges_balance_tokens():
+    """caption shards are balanced by token count.  Ranges are contiguous, cover every caption once, and no
+    rank's token sum exceeds the mean by more than one caption's length."""
+    from itr_amd import evalpipe
+    rng = np.random.RandomState(0)
+    for n_cap, world in ((25000, 8), (5000, 3), (7, 4), (3, 8), (0, 2)):
+        lens = rng.randint(6, 21, size=n_cap)
+        lens[: n_cap // 3] = np.sort(lens[: n_cap // 3])[::-1]            # a skewed head: count-balanced shards would be unequal
+        r = evalpipe.caption_ranges(n_cap, world, lens)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == n_cap
+        assert all(r[q][1] == r[q + 1][0] and r[q][0] <= r[q][1] for q in range(world - 1))
+        sums = [int(lens[lo:hi].sum()) for lo, hi in r]
+        assert sum(sums) == int(lens.sum())
+        if n_cap >= world * 4:
+            assert max(sums) <= lens.sum() / world + 20 and min(sums) >= lens.sum() / world - 20
+    assert evalpipe.caption_ranges(10, 1, np.ones(10)) == [(0, 10)]
+    assert evalpipe.caption_ranges(10, 2) == [(0, 5), (5, 10)]
+    with pytest.raises(ValueError):
+        evalpipe.caption_ranges(10, 2, np.ones(9))

@@ -171,16 +171,19 @@ def test_sgraf_model_wrapper(golden, dev, mod):
 
 
 @pytest.mark.gpu
-def test_bench_collectives_single_rank():
-    """Every RCCL call of the N>1 path (all-gather of the packed words, fp32 max / int32 sum / sign-flipped int64
-    max all-reduces) executed with a 1-rank nccl group on the 1-GPU box: same ranks as the no-collective run."""
+@pytest.mark.parametrize("workload", ["scan_t2i_f30k1k", "sgraf_sgr_f30k1k", "sgraf_saf_f30k1k", "vsepp_f30k1k", "camera_f30k1k"])
+def test_bench_collectives_single_rank(workload):
+    """Every RCCL call of the N>1 path (asynchronous all-gather of the packed words / of the pooled caption vectors, fp32
+    max / int32 sum / sign-flipped int64 max all-reduces, the ragged rank gather) executed with a 1-rank nccl group on the
+    1-GPU box, for the word-level (SCAN, SGRAF) and the pooled (VSE++, CAMERA with its BERT tower) workloads: same rank
+    vectors as the no-collective run."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "scan_t2i_f30k1k", "--steps", "1",
-           "--warmup", "0", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline", "--no-variants"]
     outs = []
     for force in ("0", "1"):
         env = dict(os.environ, ITR_FORCE_COLLECTIVES=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
@@ -189,13 +192,13 @@ def test_bench_collectives_single_rank():
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]   # RCCL prints a version banner too
         assert len(line) == 1, r.stdout[-2000:]
         outs.append(json.loads(line[0]))
-    assert outs[0]["recall"] == outs[1]["recall"]
+    assert outs[0]["recall"] == outs[1]["recall"] and outs[0]["rank_checksum"] == outs[1]["rank_checksum"]
     assert outs[1]["n_gpus"] == 1
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload,world", [("scan_t2i_f30k1k", 2), ("scan_t2i_f30k1k", 3), ("sgraf_saf_f30k1k", 2), ("vsepp_f30k1k", 2),
-                                            ("vsrn_f30k1k", 2)])
+@pytest.mark.parametrize("workload,world", [("scan_t2i_f30k1k", 2), ("scan_t2i_f30k1k", 3), ("sgraf_saf_f30k1k", 2), ("sgraf_sgr_f30k1k", 3),
+                                            ("vsepp_f30k1k", 2), ("vsrn_f30k1k", 2), ("camera_f30k1k", 2)])
 def test_sharded_eval_equals_single_process_on_one_gpu(workload, world):
     """The WHOLE sharded pipeline (row-sharded images, caption slices, packed all-gather, max / sum / key reductions,
     ragged rank gather) with real kernels: `world` ranks share this box's one GPU through the gloo backend (RCCL refuses

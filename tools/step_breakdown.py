@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Host/device time split of one bench step (default workload): where do the milliseconds outside
 scan_xattn_kernel go?  Run on the GPU box:  python tools/step_breakdown.py [--workload W] [--shard P]
---shard P runs rank 0's share of a P-way row/caption sharding (what one of P GPUs would do, minus the collectives)."""
+--shard P runs rank 0's share of a P-way sharding (image rows by count, captions by TOKEN count -- evalpipe.caption_ranges)
+the way evalpipe.scan_eval orders it: towers -> [all-gather of the packed words starts] -> the columns of the rank's own
+captions are scored -> [wait] -> the other ranks' columns.  The collective itself cannot run on a 1-GPU box; the tool prints
+the time of the own-column launch next to the modelled exchange time it has to cover."""
 import argparse
 import cProfile
 import os
@@ -31,7 +34,8 @@ feats = ops.l2norm(torch.randn(n_img, 36, 2048, device=dev, generator=g))
 lengths, tokens = bench.make_captions(n_cap, wl["vocab"])
 P = args.shard
 i0, i1 = evalpipe.block_range(n_img, P, 0, 4)
-c0, c1 = evalpipe.block_range(n_cap, P, 0)
+ranges = evalpipe.caption_ranges(n_cap, P, lengths)
+c0, c1 = ranges[0]
 model = evalpipe.GruModelEval({k: v.to(dev) for k, v in wi.items()}, {k: v.to(dev) for k, v in wt.items()}, cfg)
 feats_local = feats[i0:i1].contiguous()
 toks, tok_off, lens_sorted, order = bench.shard_captions(lengths, tokens, c0, c1, dev)
@@ -47,10 +51,20 @@ def staged():
     t = [sync()]
     img = model.encode_images(feats_local); t.append(sync())
     words = model.encode_captions(toks, tok_off, lens_sorted); t.append(sync())
-    # stand-in for the all-gather: the full packed word matrix (encoded once outside the timing)
-    plan = ops.ScanPlan(cap_off_all, cap_len_all, words_all.shape[0], dev); t.append(sync())
-    ws = ops.scan_prepare(img, words_all, plan, "t2i"); t.append(sync())
-    S = ops.scan_xattn_scores(img, words_all, plan, cross_attn="t2i", workspace=ws); t.append(sync())
+    S = torch.empty(i1 - i0, n_cap, device=dev)
+    # own columns: scored from the local word matrix while the exchange would be in flight
+    ls_loc = np.zeros(c1 - c0, np.int64); off_loc = np.zeros(c1 - c0, np.int64)
+    lsrt = np.asarray(lens_sorted, np.int64)
+    ls_loc[np.asarray(order)] = lsrt; off_loc[np.asarray(order)] = np.concatenate([[0], np.cumsum(lsrt)[:-1]])
+    plan = ops.ScanPlan(off_loc, ls_loc, words.shape[0], dev)
+    ws = ops.scan_prepare(img, words, plan, "t2i")
+    ops.scan_xattn_scores(img, words, plan, cross_attn="t2i", workspace=ws, out=S[:, c0:c1]); t.append(sync())
+    # stand-in for the gathered buffer: the full packed word matrix (encoded once outside the timing)
+    if c1 < n_cap:
+        plan = ops.ScanPlan(cap_off_all[c1:], cap_len_all[c1:], words_all.shape[0], dev)
+        ws = ops.scan_prepare(img, words_all, plan, "t2i")
+        ops.scan_xattn_scores(img, words_all, plan, cross_attn="t2i", workspace=ws, out=S[:, c1:])
+    t.append(sync())
     r = evalpipe.finalize_ranks(evalpipe.Comm(), S, 0, n_img if P == 1 else (i1 - i0)); t.append(sync())
     return np.diff(t) * 1e3
 
@@ -63,9 +77,19 @@ cap_len_all[np.asarray(order_all)] = ls; cap_off_all[np.asarray(order_all)] = of
 if P > 1:   # rank-local GT layout is only meaningful for P == 1; ranks here are timing-only
     pass
 staged()
+tok_sums = [int(lengths[lo:hi].sum()) for lo, hi in ranges]
+recv_gb = (sum(tok_sums) - tok_sums[0]) * 1024 * 4 / 1e9
+xgmi_ms = recv_gb / (7 * 153.0 * 0.5) * 1e3          # 7 links x 153 GB/s per direction, half of peak
 for _ in range(2):
     d = staged()
-    print("P=%d  img %.1f  text %.1f  plan(host) %.1f  prepare %.1f  scan %.1f  rank %.1f   total %.1f ms" % ((P,) + tuple(d) + (d.sum(),)))
+    print("P=%d  img %.1f  text %.1f (%d of %d tokens)  own columns %.1f  other columns %.1f  rank %.1f   total %.1f ms" % (
+        (P, d[0], d[1], tok_sums[0], sum(tok_sums), d[2], d[3], d[4], d.sum())))
+if P > 1:
+    print("      exchange: %.2f GB received per GPU, ~%.1f ms at half of the xGMI peak -- %s the %.1f ms own-column launch it runs under; "
+          "token sums per rank min %d max %d (count-balanced shards: min %d max %d)" % (
+              recv_gb, xgmi_ms, "covered by" if xgmi_ms <= d[2] else "LONGER than", d[2], min(tok_sums), max(tok_sums),
+              min(int(lengths[evalpipe.block_range(n_cap, P, q)[0]:evalpipe.block_range(n_cap, P, q)[1]].sum()) for q in range(P)),
+              max(int(lengths[evalpipe.block_range(n_cap, P, q)[0]:evalpipe.block_range(n_cap, P, q)[1]].sum()) for q in range(P))))
 
 if P == 1:
     def step():
