@@ -218,6 +218,7 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
         cfg_file, ckpt, trans = bert_files(os.path.join("/tmp", "itr_bench_bert"))
         cfg = C.build_config(['with', kind, 'data_name=coco_precomp'])
         cfg.update(bert_config_file=cfg_file, init_checkpoint=ckpt, trans_cfg=trans, vocab_size=30522)
+    torch.manual_seed(0)       # (bert_files() draws random numbers only when it has to create the checkpoint: seed AFTER it)
     model = get_model(cfg)
     if kind == "VSRN":
         # Rs_GCN initialises its BatchNorm to gamma = beta = 0 (an identity layer): trained-like statistics instead
