@@ -90,7 +90,8 @@ class PrecompDataset(data.Dataset):
             if default_regex or self.word_tokenize is tokenization.regex_word_tokenize:
                 flat, counts = tokenization.regex_word_tokenize_lines([self.caption_text(c).lower() for c in self.captions])
                 w2i, unk = self.vocab.word2idx, self.vocab('<unk>')
-                ids = np.fromiter((w2i.get(t, unk) for t in flat), dtype=np.int64, count=len(flat))
+                import itertools
+                ids = np.fromiter(map(w2i.get, flat, itertools.repeat(unk)), dtype=np.int64, count=len(flat))
                 counts = np.asarray(counts, dtype=np.int64)
                 lens = counts + 2
                 off = np.concatenate([[0], np.cumsum(lens)])

@@ -190,14 +190,17 @@ class GruModelEval:
 
     def scan_eval(self, feats_local, tokens_packed, tok_off, lengths_sorted, order_local, n_img_total,
                   n_cap_total, im_div=5, timers=None, sgraf_weights=None, cap_ranges=None):
-        """cap_ranges: the caption range of EVERY rank (caption_ranges(); default: equal counts); this rank's inputs hold
+        """feats_local: this rank's region features [n_img_local, 36, F] in HBM, or an iterable of row blocks
+        (r0, r1, tensor[r1 - r0, 36, F]) covering them in order (evaluate_precomp streams a memory-mapped file that way:
+        block k is projected and scored while block k+1 crosses PCIe).
+        cap_ranges: the caption range of EVERY rank (caption_ranges(); default: equal counts); this rank's inputs hold
         its own range.  Order of work with several ranks: host metadata exchange (lengths) -> towers -> the all-gather of
         the packed word embeddings is started -> the columns of the captions this rank encoded itself are scored while the
         exchange is in flight -> the other ranks' columns.  A pair's score depends on that pair only (whatever tile the
         caption shares with others), so the matrix is bit-identical to the single-process one."""
         comm = self.comm
         cfg = self.cfg
-        dev = feats_local.device
+        dev = tokens_packed.device
         ranges = cap_ranges or [block_range(n_cap_total, comm.world, q) for q in range(comm.world)]
         cap_counts = [hi - lo for lo, hi in ranges]
         # -- host metadata first: lengths / offsets of this rank's captions in their original order, token count
@@ -217,9 +220,15 @@ class GruModelEval:
         meta[1 + maxcap:1 + maxcap + n_loc] = off_loc
         metas = comm.all_gather_list(meta)
         tok_counts = [int(m[0]) for m in metas]
-        # -- step 1: towers
-        img = self.encode_images(feats_local)
+        # -- step 1: towers (text first: it needs no image, and the first feature block may still be on its way)
         words = self.encode_captions(tokens_packed, tok_off, lengths_sorted)
+        if torch.is_tensor(feats_local):
+            blocks = [(0, feats_local.shape[0], feats_local)]
+            n_img_local = feats_local.shape[0]
+        else:
+            blocks = feats_local
+            n_img_local = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)
+            n_img_local = n_img_local[1] - n_img_local[0]
         # -- step 2: start the one exchange
         words_all, maxtok, wait = comm.all_gather_rows_async(words, tok_counts)
         cap_len = np.concatenate([m[1:1 + cap_counts[q]] for q, m in enumerate(metas)])
@@ -228,9 +237,12 @@ class GruModelEval:
 
         if timers is not None:
             timers['segments'] = []      # (start, end) HIP events around every scoring launch of this step
+        plans = {}
 
-        def score(words_t, off, lens, out):
-            plan_ = ops.ScanPlan(off, lens, words_t.shape[0], dev)
+        def score(img, key, words_t, off, lens, out):
+            if key not in plans:                       # the column-tile plan of a caption set is reused by every row block
+                plans[key] = ops.ScanPlan(off, lens, words_t.shape[0], dev)
+            plan_ = plans[key]
             ws = None if sgraf_weights is not None else ops.scan_prepare(img, words_t, plan_, xa)   # tile packing, Gram matrices: not the kernel timed
             if timers is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -247,20 +259,29 @@ class GruModelEval:
                 timers['segments'].append(ev)
             return plan_
 
-        # -- step 3: local row block.  One launch when there is nothing to wait for; else own columns first
-        S = torch.empty(img.shape[0], n_cap_total, device=dev, dtype=torch.float32)
-        if comm.world == 1:
+        # -- step 3: local row block(s).  One launch per row block when there is nothing to wait for; else the first block
+        # scores this rank's own columns first
+        S = torch.empty(n_img_local, n_cap_total, device=dev, dtype=torch.float32)
+        plan = None
+        waited = False
+        for r0, r1, fblock in blocks:
+            img = self.encode_images(fblock)
+            if comm.world == 1 or waited:
+                if not waited:
+                    wait()
+                    waited = True
+                plan = score(img, 'all', words_all, cap_off, cap_len, S[r0:r1])
+            else:
+                c0, c1 = ranges[comm.rank]
+                if c1 > c0:
+                    plan = score(img, 'own', words, off_loc, len_loc, S[r0:r1, c0:c1])
+                wait()
+                waited = True
+                for key, lo, hi in (('left', 0, c0), ('right', c1, n_cap_total)):
+                    if hi > lo:
+                        plan = score(img, key, words_all, cap_off[lo:hi], cap_len[lo:hi], S[r0:r1, lo:hi])
+        if not waited:
             wait()
-            plan = score(words_all, cap_off, cap_len, S)
-        else:
-            c0, c1 = ranges[comm.rank]
-            plan = None
-            if c1 > c0:
-                plan = score(words, off_loc, len_loc, S[:, c0:c1])
-            wait()
-            for lo, hi in ((0, c0), (c1, n_cap_total)):
-                if hi > lo:
-                    plan = score(words_all, cap_off[lo:hi], cap_len[lo:hi], S[:, lo:hi])
         if timers is not None and timers['segments']:
             timers['scan_start'], timers['scan_end'] = timers['segments'][-1]    # (one launch: the kernel; several: the last one)
         # -- step 4
@@ -287,10 +308,9 @@ class PooledModelEval:
             return ops.pdist_cos(img, cap)                  # Objectives.py:310-323
         return ops.cosine_scores(img, cap)                  # Objectives.py:18-21
 
-    def encode(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, lengths):
-        """Local shards -> (img_emb, cap_emb); image and caption counts are independent here (unique images)."""
+    def encode_images(self, images, boxes, imgs_wh):
         m, bs = self.model, self.batch
-        imgs, caps = [], []
+        imgs = []
         with torch.no_grad():
             for b0 in range(0, images.shape[0], bs):
                 sl = slice(b0, b0 + bs)
@@ -298,6 +318,12 @@ class PooledModelEval:
                     imgs.append(m.img_enc(images[sl], boxes[sl], imgs_wh[sl])[0])
                 else:
                     imgs.append(m.img_enc(images[sl]))
+        return torch.cat(imgs, 0)
+
+    def encode_captions(self, captions, captions_mask, captions_type_ids, lengths):
+        m, bs = self.model, self.batch
+        caps = []
+        with torch.no_grad():
             for b0 in range(0, captions.shape[0], bs):
                 sl = slice(b0, b0 + bs)
                 if self.name == 'CAMERA':
@@ -306,12 +332,17 @@ class PooledModelEval:
                     caps.append(m.txt_enc(captions[sl], captions_mask[sl], captions_type_ids[sl], lengths[b0:b0 + bs]))
                 else:
                     caps.append(m.txt_enc(captions[sl], lengths[b0:b0 + bs])[0])
-        return torch.cat(imgs, 0), torch.cat(caps, 0)
+        return torch.cat(caps, 0)
+
+    def encode(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, lengths):
+        """Local shards -> (img_emb, cap_emb); image and caption counts are independent here (unique images)."""
+        return self.encode_images(images, boxes, imgs_wh), self.encode_captions(captions, captions_mask, captions_type_ids, lengths)
 
     def eval(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, lengths, n_img_total, n_cap_total,
-             im_div=5, timers=None):
+             im_div=5, timers=None, cap_emb=None):
         comm = self.comm
-        img, cap = self.encode(images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, lengths)
+        cap = cap_emb if cap_emb is not None else self.encode_captions(captions, captions_mask, captions_type_ids, lengths)
+        img = self.encode_images(images, boxes, imgs_wh)
         cap_counts = [block_range(n_cap_total, comm.world, q)[1] - block_range(n_cap_total, comm.world, q)[0]
                       for q in range(comm.world)]
         cap_all, maxrows = comm.all_gather_rows(cap, cap_counts)
@@ -328,28 +359,102 @@ class PooledModelEval:
 
 # ---------------------------------------------------------------------------------------------------------
 # Real data: checkpointed model + precomp files -> sharded, device-resident evaluation (the bench's path on a dataset)
-def _features_to_device(arr, i0, i1, dev, chunk=512):
-    """Rows [i0, i1) of a memory-mapped .npy -> one HBM tensor; pinned staging + a side stream so that reading the
-    next chunk from the page cache / disk overlaps the copy of the previous one."""
+_PINNED = {}
+
+
+def _pinned(shape, slot):
+    """Page-locked staging buffers are expensive to create (cudaHostAlloc of tens of MB): kept for the process."""
+    key = (tuple(shape), slot)
+    if key not in _PINNED:
+        _PINNED[key] = torch.empty(shape, dtype=torch.float32).pin_memory()
+    return _PINNED[key]
+
+
+def _stage_rows(arr, r0, r1, dst, stream, chunk=128):
+    """Rows [r0, r1) of a memory-mapped .npy -> dst (HBM, r1 - r0 rows) through two pinned staging buffers; the H2D copies
+    run on `stream`, so reading chunk k+1 from the page cache overlaps the DMA of chunk k.  Returns the event of the last copy."""
+    ev = [None, None]
+    last = None
+    for k, c0 in enumerate(range(r0, r1, chunk)):
+        c1 = min(r1, c0 + chunk)
+        b = k & 1
+        buf = _pinned((chunk,) + tuple(arr.shape[1:]), b)
+        if ev[b] is not None:
+            ev[b].synchronize()                  # the copy that last used this staging buffer is done
+        np.copyto(buf[:c1 - c0].numpy(), arr[c0:c1], casting='same_kind')
+        with torch.cuda.stream(stream):
+            dst[c0 - r0:c1 - r0].copy_(buf[:c1 - c0], non_blocking=True)
+            ev[b] = torch.cuda.Event()
+            ev[b].record(stream)
+            last = ev[b]
+    for e in ev:
+        if e is not None:
+            e.synchronize()                      # the staging buffers are reused by the next call
+    return last
+
+
+def _features_to_device(arr, i0, i1, dev, chunk=128):
+    """Rows [i0, i1) of a memory-mapped .npy -> one HBM tensor."""
     out = torch.empty((i1 - i0,) + tuple(arr.shape[1:]), device=dev, dtype=torch.float32)
     stream = torch.cuda.Stream(device=dev)
     # `out` may be a block the caching allocator just recycled from kernels still queued on the current stream (validation
     # right after an asynchronous training step): the copies must not overtake them
     stream.wait_stream(torch.cuda.current_stream(dev))
-    bufs = [torch.empty((chunk,) + tuple(arr.shape[1:]), dtype=torch.float32).pin_memory() for _ in range(2)]
-    evs = [None, None]
-    for k, r0 in enumerate(range(i0, i1, chunk)):
-        r1 = min(i1, r0 + chunk)
-        b = k & 1
-        if evs[b] is not None:
-            evs[b].synchronize()                  # the copy that last used this staging buffer is done
-        bufs[b][:r1 - r0].copy_(torch.from_numpy(np.ascontiguousarray(arr[r0:r1], dtype=np.float32)))
-        with torch.cuda.stream(stream):
-            out[r0 - i0:r1 - i0].copy_(bufs[b][:r1 - r0], non_blocking=True)
-            evs[b] = torch.cuda.Event()
-            evs[b].record(stream)
+    if i1 > i0:
+        _stage_rows(arr, i0, i1, out, stream, chunk)
     torch.cuda.current_stream(dev).wait_stream(stream)
     return out
+
+
+class _FeatureBlocks:
+    """Rows [i0, i1) of a memory-mapped feature file as a sequence of HBM row blocks (r0, r1, tensor) for scan_eval:
+    two device buffers; block k+1 is staged (page cache -> pinned -> HBM on a side stream) after the consumer has QUEUED its
+    kernels for block k, so the copy runs under them -- the 1.47 GB of the MS-COCO 5k test features never sit exposed on the
+    PCIe link except for the first block, whose staging `prefetch()` starts on a helper thread while the captions are
+    tokenised."""
+
+    def __init__(self, arr, i0, i1, dev, block_rows=640):
+        self.arr, self.i0, self.i1, self.dev = arr, i0, i1, dev
+        self.block = max(_IMG_ALIGN, block_rows // _IMG_ALIGN * _IMG_ALIGN)
+        n = min(self.block, max(i1 - i0, 0))
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        self.bufs = [torch.empty((n,) + tuple(arr.shape[1:]), device=dev, dtype=torch.float32) for _ in range(2)]
+        self.consumed = [None, None]     # event on the consumer's stream: kernels reading buffer b are queued up to here
+        self._thread, self._first = None, None
+
+    def _stage(self, k):
+        r0 = self.i0 + k * self.block
+        r1 = min(self.i1, r0 + self.block)
+        b = k & 1
+        if self.consumed[b] is not None:
+            self.stream.wait_event(self.consumed[b])       # do not overwrite a block the GPU is still reading
+        return _stage_rows(self.arr, r0, r1, self.bufs[b][:r1 - r0], self.stream)
+
+    def prefetch(self):
+        """Stage block 0 on a helper thread (numpy / torch copies release the GIL)."""
+        import threading
+        if self.i1 > self.i0 and self._thread is None:
+            def run():
+                torch.cuda.set_device(self.dev)
+                self._first = self._stage(0)
+            self._thread = threading.Thread(target=run)
+            self._thread.start()
+
+    def __iter__(self):
+        cur = torch.cuda.current_stream(self.dev)
+        n_blocks = -(-(self.i1 - self.i0) // self.block) if self.i1 > self.i0 else 0
+        for k in range(n_blocks):
+            if k == 0 and self._thread is not None:
+                self._thread.join()
+                ev = self._first
+            else:
+                ev = self._stage(k)
+            cur.wait_event(ev)
+            r0 = k * self.block
+            r1 = min(self.i1 - self.i0, r0 + self.block)
+            yield r0, r1, self.bufs[k & 1][:r1 - r0]
+            self.consumed[k & 1] = cur.record_event()      # the consumer has queued its work on this block
 
 
 def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
@@ -374,7 +479,12 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
         raise NotImplementedError("evaluate_precomp expects the 5-captions-per-image layout of the precomp test splits")
     i0, i1 = block_range(n_img, comm.world, comm.rank, _IMG_ALIGN)
     model.val_start()
-    feats = _features_to_device(dataset.images, img_lo + i0, img_lo + i1, dev)
+    streamed = name in ('SCAN', 'SGRAF')       # word-level scorers: seconds of GPU work per row block to hide the copies under
+    if streamed:
+        feats = _FeatureBlocks(dataset.images, img_lo + i0, img_lo + i1, dev)
+        feats.prefetch()                       # block 0 crosses PCIe while the captions are tokenised
+    elif name not in ('SAEM', 'CAMERA'):
+        feats = _features_to_device(dataset.images, img_lo + i0, img_lo + i1, dev)
     with torch.no_grad():
         if name in ('SCAN', 'SGRAF', 'VSE++', 'VSE_PP', 'VSRN'):
             if name == 'VSRN':
@@ -444,10 +554,14 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
         c0, c1 = block_range(n_cap, comm.world, comm.rank)     # every caption is max_words ids: equal counts = equal tokens
         ids_np, mask_np, types_np = dataset.bert_features_range(cap_lo + c0, cap_lo + c1)
         ids, mask, types = (ops.h2d(a, dev, torch.long).reshape(-1, dataset.max_words) for a in (ids_np, mask_np, types_np))
+        pe = PooledModelEval(model, comm, batch=batch)
+        lens_b = [int(v) for v in mask_np.sum(1)]
+        # text tower first: its ~second of queued GPU work (12 BERT layers) covers the host-side staging of the features
+        cap = pe.encode_captions(ids, mask, types, lens_b)
+        feats = _features_to_device(dataset.images, img_lo + i0, img_lo + i1, dev)
         boxes = wh = None
         if name == 'CAMERA':
             boxes = _features_to_device(dataset.boxes, img_lo + i0, img_lo + i1, dev)
             wh = _features_to_device(dataset.img_wh, img_lo + i0, img_lo + i1, dev)
-        pe = PooledModelEval(model, comm, batch=batch)
-        _, ranks = pe.eval(feats, boxes, wh, ids, mask, types, [int(v) for v in mask_np.sum(1)], n_img, n_cap, im_div)
+        _, ranks = pe.eval(feats, boxes, wh, None, None, None, lens_b, n_img, n_cap, im_div, cap_emb=cap)
         return ranks
