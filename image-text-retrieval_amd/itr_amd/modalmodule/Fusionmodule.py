@@ -95,8 +95,20 @@ class EncoderSimilarity(nn.Module):
             _xavier(m)
 
     def forward(self, img_emb, cap_emb, cap_lens, *args, **kwargs):
+        """(B, 36, D), padded (Nc, L, D), lengths -> (B, Nc) (Fusionmodule.py:406-451).  Evaluation: the fused kernels.  Training
+        mode (batch statistics, live dropout) or a differentiable call: the reference's per-caption structure on the autograd
+        tape (encoder_similarity_train), fed with the captions re-packed from the padded tensor."""
         if self.training:
-            raise NotImplementedError("training mode runs inside SGRAF.train_emb (Fusionmodule.encoder_similarity_train); call val_start()")
+            from .. import autograd as ag
+            Nc, L, D = cap_emb.shape
+            lens = [int(x) for x in cap_lens][:Nc]
+            flat = np.concatenate([b * L + np.arange(l, dtype=np.int64) for b, l in enumerate(lens)])
+            words = cap_emb.reshape(Nc * L, D).index_select(0, ops.h2d(flat, cap_emb.device))
+            off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            if not hasattr(self, '_seeds'):
+                self._seeds = ag.DropoutSeeds()
+            self._seeds.new_step()
+            return encoder_similarity_train(self, img_emb, words, off, lens, self._seeds, self.training)
         return ops.sgraf_padded(img_emb, cap_emb, cap_lens, self.state_dict(), self.module_name, self.sgr_step)
 
     def forward_packed(self, img_emb, words, plan):

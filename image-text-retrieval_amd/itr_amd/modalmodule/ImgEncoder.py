@@ -11,6 +11,13 @@ from .. import ops
 from . import bert
 
 
+def _on_tape(module, *inputs):
+    """True when a forward call must be differentiable: autograd is recording and an input or a parameter requires grad."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(torch.is_tensor(t) and t.requires_grad for t in inputs) or any(p.requires_grad for p in module.parameters())
+
+
 class EncoderImagePrecomp(nn.Module):
     """fc + l2norm over precomputed region features (ImgEncoder.py:112-159)."""
 
@@ -40,9 +47,23 @@ class EncoderImagePrecomp(nn.Module):
         return fc.weight
 
     def forward(self, images):
+        """One module, two modes: in training mode with autograd recording (a training step composed from the module seams like
+        the reference's train_emb, Models.py:182-225) the tower runs on the tape (HIP forward AND backward nodes,
+        itr_amd/autograd.py); in evaluation mode the fused kernel."""
+        if self.training and _on_tape(self, images):
+            return self.forward_train(images)
         if self.use_abs and self.no_imgnorm:
             raise NotImplementedError("use_abs without normalisation")
         return ops.proj_l2norm(images, self._weight().detach(), self.fc.bias.detach(), self.no_imgnorm, self.use_abs)
+
+    def forward_train(self, images):
+        from .. import autograd as ag
+        x = ag.linear(images, self._weight(), self.fc.bias)
+        if not self.no_imgnorm:
+            x = ag.l2norm_rows(x)
+        if self.use_abs:                       # order embeddings (ImgEncoder.py:143-145); elementwise glue on the tape
+            x = x.abs()
+        return x
 
     def load_state_dict(self, state_dict):
         """Accept a state_dict from the full-CNN model: keep only matching names (ImgEncoder.py:149-159)."""
@@ -94,8 +115,8 @@ class EncoderImagePrecompAttn(nn.Module):
         self.fc.bias.data.fill_(0)
 
     def forward(self, images):
-        if self.training:
-            raise NotImplementedError("EncoderImagePrecompAttn: training mode is not built (SURVEY.md 8(f)-4)")
+        if self.training:                                # batch statistics, gradients: the tape implementation
+            return self.forward_train(images)
         x = ops.linear(images, self.fc.weight.detach(), self.fc.bias.detach())
         if self.data_name != 'f30k_precomp':
             x = ops.l2norm(x, dim=1)

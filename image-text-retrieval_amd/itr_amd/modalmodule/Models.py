@@ -83,8 +83,7 @@ class base_module(nn.Module):
             self.logger.update(k, v, n)
 
     def train_emb(self, train_data, *a, **k):
-        raise NotImplementedError("train_emb of %s needs backward kernels that are not built (SURVEY.md 8f-3); "
-                                  "forward_emb / forward_loss are available" % type(self).__name__)
+        raise NotImplementedError("%s does not define train_emb" % type(self).__name__)      # (every model family of the reference does)
 
     # ---- data-parallel sharding of one global batch
     def _dp_comm(self):
@@ -120,31 +119,12 @@ class base_module(nn.Module):
         images = self._dev(images)
         captions = self._dev(captions)
         ie, te = self.img_enc, self.txt_enc
-        x = ops.mean_mid(images) if pooled_images else images
-        img = ag.linear(x, ie._weight(), ie.fc.bias)
-        if not ie.no_imgnorm:
-            img = ag.l2norm_rows(img)
-        if getattr(ie, 'use_abs', False):      # order embeddings (ImgEncoder.py:143-145); elementwise glue on the tape
-            img = img.abs()
-        toks, off, lens, _ = TextEncoder.pack_tokens(captions, lengths)
-        if getattr(te, 'dropout_p', 0.) > 0 and te.training:
-            # nn.Dropout on the word embeddings (TextEncoder.py:42; SGRAF: p = 0.4): gather the rows on the tape, drop, and feed the
-            # GRU kernels the dropped rows as a dense "embedding table" indexed by arange (the VSRN region-GRU trick)
-            if not hasattr(self, '_seeds'):
-                self._seeds = ag.DropoutSeeds()
-                self._seeds.new_step()
-            emb = ag.dropout(ag.gather_rows(te.embed.weight, toks), te.dropout_p, self._seeds)
-            toks = torch.arange(emb.shape[0], device=emb.device, dtype=torch.int64)
-            seq = ag.gru_sequence(toks, off, lens, emb, dict(te.rnn.named_parameters()), te.use_bi_gru)
-        else:
-            seq = ag.gru_sequence(toks, off, lens, te.embed.weight, dict(te.rnn.named_parameters()), te.use_bi_gru)
-        if last_state:
-            last = off + ops.h2d(np.asarray(lens, np.int64), off.device) - 1
-            seq = ag.gather_rows(seq, last)
-        if not te.no_txtnorm:
-            seq = ag.l2norm_rows(seq)
-        if getattr(te, 'use_abs', False):      # TextEncoder.py:66-68
-            seq = seq.abs()
+        img = ie.forward_train(ops.mean_mid(images) if pooled_images else images)
+        if getattr(te, 'dropout_p', 0.) > 0 and te.training and not hasattr(self, '_seeds'):
+            self._seeds = ag.DropoutSeeds()
+            self._seeds.new_step()
+        assert last_state == (te.method_name in ('VSE++', 'VSRN'))
+        seq, off, lens, _ = te.forward_packed_train(captions, lengths, seeds=getattr(self, '_seeds', None))
         return img, seq, off, lens
 
     def _step(self, loss, batch_size, logged=None):

@@ -79,8 +79,30 @@ class ContrastiveLoss(nn.Module):
         elif self.config['name'] == 'SGRAF':
             self.sim = lambda x, y, m, n: x
 
+    def _sim_on_tape(self, im, s, s_l):
+        """self.sim with gradients: the same measures as autograd nodes (HIP forward + backward kernels, itr_amd/autograd.py)."""
+        from .. import autograd as ag
+        import numpy as np
+        name, cfg = self.config['name'], self.config
+        if name == 'SGRAF':
+            return im                                       # the similarity matrix comes from sim_enc (Objectives.py:73-74)
+        if name == 'SCAN':
+            Nc, L, D = s.shape
+            lens = [int(x) for x in s_l][:Nc]
+            flat = np.concatenate([b * L + np.arange(l, dtype=np.int64) for b, l in enumerate(lens)])
+            words = s.reshape(Nc * L, D).index_select(0, ops.h2d(flat, s.device))     # padded -> packed, on the tape
+            off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            fn = ag.scan_t2i_scores if cfg['cross_attn'] == 't2i' else ag.scan_i2t_scores
+            return fn(im, words, off, lens, cfg['raw_feature_norm'], cfg['agg_func'], cfg['lambda_lse'], cfg['lambda_softmax'])
+        if name == 'SAEM':
+            raise NotImplementedError("SAEM's loss terms are composed in SAEM.forward_loss / train_emb")
+        return ag.order_scores(im, s) if self.sim is order_sim else ag.cosine_scores(im, s)
+
     def forward(self, im, s=None, s_l=None):
-        scores = self.sim(im, s, s_l, self.config)
+        if torch.is_grad_enabled() and (im.requires_grad or (torch.is_tensor(s) and s.requires_grad)):
+            scores = self._sim_on_tape(im, s, s_l)
+        else:
+            scores = self.sim(im, s, s_l, self.config)
         return ops.hinge_loss(scores, self.margin, self.max_violation)
 
 

@@ -38,7 +38,7 @@ class EncoderText(nn.Module):
         self.use_abs = use_abs
         self.method_name = method_name
         self.embed = nn.Embedding(vocab_size, word_dim)
-        self.dropout_p = dropout          # identity in eval mode; training backward is SURVEY 8(f)-3
+        self.dropout_p = dropout          # live in training mode (forward_packed_train), identity in evaluation
         self.use_bi_gru = use_bi_gru
         self.rnn = nn.GRU(word_dim, embed_size, num_layers, batch_first=True, bidirectional=use_bi_gru)
         self.init_weights()
@@ -58,16 +58,43 @@ class EncoderText(nn.Module):
                              use_abs=self.use_abs, gather_last=last)
         return out, off, lens, mask
 
+    def forward_packed_train(self, x, lengths, seeds=None):
+        """The tower on the autograd tape, packed layout: -> (word / caption embeddings, tok_off, lens, mask).  nn.Dropout on
+        the word embeddings (TextEncoder.py:42; SGRAF: p = 0.4) in training mode: the rows are gathered on the tape, dropped,
+        and fed to the GRU kernels as a dense "embedding table" indexed by arange (the VSRN region-GRU trick)."""
+        from .. import autograd as ag
+        toks, off, lens, mask = pack_tokens(x, lengths)
+        table = self.embed.weight
+        if self.dropout_p > 0 and self.training:
+            if seeds is None:
+                if not hasattr(self, '_seeds'):
+                    self._seeds = ag.DropoutSeeds()
+                self._seeds.new_step()
+                seeds = self._seeds
+            table = ag.dropout(ag.gather_rows(self.embed.weight, toks), self.dropout_p, seeds)
+            toks = torch.arange(table.shape[0], device=table.device, dtype=torch.int64)
+        seq = ag.gru_sequence(toks, off, lens, table, dict(self.rnn.named_parameters()), self.use_bi_gru)
+        if self.method_name in ('VSE++', 'VSRN'):
+            last = off + ops.h2d(np.asarray(lens, np.int64), off.device) - 1
+            seq = ag.gather_rows(seq, last)
+        if not self.no_txtnorm:
+            seq = ag.l2norm_rows(seq)
+        if self.use_abs:                       # TextEncoder.py:66-68
+            seq = seq.abs()
+        return seq, off, lens, mask
+
     def forward(self, x, lengths):
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("training-mode dropout/backward is not built (SURVEY 8f-3); call val_start()")
-        out, off, lens, mask = self.forward_packed(x, lengths)
+        """One module, two modes (see EncoderImagePrecomp.forward): in training mode the tape implementation (gradients, live
+        dropout), in evaluation mode the fused kernels.  Returns the reference's layout either way."""
+        from .ImgEncoder import _on_tape
+        train_path = self.training and (_on_tape(self, x) or self.dropout_p > 0)
+        out, off, lens, mask = self.forward_packed_train(x, lengths) if train_path else self.forward_packed(x, lengths)
         cap_len = torch.as_tensor(lens, dtype=torch.int64)
         if self.method_name in ('VSE++', 'VSRN'):
             return out, cap_len
         B, L = x.shape[0], max(lens)
         cap_emb = torch.zeros(B, L, self.embed_size, device=x.device, dtype=torch.float32)
-        cap_emb[mask[:, :L]] = out                    # scatter back to the padded layout (plumbing)
+        cap_emb[mask[:, :L]] = out                    # scatter back to the padded layout (plumbing; differentiable on the tape)
         return cap_emb, cap_len
 
 

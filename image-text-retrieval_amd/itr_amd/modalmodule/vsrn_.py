@@ -57,7 +57,7 @@ class Rs_GCN(nn.Module):
     def forward(self, v):
         """v (B, N, D) -> v* (B, N, D)."""
         if self.training:
-            raise NotImplementedError("Rs_GCN: training mode (batch statistics, backward) is not built")
+            return self.forward_train(v)      # batch statistics, gradients: the tape implementation
         w3, b3, ww, wb = self._weights()
         B, N, D = v.shape
         tpg = ops.linear(v.reshape(B * N, D), w3, b3)                        # [B*N, 3C]: theta | phi | g

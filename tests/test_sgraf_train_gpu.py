@@ -96,3 +96,30 @@ def test_sgraf_train_emb_with_dropout(golden, dev):
         runs.append(losses)
     assert all(np.isfinite(runs[0])) and runs[0] == runs[1]
     assert abs(runs[0][0] - float(g['SAF_s1_loss'])) > 1e-4         # the 0.4 dropout sites are live
+
+
+@pytest.mark.parametrize("mod", ["SAF", "SGR"])
+def test_sgraf_step_through_the_module_seams(golden, dev, mod):
+    """The reference composes its SGRAF step from the module seams (Models.py:507-546): forward_emb -> sim_enc(img, cap, lens)
+    -> criterion(sims) -> backward.  In training mode those seams run on the autograd tape here too (one module, two modes)
+    and give G20's first-step loss and gradients."""
+    g = golden("g20_sgraf_train")
+    model = _model(g, mod)
+    images, _, _, ids, lens, _, _, _ = _batch(g, mod, 1)
+    model.optimizer.zero_grad()
+    img_emb, cap_emb = model.forward_emb(images, ids, lens)
+    assert img_emb.requires_grad and cap_emb.requires_grad and cap_emb.dim() == 3
+    sims = model.sim_enc(img_emb, cap_emb, lens)
+    loss = model.criterion(sims)
+    pre = '%s_s1_' % mod
+    assert float(loss) == pytest.approx(float(g[pre + 'loss']), abs=3e-5)
+    loss.backward()
+    model.optimizer.step(max_norm=model.grad_clip)
+    coef = min(1.0, model.grad_clip / (float(model.optimizer.last_grad_norm[0]) + 1e-6))
+    worst = []
+    for which, m in (('img', model.img_enc), ('txt', model.txt_enc), ('sim', model.sim_enc)):
+        for n, p in m.named_parameters():
+            want = T(g[pre + 'grad_%s.%s' % (which, n)])
+            if float(want.abs().max()) > 1e-6:
+                worst.append((float((p.grad.detach().cpu() * coef - want).norm() / (want.norm() + 1e-12)), which + '.' + n))
+    assert max(worst)[0] <= 2e-4, sorted(worst, reverse=True)[:5]

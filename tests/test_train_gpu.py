@@ -263,6 +263,39 @@ def test_scan_train_emb_matches_reference(golden, dev):
         _check_step(model, g, 's%d_grad_' % step, 's%d_img_' % step, 's%d_txt_' % step, cfg['learning_rate'])
 
 
+def test_scan_trains_through_the_module_seams(golden, dev):
+    """One module, two modes: the step composed the way the reference's train_emb composes it (Models.py:182-225) --
+    model.img_enc(images), model.txt_enc(captions, lengths) (padded output), model.criterion(img, cap, lens), backward,
+    clip + Adam -- reproduces G15 (the reference's own two steps) exactly like model.train_emb does."""
+    g = golden("g15_train_step")
+    cfg_ref = json.loads(bytes(g["cfg_json"]).decode())
+    cfg = C.build_config(['with', 'SCAN', 'data_name=f30k_precomp'])
+    cfg.update({k: v for k, v in cfg_ref.items() if k != "name"})
+    model = get_model(cfg)
+    _load(model, g, 'w0_img_', 'w0_txt_')
+    model.train_start()
+    for step in (1, 2):
+        lens = [int(x) for x in g["s%d_lens" % step]]
+        images, captions = T(g["s%d_feats" % step]).cuda(), T(g["s%d_ids" % step]).cuda()
+        model.optimizer.zero_grad()
+        img_emb = model.img_enc(images)
+        cap_emb, cap_lens = model.txt_enc(captions, lens)
+        assert img_emb.requires_grad and cap_emb.requires_grad and cap_emb.shape == (len(lens), max(lens), cfg['embed_size'])
+        loss = model.criterion(img_emb, cap_emb, cap_lens)
+        assert abs(float(loss) - float(g["s%d_loss" % step])) <= 1e-4
+        loss.backward()
+        model.optimizer.step(max_norm=model.grad_clip)
+        _check_step(model, g, 's%d_grad_' % step, 's%d_img_' % step, 's%d_txt_' % step, cfg['learning_rate'])
+    # the two modes of one module agree: training mode = tape (differentiable), evaluation mode = fused kernels
+    t_img = model.img_enc(images)
+    t_cap, _ = model.txt_enc(captions, lens)
+    model.val_start()
+    e_img = model.img_enc(images)
+    e_cap, _ = model.txt_enc(captions, lens)
+    assert t_img.requires_grad and not e_img.requires_grad and not e_cap.requires_grad
+    assert md(t_img, e_img) <= 2e-6 and md(t_cap, e_cap) <= 5e-6
+
+
 def test_scan_i2t_train_emb_vs_oracle_step(golden, dev):
     """cross_attn='i2t': one train_emb step from the G15 weights against the oracle's restated step (the oracle's step is
     pinned by the reference's own train_emb for t2i, its i2t similarity by G5)."""

@@ -51,9 +51,13 @@ def test_vsrn_image_tower_golden(golden, dev, tag, data_name):
     feat, gcn = enc(T(g[tag + "_images"]).to(dev))
     assert np.abs(feat.cpu().numpy() - g[tag + "_feat"]).max() <= 2e-6
     assert np.abs(gcn.cpu().numpy() - g[tag + "_gcn"]).max() <= 2e-6
+    # one module, two modes: in training mode the same call runs on the autograd tape (GCN BatchNorms on batch statistics,
+    # tests/test_vsrn_train_gpu.py pins its numbers against the reference's train_emb)
     enc.train()
-    with pytest.raises(NotImplementedError):
-        enc(T(g[tag + "_images"]).to(dev))
+    feat_t, gcn_t = enc(T(g[tag + "_images"]).to(dev))
+    assert feat_t.requires_grad and gcn_t.requires_grad and feat_t.shape == feat.shape and not feat.requires_grad
+    feat_t.square().sum().backward()
+    assert enc.fc.weight.grad is not None and bool(torch.isfinite(enc.fc.weight.grad).all())
 
 
 def test_vsrn_model_golden(golden, dev):
