@@ -471,8 +471,20 @@ int gemm_nt_splitk_partials(const float *A, int64_t lda, const float *B, int64_t
     return ITR_OK;
 }
 
+bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M,
+                    int64_t N, int64_t K, int act, hipStream_t st, int *rc);      // gemm_stream.hip
+
 int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
+    // short K, many row tiles: the streaming kernel takes the whole 128-row tiles, the tile kernel the remaining rows
+    int rc = ITR_OK;
+    if (gemm_nt_stream(A, lda, B, ldb, bias, C, ldc, M, N, K, act, st, &rc)) {
+        if (rc != ITR_OK) return rc;
+        const int64_t done = M / BM * BM;
+        if (done == M) return ITR_OK;
+        GemmArgs gt{A + done * lda, B, bias, C + done * ldc, lda, ldb, ldc, M - done, N, K, act, 1, BM, nullptr, nullptr, 0, 0, 0, nullptr};
+        return launch_gemm(gt, st);
+    }
     GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, 0, 0, nullptr};
     return launch_gemm(g, st);
 }

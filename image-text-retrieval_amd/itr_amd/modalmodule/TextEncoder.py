@@ -31,8 +31,9 @@ class EncoderText(nn.Module):
     def __init__(self, vocab_size, word_dim, embed_size, num_layers, use_bi_gru=False, no_txtnorm=False,
                  dropout=0., use_abs=False, method_name=None):
         super().__init__()
-        if num_layers != 1:
-            raise NotImplementedError("only num_layers == 1 (every config of the reference) is built")
+        if num_layers < 1:
+            raise ValueError("num_layers must be >= 1")
+        self.num_layers = num_layers
         self.embed_size = embed_size
         self.no_txtnorm = no_txtnorm
         self.use_abs = use_abs
@@ -51,10 +52,64 @@ class EncoderText(nn.Module):
         w.update({'rnn.' + k: v.detach() for k, v in self.rnn.named_parameters()})
         return w
 
+    # ---- nn.GRU(num_layers > 1) (TextEncoder.py:31; no reference config uses it, the constructor argument exists): layer l > 0
+    # reads the previous layer's output sequence -- for a bi-GRU the CONCATENATION [forward | backward] (2 D wide) -- so the lower
+    # layers run the two directions as separate uni-directional passes of the same kernels over a dense "embedding table" (the
+    # backward direction on the caption's rows in reverse order) and only the top layer uses the fused (fwd + bwd) / 2 form.
+    @staticmethod
+    def _reversed_rows(lens, device):
+        """index of the row that is the mirror image of row r inside its caption (packed layout)."""
+        idx = np.concatenate([o + np.arange(l - 1, -1, -1, dtype=np.int64) for o, l in zip(np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)]) \
+            if len(lens) else np.zeros(0, np.int64)
+        return ops.h2d(idx, device)
+
+    def _layer_params(self, layer, reverse, detach):
+        sfx = '_l%d%s' % (layer, '_reverse' if reverse else '')
+        get = (lambda n: getattr(self.rnn, n + sfx).detach()) if detach else (lambda n: getattr(self.rnn, n + sfx))
+        return {'weight_ih_l0': get('weight_ih'), 'weight_hh_l0': get('weight_hh'), 'bias_ih_l0': get('bias_ih'), 'bias_hh_l0': get('bias_hh')}
+
+    def _lower_layers(self, toks, off, lens, table, tape):
+        """Layers 0 .. num_layers-2 -> (row indices, dense input table) for the top layer."""
+        from .. import autograd as ag
+        dev = toks.device
+        for layer in range(self.num_layers - 1):
+            ar = torch.arange(toks.numel(), device=dev, dtype=torch.int64)
+
+            def run(tokens, reverse):
+                prm = self._layer_params(layer, reverse, detach=not tape)
+                if tape:
+                    return ag.gru_sequence(tokens, off, lens, table, prm, False)
+                w = {'embed.weight': table.detach()}
+                w.update({'rnn.' + k: v for k, v in prm.items()})
+                return ops.gru_encode(tokens, off, lens, w, False, no_txtnorm=True)
+            fwd = run(toks, False)
+            if self.use_bi_gru:
+                rev = self._reversed_rows(lens, dev)
+                bwd = run(toks.index_select(0, rev), True)            # the caption's tokens last-to-first
+                bwd = ag.gather_rows(bwd, rev) if tape else bwd.index_select(0, rev)      # back to reading order
+                table = torch.cat([fwd, bwd], 1)
+            else:
+                table = fwd
+            toks = ar
+        return toks, table
+
+    def _top_weights(self, table, detach):
+        top = self.num_layers - 1
+        w = {'embed.weight': table.detach() if detach else table}
+        for rev in ((False, True) if self.use_bi_gru else (False,)):
+            for k, v in self._layer_params(top, rev, detach).items():
+                w['rnn.' + k + ('_reverse' if rev else '')] = v
+        return w
+
     def forward_packed(self, x, lengths):
         toks, off, lens, mask = pack_tokens(x, lengths)
         last = self.method_name in ('VSE++', 'VSRN')
-        out = ops.gru_encode(toks, off, lens, self._weights(), self.use_bi_gru, no_txtnorm=self.no_txtnorm,
+        if self.num_layers == 1:
+            w = self._weights()
+        else:
+            toks, table = self._lower_layers(toks, off, lens, self.embed.weight.detach(), tape=False)
+            w = self._top_weights(table, detach=True)
+        out = ops.gru_encode(toks, off, lens, w, self.use_bi_gru, no_txtnorm=self.no_txtnorm,
                              use_abs=self.use_abs, gather_last=last)
         return out, off, lens, mask
 
@@ -73,7 +128,12 @@ class EncoderText(nn.Module):
                 seeds = self._seeds
             table = ag.dropout(ag.gather_rows(self.embed.weight, toks), self.dropout_p, seeds)
             toks = torch.arange(table.shape[0], device=table.device, dtype=torch.int64)
-        seq = ag.gru_sequence(toks, off, lens, table, dict(self.rnn.named_parameters()), self.use_bi_gru)
+        if self.num_layers == 1:
+            seq = ag.gru_sequence(toks, off, lens, table, dict(self.rnn.named_parameters()), self.use_bi_gru)
+        else:
+            toks, table = self._lower_layers(toks, off, lens, table, tape=True)
+            top = {k[len('rnn.'):]: v for k, v in self._top_weights(table, detach=False).items() if k.startswith('rnn.')}
+            seq = ag.gru_sequence(toks, off, lens, table, top, self.use_bi_gru)
         if self.method_name in ('VSE++', 'VSRN'):
             last = off + ops.h2d(np.asarray(lens, np.int64), off.device) - 1
             seq = ag.gather_rows(seq, last)
