@@ -1,9 +1,9 @@
 // Streaming fp32 "NT" GEMM for SHORT K:  C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]),  act in {none, relu}.
 //
 // gemm_nt_fast_kernel (gemm_f32.hip) works tile by tile: every 128 x 128 output tile pays a pipeline fill (its first
-// operand chunk costs a full L2 / HBM latency before the first MFMA) and a drain.  At K = 2048 that is noise; at K = 256
-// -- the S x S projections of SGRAF's graph-reasoning steps (Fusionmodule.py:589-597), two per step over ~5 M node rows --
-// a tile is 8 chunks long and the kernel reaches 91 TFLOP/s instead of 131.  Here a workgroup owns ONE 128-column tile
+// operand chunk costs a full L2 / HBM latency before the first MFMA) and a drain.  At K = 256 -- the S x S projections of
+// SGRAF's graph-reasoning steps (Fusionmodule.py:589-597), two per step over ~5 M node rows -- a tile is 8 chunks long and
+// that kernel reaches 79-91 TFLOP/s; even at K = 2048 the fill / drain and its compiler-scheduled loop leave it at 132.  Here a workgroup owns ONE 128-column tile
 // and streams down a contiguous range of 128-row tiles: operand chunks of tile t+1 are requested while the last chunks of
 // tile t are multiplied, the accumulators are flushed between two chunks, the loop never drains.  The B panel of the
 // workgroup (128 x K) is re-read from L2 for every row tile (it is the same 128 KB every time).
@@ -84,7 +84,10 @@ bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, co
         cus = prop.multiProcessorCount;
     }
     static const bool off = getenv("ITR_GEMM_STREAM") && atoi(getenv("ITR_GEMM_STREAM")) == 0;
-    if (off || (act != 0 && act != 1) || K % 64 != 0 || K < 64 || K > 512 || N % GS_BM != 0 || M < GS_BM) return false;
+    // (measured: ahead of the tile kernel at every K -- 179 200 x 1 024 x 2 048: 132 -> 147 TFLOP/s, 800 000 x 2 304 x 768: 120 -> 135,
+    // 265 000 x 256 x 256: 79 -> 104; tools/gemm_stream_check.py.  ITR_GEMM_STREAM_KMAX caps K for experiments.)
+    static const int64_t kmax = getenv("ITR_GEMM_STREAM_KMAX") ? atoll(getenv("ITR_GEMM_STREAM_KMAX")) : (1ll << 40);
+    if (off || (act != 0 && act != 1) || K % 64 != 0 || K < 64 || K > kmax || N % GS_BM != 0 || M < GS_BM) return false;
     if ((lda % 4) || (ldb % 4) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return false;
     if ((uint64_t)lda * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldb * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldc * 4u * GS_BM >= (1ull << 31)) return false;
     const int64_t tiles_m = M / GS_BM, tiles_n = N / GS_BM;      // whole row tiles; a remainder of rows goes to the tile kernel

@@ -18,6 +18,7 @@ CSRC = os.path.join(ROOT, "image-text-retrieval_amd", "csrc")
 # exit -- a union-at-joins dataflow cannot prove that, it reports the park code after the loop).
 CASES = [("scan_xattn.hip", ["scan_xattn_kernelILi0E", "scan_xattn_kernelILi1E"]),
          ("gemm_f32.hip", ["gemm_nt_fast_kernel"]),
+         ("gemm_stream.hip", ["gemm_nt_stream_kernelILb0E", "gemm_nt_stream_kernelILb1E"]),
          ("sgraf_loc.hip", ["sgraf_loc_kernel"])]
 
 
@@ -60,8 +61,9 @@ def test_audit_detects_a_touched_register():
     assert any("in flight at s_endpgm" in r for r in rep)
 
 
-def test_generated_main_loop_is_current():
-    """csrc/scan_mainloop_asm.inc is generated (tools/gen_scan_mainloop.py); the committed file must be what the generator emits."""
+@pytest.mark.parametrize("gen", ["gen_scan_mainloop.py", "gen_gemm_stream.py"])
+def test_generated_asm_bodies_are_current(gen):
+    """csrc/scan_mainloop_asm.inc and csrc/gemm_stream_asm.inc are generated; the committed files must be what the generators emit."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_scan_mainloop.py"), "--check"])
-    assert r.returncode == 0, "regenerate: python tools/gen_scan_mainloop.py"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), "--check"])
+    assert r.returncode == 0, "regenerate: python tools/%s" % gen
