@@ -92,7 +92,8 @@ bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, co
     if ((uint64_t)lda * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldb * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldc * 4u * GS_BM >= (1ull << 31)) return false;
     const int64_t tiles_m = M / GS_BM, tiles_n = N / GS_BM;      // whole row tiles; a remainder of rows goes to the tile kernel
     const int64_t resident = 2 * (int64_t)cus;
-    if (tiles_m * tiles_n < 4 * resident) return false;          // streaming pays when every workgroup gets several tiles
+    static const int64_t min_rounds = getenv("ITR_GEMM_STREAM_MINROUNDS") ? atoll(getenv("ITR_GEMM_STREAM_MINROUNDS")) : 4;
+    if (tiles_m * tiles_n < min_rounds * resident) return false;  // streaming pays when every workgroup gets several tiles
     int64_t grid = resident / tiles_n * tiles_n;
     if (grid < tiles_n) grid = tiles_n;
     GemmStreamArgs g{A, B, bias, C, lda, ldb, ldc, tiles_m, tiles_n, (int)K};

@@ -240,19 +240,24 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                     for (int k = 0; k < ncap; ++k) {
                         const int c0 = __builtin_amdgcn_readfirstlane(sm.meta.cap_start[k]);
                         const int c1 = __builtin_amdgcn_readfirstlane(sm.meta.cap_start[k + 1]);
-                        float s0 = 0.f, s1 = 0.f;
+                        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four independent chains: the loop is LDS-latency bound
                         int c = c0;
-                        for (; c + 1 < c1; c += 2) {
+                        for (; c + 3 < c1; c += 4) {
                             float v0 = colbase[c * SC_LDT], v1 = colbase[(c + 1) * SC_LDT];
-                            if (NORM == 0 || NORM == 6) { v0 = leaky(v0); v1 = leaky(v1); }
+                            float v2 = colbase[(c + 2) * SC_LDT], v3 = colbase[(c + 3) * SC_LDT];
+                            if (NORM == 0 || NORM == 6) { v0 = leaky(v0); v1 = leaky(v1); v2 = leaky(v2); v3 = leaky(v3); }
                             s0 += (NORM <= 1) ? v0 * v0 : fabsf(v0);
                             s1 += (NORM <= 1) ? v1 * v1 : fabsf(v1);
+                            s2 += (NORM <= 1) ? v2 * v2 : fabsf(v2);
+                            s3 += (NORM <= 1) ? v3 * v3 : fabsf(v3);
                         }
-                        if (c < c1) {
+                        for (; c < c1; ++c) {
                             float v0 = colbase[c * SC_LDT];
                             if (NORM == 0 || NORM == 6) v0 = leaky(v0);
                             s0 += (NORM <= 1) ? v0 * v0 : fabsf(v0);
                         }
+                        s0 += s2;
+                        s1 += s3;
                         const float sum = s0 + s1;
                         sm.stat[0][k][row] = fast_rcp((NORM <= 1 ? fast_sqrt(sum) : sum) + 1e-8f) * ls_log2e;
                     }
