@@ -45,6 +45,9 @@ def test_integration_md_binding_runs_and_matches_oracle(dev):
     with pytest.raises(ValueError):
         m._chk(m._lib.itr_gemm_nt(None, 1, None, 1, None, None, 1, 2, 2, 2, 0, None))    # null pointers -> ValueError + message
     sims = rng.randn(8, 40)
+    sims[:, 1::2] = sims[:, 0::2] - 2.0 ** -30            # neighbours closer than an fp32 ulp (fp32 would tie them, and ties go to the higher index)
     i_rank, i_top, t_rank, t_top = m._ranks(sims)
-    w = O.rank_counts(sims.astype(np.float32))
+    w = O.rank_counts(sims)                               # float64, like the reference's argsort
     assert (i_rank == w[0]).all() and (i_top == w[1]).all() and (t_rank == w[2]).all() and (t_top == w[3]).all()
+    w32 = O.rank_counts(sims.astype(np.float32))
+    assert any((a != b).any() for a, b in zip(w, w32))   # (an fp32 ranker gets this matrix wrong)
