@@ -52,5 +52,6 @@ for extra in (0, 4000):
                   "workgroups %d" % (wall_ms, slots, float(cyc[7]) * 1e-5 / (slots * wall_ms), nblocks))
             print("   shader clock during the kernel: %.3f GHz (sum of phase cycles / 100 MHz real-time ticks)" % (
                 float(cyc[:7].sum()) / float(cyc[7]) * 0.1))
-        print("blocks/CU=%d flag %d: cycles per workgroup: prologue %.0f  main %.0f  park %.0f  E1 %.0f  E2 %.0f" % (
-            2 if extra == 0 else 1, flag, cyc[4] / nblocks, cyc[0] / nblocks, cyc[1] / nblocks, cyc[2] / nblocks, cyc[3] / nblocks), " E2a %.0f E2b %.0f (E2 = rest after E2b)" % (cyc[5] / nblocks, cyc[6] / nblocks))
+        # (the prologue, the K loop and the park are one asm statement now: slot 4 holds all three, slots 0 / 1 are empty)
+        print("blocks/CU=%d flag %d: cycles per workgroup: prologue + K loop + park %.0f  E1 %.0f  E2a %.0f  E2b %.0f  E2 rest + E3 %.0f" % (
+            2 if extra == 0 else 1, flag, (cyc[4] + cyc[0] + cyc[1]) / nblocks, cyc[2] / nblocks, cyc[5] / nblocks, cyc[6] / nblocks, cyc[3] / nblocks))
