@@ -78,6 +78,35 @@ __global__ void gather_last_kernel(const float *__restrict__ out, const int64_t 
     for (int k = threadIdx.x; k < D; k += blockDim.x) out_last[b * D + k] = src[k];
 }
 
+// out = (out + other) / 2: the direction average of a bi-GRU (TextEncoder.py:54-55) when the two directions ran side by side
+__global__ __launch_bounds__(256) void avg2_kernel(float *__restrict__ out, const float *__restrict__ other, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = reinterpret_cast<float4 *>(out)[i];
+    const float4 b = reinterpret_cast<const float4 *>(other)[i];
+    a.x = (a.x + b.x) / 2.f; a.y = (a.y + b.y) / 2.f; a.z = (a.z + b.z) / 2.f; a.w = (a.w + b.w) / 2.f;
+    reinterpret_cast<float4 *>(out)[i] = a;
+}
+
+// A second HIP stream per device for the reverse direction of a bi-GRU: the two recurrences are independent, and a time step's
+// GEMM (M = active captions <= a few thousand rows) leaves most CUs idle in its last wave of tiles -- the other direction fills them.
+struct SideStream {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static SideStream *side_stream() {
+    static SideStream per_dev[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream &s = per_dev[dev];
+    if (!s.st) {
+        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) { s.st = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &s;
+}
+
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GruWs {
@@ -122,12 +151,16 @@ extern "C" int itr_proj_l2norm(const float *x, const float *W, const float *b, f
     return ITR_OK;
 }
 
-extern "C" size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional) {
+static size_t gru_ws_one(int64_t n_tok, int64_t B, int E, int D) {
     using itr::al256;
-    (void)bidirectional;
     return al256((size_t)n_tok * itr::pad32(E) * 4) + al256((size_t)n_tok * 3 * D * 4) + al256((size_t)B * 3 * D * 4) +
            al256((size_t)B * D * 4) + al256((size_t)n_tok * D * 4) + al256((size_t)3 * D * itr::pad32(E) * 4) +
            al256(itr::gru_splitk_bytes(B, D)) + 256;
+}
+
+extern "C" size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional) {
+    // a bi-GRU runs its two directions side by side (second HIP stream): each needs its own gate pre-activations and state
+    return gru_ws_one(n_tok, B, E, D) * (bidirectional ? 2 : 1);
 }
 
 extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev,
@@ -165,29 +198,53 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
                        w.bad);
     ITR_CHECK_LAUNCH("embed_gather");
 
+    // the reverse direction on a second stream with its own buffers (ITR_GRU_NO_OVERLAP=1: one after the other, for A/B timing)
+    SideStream *side = (bi && !getenv("ITR_GRU_NO_OVERLAP")) ? side_stream() : nullptr;
+    GruWs w2 = w;
+    if (bi) {
+        w2 = carve(static_cast<char *>(workspace) + gru_ws_one(n_tok, B, E, D), n_tok, B, E, D);
+        w2.x = w.x;                      // the gathered embeddings are shared (read-only)
+    }
+    if (side) {
+        ITR_CHECK_HIP(hipEventRecord(side->fork, st));
+        ITR_CHECK_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+    }
     for (int dir = 0; dir < (bi ? 2 : 1); ++dir) {
         const float *wi = dir ? w_ih_rev : w_ih, *wh = dir ? w_hh_rev : w_hh;
         const float *bi_ = dir ? b_ih_rev : b_ih, *bh = dir ? b_hh_rev : b_hh;
+        const GruWs &ww = dir ? w2 : w;
+        hipStream_t sd = (dir && side) ? side->st : st;
+        float *dst = dir ? w2.out_tmp : seq;             // reverse direction: its own sequence buffer, averaged in below
         const float *wi_use = wi;
         if (Ep != E) {   // zero-padded copy of W_ih: K = Ep is a multiple of 32 (zeros add nothing)
-            hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)(3 * D)), dim3(128), 0, st, wi, (int64_t)3 * D, E, Ep, w.wpad);
+            hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)(3 * D)), dim3(128), 0, sd, wi, (int64_t)3 * D, E, Ep, ww.wpad);
             ITR_CHECK_LAUNCH("pad_cols");
-            wi_use = w.wpad;
+            wi_use = ww.wpad;
         }
-        int rc = gemm_nt(w.x, Ep, wi_use, Ep, bi_, w.gi, 3 * D, n_tok, 3 * D, Ep, 0, st);
+        int rc = gemm_nt(w.x, Ep, wi_use, Ep, bi_, ww.gi, 3 * D, n_tok, 3 * D, Ep, 0, sd);
         if (rc != ITR_OK) return rc;
-        ITR_CHECK_HIP(hipMemsetAsync(w.h, 0, (size_t)B * D * 4, st));
+        ITR_CHECK_HIP(hipMemsetAsync(ww.h, 0, (size_t)B * D * 4, sd));
         int64_t n_act = B;
         for (int t = 0; t < Lmax; ++t) {
             while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
-            rc = (splits_h > 1) ? gemm_nt_splitk(w.h, D, wh, D, bh, w.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, w.skbuf, st)
-                                : gemm_nt(w.h, D, wh, D, bh, w.gh, 3 * D, n_act, 3 * D, D, 0, st);
+            rc = (splits_h > 1) ? gemm_nt_splitk(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, ww.skbuf, sd)
+                                : gemm_nt(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, sd);
             if (rc != ITR_OK) return rc;
             dim3 grid((unsigned)n_act, (unsigned)ceil_div(D, 256));
-            hipLaunchKernelGGL(gru_gate_kernel, grid, dim3(256), 0, st, w.gi, w.gh, w.h, seq, tok_off, len_dev, t, dir,
-                               dir, D, n_act);
+            hipLaunchKernelGGL(gru_gate_kernel, grid, dim3(256), 0, sd, ww.gi, ww.gh, ww.h, dst, tok_off, len_dev, t, dir,
+                               0, D, n_act);
             ITR_CHECK_LAUNCH("gru_gate");
         }
+    }
+    if (bi) {
+        if (side) {
+            ITR_CHECK_HIP(hipEventRecord(side->join, side->st));
+            ITR_CHECK_HIP(hipStreamWaitEvent(st, side->join, 0));
+        }
+        ITR_REQUIRE(D % 4 == 0, "itr_gru_fwd: embed dim must be a multiple of 4");
+        const int64_t n4 = n_tok * (int64_t)D / 4;
+        hipLaunchKernelGGL(avg2_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, seq, w2.out_tmp, n4);
+        ITR_CHECK_LAUNCH("gru avg2");
     }
     float *final_ = seq;
     int64_t final_rows = n_tok;
