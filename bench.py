@@ -245,7 +245,9 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
                                        dict(bi_gru=kind == "VSE++", no_txtnorm=False, no_imgnorm=False), comm)
     else:
         feats, boxes, imgs_wh, ids, mask, types, lengths = pooled_inputs(n_img, n_cap, kind, dev)
-    pe = evalpipe.PooledModelEval(model, comm, batch=1024)   # 1024 captions x 32 tokens = 256 M-tiles: whole rounds of the persistent GEMM
+    # captions per text-tower pass: 4096 x 32 tokens = 1024 row tiles, i.e. >= 4 tiles per resident workgroup for every 768-wide
+    # layer, which is what the streaming GEMM asks for (ITR_POOLED_BATCH overrides)
+    pe = evalpipe.PooledModelEval(model, comm, batch=int(os.environ.get('ITR_POOLED_BATCH', '4096')))
     timers = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
 
     def step(tm=None):

@@ -297,7 +297,7 @@ class PooledModelEval:
     (cosine / pdist_cos / MultiViewMatching with its max-over-views epilogue) and the ranks are finished exactly as
     for SCAN (finalize_ranks)."""
 
-    def __init__(self, model, comm=None, batch=1024):
+    def __init__(self, model, comm=None, batch=4096):
         self.model, self.comm, self.batch = model, comm or Comm(), batch
         self.name = model.config['name']
 
@@ -457,14 +457,15 @@ class _FeatureBlocks:
             self.consumed[k & 1] = cur.record_event()      # the consumer has queued its work on this block
 
 
-def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
+def evaluate_precomp(model, dataset, comm=None, fold=None, batch=4096, block_rows=640):
     """Recall ranks of `model` on a PrecompDataset (datamodule.data_loader), one process per GPU.
 
     Unlike encode_data + cal_sims (the reference-shaped path: 5 x redundant image encodes, host numpy arrays, a Python
     tile loop), every unique image is encoded once, nothing returns to the host but the rank vectors, the caption
     axis is sharded over ranks and exchanged with ONE all-gather, and the row block of the similarity matrix is scored
     by the fused kernels.  fold = (k, size) restricts to captions [k*size, (k+1)*size) (MS-COCO 1k folds,
-    evaluation.py:296-300).  Returns (i2t_rank, i2t_top1, t2i_rank, t2i_top1) as host int64 arrays."""
+    evaluation.py:296-300).  block_rows: images per streamed feature block of the word-level models (see _FeatureBlocks).
+    Returns (i2t_rank, i2t_top1, t2i_rank, t2i_top1) as host int64 arrays."""
     comm = comm or Comm()
     cfg = model.config
     name = cfg['name']
@@ -481,7 +482,7 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=1024):
     model.val_start()
     streamed = name in ('SCAN', 'SGRAF')       # word-level scorers: seconds of GPU work per row block to hide the copies under
     if streamed:
-        feats = _FeatureBlocks(dataset.images, img_lo + i0, img_lo + i1, dev)
+        feats = _FeatureBlocks(dataset.images, img_lo + i0, img_lo + i1, dev, block_rows)
         feats.prefetch()                       # block 0 crosses PCIe while the captions are tokenised
     elif name not in ('SAEM', 'CAMERA'):
         feats = _features_to_device(dataset.images, img_lo + i0, img_lo + i1, dev)

@@ -130,6 +130,26 @@ def test_evalrank_fast_equals_reference_shaped_path(golden, dev, tmp_path):
             assert any((np.asarray(cos[k]) != np.asarray(fast[k])).any() for k in ('i2t_ranks', 't2i_ranks'))
 
 
+def test_streamed_feature_blocks_give_the_same_ranks(golden, dev, tmp_path):
+    """evaluate_precomp streams the feature file in row blocks (block k+1 crosses PCIe under the scoring of block k): with
+    4-image blocks the toy split takes several blocks, and the rank vectors equal the single-block run's."""
+    from itr_amd import evalpipe
+    g = golden("g14_data_layer")
+    name, data_path, vdir = _materialise(g, tmp_path)
+    for model_name, extra in (('SCAN', []), ('SGRAF', ['module_name=SAF'])):
+        cfg = C.build_config(['with', model_name, 'data_name=%s' % name, 'bi_gru=True', 'seed=3'] + extra)
+        cfg.update(img_dim=8, embed_size=32, word_dim=16, vocab_size=int(g["vocab_len"]), data_path=data_path, vocab_path=vdir,
+                   batch_size=7, workers=0, save_dir=str(tmp_path), word_tokenize=None, sim_dim=16, vocab_type='json')
+        torch.manual_seed(3)
+        model = get_model(cfg)
+        dset = dl.PrecompDataset(os.path.join(data_path, name), 'test', cfg)
+        one = evalpipe.evaluate_precomp(model, dset)
+        many = evalpipe.evaluate_precomp(model, dset, block_rows=4)
+        assert len(dset.images) > 4
+        for a, b in zip(one, many):
+            assert (np.asarray(a) == np.asarray(b)).all()
+
+
 def _with_measure(model, measure):
     model.config['measure'] = measure
     return model
