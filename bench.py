@@ -317,7 +317,7 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
     out = {"metric": "pairs/sec scored (5k img x 25k cap) + Recall@1 parity, 1/2/4/8 MI355X", "value": float(n_img) * n_cap / (dt / args.steps),
            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": args.workload, "model": model_name, "n_img": n_img, "n_cap": n_cap, "regions": 36, "feat_dim": 2048,
+           "config": {"workload": args.workload, "scorer": model_name, "n_img": n_img, "n_cap": n_cap, "regions": 36, "feat_dim": 2048,
                       "embed": dims, "parallelism": "row-shard x%d + 1 all-gather of caption embeddings" % world,
                       "step": "encode(image tower + text tower) + score + rank(i2t,t2i)"},
            "recall": {"i2t_r1": i2t[0], "i2t_r5": i2t[1], "i2t_r10": i2t[2], "t2i_r1": t2i[0], "t2i_r5": t2i[1], "t2i_r10": t2i[2]},
@@ -442,7 +442,8 @@ def main_from_files(args, world, rank, dev, use_dist):
            "config": {"workload": "scan_t2i_coco5k_from_files", "n_img": n_img, "n_cap": n_cap, "n_words": int(np.sum(lens_all)),
                       "step": "mmap .npy -> pinned -> HBM (row blocks under the scoring) + tokenise + encode + score + rank"},
            "resident": {"value": pairs / dt_res, "ms_per_step": 1e3 * dt_res, "note": "same data already in HBM, captions packed beforehand"},
-           "files_over_resident_time": dt_files / dt_res, "ranks_identical_to_resident": bool(same)}
+           "files_over_resident_time": dt_files / dt_res, "ranks_identical_to_resident": bool(same),
+           "rank_checksum": [int((np.asarray(r, np.int64) * (np.arange(len(r)) % 9973 + 1)).sum()) for r in ranks_f]}
     print(json.dumps(out), flush=True)
 
 
@@ -593,7 +594,7 @@ def main():
             "value": pairs / (dt / args.steps), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": args.workload, "model": model_name,
+            "config": {"workload": args.workload, "scorer": model_name,
                        "n_img": n_img, "n_cap": n_cap, "regions": R, "feat_dim": F_, "embed": D,
                        "n_words": n_words, "parallelism": "row-shard x%d + 1 all-gather" % world,
                        "step": "encode(img proj + bi-GRU) + score + rank(i2t,t2i)"},

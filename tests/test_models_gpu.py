@@ -227,3 +227,35 @@ def test_sharded_eval_equals_single_process_on_one_gpu(workload, world):
     if workload.startswith("scan_"):       # the separately reported split-fp16 variant rides along with the single-GPU fp32 line only
         v = single["variant_fp16x3"]
         assert v["max_abs_diff_vs_fp32_scores"] <= 1e-5 and v["recall"] == single["recall"] and "variant_fp16x3" not in multi
+
+
+@pytest.mark.gpu
+def test_from_files_path_single_and_two_ranks(tmp_path):
+    """bench.py --from-files on a small synthetic precomp directory (tools/make_synth_precomp.py): the file -> rank path
+    (memory-mapped features streamed in row blocks, one-pass tokenisation, token-balanced caption ranges) gives the rank vectors
+    of the resident-input step, with one process and with two ranks (gloo, sharing the GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = str(tmp_path / "synth")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "make_synth_precomp.py"), d, "--n-img", "1300", "--vocab", "500"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    base = [os.path.join(root, "bench.py"), "--from-files", d, "--steps", "1", "--warmup", "1"]
+
+    def run(cmd, env):
+        rr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert rr.returncode == 0, rr.stderr[-3000:]
+        line = [ln for ln in rr.stdout.splitlines() if ln.startswith('{"metric"')]
+        assert len(line) == 1, rr.stdout[-2000:]
+        return json.loads(line[0])
+
+    single = run([sys.executable] + base, dict(os.environ))
+    assert single["ranks_identical_to_resident"] and single["config"]["n_img"] == 1300 and single["config"]["n_cap"] == 6500
+    env = dict(os.environ, ITR_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    multi = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                 "--master-port", "29577", base[0], "--gpus", "2"] + base[1:], env)
+    assert multi["n_gpus"] == 2 and multi["ranks_identical_to_resident"]
+    assert multi["rank_checksum"] == single["rank_checksum"]
