@@ -23,6 +23,7 @@ struct GemmStreamArgs {
     int64_t lda, ldb, ldc;
     int64_t tiles_m, tiles_n;
     int K;
+    int xcd_map;      // 1: the workgroups of one row range (all column tiles) sit on ONE XCD and share the A chunks in its L2
 };
 
 template <bool RELU>
@@ -36,8 +37,12 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gemm_nt_stream_kernel(GemmStrea
     // (32-bit tile arithmetic, made provably wave-uniform for the "s" operands of the asm statement: hipcc expands a
     // division by a run-time value on the vector ALU)
     const unsigned tiles_n = (unsigned)g.tiles_n, tiles_m = (unsigned)g.tiles_m;
-    const unsigned tn_u = __builtin_amdgcn_readfirstlane(blockIdx.x % tiles_n), iw = __builtin_amdgcn_readfirstlane(blockIdx.x / tiles_n);
+    // Consecutive workgroup ids go round the 8 XCDs.  With xcd_map, slot s of XCD x is (column tile s % tiles_n, row range
+    // (s / tiles_n) * 8 + x): the tiles_n workgroups that walk the same rows run side by side under one L2 and A leaves HBM once.
     const unsigned nw = __builtin_amdgcn_readfirstlane(gridDim.x / tiles_n);
+    const unsigned slot = g.xcd_map ? blockIdx.x >> 3 : blockIdx.x;
+    const unsigned tn_u = __builtin_amdgcn_readfirstlane(slot % tiles_n);
+    const unsigned iw = __builtin_amdgcn_readfirstlane(g.xcd_map ? (slot / tiles_n) * 8u + (blockIdx.x & 7u) : slot / tiles_n);
     const unsigned q_ = __builtin_amdgcn_readfirstlane(tiles_m / nw), r_ = __builtin_amdgcn_readfirstlane(tiles_m % nw);
     const int64_t tn = tn_u;
     const int64_t t0 = iw < r_ ? (int64_t)iw * (q_ + 1) : (int64_t)r_ * (q_ + 1) + (int64_t)(iw - r_) * q_;
@@ -96,7 +101,10 @@ bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, co
     if (tiles_m * tiles_n < min_rounds * resident) return false;  // streaming pays when every workgroup gets several tiles
     int64_t grid = resident / tiles_n * tiles_n;
     if (grid < tiles_n) grid = tiles_n;
-    GemmStreamArgs g{A, B, bias, C, lda, ldb, ldc, tiles_m, tiles_n, (int)K};
+    static const bool xcd_off = getenv("ITR_GEMM_STREAM_XCD") && atoi(getenv("ITR_GEMM_STREAM_XCD")) == 0;
+    // (measured: +2-3 % from 4 column tiles up -- 179 200 x 1 024 x 2 048: 142 -> 147 TFLOP/s; nothing at 2)
+    const int xcd_map = (!xcd_off && tiles_n >= 4 && grid % 8 == 0 && (grid / 8) % tiles_n == 0) ? 1 : 0;
+    GemmStreamArgs g{A, B, bias, C, lda, ldb, ldc, tiles_m, tiles_n, (int)K, xcd_map};
     if (act == 1)
         hipLaunchKernelGGL(gemm_nt_stream_kernel<true>, dim3((unsigned)grid), dim3(GS_THREADS), 0, st, g);
     else

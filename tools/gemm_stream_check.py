@@ -30,7 +30,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         print("  M=%7d N=%4d K=%4d act=%-5s %8.3f ms  %6.1f TF/s   max|d| vs fp64 %.2e   checksum %.6f" % (
             M, N, K, act, ms, 2.0 * M * N * K / ms / 1e9, err, float(got.double().sum())))
 else:
-    for mode in ("1", "0"):
-        print("ITR_GEMM_STREAM=%s" % mode)
+    for mode, xcd in (("1", "1"), ("1", "0"), ("0", "0")):
+        print("ITR_GEMM_STREAM=%s ITR_GEMM_STREAM_XCD=%s" % (mode, xcd))
         sys.stdout.flush()
-        subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, ITR_GEMM_STREAM=mode))
+        subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, ITR_GEMM_STREAM=mode, ITR_GEMM_STREAM_XCD=xcd))

@@ -114,10 +114,19 @@ def slot(mf, mem):
     return out + list(mem[len(mf):])
 
 
-def chunk(cur, nxt):
-    ins = ["s_waitcnt vmcnt(0) lgkmcnt(0)"]        # the stage (chunk g+1) landed; F0(g), read during the previous half, landed
+def head(nxt):
+    """Start of a chunk: the stage (chunk g+1) has landed -> park it in the other LDS buffer, request chunk g+2."""
     ld, adv = gload()
-    ins += slot(mfmas(0), lstore(nxt) + ld + fread(1, cur) + adv[:8])
+    return ["s_waitcnt vmcnt(0) lgkmcnt(0)"], lstore(nxt) + ld, adv
+
+
+def chunk(cur, nxt, with_head=True):
+    """with_head=False: the first chunk of a row tile, whose head was issued in front of the previous tile's stores (epilogue)."""
+    if with_head:
+        ins, mem, adv = head(nxt)
+    else:
+        ins, mem, adv = ["s_waitcnt lgkmcnt(0)"], [], []
+    ins += slot(mfmas(0), mem + fread(1, cur) + adv[:8])
     ins += adv[8:]
     ins += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
     ins += slot(mfmas(1), fread(0, nxt))
@@ -135,6 +144,10 @@ def epilogue(relu):
                 ins.append("v_add_f32 v%d, v%d, %%[bias%d]" % (reg, reg, j))
                 if relu:
                     ins.append("v_max_f32 v%d, v%d, 0" % (reg, reg))
+    # The head of the next chunk goes IN FRONT of the stores: vmcnt counts loads and stores in issue order and stops at 63, so a
+    # wait for the operand loads issued before 64 stores would also wait for every store's write acknowledgement.
+    w, mem, adv = head(1)
+    ins += w + mem + adv
     ins += ["s_mov_b64 s[%d:%d], s[%d:%d]" % (S_ROW, S_ROW + 1, S_PC, S_PC + 1)]
     for idx in range(32):
         i, r = idx // 16, idx % 16
@@ -161,9 +174,14 @@ def program(relu):
     ins += ld + adv + ["s_waitcnt vmcnt(0)"] + lstore(0)
     ld, adv = gload()
     ins += ld + adv + ["s_waitcnt lgkmcnt(0)", "s_barrier"] + fread(0, 0)
-    ins += [L("tile") + ":", "s_mov_b32 s%d, s%d" % (S_CNT, S_NK2), L("chunk") + ":"]
+    w, mem, adv = head(1)                          # head of the first tile's first chunk (later tiles: inside the epilogue)
+    ins += w + mem + adv
+    ins += [L("tile") + ":"]
+    ins += chunk(0, 1, with_head=False) + chunk(1, 0)
+    ins += ["s_sub_u32 s%d, s%d, 1" % (S_CNT, S_NK2), "s_cmp_eq_u32 s%d, 0" % S_CNT, "s_cbranch_scc1 " + L("flush"), L("chunk") + ":"]
     ins += chunk(0, 1) + chunk(1, 0)
     ins += ["s_sub_u32 s%d, s%d, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 s%d, 0" % S_CNT, "s_cbranch_scc1 " + L("chunk")]
+    ins += [L("flush") + ":"]
     ins += epilogue(relu)
     ins += ["s_sub_u32 s%d, s%d, 1" % (S_NT, S_NT), "s_cmp_lg_u32 s%d, 0" % S_NT, "s_cbranch_scc1 " + L("tile")]
     ins += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]      # the tail prefetch (re-read of the last tile) and the stores are done
