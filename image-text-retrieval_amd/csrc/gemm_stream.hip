@@ -5,12 +5,13 @@
 // SGRAF's graph-reasoning steps (Fusionmodule.py:589-597), two per step over ~5 M node rows -- a tile is 8 chunks long and
 // that kernel reaches 79-91 TFLOP/s; even at K = 2048 the fill / drain and its compiler-scheduled loop leave it at 132.  Here a workgroup owns ONE 128-column tile
 // and streams down a contiguous range of 128-row tiles: operand chunks of tile t+1 are requested while the last chunks of
-// tile t are multiplied, the accumulators are flushed between two chunks, the loop never drains.  The B panel of the
+// tile t are multiplied, and tile t is flushed (bias, relu, stores) from its own accumulator set behind the MFMAs that fill the
+// other set with tile t+1: the loop never drains and the stores never arrive in a burst.  The B panel of the
 // workgroup (128 x K) is re-read from L2 for every row tile (it is the same 128 KB every time).
 //
 // The body is one generated asm statement (gemm_stream_asm.inc, tools/gen_gemm_stream.py) with hand-allocated registers:
 // see scan_mainloop.inc for why the loops that hide loads from hipcc are not written in C++ any more.
-// Preconditions (checked by the host wrapper): M % 128 == 0, N % 128 == 0, K % 64 == 0, 16-byte aligned rows.
+// Preconditions (checked by the host wrapper): M % 128 == 0, N % 128 == 0, K % 64 == 0, K >= 128, 16-byte aligned rows.
 #include "itr_common.h"
 
 namespace itr {
@@ -92,7 +93,7 @@ bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, co
     // (measured: ahead of the tile kernel at every K -- 179 200 x 1 024 x 2 048: 132 -> 147 TFLOP/s, 800 000 x 2 304 x 768: 120 -> 135,
     // 265 000 x 256 x 256: 79 -> 104; tools/gemm_stream_check.py.  ITR_GEMM_STREAM_KMAX caps K for experiments.)
     static const int64_t kmax = getenv("ITR_GEMM_STREAM_KMAX") ? atoll(getenv("ITR_GEMM_STREAM_KMAX")) : (1ll << 40);
-    if (off || (act != 0 && act != 1) || K % 64 != 0 || K < 64 || K > kmax || N % GS_BM != 0 || M < GS_BM) return false;
+    if (off || (act != 0 && act != 1) || K % 64 != 0 || K < 128 || K > kmax || N % GS_BM != 0 || M < GS_BM) return false;
     if ((lda % 4) || (ldb % 4) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return false;
     if ((uint64_t)lda * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldb * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldc * 4u * GS_BM >= (1ull << 31)) return false;
     const int64_t tiles_m = M / GS_BM, tiles_n = N / GS_BM;      // whole row tiles; a remainder of rows goes to the tile kernel

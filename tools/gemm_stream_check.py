@@ -9,7 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from itr_amd import ops
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    for (M, N, K, act) in [(128 * 2048 + 37, 256, 256, None), (128 * 2100, 256, 256, 'relu'), (128 * 4200, 128, 64, None), (265000, 256, 256, 'relu'),
+    for (M, N, K, act) in [(128 * 2048 + 37, 256, 256, None), (128 * 2100, 256, 256, 'relu'), (128 * 4200, 128, 128, None), (128 * 40000, 256, 256, 'relu'), (265000, 256, 256, 'relu'),
                            (128 * 1030, 384, 128, None), (128 * 2500, 256, 512, 'relu')] + [(128 * 1400, 1024, 2048, None), (128 * 6250, 2304, 768, None),
                            (128 * 6250, 768, 3072, None), (128 * 2070, 256, 1024, None), (128 * 200, 3072, 1024, None)]:
         a = torch.randn(M, K, device=dev); b = torch.randn(N, K, device=dev) * 0.1; bias = torch.randn(N, device=dev)

@@ -3,19 +3,27 @@
 as ONE inline-asm statement per epilogue variant, with hand-allocated registers.
 
 What it is for.  `C = act(A B^T + bias)` with a SHORT K (the 256 x 256 projections of the SGRAF graph-reasoning steps, SAEM's
-256-wide layers): a 128 x 128 output tile is only K / 32 = 8 chunks long, and the tile-at-a-time kernel (gemm_f32.hip) pays a
-pipeline fill (first operand chunk: a full L2 / HBM latency) and a drain per tile -- 91 TFLOP/s at 265 000 x 256 x 256 against
-131 at K = 2 048.  Here a workgroup owns ONE column tile and STREAMS down its range of row tiles: the operand pipeline never
-drains at a tile boundary (while the last chunks of tile t are multiplied, chunks 0 and 1 of tile t+1 are already on their way),
-the accumulators are flushed (bias, optional relu, store) between two chunks, and the loop goes on.
+256-wide layers, BERT's 768-wide ones): a 128 x 128 output tile is only K / 32 chunks long, and the tile-at-a-time kernel
+(gemm_f32.hip) pays a pipeline fill (first operand chunk: a full L2 / HBM latency) and a drain per tile.  Here a workgroup owns
+ONE column tile and STREAMS down its range of row tiles: the operand pipeline never drains at a tile boundary (while the last
+chunks of tile t are multiplied, chunks 0 and 1 of tile t+1 are already on their way).
+
+Two accumulator sets.  Tile t accumulates into set t & 1; the OTHER set still holds tile t-1, and its flush (bias, optional
+relu, 64 row stores per wave) is slotted behind the MFMAs of tile t's first two chunks, two instruction groups per MFMA.  A
+flush issued as one block (the first version of this kernel) cost ~3.4 chunk times per tile: the 8 waves of a compute unit push
+their 512 store instructions through one address unit at the same moment and nothing multiplies meanwhile.  The first MFMA
+into each accumulator of a tile takes C = 0 as an inline constant, so the sets are never zeroed.
 
 Per 32-wide K chunk (64 x v_mfma_f32_32x32x2_f32 per wave, 4 waves = 2 x 2 of 64 x 64):
     wait the register stage (chunk g+1) | park it in the other LDS buffer | request chunk g+2 | read fragment set F1(g)
     32 MFMAs on F0(g), one memory instruction slotted behind each of the first 24, scalar pointer updates behind the rest
     s_waitcnt lgkmcnt(0); s_barrier
     read F0(g+1) from the other buffer behind the first 8 of the 32 MFMAs on F1(g)
-LDS layout, fragment mapping and the k-ordering are those of gemm_nt_fast_kernel (plane / XOR layout, gemm_f32.hip).
-All registers the statement touches are named literally and declared clobbered (see tools/gen_scan_mainloop.py for why).
+vmcnt counts loads and stores in issue order: the chunk after one that issued S flush stores behind its last operand load waits
+with vmcnt(S) -- the loads have landed, the stores need not have been acknowledged.
+LDS layout, fragment mapping and the k-ordering are those of gemm_nt_fast_kernel (plane / XOR layout, gemm_f32.hip): results
+are bit-identical to that kernel's.  All registers the statement touches are named literally and declared clobbered (see
+tools/gen_scan_mainloop.py for why); hipcc keeps its 20 address / bias values in v0..v31.
 
     python tools/gen_gemm_stream.py [--check]
 """
@@ -30,22 +38,27 @@ OPER_BYTES = 8 * BM * 16          # one operand of one chunk: 8 planes x 128 row
 BUF_BYTES = 2 * OPER_BYTES        # A | B
 
 # ---- register map
-ACC0 = 64                          # acc[i][j]: 16 registers each, v[64:127]
-FRAG = {(0, 'A'): 128, (0, 'B'): 144, (1, 'A'): 160, (1, 'B'): 176}     # fragment set -> base; [q_ (2)][t (2)] float4
-STAGE = 192                        # ra0..3, rb0..3: v[192:223]
-V_LO, V_HI = 64, 223
+ACC0 = 32                          # set s, acc[i][j]: 16 registers each: v[32:95] (set 0), v[96:159] (set 1)
+FRAG = {(0, 'A'): 160, (0, 'B'): 176, (1, 'A'): 192, (1, 'B'): 208}     # fragment set -> base; [q_ (2)][t (2)] float4
+STAGE = 224                        # ra0..3, rb0..3: v[224:255]
+V_LO, V_HI = 32, 255
 # scalars
-S_PA, S_PB, S_PC, S_ROW = 70, 72, 74, 88
+S_PA, S_PB, S_PC, S_ROW, S_PCP = 70, 72, 74, 88, 92
 S_TSTEP, S_KB, S_LDC4, S_LDC4X5, S_NT, S_NK2, S_LK, S_NKM1, S_T0, S_T1, S_LT, S_T2, S_CNT = 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 90
-S_LO, S_HI = 70, 90
+S_LO, S_HI = 70, 93
+NF = 2                             # flush groups slotted behind one MFMA
 
 
 def v4(b):
     return "v[%d:%d]" % (b, b + 3)
 
 
-def acc(i, j):
-    b = ACC0 + (i * 2 + j) * 16
+def acc_base(s, i, j):
+    return ACC0 + 64 * s + (i * 2 + j) * 16
+
+
+def acc(s, i, j):
+    b = acc_base(s, i, j)
     return "v[%d:%d]" % (b, b + 15)
 
 
@@ -57,26 +70,28 @@ def lstore(buf):
 
 
 def gload():
+    """8 loads of the chunk the running pointers address, and the pointer update as groups of scalar instructions (a group is
+    never split: its members talk through SCC)."""
     ins = []
     for s in range(4):     # A and B passes alternate like the C++ kernel does
         ins.append("global_load_dwordx4 %s, %%[oa%d], s[%d:%d]" % (v4(STAGE + 4 * s), s, S_PA, S_PA + 1))
         ins.append("global_load_dwordx4 %s, %%[ob%d], s[%d:%d]" % (v4(STAGE + 16 + 4 * s), s, S_PB, S_PB + 1))
     # advance the load stream by one chunk; at the end of a row tile step to the next one (or stay on the last one)
-    adv = ["s_cmp_eq_u32 s%d, s%d" % (S_LK, S_NKM1),                       # SCC = this was the last chunk of its row tile
-           "s_cselect_b32 s%d, s%d, 0" % (S_T1, S_KB),                     # rewind by K bytes ...
-           "s_cselect_b32 s%d, s%d, 0" % (S_T2, S_TSTEP),                  # ... and step one row tile down
-           "s_cselect_b32 s%d, -1, s%d" % (S_LK, S_LK),
-           "s_add_u32 s%d, s%d, 1" % (S_LK, S_LK),
-           "s_cmp_gt_u32 s%d, 1" % S_LT,                                   # is there another row tile to fetch?
-           "s_cselect_b32 s%d, s%d, 0" % (S_T2, S_T2),
-           "s_cmp_lg_u32 s%d, 0" % S_T2,
-           "s_cselect_b32 s%d, 1, 0" % S_T0,
-           "s_sub_u32 s%d, s%d, s%d" % (S_LT, S_LT, S_T0),
-           "s_add_u32 s%d, s%d, 128" % (S_PA, S_PA), "s_addc_u32 s%d, s%d, 0" % (S_PA + 1, S_PA + 1),
-           "s_sub_u32 s%d, s%d, s%d" % (S_PA, S_PA, S_T1), "s_subb_u32 s%d, s%d, 0" % (S_PA + 1, S_PA + 1),
-           "s_add_u32 s%d, s%d, s%d" % (S_PA, S_PA, S_T2), "s_addc_u32 s%d, s%d, 0" % (S_PA + 1, S_PA + 1),
-           "s_add_u32 s%d, s%d, 128" % (S_PB, S_PB), "s_addc_u32 s%d, s%d, 0" % (S_PB + 1, S_PB + 1),
-           "s_sub_u32 s%d, s%d, s%d" % (S_PB, S_PB, S_T1), "s_subb_u32 s%d, s%d, 0" % (S_PB + 1, S_PB + 1)]
+    adv = [["s_cmp_eq_u32 s%d, s%d" % (S_LK, S_NKM1),                      # SCC = this was the last chunk of its row tile
+            "s_cselect_b32 s%d, s%d, 0" % (S_T1, S_KB),                    # rewind by K bytes ...
+            "s_cselect_b32 s%d, s%d, 0" % (S_T2, S_TSTEP),                 # ... and step one row tile down
+            "s_cselect_b32 s%d, -1, s%d" % (S_LK, S_LK)],
+           ["s_add_u32 s%d, s%d, 1" % (S_LK, S_LK)],
+           ["s_cmp_gt_u32 s%d, 1" % S_LT,                                  # is there another row tile to fetch?
+            "s_cselect_b32 s%d, s%d, 0" % (S_T2, S_T2)],
+           ["s_cmp_lg_u32 s%d, 0" % S_T2,
+            "s_cselect_b32 s%d, 1, 0" % S_T0],
+           ["s_sub_u32 s%d, s%d, s%d" % (S_LT, S_LT, S_T0)],
+           ["s_add_u32 s%d, s%d, 128" % (S_PA, S_PA), "s_addc_u32 s%d, s%d, 0" % (S_PA + 1, S_PA + 1)],
+           ["s_sub_u32 s%d, s%d, s%d" % (S_PA, S_PA, S_T1), "s_subb_u32 s%d, s%d, 0" % (S_PA + 1, S_PA + 1)],
+           ["s_add_u32 s%d, s%d, s%d" % (S_PA, S_PA, S_T2), "s_addc_u32 s%d, s%d, 0" % (S_PA + 1, S_PA + 1)],
+           ["s_add_u32 s%d, s%d, 128" % (S_PB, S_PB), "s_addc_u32 s%d, s%d, 0" % (S_PB + 1, S_PB + 1)],
+           ["s_sub_u32 s%d, s%d, s%d" % (S_PB, S_PB, S_T1), "s_subb_u32 s%d, s%d, 0" % (S_PB + 1, S_PB + 1)]]
     return ins, adv
 
 
@@ -92,8 +107,9 @@ def fread(fset, buf):
     return ins
 
 
-def mfmas(fset):
-    """32 MFMAs of one fragment set, component-major: consecutive instructions never touch the same accumulator."""
+def mfmas(aset, fset, first=False):
+    """32 MFMAs of one fragment set, component-major: consecutive instructions never touch the same accumulator.
+    first: the four that open the tile take C = 0."""
     out = []
     for q_ in range(2):
         for c in range(4):
@@ -101,90 +117,112 @@ def mfmas(fset):
                 for j in range(2):
                     a = FRAG[(fset, 'A')] + (q_ * 2 + i) * 4 + c
                     b = FRAG[(fset, 'B')] + (q_ * 2 + j) * 4 + c
-                    out.append("v_mfma_f32_32x32x2_f32 %s, v%d, v%d, %s" % (acc(i, j), a, b, acc(i, j)))
+                    src = "0" if (first and q_ == 0 and c == 0) else acc(aset, i, j)
+                    out.append("v_mfma_f32_32x32x2_f32 %s, v%d, v%d, %s" % (acc(aset, i, j), a, b, src))
     return out
 
 
-def slot(mf, mem):
-    out = []
-    for i, x in enumerate(mf):
-        out.append(x)
-        if i < len(mem):
-            out.append(mem[i])
-    return out + list(mem[len(mf):])
-
-
-def head(nxt):
-    """Start of a chunk: the stage (chunk g+1) has landed -> park it in the other LDS buffer, request chunk g+2."""
-    ld, adv = gload()
-    return ["s_waitcnt vmcnt(0) lgkmcnt(0)"], lstore(nxt) + ld, adv
-
-
-def chunk(cur, nxt, with_head=True):
-    """with_head=False: the first chunk of a row tile, whose head was issued in front of the previous tile's stores (epilogue)."""
-    if with_head:
-        ins, mem, adv = head(nxt)
-    else:
-        ins, mem, adv = ["s_waitcnt lgkmcnt(0)"], [], []
-    ins += slot(mfmas(0), mem + fread(1, cur) + adv[:8])
-    ins += adv[8:]
-    ins += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
-    ins += slot(mfmas(1), fread(0, nxt))
-    return ins
-
-
-def epilogue(relu):
-    """Flush the four 64 x 64 quadrants of this wave: + bias, [relu], store row by row, zero.  C/D layout of
-    v_mfma_f32_32x32x2_f32: register r of lane (fi = lane & 31, fg = lane >> 5) is row (r & 3) + 8 (r >> 2) + 4 fg, column fi."""
-    ins = ["s_nop 15", "s_nop 7"]                 # 16-pass MFMA results -> VALU
-    for i in range(2):
-        for j in range(2):
-            for r in range(16):
-                reg = ACC0 + (i * 2 + j) * 16 + r
-                ins.append("v_add_f32 v%d, v%d, %%[bias%d]" % (reg, reg, j))
-                if relu:
-                    ins.append("v_max_f32 v%d, v%d, 0" % (reg, reg))
-    # The head of the next chunk goes IN FRONT of the stores: vmcnt counts loads and stores in issue order and stops at 63, so a
-    # wait for the operand loads issued before 64 stores would also wait for every store's write acknowledgement.
-    w, mem, adv = head(1)
-    ins += w + mem + adv
-    ins += ["s_mov_b64 s[%d:%d], s[%d:%d]" % (S_ROW, S_ROW + 1, S_PC, S_PC + 1)]
+def flush_groups(fs, relu):
+    """Flush of accumulator set fs to the tile at s[S_ROW], as groups: + bias, [relu], store, row by row.  C/D layout of
+    v_mfma_f32_32x32x2_f32: register r of lane (fi = lane & 31, fg = lane >> 5) is row (r & 3) + 8 (r >> 2) + 4 fg, column fi.
+    Rows of acc[0][*] first: the MFMAs that finished the tile ended on acc[1][1]."""
+    gs = []
     for idx in range(32):
         i, r = idx // 16, idx % 16
         for j in range(2):
-            ins.append("global_store_dword %%[voffc], v%d, s[%d:%d] offset:%d" % (ACC0 + (i * 2 + j) * 16 + r, S_ROW, S_ROW + 1, j * 128))
+            reg = acc_base(fs, i, j) + r
+            gs.append(["v_add_f32 v%d, v%d, %%[bias%d]" % (reg, reg, j)])
+            if relu:
+                gs.append(["v_max_f32 v%d, v%d, 0" % (reg, reg)])
+            gs.append(["global_store_dword %%[voffc], v%d, s[%d:%d] offset:%d" % (reg, S_ROW, S_ROW + 1, j * 128)])
         step = S_LDC4X5 if idx % 4 == 3 else S_LDC4
-        ins += ["s_add_u32 s%d, s%d, s%d" % (S_ROW, S_ROW, step), "s_addc_u32 s%d, s%d, 0" % (S_ROW + 1, S_ROW + 1)]
-    ins += ["v_mov_b32 v%d, 0" % r for r in range(ACC0, ACC0 + 64)]
-    ins += ["s_lshl_b32 s%d, s%d, 7" % (S_T0, S_LDC4), "s_add_u32 s%d, s%d, s%d" % (S_PC, S_PC, S_T0),
-            "s_addc_u32 s%d, s%d, 0" % (S_PC + 1, S_PC + 1)]
+        gs.append(["s_add_u32 s%d, s%d, s%d" % (S_ROW, S_ROW, step), "s_addc_u32 s%d, s%d, 0" % (S_ROW + 1, S_ROW + 1)])
+    return gs
+
+
+def stores_behind_last_load(ins):
+    last = max(n for n, x in enumerate(ins) if x.startswith("global_load"))
+    return sum(1 for x in ins[last:] if x.startswith("global_store"))
+
+
+def slot(mf, mem, fl=(), skip=0):
+    """Behind MFMA number n: mem[n] (an instruction or a group), then NF groups of fl (from MFMA `skip` on).  Returns the
+    instruction list and what is left of fl."""
+    out, fl = [], list(fl)
+    for n, x in enumerate(mf):
+        out.append(x)
+        if n < len(mem):
+            out += mem[n] if isinstance(mem[n], list) else [mem[n]]
+        if n >= skip:
+            for g in fl[:NF]:
+                out += g
+            fl = fl[NF:]
+    for m in mem[len(mf):]:
+        out += m if isinstance(m, list) else [m]
+    return out, fl
+
+
+def chunk(aset, cur, nxt, vmn=0, first=False, fl=()):
+    """One chunk into accumulator set aset.  vmn: stores the previous chunk issued behind the operand loads this one waits for.
+    Returns (instructions, flush groups left over, stores issued behind this chunk's last operand load)."""
+    ins = ["s_waitcnt vmcnt(%d) lgkmcnt(0)" % vmn]   # the stage (chunk g+1) landed; F0(g), read during the previous half, landed
+    ld, adv = gload()
+    body, fl = slot(mfmas(aset, 0, first), lstore(nxt) + ld + fread(1, cur) + adv, fl, skip=2 if first else 0)
+    ins += body
+    ins += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    body, fl = slot(mfmas(aset, 1), fread(0, nxt), fl)
+    ins += body
+    return ins, fl, stores_behind_last_load(ins)
+
+
+def flush_block(fs, relu):
+    """The last tile's flush, on its own."""
+    ins = ["s_nop 15", "s_nop 7", "s_mov_b64 s[%d:%d], s[%d:%d]" % (S_ROW, S_ROW + 1, S_PCP, S_PCP + 1)]   # 16-pass MFMA results -> VALU
+    for g in flush_groups(fs, relu):
+        ins += g
+    return ins
+
+
+def tile(aset, relu, L):
+    """One row tile into set aset while set 1 - aset (the previous tile) is flushed.  >= 4 chunks (K >= 128)."""
+    t = "t%d" % aset
+    ins = [L(t) + ":", "s_mov_b64 s[%d:%d], s[%d:%d]" % (S_ROW, S_ROW + 1, S_PCP, S_PCP + 1)]
+    fl = flush_groups(1 - aset, relu)
+    c, fl, s0 = chunk(aset, 0, 1, 0, True, fl)
+    ins += c
+    c, fl, s1 = chunk(aset, 1, 0, s0, False, fl)
+    ins += c
+    assert not fl and s0 <= 63 and s1 <= 63, (len(fl), s0, s1)
+    ins += chunk(aset, 0, 1, s1)[0] + chunk(aset, 1, 0)[0]
+    ins += ["s_sub_u32 s%d, s%d, 2" % (S_CNT, S_NK2), "s_cmp_eq_u32 s%d, 0" % S_CNT, "s_cbranch_scc1 " + L(t + "_end"), L(t + "_chunk") + ":"]
+    ins += chunk(aset, 0, 1)[0] + chunk(aset, 1, 0)[0]
+    ins += ["s_sub_u32 s%d, s%d, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 s%d, 0" % S_CNT, "s_cbranch_scc1 " + L(t + "_chunk"), L(t + "_end") + ":"]
+    # this tile becomes the one to flush; the output pointer moves one row tile down
+    ins += ["s_mov_b64 s[%d:%d], s[%d:%d]" % (S_PCP, S_PCP + 1, S_PC, S_PC + 1),
+            "s_lshl_b32 s%d, s%d, 7" % (S_T0, S_LDC4), "s_add_u32 s%d, s%d, s%d" % (S_PC, S_PC, S_T0), "s_addc_u32 s%d, s%d, 0" % (S_PC + 1, S_PC + 1),
+            "s_sub_u32 s%d, s%d, 1" % (S_NT, S_NT), "s_cmp_eq_u32 s%d, 0" % S_NT, "s_cbranch_scc1 " + L("last%d" % aset)]
     return ins
 
 
 def program(relu):
     L = lambda name: ".Lgs%d_%s_%%=" % (relu, name)
     ins = ["s_mov_b64 s[%d:%d], %%[pa]" % (S_PA, S_PA + 1), "s_mov_b64 s[%d:%d], %%[pb]" % (S_PB, S_PB + 1),
-           "s_mov_b64 s[%d:%d], %%[pc]" % (S_PC, S_PC + 1), "s_mov_b32 s%d, %%[tstep]" % S_TSTEP, "s_mov_b32 s%d, %%[kbytes]" % S_KB,
+           "s_mov_b64 s[%d:%d], %%[pc]" % (S_PC, S_PC + 1), "s_mov_b64 s[%d:%d], %%[pc]" % (S_PCP, S_PCP + 1),
+           "s_mov_b32 s%d, %%[tstep]" % S_TSTEP, "s_mov_b32 s%d, %%[kbytes]" % S_KB,
            "s_mov_b32 s%d, %%[ldc4]" % S_LDC4, "s_mul_i32 s%d, s%d, 5" % (S_LDC4X5, S_LDC4), "s_mov_b32 s%d, %%[ntile]" % S_NT,
            "s_mov_b32 s%d, %%[ntile]" % S_LT, "s_mov_b32 s%d, %%[nk2]" % S_NK2, "s_lshl_b32 s%d, s%d, 1" % (S_NKM1, S_NK2),
            "s_sub_u32 s%d, s%d, 1" % (S_NKM1, S_NKM1), "s_mov_b32 s%d, 0" % S_LK]
-    ins += ["v_mov_b32 v%d, 0" % r for r in range(ACC0, ACC0 + 64)]
+    # The first tile "flushes" set 1 to its own output tile (bias / relu(bias) rows, overwritten by its real flush later).
+    ins += ["v_mov_b32 v%d, 0" % r for r in range(ACC0 + 64, ACC0 + 128)]
     # prologue: chunk 0 -> LDS buffer 0, chunk 1 -> stage
     ld, adv = gload()
-    ins += ld + adv + ["s_waitcnt vmcnt(0)"] + lstore(0)
+    ins += ld + sum(adv, []) + ["s_waitcnt vmcnt(0)"] + lstore(0)
     ld, adv = gload()
-    ins += ld + adv + ["s_waitcnt lgkmcnt(0)", "s_barrier"] + fread(0, 0)
-    w, mem, adv = head(1)                          # head of the first tile's first chunk (later tiles: inside the epilogue)
-    ins += w + mem + adv
-    ins += [L("tile") + ":"]
-    ins += chunk(0, 1, with_head=False) + chunk(1, 0)
-    ins += ["s_sub_u32 s%d, s%d, 1" % (S_CNT, S_NK2), "s_cmp_eq_u32 s%d, 0" % S_CNT, "s_cbranch_scc1 " + L("flush"), L("chunk") + ":"]
-    ins += chunk(0, 1) + chunk(1, 0)
-    ins += ["s_sub_u32 s%d, s%d, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 s%d, 0" % S_CNT, "s_cbranch_scc1 " + L("chunk")]
-    ins += [L("flush") + ":"]
-    ins += epilogue(relu)
-    ins += ["s_sub_u32 s%d, s%d, 1" % (S_NT, S_NT), "s_cmp_lg_u32 s%d, 0" % S_NT, "s_cbranch_scc1 " + L("tile")]
-    ins += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]      # the tail prefetch (re-read of the last tile) and the stores are done
+    ins += ld + sum(adv, []) + ["s_waitcnt lgkmcnt(0)", "s_barrier"] + fread(0, 0)
+    ins += tile(0, relu, L) + tile(1, relu, L) + ["s_branch " + L("t0")]
+    ins += [L("last0") + ":"] + flush_block(0, relu) + ["s_branch " + L("done")]
+    ins += [L("last1") + ":"] + flush_block(1, relu)
+    ins += [L("done") + ":", "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]      # the tail prefetch (re-read of the last tile) and the stores are done
     return ins
 
 
@@ -213,7 +251,8 @@ def render_one(relu):
 
 def render():
     out = ["// GENERATED by tools/gen_gemm_stream.py -- do not edit; regenerate and commit (tests/test_isa_audit.py checks it is current).",
-           "// Body of gemm_nt_stream_kernel<RELU>: prologue + tile loop (chunk loop, flush) with hand-allocated registers.",
+           "// Body of gemm_nt_stream_kernel<RELU>: prologue + tile loop (two accumulator sets; the previous tile is flushed behind the",
+           "// MFMAs of the current one) with hand-allocated registers.",
            "    if constexpr (RELU) {", render_one(1).rstrip("\n"), "    } else {", render_one(0).rstrip("\n"), "    }"]
     return "\n".join(out) + "\n"
 
