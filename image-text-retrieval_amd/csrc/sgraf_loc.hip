@@ -16,6 +16,11 @@
 // LDS: A slice 2 x 8 KB + W_loc slice 2 x 32 KB = 80 KB -> two workgroups per CU.  Operand layout as in gemm_f32.hip:
 // 8 planes of float4 (plane p = k / 4), physical row = row ^ p (conflict-free ds_write_b128 / ds_read_b128); the stage-1
 // results are scattered with ds_write_b32 whose 32 lanes per cycle cover 32 distinct banks (4 planes x 8 rows).
+//
+// The D loop is one generated asm statement (sgraf_loc_asm.inc, tools/gen_sgraf_loc.py): slice k+1 is PRODUCED (stage-1
+// MFMAs, squared difference, LDS stores, refill of the register stage with slice k+2) behind the first half of slice k's
+// stage-2 MFMAs, one barrier mid-way, the next fragments are read behind the second half.  The C++ loop it replaces ran
+// stage 1 after stage 2 and then met a barrier: 127 -> 137 TFLOP/s (stage 1 + 2 flop, SGRAF 1k x 5k).
 #include "scan_common.h"
 
 namespace itr {
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
     const int64_t ncols = g.n_tiles * SC_NT;
     const int64_t row0 = ii * ncols + ct * SC_NT;
     const int D = g.D;
-    const int nk = D / LK;
+    const int nk = __builtin_amdgcn_readfirstlane(D / LK);
 
     // ---- stage-1 operands
     const int si = lane & 15, sg = lane >> 4;
@@ -74,131 +79,31 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
     const unsigned rowb = (unsigned)D * 4u;
     const unsigned voff_v = (unsigned)sg * rowb + si * 4u;            // V[4q + sg][d0 + si]      (q via the base, +16 columns via offset:64)
     const unsigned voff_z = 4u * sg * rowb + si * 4u;                 // E[4 sg + j][d0 + si]     (j via the base)
-    float vb[2][9], zz[2][4];
-#define LOC_LDG1(dst, base, voff, IMM) asm volatile("global_load_dword %0, %1, %2 offset:" #IMM : "=v"(dst) : "v"(voff), "s"(base) : "memory");
-#define LOC_LDG4(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
-#define LOC_LOAD_VZ(kc_)                                                                                        \
-    {                                                                                                           \
-        const char *vb_ = vbase + (int64_t)(kc_) * (LK * 4);                                                    \
-        const char *zb_ = zbase + (int64_t)(kc_) * (LK * 4);                                                    \
-        _Pragma("unroll") for (int q = 0; q < 9; ++q) {                                                         \
-            const char *b_ = vb_ + (int64_t)(4 * q) * rowb;                                                     \
-            LOC_LDG1(vb[0][q], b_, voff_v, 0) LOC_LDG1(vb[1][q], b_, voff_v, 64)                                \
-        }                                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-            const char *b_ = zb_ + (int64_t)j * rowb;                                                           \
-            LOC_LDG1(zz[0][j], b_, voff_z, 0) LOC_LDG1(zz[1][j], b_, voff_z, 64)                                \
-        }                                                                                                       \
-    }
-#define LOC_STAGE1(buf_)                                                                                        \
-    {                                                                                                           \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                      \
-            f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};                                                                \
-            _Pragma("unroll") for (int q = 0; q < 9; ++q)                                                       \
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[q], vb[nt][q], c, 0, 0, 0);                         \
-            const int k = nt * 16 + si, p = k >> 2;                                                             \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
-                const float v = c[j] - zz[nt][j];                                                               \
-                const int row = 16 * wave + 4 * sg + j;                                                         \
-                reinterpret_cast<float *>(&sm.a[buf_][p][row ^ p])[k & 3] = v * v;                              \
-            }                                                                                                   \
-        }                                                                                                       \
-    }
-
     // ---- stage-2 operands
     const int ld_row = tid >> 3, ld_p = tid & 7;
-    f32x4 rw[8];
     const unsigned voff_w = (unsigned)ld_row * rowb + ld_p * 16u;     // W[ld_row + 32 s][kc*32 + 4 ld_p ..]  (s via the base)
-#define LOC_GLOAD_W(kc_)                                                                                        \
-    {                                                                                                           \
-        const char *wb_ = wbase + (int64_t)(kc_) * (LK * 4);                                                    \
-        _Pragma("unroll") for (int s = 0; s < 8; ++s) { const char *b_ = wb_ + (int64_t)(32 * s) * rowb; LOC_LDG4(rw[s], b_, voff_w) } \
-    }
-// every asm load above has landed; the statements name the destination registers so that their consumers stay behind
-#define LOC_VMWAIT                                                                                              \
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rw[0]), "+v"(rw[1]), "+v"(rw[2]), "+v"(rw[3]), "+v"(rw[4]), "+v"(rw[5]), "+v"(rw[6]), "+v"(rw[7]), \
-                 "+v"(zz[0][0]), "+v"(zz[0][1]), "+v"(zz[0][2]), "+v"(zz[0][3]), "+v"(zz[1][0]), "+v"(zz[1][1]), "+v"(zz[1][2]), "+v"(zz[1][3])::"memory"); \
-    asm volatile("" : "+v"(vb[0][0]), "+v"(vb[0][1]), "+v"(vb[0][2]), "+v"(vb[0][3]), "+v"(vb[0][4]), "+v"(vb[0][5]), "+v"(vb[0][6]), "+v"(vb[0][7]), \
-                 "+v"(vb[0][8]), "+v"(vb[1][0]), "+v"(vb[1][1]), "+v"(vb[1][2]), "+v"(vb[1][3]), "+v"(vb[1][4]), "+v"(vb[1][5]), "+v"(vb[1][6]), \
-                 "+v"(vb[1][7]), "+v"(vb[1][8])::"memory");
-#define LOC_LSTORE_W(buf_)                                                                                      \
-    { _Pragma("unroll") for (int s = 0; s < 8; ++s) *reinterpret_cast<f32x4 *>(&sm.w[buf_][ld_p][(ld_row + 32 * s) ^ ld_p]) = rw[s]; }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    LOC_GLOAD_W(0)
-    LOC_LOAD_VZ(0)
-    LOC_VMWAIT
-    LOC_STAGE1(0)
-    LOC_LSTORE_W(0)
-    __syncthreads();
-
     const int fi = lane & 31, fg = lane >> 5;
-    // Branch-free K loop (one basic block per slice, so that the scheduler may overlap the phases): the tail iteration
-    // re-produces the last slice into the idle buffer.  Issue order requested from the scheduler: the global loads of
-    // the next slice go out first, one per stage-2 MFMA; then the fragment reads; the stage-1 MFMAs, the squared
-    // difference and the LDS stores of the next slice close the iteration.
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        const int kn = kc + 1 < nk ? kc + 1 : nk - 1;
-        LOC_GLOAD_W(kn)
-        LOC_LOAD_VZ(kn)
+    // ---- LDS byte addresses (buffer 0; the other buffer and the passes are immediates in the generated loop)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_raw;
+    unsigned ast[2][4];            // stage-1 result (row 16 wave + 4 sg + j, column k = 16 nt + si) in the A-operand layout
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int p = 2 * q + fg;
-            float4 a[2], b[2];
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = sm.a[buf][p][(i * 32 + fi) ^ p];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = sm.w[buf][p][(wave * 64 + j * 32 + fi) ^ p];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const int k = nt * 16 + si, p = k >> 2, row = 16 * wave + 4 * sg + j;
+            ast[nt][j] = lds0 + (unsigned)((p * LM + (row ^ p)) * 16 + (k & 3) * 4);
         }
-        LOC_VMWAIT
-        LOC_STAGE1(buf ^ 1)
-        LOC_LSTORE_W(buf ^ 1)
+    const unsigned wst = lds0 + (unsigned)sizeof(sm.a) + (unsigned)(ld_p * LN + (ld_row ^ ld_p)) * 16u;      // + 512 s
+    unsigned fa[4], fb[4];         // fragment reads: plane p = 2q + fg, physical row = row ^ p = base + (fi ^ p)
 #pragma unroll
-        for (int i_ = 0; i_ < 4; ++i_) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // first fragment reads
-#pragma unroll
-        for (int i_ = 0; i_ < 34; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 // VMEM read
-        }
-#pragma unroll
-        for (int i_ = 0; i_ < 12; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 // DS read
-        }
-        __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const int p = 2 * q + fg;
+        fa[q] = lds0 + (unsigned)(p * LM + (fi ^ p)) * 16u;                                                    // + 512 i
+        fb[q] = lds0 + (unsigned)sizeof(sm.a) + (unsigned)(p * LN + wave * 64 + (fi ^ p)) * 16u;               // + 512 j
     }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef LOC_LDG1
-#undef LOC_LDG4
-#undef LOC_VMWAIT
-#undef LOC_LOAD_VZ
-#undef LOC_STAGE1
-#undef LOC_GLOAD_W
-#undef LOC_LSTORE_W
+    f32x16 acc[2][2];
+    // The D loop: one generated asm statement (tools/gen_sgraf_loc.py has the schedule and the register map).
+#include "sgraf_loc_asm.inc"
 
     // ---- epilogue: + bias, l2norm over the 256 features of a row (utils.py:10-15, eps 1e-8), store
     // acc[i][j][r]: row = i*32 + (r & 3) + 8 (r >> 2) + 4 fg, column = wave*64 + j*32 + fi
