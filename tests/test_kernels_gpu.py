@@ -317,10 +317,11 @@ def test_sgraf_golden(golden, dev, mod):
 
 
 @pytest.mark.parametrize("mod", ['SAF', 'SGR'])
-@pytest.mark.parametrize("Ni,Nc,D,S", [(9, 23, 128, 64), (21, 70, 256, 256), (6, 9, 64, 32)])
+@pytest.mark.parametrize("Ni,Nc,D,S", [(9, 23, 128, 64), (21, 70, 256, 256), (6, 9, 64, 32), (5, 20, 96, 256), (4, 12, 32, 256)])
 def test_sgraf_random_vs_oracle(dev, mod, Ni, Nc, D, S):
     """more images than one image block, ragged captions; sim_dim 64 = unfused chain, 256 = fused local-node kernel
-    (sgraf_loc.hip) with 16-image blocks and more than one caption tile.  The (6, 9) case mixes in captions of 64 / 70 / 82
+    (sgraf_loc.hip) with 16-image blocks and more than one caption tile; D = 96 / 32 = an odd number of 32-wide slices / a
+    single one (the generated slice loop is unrolled by two and leaves mid-way).  The (6, 9) case mixes in captions of 64 / 70 / 82
     words (Flickr30k has such): they do not fit the 64-node tiles of the fused pair kernels and take the per-caption composition
     of the training path in evaluation mode (ops.sgraf_scores)."""
     rng = np.random.RandomState(5)
