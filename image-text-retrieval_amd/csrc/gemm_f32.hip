@@ -124,8 +124,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2
 //     issued through inline asm with our own s_waitcnt; rows past the edge re-read the last valid row (their outputs
 //     are never stored), the tail iterations re-load the last chunk and park data nobody reads;
 //   * chunk kc+1 (loaded one iteration earlier) is parked in the other LDS buffer and chunk kc+2 requested at the TOP of
-//     iteration kc, all slotted between the 64 MFMAs of chunk kc by sched_group_barrier; one barrier per chunk;
-//   * MFMAs are issued component-major so that consecutive instructions never touch the same accumulator.
+//     iteration kc, one memory instruction behind each of the 64 MFMAs of chunk kc; one barrier per chunk, mid-way;
+//   * MFMAs are issued component-major so that consecutive instructions never touch the same accumulator;
+//   * the K loop of a tile is ONE generated asm statement (gemm_tile_asm.inc; round 2 -- before, the interleave was a request
+//     to hipcc's scheduler through sched_group_barrier and the loads were separate asm statements with compiler-allocated
+//     destinations, see scan_mainloop.inc for why that is fragile); the accumulators come back in fixed registers.
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) {
     __shared__ float4 lds[2][2][NPLANE][BM];
     const int tid = threadIdx.x;
@@ -146,11 +149,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
     const int64_t t_begin = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_);
     const int64_t t_count = q_ + (xcd < r_ ? 1 : 0);
     const int ld_row = tid >> 3, ld_p = tid & 7;
-    const int nk = (int)(g.K / BK), klast = nk - 1;
-    char *const lbase = reinterpret_cast<char *>(&lds[0][0][0][0]);
-    constexpr unsigned OPER_BYTES = NPLANE * BM * 16u, BUF_BYTES = 2u * OPER_BYTES;
-    const unsigned ls0 = (unsigned)(ld_p * BM + (ld_row ^ ld_p)) * 16u;
+    const int nk = __builtin_amdgcn_readfirstlane((int)(g.K / BK));
+    constexpr unsigned OPER_BYTES = NPLANE * BM * 16u;
     const int fi = lane & 31, fg = lane >> 5;
+    // LDS byte addresses of the generated loop (buffer 1, operand B and the 32-row passes are immediates there)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)&lds[0][0][0][0];
+    const unsigned ls0 = lds0 + (unsigned)(ld_p * BM + (ld_row ^ ld_p)) * 16u;
+    auto faddr = [&](int q, int base, int oper) -> unsigned {      // plane p = 2q + fg, row (base + fi) ^ p == base + (fi ^ p)
+        const int p = 2 * q + fg;
+        return lds0 + (unsigned)oper * OPER_BYTES + (unsigned)(p * BM + base + (fi ^ p)) * 16u;
+    };
+    const unsigned fa0 = faddr(0, wm * 64, 0), fa1 = faddr(1, wm * 64, 0), fa2 = faddr(2, wm * 64, 0), fa3 = faddr(3, wm * 64, 0);
+    const unsigned fb0 = faddr(0, wn * 64, 1), fb1 = faddr(1, wn * 64, 1), fb2 = faddr(2, wn * 64, 1), fb3 = faddr(3, wn * 64, 1);
 
   for (int64_t tt = slot; tt < t_count; tt += nslots) {
     const int64_t bid = t_begin + tt;
@@ -159,13 +169,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
     const int64_t m_end = (m0 + BM < g.M) ? m0 + BM : g.M;
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const char *abase = reinterpret_cast<const char *>(g.A + m0 * g.lda);
     const char *bbase = reinterpret_cast<const char *>(g.B + n0 * g.ldb);
     unsigned oa0, oa1, oa2, oa3, ob0, ob1, ob2, ob3;    // per-lane byte offsets (host checked: 128 rows * ld * 4 < 2^32)
@@ -183,92 +186,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
         oa0 = offa(0); oa1 = offa(1); oa2 = offa(2); oa3 = offa(3);
         ob0 = offb(0); ob1 = offb(1); ob2 = offb(2); ob3 = offb(3);
     }
-    f32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define GF_LDG(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
-#define GF_GLOAD(KC)                                                                                \
-    {                                                                                               \
-        const char *ab_ = abase + (int64_t)(KC) * (BK * 4);                                         \
-        const char *bb_ = bbase + (int64_t)(KC) * (BK * 4);                                         \
-        GF_LDG(ra0, ab_, oa0) GF_LDG(rb0, bb_, ob0) GF_LDG(ra1, ab_, oa1) GF_LDG(rb1, bb_, ob1)     \
-        GF_LDG(ra2, ab_, oa2) GF_LDG(rb2, bb_, ob2) GF_LDG(ra3, ab_, oa3) GF_LDG(rb3, bb_, ob3)     \
-    }
-#define GF_VMWAIT0                                                                                  \
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(ra2), "+v"(ra3), "+v"(rb0), "+v"(rb1), "+v"(rb2), "+v"(rb3)::"memory");
-#define GF_STS(off, v) (*reinterpret_cast<f32x4 *>(lbase + (off)) = (v))
-#define GF_LSTORE(BUF)                                                                              \
-    {                                                                                               \
-        const unsigned b_ = (BUF) * BUF_BYTES + ls0;                                                \
-        GF_STS(b_, ra0); GF_STS(b_ + 32 * 16, ra1); GF_STS(b_ + 64 * 16, ra2); GF_STS(b_ + 96 * 16, ra3); \
-        GF_STS(b_ + OPER_BYTES, rb0); GF_STS(b_ + OPER_BYTES + 32 * 16, rb1);                       \
-        GF_STS(b_ + OPER_BYTES + 64 * 16, rb2); GF_STS(b_ + OPER_BYTES + 96 * 16, rb3);             \
-    }
-    GF_GLOAD(0)
-    GF_VMWAIT0
-    GF_LSTORE(0)
-    GF_GLOAD((1 < klast ? 1 : klast))
-    __syncthreads();
-
-    // Two fragment sets per slice (F0 = planes 0..3, F1 = planes 4..7) and the barrier MID-WAY, as in the SCAN main loop:
-    //   park slice kc+1, request slice kc+2, read F1(kc);  MFMA F0(kc);  barrier;  read F0(kc+1) from the other buffer;
-    //   MFMA F1(kc)  -- after the barrier the matrix core works on registers while the first fragments of the next
-    //   slice arrive, so no LDS round trip is exposed.
-    float4 f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];     // [q within the half][tile]
-#define GF_FREAD(FA, FB, Q0, BUF)                                                                   \
-    {                                                                                               \
-        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                          \
-            const int p_ = 2 * ((Q0) + q_) + fg;                                                    \
-            _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                      \
-                FA[q_][t_] = lds[BUF][0][p_][(wm * 64 + t_ * 32 + fi) ^ p_];                        \
-                FB[q_][t_] = lds[BUF][1][p_][(wn * 64 + t_ * 32 + fi) ^ p_];                        \
-            }                                                                                       \
-        }                                                                                           \
-    }
-#define GF_MFMA_C(FA, FB, C)                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                   \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].C, FB[j].C, acc[i][j], 0, 0, 0);
-#define GF_FMFMA(FA, FB)                                                                            \
-    {                                                                                               \
-        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                          \
-            GF_MFMA_C(FA[q_], FB[q_], x) GF_MFMA_C(FA[q_], FB[q_], y) GF_MFMA_C(FA[q_], FB[q_], z) GF_MFMA_C(FA[q_], FB[q_], w) \
-        }                                                                                           \
-    }
-#define GF_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
-    GF_FREAD(f0a, f0b, 0, 0)
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        GF_VMWAIT0
-        GF_LSTORE(buf ^ 1)
-        GF_GLOAD((kc + 2 < klast ? kc + 2 : klast))
-        GF_FREAD(f1a, f1b, 2, buf)
-        GF_FMFMA(f0a, f0b)
-        // first half: 32 MFMAs against 8 ds_write_b128 + 8 global loads + 8 ds_read_b128
-#pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) { GF_SGB(0x008, 1) GF_SGB(0x200, 1) GF_SGB(0x008, 1) GF_SGB(0x020, 1) }
-#pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) { GF_SGB(0x008, 1) GF_SGB(0x100, 1) }
-        GF_SGB(0x008, 8)
-        __syncthreads();
-        GF_FREAD(f0a, f0b, 0, buf ^ 1)
-        GF_FMFMA(f1a, f1b)
-#pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) { GF_SGB(0x008, 2) GF_SGB(0x100, 1) }
-        GF_SGB(0x008, 16)
-    }
-    __syncthreads();      // every wave is done with LDS before the next tile's prologue overwrites it
-#undef GF_FREAD
-#undef GF_MFMA_C
-#undef GF_FMFMA
-#undef GF_SGB
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the unused tail prefetch
+    // The K loop of this tile: one generated asm statement (gemm_tile_asm.inc, tools/gen_gemm_tile.py) -- chunk kc+1 is parked
+    // in the other LDS buffer and chunk kc+2 requested behind the MFMAs of chunk kc's first fragment set, one barrier mid-way,
+    // the next fragments are read behind the second set; it ends with nothing in flight and a barrier.
+#include "gemm_tile_asm.inc"
     // (the loop ended on a barrier: nobody reads LDS any more, the next tile's prologue may overwrite it)
     gemm_epilogue(g, acc, &lds[0][0][0][0], tid, lane, wm, wn, m0, n0, m_end);
   }
-#undef GF_LDG
-#undef GF_GLOAD
-#undef GF_VMWAIT0
-#undef GF_STS
-#undef GF_LSTORE
 }
 
 template <bool ALIGNED>

@@ -61,7 +61,7 @@ def test_audit_detects_a_touched_register():
     assert any("in flight at s_endpgm" in r for r in rep)
 
 
-@pytest.mark.parametrize("gen", ["gen_scan_mainloop.py", "gen_gemm_stream.py", "gen_sgraf_loc.py"])
+@pytest.mark.parametrize("gen", ["gen_scan_mainloop.py", "gen_gemm_stream.py", "gen_sgraf_loc.py", "gen_gemm_tile.py"])
 def test_generated_asm_bodies_are_current(gen):
     """csrc/scan_mainloop_asm.inc, gemm_stream_asm.inc and sgraf_loc_asm.inc are generated; the committed files must be what the generators emit."""
     import subprocess
