@@ -311,22 +311,32 @@ __device__ __forceinline__ void sgr_pair_body(const PairArgs &p, const float *qg
     }
 }
 
+// NTMAX = the largest node-tile count this launch handles.  The kernel carries the registers of its largest body -- 232 VGPRs,
+// two waves per SIMD, for 64-node graphs -- and a graph of <= 16 / <= 32 nodes (captions of up to 15 / 31 words: all but a
+// handful of any test split) needs 36 / 76, i.e. three to four times the waves in flight for a kernel that waits on memory.
+// A caption set whose longest caption needs more than two tiles is served by TWO launches over the same pair grid: <2> takes
+// the pairs of 1..2 tiles, <4> (nt_lo = 3) the rest; a wave whose pair belongs to the other launch leaves at once.
+template <int NTMAX>
 __global__ __launch_bounds__(256) void sgr_pair_kernel(PairArgs p, const float *__restrict__ qglo, const float *__restrict__ qloc,
                                                        const float *__restrict__ kglo, const float *__restrict__ kloc,
                                                        float *__restrict__ yglo, float *__restrict__ yloc, int64_t npairs,
-                                                       int maxnodes, int glo_only) {
+                                                       int nt_lo, int glo_only) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pair >= npairs) return;
     const int64_t ii = pair / p.Nc, c = pair % p.Nc;
     const int nn = p.cap_len[c] + 1, col0 = p.cap_col[c];
-    const int ntmax = (maxnodes + 15) / 16;
-    float *pl = sm + (size_t)(threadIdx.x >> 6) * (ntmax * 16) * (ntmax * 16 + 4);
+    float *pl = sm + (size_t)(threadIdx.x >> 6) * (NTMAX * 16) * (NTMAX * 16 + 4);
     const int NT = (nn + 15) / 16;
+    if (NT < nt_lo || NT > NTMAX) return;               // this pair belongs to the other launch (mixed-length caption sets)
     if (NT == 1) sgr_pair_body<1>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
-    else if (NT == 2) sgr_pair_body<2>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
-    else if (NT == 3) sgr_pair_body<3>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
-    else sgr_pair_body<4>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
+    else if constexpr (NTMAX >= 2) {
+        if (NT == 2) sgr_pair_body<2>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
+        else if constexpr (NTMAX >= 3) {
+            if (NT == 3) sgr_pair_body<3>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
+            else sgr_pair_body<4>(p, qglo, qloc, kglo, kloc, yglo, yloc, ii, c, col0, nn, glo_only, pl);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void sgr_final_kernel(const float *__restrict__ xglo, int64_t Nc, int S_, const float *__restrict__ eval_w,
@@ -497,14 +507,22 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
             ITR_CHECK_LAUNCH("sgraf saf_pair");
         } else {
             const int ntmax = (max_len + 1 + 15) / 16;
-            const size_t lds = (size_t)4 * (ntmax * 16) * (ntmax * 16 + 4) * 4;   // 4 waves x P[NT*16][NT*16+4]
             ITR_UNSUPPORTED(S % 16 != 0, "itr_sgraf_scores: SGR needs sim_dim %% 16 == 0");
             for (int k = 0; k < sgr_step; ++k) {
                 const int last = (k == sgr_step - 1);
                 SG_TRY(gemm_nt(Xloc, S, Wfold[k], S, vfold[k], Qloc, S, nb * ncols, S, S, 0, st));
                 SG_TRY(gemm_nt(Xglo, S, Wfold[k], S, vfold[k], Qglo, S, nb * Nc, S, S, 0, st));
-                hipLaunchKernelGGL(sgr_pair_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), lds, st, pa, Qglo, Qloc, Xglo, Xloc,
-                                   Yglo, Yloc, npairs, max_len + 1, last);
+                const dim3 pgrid((unsigned)ceil_div(npairs, 4));
+                auto plds = [](int nt) { return (size_t)4 * (nt * 16) * (nt * 16 + 4) * 4; };   // 4 waves x P[NT*16][NT*16+4]
+                if (ntmax == 1) {
+                    hipLaunchKernelGGL(sgr_pair_kernel<1>, pgrid, dim3(256), plds(1), st, pa, Qglo, Qloc, Xglo, Xloc, Yglo, Yloc, npairs, 1, last);
+                } else {
+                    hipLaunchKernelGGL(sgr_pair_kernel<2>, pgrid, dim3(256), plds(2), st, pa, Qglo, Qloc, Xglo, Xloc, Yglo, Yloc, npairs, 1, last);
+                    if (ntmax > 2) {
+                        ITR_CHECK_LAUNCH("sgraf sgr_pair");
+                        hipLaunchKernelGGL(sgr_pair_kernel<4>, pgrid, dim3(256), plds(4), st, pa, Qglo, Qloc, Xglo, Xloc, Yglo, Yloc, npairs, 3, last);
+                    }
+                }
                 ITR_CHECK_LAUNCH("sgraf sgr_pair");
                 // NOTE: a word node is shared by all captions... it is NOT: node rows are per (image, word) and a word
                 // belongs to one caption, so writing Yloc rows per pair is race-free.
