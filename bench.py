@@ -574,10 +574,13 @@ def main():
             W_ = lengths.astype(np.float64)
             per_img = (4 * 36 * W_ * D + 2 * W_ * D * s_ + 2 * D * s_ + T_ * (6 * (W_ + 1) * s_ ** 2 + 4 * (W_ + 1) ** 2 * s_) + 2 * s_).sum()
             alg_flop = float(i1 - i0) * per_img
-            exe_flop = alg_flop
+            # executed: the key projection of every graph step is folded into the query weight (softmax_j(q_i.k_j) =
+            # softmax_j((W_k^T q_i).x_j)), so two of K8's three s x s projections per node and step are run
+            exe_flop = alg_flop - float(i1 - i0) * (T_ * 2 * (W_ + 1) * s_ ** 2).sum()
             model_name = "SGRAF-%s bi-GRU" % wl["sgraf"]
-            kernel_name = "sgraf pair stage (scan_xattn_kernel emit + gemm_nt chain + pair kernels)"
-            note = "time = the whole itr_sgraf_scores call (global nodes + per-4-image pair stage); flop = SURVEY 8d K8"
+            kernel_name = "sgraf pair stage (scan_xattn_kernel emit + sgraf_loc_kernel + gemm_nt chain + pair kernels)"
+            note = ("time = the whole itr_sgraf_scores call (global nodes + per-16-image pair stage); algorithmic_* = SURVEY 8d K8; "
+                    "achieved/frac = the flop executed: K8 minus the folded key projection of the SGR steps (nothing is folded for SAF)")
         dtype, peak = "f32", FP32_MFMA_PEAK_TFLOPS
         if wl.get("scan_precision") in ("bf16x3", "fp16x3"):
             half = "bf16" if wl["scan_precision"] == "bf16x3" else "fp16"

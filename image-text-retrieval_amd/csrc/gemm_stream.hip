@@ -98,8 +98,10 @@ bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, co
     if ((uint64_t)lda * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldb * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldc * 4u * GS_BM >= (1ull << 31)) return false;
     const int64_t tiles_m = M / GS_BM, tiles_n = N / GS_BM;      // whole row tiles; a remainder of rows goes to the tile kernel
     const int64_t resident = 2 * (int64_t)cus;
-    static const int64_t min_rounds = getenv("ITR_GEMM_STREAM_MINROUNDS") ? atoll(getenv("ITR_GEMM_STREAM_MINROUNDS")) : 4;
-    if (tiles_m * tiles_n < min_rounds * resident) return false;  // streaming pays when every workgroup gets several tiles
+    static const int64_t min_rounds = getenv("ITR_GEMM_STREAM_MINROUNDS") ? atoll(getenv("ITR_GEMM_STREAM_MINROUNDS")) : 2;
+    // streaming pays when every workgroup gets at least two tiles (measured: 16 384 x 1 024 x 1 024 = 2 rounds 130 -> 142 TFLOP/s,
+    // 12 800 x 2 304 x 768 = 3.5 rounds 114 -> 132; at one round 5 000 x 3 072 x 1 024 loses 104 -> 96)
+    if (tiles_m * tiles_n < min_rounds * resident) return false;
     int64_t grid = resident / tiles_n * tiles_n;
     if (grid < tiles_n) grid = tiles_n;
     static const bool xcd_off = getenv("ITR_GEMM_STREAM_XCD") && atoi(getenv("ITR_GEMM_STREAM_XCD")) == 0;
