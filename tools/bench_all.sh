@@ -10,7 +10,7 @@ for w in scan_i2t_coco5k vsepp_f30k1k vsrn_coco5k saem_coco5k camera_coco5k sgra
   timeout 900 python3 bench.py --workload $w --steps 3 --warmup 1 --no-variants > $OUT/$w.json 2> $OUT/$w.err
 done
 python3 tools/make_synth_precomp.py /tmp/itr_synth --n-img 5000 > /dev/null && timeout 600 python3 bench.py --from-files /tmp/itr_synth --steps 3 --warmup 1 > $OUT/scan_t2i_coco5k_from_files.json 2> $OUT/from_files.err
-for w in camera_coco5k saem_coco5k vsepp_f30k1k; do
+for w in camera_coco5k saem_coco5k vsepp_f30k1k sgraf_saf_f30k1k sgraf_sgr_f30k1k vsrn_coco5k; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o t -- python3 bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   find $OUT/prof_$w -name "*.db" -delete; find $OUT/prof_$w -name "*kernel_trace.csv" -delete
 done
