@@ -50,25 +50,44 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 //   r = s(gi_r + gh_r); z = s(gi_z + gh_z); n = tanh(gi_n + r * gh_n); h' = (1 - z) * n + z * h
 // mode 0: out[row] = h'            (forward direction, or uni-directional)
 // mode 1: out[row] = (out[row] + h') / 2   (reverse direction of a bi-GRU, TextEncoder.py:54-55)
+// VEC = 4: one thread per four consecutive hidden units, 16-byte accesses (D % 4 == 0); VEC = 1: any D.
+template <int VEC>
 __global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__ gi, const float *__restrict__ gh,
                                                        float *__restrict__ h, float *__restrict__ out,
                                                        const int64_t *__restrict__ tok_off,
                                                        const int32_t *__restrict__ len, int t, int reverse,
                                                        int mode, int D, int64_t n_act) {
     const int64_t b = blockIdx.x;
-    const int j = blockIdx.y * blockDim.x + threadIdx.x;
+    const int j = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
     if (b >= n_act || j >= D) return;
     const int64_t row = tok_off[b] + (reverse ? (len[b] - 1 - t) : t);
-    const float *gir = gi + row * 3 * D;
-    const float *ghr = gh + b * 3 * D;
-    const float r = sigmoidf_(gir[j] + ghr[j]);
-    const float z = sigmoidf_(gir[D + j] + ghr[D + j]);
-    const float n = tanhf(gir[2 * D + j] + r * ghr[2 * D + j]);
-    const float hp = h[b * D + j];
-    const float hn = (1.f - z) * n + z * hp;
-    h[b * D + j] = hn;
-    float *o = out + row * D + j;
-    *o = mode ? (*o + hn) / 2.f : hn;
+    const float *gir = gi + row * 3 * D + j;
+    const float *ghr = gh + b * 3 * D + j;
+    float ir[VEC], iz[VEC], in[VEC], hr[VEC], hz[VEC], hn_[VEC], hp[VEC], ov[VEC];
+    float *hrow = h + b * D + j, *o = out + row * D + j;
+    auto ld = [](float (&d)[VEC], const float *p) {
+        if constexpr (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(p); d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+        else d[0] = p[0];
+    };
+    auto st = [](float *p, const float (&d)[VEC]) {
+        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(p) = float4{d[0], d[1], d[2], d[3]};
+        else p[0] = d[0];
+    };
+    ld(ir, gir); ld(iz, gir + D); ld(in, gir + 2 * D);
+    ld(hr, ghr); ld(hz, ghr + D); ld(hn_, ghr + 2 * D);
+    ld(hp, hrow);
+    if (mode) ld(ov, o);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const float r = sigmoidf_(ir[k] + hr[k]);
+        const float z = sigmoidf_(iz[k] + hz[k]);
+        const float n = tanhf(in[k] + r * hn_[k]);
+        const float hn = (1.f - z) * n + z * hp[k];
+        hp[k] = hn;
+        ov[k] = mode ? (ov[k] + hn) / 2.f : hn;
+    }
+    st(hrow, hp);
+    st(o, ov);
 }
 
 __global__ void gather_last_kernel(const float *__restrict__ out, const int64_t *__restrict__ tok_off,
@@ -230,9 +249,12 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             rc = (splits_h > 1) ? gemm_nt_splitk(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, ww.skbuf, sd)
                                 : gemm_nt(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, sd);
             if (rc != ITR_OK) return rc;
-            dim3 grid((unsigned)n_act, (unsigned)ceil_div(D, 256));
-            hipLaunchKernelGGL(gru_gate_kernel, grid, dim3(256), 0, sd, ww.gi, ww.gh, ww.h, dst, tok_off, len_dev, t, dir,
-                               0, D, n_act);
+            if (D % 4 == 0)
+                hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
+                                   dst, tok_off, len_dev, t, dir, 0, D, n_act);
+            else
+                hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
+                                   dst, tok_off, len_dev, t, dir, 0, D, n_act);
             ITR_CHECK_LAUNCH("gru_gate");
         }
     }
