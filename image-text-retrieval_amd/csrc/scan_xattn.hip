@@ -417,27 +417,41 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
         if (g.dbg_cycles && tid == 0) atomicAdd(&g.dbg_cycles[7], __builtin_amdgcn_s_memrealtime() - real0_);
     } else {
         // ================= i2t: regions attend over the words of every caption ============
-        // E1: first normalisation runs along the 36 regions (query axis), per (image, word)
-        {
-            const int ii = wave, w = lane;
-            if (norm != 3 && norm != 4) {
-                NormAcc na;
-                na.init(norm);
-#pragma unroll 4
-                for (int r = 0; r < SC_R; ++r) na.pass1(AT(ii * SC_R + r, w), norm);
-                if (norm == 2)
-                    for (int r = 0; r < SC_R; ++r) na.pass2(AT(ii * SC_R + r, w), norm);
-                na.finish(norm);
-                sm.colstat[ii][w][0] = na.s0;
-                sm.colstat[ii][w][1] = na.s1;
-            }
-        }
-        __syncthreads();
         float *hbuf = reinterpret_cast<float *>(smem_raw + sizeof(sm.arawt));     // 19 KB of the staging area behind the parked block
         static_assert(sizeof(sm.arawt) + SC_NT * SC_NT * 4 <= sizeof(sm.stage), "caption Gram fits behind the parked block");
         const float *rsim = &sm.rsim2[0][0];
         // Matrix-core path: every first norm that bounds |b| <= 1 (no max shift needed for exp(ls b), ls <= 60).
         const bool mfma_path = (norm == 0 || norm == 1 || norm == 2 || norm == 5 || norm == 6) && fabsf(ls) <= 60.f;
+        // E1: first normalisation runs along the 36 regions (query axis), per (image, word): lane = word, its 36 raw scores are
+        // nine 16-byte reads of the parked column (conflict-free: the 592-byte column pitch puts 16 lanes on 64 distinct banks)
+        {
+            const int ii = wave, w = lane;
+            if (norm != 3 && norm != 4) {
+                f32x4 col[SC_R / 4];
+#pragma unroll
+                for (int q = 0; q < SC_R / 4; ++q) col[q] = *reinterpret_cast<const f32x4 *>(&AT(ii * SC_R + 4 * q, w));
+                dispatch_norm(norm, [&](auto NC) {
+                    constexpr int NORM = decltype(NC)::value;
+                    NormAcc na;
+                    na.init(NORM);
+#pragma unroll
+                    for (int q = 0; q < SC_R / 4; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) na.pass1(col[q][c], NORM);
+                    if (NORM == 2) {
+#pragma unroll
+                        for (int q = 0; q < SC_R / 4; ++q)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) na.pass2(col[q][c], NORM);
+                    }
+                    na.finish(NORM);
+                    sm.colstat[ii][w][0] = na.s0;
+                    sm.colstat[ii][w][1] = na.s1;
+                });
+            }
+        }
+        __syncthreads();
+        SC_TICK(2)   // E1 (i2t): per (image, word) statistics over the regions
         if (mfma_path) {
             // P0: block-diagonal Gram of the tile's captions, Hblk[v][w] = e_v . e_w for v, w in the same caption
             for (int idx = tid; idx < SC_NT * SC_NT; idx += SC_THREADS) hbuf[idx] = 0.f;
@@ -478,7 +492,10 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                 }
             });
             __syncthreads();
+            SC_TICK(5)   // P0 + P1: block-diagonal Gram into LDS, weights, den / num
             // P3: T = E Hblk (64 MFMAs per row tile), then E o T in place: arawt[w][row] <- e[row][w] * T[row][w]
+            // (skipping the k-steps whose Hblk rows are all zero for a column tile -- about half of them -- was tried with
+            // wave-uniform branches around the MFMAs: 42.4 -> 44.1 ms, the branches cost more than the MFMAs they skip)
             {
                 float hf[4][16];     // B fragments of Hblk, shared by every row tile of this wave
 #pragma unroll
@@ -506,6 +523,7 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                 }
             }
             __syncthreads();
+            SC_TICK(6)   // P3: T = E Hblk, E o T
             // P4: q[row][k] = sum_{w in k} (E o T) (indicator product), then the cosine term of every (region row, caption)
             float *rs_out = hbuf;       // Hblk is dead: [144][16] similarity terms for the aggregation below
             for (int mt = wave; mt < SC_MTILES; mt += 4) {
@@ -573,27 +591,38 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                 __syncthreads();   // hbuf is reloaded for the next caption
             }
         }
-        // E3: aggregate over the 36 regions
-        if (tid < SC_IMGS * SC_MAXCAP) {
-            const int ii = tid / SC_MAXCAP, k = tid % SC_MAXCAP;
+        // E3: aggregate over the 36 regions.  Wave ii = image ii; lane = (caption slot k = lane & 15, quarter of the regions
+        // lane >> 4): nine terms per lane, two xor-shuffles fold the quarters (round 1: one lane per (image, caption) walked all 36).
+        {
+            const int ii = wave, k = lane & 15, part = lane >> 4;
             const int64_t img = img0 + ii;
-            if (k < ncap && img < g.Ni) {
-                float r;
-                if (g.agg == 0) {
-                    r = 0.f;
-                    for (int t = 0; t < SC_R; ++t) r += fast_exp(rsim[(ii * SC_R + t) * SC_MAXCAP + k] * g.lambda_lse);
-                    r = fast_log(r) / g.lambda_lse;
-                } else if (g.agg == 1) {
-                    r = -INFINITY;
-                    for (int t = 0; t < SC_R; ++t) r = fmaxf(r, rsim[(ii * SC_R + t) * SC_MAXCAP + k]);
-                } else {
-                    r = 0.f;
-                    for (int t = 0; t < SC_R; ++t) r += rsim[(ii * SC_R + t) * SC_MAXCAP + k];
-                    if (g.agg == 3) r /= (float)SC_R;
-                }
-                g.S[img * g.ldS + sm.meta.cap_id[k]] = r;
+            float r;
+            if (g.agg == 0) {
+                r = 0.f;
+#pragma unroll
+                for (int t = 0; t < SC_R / 4; ++t) r += fast_exp(rsim[(ii * SC_R + part * (SC_R / 4) + t) * SC_MAXCAP + k] * g.lambda_lse);
+            } else if (g.agg == 1) {
+                r = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < SC_R / 4; ++t) r = fmaxf(r, rsim[(ii * SC_R + part * (SC_R / 4) + t) * SC_MAXCAP + k]);
+            } else {
+                r = 0.f;
+#pragma unroll
+                for (int t = 0; t < SC_R / 4; ++t) r += rsim[(ii * SC_R + part * (SC_R / 4) + t) * SC_MAXCAP + k];
             }
+            if (g.agg == 1) {
+                r = fmaxf(r, __shfl_xor(r, 16, 64));
+                r = fmaxf(r, __shfl_xor(r, 32, 64));
+            } else {
+                r += __shfl_xor(r, 16, 64);
+                r += __shfl_xor(r, 32, 64);
+            }
+            if (g.agg == 0) r = fast_log(r) / g.lambda_lse;
+            else if (g.agg == 3) r /= (float)SC_R;
+            if (part == 0 && k < ncap && img < g.Ni) g.S[img * g.ldS + sm.meta.cap_id[k]] = r;
         }
+        SC_TICK(3)   // P4 + E3
+        if (g.dbg_cycles && tid == 0) atomicAdd(&g.dbg_cycles[7], __builtin_amdgcn_s_memrealtime() - real0_);
     }
   }   // tile loop
 }
