@@ -395,21 +395,25 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
             }
             // E3: aggregate over the words of each caption (Objectives.py:355-366), still inside the wave: every lane turns
             // its word's term into the summand (one exp per lane for LogSumExp), lanes 0..15 then fold their caption's words
-            if (img < g.Ni) {
-                sm.rowsim[ii][w] = (g.agg == 0) ? fast_exp(simv * g.lambda_lse) : simv;
-                if (lane < ncap) {
-                    const int c0 = sm.meta.cap_start[lane], c1 = sm.meta.cap_start[lane + 1];
-                    float r;
-                    if (g.agg == 1) {
-                        r = -INFINITY;
-                        for (int c = c0; c < c1; ++c) r = fmaxf(r, sm.rowsim[ii][c]);
-                    } else {
-                        r = 0.f;
-                        for (int c = c0; c < c1; ++c) r += sm.rowsim[ii][c];
-                        if (g.agg == 0) r = fast_log(r) / g.lambda_lse;
-                        else if (g.agg == 3) r /= (float)(c1 - c0);
-                    }
-                    g.S[img * g.ldS + sm.meta.cap_id[lane]] = r;
+            // (segmented inclusive scan over the 64 lanes: six shuffle steps; lane w adds the value of lane w - off while that lane is
+            // still inside w's caption; the caption's last lane then holds its total.  Round 2 first had lanes 0..15 walk their
+            // caption's columns in LDS -- up to 20 dependent round trips.)
+            {
+                const int kcap = sm.meta.col_cap[w];                                     // -1: padding column
+                const int cbeg = kcap >= 0 ? sm.meta.cap_start[kcap] : w;
+                const int cend = kcap >= 0 ? sm.meta.cap_start[kcap + 1] : w + 1;
+                float r = (g.agg == 0) ? fast_exp(simv * g.lambda_lse) : simv;
+#pragma unroll
+                for (int off = 1; off < SC_NT; off <<= 1) {
+                    const float o = __shfl_up(r, off, 64);
+                    const bool in = (w - off) >= cbeg;
+                    if (g.agg == 1) r = in ? fmaxf(r, o) : r;
+                    else r = in ? r + o : r;
+                }
+                if (img < g.Ni && kcap >= 0 && w == cend - 1) {
+                    if (g.agg == 0) r = fast_log(r) / g.lambda_lse;
+                    else if (g.agg == 3) r /= (float)(cend - cbeg);
+                    g.S[img * g.ldS + sm.meta.cap_id[kcap]] = r;
                 }
             }
         }
