@@ -25,7 +25,15 @@ struct alignas(16) ScanTileMeta {
 };
 static_assert(sizeof(ScanTileMeta) == 256, "one 256-byte record per tile");
 
-__device__ __forceinline__ float leaky(float v) { return fmaxf(v, 0.1f * v); }   // LeakyReLU(0.1)
+// LeakyReLU(0.1) = max(v, 0.1 v).  The maximum is ONE v_max_f32: fmaxf() makes hipcc canonicalise its operands first (an extra
+// v_max_f32 v, v per element, for signalling NaNs), and in the epilogues every vector instruction waits for an issue slot next
+// to the co-resident workgroup's MFMA stream.
+__device__ __forceinline__ float leaky(float v) {
+    float r;
+    const float t = 0.1f * v;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
+    return r;
+}
 // exp via v_exp_f32 (2^x): 2 VALU instructions instead of ~12; relative error ~|x| * 1e-7, far inside the
 // parity budget for the softmax / LogSumExp arguments here (|x| <= ~10).
 __device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
