@@ -449,6 +449,9 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                             for (int c = 0; c < 4; ++c) na.pass2(col[q][c], NORM);
                     }
                     na.finish(NORM);
+                    // matrix-core path: the reciprocal norm is stored multiplied by lambda_softmax * log2(e), the weight is then ONE
+                    // v_exp_f32 of f(a) * stat (as in the t2i epilogue)
+                    if (mfma_path && NORM != 2) na.s0 *= ls * 1.44269504088896341f;
                     sm.colstat[ii][w][0] = na.s0;
                     sm.colstat[ii][w][1] = na.s1;
                 });
@@ -486,7 +489,8 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                         for (int j = 0; j < 4; ++j) {
                             const int w = 16 * u + 4 * fg + j;
                             const float av = AT(row, w);
-                            const float e = fast_exp(norm_apply_c<NORM>(av, sm.colstat[ii][w][0], sm.colstat[ii][w][1]) * ls);
+                            const float bq = norm_apply_c<NORM>(av, sm.colstat[ii][w][0], sm.colstat[ii][w][1]);
+                            const float e = (NORM == 2) ? fast_exp(bq * ls) : __builtin_amdgcn_exp2f(bq);
                             AT(row, w) = e;
                             sden = __builtin_amdgcn_mfma_f32_16x16x4f32(e, ind[4 * u + j], sden, 0, 0, 0);
                             snum = __builtin_amdgcn_mfma_f32_16x16x4f32(e * av, ind[4 * u + j], snum, 0, 0, 0);
