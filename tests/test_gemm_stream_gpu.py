@@ -16,7 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("M,N,K,act,bias", [(128 * 2048 + 37, 256, 256, None, True), (128 * 2100, 256, 256, 'relu', True),
                                             (128 * 4200, 128, 64, None, False), (128 * 1030, 384, 128, 'relu', True),
-                                            (128 * 2500, 256, 512, None, True), (128 * 2048, 256, 256, 'relu', False)])
+                                            (128 * 2500, 256, 512, None, True), (128 * 2048, 256, 256, 'relu', False),
+                                            # eight column tiles (XCD-aware map), K = 128 (the shortest tile the kernel takes);
+                                            # two or three row tiles per workgroup, K = 192 (one trip through the generic chunk loop)
+                                            (128 * 600, 1024, 128, 'relu', True), (128 * 520 + 5, 256, 192, None, True)])
 def test_stream_gemm_vs_float64(dev, M, N, K, act, bias):
     torch.manual_seed(M % 1000 + K)
     a = torch.randn(M, K, device=dev)

@@ -46,7 +46,7 @@ def test_l2norm_shapes(dev, dim):
 
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(1, 1, 4), (128, 128, 32), (130, 257, 300), (1000, 96, 2048), (4, 3072, 1024),
-                                   (333, 12, 6), (257, 129, 37)])
+                                   (333, 12, 6), (257, 129, 37), (300, 200, 96), (257, 384, 160)])   # 96 / 160: odd chunk counts of the generated tile loop
 def test_gemm_vs_fp64(dev, M, N, K):
     torch.manual_seed(M * 7 + N)
     a, b, bias = torch.randn(M, K), torch.randn(N, K), torch.randn(N)
