@@ -159,6 +159,45 @@ __global__ __launch_bounds__(256) void saf_pair_kernel(PairArgs p, const float *
     const int nn = p.cap_len[c] + 1, col0 = p.cap_col[c];
     const float bscale = bn_w[0] / sqrtf(bn_var[0] + BN_EPS);
     float asum = 0.f;
+    if (p.S == 256) {
+        // The configured sim_dim: one 16-byte load per lane and node row (lane l holds features 4l .. 4l+3), four node rows in
+        // flight per trip -- the kernel is a chain of (load, wave reduction, sigmoid) per node and waits on memory otherwise.
+        const float4 wv = *reinterpret_cast<const float4 *>(saf_w + 4 * lane);
+        const float sb = saf_b[0], bm = bn_mean[0], bb = bn_b[0];
+        float4 acc = float4{0.f, 0.f, 0.f, 0.f};
+        for (int n0 = 0; n0 < nn; n0 += 4) {
+            float4 xr[4];
+            float sr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n = n0 + k < nn ? n0 + k : nn - 1;            // the tail re-reads the last node; masked below
+                xr[k] = *reinterpret_cast<const float4 *>(node_row(p, p.xglo, p.xloc, ii, c, col0, n) + 4 * lane);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sr[k] = xr[k].x * wv.x + xr[k].y * wv.y + xr[k].z * wv.z + xr[k].w * wv.w;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sr[k] += __shfl_xor(sr[k], o, 64);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = 1.f / (1.f + expf(-(((sr[k] + sb) - bm) * bscale + bb)));
+                a = n0 + k < nn ? a : 0.f;
+                asum += fabsf(a);
+                acc.x += a * xr[k].x; acc.y += a * xr[k].y; acc.z += a * xr[k].z; acc.w += a * xr[k].w;
+            }
+        }
+        const float inv = 1.f / (asum + 1e-8f);   // l1norm
+        acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+        const float4 ev = *reinterpret_cast<const float4 *>(eval_w + 4 * lane);
+        float ss = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+        float dot = acc.x * ev.x + acc.y * ev.y + acc.z * ev.z + acc.w * ev.w;
+        ss = wave_sum(ss);
+        dot = wave_sum(dot);
+        const float score = dot / (sqrtf(ss) + 1e-8f) + eval_b[0];     // eval_w . l2norm(vec) + b
+        if (lane == 0) S[(img_index0 + ii) * ldS + c] = 1.f / (1.f + expf(-score));
+        return;
+    }
     // ONE pass over the node rows (they are the HBM traffic of this kernel): the l1 normalisation of the attention
     // weights is linear, so the un-normalised aggregate sum_n a_n x_n is divided by sum_n |a_n| at the end.
     // This lane's columns: d = lane, lane + 64, ... (S <= 1024)
