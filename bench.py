@@ -205,7 +205,8 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
     n_img, n_cap = wl["n_img"], 5 * wl["n_img"]
     comm = evalpipe.Comm()
     i0, i1 = evalpipe.block_range(n_img, comm.world, comm.rank, 4)
-    c0, c1 = evalpipe.block_range(n_cap, comm.world, comm.rank)
+    cap_ranges = [evalpipe.block_range(n_cap, comm.cap_world, q) for q in range(comm.cap_world)]
+    c0, c1 = cap_ranges[comm.cap_rank]
     torch.manual_seed(0)
     gru_text = kind in ("VSE++", "VSRN")
     if kind == "VSE++":
@@ -233,8 +234,8 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
     if gru_text:
         # packed captions of this rank, sorted by length once (like the SCAN workload): ONE GRU call per step
         lengths, tokens = make_captions(n_cap, wl["vocab"])
-        cap_ranges = evalpipe.caption_ranges(n_cap, comm.world, lengths)      # near-equal token sums per rank
-        c0, c1 = cap_ranges[comm.rank]
+        cap_ranges = evalpipe.caption_ranges(n_cap, comm.cap_world, lengths)      # near-equal token sums per owner
+        c0, c1 = cap_ranges[comm.cap_rank]
         g = torch.Generator(device=dev)
         g.manual_seed(0)
         feats = ops.l2norm(torch.randn(n_img, 36, 2048, device=dev, generator=g))
@@ -243,8 +244,12 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
         towers = evalpipe.GruModelEval({k: v.detach() for k, v in model.img_enc.state_dict().items()},
                                        {k: v.detach() for k, v in model.txt_enc.state_dict().items()},
                                        dict(bi_gru=kind == "VSE++", no_txtnorm=False, no_imgnorm=False), comm)
+        peers = None
+        if comm.virtual:
+            peers = {q: shard_captions(lengths, tokens, lo, hi, dev) for q, (lo, hi) in enumerate(cap_ranges) if q != comm.cap_rank and hi > lo}
     else:
         feats, boxes, imgs_wh, ids, mask, types, lengths = pooled_inputs(n_img, n_cap, kind, dev)
+    cap_counts = [hi - lo for lo, hi in cap_ranges]
     # captions per text-tower pass: 4096 x 32 tokens = 1024 row tiles, i.e. >= 4 tiles per resident workgroup for every 768-wide
     # layer, which is what the streaming GEMM asks for (ITR_POOLED_BATCH overrides)
     pe = evalpipe.PooledModelEval(model, comm, batch=int(os.environ.get('ITR_POOLED_BATCH', '4096')))
@@ -258,20 +263,22 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
             else:
                 img = ops.proj_l2norm(ops.mean_mid(feats[i0:i1]), towers.wi['fc.weight'], towers.wi['fc.bias'])
             cap_sorted = towers.encode_captions(toks, tok_off, lens_sorted, gather_last=True)
-            cap = torch.empty_like(cap_sorted)
-            cap[order_dev] = cap_sorted                      # back to the dataset order
-            cap_counts = [hi - lo for lo, hi in cap_ranges]
-            cap_all, maxrows = comm.all_gather_rows(cap, cap_counts)
-            if comm.on and any(c != maxrows for c in cap_counts):
-                cap_all = torch.cat([cap_all[q * maxrows:q * maxrows + cap_counts[q]] for q in range(comm.world)], 0)
-            if tm is not None:
-                tm['scan_start'].record()
-            S = ops.cosine_scores(img, cap_all)
-            if tm is not None:
-                tm['scan_end'].record()
+            send = torch.empty(max(cap_counts), cap_sorted.shape[1], device=dev, dtype=torch.float32)
+            send[order_dev] = cap_sorted                     # back to the dataset order, in the head of the exchange's send buffer
+            if peers is not None:
+                comm.peer_blocks = {}
+                for q, p in peers.items():
+                    e = towers.encode_captions(p[0], p[1], p[2], gather_last=True)
+                    blk = torch.empty_like(e)
+                    blk[torch.from_numpy(np.ascontiguousarray(p[3])).to(dev)] = e
+                    comm.peer_blocks[q] = blk
+            S = evalpipe.exchange_score(comm, img, send, cap_ranges, n_cap, ops.cosine_scores, tm)
             return S, evalpipe.finalize_ranks(comm, S, i0, n_img, 5)
+        if comm.virtual:
+            comm.peer_blocks = {q: pe.encode_captions(ids[lo:hi], mask[lo:hi], types[lo:hi], [int(x) for x in lengths[lo:hi]])
+                                for q, (lo, hi) in enumerate(cap_ranges) if q != comm.cap_rank and hi > lo}
         return pe.eval(feats[i0:i1], boxes[i0:i1], imgs_wh[i0:i1], ids[c0:c1], mask[c0:c1], types[c0:c1], [int(x) for x in lengths[c0:c1]],
-                       n_img, n_cap, timers=tm)
+                       n_img, n_cap, timers=tm, cap_ranges=cap_ranges)
 
     def barrier():
         if use_dist:
@@ -329,6 +336,10 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
                         "frac": flop / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                         "score_kernel_ms": float(np.mean(score_ms)), "algorithmic_flop_per_step": flop,
                         "note": "time = the whole step (the towers are hundreds of GEMM launches); flop = SURVEY 8d per-unit figures"}}
+    if comm.virtual:
+        out["virtual_split"] = "%d:%d" % (comm.cap_world, comm.cap_rank)
+        out["config"]["parallelism"] = "1 process, caption axis split over %d virtual owners (this one: %d): TEST HOOK, time is not a result" % (
+            comm.cap_world, comm.cap_rank)
     if world == 1 and not args.no_cpu_baseline:
         # CPU oracle (kind "port") on the first ns images and their 5*ns captions: encode + score + rank, and max |diff|
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -396,7 +407,7 @@ def main_from_files(args, world, rank, dev, use_dist):
         torch.cuda.synchronize()
 
     def step_files():
-        dset._tok_all = None                      # tokenise again: part of the path being timed
+        dset.invalidate_token_cache()             # tokenise again: part of the path being timed
         return evalpipe.evaluate_precomp(model, dset, comm)
 
     for _ in range(max(1, args.warmup)):          # (the first pass also pulls the feature file into the page cache)
@@ -421,7 +432,7 @@ def main_from_files(args, world, rank, dev, use_dist):
     ev = evalpipe.GruModelEval(wi, wt, dict(cfg, bi_gru=True, no_txtnorm=model.txt_enc.no_txtnorm, no_imgnorm=model.img_enc.no_imgnorm), comm)
 
     def step_resident():
-        return ev.scan_eval(feats, toks, tok_off, lens_sorted, order, n_img, n_cap, cap_ranges=ranges)[1]
+        return ev.scan_eval(feats, toks, tok_off, lens_sorted, order, n_img, n_cap, cap_ranges=ranges, all_lengths=lens_all)[1]
 
     ranks_r = step_resident()
     barrier()
@@ -458,6 +469,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the separately reported fp16x3 variant of the SCAN workloads")
     ap.add_argument("--cpu-sample-images", type=int, default=160)
+    ap.add_argument("--virtual-split", default=None, metavar="K[:V]",
+                    help="TEST HOOK (1 process): treat the caption axis as owned by K ranks of which this process is owner V (default K//2): "
+                         "the N>1 order of work -- asynchronous all-gather in flight on the backend's stream while the own columns are scored, "
+                         "wait, the other owners' columns from the gathered buffer -- runs on one GPU (with ITR_FORCE_COLLECTIVES=1 the "
+                         "gather is a real 1-rank RCCL collective).  The rank vectors must equal the plain run's; the time is not a result.")
     ap.add_argument("--from-files", default=None, metavar="DIR",
                     help="time the file -> rank path on a precomp dataset directory written by tools/make_synth_precomp.py (SCAN t2i): "
                          "memory-mapped .npy -> pinned -> HBM, tokenise, encode, score, rank; reported next to the resident-input number")
@@ -466,6 +482,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.virtual_split:
+        os.environ["ITR_FORCE_SPLIT"] = args.virtual_split
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     backend = os.environ.get("ITR_DIST_BACKEND", "nccl")   # "gloo": several ranks on ONE GPU (tests); collectives staged through the host
     if backend == "gloo":
@@ -520,8 +538,8 @@ def main():
     lengths, tokens = make_captions(n_cap, wl["vocab"])
     comm = evalpipe.Comm()
     i0, i1 = evalpipe.block_range(n_img, comm.world, comm.rank, 4)
-    cap_ranges = evalpipe.caption_ranges(n_cap, comm.world, lengths)      # near-equal TOKEN sums per rank
-    c0, c1 = cap_ranges[comm.rank]
+    cap_ranges = evalpipe.caption_ranges(n_cap, comm.cap_world, lengths)      # near-equal TOKEN sums per owner
+    c0, c1 = cap_ranges[comm.cap_rank]
     feats_local = feats[i0:i1].contiguous()
     feats_head = feats[:args.cpu_sample_images].cpu() if rank == 0 else None
     del feats
@@ -531,9 +549,16 @@ def main():
 
     timers = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
 
+    peers = None
+    if comm.virtual:       # the other virtual owners' packed token shards (their word embeddings are produced inside step())
+        peers = {q: shard_captions(lengths, tokens, lo, hi, dev) for q, (lo, hi) in enumerate(cap_ranges) if q != comm.cap_rank and hi > lo}
+
     def step(tm=None):
+        if peers is not None:
+            comm.peer_blocks = {q: model.encode_captions(p[0], p[1], p[2]) for q, p in peers.items()}
+        # every rank generated all the captions: their lengths are known everywhere, no metadata exchange (all_lengths)
         return model.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm, sgraf_weights=sim_w,
-                               cap_ranges=cap_ranges)
+                               cap_ranges=cap_ranges, all_lengths=lengths)
 
     def barrier():
         if use_dist:
@@ -626,12 +651,17 @@ def main():
                          "algorithmic_equiv_frac": alg_flop / (k_ms * 1e-3) / 1e12 / peak,
                          "note": note},
         }
-        if world == 1 and not is_sgraf and "scan_precision" not in wl and not args.no_variants:
+        if comm.virtual:
+            out["virtual_split"] = "%d:%d" % (comm.cap_world, comm.cap_rank)
+            out["config"]["parallelism"] = "1 process, caption axis split over %d virtual owners (this one: %d): TEST HOOK, time is not a result" % (
+                comm.cap_world, comm.cap_rank)
+        if world == 1 and not is_sgraf and "scan_precision" not in wl and not args.no_variants and not comm.virtual:
             # Reported NEXT TO the exact-fp32 metric, never instead of it: the same step with the region x word dot
             # products from split fp16 operands (hi.hi + hi.lo' + lo'.hi, fp32 accumulation) -- outside the timed region above
             vmodel = evalpipe.GruModelEval(model.wi, model.wt, dict(cfg, scan_precision="fp16x3"), comm)
             vt = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
-            vstep = lambda tm=None: vmodel.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm, cap_ranges=cap_ranges)
+            vstep = lambda tm=None: vmodel.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, timers=tm, cap_ranges=cap_ranges,
+                                                     all_lengths=lengths)
             vstep()
             torch.cuda.synchronize()
             tv = time.perf_counter()

@@ -13,6 +13,7 @@
 // see scan_mainloop.inc for why the loops that hide loads from hipcc are not written in C++ any more.
 // Preconditions (checked by the host wrapper): M % 128 == 0, N % 128 == 0, K % 64 == 0, K >= 128, 16-byte aligned rows.
 #include "itr_common.h"
+#include <mutex>
 
 namespace itr {
 
@@ -82,12 +83,24 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gemm_nt_stream_kernel(GemmStrea
 bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M,
                     int64_t N, int64_t K, int act, hipStream_t st, int *rc) {
     *rc = ITR_OK;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-        cus = prop.multiProcessorCount;
+    // resident workgroups of THIS device: CUs x what the occupancy query admits per CU (2 on gfx950: 64 KB of LDS each), cached
+    // per device under a lock (several host threads / devices may call at once)
+    static std::mutex mu;
+    static int64_t resident_of[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    int64_t resident;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!resident_of[dev]) {
+            hipDeviceProp_t prop;
+            int per_cu = 0;
+            if (hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_nt_stream_kernel<false>, GS_THREADS, 0) != hipSuccess || per_cu < 1)
+                return false;
+            resident_of[dev] = (int64_t)prop.multiProcessorCount * per_cu;
+        }
+        resident = resident_of[dev];
     }
     static const bool off = getenv("ITR_GEMM_STREAM") && atoi(getenv("ITR_GEMM_STREAM")) == 0;
     // (measured: ahead of the tile kernel at every K -- 179 200 x 1 024 x 2 048: 132 -> 147 TFLOP/s, 800 000 x 2 304 x 768: 120 -> 135,
@@ -97,7 +110,6 @@ bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, co
     if ((lda % 4) || (ldb % 4) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return false;
     if ((uint64_t)lda * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldb * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldc * 4u * GS_BM >= (1ull << 31)) return false;
     const int64_t tiles_m = M / GS_BM, tiles_n = N / GS_BM;      // whole row tiles; a remainder of rows goes to the tile kernel
-    const int64_t resident = 2 * (int64_t)cus;
     static const int64_t min_rounds = getenv("ITR_GEMM_STREAM_MINROUNDS") ? atoll(getenv("ITR_GEMM_STREAM_MINROUNDS")) : 2;
     // streaming pays when every workgroup gets at least two tiles (measured: 16 384 x 1 024 x 1 024 = 2 rounds 130 -> 142 TFLOP/s,
     // 12 800 x 2 304 x 768 = 3.5 rounds 114 -> 132; at one round 5 000 x 3 072 x 1 024 loses 104 -> 96)

@@ -256,7 +256,9 @@ __device__ __forceinline__ void sgr_pair_body(const PairArgs &p, const float *qg
     for (int t = 0; t < NT; ++t) {
         int n = t * 16 + fi;
         n = n < nn ? n : nn - 1;             // rows past the graph re-read the last node; masked below
-        qrow[t] = node_row(p, qglo, qloc, ii, c, col0, n);
+        // the last step only needs the query of node 0 (rows 1..15 of its tile are computed and dropped): every lane
+        // reads the global node's q', and the local q' projection of that step is never run (itr_sgraf_scores)
+        qrow[t] = node_row(p, qglo, qloc, ii, c, col0, glo_only ? 0 : n);
         krow[t] = node_row(p, kglo, kloc, ii, c, col0, n);
     }
     for (int u = 0; u < S / 16; ++u) {
@@ -549,7 +551,7 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
             ITR_UNSUPPORTED(S % 16 != 0, "itr_sgraf_scores: SGR needs sim_dim %% 16 == 0");
             for (int k = 0; k < sgr_step; ++k) {
                 const int last = (k == sgr_step - 1);
-                SG_TRY(gemm_nt(Xloc, S, Wfold[k], S, vfold[k], Qloc, S, nb * ncols, S, S, 0, st));
+                if (!last) SG_TRY(gemm_nt(Xloc, S, Wfold[k], S, vfold[k], Qloc, S, nb * ncols, S, S, 0, st));   // last: only node 0 queries
                 SG_TRY(gemm_nt(Xglo, S, Wfold[k], S, vfold[k], Qglo, S, nb * Nc, S, S, 0, st));
                 const dim3 pgrid((unsigned)ceil_div(npairs, 4));
                 auto plds = [](int nt) { return (size_t)4 * (nt * 16) * (nt * 16 + 4) * 4; };   // 4 waves x P[NT*16][NT*16+4]

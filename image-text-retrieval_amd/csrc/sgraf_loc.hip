@@ -22,6 +22,8 @@
 // stage-2 MFMAs, one barrier mid-way, the next fragments are read behind the second half.  The C++ loop it replaces ran
 // stage 1 after stage 2 and then met a barrier: 127 -> 137 TFLOP/s (stage 1 + 2 flop, SGRAF 1k x 5k).
 #include "scan_common.h"
+#include <stdlib.h>
+#include <vector>
 
 namespace itr {
 
@@ -37,6 +39,7 @@ struct LocArgs {
     float *X;              // [nb][ncols][256]  out: l2-normalised local nodes
     int64_t nb, n_tiles;
     int D;
+    unsigned long long *trace;   // debug (ITR_LOC_TRACE): [grid][5] = hardware id, s_memtime at entry / loop entry / loop exit / end
 };
 
 struct LocSmem {
@@ -56,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
     const int64_t xcd = bid & 7, idx = bid >> 3;
     const int64_t ct = (idx / g.nb) * 8 + xcd, ii = idx % g.nb;
     if (ct >= g.n_tiles) return;
+    const unsigned long long t_entry = g.trace ? __builtin_amdgcn_s_memtime() : 0ull;
     const int64_t ncols = g.n_tiles * SC_NT;
     const int64_t row0 = ii * ncols + ct * SC_NT;
     const int D = g.D;
@@ -102,52 +106,63 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
         fb[q] = lds0 + (unsigned)sizeof(sm.a) + (unsigned)(p * LN + wave * 64 + (fi ^ p)) * 16u;               // + 512 j
     }
     f32x16 acc[2][2];
+    const unsigned long long t_loop0 = g.trace ? __builtin_amdgcn_s_memtime() : 0ull;
     // The D loop: one generated asm statement (tools/gen_sgraf_loc.py has the schedule and the register map).
 #include "sgraf_loc_asm.inc"
+    const unsigned long long t_loop1 = g.trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
-    // ---- epilogue: + bias, l2norm over the 256 features of a row (utils.py:10-15, eps 1e-8), store
-    // acc[i][j][r]: row = i*32 + (r & 3) + 8 (r >> 2) + 4 fg, column = wave*64 + j*32 + fi
-    float ss[2][16];
+    // ---- epilogue: + bias, l2norm over the 256 features of a row (utils.py:10-15, eps 1e-8), store.
+    // acc[i][j][r]: row = i*32 + (r & 3) + 8 (r >> 2) + 4 fg, column = wave*64 + j*32 + fi -- one column per lane, so storing from
+    // the accumulators means 4-byte stores (256 per workgroup and wave...) and a cross-wave exchange for the row norms: tools/
+    // loc_trace.py measured 48 000 cycles per workgroup for that form (15 % of a workgroup's life, during which the CU has ONE
+    // workgroup in the D loop).  The tile goes through the idle operand buffers instead: [64 rows][288] floats (row stride
+    // = 8 mod 16 sixteen-byte slots: the ds_read_b128 lane groups below hit 16 distinct slots), then 8 lanes own a row segment each:
+    // row sum by three lane exchanges, one precise sqrt + divide per row, 16-byte stores of whole 128-byte lines.
+    constexpr int XS_LD = 288;
+    static_assert(LM * XS_LD * 4 <= (int)sizeof(LocSmem), "the output tile fits the operand buffers");
+    __syncthreads();                                    // every wave is done with the operand buffers
+    float *xs = reinterpret_cast<float *>(smem_raw);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const float bv = g.bias[wave * 64 + j * 32 + fi];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float s = acc[i][0][r] * acc[i][0][r] + acc[i][1][r] * acc[i][1][r];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 8, 64);
-            s += __shfl_xor(s, 4, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 1, 64);
-            ss[i][r] = s;
-        }
-    __syncthreads();                                    // every wave is done with the operand buffers
-    float *part = reinterpret_cast<float *>(smem_raw);  // [4 waves][64 rows]
-    if (fi == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part[wave * LM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg] = ss[i][r];
+            for (int r = 0; r < 16; ++r)
+                xs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * XS_LD + wave * 64 + j * 32 + fi] = acc[i][j][r] + bv;
     }
     __syncthreads();
+    {
+        const int seg = tid & 7;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = pass * 32 + (tid >> 3);
+            float4 v[8];
+            float ssq = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
-            const float tot = part[row] + part[LM + row] + part[2 * LM + row] + part[3 * LM + row];
-            const float rn = 1.f / (sqrtf(tot) + 1e-8f);
-            float *out = g.X + (row0 + row) * LN + wave * 64 + fi;
-            out[0] = acc[i][0][r] * rn;
-            out[32] = acc[i][1][r] * rn;
+            for (int k = 0; k < 8; ++k) {
+                v[k] = *reinterpret_cast<const float4 *>(xs + row * XS_LD + 32 * k + 4 * seg);
+                ssq += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+            }
+            ssq += __shfl_xor(ssq, 1, 64);
+            ssq += __shfl_xor(ssq, 2, 64);
+            ssq += __shfl_xor(ssq, 4, 64);
+            const float rn = 1.f / (sqrtf(ssq) + 1e-8f);
+            float *out = g.X + (row0 + row) * LN + 4 * seg;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<float4 *>(out + 32 * k) = float4{v[k].x * rn, v[k].y * rn, v[k].z * rn, v[k].w * rn};
         }
+    }
+    if (g.trace && tid == 0) {
+        // HW_REG_HW_ID (id 4): cu_id [11:8], sh_id [12], se_id [15:13]; HW_REG_XCC_ID (id 20): xcc_id [3:0]
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the row stores are part of the workgroup's life
+        unsigned long long *t = g.trace + (size_t)blockIdx.x * 5;
+        t[0] = ((unsigned long long)xcc << 32) | hw;
+        t[1] = t_entry; t[2] = t_loop0; t[3] = t_loop1; t[4] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 int sgraf_loc_fused(const float *P, const float *cn, const float *img, const float *wtiled, const float *W, const float *bias,
@@ -164,8 +179,24 @@ int sgraf_loc_fused(const float *P, const float *cn, const float *img, const flo
         attr_done = true;
     }
     if (nb == 0 || n_tiles == 0) return ITR_OK;
-    LocArgs g{P, cn, img, wtiled, W, bias, X, nb, n_tiles, D};
+    LocArgs g{P, cn, img, wtiled, W, bias, X, nb, n_tiles, D, nullptr};
     const int64_t grid = ceil_div(n_tiles, (int64_t)8) * 8 * nb;
+    // Debug only (tools/loc_trace.py): ITR_LOC_TRACE=<file> makes every launch synchronous and rewrites <file> with one record
+    // per workgroup (hardware id + four s_memtime stamps), from which the tool rebuilds each CU's timeline.
+    static const char *trace_path = getenv("ITR_LOC_TRACE");
+    if (trace_path && *trace_path) {
+        const size_t bytes = (size_t)grid * 5 * sizeof(unsigned long long);
+        ITR_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&g.trace), bytes));
+        ITR_CHECK_HIP(hipMemsetAsync(g.trace, 0, bytes, st));
+        hipLaunchKernelGGL(sgraf_loc_kernel, dim3((unsigned)grid), dim3(256), sizeof(LocSmem), st, g);
+        ITR_CHECK_LAUNCH("sgraf_loc");
+        ITR_CHECK_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> host((size_t)grid * 5);
+        ITR_CHECK_HIP(hipMemcpy(host.data(), g.trace, bytes, hipMemcpyDeviceToHost));
+        ITR_CHECK_HIP(hipFree(g.trace));
+        if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 1, bytes, f); fclose(f); }
+        return ITR_OK;
+    }
     hipLaunchKernelGGL(sgraf_loc_kernel, dim3((unsigned)grid), dim3(256), sizeof(LocSmem), st, g);
     ITR_CHECK_LAUNCH("sgraf_loc");
     return ITR_OK;

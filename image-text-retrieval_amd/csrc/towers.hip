@@ -10,6 +10,7 @@
 // write, direction average and last-step gather folded in).
 #include <stdlib.h>
 #include "itr_common.h"
+#include <mutex>
 
 namespace itr {
 
@@ -106,24 +107,46 @@ __global__ __launch_bounds__(256) void avg2_kernel(float *__restrict__ out, cons
     a.x = (a.x + b.x) / 2.f; a.y = (a.y + b.y) / 2.f; a.z = (a.z + b.z) / 2.f; a.w = (a.w + b.w) / 2.f;
     reinterpret_cast<float4 *>(out)[i] = a;
 }
+// the same for an element count that is not a multiple of 4 (embed dims that are not: no 16-byte rows to rely on)
+__global__ __launch_bounds__(256) void avg2_scalar_kernel(float *__restrict__ out, const float *__restrict__ other, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (out[i] + other[i]) / 2.f;
+}
 
 // A second HIP stream per device for the reverse direction of a bi-GRU: the two recurrences are independent, and a time step's
 // GEMM (M = active captions <= a few thousand rows) leaves most CUs idle in its last wave of tiles -- the other direction fills them.
+// The stream is created once per device (under a lock: several host threads may encode at once); the fork / join events are
+// per call, so concurrent callers never share an event.
 struct SideStream {
     hipStream_t st = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-};
-static SideStream *side_stream() {
-    static SideStream per_dev[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideStream &s = per_dev[dev];
-    if (!s.st) {
-        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) { s.st = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    bool forked = false;
+    // Makes `main` wait for everything queued on the side stream.  Called on EVERY path out of itr_gru_fwd after the fork, the
+    // error paths included: the caller frees the workspace after an error, and kernels still queued on the side stream would
+    // read and write recycled memory.
+    void join_into(hipStream_t main) {
+        if (forked) {
+            if (hipEventRecord(join, st) != hipSuccess || hipStreamWaitEvent(main, join, 0) != hipSuccess) (void)hipStreamSynchronize(st);
+            forked = false;
+        }
     }
-    return &s;
+    ~SideStream() {
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+    }
+};
+static bool side_stream(SideStream &s) {
+    static std::mutex mu;
+    static hipStream_t per_dev[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!per_dev[dev] && hipStreamCreateWithFlags(&per_dev[dev], hipStreamNonBlocking) != hipSuccess) { per_dev[dev] = nullptr; return false; }
+        s.st = per_dev[dev];
+    }
+    return hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
 }
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -218,7 +241,8 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     ITR_CHECK_LAUNCH("embed_gather");
 
     // the reverse direction on a second stream with its own buffers (ITR_GRU_NO_OVERLAP=1: one after the other, for A/B timing)
-    SideStream *side = (bi && !getenv("ITR_GRU_NO_OVERLAP")) ? side_stream() : nullptr;
+    SideStream side_obj;
+    SideStream *side = (bi && !getenv("ITR_GRU_NO_OVERLAP") && side_stream(side_obj)) ? &side_obj : nullptr;
     GruWs w2 = w;
     if (bi) {
         w2 = carve(static_cast<char *>(workspace) + gru_ws_one(n_tok, B, E, D), n_tok, B, E, D);
@@ -227,45 +251,50 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     if (side) {
         ITR_CHECK_HIP(hipEventRecord(side->fork, st));
         ITR_CHECK_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+        side->forked = true;
     }
-    for (int dir = 0; dir < (bi ? 2 : 1); ++dir) {
-        const float *wi = dir ? w_ih_rev : w_ih, *wh = dir ? w_hh_rev : w_hh;
-        const float *bi_ = dir ? b_ih_rev : b_ih, *bh = dir ? b_hh_rev : b_hh;
-        const GruWs &ww = dir ? w2 : w;
-        hipStream_t sd = (dir && side) ? side->st : st;
-        float *dst = dir ? w2.out_tmp : seq;             // reverse direction: its own sequence buffer, averaged in below
-        const float *wi_use = wi;
-        if (Ep != E) {   // zero-padded copy of W_ih: K = Ep is a multiple of 32 (zeros add nothing)
-            hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)(3 * D)), dim3(128), 0, sd, wi, (int64_t)3 * D, E, Ep, ww.wpad);
-            ITR_CHECK_LAUNCH("pad_cols");
-            wi_use = ww.wpad;
-        }
-        int rc = gemm_nt(w.x, Ep, wi_use, Ep, bi_, ww.gi, 3 * D, n_tok, 3 * D, Ep, 0, sd);
-        if (rc != ITR_OK) return rc;
-        ITR_CHECK_HIP(hipMemsetAsync(ww.h, 0, (size_t)B * D * 4, sd));
-        int64_t n_act = B;
-        for (int t = 0; t < Lmax; ++t) {
-            while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
-            rc = (splits_h > 1) ? gemm_nt_splitk(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, ww.skbuf, sd)
-                                : gemm_nt(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, sd);
+    auto directions = [&]() -> int {
+        for (int dir = 0; dir < (bi ? 2 : 1); ++dir) {
+            const float *wi = dir ? w_ih_rev : w_ih, *wh = dir ? w_hh_rev : w_hh;
+            const float *bi_ = dir ? b_ih_rev : b_ih, *bh = dir ? b_hh_rev : b_hh;
+            const GruWs &ww = dir ? w2 : w;
+            hipStream_t sd = (dir && side) ? side->st : st;
+            float *dst = dir ? w2.out_tmp : seq;             // reverse direction: its own sequence buffer, averaged in below
+            const float *wi_use = wi;
+            if (Ep != E) {   // zero-padded copy of W_ih: K = Ep is a multiple of 32 (zeros add nothing)
+                hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)(3 * D)), dim3(128), 0, sd, wi, (int64_t)3 * D, E, Ep, ww.wpad);
+                ITR_CHECK_LAUNCH("pad_cols");
+                wi_use = ww.wpad;
+            }
+            int rc = gemm_nt(w.x, Ep, wi_use, Ep, bi_, ww.gi, 3 * D, n_tok, 3 * D, Ep, 0, sd);
             if (rc != ITR_OK) return rc;
-            if (D % 4 == 0)
-                hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
-                                   dst, tok_off, len_dev, t, dir, 0, D, n_act);
-            else
-                hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
-                                   dst, tok_off, len_dev, t, dir, 0, D, n_act);
-            ITR_CHECK_LAUNCH("gru_gate");
+            ITR_CHECK_HIP(hipMemsetAsync(ww.h, 0, (size_t)B * D * 4, sd));
+            int64_t n_act = B;
+            for (int t = 0; t < Lmax; ++t) {
+                while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
+                rc = (splits_h > 1) ? gemm_nt_splitk(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, ww.skbuf, sd)
+                                    : gemm_nt(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, sd);
+                if (rc != ITR_OK) return rc;
+                if (D % 4 == 0)
+                    hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
+                                       dst, tok_off, len_dev, t, dir, 0, D, n_act);
+                else
+                    hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
+                                       dst, tok_off, len_dev, t, dir, 0, D, n_act);
+                ITR_CHECK_LAUNCH("gru_gate");
+            }
         }
-    }
+        return ITR_OK;
+    };
+    const int rc_dirs = directions();
+    if (side) side->join_into(st);        // also on the error paths: nothing stays queued on the side stream behind our back
+    if (rc_dirs != ITR_OK) return rc_dirs;
     if (bi) {
-        if (side) {
-            ITR_CHECK_HIP(hipEventRecord(side->join, side->st));
-            ITR_CHECK_HIP(hipStreamWaitEvent(st, side->join, 0));
-        }
-        ITR_REQUIRE(D % 4 == 0, "itr_gru_fwd: embed dim must be a multiple of 4");
-        const int64_t n4 = n_tok * (int64_t)D / 4;
-        hipLaunchKernelGGL(avg2_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, st, seq, w2.out_tmp, n4);
+        const int64_t n = n_tok * (int64_t)D;
+        if (n % 4 == 0)
+            hipLaunchKernelGGL(avg2_kernel, dim3((unsigned)ceil_div(n / 4, 256)), dim3(256), 0, st, seq, w2.out_tmp, n / 4);
+        else
+            hipLaunchKernelGGL(avg2_scalar_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, seq, w2.out_tmp, n);
         ITR_CHECK_LAUNCH("gru avg2");
     }
     float *final_ = seq;

@@ -84,7 +84,11 @@ class PrecompDataset(data.Dataset):
         first call and kept (evaluation asks for the same captions every epoch; every rank of a sharded evaluation needs all
         lengths to balance its caption ranges by token count).  Uses the one-pass regex tokeniser when that is the
         tokeniser in effect; any other `word_tokenize` goes caption by caption."""
-        if getattr(self, '_tok_all', None) is None:
+        # the cache belongs to (vocabulary, tokeniser, caption list): replacing any of them re-tokenises; invalidate_token_cache()
+        # drops it explicitly (bench.py --from-files does, to keep tokenisation inside the timed step)
+        key = (id(self.vocab), self.word_tokenize, id(self.captions), len(self.captions))
+        if getattr(self, '_tok_all', None) is None or getattr(self, '_tok_key', None) != key:
+            self._tok_key = key
             n = len(self.captions)
             default_regex = self.word_tokenize is tokenization.word_tokenize and not tokenization.nltk_available()
             if default_regex or self.word_tokenize is tokenization.regex_word_tokenize:
@@ -111,20 +115,25 @@ class PrecompDataset(data.Dataset):
         packed, lens, off = self._tok_all
         return packed[off[lo]:off[hi]], lens[lo:hi]
 
+    def invalidate_token_cache(self):
+        self._tok_all = None
+        self.__dict__.pop('_bert_rows', None)
+
     def bert_features_range(self, lo, hi):
-        """convert_to_feature of captions lo .. hi-1 -> (ids, mask, type_ids) int64 arrays [hi - lo, max_words]; rows are
-        computed once and kept (a validation pass asks for the same captions every epoch)."""
-        cache = self.__dict__.setdefault('_bert_rows', {})
-        miss = [i for i in range(lo, hi) if i not in cache]
-        for i in miss:
-            _, ids, mask, types = convert_to_feature(self.captions[i], self.max_words, self.tokenizer)
-            cache[i] = (ids, mask, types)
+        """convert_to_feature of captions lo .. hi-1 -> (ids, mask, type_ids) int64 arrays [hi - lo, max_words].  The rows of
+        the LAST requested range are kept as three int64 arrays (a validation pass asks for the same range every epoch); a
+        different range replaces them, so the cache is bounded by one range (3 x 8 x max_words bytes per caption) whatever
+        split it is called on."""
+        cached = self.__dict__.get('_bert_rows')
+        if cached is not None and cached[0] == (lo, hi, id(self.captions), id(self.tokenizer)):
+            return cached[1]
         n = hi - lo
-        out = [np.zeros((n, self.max_words), np.int64) for _ in range(3)]
+        out = tuple(np.zeros((n, self.max_words), np.int64) for _ in range(3))
         for r, i in enumerate(range(lo, hi)):
-            for k in range(3):
-                out[k][r] = cache[i][k]
-        return tuple(out)
+            _, ids, mask, types = convert_to_feature(self.captions[i], self.max_words, self.tokenizer)
+            out[0][r], out[1][r], out[2][r] = ids, mask, types
+        self._bert_rows = ((lo, hi, id(self.captions), id(self.tokenizer)), out)
+        return out
 
     def vsrn_ids(self, index):
         """The caption layout the reference feeds VSRN (data_loader.py:117-125), as written: more than max_len tokens ->

@@ -45,16 +45,26 @@ def caption_ranges(n_cap, world, weights=None):
     bounds = [0]
     for q in range(1, world):
         b = int(np.searchsorted(cs, cs[-1] * q / world, side='left'))
-        bounds.append(max(bounds[-1], min(n_cap, b)))
+        # every rank keeps at least one caption while there are enough of them (a few very long captions, or world close
+        # to n_cap, would otherwise leave a rank with an empty range: its text tower has nothing to encode)
+        lo = min(bounds[-1] + 1, n_cap)
+        hi = max(lo, n_cap - (world - q))
+        bounds.append(min(max(b, lo), hi))
     bounds.append(n_cap)
     return [(bounds[q], bounds[q + 1]) for q in range(world)]
 
 
 class Comm:
     """Minimal collective layer: torch.distributed (backend nccl == RCCL over xGMI on ROCm, gloo in
-    the CPU tests) or a no-op for a single process."""
+    the CPU tests) or a no-op for a single process.
 
-    def __init__(self, group=None):
+    Virtual caption split (`virtual_split="k[:v]"` or ITR_FORCE_SPLIT, single real rank only): the caption axis is treated as
+    owned by k ranks of which this process is owner v.  The images stay whole (one real rank), the k - 1 other owners' embedding
+    blocks are handed over in `peer_blocks`, and the exchange is a REAL asynchronous all-gather on the backend's stream (1-rank
+    RCCL group when one is initialised, a side-stream copy otherwise) -- so the N > 1 order of work (gather in flight while the
+    own columns are scored, wait(), the other owners' columns from the gathered buffer) executes on a 1-GPU box."""
+
+    def __init__(self, group=None, virtual_split=None):
         self.on = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(group) > 1 or os.environ.get("ITR_FORCE_COLLECTIVES") == "1")
         self.group = group
@@ -63,6 +73,20 @@ class Comm:
         # gloo moves host memory: device tensors are staged through the host (tests: two ranks sharing ONE GPU, which
         # RCCL refuses; production runs use backend nccl = RCCL over xGMI and never take this branch)
         self.host_staged = self.on and dist.get_backend(group) == "gloo"
+        self.cap_world, self.cap_rank = self.world, self.rank        # owners of the caption axis (= the ranks, unless virtual)
+        self.peer_blocks = None                                      # virtual split: {owner q: its block}, set by the caller per step
+        vs = virtual_split if virtual_split is not None else os.environ.get("ITR_FORCE_SPLIT")
+        if vs:
+            k, _, v = str(vs).partition(":")
+            k = int(k)
+            v = int(v) if v else k // 2
+            if self.world != 1:
+                raise ValueError("a virtual caption split needs a single real rank (world is %d)" % self.world)
+            if not 0 <= v < k:
+                raise ValueError("virtual split %r: owner index out of range" % (vs,))
+            if k > 1:
+                self.cap_world, self.cap_rank = k, v
+        self.virtual = self.cap_world != self.world
 
     def all_gather_rows(self, local, counts):
         """Concatenate row blocks of different heights.  Returns (buffer [world*maxrows, ...], maxrows):
@@ -81,24 +105,62 @@ class Comm:
             dist.all_gather_into_tensor(out, pad, group=self.group)
         return out, maxrows
 
-    def all_gather_rows_async(self, local, counts):
-        """all_gather_rows that returns at once: (buffer, maxrows, wait).  With RCCL the collective runs on the backend's
-        own stream; kernels launched on the current stream before `wait()` overlap it (the caller scores the captions
-        it already holds meanwhile).  gloo (tests) and a single process complete immediately."""
+    def all_gather_rows_async(self, send, counts):
+        """The one exchange.  `send` is this owner's block ALREADY in a buffer of max(counts) rows (the towers write straight
+        into it: no zero-filled staging copy; rows past the owner's count are never read).  Returns (buffer, maxrows, wait):
+        owner q's rows live at buffer[q*maxrows : q*maxrows + counts[q]].  With RCCL the collective runs on the backend's own
+        stream; kernels launched on the current stream before `wait()` overlap it (the caller scores the captions it already
+        holds meanwhile).  gloo (tests) completes immediately."""
         maxrows = int(max(counts))
+        if send.shape[0] != maxrows:
+            raise ValueError("all_gather_rows_async: the send buffer has %d rows, the largest block %d" % (send.shape[0], maxrows))
+        if self.virtual:
+            return self._virtual_gather(send, counts, maxrows)
         if not self.on:
-            return local, maxrows, (lambda: None)
-        if self.host_staged and local.is_cuda or dist.get_backend(self.group) != "nccl":
-            out, maxrows = self.all_gather_rows(local, counts)
+            return send, maxrows, (lambda: None)
+        out = torch.empty((self.world * maxrows,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if self.host_staged and send.is_cuda:
+            parts = [torch.empty(send.shape, dtype=send.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, send.cpu(), group=self.group)
+            out.copy_(torch.cat(parts, 0))
             return out, maxrows, (lambda: None)
-        pad = torch.zeros((maxrows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        pad[:local.shape[0]] = local
-        out = torch.empty((self.world * maxrows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        work = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
-        keep = (pad,)            # the send buffer must outlive the collective
+        if dist.get_backend(self.group) != "nccl":
+            dist.all_gather_into_tensor(out, send, group=self.group)
+            return out, maxrows, (lambda: None)
+        work = dist.all_gather_into_tensor(out, send, group=self.group, async_op=True)
 
-        def wait(_w=work, _k=keep):
-            _w.wait()            # current stream waits for the collective; the host does not block
+        def wait(_w=work, _k=send):     # (the send buffer outlives the collective through the closure)
+            _w.wait()                   # current stream waits for the collective; the host does not block
+        return out, maxrows, wait
+
+    def _virtual_gather(self, send, counts, maxrows):
+        k, v = self.cap_world, self.cap_rank
+        if self.peer_blocks is None or set(self.peer_blocks) != set(q for q in range(k) if q != v and counts[q]):
+            raise ValueError("virtual split: peer_blocks must hold the block of every other non-empty owner")
+        stage = torch.empty((k * maxrows,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        stage[v * maxrows:(v + 1) * maxrows] = send
+        for q, blk in self.peer_blocks.items():
+            if blk.shape[0] != counts[q]:
+                raise ValueError("virtual split: owner %d hands over %d rows, expected %d" % (q, blk.shape[0], counts[q]))
+            stage[q * maxrows:q * maxrows + counts[q]] = blk
+        out = torch.empty_like(stage)
+        if self.on and dist.get_backend(self.group) == "nccl":
+            work = dist.all_gather_into_tensor(out, stage, group=self.group, async_op=True)     # 1 rank: out = stage, on RCCL's stream
+
+            def wait(_w=work, _k=stage):
+                _w.wait()
+            return out, maxrows, wait
+        if not send.is_cuda:               # (CPU tests of the split logic)
+            out.copy_(stage)
+            return out, maxrows, (lambda: None)
+        side = torch.cuda.Stream(device=send.device)
+        side.wait_stream(torch.cuda.current_stream(send.device))
+        with torch.cuda.stream(side):
+            out.copy_(stage, non_blocking=True)
+        stage.record_stream(side)
+
+        def wait(_s=side, _d=send.device):
+            torch.cuda.current_stream(_d).wait_stream(_s)
         return out, maxrows, wait
 
     def all_gather_list(self, obj_array):
@@ -172,10 +234,10 @@ class GruModelEval:
         return ops.proj_l2norm(feats_local, self.wi['fc.weight'], self.wi['fc.bias'],
                                no_imgnorm=self.cfg.get('no_imgnorm', False), use_abs=self.cfg.get('img_use_abs', False))
 
-    def encode_captions(self, tokens_packed, tok_off, lengths_sorted, gather_last=False):
+    def encode_captions(self, tokens_packed, tok_off, lengths_sorted, gather_last=False, out=None):
         return ops.gru_encode(tokens_packed, tok_off, lengths_sorted, self.wt, self.cfg.get('bi_gru', False),
                               no_txtnorm=self.cfg.get('no_txtnorm', False), use_abs=self.cfg.get('txt_use_abs', False),
-                              gather_last=gather_last)
+                              gather_last=gather_last, out=out)
 
     # -- whole step for SCAN.  Local inputs:
     #   feats_local [n_img_local, 36, F]          unique images rows [i0, i1)
@@ -189,39 +251,78 @@ class GruModelEval:
                               n_cap_total, im_div, timers, sgraf_weights=sim_weights)
 
     def scan_eval(self, feats_local, tokens_packed, tok_off, lengths_sorted, order_local, n_img_total,
-                  n_cap_total, im_div=5, timers=None, sgraf_weights=None, cap_ranges=None):
+                  n_cap_total, im_div=5, timers=None, sgraf_weights=None, cap_ranges=None, all_lengths=None):
         """feats_local: this rank's region features [n_img_local, 36, F] in HBM, or an iterable of row blocks
         (r0, r1, tensor[r1 - r0, 36, F]) covering them in order (evaluate_precomp streams a memory-mapped file that way:
         block k is projected and scored while block k+1 crosses PCIe).
-        cap_ranges: the caption range of EVERY rank (caption_ranges(); default: equal counts); this rank's inputs hold
-        its own range.  Order of work with several ranks: host metadata exchange (lengths) -> towers -> the all-gather of
-        the packed word embeddings is started -> the columns of the captions this rank encoded itself are scored while the
-        exchange is in flight -> the other ranks' columns.  A pair's score depends on that pair only (whatever tile the
-        caption shares with others), so the matrix is bit-identical to the single-process one."""
+        cap_ranges: the caption range of EVERY caption owner (caption_ranges(); default: equal counts); this rank's inputs
+        hold its own range.
+        all_lengths: the length of EVERY caption of the evaluation in dataset order (host array).  Every rank of the bench
+        and of the file path knows them (synthetic captions are generated, a split is tokenised, on every rank), and every
+        owner packs its range in the loader's order (stable sort by length, descending: data_loader.py:146) -- so token counts,
+        offsets and lengths of the other owners' blocks follow without any exchange.  Without it the lengths are exchanged
+        first (one small device all-gather + host sync before the towers are queued).
+        Order of work with several owners: towers (the text tower writes into the head of the max-sized send buffer) -> the
+        all-gather of the packed word embeddings is started -> the columns of the captions this rank encoded itself are
+        scored while the exchange is in flight -> wait -> the other owners' columns (one launch left and right of the own
+        range).  A pair's score depends on that pair only (whatever tile the caption shares with others), so the matrix is
+        bit-identical to the single-process one."""
         comm = self.comm
         cfg = self.cfg
         dev = tokens_packed.device
-        ranges = cap_ranges or [block_range(n_cap_total, comm.world, q) for q in range(comm.world)]
+        kw, kr = comm.cap_world, comm.cap_rank
+        ranges = cap_ranges or [block_range(n_cap_total, kw, q) for q in range(kw)]
+        if len(ranges) != kw:
+            raise ValueError("scan_eval: %d caption ranges for %d caption owners" % (len(ranges), kw))
         cap_counts = [hi - lo for lo, hi in ranges]
-        # -- host metadata first: lengths / offsets of this rank's captions in their original order, token count
+        # -- host metadata: lengths / offsets of this rank's captions in their original order
         lens_sorted = np.asarray(lengths_sorted, dtype=np.int64)
         off_sorted = np.concatenate([[0], np.cumsum(lens_sorted)[:-1]]) if len(lens_sorted) else np.zeros(0, np.int64)
         n_loc = len(lens_sorted)
-        if n_loc != cap_counts[comm.rank]:
-            raise ValueError("scan_eval: %d local captions, range of rank %d holds %d" % (n_loc, comm.rank, cap_counts[comm.rank]))
+        if n_loc != cap_counts[kr]:
+            raise ValueError("scan_eval: %d local captions, range of owner %d holds %d" % (n_loc, kr, cap_counts[kr]))
+        order_local = np.asarray(order_local, dtype=np.int64)
         len_loc = np.zeros(n_loc, np.int64)
         off_loc = np.zeros(n_loc, np.int64)
-        len_loc[np.asarray(order_local)] = lens_sorted       # back to the original caption order
-        off_loc[np.asarray(order_local)] = off_sorted
-        maxcap = max(cap_counts)
-        meta = np.zeros(2 * maxcap + 1, np.int64)
-        meta[0] = int(lens_sorted.sum())
-        meta[1:1 + n_loc] = len_loc
-        meta[1 + maxcap:1 + maxcap + n_loc] = off_loc
-        metas = comm.all_gather_list(meta)
-        tok_counts = [int(m[0]) for m in metas]
-        # -- step 1: towers (text first: it needs no image, and the first feature block may still be on its way)
-        words = self.encode_captions(tokens_packed, tok_off, lengths_sorted)
+        len_loc[order_local] = lens_sorted       # back to the original caption order
+        off_loc[order_local] = off_sorted
+        n_tok = int(lens_sorted.sum())
+        if kw == 1:
+            tok_counts, cap_len, offs = [n_tok], len_loc, [off_loc]
+        elif all_lengths is not None:
+            cap_len = np.asarray(all_lengths, dtype=np.int64)
+            c0, c1 = ranges[kr]
+            if len(cap_len) != n_cap_total or not np.array_equal(cap_len[c0:c1], len_loc):
+                raise ValueError("scan_eval: all_lengths does not match this rank's captions")
+            if not np.array_equal(order_local, np.argsort(-len_loc, kind="stable")):
+                raise ValueError("scan_eval: with all_lengths every owner packs its captions by stable descending length")
+            tok_counts, offs = [], []
+            for lo, hi in ranges:
+                lq = cap_len[lo:hi]
+                oq = np.argsort(-lq, kind="stable")
+                ls = lq[oq]
+                off_q = np.zeros(hi - lo, np.int64)
+                off_q[oq] = np.cumsum(ls) - ls
+                offs.append(off_q)
+                tok_counts.append(int(lq.sum()))
+        else:
+            if comm.virtual:
+                raise ValueError("scan_eval: a virtual caption split needs all_lengths")
+            maxcap = max(cap_counts)
+            meta = np.zeros(2 * maxcap + 1, np.int64)
+            meta[0] = n_tok
+            meta[1:1 + n_loc] = len_loc
+            meta[1 + maxcap:1 + maxcap + n_loc] = off_loc
+            metas = comm.all_gather_list(meta)
+            tok_counts = [int(m[0]) for m in metas]
+            cap_len = np.concatenate([m[1:1 + cap_counts[q]] for q, m in enumerate(metas)])
+            offs = [m[1 + maxcap:1 + maxcap + cap_counts[q]] for q, m in enumerate(metas)]
+        maxtok = max(tok_counts)
+        # -- step 1: towers (text first: it needs no image, and the first feature block may still be on its way).  The word
+        # embeddings land in the head of the send buffer of the exchange (maxtok rows; the tail is never read).
+        D_emb = self.wt['rnn.weight_hh_l0'].shape[1]
+        send = torch.empty(maxtok, D_emb, device=dev, dtype=torch.float32)
+        words = self.encode_captions(tokens_packed, tok_off, lengths_sorted, out=send[:n_tok])
         if torch.is_tensor(feats_local):
             blocks = [(0, feats_local.shape[0], feats_local)]
             n_img_local = feats_local.shape[0]
@@ -230,9 +331,8 @@ class GruModelEval:
             n_img_local = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)
             n_img_local = n_img_local[1] - n_img_local[0]
         # -- step 2: start the one exchange
-        words_all, maxtok, wait = comm.all_gather_rows_async(words, tok_counts)
-        cap_len = np.concatenate([m[1:1 + cap_counts[q]] for q, m in enumerate(metas)])
-        cap_off = np.concatenate([m[1 + maxcap:1 + maxcap + cap_counts[q]] + q * maxtok for q, m in enumerate(metas)])
+        words_all, maxtok, wait = comm.all_gather_rows_async(send, tok_counts)
+        cap_off = np.concatenate([offs[q] + q * maxtok for q in range(kw)])
         xa = cfg.get('cross_attn', 't2i')
 
         if timers is not None:
@@ -266,13 +366,13 @@ class GruModelEval:
         waited = False
         for r0, r1, fblock in blocks:
             img = self.encode_images(fblock)
-            if comm.world == 1 or waited:
+            if kw == 1 or waited:
                 if not waited:
                     wait()
                     waited = True
                 plan = score(img, 'all', words_all, cap_off, cap_len, S[r0:r1])
             else:
-                c0, c1 = ranges[comm.rank]
+                c0, c1 = ranges[kr]
                 if c1 > c0:
                     plan = score(img, 'own', words, off_loc, len_loc, S[r0:r1, c0:c1])
                 wait()
@@ -290,6 +390,43 @@ class GruModelEval:
         return S, ranks, plan
 
 
+def exchange_score(comm, img, send, ranges, n_cap_total, score_fn, timers=None):
+    """Steps 2 + 3 for the models whose caption embedding is ONE vector: the all-gather of the caption embeddings is started
+    (`send`: this owner's block in a buffer of max-count rows), the columns of the owner's own captions are scored meanwhile,
+    then -- after wait() -- the other owners' columns, one launch per run of adjacent full blocks (equal counts: one launch left
+    and one right of the own range).  score_fn(img, cap_rows, out=column block of S).  -> S [n_img_local, n_cap_total]."""
+    kw, kr = comm.cap_world, comm.cap_rank
+    counts = [hi - lo for lo, hi in ranges]
+    cap_all, maxrows, wait = comm.all_gather_rows_async(send, counts)
+    n_img_local = img.shape[0]
+    S = torch.empty(n_img_local, n_cap_total, device=img.device, dtype=torch.float32)
+    if timers is not None:
+        timers['scan_start'].record()
+    if kw == 1:
+        wait()
+        if n_img_local and n_cap_total:
+            score_fn(img, cap_all[:n_cap_total], out=S)
+    else:
+        c0, c1 = ranges[kr]
+        if n_img_local and c1 > c0:
+            score_fn(img, send[:c1 - c0], out=S[:, c0:c1])
+        wait()
+        runs = []                          # [first row of cap_all, row count, first column]
+        for q in range(kw):
+            if q == kr or counts[q] == 0:
+                continue
+            if runs and runs[-1][0] + runs[-1][1] == q * maxrows and runs[-1][2] + runs[-1][1] == ranges[q][0]:
+                runs[-1][1] += counts[q]
+            else:
+                runs.append([q * maxrows, counts[q], ranges[q][0]])
+        for r0, n, col in runs:
+            if n_img_local:
+                score_fn(img, cap_all[r0:r0 + n], out=S[:, col:col + n])
+    if timers is not None:
+        timers['scan_end'].record()
+    return S
+
+
 class PooledModelEval:
     """Sharded evaluation of the models whose caption embedding is ONE vector (VSE++, SAEM, CAMERA):
     rank p encodes its image rows and its caption slice in batches, ONE all-gather moves the caption embeddings
@@ -301,12 +438,12 @@ class PooledModelEval:
         self.model, self.comm, self.batch = model, comm or Comm(), batch
         self.name = model.config['name']
 
-    def _score(self, img, cap):
+    def _score(self, img, cap, out=None):
         if self.name == 'CAMERA':
-            return ops.mvm_scores(img, cap)                 # Fusionmodule.py:674-692
+            return ops.mvm_scores(img, cap, out=out)        # Fusionmodule.py:674-692
         if self.name == 'SAEM':
-            return ops.pdist_cos(img, cap)                  # Objectives.py:310-323
-        return ops.cosine_scores(img, cap)                  # Objectives.py:18-21
+            return ops.pdist_cos(img, cap, out=out)         # Objectives.py:310-323
+        return ops.cosine_scores(img, cap, out=out)         # Objectives.py:18-21
 
     def encode_images(self, images, boxes, imgs_wh):
         m, bs = self.model, self.batch
@@ -320,39 +457,50 @@ class PooledModelEval:
                     imgs.append(m.img_enc(images[sl]))
         return torch.cat(imgs, 0)
 
-    def encode_captions(self, captions, captions_mask, captions_type_ids, lengths):
+    def encode_captions(self, captions, captions_mask, captions_type_ids, lengths, rows=None):
+        """-> caption embeddings [n, D...]; with `rows` >= n the result is the head of a buffer of `rows` rows (the send
+        buffer of the exchange: the batches are written straight into it)."""
         m, bs = self.model, self.batch
-        caps = []
+        n = captions.shape[0]
+        buf = None
         with torch.no_grad():
-            for b0 in range(0, captions.shape[0], bs):
+            for b0 in range(0, n, bs):
                 sl = slice(b0, b0 + bs)
                 if self.name == 'CAMERA':
-                    caps.append(m.txt_enc(captions[sl], captions_mask[sl], captions_type_ids[sl]))
+                    e = m.txt_enc(captions[sl], captions_mask[sl], captions_type_ids[sl])
                 elif self.name == 'SAEM':
-                    caps.append(m.txt_enc(captions[sl], captions_mask[sl], captions_type_ids[sl], lengths[b0:b0 + bs]))
+                    e = m.txt_enc(captions[sl], captions_mask[sl], captions_type_ids[sl], lengths[b0:b0 + bs])
                 else:
-                    caps.append(m.txt_enc(captions[sl], lengths[b0:b0 + bs])[0])
-        return torch.cat(caps, 0)
+                    e = m.txt_enc(captions[sl], lengths[b0:b0 + bs])[0]
+                if buf is None:
+                    buf = torch.empty((max(rows or n, n),) + tuple(e.shape[1:]), device=e.device, dtype=e.dtype)
+                buf[b0:b0 + e.shape[0]] = e
+        if buf is None:
+            raise ValueError("PooledModelEval.encode_captions: an empty caption shard (every owner holds at least one caption)")
+        return buf[:n] if rows is None else buf
 
     def encode(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, lengths):
         """Local shards -> (img_emb, cap_emb); image and caption counts are independent here (unique images)."""
         return self.encode_images(images, boxes, imgs_wh), self.encode_captions(captions, captions_mask, captions_type_ids, lengths)
 
     def eval(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, lengths, n_img_total, n_cap_total,
-             im_div=5, timers=None, cap_emb=None):
+             im_div=5, timers=None, cap_emb=None, cap_ranges=None):
+        """cap_emb: this owner's caption embeddings when the caller has run the text tower already -- its count rows, or
+        a buffer of max-count rows whose head they are."""
         comm = self.comm
-        cap = cap_emb if cap_emb is not None else self.encode_captions(captions, captions_mask, captions_type_ids, lengths)
+        kw, kr = comm.cap_world, comm.cap_rank
+        ranges = cap_ranges or [block_range(n_cap_total, kw, q) for q in range(kw)]
+        counts = [hi - lo for lo, hi in ranges]
+        maxrows = max(counts)
+        if cap_emb is None:
+            send = self.encode_captions(captions, captions_mask, captions_type_ids, lengths, rows=maxrows)
+        elif cap_emb.shape[0] == maxrows:
+            send = cap_emb
+        else:
+            send = torch.empty((maxrows,) + tuple(cap_emb.shape[1:]), device=cap_emb.device, dtype=cap_emb.dtype)
+            send[:cap_emb.shape[0]] = cap_emb
         img = self.encode_images(images, boxes, imgs_wh)
-        cap_counts = [block_range(n_cap_total, comm.world, q)[1] - block_range(n_cap_total, comm.world, q)[0]
-                      for q in range(comm.world)]
-        cap_all, maxrows = comm.all_gather_rows(cap, cap_counts)
-        if comm.on and any(c != maxrows for c in cap_counts):
-            cap_all = torch.cat([cap_all[q * maxrows:q * maxrows + cap_counts[q]] for q in range(comm.world)], 0)
-        if timers is not None:
-            timers['scan_start'].record()
-        S = self._score(img, cap_all)
-        if timers is not None:
-            timers['scan_end'].record()
+        S = exchange_score(comm, img, send, ranges, n_cap_total, self._score, timers)
         row0 = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)[0]
         return S, finalize_ranks(comm, S, row0, n_img_total, im_div)
 
@@ -360,14 +508,24 @@ class PooledModelEval:
 # ---------------------------------------------------------------------------------------------------------
 # Real data: checkpointed model + precomp files -> sharded, device-resident evaluation (the bench's path on a dataset)
 _PINNED = {}
+_PINNED_LOCK = __import__("threading").Lock()
 
 
-def _pinned(shape, slot):
-    """Page-locked staging buffers are expensive to create (cudaHostAlloc of tens of MB): kept for the process."""
-    key = (tuple(shape), slot)
-    if key not in _PINNED:
-        _PINNED[key] = torch.empty(shape, dtype=torch.float32).pin_memory()
-    return _PINNED[key]
+def _pinned_pair(shape):
+    """Two page-locked staging buffers of `shape`, taken from a process-wide pool and handed back by `_pinned_release`
+    (cudaHostAlloc of tens of MB is expensive: the buffers are kept for the process).  A pair belongs to ONE _stage_rows call
+    at a time -- a prefetch on the helper thread and a copy on the main thread never share staging memory."""
+    key = tuple(shape)
+    with _PINNED_LOCK:
+        pool = _PINNED.setdefault(key, [])
+        if pool:
+            return pool.pop()
+    return [torch.empty(shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+
+
+def _pinned_release(shape, pair):
+    with _PINNED_LOCK:
+        _PINNED.setdefault(tuple(shape), []).append(pair)
 
 
 def _stage_rows(arr, r0, r1, dst, stream, chunk=128):
@@ -375,21 +533,26 @@ def _stage_rows(arr, r0, r1, dst, stream, chunk=128):
     run on `stream`, so reading chunk k+1 from the page cache overlaps the DMA of chunk k.  Returns the event of the last copy."""
     ev = [None, None]
     last = None
-    for k, c0 in enumerate(range(r0, r1, chunk)):
-        c1 = min(r1, c0 + chunk)
-        b = k & 1
-        buf = _pinned((chunk,) + tuple(arr.shape[1:]), b)
-        if ev[b] is not None:
-            ev[b].synchronize()                  # the copy that last used this staging buffer is done
-        np.copyto(buf[:c1 - c0].numpy(), arr[c0:c1], casting='same_kind')
-        with torch.cuda.stream(stream):
-            dst[c0 - r0:c1 - r0].copy_(buf[:c1 - c0], non_blocking=True)
-            ev[b] = torch.cuda.Event()
-            ev[b].record(stream)
-            last = ev[b]
-    for e in ev:
-        if e is not None:
-            e.synchronize()                      # the staging buffers are reused by the next call
+    shape = (chunk,) + tuple(arr.shape[1:])
+    pair = _pinned_pair(shape)
+    try:
+        for k, c0 in enumerate(range(r0, r1, chunk)):
+            c1 = min(r1, c0 + chunk)
+            b = k & 1
+            buf = pair[b]
+            if ev[b] is not None:
+                ev[b].synchronize()                  # the copy that last used this staging buffer is done
+            np.copyto(buf[:c1 - c0].numpy(), arr[c0:c1], casting='same_kind')
+            with torch.cuda.stream(stream):
+                dst[c0 - r0:c1 - r0].copy_(buf[:c1 - c0], non_blocking=True)
+                ev[b] = torch.cuda.Event()
+                ev[b].record(stream)
+                last = ev[b]
+    finally:
+        for e in ev:
+            if e is not None:
+                e.synchronize()                      # the staging buffers go back to the pool idle
+        _pinned_release(shape, pair)
     return last
 
 
@@ -421,7 +584,7 @@ class _FeatureBlocks:
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         self.bufs = [torch.empty((n,) + tuple(arr.shape[1:]), device=dev, dtype=torch.float32) for _ in range(2)]
         self.consumed = [None, None]     # event on the consumer's stream: kernels reading buffer b are queued up to here
-        self._thread, self._first = None, None
+        self._thread, self._first, self._error = None, None, None
 
     def _stage(self, k):
         r0 = self.i0 + k * self.block
@@ -436,8 +599,11 @@ class _FeatureBlocks:
         import threading
         if self.i1 > self.i0 and self._thread is None:
             def run():
-                torch.cuda.set_device(self.dev)
-                self._first = self._stage(0)
+                try:
+                    torch.cuda.set_device(self.dev)
+                    self._first = self._stage(0)
+                except BaseException as e:       # (mmap read error, pin_memory OOM, HIP error): re-raised on the consumer's thread
+                    self._error = e
             self._thread = threading.Thread(target=run)
             self._thread.start()
 
@@ -447,6 +613,8 @@ class _FeatureBlocks:
         for k in range(n_blocks):
             if k == 0 and self._thread is not None:
                 self._thread.join()
+                if self._error is not None:
+                    raise self._error
                 ev = self._first
             else:
                 ev = self._stage(k)
@@ -467,6 +635,8 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=4096, block_row
     evaluation.py:296-300).  block_rows: images per streamed feature block of the word-level models (see _FeatureBlocks).
     Returns (i2t_rank, i2t_top1, t2i_rank, t2i_top1) as host int64 arrays."""
     comm = comm or Comm()
+    if comm.virtual:
+        raise ValueError("evaluate_precomp: the virtual caption split is a test hook of the resident-input path (bench.py --virtual-split)")
     cfg = model.config
     name = cfg['name']
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -490,8 +660,8 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=4096, block_row
         if name in ('SCAN', 'SGRAF', 'VSE++', 'VSE_PP', 'VSRN'):
             if name == 'VSRN':
                 # VSRN: the reference's padded caption layout (every caption max_len + 1 ids, PrecompDataset.vsrn_ids): equal lengths
-                ranges = caption_ranges(n_cap, comm.world)
-                c0, c1 = ranges[comm.rank]
+                ranges = caption_ranges(n_cap, comm.cap_world)
+                c0, c1 = ranges[comm.cap_rank]
                 ids = [dataset.vsrn_ids(cap_lo + j)[0] for j in range(c0, c1)]
                 lens = np.asarray([len(x) for x in ids], np.int64)
                 flat = np.concatenate([np.asarray(x, np.int64) for x in ids]) if len(ids) else np.zeros(0, np.int64)
@@ -499,8 +669,8 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=4096, block_row
                 # every rank tokenises the split once (one regex pass, cached in the dataset) and so knows ALL lengths: the
                 # caption ranges are balanced by token count without any exchange
                 flat_all, lens_all = dataset.token_ids_range(cap_lo, cap_hi)
-                ranges = caption_ranges(n_cap, comm.world, lens_all)
-                c0, c1 = ranges[comm.rank]
+                ranges = caption_ranges(n_cap, comm.cap_world, lens_all)
+                c0, c1 = ranges[comm.cap_rank]
                 offs_all = np.concatenate([[0], np.cumsum(lens_all)])
                 lens = lens_all[c0:c1]
                 flat = flat_all[offs_all[c0]:offs_all[c1]]
@@ -531,34 +701,34 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=4096, block_row
                 else:
                     img = ev.encode_images(ops.mean_mid(feats))
                 cap_sorted = ev.encode_captions(toks, off, lens_sorted, gather_last=True)
-                cap = torch.empty_like(cap_sorted)
-                cap[torch.from_numpy(np.ascontiguousarray(order)).to(dev)] = cap_sorted
                 counts = [hi - lo for lo, hi in ranges]
-                cap_all, maxrows = comm.all_gather_rows(cap, counts)
-                if comm.on and any(c != maxrows for c in counts):
-                    cap_all = torch.cat([cap_all[q * maxrows:q * maxrows + counts[q]] for q in range(comm.world)], 0)
+                send = torch.empty(max(counts), cap_sorted.shape[1], device=dev, dtype=torch.float32)
+                send[torch.from_numpy(np.ascontiguousarray(order)).to(dev)] = cap_sorted      # dataset order, head of the send buffer
                 # ranked with the similarity the model was trained for: criterion.sim = cosine_sim or order_sim
                 # (Objectives.py:45-50; the reference's cal_sims calls model.criterion.sim, evaluation.py:128-131)
                 if cfg.get('measure', 'cosine') == 'order':
-                    S = ops.order_scores(img, cap_all)
+                    fn = ops.order_scores
                 elif cfg.get('measure', 'cosine') == 'cosine':
-                    S = ops.cosine_scores(img, cap_all)
+                    fn = ops.cosine_scores
                 else:
                     raise ValueError("unknown measure:", cfg.get('measure'))
+                S = exchange_score(comm, img, send, ranges, n_cap, fn)
                 return finalize_ranks(comm, S, i0, n_img, im_div)
             sw = {k: v.detach() for k, v in model.sim_enc.state_dict().items()} if name == 'SGRAF' else None
-            _, ranks, _ = ev.scan_eval(feats, toks, off, lens_sorted, order, n_img, n_cap, im_div, sgraf_weights=sw, cap_ranges=ranges)
+            _, ranks, _ = ev.scan_eval(feats, toks, off, lens_sorted, order, n_img, n_cap, im_div, sgraf_weights=sw, cap_ranges=ranges,
+                                       all_lengths=lens_all)
             return ranks
         # ---- BERT models: one vector per caption
         if name not in ('SAEM', 'CAMERA'):
             raise NotImplementedError("evaluate_precomp: model %r" % name)
         c0, c1 = block_range(n_cap, comm.world, comm.rank)     # every caption is max_words ids: equal counts = equal tokens
+        max_count = block_range(n_cap, comm.world, 0)[1]
         ids_np, mask_np, types_np = dataset.bert_features_range(cap_lo + c0, cap_lo + c1)
         ids, mask, types = (ops.h2d(a, dev, torch.long).reshape(-1, dataset.max_words) for a in (ids_np, mask_np, types_np))
         pe = PooledModelEval(model, comm, batch=batch)
         lens_b = [int(v) for v in mask_np.sum(1)]
         # text tower first: its ~second of queued GPU work (12 BERT layers) covers the host-side staging of the features
-        cap = pe.encode_captions(ids, mask, types, lens_b)
+        cap = pe.encode_captions(ids, mask, types, lens_b, rows=max_count)      # (the send buffer of the exchange)
         feats = _features_to_device(dataset.images, img_lo + i0, img_lo + i1, dev)
         boxes = wh = None
         if name == 'CAMERA':

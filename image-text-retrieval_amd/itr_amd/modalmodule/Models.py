@@ -123,7 +123,8 @@ class base_module(nn.Module):
         if getattr(te, 'dropout_p', 0.) > 0 and te.training and not hasattr(self, '_seeds'):
             self._seeds = ag.DropoutSeeds()
             self._seeds.new_step()
-        assert last_state == (te.method_name in ('VSE++', 'VSRN'))
+        if last_state != (te.method_name in ('VSE++', 'VSRN')):
+            raise ValueError("_train_towers: last_state=%r does not match the text tower's pooling (method_name=%r)" % (last_state, te.method_name))
         seq, off, lens, _ = te.forward_packed_train(captions, lengths, seeds=getattr(self, '_seeds', None))
         return img, seq, off, lens
 

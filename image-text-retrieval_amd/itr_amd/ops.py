@@ -165,7 +165,17 @@ def proj_l2norm(images, weight, bias, no_imgnorm=False, use_abs=False):
     return out
 
 
-def cosine_scores(im, s):
+def _score_out(out, Ni, Nc, dev, name):
+    """The (Ni, Nc) result buffer of a score op: a fresh tensor, or the caller's -- possibly a column block of a wider score
+    matrix (row stride > Nc; the sharded evaluation scores caption ranges into their columns, evalpipe.py)."""
+    if out is None:
+        return torch.empty(Ni, Nc, device=dev, dtype=torch.float32)
+    if not (out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (Ni, Nc) and (Nc <= 1 or out.stride(1) == 1)):
+        raise ValueError("%s: out must be a (%d, %d) fp32 CUDA view with contiguous rows" % (name, Ni, Nc))
+    return out
+
+
+def cosine_scores(im, s, out=None):
     """cosine_sim (Objectives.py:18-21): im @ s^T."""
     lib = _lib.load()
     im = _dev(im, name="im")
@@ -173,19 +183,19 @@ def cosine_scores(im, s):
     if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
         raise ValueError("cosine_scores: expected (Ni, D) and (Nc, D), got %s and %s" % (tuple(im.shape), tuple(s.shape)))
     if FP16X3 and im.shape[0] and s.shape[0] and im.shape[1] % 32 == 0:
-        return gemm_nt_f16x3(split_f16(im), split_f16(s), None)
+        return gemm_nt_f16x3(split_f16(im), split_f16(s), None, out=out)
     if BF16X3 and im.shape[0] and s.shape[0] and im.shape[1] % 32 == 0:
-        return gemm_nt_bf16(split_bf16(im), split_bf16(s), None, 3)
-    S = torch.empty(im.shape[0], s.shape[0], device=im.device, dtype=torch.float32)
-    _lib.check(lib.itr_cosine_scores(_p(im), _p(s), _p(S), im.shape[0], s.shape[0], im.shape[1], s.shape[0], _stream()))
+        return gemm_nt_bf16(split_bf16(im), split_bf16(s), None, 3, out=out)
+    S = _score_out(out, im.shape[0], s.shape[0], im.device, "cosine_scores")
+    _lib.check(lib.itr_cosine_scores(_p(im), _p(s), _p(S), im.shape[0], s.shape[0], im.shape[1], S.stride(0) if S.shape[0] > 1 else max(S.shape[1], S.stride(0)), _stream()))
     return S
 
 
-def pdist_cos(x1, x2):
+def pdist_cos(x1, x2, out=None):
     """Objectives.pdist_cos (:310-323): rows / ||row|| (no eps), mm, NaN -> 0."""
     a = _norm(x1, -1, 0.0, 3)
     b = _norm(x2, -1, 0.0, 3)
-    res = cosine_scores(a, b)
+    res = cosine_scores(a, b, out=out)
     return torch.nan_to_num_(res, nan=0.0, posinf=float('inf'), neginf=float('-inf'))
 
 
@@ -250,15 +260,18 @@ def gemm_nt_f16x3(a, b, bias=None, act=None, M=None, K=None, lda=None, out=None)
     return out
 
 
-def order_scores(im, s):
+def order_scores(im, s, out=None):
     """order_sim (Objectives.py:24-30): -sqrt(sum_d max(0, s - im)^2) for every (image, sentence) pair."""
     lib = _lib.load()
     im, s = _dev(im, name="im"), _dev(s, name="s")
     if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
         raise ValueError("order_scores: im %s vs s %s" % (tuple(im.shape), tuple(s.shape)))
-    out = torch.empty(im.shape[0], s.shape[0], device=im.device, dtype=torch.float32)
-    _lib.check(lib.itr_order_scores(_p(im), _p(s), _p(out), im.shape[0], s.shape[0], im.shape[1], _stream()))
-    return out
+    res = torch.empty(im.shape[0], s.shape[0], device=im.device, dtype=torch.float32)
+    _lib.check(lib.itr_order_scores(_p(im), _p(s), _p(res), im.shape[0], s.shape[0], im.shape[1], _stream()))
+    if out is not None:          # (the order kernel writes dense rows: a column block of a wider matrix is filled by a copy)
+        _score_out(out, im.shape[0], s.shape[0], im.device, "order_scores").copy_(res)
+        return out
+    return res
 
 
 def pdist(x1, x2):
@@ -274,7 +287,7 @@ def pdist(x1, x2):
     return S
 
 
-def mvm_scores(imgs, caps):
+def mvm_scores(imgs, caps, out=None):
     """MultiViewMatching.forward (Fusionmodule.py:674-692)."""
     lib = _lib.load()
     imgs = _dev(imgs, name="imgs")
@@ -282,8 +295,8 @@ def mvm_scores(imgs, caps):
     if imgs.dim() != 3 or caps.dim() != 2 or imgs.shape[2] != caps.shape[1]:
         raise ValueError("mvm_scores: expected (Ni, k, D) and (Nc, D)")
     Ni, k, D = imgs.shape
-    S = torch.empty(Ni, caps.shape[0], device=imgs.device, dtype=torch.float32)
-    _lib.check(lib.itr_mvm_scores(_p(imgs), _p(caps), _p(S), Ni, caps.shape[0], k, D, caps.shape[0], _stream()))
+    S = _score_out(out, Ni, caps.shape[0], imgs.device, "mvm_scores")
+    _lib.check(lib.itr_mvm_scores(_p(imgs), _p(caps), _p(S), Ni, caps.shape[0], k, D, S.stride(0) if Ni > 1 else max(S.shape[1], S.stride(0)), _stream()))
     return S
 
 
@@ -693,11 +706,12 @@ def sgraf_padded(images, captions, cap_lens, weights, module_name='SAF', sgr_ste
 
 
 def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtnorm=False, use_abs=False,
-               gather_last=False):
+               gather_last=False, out=None):
     """EncoderText.forward on packed captions (TextEncoder.py:38-70).
     tokens_packed (n_tok,) int64 cuda; tok_off (B,) int64; lengths: host list sorted descending.
     weights: dict with the reference's state_dict names.  -> (n_tok, D) packed word embeddings, or
-    (B, D) when gather_last."""
+    (B, D) when gather_last.  `out`: the caller's contiguous (n_tok, D) / (B, D) result buffer -- e.g. the head of the
+    send buffer of the sharded evaluation's all-gather (evalpipe.py)."""
     lib = _lib.load()
     tokens_packed = _dev(tokens_packed, torch.int64, "tokens")
     len_host = _host_i32(lengths)
@@ -723,8 +737,12 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
                _dev(weights['rnn.bias_ih_l0_reverse']), _dev(weights['rnn.bias_hh_l0_reverse'])]
     wsb = lib.itr_gru_workspace_bytes(n_tok, B, E, D, int(bool(bidirectional)))
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-    out = None if gather_last else torch.empty(n_tok, D, device=dev, dtype=torch.float32)
-    out_last = torch.empty(B, D, device=dev, dtype=torch.float32) if gather_last else None
+    if out is not None and not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+                                and tuple(out.shape) == ((B, D) if gather_last else (n_tok, D))):
+        raise ValueError("gru_encode: out must be a contiguous fp32 CUDA tensor of shape %s" % (((B, D) if gather_last else (n_tok, D)),))
+    res = out
+    out = None if gather_last else (res if res is not None else torch.empty(n_tok, D, device=dev, dtype=torch.float32))
+    out_last = (res if res is not None else torch.empty(B, D, device=dev, dtype=torch.float32)) if gather_last else None
     _lib.check(lib.itr_gru_fwd(_p(tokens_packed), _p(tok_off), _p(len_dev), len_host.ctypes.data_as(C.c_void_p), B,
                                n_tok, _p(emb), V, E, D, _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), _p(rev[0]),
                                _p(rev[1]), _p(rev[2]), _p(rev[3]), int(no_txtnorm), int(use_abs), int(gather_last),

@@ -76,6 +76,20 @@ def _worker(rank, world, port, ni, tmp):
     buf, maxrows = comm.all_gather_rows(local, counts)
     for q in range(world):
         ok = ok and bool((buf[q * maxrows:q * maxrows + counts[q]] == q).all())
+    # the pooled models' exchange: own columns first, then the other owners' (exchange_score), unequal blocks
+    n_cap, D = 23, 6
+    emb = torch.from_numpy(rng.randn(n_cap, D).astype(np.float32))
+    img = torch.from_numpy(rng.randn(5, D).astype(np.float32))
+    ranges = [(0, 9), (9, 23)]
+    counts = [hi - lo for lo, hi in ranges]
+    send = torch.zeros(max(counts), D)
+    send[:counts[rank]] = emb[ranges[rank][0]:ranges[rank][1]]
+
+    def score(im, cap, out):
+        out.copy_(im @ cap.t())
+        return out
+    S = evalpipe.exchange_score(comm, img, send, ranges, n_cap, score)
+    ok = ok and bool(torch.allclose(S, img @ emb.t(), rtol=0, atol=1e-6))
     open(os.path.join(tmp, "ok_%d" % rank), "w").write("1" if ok else "0")
     dist.destroy_process_group()
 
@@ -121,3 +135,49 @@ def test_caption_ranges_balance_tokens():
     assert evalpipe.caption_ranges(10, 2) == [(0, 5), (5, 10)]
     with pytest.raises(ValueError):
         evalpipe.caption_ranges(10, 2, np.ones(9))
+
+
+def test_caption_ranges_never_leave_an_owner_empty():
+    """A few very long captions (or as many owners as captions) must not produce an empty range: that owner's text tower
+    would have nothing to encode while the others wait for it in the all-gather."""
+    sys.path.insert(0, os.path.join(ROOT, "image-text-retrieval_amd"))
+    from itr_amd import evalpipe
+    for w, world in (([1000, 1, 1, 1, 1, 1, 1, 1], 4), ([1, 1, 1, 1, 1, 1, 1, 1000], 4), ([5, 5, 5, 5], 4), ([3, 900, 2, 2, 800, 1], 5)):
+        r = evalpipe.caption_ranges(len(w), world, w)
+        assert r[0][0] == 0 and r[-1][1] == len(w)
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert all(hi > lo for lo, hi in r), (w, world, r)
+    r = evalpipe.caption_ranges(2, 4, [7, 7])          # fewer captions than owners: the first owners get one each
+    assert [hi - lo for lo, hi in r] == [1, 1, 0, 0]
+
+
+def test_virtual_caption_split_scores_like_one_owner():
+    """Comm(virtual_split="k:v") on one process: exchange_score takes the several-owner order of work (own columns, wait,
+    the other owners' columns from the gathered buffer) and must fill the same matrix as the plain single-owner call."""
+    sys.path.insert(0, os.path.join(ROOT, "image-text-retrieval_amd"))
+    from itr_amd import evalpipe
+    rng = np.random.RandomState(3)
+    n_cap, D = 31, 5
+    emb = torch.from_numpy(rng.randn(n_cap, D).astype(np.float32))
+    img = torch.from_numpy(rng.randn(7, D).astype(np.float32))
+    calls = []
+
+    def score(im, cap, out):
+        calls.append(cap.shape[0])
+        out.copy_(im @ cap.t())
+        return out
+    want = img @ emb.t()
+    for k, v, ranges in ((3, 1, [(0, 11), (11, 22), (22, 31)]), (4, 0, [(0, 2), (2, 12), (12, 22), (22, 31)]),
+                         (4, 3, [(0, 8), (8, 16), (16, 24), (24, 31)]), (3, 1, [(0, 10), (10, 10), (10, 31)])):
+        comm = evalpipe.Comm(virtual_split="%d:%d" % (k, v))
+        assert comm.virtual and comm.world == 1 and (comm.cap_world, comm.cap_rank) == (k, v)
+        counts = [hi - lo for lo, hi in ranges]
+        send = torch.full((max(counts), D), float("nan"))
+        send[:counts[v]] = emb[ranges[v][0]:ranges[v][1]]
+        comm.peer_blocks = {q: emb[lo:hi].clone() for q, (lo, hi) in enumerate(ranges) if q != v and hi > lo}
+        del calls[:]
+        S = evalpipe.exchange_score(comm, img, send, ranges, n_cap, score)
+        assert torch.allclose(S, want, rtol=0, atol=1e-6), (k, v)
+        assert sum(calls) == n_cap and (counts[v] == 0 or calls[0] == counts[v])      # own block first, every caption exactly once
+    with pytest.raises(ValueError):
+        evalpipe.Comm(virtual_split="3:3")

@@ -30,7 +30,7 @@ def _problem(n_img, seed, dev, D=1024):
     return img, words, lens, off
 
 
-@pytest.mark.parametrize("n_img,xa", [(5000, 't2i'), (1000, 't2i'), (1000, 'i2t')])
+@pytest.mark.parametrize("n_img,xa", [(5000, 't2i'), (1000, 't2i'), (1000, 'i2t'), (5000, 'i2t')])
 def test_scan_full_size(dev, n_img, xa):
     img, words, lens, off = _problem(n_img, 11, dev)
     n_cap = len(lens)
@@ -113,16 +113,17 @@ def test_scan_repeated_launches_are_bit_identical(dev):
         assert torch.equal(again, ref)
 
 
-@pytest.mark.parametrize("mod", ['SAF', 'SGR'])
-def test_sgraf_full_size(dev, mod):
-    """BASELINE config 5 shape (embed 1024, sim_dim 256, sgr_step 3) on the f30k-size problem 1k x 5k: oracle spot check on
+@pytest.mark.parametrize("mod,n_img", [('SAF', 1000), ('SGR', 1000), ('SAF', 5000), ('SGR', 5000)])
+def test_sgraf_full_size(dev, mod, n_img):
+    """BASELINE config 5 shape (embed 1024, sim_dim 256, sgr_step 3) on the f30k-size problem 1k x 5k AND at the size the
+    config states, 5 000 x 25 000 (325 000 words, 5 100 column tiles, 313 blocks of 16 images): oracle spot check on
     24 scattered images x 40 scattered captions (a pair's score depends on that pair only: BatchNorms run on running
     statistics), and row-shard invariance (the multi-GPU contract of SURVEY 8e) -- Fusionmodule.py:406-451."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
     import sgraf_weights
-    n_img, D, S_ = 1000, 1024, 256
+    D, S_ = 1024, 256
     img, words, lens, off = _problem(n_img, 17, dev, D)
     words = ops.l2norm(words)                               # SGRAF's text tower normalises the word vectors
     n_cap = len(lens)
@@ -192,19 +193,20 @@ def test_pooled_bert_models_full_size(dev, kind):
     # ---- rank vectors vs a host argsort of the same matrix (evaluation.py:156-222)
     i_rank, i_top, t_rank, t_top = [np.asarray(r) for r in ranks]
     rng = np.random.RandomState(1)
+    cidx, rows_idx = np.arange(n_cap), np.arange(n_img)
     for i in rng.choice(n_img, 24, replace=False):
         row = S[i].cpu().numpy()
-        order = np.argsort(row, kind="stable")[::-1]
-        pos = np.empty(n_cap, np.int64)
-        pos[order] = np.arange(n_cap)
         lo = min(int((row > row[g_]).sum()) for g_ in range(5 * i, 5 * i + 5))       # exact ties (random-init BERT: near-identical
         hi = min(int((row >= row[g_]).sum()) - 1 for g_ in range(5 * i, 5 * i + 5))  # captions): the rank lies in the tie band
         assert lo <= i_rank[i] <= hi
+        # ... and inside the band the pinned tie rule (G12 / G22): among equal scores the higher index ranks first
+        assert i_rank[i] == min(int((row > row[g_]).sum() + ((row == row[g_]) & (cidx > g_)).sum()) for g_ in range(5 * i, 5 * i + 5))
+        assert i_top[i] == n_cap - 1 - int(np.argmax(row[::-1]))
     for j in rng.choice(n_cap, 24, replace=False):
         col = S[:, j].cpu().numpy()
         assert int((col > col[j // 5]).sum()) <= t_rank[j] <= int((col >= col[j // 5]).sum()) - 1
-    want = ops.rank_counts(S)
-    assert (want[0].cpu().numpy() == i_rank).all() and (want[2].cpu().numpy() == t_rank).all()
+        assert t_rank[j] == int((col > col[j // 5]).sum() + ((col == col[j // 5]) & (rows_idx > j // 5)).sum())
+        assert t_top[j] == n_img - 1 - int(np.argmax(col[::-1]))
     # ---- a row block of images encoded and scored alone gives the same rows
     r0, r1 = 1024, 1024 + 256
     img_b, _ = pe.encode(feats[r0:r1], None if boxes is None else boxes[r0:r1], None if imgs_wh is None else imgs_wh[r0:r1],
@@ -214,3 +216,56 @@ def test_pooled_bert_models_full_size(dev, kind):
     assert torch.equal(img_b, img_all)
     Sb = pe._score(img_all, cap_all)
     assert float((Sb - S[r0:r1, :2048]).abs().max()) <= 1e-6
+
+
+def test_vsepp_full_size(dev):
+    """BASELINE config 2 at its stated size (Flickr30k test fold: 1 000 images x 5 000 captions, bi-GRU text tower, embed 1024,
+    mean-pooled regions): image projection + text tower + cosine scores against the CPU oracle on a 40-image x 200-caption
+    corner, and the rank vectors against a host argsort of the GPU's matrix -- ImgEncoder.py:133-147, TextEncoder.py:38-70,
+    Objectives.py:18-21, evaluation.py:156-222."""
+    import bench
+    n_img, n_cap, vocab = 1000, 5000, 8481
+    wi, wt = bench.make_weights(vocab)
+    wid = {k: v.to(dev) for k, v in wi.items()}
+    wtd = {k: v.to(dev) for k, v in wt.items()}
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    feats = ops.l2norm(torch.randn(n_img, 36, 2048, device=dev, generator=g))
+    lengths, tokens = bench.make_captions(n_cap, vocab)
+    toks, tok_off, lens_sorted, order = bench.shard_captions(lengths, tokens, 0, n_cap, dev)
+    img = ops.proj_l2norm(ops.mean_mid(feats), wid['fc.weight'], wid['fc.bias'])
+    cap_sorted = ops.gru_encode(toks, tok_off, lens_sorted, wtd, True, gather_last=True)
+    cap = torch.empty_like(cap_sorted)
+    cap[torch.from_numpy(np.ascontiguousarray(order)).to(dev)] = cap_sorted
+    S = ops.cosine_scores(img, cap)
+    assert S.shape == (n_img, n_cap) and bool(torch.isfinite(S).all())
+    # ---- oracle on the corner (the captions of the corner are encoded by the oracle in ITS batch: a caption's embedding
+    # depends on that caption only)
+    ns, ncs = 40, 200
+    lens = lengths[:ncs]
+    order_s = np.argsort(-lens, kind="stable")
+    ids_s = torch.zeros(ncs, int(lens.max()), dtype=torch.long)
+    for r, i in enumerate(order_s):
+        ids_s[r, :lens[i]] = torch.from_numpy(tokens[int(i)])
+    with torch.no_grad():
+        img_o = O.encoder_image_precomp(feats[:ns].cpu().mean(1), wi["fc.weight"], wi["fc.bias"])
+        cs, _ = O.encoder_text(ids_s, [int(lens[i]) for i in order_s], wt, True, False, False, "VSE++")
+        cap_o = torch.zeros_like(cs)
+        cap_o[torch.as_tensor(order_s)] = cs
+        S_o = O.cosine_sim(img_o, cap_o)
+    assert float((img[:ns].cpu() - img_o).abs().max()) <= 2e-6
+    assert float((cap[:ncs].cpu() - cap_o).abs().max()) <= 5e-6
+    assert float((S[:ns, :ncs].cpu() - S_o).abs().max()) <= 5e-6
+    # ---- ranks of the whole fold vs a host argsort of the same matrix (continuous scores: no exact ties)
+    i_rank, i_top, t_rank, t_best, _ = ops.rank_counts(S)
+    Sh = S.cpu().numpy()
+    i_rank, i_top, t_rank = i_rank.cpu().numpy(), i_top.cpu().numpy(), t_rank.cpu().numpy()
+    t_top = (t_best & 0xffffffff).cpu().numpy()
+    want = O.rank_counts(Sh)
+    for got, ref in zip((i_rank, i_top, t_rank, t_top), want):
+        assert (np.asarray(got) == np.asarray(ref)).all()
+    for i in range(0, n_img, 97):
+        order_r = np.argsort(Sh[i])[::-1]
+        pos = np.empty(n_cap, np.int64)
+        pos[order_r] = np.arange(n_cap)
+        assert i_rank[i] == pos[5 * i:5 * i + 5].min() and i_top[i] == order_r[0]

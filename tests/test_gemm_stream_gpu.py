@@ -49,3 +49,28 @@ def test_stream_gemm_equals_tile_kernel_bitwise(dev):
     assert len(blocks) == 4, r.stdout[-2000:]
     sums = [[ln.split("checksum")[1].strip() for ln in blk.splitlines() if "checksum" in ln] for blk in blocks[1:]]
     assert len(sums[0]) >= 5 and sums[0] == sums[1] == sums[2], (sums, r.stdout[-1500:])
+
+
+def test_stream_gemm_overlapping_rows_and_strided_output(dev):
+    """The call shapes the plain-shape test does not reach: rows that OVERLAP (lda < K: SAEM's Conv2d(1, C, (k, 768))
+    over a token sequence is a GEMM with lda = 768, K = k * 768 -- TextEncoder.py:115-152) and an output that is a column block
+    of a wider matrix (ldc > N, base not 128-byte aligned), both large enough for the streaming kernel."""
+    torch.manual_seed(5)
+    lda, K, N = 256, 512, 256                       # row m = base[m * 256 : m * 256 + 512]: consecutive rows share 256 floats
+    M = 128 * 2100
+    base = torch.randn((M - 1) * lda + K, device=dev)
+    w = torch.randn(N, K, device=dev) * 0.1
+    bv = torch.randn(N, device=dev)
+    wide = torch.full((M, N + 36), float("nan"), device=dev)
+    out = wide[:, 20:20 + N]                        # ldc = N + 36, first element 80 bytes into the row
+    got = ops.linear_strided(base, lda, M, K, w, bv, act='relu', out=out)
+    assert got.data_ptr() == out.data_ptr()
+    assert bool(torch.isnan(wide[:, :20]).all()) and bool(torch.isnan(wide[:, 20 + N:]).all())     # nothing written outside the block
+    idx = torch.randint(0, M, (4000,), device=dev)
+    idx[:4] = torch.tensor([0, 127, 128, M - 1], device=dev)
+    rows = torch.stack([base[i * lda:i * lda + K] for i in idx.tolist()]).double()
+    want = (rows @ w.double().t() + bv.double()).clamp(min=0)
+    scale = float((rows.abs() @ w.double().abs().t()).max())
+    assert float((out[idx].double() - want).abs().max()) <= 4e-7 * scale
+    dense = ops.linear_strided(base, lda, M, K, w, bv, act='relu')                                   # the same call, dense output
+    assert torch.equal(dense, out)
