@@ -1,0 +1,562 @@
+// SGRAF Similarity Graph Reasoning, all steps of a group of captions in ONE workgroup
+// (GraphReasoning.forward x sgr_step + sim_eval_w, itr/modalmodule/Fusionmodule.py:564-597, :437-444), sim_dim = 256.
+//
+// A graph is one (image, caption) pair: node 0 = the global similarity vector, nodes 1..W = the local (word) ones; graphs never
+// talk to each other.  The unfused chain (sgraf.hip) runs every step as  GEMM (q' = W' x + v)  ->  pair kernel
+// (softmax(q' X^T) X)  ->  GEMM (relu(W_g y + b))  over ALL node rows of a 16-image block, with q', y and the new x crossing HBM
+// (3 KB per node and step; the pair kernel is memory-bound, 18 % of the SGR time in round 2).  Here a workgroup owns up to 64
+// node rows = a GROUP of whole captions of one image (host plan: best-fit-decreasing bins of len + 1 rows, <= 16 captions) and
+// keeps them in LDS through all steps; HBM sees the node rows once (64 KB in) and one score per caption (out).
+//
+// Everything is computed TRANSPOSED so that each product leaves its result in the register layout the next one needs:
+//   P1  Q'^T[o, n] = W'[o, :] . X[n, :]      A = weight fragments streamed from L2 (pre-packed in fragment order: one coalesced
+//                                             16-byte load per lane and 16 x 16 k-block), B = X^T from LDS.  Wave w owns the 32
+//                                             output features 32 w .. 32 w + 31 (two 16-row tiles) for ALL node rows, so a weight
+//                                             element is loaded exactly once per workgroup (512 KB per step against 21 MFLOP).
+//   P2  per (caption, 16-query tile), one wave each:
+//         E^T[j, i] = X[j, :] . Q'[i, :]      A = X rows, B = Q' rows (both gathered from LDS by node)
+//         softmax over j in the accumulator layout (column i = lane & 15: two cross-lane steps), P^T stays in registers
+//         Y^T[d, i] = sum_j X[j, d] P^T[j, i]  A = X columns, B = the softmax registers as they are
+//       Y overwrites the Q' rows of the same 16 nodes (nobody else reads them).
+//   P3  X'^T[o, n] = relu(W_g[o, :] . Y[n, :] + b)    as P1, from the Q'/Y buffer back into the X buffer.
+// The last step needs node 0 only (Fusionmodule.py:443 reads sim_emb[:, 0]): P1 / P3 run on the first 16 rows (the global nodes of
+// the group's captions live there), P2 computes one query column per caption.  Then sigmoid(sim_eval_w . x_0 + b) -> S.
+// v_mfma_f32_16x16x4_f32 throughout (exact fp32).  LDS: two [64][264] fp32 buffers (row stride 264 = 2 mod 16 sixteen-byte slots:
+// the ds_read_b128 lane groups of a 16-row x 4-slot fragment read hit 16 distinct slots) + the group record = 135.7 KB,
+// one 512-thread workgroup per CU.
+#include "scan_common.h"
+#include <string.h>
+#include <stdlib.h>
+#include <vector>
+
+namespace itr {
+
+constexpr int SF_ROWS = 64, SF_S = 256, SF_LD = 264, SF_MAXCAP = 16, SF_MAXUNIT = 24, SF_THREADS = 512, SF_WAVES = 8;
+
+// One record per group of captions (built on the device from the host's bin plan: sgr_group_meta_kernel).
+struct alignas(16) SgrGroupMeta {
+    int32_t ncap, nrows, nunit, pad0;
+    int32_t cap_id[SF_MAXCAP];
+    int16_t wstart[SF_MAXCAP];           // LDS row of a caption's first word node (its global node is row = slot)
+    int16_t nn[SF_MAXCAP];               // nodes of the caption's graph = words + 1
+    uint8_t unit_cap[SF_MAXUNIT];        // P2 work units (caption slot, 16-query tile), largest graphs first
+    uint8_t unit_tile[SF_MAXUNIT];
+    int32_t row_src[SF_ROWS];            // rows < ncap: caption id (global node); others: tile-packed column of the word
+    uint8_t unit_poff[SF_MAXUNIT];       // first 1 KB softmax tile of a unit in the P^T scratch (prefix sum of the units' key-tile counts)
+    uint8_t cap_poff[SF_MAXCAP];         // the same for the last step, whose units are the captions
+    int32_t pad1[6];
+};
+static_assert(sizeof(SgrGroupMeta) == 512, "one 512-byte record per group");
+
+constexpr int SF_PTILES = 24;            // softmax tiles (16 x 16 floats) of one group: sum over captions of (key tiles)^2; at most 24 for <= 64
+                                         // node rows in <= 16 graphs of >= 2 nodes (one 33-node graph + fifteen 2-node ones: 9 + 15)
+constexpr size_t SF_LDS_BYTES = 2 * SF_ROWS * SF_LD * sizeof(float) + sizeof(SgrGroupMeta) + SF_PTILES * 1024;
+
+__global__ __launch_bounds__(256) void sgr_group_meta_kernel(const int32_t *__restrict__ grp_begin, const int32_t *__restrict__ grp_order,
+                                                             const int32_t *__restrict__ cap_len, const int32_t *__restrict__ cap_col,
+                                                             int64_t n_groups, SgrGroupMeta *__restrict__ meta, int *__restrict__ bad) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= n_groups) return;
+    SgrGroupMeta m;
+    memset(&m, 0, sizeof(m));
+    const int b0 = grp_begin[gi], ncap = grp_begin[gi + 1] - b0;
+    int rows = ncap;
+    bool ok = ncap >= 1 && ncap <= SF_MAXCAP;
+    for (int s = 0; ok && s < ncap; ++s) {
+        const int c = grp_order[b0 + s], len = cap_len[c];
+        if (len < 1 || rows + len > SF_ROWS) { ok = false; break; }
+        m.cap_id[s] = c;
+        m.nn[s] = (int16_t)(len + 1);
+        m.wstart[s] = (int16_t)rows;
+        m.row_src[s] = c;
+        for (int w = 0; w < len; ++w) m.row_src[rows + w] = cap_col[c] + w;
+        rows += len;
+    }
+    if (!ok) { atomicExch(bad, 1); m.ncap = 0; meta[gi] = m; return; }     // the host plan is wrong: the group scores nothing, the caller is told
+    m.ncap = ncap;
+    m.nrows = rows;
+    int nu = 0;
+    for (int nt = 4; nt >= 1; --nt)
+        for (int s = 0; s < ncap; ++s)
+            if ((m.nn[s] + 15) / 16 == nt)
+                for (int b = 0; b < nt; ++b) { m.unit_cap[nu] = (uint8_t)s; m.unit_tile[nu] = (uint8_t)b; ++nu; }
+    m.nunit = nu;
+    int po = 0;
+    for (int u = 0; u < nu; ++u) { m.unit_poff[u] = (uint8_t)po; po += (m.nn[m.unit_cap[u]] + 15) / 16; }
+    if (po > SF_PTILES) { atomicExch(bad, 1); m.ncap = 0; meta[gi] = m; return; }
+    po = 0;
+    for (int s = 0; s < ncap; ++s) { m.cap_poff[s] = (uint8_t)po; po += (m.nn[s] + 15) / 16; }
+    meta[gi] = m;
+}
+
+// W [256][256] row-major -> MFMA A-fragment order: frag[((ot * 16 + ks) * 64 + lane)] (float4) = W[16 ot + (lane & 15)][16 ks + 4 (lane >> 4) + 0..3]
+__global__ __launch_bounds__(256) void sgr_pack_weight_kernel(const float *__restrict__ W, float4 *__restrict__ frag) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // 16 * 16 * 64 fragments
+    if (idx >= 16 * 16 * 64) return;
+    const int lane = idx & 63, ks = (idx >> 6) & 15, ot = idx >> 10;
+    frag[idx] = *reinterpret_cast<const float4 *>(W + (16 * ot + (lane & 15)) * SF_S + 16 * ks + 4 * (lane >> 4));
+}
+
+struct SgrFusedArgs {
+    const float *xloc, *xglo;            // [nb][ncols][256], [nb][Nc][256]
+    const SgrGroupMeta *meta;
+    int64_t n_groups, nb, Nc, ncols;
+    const float4 *wq[8], *wg[8];         // fragment-ordered folded query weight / graph weight of every step
+    const float *vq[8], *bg[8];
+    int steps;
+    const float *eval_w, *eval_b;
+    float *S;
+    int64_t ldS, img_index0;
+    unsigned long long *trace;           // debug (ITR_SGR_TRACE): [grid][16] = hardware id, s_memtime at entry / after the load / after every phase
+};
+
+#define SF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// Weight-fragment loads of the projections go through inline asm with their own s_waitcnt: hipcc sinks a plain load next to its
+// first use (the loop then opened every k-block with an exposed L2 round trip: "global_load ...; s_waitcnt vmcnt(2); v_mfma"),
+// an asm load stays where it is written -- one k-block (8 NG MFMAs) ahead of its consumer.  The destination is opaque to the
+// compiler until SF_WAIT_VM names it ("+v": no consumer is scheduled above the wait; tests/test_isa_audit.py checks that no compiler
+// instruction touches the registers in between).
+#define SF_GLOAD(dst, ptr, imm) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "i"(imm))
+#define SF_LREAD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define SF_WAIT_ALL(x, y) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x), "+v"(y))
+#define SF_WAIT_ALL1(x) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x))
+#define SF_OPAQUE(x) asm volatile("" : "+v"(x))
+
+// One 16-wide k-block of a projection: requests block KS + 1 (weights from L2, node fragments from LDS -- both through asm: hipcc
+// also delays plain LDS reads to the block that uses them), runs the 8 NG MFMAs of block KS, waits.
+template <int KS, int NG>
+__device__ __forceinline__ void sf_kblock(unsigned baddr, const float4 *const (&wp)[2][4], f32x4 (&acc0)[NG], f32x4 (&acc1)[NG],
+                                          f32x4 &a0, f32x4 &a1, f32x4 (&b)[NG], const float4 *nxt, f32x4 &x0, f32x4 &x1) {
+    f32x4 n0, n1;
+    f32x4 nb[NG];
+    if constexpr (KS == 15) {
+        // the first fragments of the NEXT projection (they depend on nothing computed here): requested behind the last block's
+        // MFMAs, waited for right after them, so the next phase opens with MFMAs instead of an L2 round trip after its barrier
+        SF_GLOAD(x0, nxt, 0);
+        SF_GLOAD(x1, nxt + 16 * 64, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (KS < 15) {
+        SF_GLOAD(n0, wp[0][(KS + 1) / 4], ((KS + 1) % 4) * 1024);
+        SF_GLOAD(n1, wp[1][(KS + 1) / 4], ((KS + 1) % 4) * 1024);
+        SF_LREAD(nb[0], baddr, 64 * (KS + 1));
+        if constexpr (NG > 1) SF_LREAD(nb[1], baddr, 16 * SF_LD * 4 + 64 * (KS + 1));
+        if constexpr (NG > 2) SF_LREAD(nb[2], baddr, 2 * 16 * SF_LD * 4 + 64 * (KS + 1));
+        if constexpr (NG > 3) SF_LREAD(nb[3], baddr, 3 * 16 * SF_LD * 4 + 64 * (KS + 1));
+        __builtin_amdgcn_sched_barrier(0);      // the requests stay AHEAD of this block's MFMAs (hipcc otherwise sinks them to the wait)
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng) { acc0[ng] = SF_MFMA(a0[r], b[ng][r], acc0[ng]); acc1[ng] = SF_MFMA(a1[r], b[ng][r], acc1[ng]); }
+    if constexpr (KS < 15) {
+        __builtin_amdgcn_sched_barrier(0);
+        SF_WAIT_ALL(n0, n1);
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng) SF_OPAQUE(nb[ng]);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0; a1 = n1;
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng) b[ng] = nb[ng];
+        sf_kblock<KS + 1, NG>(baddr, wp, acc0, acc1, a0, a1, b, nxt, x0, x1);
+    }
+    if constexpr (KS == 15) {
+        __builtin_amdgcn_sched_barrier(0);
+        SF_WAIT_ALL(x0, x1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// dst[n][o] = act(sum_k W[o][k] src[n][k] + bias[o]) for the node rows of the first NG 16-row groups; this wave's 32 features.
+// src_lds = LDS byte address of the source buffer.  (a0, a1) in: the fragments of k-block 0 (landed); out: those of the projection
+// whose fragment-ordered weight is `wnext`.
+template <int NG, bool RELU>
+__device__ __forceinline__ void sf_project(unsigned src_lds, float *__restrict__ dst, const float4 *__restrict__ wfrag,
+                                           const float *__restrict__ bias, int wave, int lane, f32x4 &a0, f32x4 &a1, const float4 *wnext) {
+    const int fi = lane & 15, fq = lane >> 4;
+    const float4 *w0 = wfrag + (size_t)(2 * wave) * 16 * 64 + lane, *w1 = w0 + 16 * 64;
+    const float4 *const wp[2][4] = {{w0, w0 + 256, w0 + 512, w0 + 768}, {w1, w1 + 256, w1 + 512, w1 + 768}};   // 4 KB apart: 12-bit offsets
+    const unsigned baddr = src_lds + (unsigned)(fi * SF_LD + 4 * fq) * 4u;
+    f32x4 acc0[NG], acc1[NG];
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) { acc0[ng] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[ng] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f32x4 b[NG];
+    SF_LREAD(b[0], baddr, 0);
+    if constexpr (NG > 1) SF_LREAD(b[1], baddr, 16 * SF_LD * 4);
+    if constexpr (NG > 2) SF_LREAD(b[2], baddr, 2 * 16 * SF_LD * 4);
+    if constexpr (NG > 3) SF_LREAD(b[3], baddr, 3 * 16 * SF_LD * 4);
+    SF_WAIT_ALL1(b[0]);
+#pragma unroll
+    for (int ng = 1; ng < NG; ++ng) SF_OPAQUE(b[ng]);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 x0, x1;
+    sf_kblock<0, NG>(baddr, wp, acc0, acc1, a0, a1, b, wnext + (size_t)(2 * wave) * 16 * 64 + lane, x0, x1);
+    a0 = x0; a1 = x1;
+    // 16-pass results of the last MFMAs: the compiler pads its own consumers (no asm reads the accumulators)
+    // accumulator element r of tile t: feature 16 (2 wave + t) + 4 fq + r, node 16 ng + fi  ->  one 16-byte store per tile
+    const float4 bv0 = *reinterpret_cast<const float4 *>(bias + 32 * wave + 4 * fq);
+    const float4 bv1 = *reinterpret_cast<const float4 *>(bias + 32 * wave + 16 + 4 * fq);
+    float *drow = dst + fi * SF_LD + 32 * wave + 4 * fq;
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) {
+        float4 v0{acc0[ng][0] + bv0.x, acc0[ng][1] + bv0.y, acc0[ng][2] + bv0.z, acc0[ng][3] + bv0.w};
+        float4 v1{acc1[ng][0] + bv1.x, acc1[ng][1] + bv1.y, acc1[ng][2] + bv1.z, acc1[ng][3] + bv1.w};
+        if (RELU) {
+            v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+            v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+        }
+        *reinterpret_cast<float4 *>(drow + ng * 16 * SF_LD) = v0;
+        *reinterpret_cast<float4 *>(drow + ng * 16 * SF_LD + 16) = v1;
+    }
+}
+
+template <bool RELU>
+__device__ __forceinline__ void sf_project_n(int ng, unsigned src, float *dst, const float4 *wfrag, const float *bias, int wave, int lane,
+                                             f32x4 &a0, f32x4 &a1, const float4 *wnext) {
+    switch (ng) {
+        case 1: sf_project<1, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
+        case 2: sf_project<2, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
+        case 3: sf_project<3, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
+        default: sf_project<4, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
+    }
+}
+
+// all-reduce over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48) in registers: v_permlane32_swap / v_permlane16_swap
+// exchange halves / odd-even rows of two copies, so two VALU steps replace two LDS-crossbar round trips (ds_bpermute) each
+__device__ __forceinline__ float sf_rows_max(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float sf_rows_sum(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+#define SF_LREAD32(dst, addr, imm) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define SF_WAIT_LGKM1(x) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x))
+
+// One 16-feature block of E^T = X Q'^T for a unit: requests the row fragments of block U + 1 (asm LDS reads, see sf_kblock), runs the
+// 4 NTC MFMAs of block U on TWO accumulators per tile, alternating (a chain of dependent MFMAs runs at 40, not 32, cycles each).
+template <int U, int NTC>
+__device__ __forceinline__ void sf_eblock(unsigned qaddr, const unsigned (&kaddr)[NTC], f32x4 (&e0)[NTC], f32x4 (&e1)[NTC], f32x4 &q, f32x4 (&k)[NTC]) {
+    f32x4 nq, nk[NTC];
+    if constexpr (U < 15) {
+        SF_LREAD(nq, qaddr, 64 * (U + 1));
+#pragma unroll
+        for (int a = 0; a < NTC; ++a) SF_LREAD(nk[a], kaddr[a], 64 * (U + 1));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) { e0[a] = SF_MFMA(k[a][0], q[0], e0[a]); e1[a] = SF_MFMA(k[a][1], q[1], e1[a]); }
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) { e0[a] = SF_MFMA(k[a][2], q[2], e0[a]); e1[a] = SF_MFMA(k[a][3], q[3], e1[a]); }
+    if constexpr (U < 15) {
+        __builtin_amdgcn_sched_barrier(0);
+        SF_WAIT_LGKM1(nq);
+#pragma unroll
+        for (int a = 0; a < NTC; ++a) SF_OPAQUE(nk[a]);
+        __builtin_amdgcn_sched_barrier(0);
+        q = nq;
+#pragma unroll
+        for (int a = 0; a < NTC; ++a) k[a] = nk[a];
+        sf_eblock<U + 1, NTC>(qaddr, kaddr, e0, e1, q, k);
+    }
+}
+
+// P2, first half.  One unit = the 16 query nodes of tile `tile` of caption slot `ci` (tile 0 with query = node 0 only when `last`)
+// against the caption's NTC key tiles: E^T, softmax over the keys, P^T -> LDS (`pt`: NTC tiles of [4 fq][16 fi] float4 -- a lane
+// stores its accumulator registers as they are and the second half reads them back as MFMA B operands).
+template <int NTC>
+__device__ __forceinline__ void sf_attend_e(unsigned xb_lds, unsigned qy_lds, const SgrGroupMeta &m, int ci, int tile, bool last, int lane,
+                                            float4 *__restrict__ pt) {
+    const int fi = lane & 15, fq = lane >> 4;
+    const int nn = m.nn[ci], ws = m.wstart[ci];
+    auto row_of = [&](int n) { n = n < nn ? n : nn - 1; return n == 0 ? ci : ws + n - 1; };   // rows past the graph re-read its last node (masked)
+    const unsigned qaddr = qy_lds + (unsigned)(row_of(last ? 0 : 16 * tile + fi) * SF_LD + 4 * fq) * 4u;
+    unsigned kaddr[NTC];
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) kaddr[a] = xb_lds + (unsigned)(row_of(16 * a + fi) * SF_LD + 4 * fq) * 4u;
+    f32x4 e0[NTC], e1[NTC], q, k[NTC];
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) { e0[a] = f32x4{0.f, 0.f, 0.f, 0.f}; e1[a] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    SF_LREAD(q, qaddr, 0);
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) SF_LREAD(k[a], kaddr[a], 0);
+    SF_WAIT_LGKM1(q);
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) SF_OPAQUE(k[a]);
+    __builtin_amdgcn_sched_barrier(0);
+    sf_eblock<0, NTC>(qaddr, kaddr, e0, e1, q, k);
+    // softmax over the keys j = 16 a + 4 fq + r of column i = fi (Fusionmodule.py:595: softmax(sim_edge, dim=-1))
+    float p[NTC][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < NTC; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = (16 * a + 4 * fq + r < nn) ? e0[a][r] + e1[a][r] : -INFINITY;
+            p[a][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = sf_rows_max(mx);
+    // exp through v_exp_f32 and the reciprocal through v_rcp_f32 (1 ulp each; the weights sum to 1 within 1e-7, far inside the 5e-6
+    // parity budget of the scores): the softmax of a unit is ~40 vector instructions instead of ~150, on the unit's critical path
+    float den = 0.f;
+#pragma unroll
+    for (int a = 0; a < NTC; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p[a][r] = fast_exp(p[a][r] - mx); den += p[a][r]; }
+    den = sf_rows_sum(den);
+    const float inv = fast_rcp(den);
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) pt[a * 64 + lane] = float4{p[a][0] * inv, p[a][1] * inv, p[a][2] * inv, p[a][3] * inv};
+}
+
+// One chunk of a Y task: key tile a = C / 2, feature tiles t = 2 (C % 2) and + 1: 8 A operands (asm LDS reads, requested one chunk
+// ahead -- the 4-bit lgkmcnt allows 15 in flight), 8 MFMAs alternating between two accumulators.
+template <int C, int NTC>
+__device__ __forceinline__ void sf_ychunk(const unsigned (&vaddr)[NTC][4], const float4 (&p)[NTC], f32x4 (&y)[4], float (&cur)[4][2]) {
+    float nxt[4][2];
+    constexpr int a = C / 2, th = C % 2;
+    if constexpr (C + 1 < 2 * NTC) {
+        constexpr int na = (C + 1) / 2, nth = (C + 1) % 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { SF_LREAD32(nxt[r][0], vaddr[na][r], 128 * nth); SF_LREAD32(nxt[r][1], vaddr[na][r], 128 * nth + 64); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    y[2 * th] = SF_MFMA(cur[0][0], p[a].x, y[2 * th]); y[2 * th + 1] = SF_MFMA(cur[0][1], p[a].x, y[2 * th + 1]);
+    y[2 * th] = SF_MFMA(cur[1][0], p[a].y, y[2 * th]); y[2 * th + 1] = SF_MFMA(cur[1][1], p[a].y, y[2 * th + 1]);
+    y[2 * th] = SF_MFMA(cur[2][0], p[a].z, y[2 * th]); y[2 * th + 1] = SF_MFMA(cur[2][1], p[a].z, y[2 * th + 1]);
+    y[2 * th] = SF_MFMA(cur[3][0], p[a].w, y[2 * th]); y[2 * th + 1] = SF_MFMA(cur[3][1], p[a].w, y[2 * th + 1]);
+    if constexpr (C + 1 < 2 * NTC) {
+        __builtin_amdgcn_sched_barrier(0);
+        SF_WAIT_LGKM1(nxt[0][0]);
+        SF_OPAQUE(nxt[0][1]);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) { SF_OPAQUE(nxt[r][0]); SF_OPAQUE(nxt[r][1]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cur[r][0] = nxt[r][0]; cur[r][1] = nxt[r][1]; }
+        sf_ychunk<C + 1, NTC>(vaddr, p, y, cur);
+    }
+}
+
+// P2, second half.  One task = a unit x a quarter of the 256 features: Y^T[d][i] = sum_j X[j][d] P^T[j][i] for d in
+// [64 dq, 64 dq + 64): A = X[row(16 a + 4 fq + r)][64 dq + 16 t + fi], B = the stored softmax registers.  Y overwrites the Q' rows of
+// the unit's query nodes (every E^T of the step is finished: barrier between the halves).
+template <int NTC>
+__device__ __forceinline__ void sf_attend_y(unsigned xb_lds, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int tile, bool last, int dq,
+                                            int lane, const float4 *__restrict__ pt) {
+    const int fi = lane & 15, fq = lane >> 4;
+    const int nn = m.nn[ci], ws = m.wstart[ci];
+    auto row_of = [&](int n) { n = n < nn ? n : nn - 1; return n == 0 ? ci : ws + n - 1; };
+    unsigned vaddr[NTC][4];
+#pragma unroll
+    for (int a = 0; a < NTC; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vaddr[a][r] = xb_lds + (unsigned)(row_of(16 * a + 4 * fq + r) * SF_LD + 64 * dq + fi) * 4u;
+    float4 p[NTC];
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) p[a] = pt[a * 64 + lane];
+    const bool wr = last ? (fi == 0) : (16 * tile + fi < nn);
+    float *yrow = qy + row_of(last ? 0 : 16 * tile + fi) * SF_LD + 64 * dq + 4 * fq;
+    f32x4 y[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cur[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { SF_LREAD32(cur[r][0], vaddr[0][r], 0); SF_LREAD32(cur[r][1], vaddr[0][r], 64); }
+    SF_WAIT_LGKM1(cur[0][0]);
+    SF_OPAQUE(cur[0][1]);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) { SF_OPAQUE(cur[r][0]); SF_OPAQUE(cur[r][1]); }
+    __builtin_amdgcn_sched_barrier(0);
+    sf_ychunk<0, NTC>(vaddr, p, y, cur);
+    if (wr) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<float4 *>(yrow + 16 * t) = float4{y[t][0], y[t][1], y[t][2], y[t][3]};
+    }
+}
+
+__global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char sf_smem[];
+    float *xb = reinterpret_cast<float *>(sf_smem);
+    float *qy = xb + SF_ROWS * SF_LD;
+    SgrGroupMeta &m = *reinterpret_cast<SgrGroupMeta *>(qy + SF_ROWS * SF_LD);
+    float4 *ptile = reinterpret_cast<float4 *>(reinterpret_cast<char *>(&m) + sizeof(SgrGroupMeta));      // [SF_PTILES][64] float4
+    const unsigned xb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)sf_smem;
+    const unsigned qy_lds = xb_lds + (unsigned)(SF_ROWS * SF_LD * sizeof(float));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t grp = blockIdx.x / g.nb, ii = blockIdx.x % g.nb;      // consecutive workgroups: one group, the images of the block
+    unsigned long long tstamp[13];
+    int nstamp = 0;
+#define SF_STAMP() { if (g.trace && nstamp < 13) tstamp[nstamp++] = __builtin_amdgcn_s_memtime(); }
+    SF_STAMP()
+    if (tid < (int)(sizeof(SgrGroupMeta) / 4)) reinterpret_cast<int32_t *>(&m)[tid] = reinterpret_cast<const int32_t *>(g.meta + grp)[tid];
+    __syncthreads();
+    const int ncap = m.ncap, nrows = m.nrows;
+    if (ncap == 0) return;
+    // first weight fragments of the first projection (every later projection receives its own from the one before it)
+    const size_t wfo = (size_t)(2 * wave) * 16 * 64 + lane;
+    f32x4 fa0, fa1;
+    {
+        const float4 t0 = g.wq[0][wfo], t1 = g.wq[0][wfo + 16 * 64];
+        fa0 = f32x4{t0.x, t0.y, t0.z, t0.w};
+        fa1 = f32x4{t1.x, t1.y, t1.z, t1.w};
+    }
+    // ---- node rows -> LDS (one 1 KB row per wave-instruction); rows past the group are zeroed (their products are never read)
+    {
+        float4 v[SF_ROWS / SF_WAVES];
+#pragma unroll
+        for (int k = 0; k < SF_ROWS / SF_WAVES; ++k) {
+            const int r = wave + SF_WAVES * k;
+            v[k] = float4{0.f, 0.f, 0.f, 0.f};
+            if (r < nrows) {
+                const float *src = r < ncap ? g.xglo + (ii * g.Nc + m.row_src[r]) * SF_S : g.xloc + (ii * g.ncols + m.row_src[r]) * SF_S;
+                v[k] = reinterpret_cast<const float4 *>(src)[lane];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SF_ROWS / SF_WAVES; ++k)
+            *reinterpret_cast<float4 *>(xb + (wave + SF_WAVES * k) * SF_LD + 4 * lane) = v[k];
+    }
+    __syncthreads();
+    SF_STAMP()
+    const int ng_all = (nrows + 15) >> 4;
+    for (int k = 0; k < g.steps; ++k) {
+        const bool last = (k == g.steps - 1);
+        sf_project_n<false>(last ? 1 : ng_all, xb_lds, qy, g.wq[k], g.vq[k], wave, lane, fa0, fa1, g.wg[k]);
+        __syncthreads();
+        SF_STAMP()
+        // P2.  Units are sorted by size; unit u goes to wave (u & 7) for u & 7 < 4 and to wave 11 - (u & 7) otherwise (a snake
+        // over the four SIMDs: waves w and w + 4 share one, and share its matrix pipe).
+        const int nu = last ? ncap : m.nunit;
+        for (int u = 0; u < nu; ++u) {
+            const int wv = (u & 7) < 4 ? (u & 7) : 11 - (u & 7);
+            if (wv != wave) continue;
+            const int ci = last ? u : m.unit_cap[u], tile = last ? 0 : m.unit_tile[u];
+            float4 *pt = ptile + (size_t)(last ? m.cap_poff[u] : m.unit_poff[u]) * 64;
+            switch ((m.nn[ci] + 15) >> 4) {
+                case 1: sf_attend_e<1>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+                case 2: sf_attend_e<2>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+                case 3: sf_attend_e<3>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+                default: sf_attend_e<4>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+            }
+        }
+        __syncthreads();
+        // tasks = unit x feature quarter, task t -> wave t & 7: the four quarters of a unit run on four different SIMDs
+        for (int t = wave; t < 4 * nu; t += SF_WAVES) {
+            const int u = t >> 2, dq = t & 3;
+            const int ci = last ? u : m.unit_cap[u], tile = last ? 0 : m.unit_tile[u];
+            const float4 *pt = ptile + (size_t)(last ? m.cap_poff[u] : m.unit_poff[u]) * 64;
+            switch ((m.nn[ci] + 15) >> 4) {
+                case 1: sf_attend_y<1>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
+                case 2: sf_attend_y<2>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
+                case 3: sf_attend_y<3>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
+                default: sf_attend_y<4>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
+            }
+        }
+        __syncthreads();
+        SF_STAMP()
+        sf_project_n<true>(last ? 1 : ng_all, qy_lds, xb, g.wg[k], g.bg[k], wave, lane, fa0, fa1, g.wq[last ? k : k + 1]);
+        __syncthreads();
+        SF_STAMP()
+    }
+    // ---- sim = sigmoid(sim_eval_w . x_0 + b)  (Fusionmodule.py:443-444)
+    const float4 ew = *reinterpret_cast<const float4 *>(g.eval_w + 4 * lane);
+    for (int ci = wave; ci < ncap; ci += SF_WAVES) {
+        const float4 x = *reinterpret_cast<const float4 *>(xb + ci * SF_LD + 4 * lane);
+        float s = x.x * ew.x + x.y * ew.y + x.z * ew.z + x.w * ew.w;
+        s = wave_sum(s) + g.eval_b[0];
+        if (lane == 0) g.S[(g.img_index0 + ii) * g.ldS + m.cap_id[ci]] = 1.f / (1.f + expf(-s));
+    }
+    if (g.trace && tid == 0) {
+        SF_STAMP()
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
+        unsigned long long *t = g.trace + (size_t)blockIdx.x * 16;
+        t[0] = ((unsigned long long)xcc << 32) | hw;
+        t[1] = ((unsigned long long)nrows << 32) | (unsigned)(m.nunit << 8) | (unsigned)ncap;
+        for (int q = 0; q < nstamp; ++q) t[2 + q] = tstamp[q];
+    }
+#undef SF_STAMP
+}
+
+size_t sgr_fused_workspace_bytes(int64_t n_groups, int sgr_step) {
+    return ((size_t)n_groups * sizeof(SgrGroupMeta) + 255) / 256 * 256 + (size_t)sgr_step * 2 * SF_S * SF_S * 4 + 256;
+}
+
+// One-time preparation per itr_sgraf_scores call: group records + fragment-ordered weights.
+int sgr_fused_prepare(const int32_t *grp_begin, const int32_t *grp_order, int64_t n_groups, const int32_t *cap_len, const int32_t *cap_col,
+                      const float *const *wq, const float *const *wg, int sgr_step, void *ws, int *bad_flag, hipStream_t st) {
+    SgrGroupMeta *meta = static_cast<SgrGroupMeta *>(ws);
+    float4 *frag = reinterpret_cast<float4 *>(static_cast<char *>(ws) + ((size_t)n_groups * sizeof(SgrGroupMeta) + 255) / 256 * 256);
+    hipLaunchKernelGGL(sgr_group_meta_kernel, dim3((unsigned)ceil_div(n_groups, 256)), dim3(256), 0, st, grp_begin, grp_order, cap_len, cap_col,
+                       n_groups, meta, bad_flag);
+    ITR_CHECK_LAUNCH("sgr group meta");
+    for (int k = 0; k < sgr_step; ++k) {
+        hipLaunchKernelGGL(sgr_pack_weight_kernel, dim3(64), dim3(256), 0, st, wq[k], frag + (size_t)(2 * k) * SF_S * SF_S / 4);
+        hipLaunchKernelGGL(sgr_pack_weight_kernel, dim3(64), dim3(256), 0, st, wg[k], frag + (size_t)(2 * k + 1) * SF_S * SF_S / 4);
+    }
+    ITR_CHECK_LAUNCH("sgr pack weights");
+    return ITR_OK;
+}
+
+int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t nb, int64_t Nc, int64_t ncols,
+                     const float *const *vq, const float *const *bg, int sgr_step, const float *eval_w, const float *eval_b, float *S,
+                     int64_t ldS, int64_t img_index0, hipStream_t st) {
+    static bool attr_done = false;   // idempotent: racing callers set the same value
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sgr_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)SF_LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("sgr_fused: cannot reserve %zu B of LDS: %s", SF_LDS_BYTES, hipGetErrorString(e));
+            return ITR_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    if (nb == 0 || n_groups == 0) return ITR_OK;
+    SgrFusedArgs g;
+    memset(&g, 0, sizeof(g));
+    g.xloc = xloc; g.xglo = xglo;
+    g.meta = static_cast<const SgrGroupMeta *>(ws);
+    const float4 *frag = reinterpret_cast<const float4 *>(static_cast<char *>(ws) + ((size_t)n_groups * sizeof(SgrGroupMeta) + 255) / 256 * 256);
+    g.n_groups = n_groups; g.nb = nb; g.Nc = Nc; g.ncols = ncols;
+    for (int k = 0; k < sgr_step; ++k) {
+        g.wq[k] = frag + (size_t)(2 * k) * SF_S * SF_S / 4;
+        g.wg[k] = frag + (size_t)(2 * k + 1) * SF_S * SF_S / 4;
+        g.vq[k] = vq[k];
+        g.bg[k] = bg[k];
+    }
+    g.steps = sgr_step;
+    g.eval_w = eval_w; g.eval_b = eval_b; g.S = S; g.ldS = ldS; g.img_index0 = img_index0;
+    const int64_t grid = n_groups * nb;
+    ITR_REQUIRE(grid < (1ll << 31), "sgr_fused: grid too large");
+    // Debug only (tools/sgr_trace.py): ITR_SGR_TRACE=<file> makes every launch synchronous and rewrites <file> with one record per
+    // workgroup (hardware id, group shape, s_memtime after every phase).
+    static const char *trace_path = getenv("ITR_SGR_TRACE");
+    if (trace_path && *trace_path) {
+        const size_t bytes = (size_t)grid * 16 * sizeof(unsigned long long);
+        ITR_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&g.trace), bytes));
+        ITR_CHECK_HIP(hipMemsetAsync(g.trace, 0, bytes, st));
+        hipLaunchKernelGGL(sgr_fused_kernel, dim3((unsigned)grid), dim3(SF_THREADS), SF_LDS_BYTES, st, g);
+        ITR_CHECK_LAUNCH("sgr_fused");
+        ITR_CHECK_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> host((size_t)grid * 16);
+        ITR_CHECK_HIP(hipMemcpy(host.data(), g.trace, bytes, hipMemcpyDeviceToHost));
+        ITR_CHECK_HIP(hipFree(g.trace));
+        if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 1, bytes, f); fclose(f); }
+        return ITR_OK;
+    }
+    hipLaunchKernelGGL(sgr_fused_kernel, dim3((unsigned)grid), dim3(SF_THREADS), SF_LDS_BYTES, st, g);
+    ITR_CHECK_LAUNCH("sgr_fused");
+    return ITR_OK;
+}
+
+}  // namespace itr

@@ -11,6 +11,7 @@
 //      (q' = (Wk^T Wq) x + Wk^T bq, see below), MFMA pair kernel softmax(q' X^T) X, graph GEMM; sigmoid(sim_eval_w) (:443-444)
 // The global nodes img_glo / cap_glo (VisualSA :491-507, TextSA :543-559) are computed once per call.
 #include "scan_common.h"
+#include <stdlib.h>
 
 namespace itr {
 
@@ -30,6 +31,13 @@ int scan_scores_impl(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, 
 
 int sgraf_loc_fused(const float *P, const float *cn, const float *img, const float *wtiled, const float *W, const float *bias,
                     float *X, int64_t nb, int64_t n_tiles, int D, hipStream_t st);
+// sgr_fused.hip: all graph-reasoning steps of a group of captions in one workgroup
+size_t sgr_fused_workspace_bytes(int64_t n_groups, int sgr_step);
+int sgr_fused_prepare(const int32_t *grp_begin, const int32_t *grp_order, int64_t n_groups, const int32_t *cap_len, const int32_t *cap_col,
+                      const float *const *wq, const float *const *wg, int sgr_step, void *ws, int *bad_flag, hipStream_t st);
+int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t nb, int64_t Nc, int64_t ncols,
+                     const float *const *vq, const float *const *bg, int sgr_step, const float *eval_w, const float *eval_b, float *S,
+                     int64_t ldS, int64_t img_index0, hipStream_t st);
 
 constexpr float BN_EPS = 1e-5f;
 
@@ -413,13 +421,15 @@ extern "C" size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_ro
     const int nbuf = module == 1 ? 3 : 1;                                        // X (+ Q', Y for SGR)
     b += (al((size_t)IB * ncols * S * 4) + al((size_t)IB * Nc * S * 4)) * nbuf;
     if (module == 1) b += al((size_t)S * S * 4) * 2 + (al((size_t)S * S * 4) + al((size_t)S * 4)) * 8;   // W^T scratch, folded query weights
+    if (module == 1 && S == 256) b += al(sgr_fused_workspace_bytes(Nc, 8)) + 256;                       // group records (<= one per caption), weight fragments, flag
     return b;
 }
 
 extern "C" int itr_sgraf_scores(const float *img, const float *words, const int64_t *cap_off, const int32_t *cap_len,
                                 const int32_t *tile_begin_dev, const int32_t *cap_order_dev, int64_t n_tiles,
                                 int64_t Ni, int64_t Nc, int64_t n_rows, int max_len, int R, int D, int S, int module,
-                                int sgr_step, const itr_sgraf_weights *w, float *Sout, int64_t ldS, void *workspace,
+                                int sgr_step, const itr_sgraf_weights *w, const int32_t *node_group_begin_dev,
+                                const int32_t *node_group_order_dev, int64_t n_node_groups, float *Sout, int64_t ldS, void *workspace,
                                 size_t workspace_bytes, itr_stream_t stream) {
     using namespace itr;
     ITR_REQUIRE(img && words && cap_off && cap_len && tile_begin_dev && cap_order_dev && w && Sout && workspace,
@@ -435,6 +445,10 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     if (Ni == 0 || Nc == 0) return ITR_OK;
     hipStream_t st = as_stream(stream);
     const int64_t ncols = n_tiles * SC_NT, IB = sgraf_ib(S);
+    // SGR with the configured sim_dim and a node-group plan: the graph steps run fused (sgr_fused.hip); otherwise step by step
+    ITR_REQUIRE(n_node_groups >= 0 && n_node_groups <= Nc, "itr_sgraf_scores: bad node-group count");
+    const bool fused_sgr = module == 1 && S == 256 && node_group_begin_dev && node_group_order_dev && n_node_groups > 0 &&
+                           !getenv("ITR_SGR_UNFUSED");
 
     // ---- carve
     char *p = static_cast<char *>(workspace);
@@ -461,6 +475,12 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
         Yloc = (float *)take((size_t)IB * ncols * S * 4); Yglo = (float *)take((size_t)IB * Nc * S * 4);
         WqT = (float *)take((size_t)S * S * 4); WkT = (float *)take((size_t)S * S * 4);
         for (int k = 0; k < 8; ++k) { Wfold[k] = (float *)take((size_t)S * S * 4); vfold[k] = (float *)take((size_t)S * 4); }
+    }
+    void *fused_ws = nullptr;
+    int *fused_bad = nullptr;
+    if (module == 1 && S == 256) {
+        fused_ws = take(sgr_fused_workspace_bytes(Nc, 8));
+        fused_bad = (int *)take(256);
     }
     int rc;
 #define SG_TRY(x) { rc = (x); if (rc != ITR_OK) return rc; }
@@ -520,6 +540,12 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
         }
     }
 
+    if (fused_sgr) {
+        ITR_CHECK_HIP(hipMemsetAsync(fused_bad, 0, sizeof(int), st));
+        SG_TRY(sgr_fused_prepare(node_group_begin_dev, node_group_order_dev, n_node_groups, cap_len, cap_col, Wfold, w->sgr_g_w, sgr_step, fused_ws,
+                                 fused_bad, st));
+    }
+
     PairArgs pa{Xglo, Xloc, cap_col, cap_len, Nc, ncols, S};
     for (int64_t i0 = 0; i0 < Ni; i0 += IB) {
         const int64_t nb = (Ni - i0 < IB) ? Ni - i0 : IB;
@@ -546,6 +572,9 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
             hipLaunchKernelGGL(saf_pair_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), 0, st, pa, w->saf_w, w->saf_b, w->saf_bn_w,
                                w->saf_bn_b, w->saf_bn_mean, w->saf_bn_var, w->eval_w, w->eval_b, npairs, Sout, ldS, i0);
             ITR_CHECK_LAUNCH("sgraf saf_pair");
+        } else if (fused_sgr) {
+            SG_TRY(sgr_fused_scores(Xloc, Xglo, fused_ws, n_node_groups, nb, Nc, ncols, vfold, w->sgr_g_b, sgr_step, w->eval_w, w->eval_b, Sout,
+                                    ldS, i0, st));
         } else {
             const int ntmax = (max_len + 1 + 15) / 16;
             ITR_UNSUPPORTED(S % 16 != 0, "itr_sgraf_scores: SGR needs sim_dim %% 16 == 0");

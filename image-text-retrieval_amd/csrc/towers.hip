@@ -212,6 +212,8 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
                            const float *b_hh_rev, int no_txtnorm, int use_abs, int gather_last, float *out,
                            float *out_last, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
     using namespace itr;
+    const bool batch_invariant = (gather_last & ITR_GRU_BATCH_INVARIANT) != 0;
+    gather_last &= ITR_GRU_GATHER_LAST;
     ITR_REQUIRE(tokens && tok_off && len_dev && len_host && embed && w_ih && w_hh && b_ih && b_hh && workspace,
                 "itr_gru_fwd: null pointer");
     ITR_REQUIRE(B >= 1 && n_tok >= 1 && E > 0 && D > 0 && V > 0, "itr_gru_fwd: bad shape");
@@ -235,7 +237,9 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
 
     ITR_CHECK_HIP(hipMemsetAsync(w.bad, 0, sizeof(int), st));
     const int Ep = pad32(E);
-    const int splits_h = (B <= 1024 && !getenv("ITR_GRU_NO_SPLITK")) ? gemm_splitk_choice(B, 3 * D, D) : 1;   // env: A/B switch for tools/
+    // (split-K sums a dot product in slices: the result depends on the batch size through the slice count -- never with
+    // ITR_GRU_BATCH_INVARIANT; the plain kernels all run the same fmaf chain per output element whatever M is)
+    const int splits_h = (B <= 1024 && !batch_invariant && !getenv("ITR_GRU_NO_SPLITK")) ? gemm_splitk_choice(B, 3 * D, D) : 1;   // env: A/B switch for tools/
     hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, Ep, w.x,
                        w.bad);
     ITR_CHECK_LAUNCH("embed_gather");

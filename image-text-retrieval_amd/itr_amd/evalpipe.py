@@ -237,7 +237,7 @@ class GruModelEval:
     def encode_captions(self, tokens_packed, tok_off, lengths_sorted, gather_last=False, out=None):
         return ops.gru_encode(tokens_packed, tok_off, lengths_sorted, self.wt, self.cfg.get('bi_gru', False),
                               no_txtnorm=self.cfg.get('no_txtnorm', False), use_abs=self.cfg.get('txt_use_abs', False),
-                              gather_last=gather_last, out=out)
+                              gather_last=gather_last, out=out, batch_invariant=True)     # every partition of the captions: same bits
 
     # -- whole step for SCAN.  Local inputs:
     #   feats_local [n_img_local, 36, F]          unique images rows [i0, i1)
@@ -334,6 +334,14 @@ class GruModelEval:
         words_all, maxtok, wait = comm.all_gather_rows_async(send, tok_counts)
         cap_off = np.concatenate([offs[q] + q * maxtok for q in range(kw)])
         xa = cfg.get('cross_attn', 't2i')
+        # The own / left / right launches pack the captions into OTHER column tiles than one launch over all of them.  A
+        # pair's score does not depend on the tile its caption sits in for SCAN t2i and SGRAF (every reduction runs in an
+        # order relative to the caption's first word: bit-identical matrices, asserted by the sharded tests) -- but the i2t
+        # kernel sums over a caption's words with indicator MFMAs whose association order follows the caption's column inside
+        # the tile (differences of 1 ulp, a handful of near-tie rank flips at 5k x 25k).  i2t therefore waits for the exchange
+        # and scores all columns in one launch from the same plan as a single process: identical ranks, the exchange
+        # (~2 ms of a 130 ms step at 8 ranks) not hidden.
+        overlap = kw > 1 and (sgraf_weights is not None or xa != 'i2t')
 
         if timers is not None:
             timers['segments'] = []      # (start, end) HIP events around every scoring launch of this step
@@ -366,7 +374,7 @@ class GruModelEval:
         waited = False
         for r0, r1, fblock in blocks:
             img = self.encode_images(fblock)
-            if kw == 1 or waited:
+            if not overlap or waited:
                 if not waited:
                     wait()
                     waited = True

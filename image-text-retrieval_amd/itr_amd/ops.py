@@ -383,6 +383,28 @@ class ScanPlan:
         self.cap_order = h2d(order, device)
         self.cap_len = h2d(k_len.copy(), device)
         self.cap_off = h2d(np.asarray(k_off, dtype=np.int64), device)
+        self._k_len = k_len
+        self._node_groups = None
+
+    def node_groups(self):
+        """SGRAF-SGR's fused graph steps (csrc/sgr_fused.hip): bins of whole captions with at most 64 NODE rows (words + the
+        global node of every caption) and at most 16 captions -- the same best-fit-decreasing planner run on len + 1.
+        -> (group_begin int32[n + 1], group_order int32[Nc_kernel], n) on the device, or None when a caption has more than 63
+        words (its graph does not fit one workgroup)."""
+        if self._node_groups is None:
+            lib = _lib.load()
+            if self.Nc_kernel == 0 or int(self._k_len.max()) + 1 > SCAN_NT:
+                self._node_groups = False
+            else:
+                nodes = np.ascontiguousarray(self._k_len.astype(np.int32) + 1)
+                tb = np.zeros(self.Nc_kernel + 1, dtype=np.int32)
+                order = np.zeros(self.Nc_kernel, dtype=np.int32)
+                nt = C.c_int64(0)
+                _lib.check(lib.itr_scan_plan_tiles(nodes.ctypes.data_as(C.c_void_p), self.Nc_kernel, SCAN_NT, tb.ctypes.data_as(C.c_void_p),
+                                                   order.ctypes.data_as(C.c_void_p), C.byref(nt)))
+                n = int(nt.value)
+                self._node_groups = (h2d(tb[:n + 1].copy(), self.device), h2d(order, self.device), n)
+        return self._node_groups or None
 
 
 def scan_prepare(images, words, plan, cross_attn='t2i'):
@@ -672,9 +694,11 @@ def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, ou
             wsb = lib.itr_sgraf_workspace_bytes(Ni, plan.Nc_kernel, words.shape[0], plan.n_tiles, D, S_dim, mod)
             ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
             max_len = int(plan.len_host[plan.short_idx].max())
+            grp = plan.node_groups() if mod == 1 else None
             _lib.check(lib.itr_sgraf_scores(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
                                             _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc_kernel, words.shape[0], max_len, R, D, S_dim,
-                                            mod, int(sgr_step), C.byref(st), _p(part), part.stride(0), _p(ws), wsb, _stream()))
+                                            mod, int(sgr_step), C.byref(st), _p(grp[0]) if grp else None, _p(grp[1]) if grp else None,
+                                            grp[2] if grp else 0, _p(part), part.stride(0), _p(ws), wsb, _stream()))
             out[:, torch.from_numpy(plan.short_idx).to(dev)] = part
         sim_enc = Fusionmodule.EncoderSimilarity(D, S_dim, module_name, sgr_step)
         own = sim_enc.state_dict()
@@ -691,9 +715,11 @@ def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, ou
                                                                                                    training=False)
         return out
     max_len = int(plan.len_host.max()) if plan.Nc else 1
+    grp = plan.node_groups() if mod == 1 else None      # SGR: the graph steps of a group of captions run in one workgroup
     _lib.check(lib.itr_sgraf_scores(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
                                     _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc, words.shape[0], max_len, R, D, S_dim,
-                                    mod, int(sgr_step), C.byref(st), _p(out), out.stride(0), _p(ws), wsb, _stream()))
+                                    mod, int(sgr_step), C.byref(st), _p(grp[0]) if grp else None, _p(grp[1]) if grp else None,
+                                    grp[2] if grp else 0, _p(out), out.stride(0), _p(ws), wsb, _stream()))
     return out
 
 
@@ -706,12 +732,13 @@ def sgraf_padded(images, captions, cap_lens, weights, module_name='SAF', sgr_ste
 
 
 def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtnorm=False, use_abs=False,
-               gather_last=False, out=None):
+               gather_last=False, out=None, batch_invariant=False):
     """EncoderText.forward on packed captions (TextEncoder.py:38-70).
     tokens_packed (n_tok,) int64 cuda; tok_off (B,) int64; lengths: host list sorted descending.
     weights: dict with the reference's state_dict names.  -> (n_tok, D) packed word embeddings, or
     (B, D) when gather_last.  `out`: the caller's contiguous (n_tok, D) / (B, D) result buffer -- e.g. the head of the
-    send buffer of the sharded evaluation's all-gather (evalpipe.py)."""
+    send buffer of the sharded evaluation's all-gather (evalpipe.py).  batch_invariant: a caption's embedding does not
+    depend, bit for bit, on which other captions share its batch (ITR_GRU_BATCH_INVARIANT, include/itr_hip.h)."""
     lib = _lib.load()
     tokens_packed = _dev(tokens_packed, torch.int64, "tokens")
     len_host = _host_i32(lengths)
@@ -745,7 +772,7 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
     out_last = (res if res is not None else torch.empty(B, D, device=dev, dtype=torch.float32)) if gather_last else None
     _lib.check(lib.itr_gru_fwd(_p(tokens_packed), _p(tok_off), _p(len_dev), len_host.ctypes.data_as(C.c_void_p), B,
                                n_tok, _p(emb), V, E, D, _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), _p(rev[0]),
-                               _p(rev[1]), _p(rev[2]), _p(rev[3]), int(no_txtnorm), int(use_abs), int(gather_last),
+                               _p(rev[1]), _p(rev[2]), _p(rev[3]), int(no_txtnorm), int(use_abs), int(bool(gather_last)) | (2 if batch_invariant else 0),
                                _p(out), _p(out_last), _p(ws), wsb, _stream()))
     return out_last if gather_last else out
 

@@ -113,9 +113,14 @@ int itr_proj_l2norm(const float *x, const float *W, const float *b, float *out, 
  * (int64 ids, device) and of `out` (fp32 [n_tok, D]).  Captions must be sorted by length
  * DESCENDING (collate_fn does this, data_loader.py:146).  Host arrays: len_host[B].
  * w_ih [3D,E], w_hh [3D,D], b_ih/b_hh [3D] with torch gate order (r,z,n); *_rev = NULL for a
- * uni-directional GRU.  gather_last != 0 writes only the len-1 state of every caption to
- * out_last[B,D] (method_name in {VSE++,VSRN}, TextEncoder.py:57-60) -- `out` may be NULL then.
+ * uni-directional GRU.  gather_last is a flag word: bit 0 (ITR_GRU_GATHER_LAST) writes only the len-1 state of every
+ * caption to out_last[B,D] (method_name in {VSE++,VSRN}, TextEncoder.py:57-60) -- `out` may be NULL then; bit 1
+ * (ITR_GRU_BATCH_INVARIANT) makes a caption's result independent of the batch it is encoded in, bit for bit (the
+ * recurrence GEMM of a small batch is otherwise split along K, which sums in another order): the sharded evaluation
+ * sets it so that every partition of the caption axis gives the single-process rank vectors.
  * workspace: itr_gru_workspace_bytes(n_tok, B, E, D, bi) bytes. */
+#define ITR_GRU_GATHER_LAST 1
+#define ITR_GRU_BATCH_INVARIANT 2
 size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional);
 int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev,
                 const int32_t *len_host, int64_t B, int64_t n_tok, const float *embed, int64_t V,
@@ -226,7 +231,11 @@ int itr_camera_summarize(const float *smry, const float *X, float *out, int64_t 
  * img [Ni,36,D] (l2-normalised regions), words [n_rows,D] with the caption layout of the SCAN entry points
  * (cap_off / cap_len / tile plan from itr_scan_plan_tiles on the word lengths).  module: 0 = SAF, 1 = SGR.
  * weights: device pointers named after the reference's state_dict (row-major [out,in] like nn.Linear).
- * S[i,c] in (0,1).  max_len = longest caption (<= 63).  workspace: itr_sgraf_workspace_bytes(...). */
+ * S[i,c] in (0,1).  max_len = longest caption (<= 63).  workspace: itr_sgraf_workspace_bytes(...).
+ * node_group_*: optional plan for SGR's fused graph steps (GraphReasoning x sgr_step, Fusionmodule.py:564-597, in one
+ * workgroup per group of captions): itr_scan_plan_tiles run on (cap_len[c] + 1) -- the node count of caption c's graph --
+ * gives bins of whole captions with <= 64 node rows and <= 16 captions; pass its tile_begin / cap_order arrays (device
+ * copies) and the bin count.  NULL / 0: the steps run one kernel chain per step (also taken for sim_dim != 256). */
 typedef struct {
     /* v_global_w (VisualSA :464-507) */
     const float *v_loc_w, *v_loc_b, *v_loc_bn_w, *v_loc_bn_b, *v_loc_bn_mean, *v_loc_bn_var; /* Linear[D,D], BN(36) */
@@ -246,7 +255,8 @@ size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_rows, int64_t
 int itr_sgraf_scores(const float *img, const float *words, const int64_t *cap_off, const int32_t *cap_len,
                      const int32_t *tile_begin_dev, const int32_t *cap_order_dev, int64_t n_tiles,
                      int64_t Ni, int64_t Nc, int64_t n_rows, int max_len, int R, int D, int S, int module,
-                     int sgr_step, const itr_sgraf_weights *w, float *S_out, int64_t ldS, void *workspace,
+                     int sgr_step, const itr_sgraf_weights *w, const int32_t *node_group_begin_dev,
+                     const int32_t *node_group_order_dev, int64_t n_node_groups, float *S_out, int64_t ldS, void *workspace,
                      size_t workspace_bytes, itr_stream_t stream);
 
 /* diagnostics (tools/): occupancy of the SCAN kernel as reported by the HIP runtime */

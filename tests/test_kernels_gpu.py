@@ -354,6 +354,69 @@ def test_sgraf_random_vs_oracle(dev, mod, Ni, Nc, D, S):
     assert maxdiff(got, want) <= 5e-6
 
 
+def _sgraf_weights(D, S, steps, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    w = {}
+    def lin(name, o, i):
+        r = float(np.sqrt(6.0 / (i + o)))
+        w[name + ".weight"] = (torch.rand(o, i, generator=g) * 2 - 1) * r
+        w[name + ".bias"] = torch.randn(o, generator=g) * 0.02
+    def bn(name, n):
+        w[name + ".weight"] = torch.rand(n, generator=g) * 0.4 + 0.8; w[name + ".bias"] = torch.randn(n, generator=g) * 0.05
+        w[name + ".running_mean"] = torch.randn(n, generator=g) * 0.1; w[name + ".running_var"] = torch.rand(n, generator=g) + 0.5
+    lin("v_global_w.embedding_local.0", D, D); bn("v_global_w.embedding_local.1", 36)
+    lin("v_global_w.embedding_global.0", D, D); bn("v_global_w.embedding_global.1", D)
+    lin("v_global_w.embedding_common.0", 1, D)
+    lin("t_global_w.embedding_local.0", D, D); lin("t_global_w.embedding_global.0", D, D); lin("t_global_w.embedding_common.0", 1, D)
+    lin("sim_tranloc_w", S, D); lin("sim_tranglo_w", S, D); lin("sim_eval_w", 1, S)
+    for k in range(steps):
+        for nm in ("graph_query_w", "graph_key_w", "sim_graph_w"):
+            lin("SGR_module.sgr%d.%s" % (k, nm), S, S)
+    return w
+
+
+@pytest.mark.parametrize("case,steps", [("mixed", 3), ("long", 3), ("tiny", 2), ("single", 1), ("uniform", 3), ("tiles", 3)])
+def test_sgr_fused_graph_steps(dev, case, steps):
+    """csrc/sgr_fused.hip (all graph-reasoning steps of a group of captions in one workgroup; GraphReasoning.forward,
+    Fusionmodule.py:564-597) against the CPU oracle AND against the step-by-step kernel chain it replaces
+    (ITR_SGR_UNFUSED=1), on caption sets that exercise the group plan: graphs of 1..4 node tiles in one group (captions of up
+    to 63 words), groups of sixteen one- and two-word captions (every row of the first 16 a global node), a single caption,
+    sgr_step 1 / 2 / 3 (the last step only computes node 0; with one step it is also the first)."""
+    import os
+    rng = np.random.RandomState(11)
+    torch.manual_seed(11)
+    D, S = 64, 256
+    if case == "mixed":
+        lens = [int(x) for x in rng.randint(1, 40, size=37)] + [63, 48, 33, 32, 31, 17, 16, 15, 1]
+    elif case == "long":
+        lens = [63, 62, 50, 47, 63, 40]
+    elif case == "tiny":
+        lens = [1] * 23 + [2] * 19 + [3] * 5
+    elif case == "single":
+        lens = [9]
+    elif case == "tiles":      # the groups with the most softmax tiles: a 33-node graph + fifteen 2-node ones (24), a 49-node graph + seven (23)
+        lens = [32] + [1] * 15 + [48] + [1] * 7 + [16, 16, 16, 12]
+    else:
+        lens = [13] * 41
+    Ni, Nc, L = 19, len(lens), max(lens)
+    img = O.l2norm(torch.randn(Ni, 36, D), -1)
+    cap = O.l2norm(torch.randn(Nc, L, D), -1)
+    w = _sgraf_weights(D, S, steps)
+    wd = {k: v.to(dev) for k, v in w.items()}
+    want = O.sgraf_similarity(w, img, cap, lens, 'SGR', steps)
+    got = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
+    assert maxdiff(got, want) <= 5e-6
+    os.environ["ITR_SGR_UNFUSED"] = "1"
+    try:
+        chain = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
+    finally:
+        del os.environ["ITR_SGR_UNFUSED"]
+    assert maxdiff(chain, want) <= 5e-6
+    assert float((got - chain).abs().max()) <= 2e-6            # two summation orders of the same fp32 arithmetic
+    again = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
+    assert torch.equal(again, got)                              # run-to-run bit-identical
+
+
 # ------------------------------------------------------------------------------------------ GRU
 def pack(ids, lengths, dev):
     toks = torch.cat([ids[b, :l] for b, l in enumerate(lengths)]).to(dev)

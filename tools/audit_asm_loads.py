@@ -136,11 +136,18 @@ def transfer(block, inflight, report):
                 dst = regs_of(code.split(",")[0])
                 for r in dst:
                     st[r] = "%s: %s" % (block.label, code.strip())
-            elif op == "s_waitcnt" and "vmcnt" in code:
+            elif op.startswith("ds_read"):        # asm LDS reads (sgr_fused.hip): in flight until an asm lgkmcnt(0)
+                for r in regs_of(code.split(",")[0]):
+                    st[r] = "lds %s: %s" % (block.label, code.strip())
+            elif op == "s_waitcnt" and ("vmcnt" in code or "lgkmcnt" in code):
                 cov = s.split("covers", 1)[1] if "covers" in s else None
                 if cov is None:
                     if "vmcnt(0)" in code:
-                        st.clear()
+                        for r in [r for r, w in st.items() if not w.startswith("lds ")]:
+                            st.pop(r)
+                    if "lgkmcnt(0)" in code:
+                        for r in [r for r, w in st.items() if w.startswith("lds ")]:
+                            st.pop(r)
                 else:
                     for r in regs_of(cov):
                         st.pop(r, None)
