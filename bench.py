@@ -136,6 +136,35 @@ def cpu_baseline(wl, wi, wt, feats_cpu, lengths, tokens, n_img_s, seconds_cap=60
                        % (n_img_s, n_cap_s, dt)), S, ranks
 
 
+def scan_sustained_clock(model, feats_local, toks, tok_off, lens_sorted, order, cfg, dev):
+    """Shader clock the chip sustains UNDER the SCAN kernel (MI355X is power-managed: the fp32-MFMA loop runs below the 2 400 MHz
+    the peak is quoted at).  One extra, untimed launch with ITR_SCAN_DEBUG=16: every workgroup adds its s_memtime (shader cycles)
+    and s_memrealtime (100 MHz) deltas into eight counters at the head of a scratch score buffer; clock = cycles / realtime.
+    (The stamps themselves cost the kernel a few percent: the launch is not the timed one.)"""
+    from itr_amd import ops
+    img = model.encode_images(feats_local)
+    words_sorted = model.encode_captions(toks, tok_off, lens_sorted)
+    lens = np.zeros(len(lens_sorted), np.int64)
+    off = np.zeros(len(lens_sorted), np.int64)
+    ls = np.asarray(lens_sorted, np.int64)
+    lens[np.asarray(order)] = ls
+    off[np.asarray(order)] = np.cumsum(ls) - ls
+    plan = ops.ScanPlan(off, lens, words_sorted.shape[0], dev)
+    xa = cfg.get("cross_attn", "t2i")
+    ws = ops.scan_prepare(img, words_sorted, plan, xa)
+    scratch = torch.zeros(img.shape[0], plan.Nc + 64, device=dev)
+    os.environ["ITR_SCAN_DEBUG"] = "16"
+    try:
+        ops.scan_xattn_scores(img, words_sorted, plan, cross_attn=xa, raw_feature_norm=cfg.get("raw_feature_norm", "clipped_l2norm"),
+                              agg_func=cfg.get("agg_func", "LogSumExp"), lambda_lse=cfg.get("lambda_lse", 6.0),
+                              lambda_softmax=cfg.get("lambda_softmax", 9.0), out=scratch, workspace=ws)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["ITR_SCAN_DEBUG"]
+    c = scratch.view(torch.int64).flatten()[:8].cpu().numpy().astype(np.float64)
+    return 100.0 * c[:7].sum() / c[7] if c[7] > 0 else None
+
+
 def pmc_traffic(workload, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN/scan_pmc.json;
     FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md).  bench.py cannot collect PMC counters itself (they need their own
@@ -629,6 +658,7 @@ def main():
             "metric": "pairs/sec scored (5k img x 25k cap) + Recall@1 parity, 1/2/4/8 MI355X",
             "value": pairs / (dt / args.steps), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "step_ms": [round(x, 2) for x in step_ms],
+            "step_ms_drift": round(step_ms[-1] - step_ms[0], 2) if len(step_ms) > 1 else 0.0,      # > 0: the chip clocks down as it warms up
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": args.workload, "scorer": model_name,
@@ -655,6 +685,14 @@ def main():
             out["virtual_split"] = "%d:%d" % (comm.cap_world, comm.cap_rank)
             out["config"]["parallelism"] = "1 process, caption axis split over %d virtual owners (this one: %d): TEST HOOK, time is not a result" % (
                 comm.cap_world, comm.cap_rank)
+        if world == 1 and not is_sgraf and "scan_precision" not in wl and not comm.virtual:
+            # the peak is quoted at 2 400 MHz; the chip sustains less under this kernel (power management): measured in-kernel
+            mhz = scan_sustained_clock(model, feats_local, toks, tok_off, lens_sorted, order, cfg, dev)
+            if mhz:
+                out["roofline"]["sustained_clock_mhz"] = mhz
+                out["roofline"]["frac_of_sustained_clock_peak"] = out["roofline"]["frac"] * 2400.0 / mhz
+                out["roofline"]["clock_note"] = ("s_memtime / s_memrealtime summed over every workgroup of one extra instrumented launch; "
+                                                 "frac uses the 2 400 MHz peak, frac_of_sustained_clock_peak the clock the chip actually ran at")
         if world == 1 and not is_sgraf and "scan_precision" not in wl and not args.no_variants and not comm.virtual:
             # Reported NEXT TO the exact-fp32 metric, never instead of it: the same step with the region x word dot
             # products from split fp16 operands (hi.hi + hi.lo' + lo'.hi, fp32 accumulation) -- outside the timed region above
