@@ -107,7 +107,7 @@ struct SgrFusedArgs {
     const float *eval_w, *eval_b;
     float *S;
     int64_t ldS, img_index0;
-    unsigned long long *trace;           // debug (ITR_SGR_TRACE): [grid][16] = hardware id, s_memtime at entry / after the load / after every phase
+    unsigned long long *trace;           // debug (ITR_SGR_TRACE): [grid][20] = hardware id, group shape, s_memtime at entry / after the load / after every phase
 };
 
 #define SF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -319,14 +319,14 @@ __device__ __forceinline__ void sf_attend_e(unsigned xb_lds, unsigned qy_lds, co
 
 // One chunk of a Y task: key tile a = C / 2, feature tiles t = 2 (C % 2) and + 1: 8 A operands (asm LDS reads, requested one chunk
 // ahead -- the 4-bit lgkmcnt allows 15 in flight), 8 MFMAs alternating between two accumulators.
-template <int C, int NTC>
+template <int C, int NTC, int H>
 __device__ __forceinline__ void sf_ychunk(const unsigned (&vaddr)[NTC][4], const float4 (&p)[NTC], f32x4 (&y)[4], float (&cur)[4][2]) {
     float nxt[4][2];
     constexpr int a = C / 2, th = C % 2;
     if constexpr (C + 1 < 2 * NTC) {
         constexpr int na = (C + 1) / 2, nth = (C + 1) % 2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { SF_LREAD32(nxt[r][0], vaddr[na][r], 128 * nth); SF_LREAD32(nxt[r][1], vaddr[na][r], 128 * nth + 64); }
+        for (int r = 0; r < 4; ++r) { SF_LREAD32(nxt[r][0], vaddr[na][r], H + 128 * nth); SF_LREAD32(nxt[r][1], vaddr[na][r], H + 128 * nth + 64); }
         __builtin_amdgcn_sched_barrier(0);
     }
     y[2 * th] = SF_MFMA(cur[0][0], p[a].x, y[2 * th]); y[2 * th + 1] = SF_MFMA(cur[0][1], p[a].x, y[2 * th + 1]);
@@ -342,15 +342,36 @@ __device__ __forceinline__ void sf_ychunk(const unsigned (&vaddr)[NTC][4], const
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { cur[r][0] = nxt[r][0]; cur[r][1] = nxt[r][1]; }
-        sf_ychunk<C + 1, NTC>(vaddr, p, y, cur);
+        sf_ychunk<C + 1, NTC, H>(vaddr, p, y, cur);
     }
 }
 
-// P2, second half.  One task = a unit x a quarter of the 256 features: Y^T[d][i] = sum_j X[j][d] P^T[j][i] for d in
-// [64 dq, 64 dq + 64): A = X[row(16 a + 4 fq + r)][64 dq + 16 t + fi], B = the stored softmax registers.  Y overwrites the Q' rows of
-// the unit's query nodes (every E^T of the step is finished: barrier between the halves).
+// P2, second half.  One task = a unit x HALF of the 256 features (two quarters of 64, one after the other: the row addresses and
+// the softmax registers are set up once): Y^T[d][i] = sum_j X[j][d] P^T[j][i], A = X[row(16 a + 4 fq + r)][d], B = the stored
+// softmax registers.  Y overwrites the Q' rows of the unit's query nodes (every E^T of the step is finished: barrier between the
+// halves of P2).
+template <int NTC, int H>
+__device__ __forceinline__ void sf_yquarter(const unsigned (&vaddr)[NTC][4], const float4 (&p)[NTC], float *__restrict__ yrow, bool wr) {
+    f32x4 y[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cur[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { SF_LREAD32(cur[r][0], vaddr[0][r], H); SF_LREAD32(cur[r][1], vaddr[0][r], H + 64); }
+    SF_WAIT_LGKM1(cur[0][0]);
+    SF_OPAQUE(cur[0][1]);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) { SF_OPAQUE(cur[r][0]); SF_OPAQUE(cur[r][1]); }
+    __builtin_amdgcn_sched_barrier(0);
+    sf_ychunk<0, NTC, H>(vaddr, p, y, cur);
+    if (wr) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<float4 *>(yrow + H / 4 + 16 * t) = float4{y[t][0], y[t][1], y[t][2], y[t][3]};
+    }
+}
+
 template <int NTC>
-__device__ __forceinline__ void sf_attend_y(unsigned xb_lds, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int tile, bool last, int dq,
+__device__ __forceinline__ void sf_attend_y(unsigned xb_lds, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int tile, bool last, int half,
                                             int lane, const float4 *__restrict__ pt) {
     const int fi = lane & 15, fq = lane >> 4;
     const int nn = m.nn[ci], ws = m.wstart[ci];
@@ -359,28 +380,14 @@ __device__ __forceinline__ void sf_attend_y(unsigned xb_lds, float *__restrict__
 #pragma unroll
     for (int a = 0; a < NTC; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vaddr[a][r] = xb_lds + (unsigned)(row_of(16 * a + 4 * fq + r) * SF_LD + 64 * dq + fi) * 4u;
+        for (int r = 0; r < 4; ++r) vaddr[a][r] = xb_lds + (unsigned)(row_of(16 * a + 4 * fq + r) * SF_LD + 128 * half + fi) * 4u;
     float4 p[NTC];
 #pragma unroll
     for (int a = 0; a < NTC; ++a) p[a] = pt[a * 64 + lane];
     const bool wr = last ? (fi == 0) : (16 * tile + fi < nn);
-    float *yrow = qy + row_of(last ? 0 : 16 * tile + fi) * SF_LD + 64 * dq + 4 * fq;
-    f32x4 y[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) y[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float cur[4][2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { SF_LREAD32(cur[r][0], vaddr[0][r], 0); SF_LREAD32(cur[r][1], vaddr[0][r], 64); }
-    SF_WAIT_LGKM1(cur[0][0]);
-    SF_OPAQUE(cur[0][1]);
-#pragma unroll
-    for (int r = 1; r < 4; ++r) { SF_OPAQUE(cur[r][0]); SF_OPAQUE(cur[r][1]); }
-    __builtin_amdgcn_sched_barrier(0);
-    sf_ychunk<0, NTC>(vaddr, p, y, cur);
-    if (wr) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) *reinterpret_cast<float4 *>(yrow + 16 * t) = float4{y[t][0], y[t][1], y[t][2], y[t][3]};
-    }
+    float *yrow = qy + row_of(last ? 0 : 16 * tile + fi) * SF_LD + 128 * half + 4 * fq;
+    sf_yquarter<NTC, 0>(vaddr, p, yrow, wr);
+    sf_yquarter<NTC, 256>(vaddr, p, yrow, wr);
 }
 
 __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g) {
@@ -394,9 +401,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t grp = blockIdx.x / g.nb, ii = blockIdx.x % g.nb;      // consecutive workgroups: one group, the images of the block
-    unsigned long long tstamp[13];
+    unsigned long long tstamp[16];
     int nstamp = 0;
-#define SF_STAMP() { if (g.trace && nstamp < 13) tstamp[nstamp++] = __builtin_amdgcn_s_memtime(); }
+#define SF_STAMP() { if (g.trace && nstamp < 16) tstamp[nstamp++] = __builtin_amdgcn_s_memtime(); }
     SF_STAMP()
     if (tid < (int)(sizeof(SgrGroupMeta) / 4)) reinterpret_cast<int32_t *>(&m)[tid] = reinterpret_cast<const int32_t *>(g.meta + grp)[tid];
     __syncthreads();
@@ -450,9 +457,11 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g
             }
         }
         __syncthreads();
-        // tasks = unit x feature quarter, task t -> wave t & 7: the four quarters of a unit run on four different SIMDs
-        for (int t = wave; t < 4 * nu; t += SF_WAVES) {
-            const int u = t >> 2, dq = t & 3;
+        SF_STAMP()
+        // tasks = unit x feature half, task t -> wave t & 7 (units are sorted by size: waves w and w + 4, which share a SIMD, get the
+        // halves of units two places apart)
+        for (int t = wave; t < 2 * nu; t += SF_WAVES) {
+            const int u = t >> 1, dq = t & 1;
             const int ci = last ? u : m.unit_cap[u], tile = last ? 0 : m.unit_tile[u];
             const float4 *pt = ptile + (size_t)(last ? m.cap_poff[u] : m.unit_poff[u]) * 64;
             switch ((m.nn[ci] + 15) >> 4) {
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g
         SF_STAMP()
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
-        unsigned long long *t = g.trace + (size_t)blockIdx.x * 16;
+        unsigned long long *t = g.trace + (size_t)blockIdx.x * 20;
         t[0] = ((unsigned long long)xcc << 32) | hw;
         t[1] = ((unsigned long long)nrows << 32) | (unsigned)(m.nunit << 8) | (unsigned)ncap;
         for (int q = 0; q < nstamp; ++q) t[2 + q] = tstamp[q];
@@ -542,13 +551,13 @@ int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_g
     // workgroup (hardware id, group shape, s_memtime after every phase).
     static const char *trace_path = getenv("ITR_SGR_TRACE");
     if (trace_path && *trace_path) {
-        const size_t bytes = (size_t)grid * 16 * sizeof(unsigned long long);
+        const size_t bytes = (size_t)grid * 20 * sizeof(unsigned long long);
         ITR_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&g.trace), bytes));
         ITR_CHECK_HIP(hipMemsetAsync(g.trace, 0, bytes, st));
         hipLaunchKernelGGL(sgr_fused_kernel, dim3((unsigned)grid), dim3(SF_THREADS), SF_LDS_BYTES, st, g);
         ITR_CHECK_LAUNCH("sgr_fused");
         ITR_CHECK_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> host((size_t)grid * 16);
+        std::vector<unsigned long long> host((size_t)grid * 20);
         ITR_CHECK_HIP(hipMemcpy(host.data(), g.trace, bytes, hipMemcpyDeviceToHost));
         ITR_CHECK_HIP(hipFree(g.trace));
         if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 1, bytes, f); fclose(f); }

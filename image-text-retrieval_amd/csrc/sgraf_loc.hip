@@ -106,53 +106,59 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
         fb[q] = lds0 + (unsigned)sizeof(sm.a) + (unsigned)(p * LN + wave * 64 + (fi ^ p)) * 16u;               // + 512 j
     }
     f32x16 acc[2][2];
+    const float *bias_lane = g.bias + wave * 64 + 4 * fg;      // the accumulators start at the bias (generated prologue)
     const unsigned long long t_loop0 = g.trace ? __builtin_amdgcn_s_memtime() : 0ull;
     // The D loop: one generated asm statement (tools/gen_sgraf_loc.py has the schedule and the register map).
 #include "sgraf_loc_asm.inc"
     const unsigned long long t_loop1 = g.trace ? __builtin_amdgcn_s_memtime() : 0ull;
 
-    // ---- epilogue: + bias, l2norm over the 256 features of a row (utils.py:10-15, eps 1e-8), store.
-    // acc[i][j][r]: row = i*32 + (r & 3) + 8 (r >> 2) + 4 fg, column = wave*64 + j*32 + fi -- one column per lane, so storing from
-    // the accumulators means 4-byte stores (256 per workgroup and wave...) and a cross-wave exchange for the row norms: tools/
-    // loc_trace.py measured 48 000 cycles per workgroup for that form (15 % of a workgroup's life, during which the CU has ONE
-    // workgroup in the D loop).  The tile goes through the idle operand buffers instead: [64 rows][288] floats (row stride
-    // = 8 mod 16 sixteen-byte slots: the ds_read_b128 lane groups below hit 16 distinct slots), then 8 lanes own a row segment each:
-    // row sum by three lane exchanges, one precise sqrt + divide per row, 16-byte stores of whole 128-byte lines.
-    constexpr int XS_LD = 288;
-    static_assert(LM * XS_LD * 4 <= (int)sizeof(LocSmem), "the output tile fits the operand buffers");
+    // ---- epilogue: l2norm over the 256 features of a row (utils.py:10-15, eps 1e-8), store.
+    // The generated loop multiplies with swapped operands and starts from the bias, so acc[i][j] is the TRANSPOSED tile plus bias:
+    // element r = feature wave*64 + 32 j + 8 (r >> 2) + 4 fg + (r & 3) of node row 32 i + fi -- a lane owns one row per i and runs
+    // of four consecutive features.  What an instruction of this epilogue costs is its issue slot next to the co-resident
+    // workgroup's MFMA stream (~55 cycles each, tools/loc_trace.py: 48 000 cycles per workgroup for the first form, which stored
+    // 4-byte columns and exchanged all row sums through LDS; 25 000 for a version that transposed the tile through LDS), so the
+    // count is what is minimised: packed squares and packed scaling (v_pk_fma_f32 / v_pk_mul_f32 on register pairs), one
+    // v_permlane32_swap per row sum, 4 floats per lane through LDS for the cross-wave sums, sixteen 16-byte stores per lane.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 sq[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v{acc[i][j][r], acc[i][j][r + 1]};
+                sq[i] += v * v;
+            }
+    float ssum[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float s = sq[i][0] + sq[i][1];
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);    // + the other half-wave (fg)
+        ssum[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
     __syncthreads();                                    // every wave is done with the operand buffers
-    float *xs = reinterpret_cast<float *>(smem_raw);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float bv = g.bias[wave * 64 + j * 32 + fi];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                xs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg) * XS_LD + wave * 64 + j * 32 + fi] = acc[i][j][r] + bv;
+    float *part = reinterpret_cast<float *>(smem_raw);  // [64 rows][4 waves]
+    if (fg == 0) {
+        part[(fi) * 4 + wave] = ssum[0];
+        part[(32 + fi) * 4 + wave] = ssum[1];
     }
     __syncthreads();
-    {
-        const int seg = tid & 7;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int row = pass * 32 + (tid >> 3);
-            float4 v[8];
-            float ssq = 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const float4 ps = *reinterpret_cast<const float4 *>(part + (i * 32 + fi) * 4);
+        const float rn = 1.f / (sqrtf((ps.x + ps.y) + (ps.z + ps.w)) + 1e-8f);
+        const f32x2 rn2{rn, rn};
+        float *out = g.X + (row0 + i * 32 + fi) * LN + wave * 64 + 4 * fg;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                v[k] = *reinterpret_cast<const float4 *>(xs + row * XS_LD + 32 * k + 4 * seg);
-                ssq += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                const f32x2 lo = f32x2{acc[i][j][4 * b4], acc[i][j][4 * b4 + 1]} * rn2;
+                const f32x2 hi = f32x2{acc[i][j][4 * b4 + 2], acc[i][j][4 * b4 + 3]} * rn2;
+                *reinterpret_cast<float4 *>(out + 32 * j + 8 * b4) = float4{lo[0], lo[1], hi[0], hi[1]};
             }
-            ssq += __shfl_xor(ssq, 1, 64);
-            ssq += __shfl_xor(ssq, 2, 64);
-            ssq += __shfl_xor(ssq, 4, 64);
-            const float rn = 1.f / (sqrtf(ssq) + 1e-8f);
-            float *out = g.X + (row0 + row) * LN + 4 * seg;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                *reinterpret_cast<float4 *>(out + 32 * k) = float4{v[k].x * rn, v[k].y * rn, v[k].z * rn, v[k].w * rn};
-        }
     }
     if (g.trace && tid == 0) {
         // HW_REG_HW_ID (id 4): cu_id [11:8], sh_id [12], se_id [15:13]; HW_REG_XCC_ID (id 20): xcc_id [3:0]

@@ -101,7 +101,9 @@ def bigs(fset):
         for c in range(4):
             for i in range(2):
                 for j in range(2):
-                    out.append("v_mfma_f32_32x32x2_f32 %s, v%d, v%d, %s" % (acc(i, j), base + q_ * 16 + i * 4 + c, base + q_ * 16 + 8 + j * 4 + c, acc(i, j)))
+                    # operands swapped (W fragment as A, node fragment as B): the accumulator holds the tile TRANSPOSED -- a lane owns
+                    # ONE node row and four runs of four consecutive features, which the epilogue stores as 16-byte rows
+                    out.append("v_mfma_f32_32x32x2_f32 %s, v%d, v%d, %s" % (acc(i, j), base + q_ * 16 + 8 + j * 4 + c, base + q_ * 16 + i * 4 + c, acc(i, j)))
     return out
 
 
@@ -154,15 +156,19 @@ def program():
         ins += ["s_add_u32 s%d, s%d, s%d" % (SW + 2 * s, SW + 2 * s - 2, S_T), "s_addc_u32 s%d, s%d, 0" % (SW + 2 * s + 1, SW + 2 * s - 1)]
     ins += ["s_sub_u32 s%d, %%[nk], 1" % S_REM, "s_mov_b32 s%d, %%[nk]" % S_CNT]
     loads = [load_v(nt, q) for q in range(9) for nt in range(2)] + [load_z(nt, j) for nt in range(2) for j in range(4)] + [load_w(s) for s in range(8)]
+    # the accumulators start at the bias (transposed tile: element r of acc(i, j) is feature wave*64 + 32 j + 8 (r >> 2) + 4 fg + (r & 3),
+    # %[bptr] = &bias[wave*64 + 4 fg]): four 16-byte loads per j into acc(0, j), copied to acc(1, j) below -- 64 adds fewer in the epilogue
+    bias_loads = ["global_load_dwordx4 v[%d:%d], %%[bptr], off offset:%d" % (ACC0 + j * 16 + 4 * b, ACC0 + j * 16 + 4 * b + 3, (32 * j + 8 * b) * 4)
+                  for j in range(2) for b in range(4)]
     # prologue: slice 0 -> LDS buffer 0, slice 1 -> register stage
-    ins += loads + sum(advance(), []) + ["s_waitcnt vmcnt(0)"]
+    ins += loads + bias_loads + sum(advance(), []) + ["s_waitcnt vmcnt(0)"]
     ins += [small(nt, q) for q in range(9) for nt in range(2)] + ["s_nop 15"]
     for nt in range(2):
         for j in range(4):
             ins += sqdiff(nt, j, 0)
     ins += [store_w(s, 0) for s in range(8)]
     ins += loads + sum(advance(), [])
-    ins += ["v_mov_b32 v%d, 0" % r for r in range(ACC0, ACC0 + 64)]
+    ins += ["v_mov_b32 v%d, v%d" % (ACC0 + 32 + r, ACC0 + r) for r in range(32)]          # acc(1, j) = acc(0, j) = bias
     ins += ["s_waitcnt lgkmcnt(0)", "s_barrier"] + fread(0, 0)
     ins += [L("loop") + ":"] + iteration(0)
     ins += ["s_sub_u32 s%d, s%d, 1" % (S_CNT, S_CNT), "s_cmp_eq_u32 s%d, 0" % S_CNT, "s_cbranch_scc1 " + L("done")]
@@ -184,7 +190,7 @@ def render():
     lines.append('          [voffv] "v"(voff_v), [voffz] "v"(voff_z), [voffw] "v"(voff_w), [wst] "v"(wst),')
     lines.append("          " + ", ".join('[ast%d%d] "v"(ast[%d][%d])' % (nt, j, nt, j) for nt in range(2) for j in range(4)) + ",")
     lines.append("          " + ", ".join('[fa%d] "v"(fa[%d])' % (q, q) for q in range(4)) + ", " + ", ".join('[fb%d] "v"(fb[%d])' % (q, q) for q in range(4)) + ",")
-    lines.append('          [vbase] "s"(vbase), [zbase] "s"(zbase), [wbase] "s"(wbase), [rowb] "s"(rowb), [nk] "s"(nk)')
+    lines.append('          [vbase] "s"(vbase), [zbase] "s"(zbase), [wbase] "s"(wbase), [rowb] "s"(rowb), [nk] "s"(nk), [bptr] "v"(bias_lane)')
     clob = ['"memory"', '"scc"'] + ['"s%d"' % s for s in range(S_LO, S_HI + 1)] + ['"v%d"' % r for r in CLOB_V]
     rows, row = [], []
     for c in clob:

@@ -29,14 +29,14 @@ for _ in range(2):
     ops.sgraf_scores(img, words, plan, w, "SGR", 3)
 torch.cuda.synchronize()
 
-rec = np.fromfile(TRACE, dtype=np.uint64).reshape(-1, 16)
+rec = np.fromfile(TRACE, dtype=np.uint64).reshape(-1, 20)
 rec = rec[rec[:, 2] != 0]
 shape = rec[:, 1]
 nrows = (shape >> np.uint64(32)).astype(np.int64)
 nunit = ((shape >> np.uint64(8)) & np.uint64(0xff)).astype(np.int64)
 ncap = (shape & np.uint64(0xff)).astype(np.int64)
-t = rec[:, 2:14].astype(np.int64)          # entry, loaded, 3 x (P1, P2, P3), end
-names = ["load"] + ["step %d %s" % (k, p) for k in range(3) for p in ("P1", "P2", "P3")] + ["final"]
+t = rec[:, 2:17].astype(np.int64)          # entry, loaded, 3 x (P1, P2 scores + softmax, P2 values, P3), end
+names = ["load"] + ["step %d %s" % (k, p) for k in range(3) for p in ("P1", "P2e", "P2y", "P3")] + ["final"]
 d = np.diff(t, axis=1)
 print("workgroups %d   groups %d   mean rows %.1f  captions %.1f  P2 units %.1f" % (len(rec), plan.node_groups()[2], nrows.mean(), ncap.mean(), nunit.mean()))
 ng = (nrows + 15) // 16
