@@ -636,13 +636,20 @@ def main():
             W_ = lengths.astype(np.float64)
             per_img = (4 * 36 * W_ * D + 2 * W_ * D * s_ + 2 * D * s_ + T_ * (6 * (W_ + 1) * s_ ** 2 + 4 * (W_ + 1) ** 2 * s_) + 2 * s_).sum()
             alg_flop = float(i1 - i0) * per_img
-            # executed: the key projection of every graph step is folded into the query weight (softmax_j(q_i.k_j) =
-            # softmax_j((W_k^T q_i).x_j)), so two of K8's three s x s projections per node and step are run
-            exe_flop = alg_flop - float(i1 - i0) * (T_ * 2 * (W_ + 1) * s_ ** 2).sum()
+            # executed: (i) the key projection of every graph step is folded into the query weight (softmax_j(q_i.k_j) =
+            # softmax_j((W_k^T q_i).x_j)), so two of K8's three s x s projections per node and step are run;
+            # (ii) the LAST step only produces node 0 (Fusionmodule.py:443 reads sim_emb[:, 0]): its query and graph projections
+            # run for the global node only (2 x 2 W s^2 less) and its attention for one query row (4 (W+1) s instead of 4 (W+1)^2 s).
+            # (Rounds 1-2 subtracted (i) only: their "executed" fractions counted ~8 % of flop that was never run.)
+            exe_flop = alg_flop
+            if T_:
+                exe_flop -= float(i1 - i0) * (T_ * 2 * (W_ + 1) * s_ ** 2 + 4 * W_ * s_ ** 2 + 4 * (W_ + 1) * W_ * s_).sum()
             model_name = "SGRAF-%s bi-GRU" % wl["sgraf"]
-            kernel_name = "sgraf pair stage (scan_xattn_kernel emit + sgraf_loc_kernel + gemm_nt chain + pair kernels)"
+            kernel_name = ("sgraf pair stage (scan_xattn_kernel emit + sgraf_loc_kernel + " +
+                           ("sgr_fused_kernel: all graph steps of a caption group in one workgroup)" if wl["sgraf"] == "SGR" else "saf_pair_kernel)"))
             note = ("time = the whole itr_sgraf_scores call (global nodes + per-16-image pair stage); algorithmic_* = SURVEY 8d K8; "
-                    "achieved/frac = the flop executed: K8 minus the folded key projection of the SGR steps (nothing is folded for SAF)")
+                    "achieved/frac = the flop executed: K8 minus the folded key projection of the SGR steps and minus the last step's work on "
+                    "nodes other than node 0, which nothing reads (nothing is subtracted for SAF)")
         dtype, peak = "f32", FP32_MFMA_PEAK_TFLOPS
         if wl.get("scan_precision") in ("bf16x3", "fp16x3"):
             half = "bf16" if wl["scan_precision"] == "bf16x3" else "fp16"
