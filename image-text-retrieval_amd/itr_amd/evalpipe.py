@@ -124,6 +124,23 @@ class Comm:
             dist.all_gather(parts, send.cpu(), group=self.group)
             out.copy_(torch.cat(parts, 0))
             return out, maxrows, (lambda: None)
+        if os.environ.get("ITR_EXCHANGE") == "p2p":
+            # Opt-in: the exchange as world - 1 point-to-point sends and receives per rank, batched -- on RCCL one
+            # ncclGroup of ncclSend / ncclRecv pairs, i.e. every xGMI link of the fully connected node carries one block at once,
+            # instead of whatever algorithm RCCL picks for all_gather.  Not the default: it has only ever run over gloo
+            # (tests/test_distributed.py); which of the two is faster on 8 x MI355X is unmeasured.
+            out[self.rank * maxrows:(self.rank + 1) * maxrows].copy_(send)
+            ops_ = []
+            for q in range(self.world):
+                if q != self.rank:
+                    ops_.append(dist.P2POp(dist.isend, send, q, group=self.group))
+                    ops_.append(dist.P2POp(dist.irecv, out[q * maxrows:(q + 1) * maxrows], q, group=self.group))
+            reqs = dist.batch_isend_irecv(ops_)
+
+            def wait_p2p(_r=reqs, _k=send):
+                for r in _r:
+                    r.wait()
+            return out, maxrows, wait_p2p
         if dist.get_backend(self.group) != "nccl":
             dist.all_gather_into_tensor(out, send, group=self.group)
             return out, maxrows, (lambda: None)

@@ -162,3 +162,24 @@ def test_attention_kernel_shapes(dev, L, dk):
     got2 = ops.mha_small(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], None, B, L, heads, dk, scale)
     want2 = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, H)
     assert float((got2.cpu() - want2).abs().max()) <= 2e-6
+
+
+@pytest.mark.gpu
+def test_gelu_epilogue_sweep(dev):
+    """The gelu of the GEMM epilogues (csrc/itr_common.h::gelu_erf: a branch-free erf, tools/fit_erf.py) against
+    x/2 (1 + erf(x / sqrt 2)) in float64 (bert.py:29-34) on a dense sweep of [-9, 9] plus the special values: at least as
+    close to the float64 value as torch's own fp32 gelu, the error bound of the fit, and the IEEE corner cases of the formula."""
+    n = 128 * 2048
+    x = torch.linspace(-9.0, 9.0, n * 64, device=dev).reshape(n, 64).contiguous()
+    eye = torch.eye(64, device=dev)
+    got = ops.linear(x, eye, None, act='gelu').double()         # x @ I = x exactly, then the epilogue's activation
+    xd = x.double()
+    want = 0.5 * xd * (1.0 + torch.erf(xd / np.sqrt(2.0)))
+    err = float((got - want).abs().max())
+    err_torch = float((torch.nn.functional.gelu(x).double() - want).abs().max())
+    assert err <= 6e-7 and err <= err_torch, (err, err_torch)
+    sp = torch.zeros(128, 64, device=dev)                       # one special value per row, in column 0 (the other columns see value * 0)
+    sp[:8, 0] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 40.0, -40.0, float("inf"), float("nan")], device=dev)
+    out = ops.linear(sp, eye, None, act='gelu')[:8, 0].cpu()
+    assert out[0] == 0 and out[1] == 0 and abs(float(out[2])) <= 1e-30 and abs(float(out[3])) <= 1e-30
+    assert float(out[4]) == 40.0 and float(out[5]) == 0.0 and out[6] == float("inf") and bool(torch.isnan(out[7]))
