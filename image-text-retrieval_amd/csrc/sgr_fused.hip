@@ -130,6 +130,11 @@ __device__ __forceinline__ void sf_kblock(unsigned baddr, const float4 *const (&
                                           f32x4 &a0, f32x4 &a1, f32x4 (&b)[NG], const float4 *nxt, f32x4 &x0, f32x4 &x1) {
     f32x4 n0, n1;
     f32x4 nb[NG];
+    // the block's first 2 NG MFMAs go out right behind the wait that closed the previous block; the requests for block KS + 1 are
+    // issued while the matrix pipe works on them (six memory instructions ahead of the first MFMA were ~70 idle cycles per block)
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) { acc0[ng] = SF_MFMA(a0[0], b[ng][0], acc0[ng]); acc1[ng] = SF_MFMA(a1[0], b[ng][0], acc1[ng]); }
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (KS == 15) {
         // the first fragments of the NEXT projection (they depend on nothing computed here): requested behind the last block's
         // MFMAs, waited for right after them, so the next phase opens with MFMAs instead of an L2 round trip after its barrier
@@ -144,10 +149,10 @@ __device__ __forceinline__ void sf_kblock(unsigned baddr, const float4 *const (&
         if constexpr (NG > 1) SF_LREAD(nb[1], baddr, 16 * SF_LD * 4 + 64 * (KS + 1));
         if constexpr (NG > 2) SF_LREAD(nb[2], baddr, 2 * 16 * SF_LD * 4 + 64 * (KS + 1));
         if constexpr (NG > 3) SF_LREAD(nb[3], baddr, 3 * 16 * SF_LD * 4 + 64 * (KS + 1));
-        __builtin_amdgcn_sched_barrier(0);      // the requests stay AHEAD of this block's MFMAs (hipcc otherwise sinks them to the wait)
+        __builtin_amdgcn_sched_barrier(0);      // the requests stay AHEAD of the rest of this block's MFMAs (hipcc otherwise sinks them to the wait)
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 1; r < 4; ++r)
 #pragma unroll
         for (int ng = 0; ng < NG; ++ng) { acc0[ng] = SF_MFMA(a0[r], b[ng][r], acc0[ng]); acc1[ng] = SF_MFMA(a1[r], b[ng][r], acc1[ng]); }
     if constexpr (KS < 15) {
@@ -178,9 +183,12 @@ __device__ __forceinline__ void sf_project(unsigned src_lds, float *__restrict__
     const float4 *w0 = wfrag + (size_t)(2 * wave) * 16 * 64 + lane, *w1 = w0 + 16 * 64;
     const float4 *const wp[2][4] = {{w0, w0 + 256, w0 + 512, w0 + 768}, {w1, w1 + 256, w1 + 512, w1 + 768}};   // 4 KB apart: 12-bit offsets
     const unsigned baddr = src_lds + (unsigned)(fi * SF_LD + 4 * fq) * 4u;
-    f32x4 acc0[NG], acc1[NG];
-#pragma unroll
-    for (int ng = 0; ng < NG; ++ng) { acc0[ng] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[ng] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // The accumulators START at the bias (element r of tile t is feature 16 (2 wave + t) + 4 fq + r for every node column): its two
+    // 16-byte loads are requested here and land with the first node fragments -- a plain load in the epilogue was sunk there by
+    // hipcc and cost an L2 round trip at the end of every phase.
+    f32x4 bv0, bv1;
+    SF_GLOAD(bv0, bias + 32 * wave + 4 * fq, 0);
+    SF_GLOAD(bv1, bias + 32 * wave + 16 + 4 * fq, 0);
     f32x4 b[NG];
     SF_LREAD(b[0], baddr, 0);
     if constexpr (NG > 1) SF_LREAD(b[1], baddr, 16 * SF_LD * 4);
@@ -189,19 +197,22 @@ __device__ __forceinline__ void sf_project(unsigned src_lds, float *__restrict__
     SF_WAIT_ALL1(b[0]);
 #pragma unroll
     for (int ng = 1; ng < NG; ++ng) SF_OPAQUE(b[ng]);
+    SF_OPAQUE(bv0);
+    SF_OPAQUE(bv1);
     __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc0[NG], acc1[NG];
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) { acc0[ng] = bv0; acc1[ng] = bv1; }
     f32x4 x0, x1;
     sf_kblock<0, NG>(baddr, wp, acc0, acc1, a0, a1, b, wnext + (size_t)(2 * wave) * 16 * 64 + lane, x0, x1);
     a0 = x0; a1 = x1;
     // 16-pass results of the last MFMAs: the compiler pads its own consumers (no asm reads the accumulators)
     // accumulator element r of tile t: feature 16 (2 wave + t) + 4 fq + r, node 16 ng + fi  ->  one 16-byte store per tile
-    const float4 bv0 = *reinterpret_cast<const float4 *>(bias + 32 * wave + 4 * fq);
-    const float4 bv1 = *reinterpret_cast<const float4 *>(bias + 32 * wave + 16 + 4 * fq);
     float *drow = dst + fi * SF_LD + 32 * wave + 4 * fq;
 #pragma unroll
     for (int ng = 0; ng < NG; ++ng) {
-        float4 v0{acc0[ng][0] + bv0.x, acc0[ng][1] + bv0.y, acc0[ng][2] + bv0.z, acc0[ng][3] + bv0.w};
-        float4 v1{acc1[ng][0] + bv1.x, acc1[ng][1] + bv1.y, acc1[ng][2] + bv1.z, acc1[ng][3] + bv1.w};
+        float4 v0{acc0[ng][0], acc0[ng][1], acc0[ng][2], acc0[ng][3]};
+        float4 v1{acc1[ng][0], acc1[ng][1], acc1[ng][2], acc1[ng][3]};
         if (RELU) {
             v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
             v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
