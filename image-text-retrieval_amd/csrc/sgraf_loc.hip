@@ -190,11 +190,20 @@ int sgraf_loc_fused(const float *P, const float *cn, const float *img, const flo
     // Debug only (tools/loc_trace.py): ITR_LOC_TRACE=<file> makes every launch synchronous and rewrites <file> with one record
     // per workgroup (hardware id + four s_memtime stamps), from which the tool rebuilds each CU's timeline.
     static const char *trace_path = getenv("ITR_LOC_TRACE");
+    // (experiment: ITR_LOC_ONE_PER_CU=1 asks for 82 KB of LDS, so only one workgroup fits a CU -- the loop's speed without a neighbour)
+    static const size_t lds_bytes = (getenv("ITR_LOC_ONE_PER_CU") && atoi(getenv("ITR_LOC_ONE_PER_CU"))) ? 82 * 1024 : sizeof(LocSmem);
+    if (lds_bytes != sizeof(LocSmem)) {
+        static bool big_done = false;
+        if (!big_done) {
+            ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sgraf_loc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            big_done = true;
+        }
+    }
     if (trace_path && *trace_path) {
         const size_t bytes = (size_t)grid * 5 * sizeof(unsigned long long);
         ITR_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&g.trace), bytes));
         ITR_CHECK_HIP(hipMemsetAsync(g.trace, 0, bytes, st));
-        hipLaunchKernelGGL(sgraf_loc_kernel, dim3((unsigned)grid), dim3(256), sizeof(LocSmem), st, g);
+        hipLaunchKernelGGL(sgraf_loc_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, st, g);
         ITR_CHECK_LAUNCH("sgraf_loc");
         ITR_CHECK_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> host((size_t)grid * 5);
@@ -203,7 +212,7 @@ int sgraf_loc_fused(const float *P, const float *cn, const float *img, const flo
         if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 1, bytes, f); fclose(f); }
         return ITR_OK;
     }
-    hipLaunchKernelGGL(sgraf_loc_kernel, dim3((unsigned)grid), dim3(256), sizeof(LocSmem), st, g);
+    hipLaunchKernelGGL(sgraf_loc_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, st, g);
     ITR_CHECK_LAUNCH("sgraf_loc");
     return ITR_OK;
 }
