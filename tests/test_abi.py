@@ -77,6 +77,46 @@ def test_scan_tile_planner():
     assert rc == 0 and list(tb) == [0, 16, 32, 40]
 
 
+def test_sgr_node_group_plan():
+    """The plan of SGR's fused graph steps (csrc/sgr_fused.hip) is the same planner run on NODE counts (words + the global node):
+    whole captions, at most 64 node rows and 16 captions per group, every caption exactly once; the BASELINE length distribution
+    fills >= 97 % of the rows; and the kernel's softmax scratch (24 tiles of 16 x 16) holds every group the planner can emit:
+    sum over a group's captions of ceil(nodes / 16)^2 <= 24."""
+    rng = np.random.RandomState(1)
+    for lo, hi, n in ((1, 64, 3000), (6, 21, 25000), (1, 3, 500), (30, 64, 200)):
+        lens = rng.randint(lo, hi, size=n)
+        rc, tb, order = plan(lens + 1)
+        assert rc == 0 and sorted(order.tolist()) == list(range(n))
+        worst = 0
+        for a, b in zip(tb[:-1], tb[1:]):
+            nodes = lens[order[a:b]] + 1
+            assert 1 <= b - a <= 16 and nodes.sum() <= 64
+            worst = max(worst, int((((nodes + 15) // 16) ** 2).sum()))
+        assert worst <= 24
+        if (lo, hi) == (6, 21):
+            assert (lens + 1).sum() / (64.0 * (len(tb) - 1)) >= 0.97
+    # the two extreme groups by construction: a 33-node graph + fifteen 2-node ones; a 49-node graph + seven 2-node ones
+    for lens in ([32] + [1] * 15, [48] + [1] * 7):
+        rc, tb, order = plan(np.asarray(lens) + 1)
+        assert rc == 0 and len(tb) == 2
+        assert int((((np.asarray(lens) + 1 + 15) // 16) ** 2).sum()) in (24, 23)
+
+
+def test_gelu_erf_coefficients_are_the_fitted_ones():
+    """csrc/itr_common.h::gelu_erf carries the coefficients tools/fit_erf.py computes (and the error figures its comment quotes)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fit_erf.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    coefs = re.findall(r"(-?\d\.\d{9}e[+-]\d{2})f", r.stdout.splitlines()[0])
+    assert len(coefs) == 8
+    src = open(os.path.join(ROOT, "image-text-retrieval_amd", "csrc", "itr_common.h")).read()
+    for c in coefs:
+        assert c + "f" in src, "coefficient %s of tools/fit_erf.py is not in itr_common.h" % c
+    errs = [float(x) for x in re.findall(r"([0-9.]+e-0[0-9])\s*$", r.stdout, flags=re.M)]
+    assert len(errs) == 2 and errs[0] <= 1.3e-7 and errs[1] <= 5e-7
+
+
 def test_scan_tile_planner_errors():
     lib = _lib.load()
     rc, _, _ = plan([5, 0, 3])
