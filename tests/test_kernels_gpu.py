@@ -375,13 +375,13 @@ def _sgraf_weights(D, S, steps, seed=5):
     return w
 
 
-@pytest.mark.parametrize("case,steps", [("mixed", 3), ("long", 3), ("tiny", 2), ("single", 1), ("uniform", 3), ("tiles", 3)])
+@pytest.mark.parametrize("case,steps", [("mixed", 3), ("long", 3), ("tiny", 2), ("single", 1), ("uniform", 3), ("tiles", 3), ("uniform", 8), ("mixed", 5)])
 def test_sgr_fused_graph_steps(dev, case, steps):
     """csrc/sgr_fused.hip (all graph-reasoning steps of a group of captions in one workgroup; GraphReasoning.forward,
     Fusionmodule.py:564-597) against the CPU oracle AND against the step-by-step kernel chain it replaces
     (ITR_SGR_UNFUSED=1), on caption sets that exercise the group plan: graphs of 1..4 node tiles in one group (captions of up
     to 63 words), groups of sixteen one- and two-word captions (every row of the first 16 a global node), a single caption,
-    sgr_step 1 / 2 / 3 (the last step only computes node 0; with one step it is also the first)."""
+    sgr_step 1 / 2 / 3 / 5 / 8 = the most the ABI takes (the last step only computes node 0; with one step it is also the first)."""
     import os
     rng = np.random.RandomState(11)
     torch.manual_seed(11)
