@@ -50,7 +50,7 @@ static_assert(sizeof(SgrGroupMeta) == 512, "one 512-byte record per group");
 
 constexpr int SF_PTILES = 24;            // softmax tiles (16 x 16 floats) of one group: sum over captions of (key tiles)^2; at most 24 for <= 64
                                          // node rows in <= 16 graphs of >= 2 nodes (one 33-node graph + fifteen 2-node ones: 9 + 15)
-constexpr size_t SF_LDS_BYTES = 2 * SF_ROWS * SF_LD * sizeof(float) + sizeof(SgrGroupMeta) + SF_PTILES * 1024;
+constexpr size_t SF_LDS_BYTES = 2 * SF_ROWS * SF_LD * sizeof(float) + 2 * sizeof(SgrGroupMeta) + SF_PTILES * 1024;   // (the second record: persistent form)
 
 __global__ __launch_bounds__(256) void sgr_group_meta_kernel(const int32_t *__restrict__ grp_begin, const int32_t *__restrict__ grp_order,
                                                              const int32_t *__restrict__ cap_len, const int32_t *__restrict__ cap_col,
@@ -508,6 +508,139 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g
 #undef SF_STAMP
 }
 
+// Persistent form (default; ITR_SGR_PERSISTENT=0 launches one workgroup per (image, group) instead): one workgroup per CU walks
+// the (group, image) list with stride gridDim.x.  What it buys is the 64 KB of node rows of the NEXT item, requested when the last
+// step's attention starts (11 k cycles with nothing else on the vector-memory counter: the k-blocks of the last projection wait
+// with vmcnt(0), and loads complete in order) into 8 registers per lane, and stored into the X buffer after the scores of the
+// current item -- instead of a cold load phase (5-6 k cycles at the ~11 B/clk a CU streams from HBM) and a launch gap (2 k) per item.
+// The next item's group record is fetched by waves 6 and 7 during the first step's score phase.
+__global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_persistent_kernel(SgrFusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char sf_smem[];
+    float *xb = reinterpret_cast<float *>(sf_smem);
+    float *qy = xb + SF_ROWS * SF_LD;
+    SgrGroupMeta *m2 = reinterpret_cast<SgrGroupMeta *>(qy + SF_ROWS * SF_LD);      // two records: current / next item
+    float4 *ptile = reinterpret_cast<float4 *>(reinterpret_cast<char *>(m2) + 2 * sizeof(SgrGroupMeta));
+    const unsigned xb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)sf_smem;
+    const unsigned qy_lds = xb_lds + (unsigned)(SF_ROWS * SF_LD * sizeof(float));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t total = g.n_groups * g.nb;
+    int64_t item = blockIdx.x;
+    if (item >= total) return;
+    int cur = 0;
+    // ---- the first item: group record and node rows the plain way
+    if (tid < (int)(sizeof(SgrGroupMeta) / 4)) reinterpret_cast<int32_t *>(&m2[0])[tid] = reinterpret_cast<const int32_t *>(g.meta + item / g.nb)[tid];
+    __syncthreads();
+    {
+        const SgrGroupMeta &m = m2[0];
+        const int64_t ii = item % g.nb;
+        float4 v[SF_ROWS / SF_WAVES];
+#pragma unroll
+        for (int k = 0; k < SF_ROWS / SF_WAVES; ++k) {
+            const int r = wave + SF_WAVES * k;
+            v[k] = float4{0.f, 0.f, 0.f, 0.f};
+            if (r < m.nrows) {
+                const float *src = r < m.ncap ? g.xglo + (ii * g.Nc + m.row_src[r]) * SF_S : g.xloc + (ii * g.ncols + m.row_src[r]) * SF_S;
+                v[k] = reinterpret_cast<const float4 *>(src)[lane];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SF_ROWS / SF_WAVES; ++k)
+            *reinterpret_cast<float4 *>(xb + (wave + SF_WAVES * k) * SF_LD + 4 * lane) = v[k];
+    }
+    const size_t wfo = (size_t)(2 * wave) * 16 * 64 + lane;
+    f32x4 fa0, fa1;
+    {
+        const float4 t0 = g.wq[0][wfo], t1 = g.wq[0][wfo + 16 * 64];
+        fa0 = f32x4{t0.x, t0.y, t0.z, t0.w};
+        fa1 = f32x4{t1.x, t1.y, t1.z, t1.w};
+    }
+    __syncthreads();
+    for (;;) {
+        const SgrGroupMeta &m = m2[cur];
+        const int ncap = m.ncap, nrows = m.nrows;
+        const int64_t ii = item % g.nb;
+        const int64_t nxt = item + gridDim.x;
+        const bool has_next = nxt < total;                      // workgroup-uniform
+        const int ng_all = (nrows + 15) >> 4;
+        const bool meta_wave = has_next && wave >= 6;
+        f32x4 pre[SF_ROWS / SF_WAVES];
+        if (meta_wave && g.steps == 1)      // a single step is also the last one: the record must be there before its attention phase
+            reinterpret_cast<int32_t *>(&m2[cur ^ 1])[tid - 384] = reinterpret_cast<const int32_t *>(g.meta + nxt / g.nb)[tid - 384];
+        for (int k = 0; k < g.steps; ++k) {
+            const bool last = (k == g.steps - 1);
+            sf_project_n<false>((last || ncap == 0) ? 1 : ng_all, xb_lds, qy, g.wq[k], g.vq[k], wave, lane, fa0, fa1, g.wg[k]);
+            __syncthreads();
+            // the next item's group record: one dword per lane of waves 6 and 7, fetched while the other waves run the first step's
+            // score units (the unit map gives waves 6 and 7 the smallest units, or none)
+            if (k == 0 && meta_wave && g.steps > 1)
+                reinterpret_cast<int32_t *>(&m2[cur ^ 1])[tid - 384] = reinterpret_cast<const int32_t *>(g.meta + nxt / g.nb)[tid - 384];
+            if (last && has_next) {
+                // node rows of the next item -> registers (in flight during the whole attention phase below)
+                const SgrGroupMeta &mn = m2[cur ^ 1];
+                const int64_t iin = nxt % g.nb;
+                // (branch-free: a conditional load makes hipcc merge "loaded | zero" right here -- with a vmcnt(0) in front of it.
+                // Rows past the next group re-read its last row and are zeroed when they are stored.)
+                const int nrn = mn.nrows > 0 ? mn.nrows : 1;
+#pragma unroll
+                for (int q = 0; q < SF_ROWS / SF_WAVES; ++q) {
+                    int r = wave + SF_WAVES * q;
+                    r = r < nrn ? r : nrn - 1;
+                    const float *src = r < mn.ncap ? g.xglo + (iin * g.Nc + mn.row_src[r]) * SF_S : g.xloc + (iin * g.ncols + mn.row_src[r]) * SF_S;
+                    pre[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src) + lane);      // a load hipcc counts: its registers are safe
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int nu = last ? ncap : m.nunit;
+            for (int u = 0; u < nu; ++u) {
+                const int wv = (u & 7) < 4 ? (u & 7) : 11 - (u & 7);
+                if (wv != wave) continue;
+                const int ci = last ? u : m.unit_cap[u], tile = last ? 0 : m.unit_tile[u];
+                float4 *pt = ptile + (size_t)(last ? m.cap_poff[u] : m.unit_poff[u]) * 64;
+                switch ((m.nn[ci] + 15) >> 4) {
+                    case 1: sf_attend_e<1>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+                    case 2: sf_attend_e<2>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+                    case 3: sf_attend_e<3>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+                    default: sf_attend_e<4>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+                }
+            }
+            __syncthreads();
+            for (int t = wave; t < 2 * nu; t += SF_WAVES) {
+                const int u = t >> 1, dq = t & 1;
+                const int ci = last ? u : m.unit_cap[u], tile = last ? 0 : m.unit_tile[u];
+                const float4 *pt = ptile + (size_t)(last ? m.cap_poff[u] : m.unit_poff[u]) * 64;
+                switch ((m.nn[ci] + 15) >> 4) {
+                    case 1: sf_attend_y<1>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
+                    case 2: sf_attend_y<2>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
+                    case 3: sf_attend_y<3>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
+                    default: sf_attend_y<4>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
+                }
+            }
+            __syncthreads();
+            // (the last projection hands over the first fragments of the NEXT item's first projection)
+            sf_project_n<true>((last || ncap == 0) ? 1 : ng_all, qy_lds, xb, g.wg[k], g.bg[k], wave, lane, fa0, fa1, g.wq[last ? 0 : k + 1]);
+            __syncthreads();
+        }
+        const float4 ew = *reinterpret_cast<const float4 *>(g.eval_w + 4 * lane);
+        for (int ci = wave; ci < ncap; ci += SF_WAVES) {
+            const float4 x = *reinterpret_cast<const float4 *>(xb + ci * SF_LD + 4 * lane);
+            float sc = x.x * ew.x + x.y * ew.y + x.z * ew.z + x.w * ew.w;
+            sc = wave_sum(sc) + g.eval_b[0];
+            if (lane == 0) g.S[(g.img_index0 + ii) * g.ldS + m.cap_id[ci]] = 1.f / (1.f + expf(-sc));
+        }
+        if (!has_next) break;
+        __syncthreads();                                        // every wave is done with the X buffer of this item
+#pragma unroll
+        for (int q = 0; q < SF_ROWS / SF_WAVES; ++q) {
+            const bool live = wave + SF_WAVES * q < m2[cur ^ 1].nrows;
+            *reinterpret_cast<f32x4 *>(xb + (wave + SF_WAVES * q) * SF_LD + 4 * lane) = live ? pre[q] : f32x4{0.f, 0.f, 0.f, 0.f};   // (landed long ago)
+        }
+        cur ^= 1;
+        item = nxt;
+        __syncthreads();
+    }
+}
+
 size_t sgr_fused_workspace_bytes(int64_t n_groups, int sgr_step) {
     return ((size_t)n_groups * sizeof(SgrGroupMeta) + 255) / 256 * 256 + (size_t)sgr_step * 2 * SF_S * SF_S * 4 + 256;
 }
@@ -535,6 +668,9 @@ int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_g
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sgr_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)SF_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(sgr_fused_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)SF_LDS_BYTES);
         if (e != hipSuccess) {
             set_error("sgr_fused: cannot reserve %zu B of LDS: %s", SF_LDS_BYTES, hipGetErrorString(e));
             return ITR_ERR_HIP;
@@ -572,6 +708,22 @@ int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_g
         ITR_CHECK_HIP(hipMemcpy(host.data(), g.trace, bytes, hipMemcpyDeviceToHost));
         ITR_CHECK_HIP(hipFree(g.trace));
         if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 1, bytes, f); fclose(f); }
+        return ITR_OK;
+    }
+    const char *pers_env = getenv("ITR_SGR_PERSISTENT");      // (read per call: the tests run both forms in one process)
+    const bool persistent = !(pers_env && atoi(pers_env) == 0);
+    if (persistent) {
+        static int cus_of[16] = {};
+        int dev = 0;
+        ITR_CHECK_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 16 && !cus_of[dev]) {            // (idempotent: racing callers store the same value)
+            hipDeviceProp_t prop;
+            ITR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+            cus_of[dev] = prop.multiProcessorCount;
+        }
+        const int64_t cus = (dev >= 0 && dev < 16 && cus_of[dev] > 0) ? cus_of[dev] : 256;
+        hipLaunchKernelGGL(sgr_fused_persistent_kernel, dim3((unsigned)(grid < cus ? grid : cus)), dim3(SF_THREADS), SF_LDS_BYTES, st, g);
+        ITR_CHECK_LAUNCH("sgr_fused (persistent)");
         return ITR_OK;
     }
     hipLaunchKernelGGL(sgr_fused_kernel, dim3((unsigned)grid), dim3(SF_THREADS), SF_LDS_BYTES, st, g);

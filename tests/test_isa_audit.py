@@ -20,7 +20,7 @@ CASES = [("scan_xattn.hip", ["scan_xattn_kernelILi0E", "scan_xattn_kernelILi1E"]
          ("gemm_f32.hip", ["gemm_nt_fast_kernel"]),
          ("gemm_stream.hip", ["gemm_nt_stream_kernelILb0E", "gemm_nt_stream_kernelILb1E"]),
          ("sgraf_loc.hip", ["sgraf_loc_kernel"]),
-         ("sgr_fused.hip", ["sgr_fused_kernel"])]       # weight fragments AND LDS node fragments through asm (SF_GLOAD / SF_LREAD)
+         ("sgr_fused.hip", ["sgr_fused_kernel", "sgr_fused_persistent_kernel"])]       # weight fragments AND LDS node fragments through asm (SF_GLOAD / SF_LREAD)
 
 
 @pytest.mark.skipif(shutil.which(A.HIPCC) is None and not os.path.exists(A.HIPCC), reason="hipcc not installed")

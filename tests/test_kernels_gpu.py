@@ -415,6 +415,12 @@ def test_sgr_fused_graph_steps(dev, case, steps):
     assert float((got - chain).abs().max()) <= 2e-6            # two summation orders of the same fp32 arithmetic
     again = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
     assert torch.equal(again, got)                              # run-to-run bit-identical
+    os.environ["ITR_SGR_PERSISTENT"] = "0"                      # one workgroup per (image, group) instead of the persistent walk
+    try:
+        per_item = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
+    finally:
+        del os.environ["ITR_SGR_PERSISTENT"]
+    assert torch.equal(per_item, got)                           # same arithmetic per item: bit-identical
 
 
 # ------------------------------------------------------------------------------------------ GRU
