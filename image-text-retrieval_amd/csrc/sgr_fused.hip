@@ -512,7 +512,8 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g
 // the (group, image) list with stride gridDim.x.  What it buys is the 64 KB of node rows of the NEXT item, requested when the last
 // step's attention starts (11 k cycles with nothing else on the vector-memory counter: the k-blocks of the last projection wait
 // with vmcnt(0), and loads complete in order) into 8 registers per lane, and stored into the X buffer after the scores of the
-// current item -- instead of a cold load phase (5-6 k cycles at the ~11 B/clk a CU streams from HBM) and a launch gap (2 k) per item.
+// current item -- instead of a cold load phase (5-6 k cycles at the ~11 B/clk a CU streams from HBM) and a launch gap (2 k) per item
+// (SGR 1k x 5k: 763 -> 753 ms).
 // The next item's group record is fetched by waves 6 and 7 during the first step's score phase.
 __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_persistent_kernel(SgrFusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char sf_smem[];
@@ -564,33 +565,19 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_persistent_kernel(Sgr
         const bool has_next = nxt < total;                      // workgroup-uniform
         const int ng_all = (nrows + 15) >> 4;
         const bool meta_wave = has_next && wave >= 6;
-        f32x4 pre[SF_ROWS / SF_WAVES];
         if (meta_wave && g.steps == 1)      // a single step is also the last one: the record must be there before its attention phase
             reinterpret_cast<int32_t *>(&m2[cur ^ 1])[tid - 384] = reinterpret_cast<const int32_t *>(g.meta + nxt / g.nb)[tid - 384];
-        for (int k = 0; k < g.steps; ++k) {
-            const bool last = (k == g.steps - 1);
+        // a step in two halves, so that the last step can request the next item's rows between them in straight-line code (inside the
+        // step loop hipcc merged "loaded | not loaded" right behind the loads -- with a vmcnt(0))
+        auto step_project_q = [&](int k, bool last) {
             sf_project_n<false>((last || ncap == 0) ? 1 : ng_all, xb_lds, qy, g.wq[k], g.vq[k], wave, lane, fa0, fa1, g.wg[k]);
             __syncthreads();
             // the next item's group record: one dword per lane of waves 6 and 7, fetched while the other waves run the first step's
             // score units (the unit map gives waves 6 and 7 the smallest units, or none)
             if (k == 0 && meta_wave && g.steps > 1)
                 reinterpret_cast<int32_t *>(&m2[cur ^ 1])[tid - 384] = reinterpret_cast<const int32_t *>(g.meta + nxt / g.nb)[tid - 384];
-            if (last && has_next) {
-                // node rows of the next item -> registers (in flight during the whole attention phase below)
-                const SgrGroupMeta &mn = m2[cur ^ 1];
-                const int64_t iin = nxt % g.nb;
-                // (branch-free: a conditional load makes hipcc merge "loaded | zero" right here -- with a vmcnt(0) in front of it.
-                // Rows past the next group re-read its last row and are zeroed when they are stored.)
-                const int nrn = mn.nrows > 0 ? mn.nrows : 1;
-#pragma unroll
-                for (int q = 0; q < SF_ROWS / SF_WAVES; ++q) {
-                    int r = wave + SF_WAVES * q;
-                    r = r < nrn ? r : nrn - 1;
-                    const float *src = r < mn.ncap ? g.xglo + (iin * g.Nc + mn.row_src[r]) * SF_S : g.xloc + (iin * g.ncols + mn.row_src[r]) * SF_S;
-                    pre[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src) + lane);      // a load hipcc counts: its registers are safe
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        };
+        auto step_attend_project_g = [&](int k, bool last) {
             const int nu = last ? ncap : m.nunit;
             for (int u = 0; u < nu; ++u) {
                 const int wv = (u & 7) < 4 ? (u & 7) : 11 - (u & 7);
@@ -620,7 +607,30 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_persistent_kernel(Sgr
             // (the last projection hands over the first fragments of the NEXT item's first projection)
             sf_project_n<true>((last || ncap == 0) ? 1 : ng_all, qy_lds, xb, g.wg[k], g.bg[k], wave, lane, fa0, fa1, g.wq[last ? 0 : k + 1]);
             __syncthreads();
+        };
+        for (int k = 0; k + 1 < g.steps; ++k) {
+            step_project_q(k, false);
+            step_attend_project_g(k, false);
         }
+        step_project_q(g.steps - 1, true);
+        f32x4 pre[SF_ROWS / SF_WAVES];
+        if (has_next) {
+            // node rows of the next item -> registers, in flight during the whole attention phase below.  Branch-free (a conditional
+            // load makes hipcc merge "loaded | zero" right here): rows past the next group re-read its last row and are zeroed when
+            // they are stored.  Loads hipcc counts: their registers are safe.
+            const SgrGroupMeta &mn = m2[cur ^ 1];
+            const int64_t iin = nxt % g.nb;
+            const int nrn = mn.nrows > 0 ? mn.nrows : 1;
+#pragma unroll
+            for (int q = 0; q < SF_ROWS / SF_WAVES; ++q) {
+                int r = wave + SF_WAVES * q;
+                r = r < nrn ? r : nrn - 1;
+                const float *src = r < mn.ncap ? g.xglo + (iin * g.Nc + mn.row_src[r]) * SF_S : g.xloc + (iin * g.ncols + mn.row_src[r]) * SF_S;
+                pre[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src) + lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        step_attend_project_g(g.steps - 1, true);
         const float4 ew = *reinterpret_cast<const float4 *>(g.eval_w + 4 * lane);
         for (int ci = wave; ci < ncap; ci += SF_WAVES) {
             const float4 x = *reinterpret_cast<const float4 *>(xb + ci * SF_LD + 4 * lane);
