@@ -1,4 +1,4 @@
-// Streaming fp32 "NT" GEMM for SHORT K:  C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]),  act in {none, relu}.
+// Streaming fp32 "NT" GEMM for SHORT K:  C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]),  act in {none, relu, gelu}.
 //
 // gemm_nt_fast_kernel (gemm_f32.hip) works tile by tile: every 128 x 128 output tile pays a pipeline fill (its first
 // operand chunk costs a full L2 / HBM latency before the first MFMA) and a drain.  At K = 256 -- the S x S projections of
@@ -28,7 +28,7 @@ struct GemmStreamArgs {
     int xcd_map;      // 1: the workgroups of one row range (all column tiles) sit on ONE XCD and share the A chunks in its L2
 };
 
-template <bool RELU>
+template <int ACT>      // epilogue: 0 none, 1 relu, 4 gelu (apply_act's codes)
 __global__ __launch_bounds__(GS_THREADS, 2) void gemm_nt_stream_kernel(GemmStreamArgs g) {
     __shared__ float4 lds[2][2][GS_NPLANE][GS_BM];      // [buffer][operand][plane][row ^ plane]: 64 KB
     const int tid = threadIdx.x;
@@ -96,7 +96,7 @@ bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, co
             hipDeviceProp_t prop;
             int per_cu = 0;
             if (hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_nt_stream_kernel<false>, GS_THREADS, 0) != hipSuccess || per_cu < 1)
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_nt_stream_kernel<0>, GS_THREADS, 0) != hipSuccess || per_cu < 1)
                 return false;
             resident_of[dev] = (int64_t)prop.multiProcessorCount * per_cu;
         }
@@ -106,7 +106,7 @@ bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, co
     // (measured: ahead of the tile kernel at every K -- 179 200 x 1 024 x 2 048: 132 -> 147 TFLOP/s, 800 000 x 2 304 x 768: 120 -> 135,
     // 265 000 x 256 x 256: 79 -> 104; tools/gemm_stream_check.py.  ITR_GEMM_STREAM_KMAX caps K for experiments.)
     static const int64_t kmax = getenv("ITR_GEMM_STREAM_KMAX") ? atoll(getenv("ITR_GEMM_STREAM_KMAX")) : (1ll << 40);
-    if (off || (act != 0 && act != 1) || K % 64 != 0 || K < 128 || K > kmax || N % GS_BM != 0 || M < GS_BM) return false;
+    if (off || (act != 0 && act != 1 && act != 4) || K % 64 != 0 || K < 128 || K > kmax || N % GS_BM != 0 || M < GS_BM) return false;
     if ((lda % 4) || (ldb % 4) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return false;
     if ((uint64_t)lda * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldb * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldc * 4u * GS_BM >= (1ull << 31)) return false;
     const int64_t tiles_m = M / GS_BM, tiles_n = N / GS_BM;      // whole row tiles; a remainder of rows goes to the tile kernel
@@ -121,9 +121,11 @@ bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, co
     const int xcd_map = (!xcd_off && tiles_n >= 4 && grid % 8 == 0 && (grid / 8) % tiles_n == 0) ? 1 : 0;
     GemmStreamArgs g{A, B, bias, C, lda, ldb, ldc, tiles_m, tiles_n, (int)K, xcd_map};
     if (act == 1)
-        hipLaunchKernelGGL(gemm_nt_stream_kernel<true>, dim3((unsigned)grid), dim3(GS_THREADS), 0, st, g);
+        hipLaunchKernelGGL(gemm_nt_stream_kernel<1>, dim3((unsigned)grid), dim3(GS_THREADS), 0, st, g);
+    else if (act == 4)
+        hipLaunchKernelGGL(gemm_nt_stream_kernel<4>, dim3((unsigned)grid), dim3(GS_THREADS), 0, st, g);
     else
-        hipLaunchKernelGGL(gemm_nt_stream_kernel<false>, dim3((unsigned)grid), dim3(GS_THREADS), 0, st, g);
+        hipLaunchKernelGGL(gemm_nt_stream_kernel<0>, dim3((unsigned)grid), dim3(GS_THREADS), 0, st, g);
     if (hipGetLastError() != hipSuccess) { *rc = ITR_ERR_HIP; set_error("gemm_nt_stream: launch failed"); return true; }
     return true;
 }

@@ -19,7 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                             (128 * 2500, 256, 512, None, True), (128 * 2048, 256, 256, 'relu', False),
                                             # eight column tiles (XCD-aware map), K = 128 (the shortest tile the kernel takes);
                                             # two or three row tiles per workgroup, K = 192 (one trip through the generic chunk loop)
-                                            (128 * 600, 1024, 128, 'relu', True), (128 * 520 + 5, 256, 192, None, True)])
+                                            (128 * 600, 1024, 128, 'relu', True), (128 * 520 + 5, 256, 192, None, True),
+                                            # gelu epilogue (BERT's first feed-forward GEMM, bert.py:29-34): K = 768 / the shortest K / odd chunk count
+                                            (128 * 1024, 3072, 768, 'gelu', True), (128 * 2100, 256, 128, 'gelu', True), (128 * 1100 + 9, 384, 192, 'gelu', False)])
 def test_stream_gemm_vs_float64(dev, M, N, K, act, bias):
     torch.manual_seed(M % 1000 + K)
     a = torch.randn(M, K, device=dev)
@@ -34,8 +36,10 @@ def test_stream_gemm_vs_float64(dev, M, N, K, act, bias):
         want = want + bv.double()
     if act == 'relu':
         want = want.clamp(min=0)
+    if act == 'gelu':
+        want = 0.5 * want * (1.0 + torch.erf(want / 2.0 ** 0.5))
     scale = float((a[idx].double().abs() @ b.double().abs().t()).max())
-    assert float((got[idx].double() - want).abs().max()) <= 4e-7 * scale        # fp32 fmaf chain of length K
+    assert float((got[idx].double() - want).abs().max()) <= 4e-7 * scale + (5e-7 if act == 'gelu' else 0.0)   # fp32 fmaf chain of length K (+ the gelu fit)
     # every row tile was written exactly once: no row keeps the fill value
     sentinel = ops.linear(a[:128 * 3], b, bv, act=act)                           # small M: the tile kernel
     assert torch.equal(got[:128 * 3], sentinel)

@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, "image-text-retrieval_amd", "csrc")
 # exit -- a union-at-joins dataflow cannot prove that, it reports the park code after the loop).
 CASES = [("scan_xattn.hip", ["scan_xattn_kernelILi0E", "scan_xattn_kernelILi1E"]),
          ("gemm_f32.hip", ["gemm_nt_fast_kernel"]),
-         ("gemm_stream.hip", ["gemm_nt_stream_kernelILb0E", "gemm_nt_stream_kernelILb1E"]),
+         ("gemm_stream.hip", ["gemm_nt_stream_kernelILi0E", "gemm_nt_stream_kernelILi1E", "gemm_nt_stream_kernelILi4E"]),
          ("sgraf_loc.hip", ["sgraf_loc_kernel"]),
          ("sgr_fused.hip", ["sgr_fused_kernel", "sgr_fused_persistent_kernel"])]       # weight fragments AND LDS node fragments through asm (SF_GLOAD / SF_LREAD)
 

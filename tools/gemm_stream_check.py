@@ -11,7 +11,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     torch.manual_seed(0)
     for (M, N, K, act) in [(128 * 2048 + 37, 256, 256, None), (128 * 2100, 256, 256, 'relu'), (128 * 4200, 128, 128, None), (128 * 40000, 256, 256, 'relu'), (265000, 256, 256, 'relu'),
                            (128 * 1030, 384, 128, None), (128 * 2500, 256, 512, 'relu')] + [(128 * 1400, 1024, 2048, None), (128 * 6250, 2304, 768, None),
-                           (128 * 6250, 768, 3072, None), (128 * 2070, 256, 1024, None), (128 * 200, 3072, 1024, None)]:
+                           (128 * 6250, 768, 3072, None), (128 * 2070, 256, 1024, None), (128 * 200, 3072, 1024, None),
+                           (128 * 1024, 3072, 768, 'gelu'), (128 * 2100, 256, 256, 'gelu'), (128 * 1030 + 5, 384, 128, 'gelu')]:      # BERT's first feed-forward GEMM; short K
         a = torch.randn(M, K, device=dev); b = torch.randn(N, K, device=dev) * 0.1; bias = torch.randn(N, device=dev)
         got = ops.linear(a, b, bias, act=act)
         idx = torch.randint(0, M, (4000,), device=dev)
@@ -19,6 +20,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         want = a[idx].double() @ b.double().t() + bias.double()
         if act == 'relu':
             want = want.clamp(min=0)
+        if act == 'gelu':
+            want = 0.5 * want * (1.0 + torch.erf(want / 2.0 ** 0.5))
         err = float((got[idx].double() - want).abs().max())
         for _ in range(2): ops.linear(a, b, bias, act=act)
         torch.cuda.synchronize()
