@@ -40,6 +40,10 @@ struct GemmArgs {
     int accumulate;   // C = act(C + A*B^T + bias): sums the taps of a dilated Conv1d (camera_.py:100-103)
     int64_t ksplit;   // > 0: blockIdx.y owns K range [y * ksplit, (y + 1) * ksplit) and writes the raw partial product to
     float *part;      //      part + y * M * N  (row-major [M, N]); bias / activation are applied by the reduction kernel
+    // optional SECOND problem of the same shape in the same launch (fast kernel only: the two directions of a bi-GRU time step,
+    // towers.hip): tiles [ntile, 2 ntile) of the persistent tile order read A2 / B2 / bias2 and write C2
+    const float *A2, *B2, *bias2;
+    float *C2;
 };
 
 template <bool ALIGNED>
@@ -129,7 +133,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2
 //   * the K loop of a tile is ONE generated asm statement (gemm_tile_asm.inc; round 2 -- before, the interleave was a request
 //     to hipcc's scheduler through sched_group_barrier and the loads were separate asm statements with compiler-allocated
 //     destinations, see scan_mainloop.inc for why that is fragile); the accumulators come back in fixed registers.
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g_in) {
+    GemmArgs g = g_in;
     __shared__ float4 lds[2][2][NPLANE][BM];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -137,7 +142,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     const int64_t tiles_n = (g.N + BN - 1) / BN;
-    const int64_t ntile = tiles_m * tiles_n;
+    const int64_t ntile1 = tiles_m * tiles_n;
+    const int64_t ntile = g_in.A2 ? 2 * ntile1 : ntile1;
     // PERSISTENT: the grid is at most 2 workgroups per CU (8 XCDs x 64); XCD x owns a contiguous range of the tile order
     // (consecutive tiles walk down a column of M tiles and share the B panel in that XCD's L2) and its resident
     // workgroups stride through it.  A short-K tile lives ~25 us, and a fresh workgroup launch costs ~10 us of an idle
@@ -163,7 +169,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g) 
     const unsigned fb0 = faddr(0, wn * 64, 1), fb1 = faddr(1, wn * 64, 1), fb2 = faddr(2, wn * 64, 1), fb3 = faddr(3, wn * 64, 1);
 
   for (int64_t tt = slot; tt < t_count; tt += nslots) {
-    const int64_t bid = t_begin + tt;
+    int64_t bid = t_begin + tt;
+    if (bid >= ntile1) {          // second problem of a paired launch (uniform: bid is a scalar)
+        bid -= ntile1;
+        g.A = g_in.A2; g.B = g_in.B2; g.bias = g_in.bias2; g.C = g_in.C2;
+    } else {
+        g.A = g_in.A; g.B = g_in.B; g.bias = g_in.bias; g.C = g_in.C;
+    }
     const int64_t tm = bid % tiles_m, tn = bid / tiles_m;
     const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t m_end = (m0 + BM < g.M) ? m0 + BM : g.M;
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 static int launch_gemm(const GemmArgs &g, hipStream_t st) {
     if (g.M == 0 || g.N == 0) return ITR_OK;
     const int64_t tiles_m = ceil_div(g.M, g.rows_per_tile), tiles_n = ceil_div(g.N, BN);
-    const int64_t nblk = tiles_m * tiles_n;
+    const int64_t nblk = tiles_m * tiles_n * (g.A2 ? 2 : 1);
     if (nblk > 0x7fffffffLL) {
         set_error("gemm: grid too large (%lld tiles)", (long long)nblk);
         return ITR_ERR_UNSUPPORTED;
@@ -310,6 +322,10 @@ static int launch_gemm(const GemmArgs &g, hipStream_t st) {
                          ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
     const bool fast = aligned && g.group <= 1 && (g.K % BK == 0) && g.K >= BK && g.rows_per_tile == BM &&
                       (uint64_t)g.lda * 4u * BM < (1ull << 32) && (uint64_t)g.ldb * 4u * BN < (1ull << 32);
+    if (g.A2 && !(fast && (reinterpret_cast<uintptr_t>(g.A2) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.B2) & 15) == 0)) {
+        set_error("gemm: a paired launch needs the fast kernel's shape (K %% 32 == 0, 16-byte aligned rows)");
+        return ITR_ERR_UNSUPPORTED;
+    }
     if (fast) {
         const int64_t per_xcd = ceil_div(nblk, 8);
         const unsigned grid = 8u * (unsigned)(per_xcd < 64 ? per_xcd : 64);     // <= 2 workgroups per CU, persistent
@@ -410,6 +426,18 @@ int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const floa
         return launch_gemm(gt, st);
     }
     GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, 0, 0, nullptr};
+    return launch_gemm(g, st);
+}
+
+// Two GEMMs of one shape in one launch (the forward and reverse direction of a bi-GRU time step): C = A B^T + bias and
+// C2 = A2 B2^T + bias2.  Every output element is the same fmaf chain as in the single launch.  Only for shapes the fast kernel takes
+// (gemm_pair_ok); the caller falls back to two launches otherwise.
+bool gemm_pair_ok(int64_t lda, int64_t ldb, int64_t K) {
+    return lda % 4 == 0 && ldb % 4 == 0 && K % BK == 0 && K >= BK && (uint64_t)lda * 4u * BM < (1ull << 32) && (uint64_t)ldb * 4u * BN < (1ull << 32);
+}
+int gemm_nt_pair(const float *A, const float *A2, int64_t lda, const float *B, const float *B2, int64_t ldb, const float *bias, const float *bias2,
+                 float *C, float *C2, int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, 0, 1, BM, nullptr, nullptr, 0, 0, 0, nullptr, A2, B2, bias2, C2};
     return launch_gemm(g, st);
 }
 

@@ -16,9 +16,13 @@
 // second kernel), d||e_w|| partial (summed over images by itr_colsum).  The D-long contractions of the backward are
 // again plain GEMMs done by the caller:  dV = dA E + (dG + dG^T) V,   dE = dA^T V + d||e|| e / ||e||.
 #include "scan_common.h"
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace itr {
 
+constexpr int ST_RMAX = 100;  // regions per image the general instantiations hold (bottom-up features come as 36 fixed or 10..100 adaptive boxes)
 constexpr int ST_MAXW = 96;   // words per caption: the longest Flickr30k caption has 82 tokens; 96 keeps the pair in 64 KB of static LDS.
                               // Kernels are instantiated for 64 (3 workgroups per CU: every BASELINE batch) and 96.
 
@@ -30,6 +34,7 @@ struct ScanTrainArgs {
     const int64_t *cap_off;
     const int32_t *cap_len;
     int64_t Bi, Bc;
+    int R;                 // regions per image: 36 in every reference configuration (the FIXED instantiations), 1..ST_RMAX otherwise
     int norm, agg;         // norm: 0 clipped_l2norm, 1 l2norm, 2 softmax, 3 no_norm, 4 clipped, 5 l1norm, 6 clipped_l1norm;  agg: 0 LSE, 1 Max, 2 Sum, 3 Mean
     float ls, ll;
     float *S;              // [Bi, Bc]
@@ -40,31 +45,40 @@ struct ScanTrainArgs {
     float *den;            // [Bi, n_tok]        per (image, word) d||e_w||
 };
 
-template <int MAXW>
+// RMAX: the region count the arrays hold; FIXED: the count IS RMAX (compile-time loop bounds: the reference's 36), otherwise
+// g.R <= RMAX at run time (round 3: any region count).
+template <int MAXW, int RMAX>
 struct PairSmem {
-    float a[SC_R][MAXW + 1];   // raw
-    float p[SC_R][MAXW + 1];   // attention weights
-    float g[SC_R][SC_R + 1];   // Gram
-    float gp[SC_R][MAXW + 1];  // G p
-    float rn[SC_R];            // 1 / (||b[r,:]|| + eps)
-    float rs[SC_R];            // sqrt(sum_w b^2) per region (norm backward)
+    float a[RMAX][MAXW + 1];   // raw
+    float p[RMAX][MAXW + 1];   // attention weights
+    float g[RMAX][RMAX + 1];   // Gram
+    float gp[RMAX][MAXW + 1];  // G p
+    float rn[RMAX];            // 1 / (||b[r,:]|| + eps)
+    float rs[RMAX];            // sqrt(sum_w b^2) per region (norm backward)
     float s[MAXW], num[MAXW], q[MAXW], ds[MAXW];
     float red;
 };
+template <int MAXW, int RMAX>
+struct PairBwdSmem {
+    PairSmem<MAXW, RMAX> sm;
+    float da[RMAX][MAXW + 1];
+    float dqs[MAXW];
+};
 
 // everything up to s_w; returns with sm.{a,p,g,gp,rn,rs,s,num,q} valid
-template <int MAXW>
-__device__ __forceinline__ void pair_forward(const ScanTrainArgs &g, PairSmem<MAXW> &sm, int64_t i, int64_t c, int W, int64_t off) {
+template <int MAXW, int RMAX, bool FIXED>
+__device__ __forceinline__ void pair_forward(const ScanTrainArgs &g, PairSmem<MAXW, RMAX> &sm, int64_t i, int64_t c, int W, int64_t off) {
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < SC_R * W; idx += 256) {
+    const int R = FIXED ? RMAX : g.R;
+    for (int idx = tid; idx < R * W; idx += 256) {
         const int r = idx / W, w = idx - r * W;
-        sm.a[r][w] = g.A[(i * SC_R + r) * g.ldA + off + w];
+        sm.a[r][w] = g.A[(i * R + r) * g.ldA + off + w];
     }
-    for (int idx = tid; idx < SC_R * SC_R; idx += 256) sm.g[idx / SC_R][idx % SC_R] = g.G[i * SC_R * SC_R + idx];
+    for (int idx = tid; idx < R * R; idx += 256) sm.g[idx / R][idx % R] = g.G[i * R * R + idx];
     __syncthreads();
     // first normalisation along the caption's words, one lane per region row: u[r][w] -> sm.p (Objectives.py:436-457)
     const bool clip = (g.norm == 0 || g.norm == 4 || g.norm == 6), l2 = (g.norm == 0 || g.norm == 1), l1 = (g.norm == 5 || g.norm == 6);
-    if (tid < SC_R) {
+    if (tid < R) {
         const int r = tid;
         float st = 0.f, mxa = -INFINITY;
         for (int w = 0; w < W; ++w) {
@@ -86,30 +100,30 @@ __device__ __forceinline__ void pair_forward(const ScanTrainArgs &g, PairSmem<MA
         }
     }
     __syncthreads();
-    if (tid < W) {   // one lane per word: softmax over the 36 regions
+    if (tid < W) {   // one lane per word: softmax over the regions
         const int w = tid;
         float mx = -INFINITY;
-        for (int r = 0; r < SC_R; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float u = sm.p[r][w] * g.ls;
             sm.p[r][w] = u;
             mx = fmaxf(mx, u);
         }
         float den = 0.f;
-        for (int r = 0; r < SC_R; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float e = expf(sm.p[r][w] - mx);
             sm.p[r][w] = e;
             den += e;
         }
         float num = 0.f;
-        for (int r = 0; r < SC_R; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float pv = sm.p[r][w] / den;
             sm.p[r][w] = pv;
             num += pv * sm.a[r][w];
         }
         float q = 0.f;
-        for (int r = 0; r < SC_R; ++r) {
+        for (int r = 0; r < R; ++r) {
             float t = 0.f;
-            for (int s2 = 0; s2 < SC_R; ++s2) t += sm.g[r][s2] * sm.p[s2][w];
+            for (int s2 = 0; s2 < R; ++s2) t += sm.g[r][s2] * sm.p[s2][w];
             sm.gp[r][w] = t;
             q += sm.p[r][w] * t;
         }
@@ -121,13 +135,14 @@ __device__ __forceinline__ void pair_forward(const ScanTrainArgs &g, PairSmem<MA
     __syncthreads();
 }
 
-template <int MAXW>
+template <int MAXW, int RMAX, bool FIXED>
 __global__ __launch_bounds__(256) void scan_train_fwd_kernel(ScanTrainArgs g) {
-    __shared__ PairSmem<MAXW> sm;
+    extern __shared__ __attribute__((aligned(16))) char pair_smem[];
+    PairSmem<MAXW, RMAX> &sm = *reinterpret_cast<PairSmem<MAXW, RMAX> *>(pair_smem);
     const int64_t c = blockIdx.x, i = blockIdx.y;
     const int W = g.cap_len[c];
     const int64_t off = g.cap_off[c];
-    pair_forward(g, sm, i, c, W, off);
+    pair_forward<MAXW, RMAX, FIXED>(g, sm, i, c, W, off);
     if (threadIdx.x == 0) {
         float r;
         if (g.agg == 0) {
@@ -148,16 +163,19 @@ __global__ __launch_bounds__(256) void scan_train_fwd_kernel(ScanTrainArgs g) {
     }
 }
 
-template <int MAXW>
+template <int MAXW, int RMAX, bool FIXED>
 __global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
-    __shared__ PairSmem<MAXW> sm;
-    __shared__ float da[SC_R][MAXW + 1];
-    __shared__ float dqs[MAXW];
+    extern __shared__ __attribute__((aligned(16))) char pair_smem[];
+    PairBwdSmem<MAXW, RMAX> &bs = *reinterpret_cast<PairBwdSmem<MAXW, RMAX> *>(pair_smem);
+    PairSmem<MAXW, RMAX> &sm = bs.sm;
+    float(&da)[RMAX][MAXW + 1] = bs.da;
+    float(&dqs)[MAXW] = bs.dqs;
+    const int R = FIXED ? RMAX : g.R;
     const int tid = threadIdx.x;
     const int64_t c = blockIdx.x, i = blockIdx.y;
     const int W = g.cap_len[c];
     const int64_t off = g.cap_off[c];
-    pair_forward(g, sm, i, c, W, off);
+    pair_forward<MAXW, RMAX, FIXED>(g, sm, i, c, W, off);
     const float dS = g.dS[i * g.Bc + c];
     // ---- aggregation backward: ds_w
     if (tid == 0) {
@@ -198,17 +216,17 @@ __global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
         g.den[i * g.ldA + off + w] = dew;
         // dp = dnum a + 2 dq (G p);  du = ls * p (dp - sum_r p dp)
         float dot = 0.f;
-        for (int r = 0; r < SC_R; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float dp = dnum * sm.a[r][w] + 2.f * dq * sm.gp[r][w];
             da[r][w] = dp;
             dot += sm.p[r][w] * dp;
         }
-        for (int r = 0; r < SC_R; ++r) da[r][w] = g.ls * sm.p[r][w] * (da[r][w] - dot);   // = du[r][w]
+        for (int r = 0; r < R; ++r) da[r][w] = g.ls * sm.p[r][w] * (da[r][w] - dot);   // = du[r][w]
         sm.num[w] = dnum;   // reuse: dnum per word
     }
     __syncthreads();
     // ---- per region: first-norm backward  u = b * rn,  rn = 1 / (sqrt(sum b^2) + eps)
-    if (tid < SC_R) {
+    if (tid < R) {
         const int r = tid;
         const float rn = sm.rn[r], rt = sm.rs[r];
         // dot = sum_w du u-like term of the normalisation's Jacobian
@@ -232,14 +250,14 @@ __global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < SC_R * W; idx += 256) {
+    for (int idx = tid; idx < R * W; idx += 256) {
         const int r = idx / W, w = idx - r * W;
-        g.dA[(i * SC_R + r) * g.ldA + off + w] = da[r][w];
+        g.dA[(i * R + r) * g.ldA + off + w] = da[r][w];
     }
     // ---- dG partial of this pair:  sum_w dq_w p_w p_w^T
-    float *dgp = g.dGp + (i * g.Bc + c) * (SC_R * SC_R);
-    for (int idx = tid; idx < SC_R * SC_R; idx += 256) {
-        const int r = idx / SC_R, s2 = idx - r * SC_R;
+    float *dgp = g.dGp + (i * g.Bc + c) * (R * R);
+    for (int idx = tid; idx < R * R; idx += 256) {
+        const int r = idx / R, s2 = idx - r * R;
         float acc = 0.f;
         for (int w = 0; w < W; ++w) acc += dqs[w] * sm.p[r][w] * sm.p[s2][w];
         dgp[idx] = acc;
@@ -247,40 +265,50 @@ __global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
 }
 
 // dG[i] = sum_c dGp[i, c];  then dV[i] += (dG + dG^T) V[i]   (G = V V^T)
+template <int RMAX, bool FIXED>
 __global__ __launch_bounds__(256) void scan_train_gram_bwd_kernel(const float *__restrict__ dGp, int64_t Bc, const float *__restrict__ V, int D,
-                                                                  float *__restrict__ dV) {
-    __shared__ float dg[SC_R][SC_R + 1];
+                                                                  float *__restrict__ dV, int R_) {
+    __shared__ float dg[RMAX][RMAX + 1];
+    const int R = FIXED ? RMAX : R_;
     const int64_t i = blockIdx.x;
-    for (int idx = threadIdx.x; idx < SC_R * SC_R; idx += 256) {
+    for (int idx = threadIdx.x; idx < R * R; idx += 256) {
         float acc = 0.f;
-        for (int64_t c = 0; c < Bc; ++c) acc += dGp[(i * Bc + c) * (SC_R * SC_R) + idx];
-        dg[idx / SC_R][idx % SC_R] = acc;
+        for (int64_t c = 0; c < Bc; ++c) acc += dGp[(i * Bc + c) * (R * R) + idx];
+        dg[idx / R][idx % R] = acc;
     }
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256) {
-        float v[SC_R];
+        if constexpr (FIXED) {
+            float v[RMAX];
 #pragma unroll
-        for (int r = 0; r < SC_R; ++r) v[r] = V[(i * SC_R + r) * D + d];
-        for (int r = 0; r < SC_R; ++r) {
-            float acc = 0.f;
+            for (int r = 0; r < RMAX; ++r) v[r] = V[(i * RMAX + r) * D + d];
+            for (int r = 0; r < RMAX; ++r) {
+                float acc = 0.f;
 #pragma unroll
-            for (int s2 = 0; s2 < SC_R; ++s2) acc += (dg[r][s2] + dg[s2][r]) * v[s2];
-            dV[(i * SC_R + r) * D + d] += acc;
+                for (int s2 = 0; s2 < RMAX; ++s2) acc += (dg[r][s2] + dg[s2][r]) * v[s2];
+                dV[(i * RMAX + r) * D + d] += acc;
+            }
+        } else {
+            for (int r = 0; r < R; ++r) {
+                float acc = 0.f;
+                for (int s2 = 0; s2 < R; ++s2) acc += (dg[r][s2] + dg[s2][r]) * V[(i * R + s2) * D + d];
+                dV[(i * R + r) * D + d] += acc;
+            }
         }
     }
 }
 
 // G[i] = V[i] V[i]^T  (36 x 36, one workgroup per image) and ||e_w||
-__global__ __launch_bounds__(256) void scan_train_gram_kernel(const float *__restrict__ V, int D, float *__restrict__ G) {
+__global__ __launch_bounds__(256) void scan_train_gram_kernel(const float *__restrict__ V, int D, float *__restrict__ G, int R) {
     const int64_t i = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int idx = wave; idx < SC_R * SC_R; idx += 4) {
-        const int r = idx / SC_R, s2 = idx % SC_R;
-        const float *a = V + (i * SC_R + r) * D, *b = V + (i * SC_R + s2) * D;
+    for (int idx = wave; idx < R * R; idx += 4) {
+        const int r = idx / R, s2 = idx % R;
+        const float *a = V + (i * R + r) * D, *b = V + (i * R + s2) * D;
         float acc = 0.f;
         for (int d = lane; d < D; d += 64) acc += a[d] * b[d];
         acc = wave_sum(acc);
-        if (lane == 0) G[i * SC_R * SC_R + idx] = acc;
+        if (lane == 0) G[i * R * R + idx] = acc;
     }
 }
 __global__ __launch_bounds__(256) void rownorm_train_kernel(const float *__restrict__ x, int64_t rows, int D, float *__restrict__ out) {
@@ -308,11 +336,35 @@ __global__ void gram_kernel(const float *__restrict__ X, const int64_t *__restri
 
 static int check_train_args(const char *who, int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int norm, int agg, int max_len) {
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && n_tok >= 1 && D > 0, "%s: bad shape", who);
-    ITR_UNSUPPORTED(R != SC_R, "%s: built for %d regions, got %d", who, SC_R, R);
+    ITR_UNSUPPORTED(R < 1 || R > ST_RMAX, "%s: 1..%d regions per image are supported, got %d", who, ST_RMAX, R);
     ITR_UNSUPPORTED(max_len > ST_MAXW, "%s: captions of at most %d words are supported, got %d", who, ST_MAXW, max_len);
     ITR_REQUIRE(norm >= 0 && norm <= 6, "%s: unknown first norm %d", who, norm);
     ITR_REQUIRE(agg >= 0 && agg <= 3, "%s: unknown aggregation %d", who, agg);
     ITR_UNSUPPORTED(Bi > 65535, "%s: at most 65535 images per training batch", who);
+    return ITR_OK;
+}
+
+// One launch of a pair kernel instantiation with its LDS block as dynamic shared memory (the general-R ones need up to 159 KB:
+// more than the 64 KB a static declaration may have).  The attribute is set once per kernel and device.
+int allow_dynamic_lds(const void *kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    ITR_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done.count({kernel, dev})) {
+        ITR_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        done.insert({kernel, dev});
+    }
+    return ITR_OK;
+}
+template <typename Smem>
+static int launch_pair(void (*kernel)(ScanTrainArgs), const char *what, const ScanTrainArgs &g, hipStream_t st) {
+    static_assert(sizeof(Smem) <= 160 * 1024, "a pair's LDS block must fit one CU");
+    const int rc = allow_dynamic_lds(reinterpret_cast<const void *>(kernel), sizeof(Smem));
+    if (rc != ITR_OK) return rc;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)g.Bc, (unsigned)g.Bi), dim3(256), sizeof(Smem), st, g);
+    ITR_CHECK_LAUNCH(what);
     return ITR_OK;
 }
 
@@ -324,10 +376,13 @@ extern "C" int itr_scan_train_prepare(const float *V, const float *E, int64_t Bi
                                       itr_stream_t stream) {
     ITR_REQUIRE(V && E && G && enorm, "itr_scan_train_prepare: null pointer");
     ITR_REQUIRE(Bi >= 1 && n_tok >= 1 && D > 0, "itr_scan_train_prepare: bad shape");
-    ITR_UNSUPPORTED(R != SC_R, "itr_scan_train_prepare: built for %d regions", SC_R);
+    ITR_UNSUPPORTED(R < 1 || R > ST_RMAX, "itr_scan_train_prepare: 1..%d regions per image are supported, got %d", ST_RMAX, R);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Bi), dim3(256), 0, st, V, (const int64_t *)nullptr, (const int32_t *)nullptr, SC_R, D, G,
-                       (const int64_t *)nullptr, 0);
+    if (R == SC_R)
+        hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Bi), dim3(256), 0, st, V, (const int64_t *)nullptr, (const int32_t *)nullptr, SC_R, D, G,
+                           (const int64_t *)nullptr, 0);
+    else
+        hipLaunchKernelGGL(scan_train_gram_kernel, dim3((unsigned)Bi), dim3(256), 0, st, V, D, G, R);
     ITR_CHECK_LAUNCH("scan_train_gram");
     hipLaunchKernelGGL(rownorm_train_kernel, dim3((unsigned)ceil_div(n_tok, 4)), dim3(256), 0, st, E, n_tok, D, enorm);
     ITR_CHECK_LAUNCH("scan_train_rownorm");
@@ -341,11 +396,17 @@ extern "C" int itr_scan_train_fwd(const float *A, int64_t ldA, const float *G, c
     ITR_REQUIRE(ldA >= n_tok, "itr_scan_train_fwd: ldA < n_tok");
     int rc = check_train_args("itr_scan_train_fwd", Bi, Bc, n_tok, R, D, norm, agg, max_len);
     if (rc != ITR_OK) return rc;
-    ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, norm, agg, lambda_softmax, lambda_lse, S, nullptr, nullptr, nullptr, nullptr};
-    if (max_len <= 64) hipLaunchKernelGGL(scan_train_fwd_kernel<64>, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
-    else hipLaunchKernelGGL(scan_train_fwd_kernel<ST_MAXW>, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
-    ITR_CHECK_LAUNCH("scan_train_fwd");
-    return ITR_OK;
+    ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, R, norm, agg, lambda_softmax, lambda_lse, S, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t st = as_stream(stream);
+    const bool w64 = max_len <= 64;
+    if (R == SC_R)
+        return w64 ? launch_pair<PairSmem<64, SC_R>>(scan_train_fwd_kernel<64, SC_R, true>, "scan_train_fwd", g, st)
+                   : launch_pair<PairSmem<ST_MAXW, SC_R>>(scan_train_fwd_kernel<ST_MAXW, SC_R, true>, "scan_train_fwd", g, st);
+    if (R < SC_R)
+        return w64 ? launch_pair<PairSmem<64, SC_R>>(scan_train_fwd_kernel<64, SC_R, false>, "scan_train_fwd", g, st)
+                   : launch_pair<PairSmem<ST_MAXW, SC_R>>(scan_train_fwd_kernel<ST_MAXW, SC_R, false>, "scan_train_fwd", g, st);
+    return w64 ? launch_pair<PairSmem<64, ST_RMAX>>(scan_train_fwd_kernel<64, ST_RMAX, false>, "scan_train_fwd", g, st)
+               : launch_pair<PairSmem<ST_MAXW, ST_RMAX>>(scan_train_fwd_kernel<ST_MAXW, ST_RMAX, false>, "scan_train_fwd", g, st);
 }
 
 extern "C" int itr_scan_train_bwd(const float *A, int64_t ldA, const float *G, const float *enorm, const int64_t *cap_off, const int32_t *cap_len,
@@ -355,21 +416,30 @@ extern "C" int itr_scan_train_bwd(const float *A, int64_t ldA, const float *G, c
     ITR_REQUIRE(ldA >= n_tok, "itr_scan_train_bwd: ldA < n_tok");
     int rc = check_train_args("itr_scan_train_bwd", Bi, Bc, n_tok, R, D, norm, agg, max_len);
     if (rc != ITR_OK) return rc;
-    ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, norm, agg, lambda_softmax, lambda_lse, nullptr, dS, dA, dG_pairs, d_enorm_pairs};
-    if (max_len <= 64) hipLaunchKernelGGL(scan_train_bwd_kernel<64>, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
-    else hipLaunchKernelGGL(scan_train_bwd_kernel<ST_MAXW>, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), 0, as_stream(stream), g);
-    ITR_CHECK_LAUNCH("scan_train_bwd");
-    return ITR_OK;
+    // the backward keeps one more regions x words block: more than 36 regions AND more than 64 words do not fit a CU's 160 KB of LDS
+    ITR_UNSUPPORTED(R > SC_R && max_len > 64, "itr_scan_train_bwd: more than %d regions with captions of more than 64 words (got %d, %d)", SC_R, R, max_len);
+    ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, R, norm, agg, lambda_softmax, lambda_lse, nullptr, dS, dA, dG_pairs, d_enorm_pairs};
+    hipStream_t st = as_stream(stream);
+    const bool w64 = max_len <= 64;
+    if (R == SC_R)
+        return w64 ? launch_pair<PairBwdSmem<64, SC_R>>(scan_train_bwd_kernel<64, SC_R, true>, "scan_train_bwd", g, st)
+                   : launch_pair<PairBwdSmem<ST_MAXW, SC_R>>(scan_train_bwd_kernel<ST_MAXW, SC_R, true>, "scan_train_bwd", g, st);
+    if (R < SC_R)
+        return w64 ? launch_pair<PairBwdSmem<64, SC_R>>(scan_train_bwd_kernel<64, SC_R, false>, "scan_train_bwd", g, st)
+                   : launch_pair<PairBwdSmem<ST_MAXW, SC_R>>(scan_train_bwd_kernel<ST_MAXW, SC_R, false>, "scan_train_bwd", g, st);
+    return launch_pair<PairBwdSmem<64, ST_RMAX>>(scan_train_bwd_kernel<64, ST_RMAX, false>, "scan_train_bwd", g, st);
 }
 
 extern "C" int itr_scan_train_finish(const float *dG_pairs, int64_t Bi, int64_t Bc, const float *V, const float *E, const float *enorm,
                                      const float *d_enorm, int64_t n_tok, int R, int D, float *dV, float *dE, itr_stream_t stream) {
     ITR_REQUIRE(dG_pairs && V && E && enorm && d_enorm && dV && dE, "itr_scan_train_finish: null pointer");
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && n_tok >= 1 && D > 0, "itr_scan_train_finish: bad shape");
-    ITR_UNSUPPORTED(R != SC_R, "itr_scan_train_finish: built for %d regions", SC_R);
+    ITR_UNSUPPORTED(R < 1 || R > ST_RMAX, "itr_scan_train_finish: 1..%d regions per image are supported, got %d", ST_RMAX, R);
     ITR_UNSUPPORTED(n_tok > 65535, "itr_scan_train_finish: at most 65535 words per training batch");
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(scan_train_gram_bwd_kernel, dim3((unsigned)Bi), dim3(256), 0, st, dG_pairs, Bc, V, D, dV);
+    if (R == SC_R) hipLaunchKernelGGL((scan_train_gram_bwd_kernel<SC_R, true>), dim3((unsigned)Bi), dim3(256), 0, st, dG_pairs, Bc, V, D, dV, R);
+    else if (R < SC_R) hipLaunchKernelGGL((scan_train_gram_bwd_kernel<SC_R, false>), dim3((unsigned)Bi), dim3(256), 0, st, dG_pairs, Bc, V, D, dV, R);
+    else hipLaunchKernelGGL((scan_train_gram_bwd_kernel<ST_RMAX, false>), dim3((unsigned)Bi), dim3(256), 0, st, dG_pairs, Bc, V, D, dV, R);
     ITR_CHECK_LAUNCH("scan_train_gram_bwd");
     hipLaunchKernelGGL(enorm_bwd_kernel, dim3((unsigned)ceil_div(D, 256), (unsigned)n_tok), dim3(256), 0, st, E, enorm, d_enorm, n_tok, D, dE);
     ITR_CHECK_LAUNCH("scan_train_enorm_bwd");

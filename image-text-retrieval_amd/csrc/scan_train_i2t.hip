@@ -13,6 +13,7 @@
 
 namespace itr {
 
+constexpr int SI_RMAX = 100;   // as ST_RMAX (scan_train.hip)
 constexpr int SI_MAXW = 96;    // as scan_train.hip; the W x W caption Gram makes the pair 80 KB -> dynamic LDS
 
 struct ScanI2TArgs {
@@ -24,6 +25,7 @@ struct ScanI2TArgs {
     const int64_t *cap_off;
     const int32_t *cap_len;
     int64_t Bi, Bc, h_total;
+    int R;                 // regions per image: 36 in every reference configuration (FIXED instantiation), 1..SI_RMAX otherwise
     int norm, agg;
     float ls, ll;
     float *S;              // [Bi, Bc]
@@ -33,30 +35,34 @@ struct ScanI2TArgs {
     float *dvn;            // [Bc, Bi*36]       per-pair d||v_r||
 };
 
+template <int RMAX>
 struct I2TSmem {
-    float a[SC_R][SI_MAXW + 1];    // raw
-    float p[SC_R][SI_MAXW + 1];    // u, then attention weights
-    float hp[SC_R][SI_MAXW + 1];   // H p_r; the backward reuses it for dp / du / da
+    float a[RMAX][SI_MAXW + 1];    // raw
+    float p[RMAX][SI_MAXW + 1];    // u, then attention weights
+    float hp[RMAX][SI_MAXW + 1];   // H p_r; the backward reuses it for dp / du / da
     float h[SI_MAXW][SI_MAXW + 1]; // caption Gram
     float wn[SI_MAXW];             // first-norm statistic per word: 1/(||b|| + eps) | 1/(sum|b| + eps) | 1/sum exp
     float ws[SI_MAXW];             // ||b||, sum |b|, or the column maximum (softmax)
-    float s[SC_R], num[SC_R], q[SC_R], ds[SC_R];
+    float s[RMAX], num[RMAX], q[RMAX], ds[RMAX];
+    float dqs[RMAX], dnums[RMAX];  // backward
 };
 
-__device__ __forceinline__ void i2t_pair_forward(const ScanI2TArgs &g, I2TSmem &sm, int64_t i, int64_t c, int W, int64_t off) {
+template <int RMAX, bool FIXED>
+__device__ __forceinline__ void i2t_pair_forward(const ScanI2TArgs &g, I2TSmem<RMAX> &sm, int64_t i, int64_t c, int W, int64_t off) {
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < SC_R * W; idx += 256) {
+    const int R = FIXED ? RMAX : g.R;
+    for (int idx = tid; idx < R * W; idx += 256) {
         const int r = idx / W, w = idx - r * W;
-        sm.a[r][w] = g.A[(i * SC_R + r) * g.ldA + off + w];
+        sm.a[r][w] = g.A[(i * R + r) * g.ldA + off + w];
     }
     const float *H = g.H + g.h_off[c];
     for (int idx = tid; idx < W * W; idx += 256) sm.h[idx / W][idx % W] = H[idx];
     __syncthreads();
     const bool clip = (g.norm == 0 || g.norm == 4 || g.norm == 6), l2 = (g.norm == 0 || g.norm == 1), l1 = (g.norm == 5 || g.norm == 6);
-    if (tid < W) {   // one lane per word: first normalisation over the 36 regions
+    if (tid < W) {   // one lane per word: first normalisation over the regions
         const int w = tid;
         float st = 0.f, mxa = -INFINITY;
-        for (int r = 0; r < SC_R; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float b = clip ? leaky(sm.a[r][w]) : sm.a[r][w];
             st += l2 ? b * b : (l1 ? fabsf(b) : 0.f);
             mxa = fmaxf(mxa, sm.a[r][w]);
@@ -64,18 +70,18 @@ __device__ __forceinline__ void i2t_pair_forward(const ScanI2TArgs &g, I2TSmem &
         if (l2) st = sqrtf(st);
         if (g.norm == 2) {
             st = 0.f;
-            for (int r = 0; r < SC_R; ++r) st += expf(sm.a[r][w] - mxa);
+            for (int r = 0; r < R; ++r) st += expf(sm.a[r][w] - mxa);
         }
         sm.ws[w] = (g.norm == 2) ? mxa : st;
         const float rn = (l2 || l1) ? 1.f / (st + 1e-8f) : (g.norm == 2 ? 1.f / st : 1.f);
         sm.wn[w] = rn;
-        for (int r = 0; r < SC_R; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float araw = sm.a[r][w];
             sm.p[r][w] = (g.norm == 2) ? expf(araw - mxa) * rn : (clip ? leaky(araw) : araw) * rn;
         }
     }
     __syncthreads();
-    if (tid < SC_R) {   // one lane per region: softmax over the words, cosine terms
+    if (tid < R) {   // one lane per region: softmax over the words, cosine terms
         const int r = tid;
         float mx = -INFINITY;
         for (int w = 0; w < W; ++w) {
@@ -105,70 +111,75 @@ __device__ __forceinline__ void i2t_pair_forward(const ScanI2TArgs &g, I2TSmem &
         q = fmaxf(q, 0.f);
         sm.num[r] = num;
         sm.q[r] = q;
-        sm.s[r] = num / fmaxf(g.vnorm[i * SC_R + r] * sqrtf(q), 1e-8f);
+        sm.s[r] = num / fmaxf(g.vnorm[i * R + r] * sqrtf(q), 1e-8f);
     }
     __syncthreads();
 }
 
+template <int RMAX, bool FIXED>
 __global__ __launch_bounds__(256) void scan_train_i2t_fwd_kernel(ScanI2TArgs g) {
     extern __shared__ __attribute__((aligned(16))) char i2t_smem[];
-    I2TSmem &sm = *reinterpret_cast<I2TSmem *>(i2t_smem);
+    I2TSmem<RMAX> &sm = *reinterpret_cast<I2TSmem<RMAX> *>(i2t_smem);
+    const int R = FIXED ? RMAX : g.R;
     const int64_t c = blockIdx.x, i = blockIdx.y;
     const int W = g.cap_len[c];
-    i2t_pair_forward(g, sm, i, c, W, g.cap_off[c]);
+    i2t_pair_forward<RMAX, FIXED>(g, sm, i, c, W, g.cap_off[c]);
     if (threadIdx.x == 0) {
         float r;
         if (g.agg == 0) {
             float mx = -INFINITY;
-            for (int t = 0; t < SC_R; ++t) mx = fmaxf(mx, sm.s[t] * g.ll);
+            for (int t = 0; t < R; ++t) mx = fmaxf(mx, sm.s[t] * g.ll);
             float acc = 0.f;
-            for (int t = 0; t < SC_R; ++t) acc += expf(sm.s[t] * g.ll - mx);
+            for (int t = 0; t < R; ++t) acc += expf(sm.s[t] * g.ll - mx);
             r = (logf(acc) + mx) / g.ll;
         } else if (g.agg == 1) {
             r = -INFINITY;
-            for (int t = 0; t < SC_R; ++t) r = fmaxf(r, sm.s[t]);
+            for (int t = 0; t < R; ++t) r = fmaxf(r, sm.s[t]);
         } else {
             r = 0.f;
-            for (int t = 0; t < SC_R; ++t) r += sm.s[t];
-            if (g.agg == 3) r /= (float)SC_R;
+            for (int t = 0; t < R; ++t) r += sm.s[t];
+            if (g.agg == 3) r /= (float)R;
         }
         g.S[i * g.Bc + c] = r;
     }
 }
 
+template <int RMAX, bool FIXED>
 __global__ __launch_bounds__(256) void scan_train_i2t_bwd_kernel(ScanI2TArgs g) {
     extern __shared__ __attribute__((aligned(16))) char i2t_smem[];
-    I2TSmem &sm = *reinterpret_cast<I2TSmem *>(i2t_smem);
-    __shared__ float dqs[SC_R], dnums[SC_R];
+    I2TSmem<RMAX> &sm = *reinterpret_cast<I2TSmem<RMAX> *>(i2t_smem);
+    float(&dqs)[RMAX] = sm.dqs;
+    float(&dnums)[RMAX] = sm.dnums;
+    const int R = FIXED ? RMAX : g.R;
     const int tid = threadIdx.x;
     const int64_t c = blockIdx.x, i = blockIdx.y;
     const int W = g.cap_len[c];
     const int64_t off = g.cap_off[c];
-    i2t_pair_forward(g, sm, i, c, W, off);
+    i2t_pair_forward<RMAX, FIXED>(g, sm, i, c, W, off);
     const float dS = g.dS[i * g.Bc + c];
     if (tid == 0) {
         if (g.agg == 0) {
             float mx = -INFINITY;
-            for (int t = 0; t < SC_R; ++t) mx = fmaxf(mx, sm.s[t] * g.ll);
+            for (int t = 0; t < R; ++t) mx = fmaxf(mx, sm.s[t] * g.ll);
             float acc = 0.f;
-            for (int t = 0; t < SC_R; ++t) acc += expf(sm.s[t] * g.ll - mx);
-            for (int t = 0; t < SC_R; ++t) sm.ds[t] = dS * expf(sm.s[t] * g.ll - mx) / acc;
+            for (int t = 0; t < R; ++t) acc += expf(sm.s[t] * g.ll - mx);
+            for (int t = 0; t < R; ++t) sm.ds[t] = dS * expf(sm.s[t] * g.ll - mx) / acc;
         } else if (g.agg == 1) {
             int best = 0;
-            for (int t = 1; t < SC_R; ++t)
+            for (int t = 1; t < R; ++t)
                 if (sm.s[t] > sm.s[best]) best = t;
-            for (int t = 0; t < SC_R; ++t) sm.ds[t] = (t == best) ? dS : 0.f;
+            for (int t = 0; t < R; ++t) sm.ds[t] = (t == best) ? dS : 0.f;
         } else {
-            const float k = (g.agg == 3) ? dS / (float)SC_R : dS;
-            for (int t = 0; t < SC_R; ++t) sm.ds[t] = k;
+            const float k = (g.agg == 3) ? dS / (float)R : dS;
+            for (int t = 0; t < R; ++t) sm.ds[t] = k;
         }
     }
     __syncthreads();
     const bool clip = (g.norm == 0 || g.norm == 4 || g.norm == 6), l2 = (g.norm == 0 || g.norm == 1), l1 = (g.norm == 5 || g.norm == 6);
     // ---- per region: cosine backward, softmax-over-words backward -> du (kept in hp)
-    if (tid < SC_R) {
+    if (tid < R) {
         const int r = tid;
-        const float vn = g.vnorm[i * SC_R + r];
+        const float vn = g.vnorm[i * R + r];
         const float sq = sqrtf(sm.q[r]);
         const float den = vn * sq;
         float dnum = 0.f, dq = 0.f, dvn = 0.f;
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(256) void scan_train_i2t_bwd_kernel(ScanI2TArgs g) 
         }
         dqs[r] = dq;
         dnums[r] = dnum;
-        g.dvn[c * (g.Bi * SC_R) + i * SC_R + r] = dvn;
+        g.dvn[c * (g.Bi * R) + i * R + r] = dvn;
         float dot = 0.f;
         for (int w = 0; w < W; ++w) {
             const float dp = dnum * sm.a[r][w] + 2.f * dq * sm.hp[r][w];
@@ -197,13 +208,13 @@ __global__ __launch_bounds__(256) void scan_train_i2t_bwd_kernel(ScanI2TArgs g) 
         const int w = tid;
         const float rn = sm.wn[w], rt = sm.ws[w];
         float dot = 0.f;
-        for (int r = 0; r < SC_R; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float araw = sm.a[r][w];
             const float b = clip ? leaky(araw) : araw;
             if (l2 || l1) dot += sm.hp[r][w] * b;
             else if (g.norm == 2) dot += sm.hp[r][w] * expf(araw - rt) * rn;
         }
-        for (int r = 0; r < SC_R; ++r) {
+        for (int r = 0; r < R; ++r) {
             const float araw = sm.a[r][w];
             const float b = clip ? leaky(araw) : araw;
             const float du = sm.hp[r][w];
@@ -217,16 +228,16 @@ __global__ __launch_bounds__(256) void scan_train_i2t_bwd_kernel(ScanI2TArgs g) 
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < SC_R * W; idx += 256) {
+    for (int idx = tid; idx < R * W; idx += 256) {
         const int r = idx / W, w = idx - r * W;
-        g.dA[(i * SC_R + r) * g.ldA + off + w] = sm.hp[r][w];
+        g.dA[(i * R + r) * g.ldA + off + w] = sm.hp[r][w];
     }
     // ---- dH partial of this pair: sum_r dq_r p_r p_r^T
     float *dhp = g.dHp + i * g.h_total + g.h_off[c];
     for (int idx = tid; idx < W * W; idx += 256) {
         const int u = idx / W, v = idx - u * W;
         float acc = 0.f;
-        for (int r = 0; r < SC_R; ++r) acc += dqs[r] * sm.p[r][u] * sm.p[r][v];
+        for (int r = 0; r < R; ++r) acc += dqs[r] * sm.p[r][u] * sm.p[r][v];
         dhp[idx] = acc;
     }
 }
@@ -311,13 +322,25 @@ __global__ __launch_bounds__(256) void caption_gram_kernel(const float *__restri
     }
 }
 
+int allow_dynamic_lds(const void *kernel, size_t bytes);      // scan_train.hip
+
 static int check_i2t(const char *who, int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int norm, int agg, int max_len) {
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && n_tok >= 1 && D > 0, "%s: bad shape", who);
-    ITR_UNSUPPORTED(R != SC_R, "%s: built for %d regions, got %d", who, SC_R, R);
+    ITR_UNSUPPORTED(R < 1 || R > SI_RMAX, "%s: 1..%d regions per image are supported, got %d", who, SI_RMAX, R);
     ITR_UNSUPPORTED(max_len > SI_MAXW, "%s: captions of at most %d words are supported, got %d", who, SI_MAXW, max_len);
     ITR_REQUIRE(norm >= 0 && norm <= 6, "%s: unknown first norm %d", who, norm);
     ITR_REQUIRE(agg >= 0 && agg <= 3, "%s: unknown aggregation %d", who, agg);
     ITR_UNSUPPORTED(Bi > 65535, "%s: at most 65535 images per training batch", who);
+    return ITR_OK;
+}
+
+template <int RMAX>
+static int launch_i2t(void (*kernel)(ScanI2TArgs), const char *what, const ScanI2TArgs &g, hipStream_t st) {
+    static_assert(sizeof(I2TSmem<RMAX>) <= 160 * 1024, "a pair's LDS block must fit one CU");
+    const int rc = allow_dynamic_lds(reinterpret_cast<const void *>(kernel), sizeof(I2TSmem<RMAX>));
+    if (rc != ITR_OK) return rc;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)g.Bc, (unsigned)g.Bi), dim3(256), sizeof(I2TSmem<RMAX>), st, g);
+    ITR_CHECK_LAUNCH(what);
     return ITR_OK;
 }
 
@@ -329,11 +352,11 @@ extern "C" int itr_scan_train_i2t_prepare(const float *V, const float *E, const 
                                           int64_t Bi, int64_t Bc, int R, int D, float *H, float *vnorm, itr_stream_t stream) {
     ITR_REQUIRE(V && E && cap_off && cap_len && h_off && H && vnorm, "itr_scan_train_i2t_prepare: null pointer");
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && D > 0, "itr_scan_train_i2t_prepare: bad shape");
-    ITR_UNSUPPORTED(R != SC_R, "itr_scan_train_i2t_prepare: built for %d regions", SC_R);
+    ITR_UNSUPPORTED(R < 1 || R > SI_RMAX, "itr_scan_train_i2t_prepare: 1..%d regions per image are supported, got %d", SI_RMAX, R);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(caption_gram_kernel, dim3((unsigned)Bc), dim3(256), 0, st, E, cap_off, cap_len, D, H, h_off);
     ITR_CHECK_LAUNCH("scan_train_i2t gram");
-    hipLaunchKernelGGL(rownorm_i2t_kernel, dim3((unsigned)ceil_div(Bi * SC_R, 4)), dim3(256), 0, st, V, Bi * SC_R, D, vnorm);
+    hipLaunchKernelGGL(rownorm_i2t_kernel, dim3((unsigned)ceil_div(Bi * R, 4)), dim3(256), 0, st, V, Bi * R, D, vnorm);
     ITR_CHECK_LAUNCH("scan_train_i2t rownorm");
     return ITR_OK;
 }
@@ -345,16 +368,11 @@ extern "C" int itr_scan_train_i2t_fwd(const float *A, int64_t ldA, const float *
     ITR_REQUIRE(ldA >= n_tok, "itr_scan_train_i2t_fwd: ldA < n_tok");
     int rc = check_i2t("itr_scan_train_i2t_fwd", Bi, Bc, n_tok, R, D, norm, agg, max_len);
     if (rc != ITR_OK) return rc;
-    ScanI2TArgs g{A, ldA, H, h_off, vnorm, cap_off, cap_len, Bi, Bc, 0, norm, agg, lambda_softmax, lambda_lse, S, nullptr, nullptr, nullptr, nullptr};
-    static bool attr_f = false;
-    if (!attr_f) {
-        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_train_i2t_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)sizeof(I2TSmem)));
-        attr_f = true;
-    }
-    hipLaunchKernelGGL(scan_train_i2t_fwd_kernel, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), sizeof(I2TSmem), as_stream(stream), g);
-    ITR_CHECK_LAUNCH("scan_train_i2t_fwd");
-    return ITR_OK;
+    ScanI2TArgs g{A, ldA, H, h_off, vnorm, cap_off, cap_len, Bi, Bc, 0, R, norm, agg, lambda_softmax, lambda_lse, S, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t st = as_stream(stream);
+    if (R == SC_R) return launch_i2t<SC_R>(scan_train_i2t_fwd_kernel<SC_R, true>, "scan_train_i2t_fwd", g, st);
+    if (R < SC_R) return launch_i2t<SC_R>(scan_train_i2t_fwd_kernel<SC_R, false>, "scan_train_i2t_fwd", g, st);
+    return launch_i2t<SI_RMAX>(scan_train_i2t_fwd_kernel<SI_RMAX, false>, "scan_train_i2t_fwd", g, st);
 }
 
 extern "C" int itr_scan_train_i2t_bwd(const float *A, int64_t ldA, const float *H, const int64_t *h_off, int64_t h_total, const float *vnorm,
@@ -365,17 +383,12 @@ extern "C" int itr_scan_train_i2t_bwd(const float *A, int64_t ldA, const float *
     ITR_REQUIRE(ldA >= n_tok && h_total >= 1, "itr_scan_train_i2t_bwd: bad leading dimension / Gram size");
     int rc = check_i2t("itr_scan_train_i2t_bwd", Bi, Bc, n_tok, R, D, norm, agg, max_len);
     if (rc != ITR_OK) return rc;
-    ScanI2TArgs g{A, ldA, H, h_off, vnorm, cap_off, cap_len, Bi, Bc, h_total, norm, agg, lambda_softmax, lambda_lse, nullptr, dS, dA, dH_pairs,
+    ScanI2TArgs g{A, ldA, H, h_off, vnorm, cap_off, cap_len, Bi, Bc, h_total, R, norm, agg, lambda_softmax, lambda_lse, nullptr, dS, dA, dH_pairs,
                   d_vnorm_pairs};
-    static bool attr_b = false;
-    if (!attr_b) {
-        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_train_i2t_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)sizeof(I2TSmem)));
-        attr_b = true;
-    }
-    hipLaunchKernelGGL(scan_train_i2t_bwd_kernel, dim3((unsigned)Bc, (unsigned)Bi), dim3(256), sizeof(I2TSmem), as_stream(stream), g);
-    ITR_CHECK_LAUNCH("scan_train_i2t_bwd");
-    return ITR_OK;
+    hipStream_t st = as_stream(stream);
+    if (R == SC_R) return launch_i2t<SC_R>(scan_train_i2t_bwd_kernel<SC_R, true>, "scan_train_i2t_bwd", g, st);
+    if (R < SC_R) return launch_i2t<SC_R>(scan_train_i2t_bwd_kernel<SC_R, false>, "scan_train_i2t_bwd", g, st);
+    return launch_i2t<SI_RMAX>(scan_train_i2t_bwd_kernel<SI_RMAX, false>, "scan_train_i2t_bwd", g, st);
 }
 
 extern "C" int itr_scan_train_i2t_finish(const float *dH, const int64_t *h_off, const int64_t *cap_off, const int32_t *cap_len, int64_t Bc,
@@ -383,13 +396,13 @@ extern "C" int itr_scan_train_i2t_finish(const float *dH, const int64_t *h_off, 
                                          float *dV, float *dE, itr_stream_t stream) {
     ITR_REQUIRE(dH && h_off && cap_off && cap_len && E && V && vnorm && d_vnorm && dV && dE, "itr_scan_train_i2t_finish: null pointer");
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && D > 0, "itr_scan_train_i2t_finish: bad shape");
-    ITR_UNSUPPORTED(R != SC_R, "itr_scan_train_i2t_finish: built for %d regions", SC_R);
-    ITR_UNSUPPORTED(Bi * SC_R > 65535, "itr_scan_train_i2t_finish: at most 1819 images per training batch");
+    ITR_UNSUPPORTED(R < 1 || R > SI_RMAX, "itr_scan_train_i2t_finish: 1..%d regions per image are supported, got %d", SI_RMAX, R);
+    ITR_UNSUPPORTED(Bi * R > 65535, "itr_scan_train_i2t_finish: at most 65535 region rows per training batch");
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(i2t_gram_bwd_kernel, dim3((unsigned)Bc), dim3(256), 0, st, dH, h_off, cap_off, cap_len, E, D, dE);
     ITR_CHECK_LAUNCH("scan_train_i2t gram_bwd");
-    hipLaunchKernelGGL(rowscale_add_kernel, dim3((unsigned)ceil_div(D, 256), (unsigned)(Bi * SC_R)), dim3(256), 0, st, V, vnorm, d_vnorm,
-                       Bi * SC_R, D, dV);
+    hipLaunchKernelGGL(rowscale_add_kernel, dim3((unsigned)ceil_div(D, 256), (unsigned)(Bi * R)), dim3(256), 0, st, V, vnorm, d_vnorm,
+                       Bi * R, D, dV);
     ITR_CHECK_LAUNCH("scan_train_i2t vnorm_bwd");
     return ITR_OK;
 }

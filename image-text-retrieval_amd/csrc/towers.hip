@@ -16,6 +16,10 @@ namespace itr {
 
 int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
+// the two directions of a bi-GRU time step in one launch (gemm_f32.hip)
+bool gemm_pair_ok(int64_t lda, int64_t ldb, int64_t K);
+int gemm_nt_pair(const float *A, const float *A2, int64_t lda, const float *B, const float *B2, int64_t ldb, const float *bias, const float *bias2,
+                 float *C, float *C2, int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t st);
 int norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, int kind, int take_abs,
               hipStream_t st);
 // skinny GEMMs of the recurrence when the batch is small (the reference-shaped encode_data path feeds 128 captions at
@@ -52,15 +56,21 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // mode 0: out[row] = h'            (forward direction, or uni-directional)
 // mode 1: out[row] = (out[row] + h') / 2   (reverse direction of a bi-GRU, TextEncoder.py:54-55)
 // VEC = 4: one thread per four consecutive hidden units, 16-byte accesses (D % 4 == 0); VEC = 1: any D.
+// gridDim.z == 2: both directions of a bi-GRU in one launch -- z = 1 is the reverse direction, its gi / gh / h are `dir_stride`
+// floats behind the forward direction's (the two halves of the workspace are carved identically) and its output is out2.
 template <int VEC>
 __global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__ gi, const float *__restrict__ gh,
                                                        float *__restrict__ h, float *__restrict__ out,
                                                        const int64_t *__restrict__ tok_off,
                                                        const int32_t *__restrict__ len, int t, int reverse,
-                                                       int mode, int D, int64_t n_act) {
+                                                       int mode, int D, int64_t n_act, int64_t dir_stride, float *__restrict__ out2) {
     const int64_t b = blockIdx.x;
     const int j = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
     if (b >= n_act || j >= D) return;
+    if (blockIdx.z) {
+        reverse = 1;
+        gi += dir_stride; gh += dir_stride; h += dir_stride; out = out2;
+    }
     const int64_t row = tok_off[b] + (reverse ? (len[b] - 1 - t) : t);
     const float *gir = gi + row * 3 * D + j;
     const float *ghr = gh + b * 3 * D + j;
@@ -244,35 +254,66 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
                        w.bad);
     ITR_CHECK_LAUNCH("embed_gather");
 
-    // the reverse direction on a second stream with its own buffers (ITR_GRU_NO_OVERLAP=1: one after the other, for A/B timing)
-    SideStream side_obj;
-    SideStream *side = (bi && !getenv("ITR_GRU_NO_OVERLAP") && side_stream(side_obj)) ? &side_obj : nullptr;
     GruWs w2 = w;
     if (bi) {
         w2 = carve(static_cast<char *>(workspace) + gru_ws_one(n_tok, B, E, D), n_tok, B, E, D);
         w2.x = w.x;                      // the gathered embeddings are shared (read-only)
     }
+    // Both input projections first, on the caller's stream (each fills the chip by itself), THEN the fork: the two recurrences start
+    // together and their short last steps (a few hundred active captions: less than one round of tiles) overlap each other instead
+    // of the reverse direction's tail running alone (ITR_GRU_INPUT_AFTER_FORK=1: the round-2 order, for A/B timing).
+    const bool input_first = bi && !getenv("ITR_GRU_INPUT_AFTER_FORK");
+    auto input_projection = [&](int dir, hipStream_t sd) -> int {
+        const GruWs &ww = dir ? w2 : w;
+        const float *wi_use = dir ? w_ih_rev : w_ih;
+        if (Ep != E) {   // zero-padded copy of W_ih: K = Ep is a multiple of 32 (zeros add nothing)
+            hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)(3 * D)), dim3(128), 0, sd, wi_use, (int64_t)3 * D, E, Ep, ww.wpad);
+            ITR_CHECK_LAUNCH("pad_cols");
+            wi_use = ww.wpad;
+        }
+        int rc = gemm_nt(w.x, Ep, wi_use, Ep, dir ? b_ih_rev : b_ih, ww.gi, 3 * D, n_tok, 3 * D, Ep, 0, sd);
+        if (rc != ITR_OK) return rc;
+        ITR_CHECK_HIP(hipMemsetAsync(ww.h, 0, (size_t)B * D * 4, sd));
+        return ITR_OK;
+    };
+    if (input_first)
+        for (int dir = 0; dir < 2; ++dir) {
+            const int rc = input_projection(dir, st);
+            if (rc != ITR_OK) return rc;
+        }
+    // ITR_GRU_PAIRED=1 (an experiment that lost, DESIGN.md 9: 10.26 against 9.92 ms on VSE++ 1k x 5k, same box): ONE GEMM launch and
+    // ONE gate launch per time step for both directions.  The active prefix of step t is the same for both, so the pair is a GEMM
+    // of twice the tiles; but GEMM -> gates -> GEMM is then a strict chain, while two streams let one direction's gate kernel run
+    // in the other direction's last round of tiles.  Bit-identical results either way (same fmaf chain per element).
+    const bool paired = input_first && splits_h == 1 && D % 4 == 0 && gemm_pair_ok(D, D, D) && getenv("ITR_GRU_PAIRED");
+    if (paired) {
+        const int64_t dir_stride = (int64_t)(gru_ws_one(n_tok, B, E, D) / 4);
+        int64_t n_act = B;
+        for (int t = 0; t < Lmax; ++t) {
+            while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
+            int rc = gemm_nt_pair(w.h, w2.h, D, w_hh, w_hh_rev, D, b_hh, b_hh_rev, w.gh, w2.gh, 3 * D, n_act, 3 * D, D, st);
+            if (rc != ITR_OK) return rc;
+            hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024), 2u), dim3(256), 0, st, w.gi, w.gh, w.h,
+                               seq, tok_off, len_dev, t, 0, 0, D, n_act, dir_stride, w2.out_tmp);
+            ITR_CHECK_LAUNCH("gru_gate (both directions)");
+        }
+    }
+    // the reverse direction's recurrence on a second stream with its own buffers (ITR_GRU_NO_OVERLAP=1: one after the other, for A/B timing)
+    SideStream side_obj;
+    SideStream *side = (bi && !paired && !getenv("ITR_GRU_NO_OVERLAP") && side_stream(side_obj)) ? &side_obj : nullptr;
     if (side) {
         ITR_CHECK_HIP(hipEventRecord(side->fork, st));
         ITR_CHECK_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
         side->forked = true;
     }
     auto directions = [&]() -> int {
-        for (int dir = 0; dir < (bi ? 2 : 1); ++dir) {
-            const float *wi = dir ? w_ih_rev : w_ih, *wh = dir ? w_hh_rev : w_hh;
-            const float *bi_ = dir ? b_ih_rev : b_ih, *bh = dir ? b_hh_rev : b_hh;
+        for (int dir = 0; dir < (paired ? 0 : bi ? 2 : 1); ++dir) {
+            const float *wh = dir ? w_hh_rev : w_hh, *bh = dir ? b_hh_rev : b_hh;
             const GruWs &ww = dir ? w2 : w;
             hipStream_t sd = (dir && side) ? side->st : st;
             float *dst = dir ? w2.out_tmp : seq;             // reverse direction: its own sequence buffer, averaged in below
-            const float *wi_use = wi;
-            if (Ep != E) {   // zero-padded copy of W_ih: K = Ep is a multiple of 32 (zeros add nothing)
-                hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)(3 * D)), dim3(128), 0, sd, wi, (int64_t)3 * D, E, Ep, ww.wpad);
-                ITR_CHECK_LAUNCH("pad_cols");
-                wi_use = ww.wpad;
-            }
-            int rc = gemm_nt(w.x, Ep, wi_use, Ep, bi_, ww.gi, 3 * D, n_tok, 3 * D, Ep, 0, sd);
-            if (rc != ITR_OK) return rc;
-            ITR_CHECK_HIP(hipMemsetAsync(ww.h, 0, (size_t)B * D * 4, sd));
+            int rc = ITR_OK;
+            if (!input_first && (rc = input_projection(dir, sd)) != ITR_OK) return rc;
             int64_t n_act = B;
             for (int t = 0; t < Lmax; ++t) {
                 while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
@@ -281,10 +322,10 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
                 if (rc != ITR_OK) return rc;
                 if (D % 4 == 0)
                     hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
-                                       dst, tok_off, len_dev, t, dir, 0, D, n_act);
+                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr);
                 else
                     hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
-                                       dst, tok_off, len_dev, t, dir, 0, D, n_act);
+                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr);
                 ITR_CHECK_LAUNCH("gru_gate");
             }
         }

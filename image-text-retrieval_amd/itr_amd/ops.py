@@ -12,6 +12,7 @@ import torch
 from . import _lib
 
 SCAN_NT = 64
+SCAN_R = 36            # regions per image the fused SCAN / SGRAF kernels are built for (csrc/scan_common.h SC_R)
 _NORMS = {'clipped_l2norm': 0, 'l2norm': 1, 'softmax': 2, 'no_norm': 3, 'clipped': 4, 'l1norm': 5,
           'clipped_l1norm': 6}
 _AGGS = {'LogSumExp': 0, 'Max': 1, 'Sum': 2, 'Mean': 3}
@@ -409,11 +410,14 @@ class ScanPlan:
 
 def scan_prepare(images, words, plan, cross_attn='t2i'):
     """Per (image block, caption set) precompute for the SCAN kernel: tile-packed words, Gram matrices,
-    norms.  Returns the prepared workspace (a uint8 tensor)."""
+    norms.  Returns the prepared workspace (a uint8 tensor); None when the images do not have the fused kernel's 36 regions
+    (scan_xattn_scores takes the pair kernels then, which prepare per block)."""
     lib = _lib.load()
     images = _dev(images, name="images")
     words = _dev(words, name="words")
     Ni, R, D = images.shape
+    if R != SCAN_R:
+        return None
     wsb = lib.itr_scan_workspace_bytes(Ni, R, words.shape[0], plan.Nc_kernel, plan.n_tiles, D)
     ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
     if Ni == 0 or plan.Nc_kernel == 0:
@@ -426,8 +430,9 @@ def scan_prepare(images, words, plan, cross_attn='t2i'):
 
 def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='clipped_l2norm',
                       agg_func='LogSumExp', lambda_lse=6.0, lambda_softmax=9.0, out=None, workspace=None, precision='fp32'):
-    """xattn_score_t2i / _i2t (Objectives.py:329-417).  images (Ni, 36, D); words (n_rows, D) with the
-    caption layout described by `plan` (ScanPlan).  -> (Ni, Nc).
+    """xattn_score_t2i / _i2t (Objectives.py:329-417).  images (Ni, R, D); words (n_rows, D) with the
+    caption layout described by `plan` (ScanPlan).  -> (Ni, Nc).  R = 36 (every reference configuration): the fused kernel;
+    any other R <= 100: the one-workgroup-per-pair kernels of the training path (_scan_scores_pairwise), same results.
     precision='bf16x3' / 'fp16x3' (opt-in study variants): the region x word dot products run on the 16-bit
     matrix core from split operands (hi.hi + hi.lo + lo.hi, fp32 accumulation; bf16 planes: ~3e-6, fp16 planes: ~1e-7 of the
     fp32 result, fp16 needs |x| <= 65504); everything else is unchanged."""
@@ -446,6 +451,13 @@ def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='c
         out = torch.empty(Ni, plan.Nc, device=images.device, dtype=torch.float32)
     if Ni == 0 or plan.Nc == 0:
         return out
+    if R != SCAN_R:
+        # the fused kernel is built for the 36 regions of every reference configuration (4 images = 144 rows = 9 MFMA row tiles);
+        # any other region count takes the one-workgroup-per-pair kernels of the training path (1..100 regions)
+        if precision != 'fp32':
+            raise NotImplementedError("scan_xattn_scores: precision=%r with %d regions per image (the fused kernel: %d)" % (precision, R, SCAN_R))
+        return _scan_scores_pairwise(images, words, plan, np.arange(plan.Nc), cross_attn, raw_feature_norm, agg_func, lambda_lse,
+                                     lambda_softmax, out)
     if plan.long_idx is not None:
         if precision != 'fp32':
             raise NotImplementedError("scan_xattn_scores: precision=%r with captions of more than %d words" % (precision, SCAN_NT))
@@ -482,13 +494,42 @@ def _scan_scores_with_long_captions(images, words, plan, cross_attn, norm, agg, 
             _p(images), plan.n_tiles, Ni, plan.Nc_kernel, words.shape[0], R, D, 0 if cross_attn == 't2i' else 1, _NORMS[norm],
             _AGGS[agg], float(lambda_softmax), float(lambda_lse), _p(part), part.stride(0), _p(ws), ws.numel(), _stream()))
         out[:, torch.from_numpy(plan.short_idx).to(dev)] = part
-    lens = plan.len_host[plan.long_idx]
-    rows = np.concatenate([np.arange(plan.off_host[c], plan.off_host[c] + plan.len_host[c]) for c in plan.long_idx])
-    w_long = words[torch.from_numpy(rows).to(dev)].contiguous()
-    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    return _scan_scores_pairwise(images, words, plan, plan.long_idx, cross_attn, norm, agg, lambda_lse, lambda_softmax, out)
+
+
+SCAN_PAIR_MAXW, SCAN_PAIR_RMAX = 96, 100          # csrc/scan_train.hip: ST_MAXW, ST_RMAX
+
+
+def _scan_scores_pairwise(images, words, plan, cap_idx, cross_attn, norm, agg, lambda_lse, lambda_softmax, out, budget_bytes=1 << 30):
+    """out[:, cap_idx] through the forward of the training path (csrc/scan_train*.hip: one GEMM for the raw dot products of a block
+    of pairs, one workgroup per (image, caption) pair for the rest) -- the captions the fused kernel does not take (65..96 words) and
+    every caption when the images do not have the 36 regions it is built for.  The pairs are cut into blocks whose dot-product
+    matrix [images x R, words] stays under `budget_bytes`."""
+    from . import autograd
+    Ni, R, D = images.shape
+    dev = images.device
+    cap_idx = np.asarray(cap_idx, dtype=np.int64)
+    lens_all = plan.len_host[cap_idx]
+    if R > SCAN_PAIR_RMAX or (len(lens_all) and int(lens_all.max()) > SCAN_PAIR_MAXW):
+        raise NotImplementedError("scan_xattn_scores: %d regions per image / captions of %d words (supported: <= %d regions; "
+                                  "captions of <= %d words)" % (R, int(lens_all.max()) if len(lens_all) else 0, SCAN_PAIR_RMAX, SCAN_PAIR_MAXW))
     fn = autograd.scan_t2i_scores if cross_attn == 't2i' else autograd.scan_i2t_scores
+    bi = int(min(Ni, 1024, 65535 // R))                               # grid.y and the i2t kernels' 65535-row limits
+    tok_budget = max(int(budget_bytes // (4 * bi * R)), SCAN_PAIR_MAXW)
+    csum = np.concatenate([[0], np.cumsum(lens_all)])
     with torch.no_grad():
-        out[:, torch.from_numpy(plan.long_idx).to(dev)] = fn(images, w_long, off, lens, norm, agg, lambda_lse, lambda_softmax)
+        c0 = 0
+        while c0 < len(cap_idx):
+            c1 = int(np.searchsorted(csum, csum[c0] + tok_budget, side='right')) - 1
+            c1 = min(max(c1, c0 + 1), len(cap_idx))
+            ids, lens = cap_idx[c0:c1], lens_all[c0:c1]
+            rows = np.concatenate([np.arange(plan.off_host[c], plan.off_host[c] + plan.len_host[c]) for c in ids])
+            w_blk = words[h2d(rows, dev)].contiguous()
+            off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            cols = h2d(ids, dev)
+            for i0 in range(0, Ni, bi):
+                out[i0:i0 + bi, cols] = fn(images[i0:i0 + bi], w_blk, off, lens, norm, agg, lambda_lse, lambda_softmax)
+            c0 = c1
     return out
 
 

@@ -302,8 +302,38 @@ def test_scan_errors(dev):
         ops.scan_xattn_padded(img, cap, [3, 3], raw_feature_norm='bogus')
     with pytest.raises(ValueError):
         ops.scan_xattn_padded(img, cap, [3, 3], agg_func='bogus')
-    with pytest.raises(NotImplementedError):
-        ops.scan_xattn_padded(torch.zeros(2, 30, 32, device=dev), cap, [3, 3])
+    with pytest.raises(NotImplementedError):                                     # more regions than the pair kernels' LDS block holds
+        ops.scan_xattn_padded(torch.zeros(2, 101, 32, device=dev), cap, [3, 3])
+    with pytest.raises(NotImplementedError):                                     # the split-precision study variants: 36 regions only
+        ops.scan_xattn_padded(torch.zeros(2, 30, 32, device=dev), cap, [3, 3], precision='bf16x3')
+
+
+@pytest.mark.parametrize("xa", ['t2i', 'i2t'])
+@pytest.mark.parametrize("R,Ni,Nc,D,max_len", [(30, 2, 2, 32, 3), (30, 7, 40, 256, 20), (49, 5, 33, 1024, 30), (100, 3, 12, 64, 90), (10, 4, 9, 32, 70)])
+def test_scan_scores_any_region_count(dev, xa, R, Ni, Nc, D, max_len):
+    """What `test_scan_errors` used to expect a NotImplementedError for: images with R != 36 regions.  The
+    evaluation entry point takes the pair kernels for them (ops._scan_scores_pairwise) -- here with a dot-product budget so small
+    that the captions are cut into several blocks -- and must match the oracle like the fused kernel does; all norms x aggregations
+    on the smallest case."""
+    rng = np.random.RandomState(R + Nc)
+    torch.manual_seed(R + Ni)
+    lens = [max_len] + [int(x) for x in rng.randint(1, max_len + 1, size=Nc - 1)]
+    img = O.l2norm(torch.randn(Ni, R, D), -1)
+    cap = torch.randn(Nc, max_len, D) * 0.5
+    want = O.xattn_score(img, cap, lens, xa)
+    got = ops.scan_xattn_padded(img.to(dev), cap.to(dev), lens, cross_attn=xa)
+    assert got.shape == (Ni, Nc) and maxdiff(got, want) <= 2e-5
+    plan = ops.ScanPlan(np.arange(Nc, dtype=np.int64) * max_len, lens, Nc * max_len, dev)
+    out = torch.full((Ni, Nc + 3), float("nan"), device=dev)
+    ops._scan_scores_pairwise(img.to(dev), cap.to(dev).reshape(Nc * max_len, D), plan, np.arange(Nc), xa, 'clipped_l2norm', 'LogSumExp', 6.0, 9.0,
+                              out[:, 1:Nc + 1], budget_bytes=4 * Ni * R * 2 * max_len)           # blocks of two or three captions
+    assert torch.equal(out[:, 1:Nc + 1], got) and bool(torch.isnan(out[:, 0]).all()) and bool(torch.isnan(out[:, Nc + 1:]).all())
+    if Nc == 2:
+        for norm in NORMS + ['l1norm', 'clipped_l1norm']:
+            for agg in AGGS:
+                want = O.xattn_score(img, cap, lens, xa, norm, agg)
+                got = ops.scan_xattn_padded(img.to(dev), cap.to(dev), lens, cross_attn=xa, raw_feature_norm=norm, agg_func=agg)
+                assert maxdiff(got, want) <= 2e-5 * (R if agg == 'Sum' else 1), (norm, agg)
 
 
 # ------------------------------------------------------------------------------------------ SGRAF
@@ -469,6 +499,39 @@ def test_gru_full_size_vs_oracle(dev):
     for b, l in enumerate(lengths):
         assert maxdiff(got[o:o + l], want[b, :l]) <= 5e-6
         o += l
+
+
+@pytest.mark.parametrize("V,E,D,B,lo,hi", [(11353, 300, 1024, 1500, 3, 24), (500, 64, 256, 1100, 1, 9), (800, 300, 1024, 24, 6, 21)])
+def test_bigru_launch_forms_are_bit_identical(dev, monkeypatch, V, E, D, B, lo, hi):
+    """The three ways csrc/towers.hip can issue a bi-GRU -- default: both input projections, then the two recurrences on two
+    streams; ITR_GRU_INPUT_AFTER_FORK=1: each direction's projection on its own stream (round 2); ITR_GRU_PAIRED=1: ONE GEMM and ONE
+    gate launch per time step for both directions (the second problem of `gemm_nt_fast_kernel`, blockIdx.z of the gate kernel) --
+    run the same arithmetic per element: bit-identical sequence outputs and last states, and equal to the oracle (EncoderText,
+    TextEncoder.py:38-70) on the rows it can afford."""
+    rng = np.random.RandomState(B)
+    torch.manual_seed(B)
+    lengths = sorted([int(x) for x in rng.randint(lo, hi + 1, size=B)], reverse=True)
+    ids = torch.from_numpy(rng.randint(0, V, size=(B, max(lengths))))
+    rnn = torch.nn.GRU(E, D, 1, batch_first=True, bidirectional=True)
+    w = {'embed.weight': torch.empty(V, E).uniform_(-0.1, 0.1)}
+    w.update({'rnn.' + k: v.detach() for k, v in rnn.state_dict().items()})
+    wd = {k: v.to(dev) for k, v in w.items()}
+    toks, off = pack(ids, lengths, dev)
+    kw = dict(batch_invariant=True) if B <= 1024 else {}          # small batches take the paired form only without split-K
+    got = ops.gru_encode(toks, off, lengths, wd, True, **kw)
+    got_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, **kw)
+    for env in ("ITR_GRU_PAIRED", "ITR_GRU_INPUT_AFTER_FORK"):
+        monkeypatch.setenv(env, "1")
+        two = ops.gru_encode(toks, off, lengths, wd, True, **kw)
+        two_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, **kw)
+        monkeypatch.delenv(env)
+        assert torch.equal(got, two) and torch.equal(got_last, two_last), env
+    n = 20                                                         # the oracle on the 20 longest captions (a GRU row depends on no other row)
+    want, _ = O.encoder_text(ids[:n], lengths[:n], w, True, False, False, None)
+    o = 0
+    for b in range(n):
+        assert maxdiff(got[o:o + lengths[b]].cpu(), want[b, :lengths[b]]) <= 5e-6
+        o += lengths[b]
 
 
 def test_gru_rejects_unsorted(dev):

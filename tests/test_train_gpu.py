@@ -166,6 +166,46 @@ def test_scan_backward_vs_oracle_autograd(dev, norm, agg, xa):
 
 
 @pytest.mark.parametrize("xa", ['t2i', 'i2t'])
+@pytest.mark.parametrize("R,max_len", [(30, 12), (1, 5), (35, 80), (49, 20), (100, 64), (100, 96), (37, 70)])
+def test_scan_any_region_count(dev, xa, R, max_len):
+    """images with a region count other than the reference's 36 (csrc/scan_train*.hip: the FIXED = false
+    instantiations, 1..36 regions in the 36-region LDS block, 37..100 in the 100-region one).  Scores and gradients against the
+    oracle under autograd, all first norms x two aggregations.  The t2i backward keeps one more regions x words block: more than
+    36 regions with captions of more than 64 words is the one combination that does not fit a CU's LDS (NotImplementedError)."""
+    rng = np.random.RandomState(R)
+    torch.manual_seed(R)
+    Bi, Bc, D = 3, 5, 64
+    lens = [max_len] + [int(x) for x in rng.randint(1, max_len + 1, size=Bc - 1)]
+    img = O.l2norm(torch.randn(Bi, R, D), -1)
+    cap = torch.randn(Bc, max_len, D) * 0.6
+    gS = torch.randn(Bi, Bc)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    words = torch.cat([cap[k, :lens[k]] for k in range(Bc)], 0)
+    fn = ag.scan_t2i_scores if xa == 't2i' else ag.scan_i2t_scores
+    for norm, agg in [('clipped_l2norm', 'LogSumExp'), ('softmax', 'Mean'), ('l2norm', 'Max'), ('clipped_l1norm', 'Sum'), ('no_norm', 'LogSumExp')]:
+        a, c = img.clone().requires_grad_(True), cap.clone().requires_grad_(True)
+        with torch.enable_grad():
+            S = O.xattn_score(a, c, lens, xa, norm, agg, 6.0, 9.0)
+            (S * gS).sum().backward()
+        ad, wd = img.to(dev).requires_grad_(True), words.to(dev).requires_grad_(True)
+        with torch.enable_grad():
+            Sd = fn(ad, wd, off, lens, norm, agg, 6.0, 9.0)
+        tol = 2e-5 * (max(R, max_len) if agg == 'Sum' else 1)
+        assert md(Sd, S) <= tol, (norm, agg)
+        if xa == 't2i' and R > 36 and max_len > 64:
+            with pytest.raises(NotImplementedError):
+                (Sd * gS.to(dev)).sum().backward()
+            continue
+        (Sd * gS.to(dev)).sum().backward()
+        want_w = torch.cat([c.grad[k, :lens[k]] for k in range(Bc)], 0)
+        scale = max(1.0, float(a.grad.abs().max()), float(want_w.abs().max()))
+        assert md(ad.grad, a.grad) <= 2e-5 * scale, (norm, agg)
+        assert md(wd.grad, want_w) <= 2e-5 * scale, (norm, agg)
+    with pytest.raises(NotImplementedError):
+        fn(torch.zeros(2, 101, D, device=dev), wd.detach(), off, lens)
+
+
+@pytest.mark.parametrize("xa", ['t2i', 'i2t'])
 def test_scan_train_long_captions(dev, xa):
     """Training batches may hold captions of up to 96 tokens (the longest Flickr30k caption has 82)."""
     torch.manual_seed(11)
