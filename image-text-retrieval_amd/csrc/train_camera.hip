@@ -185,10 +185,12 @@ __global__ __launch_bounds__(256) void l2norm_mid_bwd_kernel(const float *__rest
 }
 
 // ---- multi-view summarisation: L = softmax over the R regions of smry [B, R, K]; out[b, v, d] = sum_r L[b, r, v] x[b, r, d]
-constexpr int SM_R = 96, SM_K = 96;      // (SGRAF: K = words of a caption / graph nodes; the longest Flickr30k caption has 82 tokens)
+int allow_dynamic_lds(const void *kernel, size_t bytes);      // scan_train.hip
+constexpr int SM_R = 192, SM_K = 192;    // (SGRAF: K = words of a caption / graph nodes; the longest Flickr30k caption has 82 tokens.  The R x K softmax block is
+                                         //  dynamic LDS: 36 KB at 96 x 96, 144 KB at the limit)
 __global__ __launch_bounds__(256) void smry_fwd_kernel(const float *__restrict__ smry, const float *__restrict__ x, float *__restrict__ Lout,
                                                        float *__restrict__ out, int R, int K, int D) {
-    __shared__ float sl[SM_R][SM_K];
+    extern __shared__ __attribute__((aligned(16))) float sl[];      // [R][K]
     const int64_t b = blockIdx.y;
     const int t = threadIdx.x;
     if (t < K) {
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void smry_fwd_kernel(const float *__restrict__
         for (int r = 0; r < R; ++r) den += expf(smry[(b * R + r) * K + t] - m);
         for (int r = 0; r < R; ++r) {
             const float p = expf(smry[(b * R + r) * K + t] - m) / den;
-            sl[r][t] = p;
+            sl[r * K + t] = p;
             if (blockIdx.x == 0) Lout[(b * R + r) * K + t] = p;
         }
     }
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void smry_fwd_kernel(const float *__restrict__
     if (d >= D) return;
     for (int v = 0; v < K; ++v) {
         float s = 0.f;
-        for (int r = 0; r < R; ++r) s = fmaf(sl[r][v], x[(b * R + r) * D + d], s);
+        for (int r = 0; r < R; ++r) s = fmaf(sl[r * K + v], x[(b * R + r) * D + d], s);
         out[(b * K + v) * D + d] = s;
     }
 }
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void smry_bwd_l_kernel(const float *__restrict
     }
 }
 // softmax backward over the R axis: dsmry[b, r, v] = L (dLraw - sum_r dLraw L)
-__global__ __launch_bounds__(128) void smry_bwd_softmax_kernel(const float *__restrict__ L, const float *__restrict__ dLraw,
+__global__ __launch_bounds__(256) void smry_bwd_softmax_kernel(const float *__restrict__ L, const float *__restrict__ dLraw,
                                                               float *__restrict__ dsmry, int R, int K) {
     const int64_t b = blockIdx.x;
     const int v = threadIdx.x;
@@ -383,10 +385,15 @@ extern "C" int itr_l2norm_mid_bwd(const float *dz, const float *z, const float *
 }
 
 extern "C" int itr_smry_fwd(const float *smry, const float *x, float *L, float *out, int64_t B, int R, int K, int D, itr_stream_t stream) {
-    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_fwd: at most 96 rows, 96 columns, 65535 groups");
+    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_fwd: at most 192 rows, 192 columns, 65535 groups");
     if (B == 0) return ITR_OK;
     ITR_REQUIRE(smry && x && L && out, "itr_smry_fwd: null pointer");
-    hipLaunchKernelGGL(itr::smry_fwd_kernel, dim3((unsigned)itr::ceil_div(D, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), smry, x, L, out,
+    const size_t lds = (size_t)R * K * sizeof(float);
+    if (lds > 48 * 1024) {
+        const int rc = itr::allow_dynamic_lds(reinterpret_cast<const void *>(itr::smry_fwd_kernel), (size_t)itr::SM_R * itr::SM_K * sizeof(float));
+        if (rc != ITR_OK) return rc;
+    }
+    hipLaunchKernelGGL(itr::smry_fwd_kernel, dim3((unsigned)itr::ceil_div(D, 256), (unsigned)B), dim3(256), lds, itr::as_stream(stream), smry, x, L, out,
                        R, K, D);
     ITR_CHECK_LAUNCH("smry_fwd");
     return ITR_OK;
@@ -394,14 +401,14 @@ extern "C" int itr_smry_fwd(const float *smry, const float *x, float *L, float *
 
 extern "C" int itr_smry_bwd(const float *x, const float *L, const float *dout, float *dx, float *dsmry, float *scratch, int64_t B, int R, int K,
                             int D, itr_stream_t stream) {
-    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_bwd: at most 96 rows, 96 columns, 65535 groups");
+    ITR_REQUIRE(B >= 0 && B <= 65535 && R >= 1 && R <= itr::SM_R && K >= 1 && K <= itr::SM_K && D >= 1, "itr_smry_bwd: at most 192 rows, 192 columns, 65535 groups");
     if (B == 0) return ITR_OK;
     ITR_REQUIRE(x && L && dout && dx && dsmry && scratch, "itr_smry_bwd: null pointer (scratch: B * R * K floats)");
     ITR_REQUIRE(B * R <= 0x7fffffff, "itr_smry_bwd: too many rows");
     hipLaunchKernelGGL(itr::smry_bwd_x_kernel, dim3((unsigned)itr::ceil_div(D, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), L, dout, dx, R,
                        K, D);
     hipLaunchKernelGGL(itr::smry_bwd_l_kernel, dim3((unsigned)(B * R)), dim3(256), 0, itr::as_stream(stream), x, dout, scratch, R, K, D);
-    hipLaunchKernelGGL(itr::smry_bwd_softmax_kernel, dim3((unsigned)B), dim3(128), 0, itr::as_stream(stream), L, scratch, dsmry, R, K);
+    hipLaunchKernelGGL(itr::smry_bwd_softmax_kernel, dim3((unsigned)B), dim3(256), 0, itr::as_stream(stream), L, scratch, dsmry, R, K);
     ITR_CHECK_LAUNCH("smry_bwd");
     return ITR_OK;
 }

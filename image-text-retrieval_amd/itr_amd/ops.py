@@ -686,6 +686,7 @@ _SAF_MAP = {"saf_w": "SAF_module.attn_sim_w.weight", "saf_b": "SAF_module.attn_s
 
 
 SGRAF_MAX_WORDS = 63      # fused pair kernels: 63 words + the global node = one 64-row tile
+SGRAF_COMPOSED_MAX_WORDS = 191   # the per-caption composition: 191 words + the global node = the 192 graph nodes itr_smry_fwd holds
 
 
 def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, out=None):
@@ -727,7 +728,7 @@ def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, ou
     if plan.long_idx is not None:
         # Captions of more than 63 words (Flickr30k has a few, up to 82 tokens) do not fit the 64-node tiles of the fused pair
         # kernels: the others are scored by the fused path, these by the per-caption composition of the training path run in
-        # evaluation mode (Fusionmodule.encoder_similarity_train(training=False): same arithmetic, HIP kernels, up to 95 words).
+        # evaluation mode (Fusionmodule.encoder_similarity_train(training=False): same arithmetic, HIP kernels, up to 191 words).
         from .modalmodule import Fusionmodule
         dev = images.device
         if plan.Nc_kernel:
@@ -746,8 +747,8 @@ def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, ou
         sim_enc.load_state_dict({k: (weights[k].detach() if k in weights else own[k]) for k in own if k in weights or k.endswith('num_batches_tracked')})
         sim_enc.to(dev).eval()
         lens = [int(plan.len_host[c]) for c in plan.long_idx]
-        if max(lens) > 95:
-            raise NotImplementedError("sgraf_scores: captions of at most 95 words are supported")
+        if max(lens) > SGRAF_COMPOSED_MAX_WORDS:
+            raise NotImplementedError("sgraf_scores: captions of at most %d words are supported" % SGRAF_COMPOSED_MAX_WORDS)
         rows = np.concatenate([np.arange(plan.off_host[c], plan.off_host[c] + plan.len_host[c]) for c in plan.long_idx])
         w_long = words[torch.from_numpy(rows).to(dev)].contiguous()
         off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)

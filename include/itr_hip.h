@@ -439,11 +439,14 @@ int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *le
                 float *d_b_ih_rev, float *d_b_hh_rev, void *workspace, size_t workspace_bytes, itr_stream_t stream);
 
 /* SCAN t2i similarity of a TRAINING batch (xattn_score_t2i, Objectives.py:329-372, under autograd).
- *   A [Bi*36, ldA] = V E^T  raw dot products (itr_gemm_nt), G [Bi, 36, 36] = V_i V_i^T and enorm[n_tok] = ||e_w||
+ *   A [Bi*R, ldA] = V E^T  raw dot products (itr_gemm_nt), G [Bi, R, R] = V_i V_i^T and enorm[n_tok] = ||e_w||
  *   (itr_scan_train_prepare);  captions packed: cap_off[Bc], cap_len[Bc] (any order), at most 96 words.
+ *   R regions per image: 36 in every reference configuration (compile-time loop bounds); any other 1 <= R <= 100 runs the
+ *   same kernels with run-time bounds (the evaluation entry point's path for images that are not 36 regions).  The backward
+ *   holds one more R x W block in LDS: R > 36 together with max_len > 64 returns ITR_ERR_UNSUPPORTED.
  *   norm in {0 clipped_l2norm, 1 l2norm, 2 softmax, 3 no_norm, 4 clipped, 5 l1norm, 6 clipped_l1norm};
  *   agg in {0 LogSumExp, 1 Max, 2 Sum, 3 Mean}.
- * itr_scan_train_bwd (dS [Bi, Bc]) writes dA [Bi*36, ldA], per-pair Gram gradients dG_pairs [Bi, Bc, 36, 36] and
+ * itr_scan_train_bwd (dS [Bi, Bc]) writes dA [Bi*R, ldA], per-pair Gram gradients dG_pairs [Bi, Bc, R, R] and
  * d_enorm_pairs [Bi, ldA]; the caller finishes with GEMMs  dV = dA E,  dE = dA^T V  and itr_scan_train_finish, which
  * ADDS (sum_c dG + its transpose) V_i to dV and  colsum_i(d_enorm_pairs) e / ||e||  (d_enorm [n_tok]) to dE. */
 int itr_scan_train_prepare(const float *V, const float *E, int64_t Bi, int64_t n_tok, int R, int D, float *G,
@@ -461,8 +464,8 @@ int itr_scan_train_finish(const float *dG_pairs, int64_t Bi, int64_t Bc, const f
 
 /* SCAN i2t similarity of a TRAINING batch (xattn_score_i2t, Objectives.py:376-417, under autograd): regions attend over
  * the words of a caption.  A as above; H = packed caption Gram matrices (caption c: W_c x W_c floats at H + h_off[c],
- * h_total = sum W_c^2) and vnorm[Bi*36] = ||v_r|| (itr_scan_train_i2t_prepare).  itr_scan_train_i2t_bwd writes dA,
- * per-pair dH partials dH_pairs [Bi, h_total] and d||v|| partials d_vnorm_pairs [Bc, Bi*36]; the caller sums them over
+ * h_total = sum W_c^2) and vnorm[Bi*R] = ||v_r|| (itr_scan_train_i2t_prepare; R as above, 1..100).  itr_scan_train_i2t_bwd writes dA,
+ * per-pair dH partials dH_pairs [Bi, h_total] and d||v|| partials d_vnorm_pairs [Bc, Bi*R]; the caller sums them over
  * images / captions (itr_colsum), runs  dV = dA E,  dE = dA^T V  and itr_scan_train_i2t_finish, which ADDS
  * (dH_c + dH_c^T) E_c to dE and  d||v|| v / ||v||  to dV. */
 int itr_scan_train_i2t_prepare(const float *V, const float *E, const int64_t *cap_off, const int32_t *cap_len,
