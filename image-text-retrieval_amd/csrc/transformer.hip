@@ -144,9 +144,8 @@ __global__ __launch_bounds__(64 * WPB) void mha_mfma_kernel(const float *__restr
                                                             const float *__restrict__ mask, float *__restrict__ out, int64_t ldo,
                                                             int L, int heads, float scale, int64_t npairs) {
     constexpr int LP = NT * 16, NPL = DK / 4, VST = DK + 16, PST = LP + 2, NDT = DK / 16;
-    constexpr int QK_F4 = NPL * LP;                                   // float4 per operand
     constexpr int V_F4 = (LP * VST + 3) / 4, P_F4 = (LP * PST + 3) / 4;
-    constexpr int WAVE_F4 = 2 * QK_F4 + V_F4 + P_F4;
+    constexpr int WAVE_F4 = V_F4 + P_F4;
     extern __shared__ float4 mha_smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -154,25 +153,30 @@ __global__ __launch_bounds__(64 * WPB) void mha_mfma_kernel(const float *__restr
     if (pair >= npairs) return;
     const int b = (int)(pair / heads), h = (int)(pair % heads);
     const int64_t row0 = (int64_t)b * L;
-    float4 *Qp = mha_smem + (size_t)wave * WAVE_F4;
-    float4 *Kp = Qp + QK_F4;
-    float *Vs = reinterpret_cast<float *>(Kp + QK_F4);
-    float *Ps = reinterpret_cast<float *>(Kp + QK_F4 + V_F4);
-    // ---- stage Q, K (plane layout) and V (row-major), zero rows beyond L
+    float *Vs = reinterpret_cast<float *>(mha_smem + (size_t)wave * WAVE_F4);
+    float *Ps = reinterpret_cast<float *>(mha_smem + (size_t)wave * WAVE_F4 + V_F4);
+    const int fi = lane & 15, fg = lane >> 4;
+    // ---- Q and K straight from memory in MFMA fragment order (round 3; before, both went through LDS in a plane layout, 30 KB per
+    // wave = ONE workgroup of four waves per CU, and a (sequence, head) pair was one exposed memory round trip after another at 1.4
+    // TB/s): lane (fi, fg) owns the 16 bytes [4 (4 qq + fg), + 4) of row 16 t + fi -- 64 contiguous bytes per row and instruction.
+    // Rows beyond L re-read row L - 1: their scores are masked (keys) or never stored (queries).  V goes to LDS row-major (the B
+    // operand of P V is read by key row), zero rows beyond L.  Everything is requested before the first wait.
+    float4 qf[NPL / 4][NT], kf[NPL / 4][NT];
+#pragma unroll
+    for (int qq = 0; qq < NPL / 4; ++qq)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int row = (t * 16 + fi < L) ? t * 16 + fi : L - 1;
+            qf[qq][t] = *reinterpret_cast<const float4 *>(q + (row0 + row) * ldq + h * DK + 4 * (4 * qq + fg));
+            kf[qq][t] = *reinterpret_cast<const float4 *>(k + (row0 + row) * ldk + h * DK + 4 * (4 * qq + fg));
+        }
     for (int idx = lane; idx < LP * NPL; idx += 64) {
         const int row = idx / NPL, p = idx % NPL;
-        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), kv = qv, vv = qv;
-        if (row < L) {
-            qv = *reinterpret_cast<const float4 *>(q + (row0 + row) * ldq + h * DK + 4 * p);
-            kv = *reinterpret_cast<const float4 *>(k + (row0 + row) * ldk + h * DK + 4 * p);
-            vv = *reinterpret_cast<const float4 *>(v + (row0 + row) * ldv + h * DK + 4 * p);
-        }
-        Qp[p * LP + (row ^ (p & 7))] = qv;
-        Kp[p * LP + (row ^ (p & 7))] = kv;
+        float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < L) vv = *reinterpret_cast<const float4 *>(v + (row0 + row) * ldv + h * DK + 4 * p);
         float *vd = Vs + row * VST + 4 * p;
         vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
     }
-    const int fi = lane & 15, fg = lane >> 4;
     // ---- S = Q K^T
     f32x4 sacc[NT][NT];
 #pragma unroll
@@ -181,13 +185,8 @@ __global__ __launch_bounds__(64 * WPB) void mha_mfma_kernel(const float *__restr
         for (int nt = 0; nt < NT; ++nt) sacc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qq = 0; qq < NPL / 4; ++qq) {
-        const int pl = 4 * qq + fg;
-        float4 a[NT], bb[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            a[t] = Qp[pl * LP + ((t * 16 + fi) ^ (pl & 7))];
-            bb[t] = Kp[pl * LP + ((t * 16 + fi) ^ (pl & 7))];
-        }
+        const float4(&a)[NT] = qf[qq];
+        const float4(&bb)[NT] = kf[qq];
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
@@ -273,11 +272,154 @@ __global__ __launch_bounds__(64 * WPB) void mha_mfma_kernel(const float *__restr
         }
 }
 
+// The same attention entirely in registers (round 3): no LDS, no staging pass.
+//   S^T = K Q^T   A = K fragments, B = Q fragments, both read from memory in fragment order (lane (fi, fg): 16 bytes at column
+//                 4 (4 qq + fg) of row 16 t + fi).  Accumulator j of tile (nt, mt) = S[query 16 mt + fi][key 16 nt + 4 fg + j]:
+//                 a query's keys live in ONE lane column -- the softmax reduces over registers and the four 16-lane rows (two
+//                 v_permlane swaps), and the normalised weights ARE the B operand of the next product (k index fg <-> key 4 fg + j).
+//   ctx^T = V^T P^T   A = V[key 16 nt + 4 fg + j][d 16 dt + fi], one dword per lane straight from memory (64 contiguous bytes per
+//                 key row); accumulator j' of tile (dt, mt) = ctx[query 16 mt + fi][d 16 dt + 4 fg + j'] -> ONE 16-byte store.
+// Against the LDS kernel above (Q, K, V, P staged per wave: 30 KB at L <= 32 -> four waves per CU, each a chain of exposed memory
+// round trips; tools/mha_bench.py, B = 3 571 sequences x 12 heads x 64): L = 12 / 30 / 45 / 64: 133 / 468 / 1 381 / 2 046 us -> 97 / 289 / 492 /
+// 933 us (5.4 / 4.6 / 4.0 / 3.0 TB/s of q + k + v + context).  Rows beyond L re-read row L - 1: as keys they are masked to weight 0, as
+// queries never stored.  The LDS kernel (itself 20-50 % faster since Q and K skip the LDS) remains for outputs without 16-byte rows.
+__device__ __forceinline__ float mha_rows_max(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float mha_rows_sum(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+template <int DK, int NT>
+__global__ __launch_bounds__(256) void mha_reg_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                      const float *__restrict__ v, int64_t ldq, int64_t ldk, int64_t ldv,
+                                                      const float *__restrict__ mask, float *__restrict__ out, int64_t ldo,
+                                                      int L, int heads, float scale, int64_t npairs) {
+    constexpr int NKQ = DK / 16, NDT = DK / 16;
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= npairs) return;
+    const int b = (int)(pair / heads), h = (int)(pair % heads);
+    const int64_t row0 = (int64_t)b * L;
+    const int fi = lane & 15, fg = lane >> 4;
+    int rowt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) rowt[t] = (t * 16 + fi < L) ? t * 16 + fi : L - 1;
+    float4 qf[NKQ][NT], kf[NKQ][NT];
+#pragma unroll
+    for (int qq = 0; qq < NKQ; ++qq)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            qf[qq][t] = *reinterpret_cast<const float4 *>(q + (row0 + rowt[t]) * ldq + h * DK + 4 * (4 * qq + fg));
+            kf[qq][t] = *reinterpret_cast<const float4 *>(k + (row0 + rowt[t]) * ldk + h * DK + 4 * (4 * qq + fg));
+        }
+    // additive mask of this lane's keys (bert.py:340-341); keys beyond L drop out
+    float madd[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = nt * 16 + 4 * fg + j;
+            madd[nt][j] = key < L ? (mask ? (1.0f - mask[row0 + key]) * -10000.0f : 0.f) : -INFINITY;
+        }
+    f32x4 sacc[NT][NT];      // [key tile][query tile]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) sacc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qq = 0; qq < NKQ; ++qq) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) sacc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[qq][nt].x, qf[qq][mt].x, sacc[nt][mt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) sacc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[qq][nt].y, qf[qq][mt].y, sacc[nt][mt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) sacc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[qq][nt].z, qf[qq][mt].z, sacc[nt][mt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) sacc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[qq][nt].w, qf[qq][mt].w, sacc[nt][mt], 0, 0, 0);
+    }
+    // V operands of the second product (requested here: in flight during the softmax)
+    float vf[NT][4][NDT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = nt * 16 + 4 * fg + j;
+            const float *vr = v + (row0 + (key < L ? key : L - 1)) * ldv + h * DK + fi;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) vf[nt][j][dt] = vr[16 * dt];
+        }
+    // softmax over the keys of query 16 mt + fi
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sacc[nt][mt][j] = sacc[nt][mt][j] * scale + madd[nt][j];
+                mx = fmaxf(mx, sacc[nt][mt][j]);
+            }
+        mx = mha_rows_max(mx);
+        float den = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sacc[nt][mt][j] = expf(sacc[nt][mt][j] - mx);
+                den += sacc[nt][mt][j];
+            }
+        den = mha_rows_sum(den);
+        const float inv = 1.f / den;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sacc[nt][mt][j] *= inv;
+    }
+    // ctx^T = V^T P^T
+    f32x4 cacc[NDT][NT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) cacc[dt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) cacc[dt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[nt][j][dt], sacc[nt][mt][j], cacc[dt][mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        const int m = mt * 16 + fi;
+        if (m < L) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+                *reinterpret_cast<float4 *>(out + (row0 + m) * ldo + h * DK + dt * 16 + 4 * fg) =
+                    float4{cacc[dt][mt][0], cacc[dt][mt][1], cacc[dt][mt][2], cacc[dt][mt][3]};
+        }
+    }
+}
+
 template <int DK, int NT, int WPB>
 static int launch_mha_mfma(const float *q, const float *k, const float *v, int64_t ldq, int64_t ldk, int64_t ldv, const float *mask,
                            float *out, int64_t ldo, int64_t B, int L, int heads, float scale, hipStream_t st) {
-    constexpr int LP = NT * 16, NPL = DK / 4, VST = DK + 16, PST = LP + 2;
-    constexpr size_t wave_bytes = (size_t)(2 * NPL * LP + (LP * VST + 3) / 4 + (LP * PST + 3) / 4) * 16;
+    constexpr int LP = NT * 16, VST = DK + 16, PST = LP + 2;
+    constexpr size_t wave_bytes = (size_t)((LP * VST + 3) / 4 + (LP * PST + 3) / 4) * 16;
     constexpr size_t lds = wave_bytes * WPB;
     static bool attr = false;
     if (!attr) {
@@ -296,6 +438,20 @@ template <int DK>
 static int dispatch_mha_mfma(const float *q, const float *k, const float *v, int64_t ldq, int64_t ldk, int64_t ldv, const float *mask,
                              float *out, int64_t ldo, int64_t B, int L, int heads, float scale, hipStream_t st) {
     const int nt = (L + 15) / 16;
+    // the register-only kernel: 16-byte context stores (ITR_MHA_LDS=1: the LDS kernel, for A/B timing)
+    if (ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !getenv("ITR_MHA_LDS")) {
+        const int64_t npairs = B * heads;
+        const dim3 grid((unsigned)ceil_div(npairs, (int64_t)4));
+#define ITR_MHA_REG(NT_)                                                                                                          \
+        hipLaunchKernelGGL((mha_reg_kernel<DK, NT_>), grid, dim3(256), 0, st, q, k, v, ldq, ldk, ldv, mask, out, ldo, L, heads, scale, npairs)
+        if (nt == 1) ITR_MHA_REG(1);
+        else if (nt == 2) ITR_MHA_REG(2);
+        else if (nt == 3) ITR_MHA_REG(3);
+        else ITR_MHA_REG(4);
+#undef ITR_MHA_REG
+        ITR_CHECK_LAUNCH("mha_reg");
+        return ITR_OK;
+    }
     if (nt == 1) return launch_mha_mfma<DK, 1, 4>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
     if (nt == 2) return launch_mha_mfma<DK, 2, 4>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
     if (nt == 3) return launch_mha_mfma<DK, 3, 2>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);

@@ -3,6 +3,7 @@ attention (AGSA), dilated-convolution multi-view summarisation, box position enc
 HIP forward (evaluation mode: BatchNorm running statistics, dropout off)."""
 import copy
 import math
+import os
 
 import torch
 from torch import nn
@@ -51,10 +52,14 @@ class GatedQueryAttLayer(nn.Module):
         dk = self.d_k
         q, k, v = [_lin(inp.reshape(B * L, D), l) for l in self.linears]       # (B*L, D) each
         q2, k2 = q.view(-1, dk), k.view(-1, dk)                                # (B*L*h, dk): heads are contiguous
-        G = ops.mul_rows(_lin(q2, self.fc_q), _lin(k2, self.fc_k))             # fc_q(query) * fc_k(key)   :38
-        M = _lin(G, self.fc_g, act='sigmoid')                                  # (B*L*h, 2*dk)              :39
-        q2 = ops.mul_rows(q2, M[:, :dk])
-        k2 = ops.mul_rows(k2, M[:, dk:])
+        if dk in (16, 32) and not os.environ.get("ITR_AGSA_UNFUSED"):          # one kernel for the gate (csrc/agsa_gate.hip); env: A/B switch
+            q2, k2 = ops.agsa_gate(q2, k2, (self.fc_q.weight, self.fc_q.bias), (self.fc_k.weight, self.fc_k.bias),
+                                   (self.fc_g.weight, self.fc_g.bias))
+        else:
+            G = ops.mul_rows(_lin(q2, self.fc_q), _lin(k2, self.fc_k))         # fc_q(query) * fc_k(key)   :38
+            M = _lin(G, self.fc_g, act='sigmoid')                              # (B*L*h, 2*dk)              :39
+            q2 = ops.mul_rows(q2, M[:, :dk])
+            k2 = ops.mul_rows(k2, M[:, dk:])
         x = ops.mha_small(q2.view(B * L, D), k2.view(B * L, D), v, None, B, L, self.h, dk, 1.0 / math.sqrt(dk))
         return x.view(B, L, D)
 

@@ -608,6 +608,21 @@ def mul_rows(a, b2d):
     return out
 
 
+def agsa_gate(q2, k2, fc_q, fc_k, fc_g):
+    """GatedQueryAttLayer's gate (camera_.py:36-44) on q2, k2 [rows, dk] (rows = positions x heads; dk = 16 or 32), fc_* = (weight,
+    bias) of the three Linear layers -> (q2 * M[:, :dk], k2 * M[:, dk:]) with M = sigmoid(fc_g(fc_q(q2) * fc_k(k2))).  One kernel
+    (csrc/agsa_gate.hip) instead of three skinny GEMMs and three elementwise products."""
+    lib = _lib.load()
+    q2, k2 = _dev(q2, name="q"), _dev(k2, name="k")
+    rows, dk = q2.shape
+    w = [_dev(t.detach(), name="gate weight") for pair in (fc_q, fc_k, fc_g) for t in pair]
+    if w[0].shape != (dk, dk) or w[2].shape != (dk, dk) or w[4].shape != (2 * dk, dk) or k2.shape != q2.shape:
+        raise ValueError("agsa_gate: q / k [rows, dk], fc_q / fc_k Linear(dk, dk), fc_g Linear(dk, 2 dk)")
+    qo, ko = torch.empty_like(q2), torch.empty_like(k2)
+    _lib.check(lib.itr_agsa_gate(_p(q2), _p(k2), rows, dk, _p(w[0]), _p(w[1]), _p(w[2]), _p(w[3]), _p(w[4]), _p(w[5]), _p(qo), _p(ko), _stream()))
+    return qo, ko
+
+
 def affine_cols(x, scale=None, shift=None, residual=None, act=None):
     """act(x*scale[c] + shift[c]) + residual (eval-mode BatchNorm1d folded to scale / shift)."""
     lib = _lib.load()

@@ -216,6 +216,9 @@ int itr_relu_maxpool(const float *x, float *out, int64_t ldo, int64_t B, int L, 
  * itr_gemm_nt_acc     : C = act(C + A B^T + bias)  -- sums the taps of the dilated Conv1d summarisation (:100-103)
  * itr_mul_rows        : out[r,c] = a[r,c] * b[r*ldb + c]   (position gating :75, query/key gates :38-40)
  * itr_affine_cols     : out = act(x*scale[c] + shift[c]) + residual  (eval BatchNorm1d folded; scale/shift/residual may be NULL)
+ * itr_agsa_gate       : the query / key gate of GatedQueryAttLayer.forward (:36-44) in one kernel: rows = positions x heads, q / k
+ *                       [rows, dk] (dk = 16 or 32; other head sizes: compose itr_gemm_nt + itr_mul_rows),  G = fc_q(q) * fc_k(k),
+ *                       M = sigmoid(fc_g(G)) [rows, 2 dk],  q_out = q * M[:, :dk],  k_out = k * M[:, dk:]  (outputs may alias inputs)
  * itr_camera_posenc   : absoluteEncode(boxes, imgs_wh) -> [B*R, 6]   (:118-128)
  * itr_camera_summarize: softmax over regions of smry[B,R,k], L^T X, F.normalize -> [B,k,D]  (ImgEncoder.py:385-389) */
 int itr_gemm_nt_acc(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
@@ -223,6 +226,8 @@ int itr_gemm_nt_acc(const float *A, int64_t lda, const float *B, int64_t ldb, co
 int itr_mul_rows(const float *a, const float *b, int64_t ldb, float *out, int64_t R, int C, itr_stream_t stream);
 int itr_affine_cols(const float *x, const float *scale, const float *shift, const float *residual, float *out,
                     int64_t R, int C, int act, itr_stream_t stream);
+int itr_agsa_gate(const float *q, const float *k, int64_t rows, int dk, const float *Wq, const float *bq, const float *Wk,
+                  const float *bk, const float *Wg, const float *bg, float *q_out, float *k_out, itr_stream_t stream);
 int itr_camera_posenc(const float *boxes, const float *imgs_wh, float *out, int64_t B, int R, itr_stream_t stream);
 int itr_camera_summarize(const float *smry, const float *X, float *out, int64_t B, int R, int k, int D,
                          itr_stream_t stream);

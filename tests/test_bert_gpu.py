@@ -142,9 +142,13 @@ def test_aux_losses_golden(golden, dev):
 
 @pytest.mark.parametrize("dk", [16, 32, 64])
 @pytest.mark.parametrize("L", [1, 7, 16, 17, 32, 36, 49, 64])
-def test_attention_kernel_shapes(dev, L, dk):
-    """softmax(Q K^T / sqrt(dk) + (1 - mask) * -10000) V (bert.py:185-207) for every tile count / head width of the
-    matrix-core kernel, with a ragged key mask, fused-QKV strides, and an odd number of (sequence, head) pairs."""
+@pytest.mark.parametrize("lds", [False, True])
+def test_attention_kernel_shapes(dev, monkeypatch, L, dk, lds):
+    """softmax(Q K^T / sqrt(dk) + (1 - mask) * -10000) V (bert.py:185-207) for every tile count / head width of the two
+    matrix-core kernels (register-only: the default; LDS-staged: outputs without 16-byte rows, forced here by ITR_MHA_LDS=1),
+    with a ragged key mask, fused-QKV strides, and an odd number of (sequence, head) pairs."""
+    if lds:
+        monkeypatch.setenv("ITR_MHA_LDS", "1")
     torch.manual_seed(L * 100 + dk)
     B, heads = 3, 3
     H = heads * dk
@@ -162,6 +166,23 @@ def test_attention_kernel_shapes(dev, L, dk):
     got2 = ops.mha_small(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], None, B, L, heads, dk, scale)
     want2 = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, H)
     assert float((got2.cpu() - want2).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("dk,rows", [(32, 16 * 700 + 5), (16, 16 * 300 + 11), (32, 3), (16, 16)])
+def test_agsa_gate(dev, dk, rows):
+    """GatedQueryAttLayer's gate (camera_.py:36-44) as one kernel (csrc/agsa_gate.hip) against float64: M = sigmoid(fc_g(fc_q(q) *
+    fc_k(k))), q * M[:, :dk], k * M[:, dk:]; a ragged last 16-row tile, fewer rows than one tile, exactly one tile."""
+    torch.manual_seed(dk + rows)
+    q, k = torch.randn(rows, dk), torch.randn(rows, dk)
+    lin = lambda o, i: (torch.randn(o, i) / i ** 0.5, torch.randn(o) * 0.1)
+    fq, fk, fg = lin(dk, dk), lin(dk, dk), lin(2 * dk, dk)
+    G = (q.double() @ fq[0].double().t() + fq[1].double()) * (k.double() @ fk[0].double().t() + fk[1].double())
+    M = torch.sigmoid(G @ fg[0].double().t() + fg[1].double())
+    qo, ko = ops.agsa_gate(q.to(dev), k.to(dev), *[(w.to(dev), b.to(dev)) for w, b in (fq, fk, fg)])
+    assert float((qo.cpu().double() - q.double() * M[:, :dk]).abs().max()) <= 2e-6
+    assert float((ko.cpu().double() - k.double() * M[:, dk:]).abs().max()) <= 2e-6
+    with pytest.raises(NotImplementedError):
+        ops.agsa_gate(torch.zeros(4, 64, device=dev), torch.zeros(4, 64, device=dev), *[(torch.zeros(o, 64, device=dev), torch.zeros(o, device=dev)) for o in (64, 64, 128)])
 
 
 @pytest.mark.gpu
