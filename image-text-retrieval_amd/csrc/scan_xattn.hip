@@ -69,7 +69,10 @@ struct ScanSmem {
         float rsim2[SC_MT][SC_MAXCAP];        //  9,216 B   i2t: per (region row, caption) term
     };
     float colstat[SC_IMGS][SC_NT][2];         //  2,048 B   i2t: per (image, word) norm statistics
-    float rowsim[SC_IMGS][SC_NT];             //  1,024 B   t2i: per (image, word) similarity term
+    union {
+        float rowsim[SC_IMGS][SC_NT];         //  1,024 B   t2i: per (image, word) similarity term
+        float split9[3][16][16];              //  3,072 B   i2t: partial sums of the ninth row tile (with the 3 KB behind the caption Gram)
+    };
     ScanTileMeta meta;                        //    256 B
 };
 
@@ -142,8 +145,12 @@ using f16x8_t = __attribute__((ext_vector_type(8))) _Float16;
 
 // PREC 0: exact fp32 main loop (scan_mainloop.inc).  PREC 1: split-bf16 "bf16x3", PREC 3: split-fp16 "fp16x3" main loop
 // (scan_mainloop_bf16.inc; opt-in, reported separately -- DESIGN.md 9); bits 2 / 3: ablation builds.  The epilogue is shared.
-template <int PREC>
+// XA: the attention direction as a compile-time constant for the exact fp32 build (0 = t2i, 1 = i2t: two kernels, so the i2t epilogue's
+// registers and scalar spills do not weigh on the t2i kernel -- adding 60 lines to the i2t branch cost the t2i kernel 0.3 % while both
+// lived in one function); -1 = g.mode at run time (the study variants).
+template <int PREC, int XA>
 __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
+    const int mode = XA >= 0 ? XA : g.mode;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ScanSmem &sm = *reinterpret_cast<ScanSmem *>(smem_raw);
 
@@ -178,7 +185,7 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
     unsigned long long tick_ = g.dbg_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long real0_ = g.dbg_cycles ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz
     // t2i: ||E_w|| of this lane's word column is only needed at the very end -- fetch it now
-    const float wnorm_pre = (g.mode == 0) ? g.wnorm[ct * SC_NT + lane] : 0.f;
+    const float wnorm_pre = (mode == 0) ? g.wnorm[ct * SC_NT + lane] : 0.f;
     // ---- tile metadata: needed by the epilogue only, so its load overlaps the main loop
     if (tid < 64) reinterpret_cast<int32_t *>(&sm.meta)[tid] = reinterpret_cast<const int32_t *>(g.meta + ct)[tid];
 
@@ -198,7 +205,7 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
     }
 #define AT(row, col) sm.arawt[col][row]
 
-    if (g.mode == 0) {
+    if (mode == 0) {
         // ================= t2i: words attend over the 36 regions of every image ============
         // The Gram matrix of this wave's image is the A operand of the ||ctx||^2 product; fetch its fragments
         // now (27 floats per lane), the latency hides behind E1.
@@ -476,10 +483,22 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ind[4 * u + j] = (sm.meta.col_cap[16 * u + 4 * fg + j] == fi) ? 1.f : 0.f;
-            // P1: e = exp(ls b) in place; den[row][k] = sum_{w in k} e, num[row][k] = sum e a as indicator products
+            // P1: e = exp(ls b) in place; den[row][k] = sum_{w in k} e, num[row][k] = sum e a as indicator products.
+            // Nine row tiles over four waves (round 3): every wave takes two whole tiles and ONE 16-column block of the ninth (rows
+            // 128..143) -- before, wave 0 took three tiles and the others waited for it at every barrier of the epilogue (3 : 2 : 2 : 2).
+            // The ninth tile's sums over the columns arrive as four partial [caption slot][row] blocks: waves 1..3 park theirs in LDS
+            // (six 1 KB slots: 3 KB behind the caption Gram, 3 KB in `split9`), wave 0 adds them in a fixed order after the barrier.
+            float *part_a = hbuf + SC_NT * SC_NT;                       // [3][16][16] behind Hblk
+            float *part_b = &sm.split9[0][0][0];                        // [3][16][16]
+            auto pden = [&](int w_) -> float * { return w_ == 1 ? part_a : (w_ == 2 ? part_a + 512 : part_b + 256); };
+            auto pnum = [&](int w_) -> float * { return w_ == 1 ? part_a + 256 : (w_ == 2 ? part_b : part_b + 512); };
+            float ind9[4];   // the same indicator for the wave's column block of the ninth tile: word 16 wave + 4 fg + j
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ind9[j] = (sm.meta.col_cap[16 * wave + 4 * fg + j] == fi) ? 1.f : 0.f;
+            f32x4 den9 = f32x4{0.f, 0.f, 0.f, 0.f}, num9 = den9;      // wave 0: the ninth tile's den / num (kept in registers until P4)
             dispatch_norm(norm, [&](auto NC) {
                 constexpr int NORM = decltype(NC)::value;
-                for (int mt = wave; mt < SC_MTILES; mt += 4) {
+                for (int mt = wave; mt < SC_MTILES - 1; mt += 4) {
                     const int row = mt * 16 + fi;
                     const int ii = row / SC_R;
                     f32x4 sden = f32x4{0.f, 0.f, 0.f, 0.f}, snum = sden;
@@ -498,8 +517,38 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                     *reinterpret_cast<f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]) = sden;     // [caption slot fi][rows 4fg..]
                     *reinterpret_cast<f32x4 *>(&sm.stat[1][fi][mt * 16 + 4 * fg]) = snum;
                 }
+                {
+                    constexpr int row0 = (SC_MTILES - 1) * 16;
+                    const int row = row0 + fi;                 // rows 128..143: all of image 3
+                    constexpr int ii = row0 / SC_R;
+                    static_assert((row0 + 15) / SC_R == ii, "the ninth row tile lies in one image");
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int w = 16 * wave + 4 * fg + j;
+                        const float av = AT(row, w);
+                        const float bq = norm_apply_c<NORM>(av, sm.colstat[ii][w][0], sm.colstat[ii][w][1]);
+                        const float e = (NORM == 2) ? fast_exp(bq * ls) : __builtin_amdgcn_exp2f(bq);
+                        AT(row, w) = e;
+                        den9 = __builtin_amdgcn_mfma_f32_16x16x4f32(e, ind9[j], den9, 0, 0, 0);
+                        num9 = __builtin_amdgcn_mfma_f32_16x16x4f32(e * av, ind9[j], num9, 0, 0, 0);
+                    }
+                    if (wave > 0) {
+                        *reinterpret_cast<f32x4 *>(pden(wave) + fi * 16 + 4 * fg) = den9;
+                        *reinterpret_cast<f32x4 *>(pnum(wave) + fi * 16 + 4 * fg) = num9;
+                    }
+                }
             });
             __syncthreads();
+            if (wave == 0) {     // (read before the next barrier: waves 1..3 reuse their slots for the ninth tile's q partials after it)
+#pragma unroll
+                for (int w_ = 1; w_ < 4; ++w_) {
+                    const f32x4 d_ = *reinterpret_cast<const f32x4 *>(pden(w_) + fi * 16 + 4 * fg);
+                    const f32x4 n_ = *reinterpret_cast<const f32x4 *>(pnum(w_) + fi * 16 + 4 * fg);
+                    den9 = f32x4{den9[0] + d_[0], den9[1] + d_[1], den9[2] + d_[2], den9[3] + d_[3]};
+                    num9 = f32x4{num9[0] + n_[0], num9[1] + n_[1], num9[2] + n_[2], num9[3] + n_[3]};
+                }
+            }
+            f32x4 ninth_t;       // T tile (rows 128 + 4 fg + j, column 16 wave + fi) of the ninth row tile, applied after P3's barrier
             SC_TICK(5)   // P0 + P1: block-diagonal Gram into LDS, weights, den / num
             // P3: T = E Hblk (64 MFMAs per row tile), then E o T in place: arawt[w][row] <- e[row][w] * T[row][w]
             // (skipping the k-steps whose Hblk rows are all zero for a column tile -- about half of them -- was tried with
@@ -510,7 +559,7 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) hf[nt][q] = hbuf[(4 * q + fg) * SC_NT + nt * 16 + fi];
-                for (int mt = wave; mt < SC_MTILES; mt += 4) {
+                for (int mt = wave; mt < SC_MTILES - 1; mt += 4) {
                     float ea[16];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) ea[q] = AT(mt * 16 + fi, 4 * q + fg);
@@ -529,20 +578,29 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                         *ep = f32x4{ev[0] * tacc[nt][0], ev[1] * tacc[nt][1], ev[2] * tacc[nt][2], ev[3] * tacc[nt][3]};
                     }
                 }
+                {
+                    // the ninth row tile: column tile nt = wave of T (a quarter of its 64 MFMAs per wave).  Its A fragments are the
+                    // weights every wave wrote in P1 (the barrier above), its result goes to the wave's own 16 columns.
+                    constexpr int row0 = (SC_MTILES - 1) * 16;
+                    float ea[16], hf9[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) ea[q] = AT(row0 + fi, 4 * q + fg);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) hf9[q] = hbuf[(4 * q + fg) * SC_NT + wave * 16 + fi];
+                    f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = t0;       // two accumulators: a chain of dependent MFMAs runs at 40, not 32, cycles each
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[q], hf9[q], t0, 0, 0, 0);
+                        t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[q + 1], hf9[q + 1], t1, 0, 0, 0);
+                    }
+                    ninth_t = f32x4{t0[0] + t1[0], t0[1] + t1[1], t0[2] + t1[2], t0[3] + t1[3]};
+                }
             }
             __syncthreads();
             SC_TICK(6)   // P3: T = E Hblk, E o T
             // P4: q[row][k] = sum_{w in k} (E o T) (indicator product), then the cosine term of every (region row, caption)
             float *rs_out = hbuf;       // Hblk is dead: [144][16] similarity terms for the aggregation below
-            for (int mt = wave; mt < SC_MTILES; mt += 4) {
-                f32x4 sq = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        sq = __builtin_amdgcn_mfma_f32_16x16x4f32(AT(mt * 16 + fi, 16 * u + 4 * fg + j), ind[4 * u + j], sq, 0, 0, 0);
-                const f32x4 dn = *reinterpret_cast<const f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]);
-                const f32x4 nm = *reinterpret_cast<const f32x4 *>(&sm.stat[1][fi][mt * 16 + 4 * fg]);
+            auto cos_terms = [&](int mt, const f32x4 &sq, const f32x4 &dn, const f32x4 &nm) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int row = mt * 16 + 4 * fg + j;
@@ -552,6 +610,39 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                     const float w2 = fast_sqrt(fmaxf(sq[j], 0.f)) * rden;
                     rs_out[row * SC_MAXCAP + fi] = (nm[j] * rden) * fast_rcp(fmaxf(w1 * w2, 1e-8f));
                 }
+            };
+            f32x4 sq9 = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                // the ninth row tile, this wave's 16 columns: E o T in place (every wave has read the tile's weights: the barrier
+                // above), then the partial q over those columns
+                constexpr int row0 = (SC_MTILES - 1) * 16;
+                f32x4 *ep = reinterpret_cast<f32x4 *>(&sm.arawt[wave * 16 + fi][row0 + 4 * fg]);
+                const f32x4 ev = *ep;
+                *ep = f32x4{ev[0] * ninth_t[0], ev[1] * ninth_t[1], ev[2] * ninth_t[2], ev[3] * ninth_t[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    sq9 = __builtin_amdgcn_mfma_f32_16x16x4f32(AT(row0 + fi, 16 * wave + 4 * fg + j), ind9[j], sq9, 0, 0, 0);
+                if (wave > 0) *reinterpret_cast<f32x4 *>(pden(wave) + fi * 16 + 4 * fg) = sq9;
+            }
+            for (int mt = wave; mt < SC_MTILES - 1; mt += 4) {
+                f32x4 sq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        sq = __builtin_amdgcn_mfma_f32_16x16x4f32(AT(mt * 16 + fi, 16 * u + 4 * fg + j), ind[4 * u + j], sq, 0, 0, 0);
+                const f32x4 dn = *reinterpret_cast<const f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]);
+                const f32x4 nm = *reinterpret_cast<const f32x4 *>(&sm.stat[1][fi][mt * 16 + 4 * fg]);
+                cos_terms(mt, sq, dn, nm);
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int w_ = 1; w_ < 4; ++w_) {
+                    const f32x4 q_ = *reinterpret_cast<const f32x4 *>(pden(w_) + fi * 16 + 4 * fg);
+                    sq9 = f32x4{sq9[0] + q_[0], sq9[1] + q_[1], sq9[2] + q_[2], sq9[3] + q_[3]};
+                }
+                cos_terms(SC_MTILES - 1, sq9, den9, num9);
             }
             rsim = rs_out;
             __syncthreads();
@@ -635,9 +726,9 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
   }   // tile loop
 }
 
-template <int PREC>
+template <int PREC, int XA = -1>
 __global__ __launch_bounds__(SC_THREADS, 2) void scan_xattn_kernel(ScanArgs g) {
-    scan_xattn_body<PREC>(g);
+    scan_xattn_body<PREC, XA>(g);
 }
 
 // ---- precompute kernels -------------------------------------------------------------------
@@ -1021,7 +1112,9 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
     ITR_UNSUPPORTED(nblk > 0x7fffffffLL, "itr_scan_xattn_scores: grid too large; shard the call");
     static bool attr_set = false;
     if (!attr_set) {
-        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<0>),
+        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<0, 0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<0, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1067,8 +1160,10 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
             hipLaunchKernelGGL(scan_xattn_kernel<3>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
         } else
             hipLaunchKernelGGL(scan_xattn_kernel<1>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
+    } else if (a.mode == 0) {
+        hipLaunchKernelGGL((scan_xattn_kernel<0, 0>), dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
     } else {
-        hipLaunchKernelGGL(scan_xattn_kernel<0>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
+        hipLaunchKernelGGL((scan_xattn_kernel<0, 1>), dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
     }
     ITR_CHECK_LAUNCH("scan_xattn");
     return ITR_OK;
@@ -1102,9 +1197,9 @@ extern "C" int itr_scan_xattn_scores_bf16x3(const float *img, int64_t n_tiles, i
 extern "C" int itr_debug_scan_occupancy(int *blocks_per_cu, int *lds_bytes) {
     using namespace itr;
     ITR_REQUIRE(blocks_per_cu && lds_bytes, "itr_debug_scan_occupancy: null pointer");
-    ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<0>),
+    ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<0, 0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScanSmem)));
-    ITR_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(scan_xattn_kernel<0>),
+    ITR_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(scan_xattn_kernel<0, 0>),
                                                                SC_THREADS, sizeof(ScanSmem)));
     *lds_bytes = (int)sizeof(ScanSmem);
     return ITR_OK;

@@ -33,7 +33,7 @@ def counter(kernel, cname):
     return None
 
 
-kern = "itr::scan_xattn_kernel<0>"
+kern = "itr::scan_xattn_kernel<0"          # <0, 0>: exact fp32, t2i (before round 3: <0>)
 f, w = counter(kern, "FETCH_SIZE"), counter(kern, "WRITE_SIZE")
 out = {"kernel": kern, "workload": workload, "n_gpus": 1,
        "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
