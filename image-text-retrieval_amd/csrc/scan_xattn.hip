@@ -46,6 +46,7 @@ struct ScanArgs {
     const float *vnorm;      // [Ni * 36]           (i2t)   ||V_r||
     const float *cgram;      // [sum W_c^2]         (i2t)   E_c E_c^T, caption c at cgram_off[c]
     const int64_t *cgram_off;  // [Nc]
+    const float *hblk;       // [n_tiles, 64, 64]   (i2t)   per column tile: the block-diagonal Gram of its captions, zero elsewhere
     float *S;
     int64_t ldS;
     int64_t Ni, Nc, n_tiles;
@@ -69,10 +70,7 @@ struct ScanSmem {
         float rsim2[SC_MT][SC_MAXCAP];        //  9,216 B   i2t: per (region row, caption) term
     };
     float colstat[SC_IMGS][SC_NT][2];         //  2,048 B   i2t: per (image, word) norm statistics
-    union {
-        float rowsim[SC_IMGS][SC_NT];         //  1,024 B   t2i: per (image, word) similarity term
-        float split9[3][16][16];              //  3,072 B   i2t: partial sums of the ninth row tile (with the 3 KB behind the caption Gram)
-    };
+    float rowsim[SC_IMGS][SC_NT];             //  1,024 B   t2i: per (image, word) similarity term
     ScanTileMeta meta;                        //    256 B
 };
 
@@ -467,40 +465,37 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
         __syncthreads();
         SC_TICK(2)   // E1 (i2t): per (image, word) statistics over the regions
         if (mfma_path) {
-            // P0: block-diagonal Gram of the tile's captions, Hblk[v][w] = e_v . e_w for v, w in the same caption
-            for (int idx = tid; idx < SC_NT * SC_NT; idx += SC_THREADS) hbuf[idx] = 0.f;
-            __syncthreads();
-            for (int k = 0; k < ncap; ++k) {
-                const int c0 = sm.meta.cap_start[k], W = sm.meta.cap_start[k + 1] - c0;
-                const float *H = g.cgram + g.cgram_off[sm.meta.cap_id[k]];
-                for (int idx = tid; idx < W * W; idx += SC_THREADS) {
-                    const int u = idx / W, v = idx - u * W;
-                    hbuf[(c0 + u) * SC_NT + c0 + v] = H[idx];
-                }
+            // One pass per 16-row tile, entirely in the wave's registers (round 3; before: weights written back to the parked block,
+            // T = E Hblk read them again as A fragments, E o T written back and read a third time for the sums, a zero-filled and
+            // gathered Hblk in LDS, four barriers -- the epilogue shares the CU's issue slots with the co-resident workgroup's main
+            // loop, so every instruction removed is time):
+            //   P1  e = exp(ls b) for (row fi, word 16 u + 4 fg + j), u, j = 0..3: sixteen registers that are at once the A fragments of
+            //       den / num = E * indicator, the B fragments of the next product and the factors of the last one
+            //   P3  T^T = Hblk E^T: A = Hblk rows as they lie in memory (lane (fi, fg): 16 bytes at column 16 u + 4 fg of row 16 nt +
+            //       fi; Hblk is symmetric), k slot fg of step 4 u + j <-> word 16 u + 4 fg + j, i.e. B = e[4 u + j].  Accumulator j' of
+            //       tile nt = T[row fi][word 16 nt + 4 fg + j']: the element that multiplies e[4 nt + j'] --
+            //   P4  q = (E o T) * indicator with A = e[4 nt + j'] * acc[nt][j'], then the cosine terms.
+            // the tile's block-diagonal caption Gram as A fragments of P3: row 16 nt + fi, 16 bytes at column 16 u + 4 fg
+            float4 hfrag[4][4];
+            {
+                const float *hb = g.hblk + ct * (int64_t)(SC_NT * SC_NT) + fi * SC_NT + 4 * fg;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) hfrag[nt][u] = *reinterpret_cast<const float4 *>(hb + nt * 16 * SC_NT + 16 * u);
             }
             float ind[16];   // indicator fragment: [word 16u + 4fg + j belongs to caption slot fi]
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ind[4 * u + j] = (sm.meta.col_cap[16 * u + 4 * fg + j] == fi) ? 1.f : 0.f;
-            // P1: e = exp(ls b) in place; den[row][k] = sum_{w in k} e, num[row][k] = sum e a as indicator products.
-            // Nine row tiles over four waves (round 3): every wave takes two whole tiles and ONE 16-column block of the ninth (rows
-            // 128..143) -- before, wave 0 took three tiles and the others waited for it at every barrier of the epilogue (3 : 2 : 2 : 2).
-            // The ninth tile's sums over the columns arrive as four partial [caption slot][row] blocks: waves 1..3 park theirs in LDS
-            // (six 1 KB slots: 3 KB behind the caption Gram, 3 KB in `split9`), wave 0 adds them in a fixed order after the barrier.
-            float *part_a = hbuf + SC_NT * SC_NT;                       // [3][16][16] behind Hblk
-            float *part_b = &sm.split9[0][0][0];                        // [3][16][16]
-            auto pden = [&](int w_) -> float * { return w_ == 1 ? part_a : (w_ == 2 ? part_a + 512 : part_b + 256); };
-            auto pnum = [&](int w_) -> float * { return w_ == 1 ? part_a + 256 : (w_ == 2 ? part_b : part_b + 512); };
-            float ind9[4];   // the same indicator for the wave's column block of the ninth tile: word 16 wave + 4 fg + j
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ind9[j] = (sm.meta.col_cap[16 * wave + 4 * fg + j] == fi) ? 1.f : 0.f;
-            f32x4 den9 = f32x4{0.f, 0.f, 0.f, 0.f}, num9 = den9;      // wave 0: the ninth tile's den / num (kept in registers until P4)
+            float *rs_out = hbuf;       // [144][16] similarity terms for the aggregation below (LDS behind the parked block)
             dispatch_norm(norm, [&](auto NC) {
                 constexpr int NORM = decltype(NC)::value;
-                for (int mt = wave; mt < SC_MTILES - 1; mt += 4) {
+                for (int mt = wave; mt < SC_MTILES; mt += 4) {
                     const int row = mt * 16 + fi;
                     const int ii = row / SC_R;
+                    float e[16];
                     f32x4 sden = f32x4{0.f, 0.f, 0.f, 0.f}, snum = sden;
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
@@ -509,143 +504,43 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                             const int w = 16 * u + 4 * fg + j;
                             const float av = AT(row, w);
                             const float bq = norm_apply_c<NORM>(av, sm.colstat[ii][w][0], sm.colstat[ii][w][1]);
-                            const float e = (NORM == 2) ? fast_exp(bq * ls) : __builtin_amdgcn_exp2f(bq);
-                            AT(row, w) = e;
-                            sden = __builtin_amdgcn_mfma_f32_16x16x4f32(e, ind[4 * u + j], sden, 0, 0, 0);
-                            snum = __builtin_amdgcn_mfma_f32_16x16x4f32(e * av, ind[4 * u + j], snum, 0, 0, 0);
+                            e[4 * u + j] = (NORM == 2) ? fast_exp(bq * ls) : __builtin_amdgcn_exp2f(bq);
+                            sden = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * u + j], ind[4 * u + j], sden, 0, 0, 0);
+                            snum = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * u + j] * av, ind[4 * u + j], snum, 0, 0, 0);
                         }
-                    *reinterpret_cast<f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]) = sden;     // [caption slot fi][rows 4fg..]
-                    *reinterpret_cast<f32x4 *>(&sm.stat[1][fi][mt * 16 + 4 * fg]) = snum;
-                }
-                {
-                    constexpr int row0 = (SC_MTILES - 1) * 16;
-                    const int row = row0 + fi;                 // rows 128..143: all of image 3
-                    constexpr int ii = row0 / SC_R;
-                    static_assert((row0 + 15) / SC_R == ii, "the ninth row tile lies in one image");
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int w = 16 * wave + 4 * fg + j;
-                        const float av = AT(row, w);
-                        const float bq = norm_apply_c<NORM>(av, sm.colstat[ii][w][0], sm.colstat[ii][w][1]);
-                        const float e = (NORM == 2) ? fast_exp(bq * ls) : __builtin_amdgcn_exp2f(bq);
-                        AT(row, w) = e;
-                        den9 = __builtin_amdgcn_mfma_f32_16x16x4f32(e, ind9[j], den9, 0, 0, 0);
-                        num9 = __builtin_amdgcn_mfma_f32_16x16x4f32(e * av, ind9[j], num9, 0, 0, 0);
-                    }
-                    if (wave > 0) {
-                        *reinterpret_cast<f32x4 *>(pden(wave) + fi * 16 + 4 * fg) = den9;
-                        *reinterpret_cast<f32x4 *>(pnum(wave) + fi * 16 + 4 * fg) = num9;
-                    }
-                }
-            });
-            __syncthreads();
-            if (wave == 0) {     // (read before the next barrier: waves 1..3 reuse their slots for the ninth tile's q partials after it)
-#pragma unroll
-                for (int w_ = 1; w_ < 4; ++w_) {
-                    const f32x4 d_ = *reinterpret_cast<const f32x4 *>(pden(w_) + fi * 16 + 4 * fg);
-                    const f32x4 n_ = *reinterpret_cast<const f32x4 *>(pnum(w_) + fi * 16 + 4 * fg);
-                    den9 = f32x4{den9[0] + d_[0], den9[1] + d_[1], den9[2] + d_[2], den9[3] + d_[3]};
-                    num9 = f32x4{num9[0] + n_[0], num9[1] + n_[1], num9[2] + n_[2], num9[3] + n_[3]};
-                }
-            }
-            f32x4 ninth_t;       // T tile (rows 128 + 4 fg + j, column 16 wave + fi) of the ninth row tile, applied after P3's barrier
-            SC_TICK(5)   // P0 + P1: block-diagonal Gram into LDS, weights, den / num
-            // P3: T = E Hblk (64 MFMAs per row tile), then E o T in place: arawt[w][row] <- e[row][w] * T[row][w]
-            // (skipping the k-steps whose Hblk rows are all zero for a column tile -- about half of them -- was tried with
-            // wave-uniform branches around the MFMAs: 42.4 -> 44.1 ms, the branches cost more than the MFMAs they skip)
-            {
-                float hf[4][16];     // B fragments of Hblk, shared by every row tile of this wave
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) hf[nt][q] = hbuf[(4 * q + fg) * SC_NT + nt * 16 + fi];
-                for (int mt = wave; mt < SC_MTILES - 1; mt += 4) {
-                    float ea[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) ea[q] = AT(mt * 16 + fi, 4 * q + fg);
                     f32x4 tacc[4];
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) tacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
+                    for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) tacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[q], hf[nt][q], tacc[nt], 0, 0, 0);
-                    // tacc[nt][j] = T[mt*16 + 4fg + j][nt*16 + fi]; the A fragments above were this wave's own rows only
+                        for (int nt = 0; nt < 4; ++nt) tacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hfrag[nt][u].x, e[4 * u + 0], tacc[nt], 0, 0, 0);
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        f32x4 *ep = reinterpret_cast<f32x4 *>(&sm.arawt[nt * 16 + fi][mt * 16 + 4 * fg]);
-                        const f32x4 ev = *ep;
-                        *ep = f32x4{ev[0] * tacc[nt][0], ev[1] * tacc[nt][1], ev[2] * tacc[nt][2], ev[3] * tacc[nt][3]};
+                        for (int nt = 0; nt < 4; ++nt) tacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hfrag[nt][u].y, e[4 * u + 1], tacc[nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) tacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hfrag[nt][u].z, e[4 * u + 2], tacc[nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) tacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hfrag[nt][u].w, e[4 * u + 3], tacc[nt], 0, 0, 0);
+                    }
+                    f32x4 sq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sq = __builtin_amdgcn_mfma_f32_16x16x4f32(e[4 * nt + j] * tacc[nt][j], ind[4 * nt + j], sq, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r2 = mt * 16 + 4 * fg + j;
+                        const int64_t img = img0 + r2 / SC_R;
+                        const float w1 = img < g.Ni ? g.vnorm[img * SC_R + r2 % SC_R] : 0.f;
+                        const float rden = sden[j] > 0.f ? fast_rcp(sden[j]) : 0.f;     // caption slots >= ncap: never read
+                        const float w2 = fast_sqrt(fmaxf(sq[j], 0.f)) * rden;
+                        rs_out[r2 * SC_MAXCAP + fi] = (snum[j] * rden) * fast_rcp(fmaxf(w1 * w2, 1e-8f));
                     }
                 }
-                {
-                    // the ninth row tile: column tile nt = wave of T (a quarter of its 64 MFMAs per wave).  Its A fragments are the
-                    // weights every wave wrote in P1 (the barrier above), its result goes to the wave's own 16 columns.
-                    constexpr int row0 = (SC_MTILES - 1) * 16;
-                    float ea[16], hf9[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) ea[q] = AT(row0 + fi, 4 * q + fg);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) hf9[q] = hbuf[(4 * q + fg) * SC_NT + wave * 16 + fi];
-                    f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = t0;       // two accumulators: a chain of dependent MFMAs runs at 40, not 32, cycles each
-#pragma unroll
-                    for (int q = 0; q < 16; q += 2) {
-                        t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[q], hf9[q], t0, 0, 0, 0);
-                        t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[q + 1], hf9[q + 1], t1, 0, 0, 0);
-                    }
-                    ninth_t = f32x4{t0[0] + t1[0], t0[1] + t1[1], t0[2] + t1[2], t0[3] + t1[3]};
-                }
-            }
-            __syncthreads();
-            SC_TICK(6)   // P3: T = E Hblk, E o T
-            // P4: q[row][k] = sum_{w in k} (E o T) (indicator product), then the cosine term of every (region row, caption)
-            float *rs_out = hbuf;       // Hblk is dead: [144][16] similarity terms for the aggregation below
-            auto cos_terms = [&](int mt, const f32x4 &sq, const f32x4 &dn, const f32x4 &nm) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = mt * 16 + 4 * fg + j;
-                    const int64_t img = img0 + row / SC_R;
-                    const float w1 = img < g.Ni ? g.vnorm[img * SC_R + row % SC_R] : 0.f;
-                    const float rden = dn[j] > 0.f ? fast_rcp(dn[j]) : 0.f;     // caption slots >= ncap: never read
-                    const float w2 = fast_sqrt(fmaxf(sq[j], 0.f)) * rden;
-                    rs_out[row * SC_MAXCAP + fi] = (nm[j] * rden) * fast_rcp(fmaxf(w1 * w2, 1e-8f));
-                }
-            };
-            f32x4 sq9 = f32x4{0.f, 0.f, 0.f, 0.f};
-            {
-                // the ninth row tile, this wave's 16 columns: E o T in place (every wave has read the tile's weights: the barrier
-                // above), then the partial q over those columns
-                constexpr int row0 = (SC_MTILES - 1) * 16;
-                f32x4 *ep = reinterpret_cast<f32x4 *>(&sm.arawt[wave * 16 + fi][row0 + 4 * fg]);
-                const f32x4 ev = *ep;
-                *ep = f32x4{ev[0] * ninth_t[0], ev[1] * ninth_t[1], ev[2] * ninth_t[2], ev[3] * ninth_t[3]};
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    sq9 = __builtin_amdgcn_mfma_f32_16x16x4f32(AT(row0 + fi, 16 * wave + 4 * fg + j), ind9[j], sq9, 0, 0, 0);
-                if (wave > 0) *reinterpret_cast<f32x4 *>(pden(wave) + fi * 16 + 4 * fg) = sq9;
-            }
-            for (int mt = wave; mt < SC_MTILES - 1; mt += 4) {
-                f32x4 sq = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        sq = __builtin_amdgcn_mfma_f32_16x16x4f32(AT(mt * 16 + fi, 16 * u + 4 * fg + j), ind[4 * u + j], sq, 0, 0, 0);
-                const f32x4 dn = *reinterpret_cast<const f32x4 *>(&sm.stat[0][fi][mt * 16 + 4 * fg]);
-                const f32x4 nm = *reinterpret_cast<const f32x4 *>(&sm.stat[1][fi][mt * 16 + 4 * fg]);
-                cos_terms(mt, sq, dn, nm);
-            }
-            __syncthreads();
-            if (wave == 0) {
-#pragma unroll
-                for (int w_ = 1; w_ < 4; ++w_) {
-                    const f32x4 q_ = *reinterpret_cast<const f32x4 *>(pden(w_) + fi * 16 + 4 * fg);
-                    sq9 = f32x4{sq9[0] + q_[0], sq9[1] + q_[1], sq9[2] + q_[2], sq9[3] + q_[3]};
-                }
-                cos_terms(SC_MTILES - 1, sq9, den9, num9);
-            }
+            });
             rsim = rs_out;
             __syncthreads();
+            SC_TICK(5)   // P1 + P3 + P4 per row tile
         } else {
             // E2: one lane per region row, loop over the captions of the tile.  Per caption: the caption Gram H_c (W x W)
             // is pulled into the part of the staging area that the parked block does not cover (19 KB free behind arawt),
@@ -792,6 +687,25 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ 
     if (lane == 0) out[row] = sqrtf(s);
 }
 
+// Hblk[t][v][w] = e_v . e_w for words v, w of the same caption of column tile t, 0 elsewhere (padding columns, different captions):
+// the dense 64 x 64 form the i2t epilogue multiplies with (round 3: built once per caption set instead of zero-filled and gathered
+// into LDS by every workgroup of the tile's 1 250 image blocks).
+__global__ __launch_bounds__(256) void scan_hblk_kernel(const ScanTileMeta *__restrict__ meta, const float *__restrict__ cgram,
+                                                        const int64_t *__restrict__ coff, float *__restrict__ hblk) {
+    const int64_t t = blockIdx.x;
+    const ScanTileMeta &m = meta[t];
+    for (int idx = threadIdx.x; idx < SC_NT * SC_NT; idx += 256) {
+        const int v = idx / SC_NT, w = idx % SC_NT;
+        const int k = m.col_cap[w];
+        float val = 0.f;
+        if (k >= 0 && m.col_cap[v] == k) {
+            const int c0 = m.cap_start[k], W = m.cap_start[k + 1] - c0;
+            val = cgram[coff[m.cap_id[k]] + (int64_t)(v - c0) * W + (w - c0)];
+        }
+        hblk[t * (SC_NT * SC_NT) + idx] = val;
+    }
+}
+
 // exclusive prefix sum of len^2 (caption Gram offsets); single workgroup, Nc is small (<= ~1e5)
 __global__ __launch_bounds__(1024) void sq_prefix_kernel(const int32_t *__restrict__ len, int64_t n,
                                                          int64_t *__restrict__ off) {
@@ -920,14 +834,15 @@ static_assert(sizeof(ScanSmem) <= 80 * 1024, "two workgroups per CU need <= 80 K
 
 // Workspace layout (prepare and scores agree on it)
 struct ScanWs {
-    float *gram, *wnorm, *vnorm, *cgram, *wtiled;
+    float *gram, *wnorm, *vnorm, *cgram, *hblk, *wtiled;
     int64_t *coff;
     ScanTileMeta *meta;
 };
 static size_t scan_ws_bytes(int64_t Ni, int R, int64_t n_rows, int64_t Nc, int64_t n_tiles, int D) {
     const size_t common = align256((size_t)n_tiles * sizeof(ScanTileMeta)) + align256((size_t)n_tiles * SC_NT * D * 4);
     const size_t t2i = align256((size_t)Ni * R * R * 4) + align256((size_t)n_tiles * SC_NT * 4);
-    const size_t i2t = align256((size_t)Ni * R * 4) + align256((size_t)Nc * 8) + align256((size_t)n_rows * SC_NT * 4);
+    const size_t i2t = align256((size_t)Ni * R * 4) + align256((size_t)Nc * 8) + align256((size_t)n_rows * SC_NT * 4) +
+                       align256((size_t)n_tiles * SC_NT * SC_NT * 4);
     return common + (t2i > i2t ? t2i : i2t);
 }
 static ScanWs scan_carve(void *workspace, int64_t Ni, int R, int64_t n_rows, int64_t Nc, int64_t n_tiles, int D, int mode) {
@@ -941,7 +856,8 @@ static ScanWs scan_carve(void *workspace, int64_t Ni, int R, int64_t n_rows, int
     } else {
         w.vnorm = reinterpret_cast<float *>(ws); ws += align256((size_t)Ni * R * 4);
         w.coff = reinterpret_cast<int64_t *>(ws); ws += align256((size_t)Nc * 8);
-        w.cgram = reinterpret_cast<float *>(ws);
+        w.cgram = reinterpret_cast<float *>(ws); ws += align256((size_t)n_rows * SC_NT * 4);
+        w.hblk = reinterpret_cast<float *>(ws);
     }
     return w;
 }
@@ -1030,6 +946,8 @@ int scan_prepare_impl(const float *img, const float *words, const int64_t *cap_o
         hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Nc), dim3(256), 0, st, words, cap_off, cap_len, 0, D, w.cgram,
                            (const int64_t *)w.coff, 0);
         ITR_CHECK_LAUNCH("scan caption gram");
+        hipLaunchKernelGGL(scan_hblk_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, w.meta, w.cgram, w.coff, w.hblk);
+        ITR_CHECK_LAUNCH("scan tile gram");
     }
     return ITR_OK;
 }
@@ -1088,7 +1006,7 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
     a.img = img; a.wtiled = w.wtiled; a.meta = w.meta;
     a.S = S; a.ldS = ldS; a.Ni = Ni; a.Nc = Nc; a.n_tiles = n_tiles; a.D = D;
     a.mode = mode; a.norm = norm; a.agg = agg; a.lambda_softmax = lambda_softmax; a.lambda_lse = lambda_lse;
-    a.gram = w.gram; a.wnorm = w.wnorm; a.vnorm = w.vnorm; a.cgram = w.cgram; a.cgram_off = w.coff;
+    a.gram = w.gram; a.wnorm = w.wnorm; a.vnorm = w.vnorm; a.cgram = w.cgram; a.cgram_off = w.coff; a.hblk = w.hblk;
     a.emit_p = emit_p; a.emit_cn = emit_cn;
     if (img_count >= 0) {   // score only images [img_index0, img_index0 + img_count) of the prepared set (S, emit_*: local rows)
         ITR_REQUIRE(img_index0 >= 0 && img_index0 + img_count <= Ni, "scan: image sub-range out of bounds");
