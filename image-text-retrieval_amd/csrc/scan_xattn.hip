@@ -371,11 +371,15 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                     const f32x4 e0 = *reinterpret_cast<const f32x4 *>(ec + 4 * fg);
                     const f32x4 e1 = *reinterpret_cast<const f32x4 *>(ec + 16 + 4 * fg);
                     const f32x4 e2 = *reinterpret_cast<const f32x4 *>(ec + 32);          // rows 32..35, used by fg == 0
+                    // (explicit fmaf chains: with "a * b + c * d" hipcc is free to contract either product, and it chose differently
+                    // for different column tiles nt in one build of round 3 -- a word's term then depended on the tile column its
+                    // caption was packed into, 1 ulp, and the sharded evaluation's partitions were no longer bit-identical)
                     float part = 0.f, tail = 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        part += e0[j] * tacc[0][nt][j] + e1[j] * tacc[1][nt][j];
-                        tail += e2[j] * tacc[2][nt][j];
+                        part = fmaf(e0[j], tacc[0][nt][j], part);
+                        part = fmaf(e1[j], tacc[1][nt][j], part);
+                        tail = fmaf(e2[j], tacc[2][nt][j], tail);
                     }
                     part += (fg == 0) ? tail : 0.f;
                     part += __shfl_xor(part, 16, 64);

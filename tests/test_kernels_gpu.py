@@ -283,6 +283,56 @@ def test_scan_random_vs_oracle(dev, xa, Ni, Nc, D):
     assert maxdiff(got, want) <= 2e-5
 
 
+@pytest.mark.parametrize("norm", NORMS)
+def test_scan_t2i_scores_do_not_depend_on_the_tile_packing(dev, norm):
+    """The sharded evaluation scores own / left / right caption ranges in separate launches and promises rank vectors that are
+    bit-identical to the single launch: a (image, caption) score of the t2i kernel may therefore not depend on WHICH
+    tile column the planner packs the caption into.  A caption subset scored alone (other tiles, other columns) must reproduce
+    the same columns of the full call exactly, for every first norm and aggregation.  (Round 3 found a build where it did not:
+    hipcc contracted `e0 * t0 + e1 * t1` differently for different 16-column tiles, 1 ulp on 0.5 % of the scores -- the q dot
+    product is now an explicit fmaf chain.  i2t sums over a caption's words in tile order and is exempt: evalpipe scores it in one
+    launch.)"""
+    rng = np.random.RandomState(3)
+    torch.manual_seed(3)
+    Ni, Nc, D = 9, 700, 256
+    lens = rng.randint(1, 30, size=Nc).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    n_rows = int(lens.sum())
+    img = ops.l2norm(torch.randn(Ni, 36, D, device=dev))
+    words = torch.randn(n_rows, D, device=dev) * 0.3
+    for agg in AGGS:
+        full = ops.scan_xattn_scores(img, words, ops.ScanPlan(off, lens, n_rows, dev), raw_feature_norm=norm, agg_func=agg)
+        for c0, c1 in ((0, 233), (233, 466), (466, 700), (101, 118)):
+            r0, r1 = int(off[c0]), int(off[c1 - 1] + lens[c1 - 1])
+            sub = ops.scan_xattn_scores(img, words[r0:r1].contiguous(), ops.ScanPlan(off[c0:c1] - r0, lens[c0:c1], r1 - r0, dev),
+                                        raw_feature_norm=norm, agg_func=agg)
+            assert torch.equal(sub, full[:, c0:c1]), (norm, agg, c0, c1, float((sub - full[:, c0:c1]).abs().max()))
+
+
+@pytest.mark.parametrize("mod", ['SAF', 'SGR'])
+def test_sgraf_scores_do_not_depend_on_the_tile_packing(dev, mod):
+    """The same for SGRAF (its attention weights come from the t2i kernel in emit mode; tools/sgraf_partition_check.py is the
+    5k-caption version of this test)."""
+    rng = np.random.RandomState(4)
+    torch.manual_seed(4)
+    Ni, Nc, D, S = 20, 500, 128, 256
+    lens = rng.randint(1, 30, size=Nc).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    n_rows = int(lens.sum())
+    img = ops.l2norm(torch.randn(Ni, 36, D, device=dev))
+    words = ops.l2norm(torch.randn(n_rows, D, device=dev))
+    w = {k: v.to(dev) for k, v in _sgraf_weights(D, S, 3).items()}
+    if mod == 'SAF':
+        w.update({"SAF_module.attn_sim_w.weight": torch.randn(1, S, device=dev) * 0.1, "SAF_module.attn_sim_w.bias": torch.zeros(1, device=dev),
+                  "SAF_module.bn.weight": torch.ones(1, device=dev), "SAF_module.bn.bias": torch.zeros(1, device=dev),
+                  "SAF_module.bn.running_mean": torch.zeros(1, device=dev), "SAF_module.bn.running_var": torch.ones(1, device=dev)})
+    full = ops.sgraf_scores(img, words, ops.ScanPlan(off, lens, n_rows, dev), w, mod, 3)
+    for c0, c1 in ((0, 170), (170, 340), (340, 500), (77, 99)):
+        r0, r1 = int(off[c0]), int(off[c1 - 1] + lens[c1 - 1])
+        sub = ops.sgraf_scores(img, words[r0:r1].contiguous(), ops.ScanPlan(off[c0:c1] - r0, lens[c0:c1], r1 - r0, dev), w, mod, 3)
+        assert torch.equal(sub, full[:, c0:c1]), (mod, c0, c1, float((sub - full[:, c0:c1]).abs().max()))
+
+
 def test_scan_l1_norms_run(dev):
     """l1norm / clipped_l1norm raise NameError in the reference; the evident intent is
     implemented and pinned against the oracle."""
