@@ -37,7 +37,8 @@ struct GemmArgs {
     const float *rowscale;
     const float *Z;
     int64_t ldz;
-    int accumulate;   // C = act(C + A*B^T + bias): sums the taps of a dilated Conv1d (camera_.py:100-103)
+    int accumulate;   // 1: C = act(C + A*B^T + bias): sums the taps of a dilated Conv1d (camera_.py:100-103); 2: C = act(Z + A*B^T + bias):
+                      //    a residual connection without first copying the residual into C (Rs_GCN, vsrn_.py:64-67)
     int64_t ksplit;   // > 0: blockIdx.y owns K range [y * ksplit, (y + 1) * ksplit) and writes the raw partial product to
     float *part;      //      part + y * M * N  (row-major [M, N]); bias / activation are applied by the reduction kernel
     // optional SECOND problem of the same shape in the same launch (fast kernel only: the two directions of a bi-GRU time step,
@@ -82,11 +83,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2
                     const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row < m_end) {
                         float v = acc[i][j][r];
-                        if (g.Z) {
+                        if (g.Z && g.accumulate != 2) {
                             v = v * g.rowscale[row] - g.Z[row * g.ldz + col];
                             v = v * v;
                         } else {
-                            if (g.accumulate) v += g.C[row * g.ldc + col];
+                            if (g.accumulate == 1) v += g.C[row * g.ldc + col];
+                            else if (g.accumulate == 2) v += g.Z[row * g.ldz + col];        // residual read from its own matrix
                             v = apply_act(v + bv, g.act);
                         }
                         g.C[row * g.ldc + col] = v;
@@ -479,6 +481,15 @@ extern "C" int itr_gemm_nt_acc(const float *A, int64_t lda, const float *B, int6
     ITR_REQUIRE(M >= 0 && N >= 0 && K >= 0 && lda >= 1 && ldb >= K && ldc >= N, "itr_gemm_nt_acc: bad shape");
     ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt_acc: unknown activation %d", act);
     return itr::gemm_nt_acc(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream));
+}
+
+extern "C" int itr_gemm_nt_residual(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, const float *R, int64_t ldr,
+                                    float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, itr_stream_t stream) {
+    ITR_REQUIRE(A && B && R && C, "itr_gemm_nt_residual: null pointer");
+    ITR_REQUIRE(M >= 0 && N >= 0 && K >= 0 && lda >= 1 && ldb >= K && ldc >= N && ldr >= N, "itr_gemm_nt_residual: bad shape");
+    ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt_residual: unknown activation %d", act);
+    itr::GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, itr::BM, nullptr, R, ldr, 2, 0, nullptr};
+    return itr::launch_gemm(g, itr::as_stream(stream));
 }
 
 extern "C" int itr_cosine_scores(const float *im, const float *s, float *S, int64_t Ni, int64_t Nc, int D,

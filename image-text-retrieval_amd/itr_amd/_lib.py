@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -83,6 +83,7 @@ SIGNATURES = {
     "itr_relu_maxpool": (i32, [vp, vp, i64, i64, i32, i32, i32, vp]),
     "itr_gemm_nt_acc": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "itr_mul_rows": (i32, [vp, vp, i64, vp, i64, i32, vp]),
+    "itr_gemm_nt_residual": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
     "itr_agsa_gate": (i32, [vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "itr_affine_cols": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "itr_camera_posenc": (i32, [vp, vp, vp, i64, i32, vp]),

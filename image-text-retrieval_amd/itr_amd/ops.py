@@ -646,6 +646,21 @@ def gemm_acc(x2d, lda, M, K, weight, bias, out, act=None):
     return out
 
 
+def gemm_residual(x2d, weight, bias, residual, act=None):
+    """act(residual + x2d @ weight^T + bias) -> new tensor (a residual connection without copying the residual into the output
+    first; same arithmetic as gemm_acc on a clone)."""
+    lib = _lib.load()
+    x2d, weight, residual = _dev(x2d, name="x"), _dev(weight, name="weight"), _dev(residual, name="residual")
+    M, K = x2d.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or tuple(residual.shape) != (M, N):
+        raise ValueError("gemm_residual: x (%d, %d), weight %s, residual %s" % (M, K, tuple(weight.shape), tuple(residual.shape)))
+    b = _dev(bias) if bias is not None else None
+    out = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    _lib.check(lib.itr_gemm_nt_residual(_p(x2d), K, _p(weight), K, _p(b), _p(residual), N, _p(out), N, M, N, K, _ACTS[act], _stream()))
+    return out
+
+
 def gcn_relation(tpg, n_img, n_regions, channels):
     """Rs_GCN between its convolutions (vsrn_.py:50-67): tpg [n_img*N, 3C] rows = theta | phi | g ->
     y [n_img*N, C] = (theta phi^T / N) g per image."""

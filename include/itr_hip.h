@@ -223,6 +223,10 @@ int itr_relu_maxpool(const float *x, float *out, int64_t ldo, int64_t B, int L, 
  * itr_camera_summarize: softmax over regions of smry[B,R,k], L^T X, F.normalize -> [B,k,D]  (ImgEncoder.py:385-389) */
 int itr_gemm_nt_acc(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                     int64_t ldc, int64_t M, int64_t N, int64_t K, int act, itr_stream_t stream);
+/* C = act(R + A B^T + bias): itr_gemm_nt_acc with the summand read from its own matrix (Rs_GCN's `W(y) + v`, vsrn_.py:64-67: no
+ * copy of v into the output first).  Same arithmetic order as itr_gemm_nt_acc on a copy: bit-identical. */
+int itr_gemm_nt_residual(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, const float *R, int64_t ldr,
+                         float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, itr_stream_t stream);
 int itr_mul_rows(const float *a, const float *b, int64_t ldb, float *out, int64_t R, int C, itr_stream_t stream);
 int itr_affine_cols(const float *x, const float *scale, const float *shift, const float *residual, float *out,
                     int64_t R, int C, int act, itr_stream_t stream);

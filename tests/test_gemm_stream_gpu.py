@@ -78,3 +78,20 @@ def test_stream_gemm_overlapping_rows_and_strided_output(dev):
     assert float((out[idx].double() - want).abs().max()) <= 4e-7 * scale
     dense = ops.linear_strided(base, lda, M, K, w, bv, act='relu')                                   # the same call, dense output
     assert torch.equal(dense, out)
+
+
+def test_gemm_residual_equals_accumulate_on_a_copy(dev):
+    """itr_gemm_nt_residual (Rs_GCN's `W(y) + v`, vsrn_.py:64-67): the residual is read by the epilogue from its own matrix instead
+    of being copied into the output first -- the same additions in the same order, bit for bit, on a ragged shape (both tile
+    kernels) and against float64."""
+    torch.manual_seed(9)
+    for M, N, K in ((128 * 40 + 17, 2048, 2048), (77, 96, 40)):
+        x, w, b, r = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) * 0.05, torch.randn(N, device=dev), torch.randn(M, N, device=dev)
+        got = ops.gemm_residual(x, w, b, r, act='relu')
+        ref = r.clone()
+        ops.gemm_acc(x, K, M, K, w, b, ref, act='relu')
+        assert torch.equal(got, ref)
+        want = (r.double() + x.double() @ w.double().t() + b.double()).clamp(min=0)
+        assert float((got.double() - want).abs().max()) <= 4e-7 * float((x.double().abs() @ w.double().abs().t()).max())
+    with pytest.raises(ValueError):
+        ops.gemm_residual(x, w, b, r[:, :5])
