@@ -21,7 +21,8 @@ struct alignas(16) ScanTileMeta {
     int32_t cap_id[SC_MAXCAP];
     int32_t cap_start[SC_MAXCAP + 1];
     int8_t col_cap[SC_NT];       // caption slot of each column, -1 = padding
-    int32_t pad_[64 - 1 - SC_MAXCAP - (SC_MAXCAP + 1) - SC_NT / 4];
+    int32_t far;                 // 1: some caption spans three or more 16-column blocks (its Gram block reaches beyond the neighbouring blocks)
+    int32_t pad_[64 - 2 - SC_MAXCAP - (SC_MAXCAP + 1) - SC_NT / 4];
 };
 static_assert(sizeof(ScanTileMeta) == 256, "one 256-byte record per tile");
 

@@ -270,11 +270,15 @@ def test_scan_golden(golden, dev, xa, agg):
 
 
 @pytest.mark.parametrize("xa", ['t2i', 'i2t'])
-@pytest.mark.parametrize("Ni,Nc,D", [(1, 1, 32), (5, 40, 1024), (9, 70, 256)])
+@pytest.mark.parametrize("Ni,Nc,D", [(1, 1, 32), (5, 40, 1024), (9, 70, 256), (6, 33, 64)])
 def test_scan_random_vs_oracle(dev, xa, Ni, Nc, D):
+    """(6, 33, 64): captions of up to 60 words -- tiles in which a caption spans three or four 16-column blocks, next to tiles
+    without one (the i2t epilogue skips the far blocks of the block-diagonal caption Gram only in the latter, `ScanTileMeta.far`)."""
     rng = np.random.RandomState(Ni + Nc)
     torch.manual_seed(Ni)
     lens = [int(x) for x in rng.randint(1 if xa == 'i2t' else 2, 21, size=Nc)]
+    if Nc == 33:
+        lens[::3] = [int(x) for x in rng.randint(25, 61, size=len(lens[::3]))]
     L = max(lens)
     img = O.l2norm(torch.randn(Ni, 36, D), -1)
     cap = torch.randn(Nc, L, D) * 0.5
