@@ -99,7 +99,86 @@ def t2i_partition():
     return 0.0 if torch.equal(sub, full[:, c0:c1]) else 2.0
 
 
+def _sgraf_w(D, S, steps):
+    g = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+    w = {}
+    def lin(name, o, i):
+        r = float(np.sqrt(6.0 / (i + o)))
+        w[name + ".weight"] = (torch.rand(o, i, generator=g) * 2 - 1) * r
+        w[name + ".bias"] = torch.randn(o, generator=g) * 0.02
+    def bn(name, n):
+        w[name + ".weight"] = torch.rand(n, generator=g) * 0.4 + 0.8; w[name + ".bias"] = torch.randn(n, generator=g) * 0.05
+        w[name + ".running_mean"] = torch.randn(n, generator=g) * 0.1; w[name + ".running_var"] = torch.rand(n, generator=g) + 0.5
+    lin("v_global_w.embedding_local.0", D, D); bn("v_global_w.embedding_local.1", 36)
+    lin("v_global_w.embedding_global.0", D, D); bn("v_global_w.embedding_global.1", D)
+    lin("v_global_w.embedding_common.0", 1, D)
+    lin("t_global_w.embedding_local.0", D, D); lin("t_global_w.embedding_global.0", D, D); lin("t_global_w.embedding_common.0", 1, D)
+    lin("sim_tranloc_w", S, D); lin("sim_tranglo_w", S, D); lin("sim_eval_w", 1, S)
+    lin("SAF_module.attn_sim_w", 1, S); bn("SAF_module.bn", 1)
+    for k in range(steps):
+        for nm in ("graph_query_w", "graph_key_w", "sim_graph_w"):
+            lin("SGR_module.sgr%d.%s" % (k, nm), S, S)
+    return w
+
+
+def sgraf():
+    mod = 'SAF' if rng.rand() < 0.4 else 'SGR'
+    Ni, Nc, D, S = int(rng.randint(1, 20)), int(rng.randint(1, 40)), int(rng.choice([32, 64, 96])), int(rng.choice([256, 256, 64]))
+    steps = int(rng.randint(1, 5)) if mod == 'SGR' else 3
+    hi = int(rng.choice([6, 20, 63, 80]))
+    lens = [int(x) for x in rng.randint(1, hi + 1, size=Nc)]
+    img = O.l2norm(torch.randn(Ni, 36, D), -1)
+    cap = O.l2norm(torch.randn(Nc, max(lens), D), -1)
+    w = _sgraf_w(D, S, steps)
+    want = O.sgraf_similarity(w, img, cap, lens, mod, steps)
+    got = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, {k: v.to(dev) for k, v in w.items()}, mod, steps)
+    return float((got.cpu() - want).abs().max()) / 5e-6
+
+
+def bigru():
+    V, E, D = int(rng.randint(5, 300)), int(rng.choice([16, 64, 300])), int(rng.choice([32, 128, 256]))
+    B = int(rng.choice([1, 3, 40, 1100]))
+    hi = int(rng.randint(1, 12))
+    lengths = sorted([int(x) for x in rng.randint(1, hi + 1, size=B)], reverse=True)
+    ids = torch.from_numpy(rng.randint(0, V, size=(B, max(lengths))))
+    bi = bool(rng.rand() < 0.7)
+    rnn = torch.nn.GRU(E, D, 1, batch_first=True, bidirectional=bi)
+    w = {'embed.weight': torch.empty(V, E).uniform_(-0.1, 0.1)}
+    w.update({'rnn.' + k: v.detach() for k, v in rnn.state_dict().items()})
+    toks = torch.cat([ids[b, :l] for b, l in enumerate(lengths)]).to(dev)
+    off = torch.tensor(np.concatenate([[0], np.cumsum(lengths)[:-1]]), dtype=torch.int64, device=dev)
+    last = bool(rng.rand() < 0.5)
+    got = ops.gru_encode(toks, off, lengths, {k: v.to(dev) for k, v in w.items()}, bi, gather_last=last, batch_invariant=bool(rng.rand() < 0.5))
+    n = min(B, 12)
+    want, _ = O.encoder_text(ids[:n], lengths[:n], w, bi, False, False, None)
+    worst, o = 0.0, 0
+    for b in range(n):
+        if last:
+            worst = max(worst, float((got[b].cpu() - want[b, lengths[b] - 1]).abs().max()))
+        else:
+            worst = max(worst, float((got[o:o + lengths[b]].cpu() - want[b, :lengths[b]]).abs().max()))
+            o += lengths[b]
+    return worst / 5e-6
+
+
+def gemm():
+    M, N, K = int(rng.choice([1, 77, 128 * 3 + 5, 128 * 40, 128 * 700 + 3])), int(rng.choice([1, 64, 96, 128, 256, 384])), int(rng.choice([4, 40, 64, 128, 192, 256, 768]))
+    act = rng.choice([None, 'relu', 'gelu', 'tanh', 'sigmoid'])
+    x, wt = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) * 0.1
+    b = torch.randn(N, device=dev) if rng.rand() < 0.7 else None
+    got = ops.linear(x, wt, b, act=act).double()
+    idx = torch.randint(0, M, (min(M, 2000),), device=dev)
+    want = x[idx].double() @ wt.double().t() + (b.double() if b is not None else 0)
+    want = {None: lambda t: t, 'relu': lambda t: t.clamp(min=0), 'gelu': lambda t: 0.5 * t * (1 + torch.erf(t / 2 ** 0.5)), 'tanh': torch.tanh,
+            'sigmoid': torch.sigmoid}[act](want)
+    scale = float((x[idx].double().abs() @ wt.double().abs().t()).max()) + 1.0
+    return float((got[idx] - want).abs().max()) / (6e-7 * scale)
+
+
 torch.manual_seed(7)
+family("SGRAF SAF / SGR", sgraf)
+family("GRU", bigru)
+family("linear (+ activations)", gemm)
 family("attention (mha_small)", mha)
 family("CAMERA gate (agsa_gate)", gate)
 family("SCAN, any region count", scan_any_r)
