@@ -61,3 +61,15 @@ gaps = np.asarray(gaps)
 print("end -> next entry on the same CU: mean %.0f  median %.0f  p90 %.0f cycles" % (gaps.mean(), np.median(gaps), np.percentile(gaps, 90)))
 tot_floor = (4 * floor_proj + 2 * floor_last).mean()
 print("projection MFMA floor per workgroup %.0f cycles = %.1f%% of lifetime + gap" % (tot_floor, 100 * tot_floor / (life.mean() + max(gaps.mean(), 0))))
+
+# attention phases against the group's shape: extra = number of (caption, query tile) units beyond one per caption, i.e. how many
+# second / third / fourth 16-node tiles the group's captions have (0: every caption has <= 16 nodes)
+extra = nunit - ncap
+print("%-22s %8s %10s %10s %10s" % ("units - captions", "groups", "P2e step0", "P2y step0", "P1 step0"))
+for x in sorted(set(extra.tolist())):
+    m = extra == x
+    print("%-22d %8d %10.0f %10.0f %10.0f" % (x, int(m.sum()), d[m, 2].mean(), d[m, 3].mean(), d[m, 1].mean()))
+print("%-22s %8s %10s %10s" % ("units", "groups", "P2e step0", "P2y step0"))
+for x in sorted(set(nunit.tolist())):
+    m = nunit == x
+    print("%-22d %8d %10.0f %10.0f" % (x, int(m.sum()), d[m, 2].mean(), d[m, 3].mean()))
