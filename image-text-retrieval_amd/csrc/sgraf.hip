@@ -142,16 +142,27 @@ __global__ __launch_bounds__(256) void glo_sqdiff_kernel(const float *__restrict
     for (int d = threadIdx.x; d < D; d += 256) { const float v = a[d] - b[d]; o[d] = v * v; }
 }
 
+// The global similarity node l2norm(W_glo (img_glo - cap_glo)^2 + b) through the LOCAL-node kernel (round 3): per image a "region
+// set" whose row 0 is img_glo and whose other rows are zero, attention weights that select row 0 and a context norm of 1 make the
+// kernel's context exactly img_glo; the captions' global vectors are its "words" (tiles of 64 captions).
+__global__ __launch_bounds__(256) void glo_onehot_kernel(float *__restrict__ P, float *__restrict__ cn, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * SC_R) return;
+    P[i] = (i % SC_R == 0) ? 1.f : 0.f;
+    if (i < rows) cn[i] = 1.f;
+}
+
 struct PairArgs {
-    const float *xglo, *xloc;      // [nb*Nc, S], [nb*ncols, S]
+    const float *xglo, *xloc;      // [nb*ldg, S], [nb*ncols, S]
     const int32_t *cap_col, *cap_len;
     int64_t Nc, ncols;
     int S;
+    int64_t ldg;                   // rows per image in xglo: Nc, or Nc rounded up to whole 64-row tiles (global nodes from the local-node kernel)
 };
 
 __device__ __forceinline__ const float *node_row(const PairArgs &p, const float *glo, const float *loc, int64_t ii,
                                                  int64_t c, int col0, int n) {
-    return n == 0 ? glo + (ii * p.Nc + c) * p.S : loc + (ii * p.ncols + col0 + n - 1) * p.S;
+    return n == 0 ? glo + (ii * p.ldg + c) * p.S : loc + (ii * p.ncols + col0 + n - 1) * p.S;
 }
 
 // AttentionFiltration + final score (Fusionmodule.py:615-619, :443-444); one wave per (image, caption) pair
@@ -390,11 +401,11 @@ __global__ __launch_bounds__(256) void sgr_pair_kernel(PairArgs p, const float *
 
 __global__ __launch_bounds__(256) void sgr_final_kernel(const float *__restrict__ xglo, int64_t Nc, int S_, const float *__restrict__ eval_w,
                                                         const float *__restrict__ eval_b, int64_t npairs, float *__restrict__ S,
-                                                        int64_t ldS, int64_t img_index0) {
+                                                        int64_t ldS, int64_t img_index0, int64_t ldg) {
     const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pair >= npairs) return;
     const int lane = threadIdx.x & 63;
-    const float *x = xglo + pair * S_;
+    const float *x = xglo + ((pair / Nc) * ldg + pair % Nc) * S_;
     float s = 0.f;
     for (int d = lane; d < S_; d += 64) s += x[d] * eval_w[d];
     s = wave_sum(s) + eval_b[0];
@@ -417,9 +428,11 @@ extern "C" size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_ro
     b += al((size_t)n_rows * D * 4) + al((size_t)Nc * D * 4) * 3;                // l_emb_t; cap_ave, g_emb_t, cap_glo
     b += al((size_t)Nc * 4) + al((size_t)Nc * 8);                                // cap_col, seg offsets (unused slot)
     b += al((size_t)IB * ncols * SC_R * 4) + al((size_t)IB * ncols * 4) + al((size_t)IB * Nc * 4);   // P, cn, scan scratch
+    const int64_t NcP = (Nc + SC_NT - 1) / SC_NT * SC_NT;                        // captions rounded up to whole 64-row tiles
     b += (S == 256 ? 0 : al((size_t)IB * ncols * D * 4)) + al((size_t)IB * Nc * D * 4);   // Aloc (unfused path only), Aglo
+    b += al((size_t)(NcP - Nc) * D * 4) + al((size_t)IB * NcP * SC_R * 4) + al((size_t)IB * NcP * 4) + al((size_t)IB * SC_R * D * 4);   // cap_glo tail, one-hot weights, unit norms, global "regions"
     const int nbuf = module == 1 ? 3 : 1;                                        // X (+ Q', Y for SGR)
-    b += (al((size_t)IB * ncols * S * 4) + al((size_t)IB * Nc * S * 4)) * nbuf;
+    b += (al((size_t)IB * ncols * S * 4) + al((size_t)IB * NcP * S * 4)) * nbuf;
     if (module == 1) b += al((size_t)S * S * 4) * 2 + (al((size_t)S * S * 4) + al((size_t)S * 4)) * 8;   // W^T scratch, folded query weights
     if (module == 1 && S == 256) b += al(sgr_fused_workspace_bytes(Nc, 8)) + 256;                       // group records (<= one per caption), weight fragments, flag
     return b;
@@ -460,19 +473,26 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     float *l_emb_v = (float *)take((size_t)Ni * SC_R * D * 4), *imgT = (float *)take((size_t)Ni * SC_R * D * 4);
     float *l_emb_t = (float *)take((size_t)n_rows * D * 4);
     float *cap_ave = (float *)take((size_t)Nc * D * 4), *g_emb_t = (float *)take((size_t)Nc * D * 4);
-    float *cap_glo = (float *)take((size_t)Nc * D * 4);
+    const int64_t NcP = (Nc + SC_NT - 1) / SC_NT * SC_NT;
+    // sim_dim 256: the global nodes come from the local-node kernel (ITR_SGRAF_GLO_GEMM=1: the (a - b)^2 kernel + GEMM + l2norm chain
+    // of rounds 1-2, for A/B timing); their rows then lie in whole 64-caption tiles: ldg = NcP rows per image
+    const bool glo_loc = (S == 256) && !getenv("ITR_SGRAF_GLO_GEMM");
+    const int64_t ldg = glo_loc ? NcP : Nc;
+    float *cap_glo = (float *)take((size_t)Nc * D * 4 + (size_t)(NcP - Nc) * D * 4);       // + zero rows up to the last tile
     int32_t *cap_col = (int32_t *)take((size_t)Nc * 4);
     take((size_t)Nc * 8);
     float *P = (float *)take((size_t)IB * ncols * SC_R * 4), *cn = (float *)take((size_t)IB * ncols * 4);
     float *sscr = (float *)take((size_t)IB * Nc * 4);
     float *Aloc = (S == 256) ? nullptr : (float *)take((size_t)IB * ncols * D * 4);
     float *Aglo = (float *)take((size_t)IB * Nc * D * 4);
-    float *Xloc = (float *)take((size_t)IB * ncols * S * 4), *Xglo = (float *)take((size_t)IB * Nc * S * 4);
+    float *Pg = (float *)take((size_t)IB * NcP * SC_R * 4), *cng = (float *)take((size_t)IB * NcP * 4);
+    float *gimg = (float *)take((size_t)IB * SC_R * D * 4);
+    float *Xloc = (float *)take((size_t)IB * ncols * S * 4), *Xglo = (float *)take((size_t)IB * NcP * S * 4);
     float *Qloc = nullptr, *Qglo = nullptr, *Yloc = nullptr, *Yglo = nullptr;
     float *WqT = nullptr, *WkT = nullptr, *Wfold[8] = {nullptr}, *vfold[8] = {nullptr};
     if (module == 1) {
-        Qloc = (float *)take((size_t)IB * ncols * S * 4); Qglo = (float *)take((size_t)IB * Nc * S * 4);
-        Yloc = (float *)take((size_t)IB * ncols * S * 4); Yglo = (float *)take((size_t)IB * Nc * S * 4);
+        Qloc = (float *)take((size_t)IB * ncols * S * 4); Qglo = (float *)take((size_t)IB * NcP * S * 4);
+        Yloc = (float *)take((size_t)IB * ncols * S * 4); Yglo = (float *)take((size_t)IB * NcP * S * 4);
         WqT = (float *)take((size_t)S * S * 4); WkT = (float *)take((size_t)S * S * 4);
         for (int k = 0; k < 8; ++k) { Wfold[k] = (float *)take((size_t)S * S * 4); vfold[k] = (float *)take((size_t)S * 4); }
     }
@@ -546,7 +566,13 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
                                  fused_bad, st));
     }
 
-    PairArgs pa{Xglo, Xloc, cap_col, cap_len, Nc, ncols, S};
+    if (glo_loc) {
+        if (NcP > Nc) ITR_CHECK_HIP(hipMemsetAsync(cap_glo + Nc * D, 0, (size_t)(NcP - Nc) * D * 4, st));
+        ITR_CHECK_HIP(hipMemsetAsync(gimg, 0, (size_t)IB * SC_R * D * 4, st));
+        hipLaunchKernelGGL(glo_onehot_kernel, dim3((unsigned)ceil_div(IB * NcP * SC_R, (int64_t)256)), dim3(256), 0, st, Pg, cng, IB * NcP);
+        ITR_CHECK_LAUNCH("sgraf glo one-hot");
+    }
+    PairArgs pa{Xglo, Xloc, cap_col, cap_len, Nc, ncols, S, ldg};
     for (int64_t i0 = 0; i0 < Ni; i0 += IB) {
         const int64_t nb = (Ni - i0 < IB) ? Ni - i0 : IB;
         // 1. attention weights + context norms  (SCAN_attention: clipped_l2norm, smooth 9)
@@ -563,17 +589,24 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
             SG_TRY(norm_rows(Xloc, Xloc, nb * ncols, S, 1e-8f, 0, 0, st));
         }
         // 4. sim_glo
-        hipLaunchKernelGGL(glo_sqdiff_kernel, dim3((unsigned)Nc, (unsigned)nb), dim3(256), 0, st, img_glo + i0 * D, cap_glo, Nc, D, Aglo);
-        ITR_CHECK_LAUNCH("sgraf glo_sqdiff");
-        SG_TRY(gemm_nt(Aglo, D, w->glo_w, D, w->glo_b, Xglo, S, nb * Nc, S, D, 0, st));
-        SG_TRY(norm_rows(Xglo, Xglo, nb * Nc, S, 1e-8f, 0, 0, st));
+        if (glo_loc) {
+            // row 0 of image ii's "region set" <- img_glo[i0 + ii] (the other 35 rows stay zero), then the local-node kernel
+            ITR_CHECK_HIP(hipMemcpy2DAsync(gimg, (size_t)SC_R * D * 4, img_glo + i0 * D, (size_t)D * 4, (size_t)D * 4, (size_t)nb,
+                                           hipMemcpyDeviceToDevice, st));
+            SG_TRY(sgraf_loc_fused(Pg, cng, gimg, cap_glo, w->glo_w, w->glo_b, Xglo, nb, NcP / SC_NT, D, st));
+        } else {
+            hipLaunchKernelGGL(glo_sqdiff_kernel, dim3((unsigned)Nc, (unsigned)nb), dim3(256), 0, st, img_glo + i0 * D, cap_glo, Nc, D, Aglo);
+            ITR_CHECK_LAUNCH("sgraf glo_sqdiff");
+            SG_TRY(gemm_nt(Aglo, D, w->glo_w, D, w->glo_b, Xglo, S, nb * Nc, S, D, 0, st));
+            SG_TRY(norm_rows(Xglo, Xglo, nb * Nc, S, 1e-8f, 0, 0, st));
+        }
         const int64_t npairs = nb * Nc;
         if (module == 0) {
             hipLaunchKernelGGL(saf_pair_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), 0, st, pa, w->saf_w, w->saf_b, w->saf_bn_w,
                                w->saf_bn_b, w->saf_bn_mean, w->saf_bn_var, w->eval_w, w->eval_b, npairs, Sout, ldS, i0);
             ITR_CHECK_LAUNCH("sgraf saf_pair");
         } else if (fused_sgr) {
-            SG_TRY(sgr_fused_scores(Xloc, Xglo, fused_ws, n_node_groups, nb, Nc, ncols, vfold, w->sgr_g_b, sgr_step, w->eval_w, w->eval_b, Sout,
+            SG_TRY(sgr_fused_scores(Xloc, Xglo, fused_ws, n_node_groups, nb, ldg, ncols, vfold, w->sgr_g_b, sgr_step, w->eval_w, w->eval_b, Sout,
                                     ldS, i0, st));
         } else {
             const int ntmax = (max_len + 1 + 15) / 16;
@@ -581,7 +614,7 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
             for (int k = 0; k < sgr_step; ++k) {
                 const int last = (k == sgr_step - 1);
                 if (!last) SG_TRY(gemm_nt(Xloc, S, Wfold[k], S, vfold[k], Qloc, S, nb * ncols, S, S, 0, st));   // last: only node 0 queries
-                SG_TRY(gemm_nt(Xglo, S, Wfold[k], S, vfold[k], Qglo, S, nb * Nc, S, S, 0, st));
+                SG_TRY(gemm_nt(Xglo, S, Wfold[k], S, vfold[k], Qglo, S, nb * ldg, S, S, 0, st));
                 const dim3 pgrid((unsigned)ceil_div(npairs, 4));
                 auto plds = [](int nt) { return (size_t)4 * (nt * 16) * (nt * 16 + 4) * 4; };   // 4 waves x P[NT*16][NT*16+4]
                 if (ntmax == 1) {
@@ -597,10 +630,10 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
                 // NOTE: a word node is shared by all captions... it is NOT: node rows are per (image, word) and a word
                 // belongs to one caption, so writing Yloc rows per pair is race-free.
                 if (!last) SG_TRY(gemm_nt(Yloc, S, w->sgr_g_w[k], S, w->sgr_g_b[k], Xloc, S, nb * ncols, S, S, 1 /*relu*/, st));
-                SG_TRY(gemm_nt(Yglo, S, w->sgr_g_w[k], S, w->sgr_g_b[k], Xglo, S, nb * Nc, S, S, 1, st));
+                SG_TRY(gemm_nt(Yglo, S, w->sgr_g_w[k], S, w->sgr_g_b[k], Xglo, S, nb * ldg, S, S, 1, st));
             }
             hipLaunchKernelGGL(sgr_final_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), 0, st, Xglo, Nc, S, w->eval_w, w->eval_b,
-                               npairs, Sout, ldS, i0);
+                               npairs, Sout, ldS, i0, ldg);
             ITR_CHECK_LAUNCH("sgraf sgr_final");
         }
     }
