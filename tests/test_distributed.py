@@ -186,3 +186,52 @@ def test_virtual_caption_split_scores_like_one_owner():
         assert sum(calls) == n_cap and (counts[v] == 0 or calls[0] == counts[v])      # own block first, every caption exactly once
     with pytest.raises(ValueError):
         evalpipe.Comm(virtual_split="3:3")
+
+
+def _run_bench(args, env_extra=None, drop=()):
+    import subprocess
+    env = dict(os.environ, **(env_extra or {}))
+    for k in drop:
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` as ONE command: the parent makes no GPU call, starts two ranks through
+    torch.distributed.run as a child process, and rank 0's line carries n_gpus = 2, the process group's world size and a rank
+    table with two distinct processes that was all-gathered through that group."""
+    import json
+    r = _run_bench(["--gpus", "2", "--launch-check"], dict(ITR_DIST_BACKEND="gloo"), drop=("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_world"] == 2 and out["launched_by"] == "bench.py"
+    assert [x["rank"] for x in out["ranks"]] == [0, 1] and len({x["pid"] for x in out["ranks"]}) == 2
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """A 1-rank process asked for 2 GPUs (or 2 ranks asked for 1) exits non-zero and prints no result line."""
+    r = _run_bench(["--gpus", "2", "--launch-check"], dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 2 and '{"metric"' not in r.stdout
+    r = _run_bench(["--gpus", "1", "--launch-check"], dict(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 2 and '{"metric"' not in r.stdout
+
+
+def test_bench_parent_makes_no_gpu_call_before_launching():
+    """The launching parent must not initialise the GPU (a re-launch from a process that has is what takes this pool's machines
+    down): between the top of main() and launch_ranks() there is no torch.cuda / HIP-library call."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
+    seen_launch = False
+    for node in ast.walk(fn):
+        if isinstance(node, ast.Call) and getattr(node.func, "id", "") == "launch_ranks":
+            seen_launch = True
+            launch_line = node.lineno
+    assert seen_launch
+    head = "\n".join(src.splitlines()[fn.lineno - 1:launch_line])
+    assert "torch.cuda" not in head and "_lib" not in head and "itr_amd" not in head
+    lr = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "launch_ranks"][0]
+    body = "\n".join(src.splitlines()[lr.body[1].lineno - 1:lr.end_lineno])      # (past the docstring)
+    assert "torch.cuda" not in body and "os.exec" not in body and "execv" not in body

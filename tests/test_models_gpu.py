@@ -1,5 +1,7 @@
 """GPU: the reference's Python seams (get_model / forward_emb / forward_loss / encode_data / cal_sims / i2t / t2i)
 re-implemented on the HIP kernels, checked against golden vectors captured from the reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -250,6 +252,46 @@ def test_sharded_eval_equals_single_process_on_one_gpu(workload, world):
     assert multi["n_gpus"] == world
     assert multi["rank_checksum"] == single["rank_checksum"]
     assert multi["recall"] == single["recall"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_as_one_command_on_one_gpu():
+    """`python bench.py --gpus 2` with NO launcher in front: bench.py starts the two ranks itself (gloo: they share
+    this box's one GPU), the line says n_gpus = 2, carries the process group's world size and the all-gathered rank table, and the
+    rank vectors equal the 1-rank line's.  `--gpus 1` is unchanged: one process, no group."""
+    single = _bench_line(_base_args("scan_t2i_f30k1k"))
+    assert single["n_gpus"] == 1 and single["rccl_world"] == 1 and len(single["ranks"]) == 1 and single["launched_by"] == "direct"
+    assert single["ranks"][0]["pci_bus_id"] is not None
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + _base_args("scan_t2i_f30k1k"),
+                       env=dict(env, ITR_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    multi = json.loads(lines[0])
+    assert multi["n_gpus"] == 2 and multi["rccl_world"] == 2 and multi["launched_by"] == "bench.py"
+    assert [x["rank"] for x in multi["ranks"]] == [0, 1] and len({x["pid"] for x in multi["ranks"]}) == 2
+    assert multi["rank_checksum"] == single["rank_checksum"] and multi["recall"] == single["recall"]
+    # two nccl ranks on ONE device is refused loudly, not run as something else
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode != 0 and '{"metric"' not in r.stdout
+
+
+@pytest.mark.gpu
+def test_other_configs_ride_along_with_the_default_line():
+    """the default workload's line carries a timed figure for every other BASELINE.json config.  Run here on the
+    small default (ITR_BENCH_OTHER=small keeps the 1k x 5k forms only, so the test stays short)."""
+    out = _bench_line(["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-variants"], env=dict(ITR_BENCH_OTHER="small"), timeout=1500)
+    oc = out["other_configs"]
+    assert set(oc) >= {"vsepp_f30k1k", "scan_t2i_f30k1k", "sgraf_saf_f30k1k", "sgraf_sgr_f30k1k"}
+    for name, o in oc.items():
+        assert o["ms_per_step"] > 0 and o["pairs_per_s"] > 0 and 0 < o["frac"] < 1 and len(o["rank_checksum"]) == 4, name
+    assert oc["scan_t2i_f30k1k"]["rank_checksum"] == _bench_line(_base_args("scan_t2i_f30k1k"))["rank_checksum"]
 
 
 @pytest.mark.gpu
