@@ -21,9 +21,15 @@
 //   P3  X'^T[o, n] = relu(W_g[o, :] . Y[n, :] + b)    as P1, from the Q'/Y buffer back into the X buffer.
 // The last step needs node 0 only (Fusionmodule.py:443 reads sim_emb[:, 0]): P1 / P3 run on the first 16 rows (the global nodes of
 // the group's captions live there), P2 computes one query column per caption.  Then sigmoid(sim_eval_w . x_0 + b) -> S.
-// v_mfma_f32_16x16x4_f32 throughout (exact fp32).  LDS: two [64][264] fp32 buffers (row stride 264 = 2 mod 16 sixteen-byte slots:
-// the ds_read_b128 lane groups of a 16-row x 4-slot fragment read hit 16 distinct slots) + the group record = 135.7 KB,
-// one 512-thread workgroup per CU.
+// v_mfma_f32_16x16x4_f32 throughout (exact fp32).  LDS: two [ROWS][264] fp32 buffers (row stride 264 = 2 mod 16 sixteen-byte slots:
+// the ds_read_b128 lane groups of a 16-row x 4-slot fragment read hit 16 distinct slots) + the group records + the softmax tiles.
+//
+// Two sizes of group (round 4).  ROWS = 32 (the planner's default: every caption of at most 31 words): 79 KB of LDS, TWO 512-thread
+// workgroups per CU -- while one of them sits in its attention phase (block-diagonal 16 x 16 tiles, at best half of the matrix pipe)
+// or at one of its barriers, the other one's projection MFMAs fill the pipe, which a single resident workgroup cannot do (round 3:
+// 80.5 % pipe busy, waves parked 28 %).  ROWS = 64 (captions of 32..63 words, and any hand-made plan with larger groups): 157 KB,
+// one workgroup per CU, as in round 3.  The groups of a call are sorted into the two classes ON THE DEVICE (sgr_group_meta_kernel +
+// sgr_group_classify_kernel: no host round trip); a class's persistent launch reads its item count from device memory.
 #include "scan_common.h"
 #include <string.h>
 #include <stdlib.h>
@@ -32,6 +38,7 @@
 namespace itr {
 
 constexpr int SF_ROWS = 64, SF_S = 256, SF_LD = 264, SF_MAXCAP = 16, SF_MAXUNIT = 24, SF_THREADS = 512, SF_WAVES = 8;
+constexpr int SF_SMALL = 32;             // node rows of the small class of groups (two workgroups per CU)
 
 // One record per group of captions (built on the device from the host's bin plan: sgr_group_meta_kernel).
 struct alignas(16) SgrGroupMeta {
@@ -48,13 +55,18 @@ struct alignas(16) SgrGroupMeta {
 };
 static_assert(sizeof(SgrGroupMeta) == 512, "one 512-byte record per group");
 
-constexpr int SF_PTILES = 24;            // softmax tiles (16 x 16 floats) of one group: sum over captions of (key tiles)^2; at most 24 for <= 64
-                                         // node rows in <= 16 graphs of >= 2 nodes (one 33-node graph + fifteen 2-node ones: 9 + 15)
-constexpr size_t SF_LDS_BYTES = 2 * SF_ROWS * SF_LD * sizeof(float) + 2 * sizeof(SgrGroupMeta) + SF_PTILES * 1024;   // (the second record: persistent form)
+// softmax tiles (16 x 16 floats) of one group = sum over its captions of (key tiles)^2.  <= 64 node rows in <= 16 graphs of >= 2 nodes:
+// at most 24 (one 33-node graph + fifteen 2-node ones: 9 + 15); <= 32 rows: at most 11 (one 17-node graph + seven 2-node ones: 4 + 7)
+constexpr int sf_ptiles(int rows) { return rows > SF_SMALL ? 24 : 12; }
+constexpr size_t sf_lds_bytes(int rows) {      // (two group records: the persistent form holds the next item's as well)
+    return 2 * (size_t)rows * SF_LD * sizeof(float) + 2 * sizeof(SgrGroupMeta) + (size_t)sf_ptiles(rows) * 1024;
+}
+static_assert(2 * sf_lds_bytes(SF_SMALL) <= 160 * 1024 && sf_lds_bytes(SF_ROWS) <= 160 * 1024, "LDS budget of a CU");
 
 __global__ __launch_bounds__(256) void sgr_group_meta_kernel(const int32_t *__restrict__ grp_begin, const int32_t *__restrict__ grp_order,
                                                              const int32_t *__restrict__ cap_len, const int32_t *__restrict__ cap_col,
-                                                             int64_t n_groups, SgrGroupMeta *__restrict__ meta, int *__restrict__ bad) {
+                                                             int64_t n_groups, SgrGroupMeta *__restrict__ meta, int *__restrict__ bad,
+                                                             int8_t *__restrict__ cls, int32_t *__restrict__ cap_bad, int64_t n_caps) {
     const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gi >= n_groups) return;
     SgrGroupMeta m;
@@ -63,7 +75,9 @@ __global__ __launch_bounds__(256) void sgr_group_meta_kernel(const int32_t *__re
     int rows = ncap;
     bool ok = ncap >= 1 && ncap <= SF_MAXCAP;
     for (int s = 0; ok && s < ncap; ++s) {
-        const int c = grp_order[b0 + s], len = cap_len[c];
+        const int c = grp_order[b0 + s];
+        if (c < 0 || c >= n_caps) { ok = false; break; }
+        const int len = cap_len[c];
         if (len < 1 || rows + len > SF_ROWS) { ok = false; break; }
         m.cap_id[s] = c;
         m.nn[s] = (int16_t)(len + 1);
@@ -72,7 +86,18 @@ __global__ __launch_bounds__(256) void sgr_group_meta_kernel(const int32_t *__re
         for (int w = 0; w < len; ++w) m.row_src[rows + w] = cap_col[c] + w;
         rows += len;
     }
-    if (!ok) { atomicExch(bad, 1); m.ncap = 0; meta[gi] = m; return; }     // the host plan is wrong: the group scores nothing, the caller is told
+    // The plan is wrong (more than 16 captions, more than 64 node rows, more softmax tiles than the scratch holds): the group is not
+    // scored, and so that this is LOUD and not a column of uninitialised memory, its captions are marked and sgr_poison_kernel writes
+    // NaN into their score columns at the end of the call (the call has returned by then: no error code can carry it).
+    auto refuse = [&]() {
+        atomicExch(bad, 1);
+        for (int s = 0; s < ncap && s < 4096; ++s) {
+            const int c = grp_order[b0 + s];
+            if (c >= 0 && c < n_caps) cap_bad[c] = 1;
+        }
+        m.ncap = 0; meta[gi] = m; cls[gi] = -1;
+    };
+    if (!ok) { refuse(); return; }
     m.ncap = ncap;
     m.nrows = rows;
     int nu = 0;
@@ -83,10 +108,51 @@ __global__ __launch_bounds__(256) void sgr_group_meta_kernel(const int32_t *__re
     m.nunit = nu;
     int po = 0;
     for (int u = 0; u < nu; ++u) { m.unit_poff[u] = (uint8_t)po; po += (m.nn[m.unit_cap[u]] + 15) / 16; }
-    if (po > SF_PTILES) { atomicExch(bad, 1); m.ncap = 0; meta[gi] = m; return; }
+    if (po > sf_ptiles(SF_ROWS)) { refuse(); return; }
+    const bool small = rows <= SF_SMALL && po <= sf_ptiles(SF_SMALL);
     po = 0;
     for (int s = 0; s < ncap; ++s) { m.cap_poff[s] = (uint8_t)po; po += (m.nn[s] + 15) / 16; }
     meta[gi] = m;
+    cls[gi] = small ? 0 : 1;
+}
+
+// Stable compaction of the group indices into the two class lists (one workgroup; a call has a few thousand groups).
+// glist[0 .. n) = small groups, glist[n_groups .. ) = large ones; gcount[0 / 1] = their numbers.
+__global__ __launch_bounds__(1024) void sgr_group_classify_kernel(const int8_t *__restrict__ cls, int64_t n_groups, int32_t *__restrict__ glist,
+                                                                  int32_t *__restrict__ gcount) {
+    __shared__ int wsum[2][16];
+    __shared__ int base[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 2) base[tid] = 0;
+    __syncthreads();
+    for (int64_t g0 = 0; g0 < n_groups; g0 += 1024) {
+        const int64_t gi = g0 + tid;
+        const int c = gi < n_groups ? cls[gi] : -1;
+        int pos[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned long long bal = __ballot(c == k);
+            pos[k] = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wsum[k][wv] = __popcll(bal);
+        }
+        __syncthreads();
+        if (c >= 0) {
+            int off = base[c];
+            for (int w = 0; w < wv; ++w) off += wsum[c][w];
+            glist[(c ? n_groups : 0) + off + pos[c]] = (int32_t)gi;
+        }
+        __syncthreads();
+        if (tid < 2) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[tid][w]; base[tid] += t; }
+        __syncthreads();
+    }
+    if (tid < 2) gcount[tid] = base[tid];
+}
+
+// A refused group's captions: NaN in their score columns (see sgr_group_meta_kernel).
+__global__ __launch_bounds__(256) void sgr_poison_kernel(const int32_t *__restrict__ cap_bad, int64_t Nc, int64_t Ni, float *__restrict__ S, int64_t ldS) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= Nc || !cap_bad[c]) return;
+    for (int64_t i = 0; i < Ni; ++i) S[i * ldS + c] = __builtin_nanf("");
 }
 
 // W [256][256] row-major -> MFMA A-fragment order: frag[((ot * 16 + ks) * 64 + lane)] (float4) = W[16 ot + (lane & 15)][16 ks + 4 (lane >> 4) + 0..3]
@@ -97,12 +163,22 @@ __global__ __launch_bounds__(256) void sgr_pack_weight_kernel(const float *__res
     frag[idx] = *reinterpret_cast<const float4 *>(W + (16 * ot + (lane & 15)) * SF_S + 16 * ks + 4 * (lane >> 4));
 }
 
+// W [256][256] row-major [o][k] -> W^T [k][o]: the operand of the last step's vector-ALU projections (a lane owns four consecutive
+// outputs o and reads them with one 16-byte load per k).
+__global__ __launch_bounds__(256) void sgr_transpose_weight_kernel(const float *__restrict__ W, float *__restrict__ WT) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // = k * 256 + o
+    if (idx >= SF_S * SF_S) return;
+    WT[idx] = W[(idx & (SF_S - 1)) * SF_S + (idx >> 8)];
+}
+
 struct SgrFusedArgs {
     const float *xloc, *xglo;            // [nb][ncols][256], [nb][Nc][256]
     const SgrGroupMeta *meta;
+    const int32_t *glist, *gcount;       // this class's group indices and their number (device memory: sgr_group_classify_kernel)
     int64_t n_groups, nb, Nc, ncols;
     const float4 *wq[8], *wg[8];         // fragment-ordered folded query weight / graph weight of every step
     const float *vq[8], *bg[8];
+    const float *wqT_last, *wgT_last;    // the LAST step's folded query weight / graph weight, transposed: [k][o] (sgr_transpose_weight_kernel)
     int steps;
     const float *eval_w, *eval_b;
     float *S;
@@ -222,14 +298,19 @@ __device__ __forceinline__ void sf_project(unsigned src_lds, float *__restrict__
     }
 }
 
-template <bool RELU>
+template <bool RELU, int ROWS>
 __device__ __forceinline__ void sf_project_n(int ng, unsigned src, float *dst, const float4 *wfrag, const float *bias, int wave, int lane,
                                              f32x4 &a0, f32x4 &a1, const float4 *wnext) {
-    switch (ng) {
-        case 1: sf_project<1, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
-        case 2: sf_project<2, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
-        case 3: sf_project<3, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
-        default: sf_project<4, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
+    if constexpr (ROWS > SF_SMALL) {
+        switch (ng) {
+            case 1: sf_project<1, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
+            case 2: sf_project<2, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
+            case 3: sf_project<3, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
+            default: sf_project<4, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext); break;
+        }
+    } else {
+        if (ng == 1) sf_project<1, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext);
+        else sf_project<2, RELU>(src, dst, wfrag, bias, wave, lane, a0, a1, wnext);
     }
 }
 
@@ -401,20 +482,218 @@ __device__ __forceinline__ void sf_attend_y(unsigned xb_lds, float *__restrict__
     sf_yquarter<NTC, 256>(vaddr, p, yrow, wr);
 }
 
-__global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g) {
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The LAST graph step on the vector ALU (round 4).  Only node 0 of every graph is read after it (Fusionmodule.py:443: sim_emb[:, 0]), so
+// the step is, per caption: q' = W' x_0 + v (one row), one softmax row over the graph's nodes, y = sum_j p_j x_j, x_0' = relu(W_g y + b).
+// As 16 x 16 x 4 MFMA tiles this was 16 node columns of which ncap (2-5) were live for the two projections, and 16 query columns of
+// which ONE was live for the attention: 8.2 k + 6.1 k + 8.2 k cycles of the matrix pipe per 32-row item, a quarter of all the MFMA time
+// of the kernel, for 2 % of its useful flop.  fp32 MFMA and the vector ALU are the same ALU on gfx950 (their times add), so the honest
+// price of the step is its useful flop at the packed-FMA rate: ~1.1 k cycles per projection, < 1 k for the attention.
+//
+// Projection: dst[n][o] = act(sum_k WT[k][o] src[n][k] + bias[o]) for the rows n < ncap (LDS rows 0 .. ncap - 1 = the global nodes).
+// Wave w owns outputs 32 w .. 32 w + 31; lane = (k slice ks = lane >> 3 of 32 k, output quad oq = lane & 7): one 16-byte weight load per
+// k (8 x 128 contiguous bytes per wave instruction), four rows per pass over the weights; the eight k slices are summed across lanes
+// (l ^ 8: DPP row_ror 8; l ^ 16, l ^ 32: the permlane swaps of sf_rows_sum) in a fixed order -- a row's result does not depend on which
+// group or slot its caption was packed into.
+template <int CTRL>
+__device__ __forceinline__ float sf_dpp(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sf_row16_sum(float v) {      // all-reduce over the 16 lanes of a row (rotations: every lane adds the same pairs)
+    v += sf_dpp<0x128>(v); v += sf_dpp<0x124>(v); v += sf_dpp<0x122>(v); v += sf_dpp<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ float sf_row16_max(float v) {
+    v = fmaxf(v, sf_dpp<0x128>(v)); v = fmaxf(v, sf_dpp<0x124>(v)); v = fmaxf(v, sf_dpp<0x122>(v)); v = fmaxf(v, sf_dpp<0x121>(v));
+    return v;
+}
+
+// NR rows per pass over the weights (row pairs past the group are skipped: wave-uniform branches), KB k per batch of weight loads
+// (the next batch is in flight while this one's FMAs run).  The one-workgroup-per-CU kernel has the registers for NR = 8, KB = 8 and
+// needs them -- nobody else hides its L2 round trips; with two workgroups per CU (128 registers a wave) NR = KB = 4.  The first batch
+// is requested by the caller BEFORE the barrier that precedes the projection (sf_last_weights0).  The order of a row's sum is the
+// same for every (NR, KB).
+template <int KB>
+__device__ __forceinline__ void sf_last_weights0(const float *__restrict__ wT, int wave, int lane, float4 (&w)[KB]) {
+    const float4 *wp = reinterpret_cast<const float4 *>(wT + (size_t)(32 * (lane >> 3)) * SF_S + 32 * wave + 4 * (lane & 7));
+#pragma unroll
+    for (int j = 0; j < KB; ++j) w[j] = wp[j * 64];
+}
+template <bool RELU, int NR, int KB>
+__device__ __forceinline__ void sf_last_project(const float *__restrict__ src, float *__restrict__ dst, const float *__restrict__ wT,
+                                                const float *__restrict__ bias, int ncap, int wave, int lane, float4 (&w)[KB]) {
+    const int oq = lane & 7, ks = lane >> 3, o0 = 32 * wave + 4 * oq;
+    const float4 *wp = reinterpret_cast<const float4 *>(wT + (size_t)(32 * ks) * SF_S + o0);      // + 64 float4 per k
+    const float4 bv = *reinterpret_cast<const float4 *>(bias + o0);
+    for (int n0 = 0; n0 < ncap; n0 += NR) {
+        const int npair = ((ncap - n0 < NR ? ncap - n0 : NR) + 1) >> 1;       // live row pairs of this pass (wave-uniform)
+        float4 acc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = float4{0.f, 0.f, 0.f, 0.f};
+        const float *xr[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) xr[r] = src + (n0 + r < ncap ? n0 + r : ncap - 1) * SF_LD + 32 * ks;   // an odd count: the last row twice (dropped)
+        if (n0 > 0) {
+#pragma unroll
+            for (int j = 0; j < KB; ++j) w[j] = wp[j * 64];
+        }
+        // a rolled loop: fully unrolled, hipcc hoists all 32 loads and the LDS reads of every batch and spills hundreds of registers
+#pragma unroll 1
+        for (int jb = 0; jb < 32 / KB; ++jb) {
+            float4 wn[KB];
+            const int jn = jb < 32 / KB - 1 ? jb + 1 : 32 / KB - 1;          // (the last batch is requested twice: branch-free)
+#pragma unroll
+            for (int j = 0; j < KB; ++j) wn[j] = wp[(KB * jn + j) * 64];
+#pragma unroll
+            for (int rp = 0; rp < NR / 2; ++rp) {
+                if (rp < npair) {
+#pragma unroll
+                    for (int r = 2 * rp; r < 2 * rp + 2; ++r)
+#pragma unroll
+                        for (int q = 0; q < KB / 4; ++q) {
+                            const float4 xa = *reinterpret_cast<const float4 *>(xr[r] + KB * jb + 4 * q);
+                            const float xs[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float4 wj = w[4 * q + j];
+                                acc[r].x = fmaf(wj.x, xs[j], acc[r].x); acc[r].y = fmaf(wj.y, xs[j], acc[r].y);
+                                acc[r].z = fmaf(wj.z, xs[j], acc[r].z); acc[r].w = fmaf(wj.w, xs[j], acc[r].w);
+                            }
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KB; ++j) w[j] = wn[j];
+        }
+#pragma unroll
+        for (int rp = 0; rp < NR / 2; ++rp) {
+            if (rp < npair) {
+#pragma unroll
+                for (int r = 2 * rp; r < 2 * rp + 2; ++r) {
+                    float4 v;
+                    v.x = sf_rows_sum(acc[r].x + sf_dpp<0x128>(acc[r].x)) + bv.x;
+                    v.y = sf_rows_sum(acc[r].y + sf_dpp<0x128>(acc[r].y)) + bv.y;
+                    v.z = sf_rows_sum(acc[r].z + sf_dpp<0x128>(acc[r].z)) + bv.z;
+                    v.w = sf_rows_sum(acc[r].w + sf_dpp<0x128>(acc[r].w)) + bv.w;
+                    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (ks == 0 && n0 + r < ncap) *reinterpret_cast<float4 *>(dst + (n0 + r) * SF_LD + o0) = v;
+                }
+            }
+        }
+    }
+}
+
+// Attention of node 0 of caption slot `ci` (one wave): e_j = q' . x_j over the graph's nodes, softmax, y = sum_j p_j x_j -> the Q'/Y row
+// of the global node.  Scores: lane = (key fi = lane & 15 of key tile a, feature quarter fq = lane >> 4), 16-byte LDS reads in the
+// conflict-free pattern of the MFMA fragment reads, the four quarters summed by sf_rows_sum.  Values: lane = feature quad, the weight
+// of node j read from the lane that holds it.  NTC = key tiles of the graph.
+template <int NTC, int UNR>
+__device__ __forceinline__ void sf_last_attend(const float *__restrict__ xb, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int lane) {
+    const int fi = lane & 15, fq = lane >> 4;
+    const int nn = m.nn[ci], ws = m.wstart[ci];
+    auto row_of = [&](int n) { n = n < nn ? n : nn - 1; return n == 0 ? ci : ws + n - 1; };
+    const float *qrow = qy + ci * SF_LD + 64 * fq;
+    const float *krow[NTC];
+    float e[NTC];
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) { krow[a] = xb + row_of(16 * a + fi) * SF_LD + 64 * fq; e[a] = 0.f; }
+#pragma unroll UNR
+    for (int j = 0; j < 16; ++j) {       // (rolled: fully unrolled, hipcc hoists all 16 (NTC + 1) LDS reads)
+        const float4 q = *reinterpret_cast<const float4 *>(qrow + 4 * j);
+#pragma unroll
+        for (int a = 0; a < NTC; ++a) {
+            const float4 x = *reinterpret_cast<const float4 *>(krow[a] + 4 * j);
+            e[a] = fmaf(q.x, x.x, e[a]); e[a] = fmaf(q.y, x.y, e[a]); e[a] = fmaf(q.z, x.z, e[a]); e[a] = fmaf(q.w, x.w, e[a]);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) {
+        e[a] = (16 * a + fi < nn) ? sf_rows_sum(e[a]) : -INFINITY;
+        mx = fmaxf(mx, e[a]);
+    }
+    mx = sf_row16_max(mx);
+    float den = 0.f;
+#pragma unroll
+    for (int a = 0; a < NTC; ++a) { e[a] = fast_exp(e[a] - mx); den += e[a]; }       // (exp(-inf) = 0 for the keys past the graph)
+    const float inv = fast_rcp(sf_row16_sum(den));
+    float4 y{0.f, 0.f, 0.f, 0.f};
+#pragma unroll UNR
+    for (int n = 0; n < nn; ++n) {                                                   // (n is wave-uniform)
+        float pv = e[0];
+#pragma unroll
+        for (int a = 1; a < NTC; ++a) pv = (n >> 4) == a ? e[a] : pv;
+        const float pn = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(pv), n & 15)) * inv;
+        const float4 x = *reinterpret_cast<const float4 *>(xb + (n == 0 ? ci : ws + n - 1) * SF_LD + 4 * lane);
+        y.x = fmaf(pn, x.x, y.x); y.y = fmaf(pn, x.y, y.y); y.z = fmaf(pn, x.z, y.z); y.w = fmaf(pn, x.w, y.w);
+    }
+    *reinterpret_cast<float4 *>(qy + ci * SF_LD + 4 * lane) = y;
+}
+template <int ROWS>
+__device__ __forceinline__ void sf_last_attend_n(const float *__restrict__ xb, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int lane) {
+    const int ntc = (m.nn[ci] + 15) >> 4;
+    if constexpr (ROWS > SF_SMALL) {
+        switch (ntc) {
+            case 1: sf_last_attend<1, 4>(xb, qy, m, ci, lane); break;
+            case 2: sf_last_attend<2, 4>(xb, qy, m, ci, lane); break;
+            case 3: sf_last_attend<3, 2>(xb, qy, m, ci, lane); break;
+            default: sf_last_attend<4, 2>(xb, qy, m, ci, lane); break;
+        }
+    } else {
+        if (ntc == 1) sf_last_attend<1, 2>(xb, qy, m, ci, lane);
+        else sf_last_attend<2, 2>(xb, qy, m, ci, lane);
+    }
+}
+
+// P2 dispatch on a caption's key-tile count (a ROWS = 32 group has graphs of at most two tiles: the wider instantiations would only
+// raise the kernel's register count past the 128 that two workgroups per CU leave a wave)
+template <int ROWS>
+__device__ __forceinline__ void sf_attend_e_n(int ntc, unsigned xb_lds, unsigned qy_lds, const SgrGroupMeta &m, int ci, int tile, bool last, int lane,
+                                              float4 *__restrict__ pt) {
+    if constexpr (ROWS > SF_SMALL) {
+        switch (ntc) {
+            case 1: sf_attend_e<1>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+            case 2: sf_attend_e<2>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+            case 3: sf_attend_e<3>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+            default: sf_attend_e<4>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+        }
+    } else {
+        if (ntc == 1) sf_attend_e<1>(xb_lds, qy_lds, m, ci, tile, last, lane, pt);
+        else sf_attend_e<2>(xb_lds, qy_lds, m, ci, tile, last, lane, pt);
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void sf_attend_y_n(int ntc, unsigned xb_lds, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int tile, bool last,
+                                              int half, int lane, const float4 *__restrict__ pt) {
+    if constexpr (ROWS > SF_SMALL) {
+        switch (ntc) {
+            case 1: sf_attend_y<1>(xb_lds, qy, m, ci, tile, last, half, lane, pt); break;
+            case 2: sf_attend_y<2>(xb_lds, qy, m, ci, tile, last, half, lane, pt); break;
+            case 3: sf_attend_y<3>(xb_lds, qy, m, ci, tile, last, half, lane, pt); break;
+            default: sf_attend_y<4>(xb_lds, qy, m, ci, tile, last, half, lane, pt); break;
+        }
+    } else {
+        if (ntc == 1) sf_attend_y<1>(xb_lds, qy, m, ci, tile, last, half, lane, pt);
+        else sf_attend_y<2>(xb_lds, qy, m, ci, tile, last, half, lane, pt);
+    }
+}
+
+template <int ROWS, int WG_PER_CU>
+__global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_kernel(SgrFusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char sf_smem[];
     float *xb = reinterpret_cast<float *>(sf_smem);
-    float *qy = xb + SF_ROWS * SF_LD;
-    SgrGroupMeta &m = *reinterpret_cast<SgrGroupMeta *>(qy + SF_ROWS * SF_LD);
-    float4 *ptile = reinterpret_cast<float4 *>(reinterpret_cast<char *>(&m) + sizeof(SgrGroupMeta));      // [SF_PTILES][64] float4
+    float *qy = xb + ROWS * SF_LD;
+    SgrGroupMeta &m = *reinterpret_cast<SgrGroupMeta *>(qy + ROWS * SF_LD);
+    float4 *ptile = reinterpret_cast<float4 *>(reinterpret_cast<char *>(&m) + 2 * sizeof(SgrGroupMeta));      // [sf_ptiles(ROWS)][64] float4
     const unsigned xb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)sf_smem;
-    const unsigned qy_lds = xb_lds + (unsigned)(SF_ROWS * SF_LD * sizeof(float));
+    const unsigned qy_lds = xb_lds + (unsigned)(ROWS * SF_LD * sizeof(float));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t grp = blockIdx.x / g.nb, ii = blockIdx.x % g.nb;      // consecutive workgroups: one group, the images of the block
-    unsigned long long tstamp[16];
+    if ((int64_t)blockIdx.x >= (int64_t)g.gcount[0] * g.nb) return;      // (the grid is sized for all the groups of the call)
+    const int64_t grp = g.glist[blockIdx.x / g.nb], ii = blockIdx.x % g.nb;      // consecutive workgroups: one group, the images of the block
     int nstamp = 0;
-#define SF_STAMP() { if (g.trace && nstamp < 16) tstamp[nstamp++] = __builtin_amdgcn_s_memtime(); }
+    // (straight to memory: a local array indexed by a run-time count would live in scratch, inside loops with hand-counted asm loads)
+#define SF_STAMP() { if (g.trace && tid == 0 && nstamp < 16) g.trace[(size_t)blockIdx.x * 20 + 2 + nstamp++] = __builtin_amdgcn_s_memtime(); }
     SF_STAMP()
     if (tid < (int)(sizeof(SgrGroupMeta) / 4)) reinterpret_cast<int32_t *>(&m)[tid] = reinterpret_cast<const int32_t *>(g.meta + grp)[tid];
     __syncthreads();
@@ -430,9 +709,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g
     }
     // ---- node rows -> LDS (one 1 KB row per wave-instruction); rows past the group are zeroed (their products are never read)
     {
-        float4 v[SF_ROWS / SF_WAVES];
+        float4 v[ROWS / SF_WAVES];
 #pragma unroll
-        for (int k = 0; k < SF_ROWS / SF_WAVES; ++k) {
+        for (int k = 0; k < ROWS / SF_WAVES; ++k) {
             const int r = wave + SF_WAVES * k;
             v[k] = float4{0.f, 0.f, 0.f, 0.f};
             if (r < nrows) {
@@ -441,31 +720,25 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g
             }
         }
 #pragma unroll
-        for (int k = 0; k < SF_ROWS / SF_WAVES; ++k)
+        for (int k = 0; k < ROWS / SF_WAVES; ++k)
             *reinterpret_cast<float4 *>(xb + (wave + SF_WAVES * k) * SF_LD + 4 * lane) = v[k];
     }
     __syncthreads();
     SF_STAMP()
     const int ng_all = (nrows + 15) >> 4;
-    for (int k = 0; k < g.steps; ++k) {
-        const bool last = (k == g.steps - 1);
-        sf_project_n<false>(last ? 1 : ng_all, xb_lds, qy, g.wq[k], g.vq[k], wave, lane, fa0, fa1, g.wg[k]);
+    for (int k = 0; k + 1 < g.steps; ++k) {
+        sf_project_n<false, ROWS>(ng_all, xb_lds, qy, g.wq[k], g.vq[k], wave, lane, fa0, fa1, g.wg[k]);
         __syncthreads();
         SF_STAMP()
         // P2.  Units are sorted by size; unit u goes to wave (u & 7) for u & 7 < 4 and to wave 11 - (u & 7) otherwise (a snake
         // over the four SIMDs: waves w and w + 4 share one, and share its matrix pipe).
-        const int nu = last ? ncap : m.nunit;
+        const int nu = m.nunit;
         for (int u = 0; u < nu; ++u) {
             const int wv = (u & 7) < 4 ? (u & 7) : 11 - (u & 7);
             if (wv != wave) continue;
-            const int ci = last ? u : m.unit_cap[u], tile = last ? 0 : m.unit_tile[u];
-            float4 *pt = ptile + (size_t)(last ? m.cap_poff[u] : m.unit_poff[u]) * 64;
-            switch ((m.nn[ci] + 15) >> 4) {
-                case 1: sf_attend_e<1>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-                case 2: sf_attend_e<2>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-                case 3: sf_attend_e<3>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-                default: sf_attend_e<4>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-            }
+            const int ci = m.unit_cap[u], tile = m.unit_tile[u];
+            float4 *pt = ptile + (size_t)m.unit_poff[u] * 64;
+            sf_attend_e_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy_lds, m, ci, tile, false, lane, pt);
         }
         __syncthreads();
         SF_STAMP()
@@ -473,21 +746,31 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g
         // halves of units two places apart)
         for (int t = wave; t < 2 * nu; t += SF_WAVES) {
             const int u = t >> 1, dq = t & 1;
-            const int ci = last ? u : m.unit_cap[u], tile = last ? 0 : m.unit_tile[u];
-            const float4 *pt = ptile + (size_t)(last ? m.cap_poff[u] : m.unit_poff[u]) * 64;
-            switch ((m.nn[ci] + 15) >> 4) {
-                case 1: sf_attend_y<1>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
-                case 2: sf_attend_y<2>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
-                case 3: sf_attend_y<3>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
-                default: sf_attend_y<4>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
-            }
+            const int ci = m.unit_cap[u], tile = m.unit_tile[u];
+            const float4 *pt = ptile + (size_t)m.unit_poff[u] * 64;
+            sf_attend_y_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy, m, ci, tile, false, dq, lane, pt);
         }
         __syncthreads();
         SF_STAMP()
-        sf_project_n<true>(last ? 1 : ng_all, qy_lds, xb, g.wg[k], g.bg[k], wave, lane, fa0, fa1, g.wq[last ? k : k + 1]);
+        sf_project_n<true, ROWS>(ng_all, qy_lds, xb, g.wg[k], g.bg[k], wave, lane, fa0, fa1, g.wq[k + 2 < g.steps ? k + 1 : 0]);
         __syncthreads();
         SF_STAMP()
     }
+    // ---- the last step: node 0 of every graph only, on the vector ALU (see sf_last_project)
+    constexpr int LNR = ROWS > SF_SMALL ? 8 : 4, LKB = ROWS > SF_SMALL ? 8 : 4;
+    float4 lw[LKB];
+    sf_last_weights0<LKB>(g.wqT_last, wave, lane, lw);
+    sf_last_project<false, LNR, LKB>(xb, qy, g.wqT_last, g.vq[g.steps - 1], ncap, wave, lane, lw);
+    sf_last_weights0<LKB>(g.wgT_last, wave, lane, lw);      // (in flight through the barrier and the attention)
+    __syncthreads();
+    SF_STAMP()
+    for (int ci = wave; ci < ncap; ci += SF_WAVES) sf_last_attend_n<ROWS>(xb, qy, m, ci, lane);
+    __syncthreads();
+    SF_STAMP()
+    SF_STAMP()
+    sf_last_project<true, LNR, LKB>(qy, xb, g.wgT_last, g.bg[g.steps - 1], ncap, wave, lane, lw);
+    __syncthreads();
+    SF_STAMP()
     // ---- sim = sigmoid(sim_eval_w . x_0 + b)  (Fusionmodule.py:443-444)
     const float4 ew = *reinterpret_cast<const float4 *>(g.eval_w + 4 * lane);
     for (int ci = wave; ci < ncap; ci += SF_WAVES) {
@@ -503,7 +786,6 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g
         unsigned long long *t = g.trace + (size_t)blockIdx.x * 20;
         t[0] = ((unsigned long long)xcc << 32) | hw;
         t[1] = ((unsigned long long)nrows << 32) | (unsigned)(m.nunit << 8) | (unsigned)ncap;
-        for (int q = 0; q < nstamp; ++q) t[2 + q] = tstamp[q];
     }
 #undef SF_STAMP
 }
@@ -515,29 +797,31 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_kernel(SgrFusedArgs g
 // current item -- instead of a cold load phase (5-6 k cycles at the ~11 B/clk a CU streams from HBM) and a launch gap (2 k) per item
 // (SGR 1k x 5k: 763 -> 753 ms).
 // The next item's group record is fetched by waves 6 and 7 during the first step's score phase.
-__global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_persistent_kernel(SgrFusedArgs g) {
+template <int ROWS, int WG_PER_CU>
+__global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_persistent_kernel(SgrFusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char sf_smem[];
     float *xb = reinterpret_cast<float *>(sf_smem);
-    float *qy = xb + SF_ROWS * SF_LD;
-    SgrGroupMeta *m2 = reinterpret_cast<SgrGroupMeta *>(qy + SF_ROWS * SF_LD);      // two records: current / next item
+    float *qy = xb + ROWS * SF_LD;
+    SgrGroupMeta *m2 = reinterpret_cast<SgrGroupMeta *>(qy + ROWS * SF_LD);      // two records: current / next item
     float4 *ptile = reinterpret_cast<float4 *>(reinterpret_cast<char *>(m2) + 2 * sizeof(SgrGroupMeta));
     const unsigned xb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char *)sf_smem;
-    const unsigned qy_lds = xb_lds + (unsigned)(SF_ROWS * SF_LD * sizeof(float));
+    const unsigned qy_lds = xb_lds + (unsigned)(ROWS * SF_LD * sizeof(float));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t total = g.n_groups * g.nb;
+    const int64_t total = (int64_t)g.gcount[0] * g.nb;        // this class's groups x the images of the block (device-side count)
     int64_t item = blockIdx.x;
     if (item >= total) return;
     int cur = 0;
     // ---- the first item: group record and node rows the plain way
-    if (tid < (int)(sizeof(SgrGroupMeta) / 4)) reinterpret_cast<int32_t *>(&m2[0])[tid] = reinterpret_cast<const int32_t *>(g.meta + item / g.nb)[tid];
+    if (tid < (int)(sizeof(SgrGroupMeta) / 4))
+        reinterpret_cast<int32_t *>(&m2[0])[tid] = reinterpret_cast<const int32_t *>(g.meta + g.glist[item / g.nb])[tid];
     __syncthreads();
     {
         const SgrGroupMeta &m = m2[0];
         const int64_t ii = item % g.nb;
-        float4 v[SF_ROWS / SF_WAVES];
+        float4 v[ROWS / SF_WAVES];
 #pragma unroll
-        for (int k = 0; k < SF_ROWS / SF_WAVES; ++k) {
+        for (int k = 0; k < ROWS / SF_WAVES; ++k) {
             const int r = wave + SF_WAVES * k;
             v[k] = float4{0.f, 0.f, 0.f, 0.f};
             if (r < m.nrows) {
@@ -546,7 +830,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_persistent_kernel(Sgr
             }
         }
 #pragma unroll
-        for (int k = 0; k < SF_ROWS / SF_WAVES; ++k)
+        for (int k = 0; k < ROWS / SF_WAVES; ++k)
             *reinterpret_cast<float4 *>(xb + (wave + SF_WAVES * k) * SF_LD + 4 * lane) = v[k];
     }
     const size_t wfo = (size_t)(2 * wave) * 16 * 64 + lane;
@@ -566,63 +850,56 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_persistent_kernel(Sgr
         const int ng_all = (nrows + 15) >> 4;
         const bool meta_wave = has_next && wave >= 6;
         if (meta_wave && g.steps == 1)      // a single step is also the last one: the record must be there before its attention phase
-            reinterpret_cast<int32_t *>(&m2[cur ^ 1])[tid - 384] = reinterpret_cast<const int32_t *>(g.meta + nxt / g.nb)[tid - 384];
-        // a step in two halves, so that the last step can request the next item's rows between them in straight-line code (inside the
-        // step loop hipcc merged "loaded | not loaded" right behind the loads -- with a vmcnt(0))
-        auto step_project_q = [&](int k, bool last) {
-            sf_project_n<false>((last || ncap == 0) ? 1 : ng_all, xb_lds, qy, g.wq[k], g.vq[k], wave, lane, fa0, fa1, g.wg[k]);
+            reinterpret_cast<int32_t *>(&m2[cur ^ 1])[tid - 384] = reinterpret_cast<const int32_t *>(g.meta + g.glist[nxt / g.nb])[tid - 384];
+        constexpr int LNR = ROWS > SF_SMALL ? 8 : 4, LKB = ROWS > SF_SMALL ? 8 : 4;
+        float4 lw[LKB];          // first batch of the last step's weights: requested ahead of the barrier that precedes their projection
+        constexpr bool early = ROWS > SF_SMALL;      // (two workgroups per CU: no registers to spare, and the other workgroup hides the trip)
+        if (early && g.steps == 1) sf_last_weights0<LKB>(g.wqT_last, wave, lane, lw);
+        for (int k = 0; k + 1 < g.steps; ++k) {
+            sf_project_n<false, ROWS>(ncap == 0 ? 1 : ng_all, xb_lds, qy, g.wq[k], g.vq[k], wave, lane, fa0, fa1, g.wg[k]);
             __syncthreads();
             // the next item's group record: one dword per lane of waves 6 and 7, fetched while the other waves run the first step's
             // score units (the unit map gives waves 6 and 7 the smallest units, or none)
-            if (k == 0 && meta_wave && g.steps > 1)
-                reinterpret_cast<int32_t *>(&m2[cur ^ 1])[tid - 384] = reinterpret_cast<const int32_t *>(g.meta + nxt / g.nb)[tid - 384];
-        };
-        auto step_attend_project_g = [&](int k, bool last) {
-            const int nu = last ? ncap : m.nunit;
+            if (k == 0 && meta_wave)
+                reinterpret_cast<int32_t *>(&m2[cur ^ 1])[tid - 384] = reinterpret_cast<const int32_t *>(g.meta + g.glist[nxt / g.nb])[tid - 384];
+            const int nu = m.nunit;
             for (int u = 0; u < nu; ++u) {
                 const int wv = (u & 7) < 4 ? (u & 7) : 11 - (u & 7);
                 if (wv != wave) continue;
-                const int ci = last ? u : m.unit_cap[u], tile = last ? 0 : m.unit_tile[u];
-                float4 *pt = ptile + (size_t)(last ? m.cap_poff[u] : m.unit_poff[u]) * 64;
-                switch ((m.nn[ci] + 15) >> 4) {
-                    case 1: sf_attend_e<1>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-                    case 2: sf_attend_e<2>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-                    case 3: sf_attend_e<3>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-                    default: sf_attend_e<4>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-                }
+                const int ci = m.unit_cap[u], tile = m.unit_tile[u];
+                float4 *pt = ptile + (size_t)m.unit_poff[u] * 64;
+                sf_attend_e_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy_lds, m, ci, tile, false, lane, pt);
             }
             __syncthreads();
             for (int t = wave; t < 2 * nu; t += SF_WAVES) {
                 const int u = t >> 1, dq = t & 1;
-                const int ci = last ? u : m.unit_cap[u], tile = last ? 0 : m.unit_tile[u];
-                const float4 *pt = ptile + (size_t)(last ? m.cap_poff[u] : m.unit_poff[u]) * 64;
-                switch ((m.nn[ci] + 15) >> 4) {
-                    case 1: sf_attend_y<1>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
-                    case 2: sf_attend_y<2>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
-                    case 3: sf_attend_y<3>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
-                    default: sf_attend_y<4>(xb_lds, qy, m, ci, tile, last, dq, lane, pt); break;
-                }
+                const int ci = m.unit_cap[u], tile = m.unit_tile[u];
+                const float4 *pt = ptile + (size_t)m.unit_poff[u] * 64;
+                sf_attend_y_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy, m, ci, tile, false, dq, lane, pt);
             }
             __syncthreads();
-            // (the last projection hands over the first fragments of the NEXT item's first projection)
-            sf_project_n<true>((last || ncap == 0) ? 1 : ng_all, qy_lds, xb, g.wg[k], g.bg[k], wave, lane, fa0, fa1, g.wq[last ? 0 : k + 1]);
+            // (the last MFMA projection of the item hands over the first fragments of the NEXT item's first projection)
+            sf_project_n<true, ROWS>(ncap == 0 ? 1 : ng_all, qy_lds, xb, g.wg[k], g.bg[k], wave, lane, fa0, fa1, g.wq[k + 2 < g.steps ? k + 1 : 0]);
+            if (early && k + 2 == g.steps) sf_last_weights0<LKB>(g.wqT_last, wave, lane, lw);
             __syncthreads();
-        };
-        for (int k = 0; k + 1 < g.steps; ++k) {
-            step_project_q(k, false);
-            step_attend_project_g(k, false);
         }
-        step_project_q(g.steps - 1, true);
-        f32x4 pre[SF_ROWS / SF_WAVES];
+        if (!early) sf_last_weights0<LKB>(g.wqT_last, wave, lane, lw);
+        // ---- the last step: node 0 of every graph only, on the vector ALU (see sf_last_project)
+        sf_last_project<false, LNR, LKB>(xb, qy, g.wqT_last, g.vq[g.steps - 1], ncap, wave, lane, lw);
+        if (early) sf_last_weights0<LKB>(g.wgT_last, wave, lane, lw);      // (in flight through the barrier and the attention)
+        __syncthreads();
+        for (int ci = wave; ci < ncap; ci += SF_WAVES) sf_last_attend_n<ROWS>(xb, qy, m, ci, lane);
+        __syncthreads();
+        f32x4 pre[ROWS / SF_WAVES];
         if (has_next) {
-            // node rows of the next item -> registers, in flight during the whole attention phase below.  Branch-free (a conditional
+            // node rows of the next item -> registers, in flight during the rest of the last step.  Branch-free (a conditional
             // load makes hipcc merge "loaded | zero" right here): rows past the next group re-read its last row and are zeroed when
             // they are stored.  Loads hipcc counts: their registers are safe.
             const SgrGroupMeta &mn = m2[cur ^ 1];
             const int64_t iin = nxt % g.nb;
             const int nrn = mn.nrows > 0 ? mn.nrows : 1;
 #pragma unroll
-            for (int q = 0; q < SF_ROWS / SF_WAVES; ++q) {
+            for (int q = 0; q < ROWS / SF_WAVES; ++q) {
                 int r = wave + SF_WAVES * q;
                 r = r < nrn ? r : nrn - 1;
                 const float *src = r < mn.ncap ? g.xglo + (iin * g.Nc + mn.row_src[r]) * SF_S : g.xloc + (iin * g.ncols + mn.row_src[r]) * SF_S;
@@ -630,7 +907,9 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_persistent_kernel(Sgr
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        step_attend_project_g(g.steps - 1, true);
+        if (!early) sf_last_weights0<LKB>(g.wgT_last, wave, lane, lw);
+        sf_last_project<true, LNR, LKB>(qy, xb, g.wgT_last, g.bg[g.steps - 1], ncap, wave, lane, lw);
+        __syncthreads();
         const float4 ew = *reinterpret_cast<const float4 *>(g.eval_w + 4 * lane);
         for (int ci = wave; ci < ncap; ci += SF_WAVES) {
             const float4 x = *reinterpret_cast<const float4 *>(xb + ci * SF_LD + 4 * lane);
@@ -641,7 +920,7 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_persistent_kernel(Sgr
         if (!has_next) break;
         __syncthreads();                                        // every wave is done with the X buffer of this item
 #pragma unroll
-        for (int q = 0; q < SF_ROWS / SF_WAVES; ++q) {
+        for (int q = 0; q < ROWS / SF_WAVES; ++q) {
             const bool live = wave + SF_WAVES * q < m2[cur ^ 1].nrows;
             *reinterpret_cast<f32x4 *>(xb + (wave + SF_WAVES * q) * SF_LD + 4 * lane) = live ? pre[q] : f32x4{0.f, 0.f, 0.f, 0.f};   // (landed long ago)
         }
@@ -651,94 +930,196 @@ __global__ __launch_bounds__(SF_THREADS, 1) void sgr_fused_persistent_kernel(Sgr
     }
 }
 
-size_t sgr_fused_workspace_bytes(int64_t n_groups, int sgr_step) {
-    return ((size_t)n_groups * sizeof(SgrGroupMeta) + 255) / 256 * 256 + (size_t)sgr_step * 2 * SF_S * SF_S * 4 + 256;
+// workspace: [group records][class of every group][class lists: 2 x n_groups][counts][bad-caption marks: n_caps][packed weights]
+struct SgrWs {
+    SgrGroupMeta *meta;
+    int8_t *cls;
+    int32_t *glist, *gcount, *cap_bad;
+    float4 *frag;
+    float *wT;                   // [2][256][256]: the last step's two weights, transposed
+    size_t bytes;
+};
+static SgrWs sgr_carve(void *ws, int64_t n_groups, int64_t n_caps, int sgr_step) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    char *p = static_cast<char *>(ws);
+    SgrWs w;
+    w.meta = reinterpret_cast<SgrGroupMeta *>(p); p += al((size_t)n_groups * sizeof(SgrGroupMeta));
+    w.cls = reinterpret_cast<int8_t *>(p); p += al((size_t)n_groups);
+    w.glist = reinterpret_cast<int32_t *>(p); p += al((size_t)2 * n_groups * 4);
+    w.gcount = reinterpret_cast<int32_t *>(p); p += 256;
+    w.cap_bad = reinterpret_cast<int32_t *>(p); p += al((size_t)n_caps * 4);
+    w.frag = reinterpret_cast<float4 *>(p); p += (size_t)sgr_step * 2 * SF_S * SF_S * 4;
+    w.wT = reinterpret_cast<float *>(p); p += (size_t)2 * SF_S * SF_S * 4;
+    w.bytes = (size_t)(p - static_cast<char *>(ws)) + 256;
+    return w;
 }
+size_t sgr_fused_workspace_bytes(int64_t n_groups, int64_t n_caps, int sgr_step) { return sgr_carve(nullptr, n_groups, n_caps, sgr_step).bytes; }
 
-// One-time preparation per itr_sgraf_scores call: group records + fragment-ordered weights.
-int sgr_fused_prepare(const int32_t *grp_begin, const int32_t *grp_order, int64_t n_groups, const int32_t *cap_len, const int32_t *cap_col,
-                      const float *const *wq, const float *const *wg, int sgr_step, void *ws, int *bad_flag, hipStream_t st) {
-    SgrGroupMeta *meta = static_cast<SgrGroupMeta *>(ws);
-    float4 *frag = reinterpret_cast<float4 *>(static_cast<char *>(ws) + ((size_t)n_groups * sizeof(SgrGroupMeta) + 255) / 256 * 256);
+// One-time preparation per itr_sgraf_scores call: group records, the two class lists, fragment-ordered weights.
+int sgr_fused_prepare(const int32_t *grp_begin, const int32_t *grp_order, int64_t n_groups, int64_t n_caps, const int32_t *cap_len,
+                      const int32_t *cap_col, const float *const *wq, const float *const *wg, int sgr_step, void *ws, int *bad_flag, hipStream_t st) {
+    const SgrWs w = sgr_carve(ws, n_groups, n_caps, sgr_step);
+    ITR_CHECK_HIP(hipMemsetAsync(w.cap_bad, 0, (size_t)n_caps * 4, st));
     hipLaunchKernelGGL(sgr_group_meta_kernel, dim3((unsigned)ceil_div(n_groups, 256)), dim3(256), 0, st, grp_begin, grp_order, cap_len, cap_col,
-                       n_groups, meta, bad_flag);
+                       n_groups, w.meta, bad_flag, w.cls, w.cap_bad, n_caps);
     ITR_CHECK_LAUNCH("sgr group meta");
+    hipLaunchKernelGGL(sgr_group_classify_kernel, dim3(1), dim3(1024), 0, st, w.cls, n_groups, w.glist, w.gcount);
+    ITR_CHECK_LAUNCH("sgr group classes");
     for (int k = 0; k < sgr_step; ++k) {
-        hipLaunchKernelGGL(sgr_pack_weight_kernel, dim3(64), dim3(256), 0, st, wq[k], frag + (size_t)(2 * k) * SF_S * SF_S / 4);
-        hipLaunchKernelGGL(sgr_pack_weight_kernel, dim3(64), dim3(256), 0, st, wg[k], frag + (size_t)(2 * k + 1) * SF_S * SF_S / 4);
+        hipLaunchKernelGGL(sgr_pack_weight_kernel, dim3(64), dim3(256), 0, st, wq[k], w.frag + (size_t)(2 * k) * SF_S * SF_S / 4);
+        hipLaunchKernelGGL(sgr_pack_weight_kernel, dim3(64), dim3(256), 0, st, wg[k], w.frag + (size_t)(2 * k + 1) * SF_S * SF_S / 4);
     }
     ITR_CHECK_LAUNCH("sgr pack weights");
+    hipLaunchKernelGGL(sgr_transpose_weight_kernel, dim3(SF_S * SF_S / 256), dim3(256), 0, st, wq[sgr_step - 1], w.wT);
+    hipLaunchKernelGGL(sgr_transpose_weight_kernel, dim3(SF_S * SF_S / 256), dim3(256), 0, st, wg[sgr_step - 1], w.wT + SF_S * SF_S);
+    ITR_CHECK_LAUNCH("sgr transpose weights");
     return ITR_OK;
 }
 
-int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t nb, int64_t Nc, int64_t ncols,
-                     const float *const *vq, const float *const *bg, int sgr_step, const float *eval_w, const float *eval_b, float *S,
-                     int64_t ldS, int64_t img_index0, hipStream_t st) {
-    static bool attr_done = false;   // idempotent: racing callers set the same value
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sgr_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)SF_LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(sgr_fused_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)SF_LDS_BYTES);
-        if (e != hipSuccess) {
-            set_error("sgr_fused: cannot reserve %zu B of LDS: %s", SF_LDS_BYTES, hipGetErrorString(e));
-            return ITR_ERR_HIP;
-        }
-        attr_done = true;
+// After the last block of images: NaN into the score columns of the captions whose group was refused (a wrong hand-made plan).
+int sgr_fused_finish(void *ws, int64_t n_groups, int64_t n_caps, int sgr_step, int64_t Ni, float *S, int64_t ldS, hipStream_t st) {
+    const SgrWs w = sgr_carve(ws, n_groups, n_caps, sgr_step);
+    if (n_caps == 0 || Ni == 0) return ITR_OK;
+    hipLaunchKernelGGL(sgr_poison_kernel, dim3((unsigned)ceil_div(n_caps, 256)), dim3(256), 0, st, w.cap_bad, n_caps, Ni, S, ldS);
+    ITR_CHECK_LAUNCH("sgr refused groups");
+    return ITR_OK;
+}
+
+int allow_dynamic_lds(const void *kernel, size_t bytes);      // scan_train.hip: once per (kernel, device), under a mutex
+
+static int sgr_cu_count(int64_t *cus) {
+    static int cus_of[64] = {};
+    int dev = 0;
+    ITR_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !cus_of[dev]) {            // (idempotent: racing callers store the same value)
+        hipDeviceProp_t prop;
+        ITR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        cus_of[dev] = prop.multiProcessorCount;
     }
-    if (nb == 0 || n_groups == 0) return ITR_OK;
-    SgrFusedArgs g;
-    memset(&g, 0, sizeof(g));
-    g.xloc = xloc; g.xglo = xglo;
-    g.meta = static_cast<const SgrGroupMeta *>(ws);
-    const float4 *frag = reinterpret_cast<const float4 *>(static_cast<char *>(ws) + ((size_t)n_groups * sizeof(SgrGroupMeta) + 255) / 256 * 256);
-    g.n_groups = n_groups; g.nb = nb; g.Nc = Nc; g.ncols = ncols;
-    for (int k = 0; k < sgr_step; ++k) {
-        g.wq[k] = frag + (size_t)(2 * k) * SF_S * SF_S / 4;
-        g.wg[k] = frag + (size_t)(2 * k + 1) * SF_S * SF_S / 4;
-        g.vq[k] = vq[k];
-        g.bg[k] = bg[k];
-    }
-    g.steps = sgr_step;
-    g.eval_w = eval_w; g.eval_b = eval_b; g.S = S; g.ldS = ldS; g.img_index0 = img_index0;
-    const int64_t grid = n_groups * nb;
+    *cus = (dev >= 0 && dev < 64 && cus_of[dev] > 0) ? cus_of[dev] : 256;
+    return ITR_OK;
+}
+
+// One class of groups.  ROWS = 32: two workgroups per CU; ROWS = 64: one.
+template <int ROWS, int WG_PER_CU>
+static int sgr_fused_launch_class(SgrFusedArgs g, int cls_index, int64_t n_groups, const SgrWs &w, bool persistent, const char *trace_path, hipStream_t st) {
+    constexpr size_t lds = sf_lds_bytes(ROWS);
+    int rc = allow_dynamic_lds(reinterpret_cast<const void *>(sgr_fused_kernel<ROWS, WG_PER_CU>), lds);
+    if (rc == ITR_OK) rc = allow_dynamic_lds(reinterpret_cast<const void *>(sgr_fused_persistent_kernel<ROWS, WG_PER_CU>), lds);
+    if (rc != ITR_OK) return rc;
+    g.glist = w.glist + (cls_index ? n_groups : 0);
+    g.gcount = w.gcount + cls_index;
+    const int64_t grid = n_groups * g.nb;                 // upper bound: the class's own count lives on the device
     ITR_REQUIRE(grid < (1ll << 31), "sgr_fused: grid too large");
-    // Debug only (tools/sgr_trace.py): ITR_SGR_TRACE=<file> makes every launch synchronous and rewrites <file> with one record per
-    // workgroup (hardware id, group shape, s_memtime after every phase).
-    static const char *trace_path = getenv("ITR_SGR_TRACE");
-    if (trace_path && *trace_path) {
+    if (trace_path) {
+        // Debug only (tools/sgr_trace.py): ITR_SGR_TRACE=<file> makes every launch synchronous and rewrites <file>.<class> with one record
+        // per workgroup (hardware id, group shape, s_memtime after every phase).
         const size_t bytes = (size_t)grid * 20 * sizeof(unsigned long long);
         ITR_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&g.trace), bytes));
         ITR_CHECK_HIP(hipMemsetAsync(g.trace, 0, bytes, st));
-        hipLaunchKernelGGL(sgr_fused_kernel, dim3((unsigned)grid), dim3(SF_THREADS), SF_LDS_BYTES, st, g);
+        hipLaunchKernelGGL((sgr_fused_kernel<ROWS, WG_PER_CU>), dim3((unsigned)grid), dim3(SF_THREADS), lds, st, g);
         ITR_CHECK_LAUNCH("sgr_fused");
         ITR_CHECK_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> host((size_t)grid * 20);
         ITR_CHECK_HIP(hipMemcpy(host.data(), g.trace, bytes, hipMemcpyDeviceToHost));
         ITR_CHECK_HIP(hipFree(g.trace));
-        if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 1, bytes, f); fclose(f); }
+        char path[1024];
+        snprintf(path, sizeof(path), "%s.%d", trace_path, ROWS);
+        if (FILE *f = fopen(path, "wb")) { fwrite(host.data(), 1, bytes, f); fclose(f); }
         return ITR_OK;
     }
-    const char *pers_env = getenv("ITR_SGR_PERSISTENT");      // (read per call: the tests run both forms in one process)
-    const bool persistent = !(pers_env && atoi(pers_env) == 0);
     if (persistent) {
-        static int cus_of[16] = {};
-        int dev = 0;
-        ITR_CHECK_HIP(hipGetDevice(&dev));
-        if (dev >= 0 && dev < 16 && !cus_of[dev]) {            // (idempotent: racing callers store the same value)
-            hipDeviceProp_t prop;
-            ITR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-            cus_of[dev] = prop.multiProcessorCount;
-        }
-        const int64_t cus = (dev >= 0 && dev < 16 && cus_of[dev] > 0) ? cus_of[dev] : 256;
-        hipLaunchKernelGGL(sgr_fused_persistent_kernel, dim3((unsigned)(grid < cus ? grid : cus)), dim3(SF_THREADS), SF_LDS_BYTES, st, g);
+        int64_t cus = 256;
+        rc = sgr_cu_count(&cus);
+        if (rc != ITR_OK) return rc;
+        const int64_t resident = cus * WG_PER_CU;
+        hipLaunchKernelGGL((sgr_fused_persistent_kernel<ROWS, WG_PER_CU>), dim3((unsigned)(grid < resident ? grid : resident)), dim3(SF_THREADS), lds, st, g);
         ITR_CHECK_LAUNCH("sgr_fused (persistent)");
         return ITR_OK;
     }
-    hipLaunchKernelGGL(sgr_fused_kernel, dim3((unsigned)grid), dim3(SF_THREADS), SF_LDS_BYTES, st, g);
+    hipLaunchKernelGGL((sgr_fused_kernel<ROWS, WG_PER_CU>), dim3((unsigned)grid), dim3(SF_THREADS), lds, st, g);
     ITR_CHECK_LAUNCH("sgr_fused");
     return ITR_OK;
 }
 
+int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t n_caps, int64_t nb, int64_t Nc, int64_t ncols,
+                     const float *const *vq, const float *const *bg, int sgr_step, const float *eval_w, const float *eval_b, float *S,
+                     int64_t ldS, int64_t img_index0, int max_len, hipStream_t st) {
+    if (nb == 0 || n_groups == 0) return ITR_OK;
+    const SgrWs w = sgr_carve(ws, n_groups, n_caps, sgr_step);
+    SgrFusedArgs g;
+    memset(&g, 0, sizeof(g));
+    g.xloc = xloc; g.xglo = xglo;
+    g.meta = w.meta;
+    g.n_groups = n_groups; g.nb = nb; g.Nc = Nc; g.ncols = ncols;
+    for (int k = 0; k < sgr_step; ++k) {
+        g.wq[k] = w.frag + (size_t)(2 * k) * SF_S * SF_S / 4;
+        g.wg[k] = w.frag + (size_t)(2 * k + 1) * SF_S * SF_S / 4;
+        g.vq[k] = vq[k];
+        g.bg[k] = bg[k];
+    }
+    g.steps = sgr_step;
+    g.wqT_last = w.wT; g.wgT_last = w.wT + SF_S * SF_S;
+    g.eval_w = eval_w; g.eval_b = eval_b; g.S = S; g.ldS = ldS; g.img_index0 = img_index0;
+    static const char *trace_env = getenv("ITR_SGR_TRACE");
+    const char *trace_path = (trace_env && *trace_env) ? trace_env : nullptr;
+    const char *pers_env = getenv("ITR_SGR_PERSISTENT");      // (read per call: the tests run both forms in one process)
+    const bool persistent = !(pers_env && atoi(pers_env) == 0);
+    // the large class first (it is empty for every caption set of at most 31 words when the plan comes from itr_sgr_plan_node_groups:
+    // its workgroups read a zero count and leave), then the small one
+    int rc = sgr_fused_launch_class<SF_ROWS, 1>(g, 1, n_groups, w, persistent, trace_path, st);
+    if (rc != ITR_OK) return rc;
+    (void)max_len;
+    return sgr_fused_launch_class<SF_SMALL, 2>(g, 0, n_groups, w, persistent, trace_path, st);
+}
+
 }  // namespace itr
+
+// Pure CPU.  The planner of SGR's fused graph steps: whole captions are bin-packed (best fit decreasing, like itr_scan_plan_tiles) by
+// NODE count = words + 1 into groups of at most 16 captions -- captions of at most 31 words into groups of <= 32 node rows (two
+// workgroups per CU), longer ones (<= 63 words) into groups of <= 64.  group_begin_host[n_groups + 1] indexes group_order_host[Nc].
+extern "C" int itr_sgr_plan_node_groups(const int32_t *cap_len_host, int64_t Nc, int32_t *group_begin_host, int32_t *group_order_host,
+                                        int64_t *n_groups) {
+    using namespace itr;
+    ITR_REQUIRE(cap_len_host && group_begin_host && group_order_host && n_groups, "itr_sgr_plan_node_groups: null pointer");
+    ITR_REQUIRE(Nc >= 0 && Nc < 0x7fffffffLL, "itr_sgr_plan_node_groups: bad caption count");
+    struct Bin { int32_t n; int32_t cap[SF_MAXCAP]; };
+    std::vector<Bin> bins;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int cap_rows = pass == 0 ? SF_SMALL : SF_ROWS, lo = pass == 0 ? 2 : SF_SMALL + 1;
+        std::vector<std::vector<int32_t>> by_n(cap_rows + 1);
+        for (int64_t c = 0; c < Nc; ++c) {
+            const int n = cap_len_host[c] + 1;
+            ITR_REQUIRE(n >= 2, "itr_sgr_plan_node_groups: caption %lld has length %d (< 1)", (long long)c, n - 1);
+            ITR_UNSUPPORTED(n > SF_ROWS, "itr_sgr_plan_node_groups: caption %lld has %d words; the fused graph steps hold <= %d", (long long)c,
+                            n - 1, SF_ROWS - 1);
+            if (n >= lo && n <= cap_rows) by_n[n].push_back((int32_t)c);
+        }
+        std::vector<std::vector<int32_t>> open(cap_rows + 1);      // open[r] = bins of this pass with r free rows and < 16 captions
+        for (int n = cap_rows; n >= lo; --n)
+            for (int32_t c : by_n[n]) {
+                int r = n;
+                while (r <= cap_rows && open[r].empty()) ++r;
+                int32_t t;
+                if (r <= cap_rows) {
+                    t = open[r].back();
+                    open[r].pop_back();
+                } else {
+                    t = (int32_t)bins.size();
+                    bins.push_back(Bin{0, {}});
+                    r = cap_rows;
+                }
+                Bin &B = bins[t];
+                B.cap[B.n++] = c;
+                if (B.n < SF_MAXCAP && r - n >= 2) open[r - n].push_back(t);
+            }
+    }
+    int64_t pos = 0;
+    for (size_t t = 0; t < bins.size(); ++t) {
+        group_begin_host[t] = (int32_t)pos;
+        for (int k = 0; k < bins[t].n; ++k) group_order_host[pos++] = bins[t].cap[k];
+    }
+    group_begin_host[bins.size()] = (int32_t)pos;
+    *n_groups = (int64_t)bins.size();
+    return ITR_OK;
+}

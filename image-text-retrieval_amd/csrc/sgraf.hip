@@ -32,12 +32,13 @@ int scan_scores_impl(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, 
 int sgraf_loc_fused(const float *P, const float *cn, const float *img, const float *wtiled, const float *W, const float *bias,
                     float *X, int64_t nb, int64_t n_tiles, int D, hipStream_t st);
 // sgr_fused.hip: all graph-reasoning steps of a group of captions in one workgroup
-size_t sgr_fused_workspace_bytes(int64_t n_groups, int sgr_step);
-int sgr_fused_prepare(const int32_t *grp_begin, const int32_t *grp_order, int64_t n_groups, const int32_t *cap_len, const int32_t *cap_col,
-                      const float *const *wq, const float *const *wg, int sgr_step, void *ws, int *bad_flag, hipStream_t st);
-int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t nb, int64_t Nc, int64_t ncols,
+size_t sgr_fused_workspace_bytes(int64_t n_groups, int64_t n_caps, int sgr_step);
+int sgr_fused_prepare(const int32_t *grp_begin, const int32_t *grp_order, int64_t n_groups, int64_t n_caps, const int32_t *cap_len,
+                      const int32_t *cap_col, const float *const *wq, const float *const *wg, int sgr_step, void *ws, int *bad_flag, hipStream_t st);
+int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t n_caps, int64_t nb, int64_t Nc, int64_t ncols,
                      const float *const *vq, const float *const *bg, int sgr_step, const float *eval_w, const float *eval_b, float *S,
-                     int64_t ldS, int64_t img_index0, hipStream_t st);
+                     int64_t ldS, int64_t img_index0, int max_len, hipStream_t st);
+int sgr_fused_finish(void *ws, int64_t n_groups, int64_t n_caps, int sgr_step, int64_t Ni, float *S, int64_t ldS, hipStream_t st);
 
 constexpr float BN_EPS = 1e-5f;
 
@@ -434,7 +435,7 @@ extern "C" size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_ro
     const int nbuf = module == 1 ? 3 : 1;                                        // X (+ Q', Y for SGR)
     b += (al((size_t)IB * ncols * S * 4) + al((size_t)IB * NcP * S * 4)) * nbuf;
     if (module == 1) b += al((size_t)S * S * 4) * 2 + (al((size_t)S * S * 4) + al((size_t)S * 4)) * 8;   // W^T scratch, folded query weights
-    if (module == 1 && S == 256) b += al(sgr_fused_workspace_bytes(Nc, 8)) + 256;                       // group records (<= one per caption), weight fragments, flag
+    if (module == 1 && S == 256) b += al(sgr_fused_workspace_bytes(Nc, Nc, 8)) + 256;                       // group records (<= one per caption), weight fragments, flag
     return b;
 }
 
@@ -499,7 +500,7 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     void *fused_ws = nullptr;
     int *fused_bad = nullptr;
     if (module == 1 && S == 256) {
-        fused_ws = take(sgr_fused_workspace_bytes(Nc, 8));
+        fused_ws = take(sgr_fused_workspace_bytes(Nc, Nc, 8));
         fused_bad = (int *)take(256);
     }
     int rc;
@@ -562,8 +563,8 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
 
     if (fused_sgr) {
         ITR_CHECK_HIP(hipMemsetAsync(fused_bad, 0, sizeof(int), st));
-        SG_TRY(sgr_fused_prepare(node_group_begin_dev, node_group_order_dev, n_node_groups, cap_len, cap_col, Wfold, w->sgr_g_w, sgr_step, fused_ws,
-                                 fused_bad, st));
+        SG_TRY(sgr_fused_prepare(node_group_begin_dev, node_group_order_dev, n_node_groups, Nc, cap_len, cap_col, Wfold, w->sgr_g_w, sgr_step,
+                                 fused_ws, fused_bad, st));
     }
 
     if (glo_loc) {
@@ -606,8 +607,8 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
                                w->saf_bn_b, w->saf_bn_mean, w->saf_bn_var, w->eval_w, w->eval_b, npairs, Sout, ldS, i0);
             ITR_CHECK_LAUNCH("sgraf saf_pair");
         } else if (fused_sgr) {
-            SG_TRY(sgr_fused_scores(Xloc, Xglo, fused_ws, n_node_groups, nb, ldg, ncols, vfold, w->sgr_g_b, sgr_step, w->eval_w, w->eval_b, Sout,
-                                    ldS, i0, st));
+            SG_TRY(sgr_fused_scores(Xloc, Xglo, fused_ws, n_node_groups, Nc, nb, ldg, ncols, vfold, w->sgr_g_b, sgr_step, w->eval_w, w->eval_b,
+                                    Sout, ldS, i0, max_len, st));
         } else {
             const int ntmax = (max_len + 1 + 15) / 16;
             ITR_UNSUPPORTED(S % 16 != 0, "itr_sgraf_scores: SGR needs sim_dim %% 16 == 0");
@@ -637,6 +638,8 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
             ITR_CHECK_LAUNCH("sgraf sgr_final");
         }
     }
+    // a refused group of a hand-made node-group plan: NaN in its captions' columns (never uninitialised memory; sgr_fused.hip)
+    if (fused_sgr) SG_TRY(sgr_fused_finish(fused_ws, n_node_groups, Nc, sgr_step, Ni, Sout, ldS, st));
 #undef SG_TRY
     return ITR_OK;
 }

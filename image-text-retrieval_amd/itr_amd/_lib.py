@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "itr_hinge_maxviol_fwd": (i32, [vp, i32, i64, f32, i32, vp, vp, vp, vp, vp]),
     "itr_hinge_maxviol_bwd": (i32, [vp, i32, i64, f32, i32, vp, vp, vp, vp, i64, vp]),
     "itr_scan_plan_tiles": (i32, [vp, i64, i32, vp, vp, vp]),
+    "itr_sgr_plan_node_groups": (i32, [vp, i64, vp, vp, vp]),
     "itr_scan_workspace_bytes": (sz, [i64, i32, i64, i64, i64, i32]),
     "itr_scan_prepare": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, sz, vp]),
     "itr_scan_xattn_scores": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp, sz, vp]),

@@ -388,8 +388,9 @@ class ScanPlan:
         self._node_groups = None
 
     def node_groups(self):
-        """SGRAF-SGR's fused graph steps (csrc/sgr_fused.hip): bins of whole captions with at most 64 NODE rows (words + the
-        global node of every caption) and at most 16 captions -- the same best-fit-decreasing planner run on len + 1.
+        """SGRAF-SGR's fused graph steps (csrc/sgr_fused.hip): groups of whole captions binned by NODE count (words + the global
+        node) -- captions of at most 31 words into groups of <= 32 node rows (two workgroups per CU), longer ones into groups of
+        <= 64; at most 16 captions per group (itr_sgr_plan_node_groups, best fit decreasing).
         -> (group_begin int32[n + 1], group_order int32[Nc_kernel], n) on the device, or None when a caption has more than 63
         words (its graph does not fit one workgroup)."""
         if self._node_groups is None:
@@ -397,13 +398,22 @@ class ScanPlan:
             if self.Nc_kernel == 0 or int(self._k_len.max()) + 1 > SCAN_NT:
                 self._node_groups = False
             else:
-                nodes = np.ascontiguousarray(self._k_len.astype(np.int32) + 1)
+                lens = np.ascontiguousarray(self._k_len.astype(np.int32))
                 tb = np.zeros(self.Nc_kernel + 1, dtype=np.int32)
                 order = np.zeros(self.Nc_kernel, dtype=np.int32)
                 nt = C.c_int64(0)
-                _lib.check(lib.itr_scan_plan_tiles(nodes.ctypes.data_as(C.c_void_p), self.Nc_kernel, SCAN_NT, tb.ctypes.data_as(C.c_void_p),
-                                                   order.ctypes.data_as(C.c_void_p), C.byref(nt)))
+                if os.environ.get("ITR_SGR_PLAN64") == "1":      # A/B switch: round 3's groups of <= 64 node rows (one workgroup per CU)
+                    nodes = np.ascontiguousarray(lens + 1)
+                    _lib.check(lib.itr_scan_plan_tiles(nodes.ctypes.data_as(C.c_void_p), self.Nc_kernel, SCAN_NT, tb.ctypes.data_as(C.c_void_p),
+                                                       order.ctypes.data_as(C.c_void_p), C.byref(nt)))
+                else:
+                    _lib.check(lib.itr_sgr_plan_node_groups(lens.ctypes.data_as(C.c_void_p), self.Nc_kernel, tb.ctypes.data_as(C.c_void_p),
+                                                            order.ctypes.data_as(C.c_void_p), C.byref(nt)))
                 n = int(nt.value)
+                # the bounds the device checks again (a group that breaks them is refused there and its columns come back NaN)
+                cnt = np.diff(tb[:n + 1])
+                rows = np.add.reduceat(lens[order] + 1, tb[:n]) if n else np.zeros(0, np.int64)
+                assert n == 0 or (cnt.min() >= 1 and cnt.max() <= 16 and rows.max() <= SCAN_NT and int(cnt.sum()) == self.Nc_kernel)
                 self._node_groups = (h2d(tb[:n + 1].copy(), self.device), h2d(order, self.device), n)
         return self._node_groups or None
 

@@ -12,7 +12,9 @@ ISA, for every kernel that contains asm loads:
      that register (forward dataflow over the kernel's control-flow graph, union at joins);
   2. nothing is in flight at s_endpgm;
   3. (optional, --no-scratch-in-loops) no scratch (spill) instruction sits in a basic block that is part of a loop which also
-     contains asm loads: spill traffic shares the vmcnt counter with the hand-counted loads.
+     contains asm loads: spill traffic shares the vmcnt counter with the hand-counted loads.  A kernel whose asm waits are ALL
+     `vmcnt(0)` (sgr_fused.hip) counts nothing by hand -- extra memory operations in flight cannot make a `vmcnt(0)` return early --
+     so there the rule is the weaker, sufficient one: no scratch instruction while a global asm load is in flight.
 
 A wait statement covers the registers it prints in its trailing comment (`s_waitcnt vmcnt(7) ; covers v[1:4] ...`, the
 "+v" operands of the statement); a bare `s_waitcnt vmcnt(0)` inside an asm block covers everything.
@@ -123,6 +125,12 @@ def build_cfg(lines):
     return blocks
 
 
+class Block1:
+    """a one-instruction view of a block (for walking a block instruction by instruction with transfer())"""
+    def __init__(self, label, insts):
+        self.label, self.insts = label, insts
+
+
 def transfer(block, inflight, report):
     """Walk one block.  inflight: {reg: 'where the load was issued'}.  Returns the state at the block's end."""
     st = dict(inflight)
@@ -193,7 +201,16 @@ def audit_kernel(name, lines, no_scratch_in_loops=False):
     report = []
     for b in blocks:
         transfer(b, state_in[b.label], report)
-    if no_scratch_in_loops:
+    asm_waits = [s for b in blocks for k, s in b.insts if k == "asm" and s.split()[0] == "s_waitcnt" and "vmcnt" in s.split(";")[0]]
+    only_full_waits = bool(asm_waits) and all("vmcnt(0)" in s.split(";")[0] for s in asm_waits)
+    if no_scratch_in_loops and only_full_waits:
+        for b in blocks:
+            st = dict(state_in[b.label])
+            for kind, s in b.insts:
+                if kind == "cc" and s.startswith("scratch_") and any(not w.startswith("lds ") for w in st.values()):
+                    report.append("%s: spill `%s` while an asm load is in flight" % (b.label, s.split(";")[0].strip()))
+                st = transfer(Block1(b.label, [(kind, s)]), st, [])
+    elif no_scratch_in_loops:
         # blocks on a cycle that also holds asm loads
         idx = {b.label: i for i, b in enumerate(blocks)}
         reach = {}

@@ -29,7 +29,8 @@ for _ in range(2):
     ops.sgraf_scores(img, words, plan, w, "SGR", 3)
 torch.cuda.synchronize()
 
-rec = np.fromfile(TRACE, dtype=np.uint64).reshape(-1, 20)
+ROWS = int(os.environ.get("SGR_TRACE_ROWS", "32"))      # which class of groups: 32 (two workgroups per CU) or 64 (ITR_SGR_PLAN64=1)
+rec = np.fromfile("%s.%d" % (TRACE, ROWS), dtype=np.uint64).reshape(-1, 20)
 rec = rec[rec[:, 2] != 0]
 shape = rec[:, 1]
 nrows = (shape >> np.uint64(32)).astype(np.int64)
@@ -52,15 +53,16 @@ life = t[:, -1] - t[:, 0]
 print("%-12s %10.0f %10.0f %10.0f" % ("lifetime", life.mean(), np.percentile(life, 10), np.percentile(life, 90)))
 hw = rec[:, 0]
 cu = ((hw >> np.uint64(32)) << np.uint64(8)) | ((hw >> np.uint64(8)) & np.uint64(0xff))
-gaps = []
+# per CU: wall time covered by its workgroups and the MFMA floor of the work it did (two workgroups per CU overlap for ROWS = 32)
+span = busy_floor = 0.0
 for c in np.unique(cu):
-    m = t[cu == c]
-    o = np.argsort(m[:, 0])
-    gaps += list(m[o][1:, 0] - m[o][:-1, -1])
-gaps = np.asarray(gaps)
-print("end -> next entry on the same CU: mean %.0f  median %.0f  p90 %.0f cycles" % (gaps.mean(), np.median(gaps), np.percentile(gaps, 90)))
-tot_floor = (4 * floor_proj + 2 * floor_last).mean()
-print("projection MFMA floor per workgroup %.0f cycles = %.1f%% of lifetime + gap" % (tot_floor, 100 * tot_floor / (life.mean() + max(gaps.mean(), 0))))
+    sel = cu == c
+    m = t[sel]
+    span += m[:, -1].max() - m[:, 0].min()
+    busy_floor += (4 * floor_proj[sel] + 2 * floor_last).sum()
+print("CUs seen %d; sum over CUs of (last end - first entry) %.3g cycles; projection MFMA floor of their work %.3g = %.1f%%" % (
+    len(np.unique(cu)), span, busy_floor, 100 * busy_floor / span))
+print("workgroup lifetimes overlapping on a CU: mean resident workgroups = %.2f" % (life.sum() / span))
 
 # attention phases against the group's shape: extra = number of (caption, query tile) units beyond one per caption, i.e. how many
 # second / third / fourth 16-node tiles the group's captions have (0: every caption has <= 16 nodes)
