@@ -178,9 +178,11 @@ struct SgrFusedArgs {
     int64_t n_groups, nb, Nc, ncols;
     const float4 *wq[8], *wg[8];         // fragment-ordered folded query weight / graph weight of every step
     const float *vq[8], *bg[8];
-    const float *wqT_last, *wgT_last;    // the LAST step's folded query weight / graph weight, transposed: [k][o] (sgr_transpose_weight_kernel)
+    const float *wqT_last;               // the LAST step's folded query weight, transposed: [k][o] (sgr_transpose_weight_kernel)
     int steps;
     const float *eval_w, *eval_b;
+    float *y0;                           // [nb][Nc][256]: y of node 0 after the last step's attention (the last graph projection and the score
+                                         // run as ONE GEMM over all the graphs of the image block afterwards: sgraf.hip)
     float *S;
     int64_t ldS, img_index0;
     unsigned long long *trace;           // debug (ITR_SGR_TRACE): [grid][20] = hardware id, group shape, s_memtime at entry / after the load / after every phase
@@ -588,7 +590,8 @@ __device__ __forceinline__ void sf_last_project(const float *__restrict__ src, f
 // conflict-free pattern of the MFMA fragment reads, the four quarters summed by sf_rows_sum.  Values: lane = feature quad, the weight
 // of node j read from the lane that holds it.  NTC = key tiles of the graph.
 template <int NTC, int UNR>
-__device__ __forceinline__ void sf_last_attend(const float *__restrict__ xb, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int lane) {
+__device__ __forceinline__ void sf_last_attend(const float *__restrict__ xb, const float *__restrict__ qy, const SgrGroupMeta &m, int ci, int lane,
+                                               float *__restrict__ yout) {
     const int fi = lane & 15, fq = lane >> 4;
     const int nn = m.nn[ci], ws = m.wstart[ci];
     auto row_of = [&](int n) { n = n < nn ? n : nn - 1; return n == 0 ? ci : ws + n - 1; };
@@ -627,21 +630,22 @@ __device__ __forceinline__ void sf_last_attend(const float *__restrict__ xb, flo
         const float4 x = *reinterpret_cast<const float4 *>(xb + (n == 0 ? ci : ws + n - 1) * SF_LD + 4 * lane);
         y.x = fmaf(pn, x.x, y.x); y.y = fmaf(pn, x.y, y.y); y.z = fmaf(pn, x.z, y.z); y.w = fmaf(pn, x.w, y.w);
     }
-    *reinterpret_cast<float4 *>(qy + ci * SF_LD + 4 * lane) = y;
+    *reinterpret_cast<float4 *>(yout + 4 * lane) = y;       // one 1 KB row per caption, straight from the registers
 }
 template <int ROWS>
-__device__ __forceinline__ void sf_last_attend_n(const float *__restrict__ xb, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int lane) {
+__device__ __forceinline__ void sf_last_attend_n(const float *__restrict__ xb, const float *__restrict__ qy, const SgrGroupMeta &m, int ci, int lane,
+                                                 float *__restrict__ yout) {
     const int ntc = (m.nn[ci] + 15) >> 4;
     if constexpr (ROWS > SF_SMALL) {
         switch (ntc) {
-            case 1: sf_last_attend<1, 4>(xb, qy, m, ci, lane); break;
-            case 2: sf_last_attend<2, 4>(xb, qy, m, ci, lane); break;
-            case 3: sf_last_attend<3, 2>(xb, qy, m, ci, lane); break;
-            default: sf_last_attend<4, 2>(xb, qy, m, ci, lane); break;
+            case 1: sf_last_attend<1, 4>(xb, qy, m, ci, lane, yout); break;
+            case 2: sf_last_attend<2, 4>(xb, qy, m, ci, lane, yout); break;
+            case 3: sf_last_attend<3, 2>(xb, qy, m, ci, lane, yout); break;
+            default: sf_last_attend<4, 2>(xb, qy, m, ci, lane, yout); break;
         }
     } else {
-        if (ntc == 1) sf_last_attend<1, 2>(xb, qy, m, ci, lane);
-        else sf_last_attend<2, 2>(xb, qy, m, ci, lane);
+        if (ntc == 1) sf_last_attend<1, 2>(xb, qy, m, ci, lane, yout);
+        else sf_last_attend<2, 2>(xb, qy, m, ci, lane, yout);
     }
 }
 
@@ -761,24 +765,16 @@ __global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_kernel(Sg
     float4 lw[LKB];
     sf_last_weights0<LKB>(g.wqT_last, wave, lane, lw);
     sf_last_project<false, LNR, LKB>(xb, qy, g.wqT_last, g.vq[g.steps - 1], ncap, wave, lane, lw);
-    sf_last_weights0<LKB>(g.wgT_last, wave, lane, lw);      // (in flight through the barrier and the attention)
     __syncthreads();
     SF_STAMP()
-    for (int ci = wave; ci < ncap; ci += SF_WAVES) sf_last_attend_n<ROWS>(xb, qy, m, ci, lane);
-    __syncthreads();
+    // y of node 0 -> memory; X'_0 = relu(W_g y + b) and sigmoid(sim_eval_w . x_0 + b) (Fusionmodule.py:443-444) run as one GEMM + one
+    // small kernel over ALL the graphs of the image block (sgraf.hip): there the weight is read once per 128 rows, here it was
+    // streamed through the CU once per item for 2-5 live rows
+    for (int ci = wave; ci < ncap; ci += SF_WAVES)
+        sf_last_attend_n<ROWS>(xb, qy, m, ci, lane, g.y0 + (ii * g.Nc + m.cap_id[ci]) * SF_S);
     SF_STAMP()
     SF_STAMP()
-    sf_last_project<true, LNR, LKB>(qy, xb, g.wgT_last, g.bg[g.steps - 1], ncap, wave, lane, lw);
-    __syncthreads();
     SF_STAMP()
-    // ---- sim = sigmoid(sim_eval_w . x_0 + b)  (Fusionmodule.py:443-444)
-    const float4 ew = *reinterpret_cast<const float4 *>(g.eval_w + 4 * lane);
-    for (int ci = wave; ci < ncap; ci += SF_WAVES) {
-        const float4 x = *reinterpret_cast<const float4 *>(xb + ci * SF_LD + 4 * lane);
-        float s = x.x * ew.x + x.y * ew.y + x.z * ew.z + x.w * ew.w;
-        s = wave_sum(s) + g.eval_b[0];
-        if (lane == 0) g.S[(g.img_index0 + ii) * g.ldS + m.cap_id[ci]] = 1.f / (1.f + expf(-s));
-    }
     if (g.trace && tid == 0) {
         SF_STAMP()
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
@@ -886,13 +882,10 @@ __global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_persisten
         if (!early) sf_last_weights0<LKB>(g.wqT_last, wave, lane, lw);
         // ---- the last step: node 0 of every graph only, on the vector ALU (see sf_last_project)
         sf_last_project<false, LNR, LKB>(xb, qy, g.wqT_last, g.vq[g.steps - 1], ncap, wave, lane, lw);
-        if (early) sf_last_weights0<LKB>(g.wgT_last, wave, lane, lw);      // (in flight through the barrier and the attention)
-        __syncthreads();
-        for (int ci = wave; ci < ncap; ci += SF_WAVES) sf_last_attend_n<ROWS>(xb, qy, m, ci, lane);
         __syncthreads();
         f32x4 pre[ROWS / SF_WAVES];
         if (has_next) {
-            // node rows of the next item -> registers, in flight during the rest of the last step.  Branch-free (a conditional
+            // node rows of the next item -> registers, in flight during the attention.  Branch-free (a conditional
             // load makes hipcc merge "loaded | zero" right here): rows past the next group re-read its last row and are zeroed when
             // they are stored.  Loads hipcc counts: their registers are safe.
             const SgrGroupMeta &mn = m2[cur ^ 1];
@@ -907,16 +900,10 @@ __global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_persisten
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!early) sf_last_weights0<LKB>(g.wgT_last, wave, lane, lw);
-        sf_last_project<true, LNR, LKB>(qy, xb, g.wgT_last, g.bg[g.steps - 1], ncap, wave, lane, lw);
-        __syncthreads();
-        const float4 ew = *reinterpret_cast<const float4 *>(g.eval_w + 4 * lane);
-        for (int ci = wave; ci < ncap; ci += SF_WAVES) {
-            const float4 x = *reinterpret_cast<const float4 *>(xb + ci * SF_LD + 4 * lane);
-            float sc = x.x * ew.x + x.y * ew.y + x.z * ew.z + x.w * ew.w;
-            sc = wave_sum(sc) + g.eval_b[0];
-            if (lane == 0) g.S[(g.img_index0 + ii) * g.ldS + m.cap_id[ci]] = 1.f / (1.f + expf(-sc));
-        }
+        // y of node 0 -> memory: the last graph projection and the score are one GEMM + one small kernel over all the graphs of the
+        // image block (sgraf.hip)
+        for (int ci = wave; ci < ncap; ci += SF_WAVES)
+            sf_last_attend_n<ROWS>(xb, qy, m, ci, lane, g.y0 + (ii * g.Nc + m.cap_id[ci]) * SF_S);
         if (!has_next) break;
         __syncthreads();                                        // every wave is done with the X buffer of this item
 #pragma unroll
@@ -936,7 +923,7 @@ struct SgrWs {
     int8_t *cls;
     int32_t *glist, *gcount, *cap_bad;
     float4 *frag;
-    float *wT;                   // [2][256][256]: the last step's two weights, transposed
+    float *wT;                   // [256][256]: the last step's folded query weight, transposed
     size_t bytes;
 };
 static SgrWs sgr_carve(void *ws, int64_t n_groups, int64_t n_caps, int sgr_step) {
@@ -949,7 +936,7 @@ static SgrWs sgr_carve(void *ws, int64_t n_groups, int64_t n_caps, int sgr_step)
     w.gcount = reinterpret_cast<int32_t *>(p); p += 256;
     w.cap_bad = reinterpret_cast<int32_t *>(p); p += al((size_t)n_caps * 4);
     w.frag = reinterpret_cast<float4 *>(p); p += (size_t)sgr_step * 2 * SF_S * SF_S * 4;
-    w.wT = reinterpret_cast<float *>(p); p += (size_t)2 * SF_S * SF_S * 4;
+    w.wT = reinterpret_cast<float *>(p); p += (size_t)SF_S * SF_S * 4;
     w.bytes = (size_t)(p - static_cast<char *>(ws)) + 256;
     return w;
 }
@@ -971,7 +958,6 @@ int sgr_fused_prepare(const int32_t *grp_begin, const int32_t *grp_order, int64_
     }
     ITR_CHECK_LAUNCH("sgr pack weights");
     hipLaunchKernelGGL(sgr_transpose_weight_kernel, dim3(SF_S * SF_S / 256), dim3(256), 0, st, wq[sgr_step - 1], w.wT);
-    hipLaunchKernelGGL(sgr_transpose_weight_kernel, dim3(SF_S * SF_S / 256), dim3(256), 0, st, wg[sgr_step - 1], w.wT + SF_S * SF_S);
     ITR_CHECK_LAUNCH("sgr transpose weights");
     return ITR_OK;
 }
@@ -1042,8 +1028,10 @@ static int sgr_fused_launch_class(SgrFusedArgs g, int cls_index, int64_t n_group
     return ITR_OK;
 }
 
+// Runs the graph steps up to the last step's attention; y0 [nb][Nc][256] receives y of node 0 of every graph.  The caller finishes:
+// x_0 = relu(W_g y + b) as one GEMM over nb * Nc rows, then sigmoid(sim_eval_w . x_0 + b) (sgraf.hip).
 int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t n_caps, int64_t nb, int64_t Nc, int64_t ncols,
-                     const float *const *vq, const float *const *bg, int sgr_step, const float *eval_w, const float *eval_b, float *S,
+                     const float *const *vq, const float *const *bg, int sgr_step, const float *eval_w, const float *eval_b, float *y0, float *S,
                      int64_t ldS, int64_t img_index0, int max_len, hipStream_t st) {
     if (nb == 0 || n_groups == 0) return ITR_OK;
     const SgrWs w = sgr_carve(ws, n_groups, n_caps, sgr_step);
@@ -1059,7 +1047,8 @@ int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_g
         g.bg[k] = bg[k];
     }
     g.steps = sgr_step;
-    g.wqT_last = w.wT; g.wgT_last = w.wT + SF_S * SF_S;
+    g.wqT_last = w.wT;
+    g.y0 = y0;
     g.eval_w = eval_w; g.eval_b = eval_b; g.S = S; g.ldS = ldS; g.img_index0 = img_index0;
     static const char *trace_env = getenv("ITR_SGR_TRACE");
     const char *trace_path = (trace_env && *trace_env) ? trace_env : nullptr;
@@ -1076,17 +1065,20 @@ int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_g
 }  // namespace itr
 
 // Pure CPU.  The planner of SGR's fused graph steps: whole captions are bin-packed (best fit decreasing, like itr_scan_plan_tiles) by
-// NODE count = words + 1 into groups of at most 16 captions -- captions of at most 31 words into groups of <= 32 node rows (two
-// workgroups per CU), longer ones (<= 63 words) into groups of <= 64.  group_begin_host[n_groups + 1] indexes group_order_host[Nc].
-extern "C" int itr_sgr_plan_node_groups(const int32_t *cap_len_host, int64_t Nc, int32_t *group_begin_host, int32_t *group_order_host,
-                                        int64_t *n_groups) {
+// NODE count = words + 1 into groups of at most 16 captions and at most 64 node rows (one workgroup per CU).  small_rows = 64: that is
+// all (the default of the Python layer: measured fastest).  small_rows = 32: captions of at most 31 words go into
+// groups of <= 32 node rows instead, which run two workgroups per CU (kept: same scores, 1.2 % slower on the bench captions).
+// group_begin_host[n_groups + 1] indexes group_order_host[Nc].
+extern "C" int itr_sgr_plan_node_groups(const int32_t *cap_len_host, int64_t Nc, int small_rows, int32_t *group_begin_host,
+                                        int32_t *group_order_host, int64_t *n_groups) {
     using namespace itr;
     ITR_REQUIRE(cap_len_host && group_begin_host && group_order_host && n_groups, "itr_sgr_plan_node_groups: null pointer");
+    ITR_REQUIRE(small_rows == SF_SMALL || small_rows == SF_ROWS, "itr_sgr_plan_node_groups: small_rows must be %d or %d", SF_SMALL, SF_ROWS);
     ITR_REQUIRE(Nc >= 0 && Nc < 0x7fffffffLL, "itr_sgr_plan_node_groups: bad caption count");
     struct Bin { int32_t n; int32_t cap[SF_MAXCAP]; };
     std::vector<Bin> bins;
-    for (int pass = 0; pass < 2; ++pass) {
-        const int cap_rows = pass == 0 ? SF_SMALL : SF_ROWS, lo = pass == 0 ? 2 : SF_SMALL + 1;
+    for (int pass = (small_rows == SF_ROWS ? 1 : 0); pass < 2; ++pass) {
+        const int cap_rows = pass == 0 ? SF_SMALL : SF_ROWS, lo = (pass == 0 || small_rows == SF_ROWS) ? 2 : SF_SMALL + 1;
         std::vector<std::vector<int32_t>> by_n(cap_rows + 1);
         for (int64_t c = 0; c < Nc; ++c) {
             const int n = cap_len_host[c] + 1;

@@ -72,7 +72,7 @@ SIGNATURES = {
     "itr_hinge_maxviol_fwd": (i32, [vp, i32, i64, f32, i32, vp, vp, vp, vp, vp]),
     "itr_hinge_maxviol_bwd": (i32, [vp, i32, i64, f32, i32, vp, vp, vp, vp, i64, vp]),
     "itr_scan_plan_tiles": (i32, [vp, i64, i32, vp, vp, vp]),
-    "itr_sgr_plan_node_groups": (i32, [vp, i64, vp, vp, vp]),
+    "itr_sgr_plan_node_groups": (i32, [vp, i64, i32, vp, vp, vp]),
     "itr_scan_workspace_bytes": (sz, [i64, i32, i64, i64, i64, i32]),
     "itr_scan_prepare": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, sz, vp]),
     "itr_scan_xattn_scores": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp, sz, vp]),

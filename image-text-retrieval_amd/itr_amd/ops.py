@@ -389,8 +389,7 @@ class ScanPlan:
 
     def node_groups(self):
         """SGRAF-SGR's fused graph steps (csrc/sgr_fused.hip): groups of whole captions binned by NODE count (words + the global
-        node) -- captions of at most 31 words into groups of <= 32 node rows (two workgroups per CU), longer ones into groups of
-        <= 64; at most 16 captions per group (itr_sgr_plan_node_groups, best fit decreasing).
+        node), at most 64 node rows and 16 captions per group (itr_sgr_plan_node_groups, best fit decreasing).
         -> (group_begin int32[n + 1], group_order int32[Nc_kernel], n) on the device, or None when a caption has more than 63
         words (its graph does not fit one workgroup)."""
         if self._node_groups is None:
@@ -402,13 +401,10 @@ class ScanPlan:
                 tb = np.zeros(self.Nc_kernel + 1, dtype=np.int32)
                 order = np.zeros(self.Nc_kernel, dtype=np.int32)
                 nt = C.c_int64(0)
-                if os.environ.get("ITR_SGR_PLAN64") == "1":      # A/B switch: round 3's groups of <= 64 node rows (one workgroup per CU)
-                    nodes = np.ascontiguousarray(lens + 1)
-                    _lib.check(lib.itr_scan_plan_tiles(nodes.ctypes.data_as(C.c_void_p), self.Nc_kernel, SCAN_NT, tb.ctypes.data_as(C.c_void_p),
-                                                       order.ctypes.data_as(C.c_void_p), C.byref(nt)))
-                else:
-                    _lib.check(lib.itr_sgr_plan_node_groups(lens.ctypes.data_as(C.c_void_p), self.Nc_kernel, tb.ctypes.data_as(C.c_void_p),
-                                                            order.ctypes.data_as(C.c_void_p), C.byref(nt)))
+                # ITR_SGR_GROUP_ROWS=32 (A/B switch): captions of <= 31 words in groups of <= 32 node rows, two workgroups per CU
+                small = 32 if os.environ.get("ITR_SGR_GROUP_ROWS") == "32" else SCAN_NT
+                _lib.check(lib.itr_sgr_plan_node_groups(lens.ctypes.data_as(C.c_void_p), self.Nc_kernel, small, tb.ctypes.data_as(C.c_void_p),
+                                                        order.ctypes.data_as(C.c_void_p), C.byref(nt)))
                 n = int(nt.value)
                 # the bounds the device checks again (a group that breaks them is refused there and its columns come back NaN)
                 cnt = np.diff(tb[:n + 1])

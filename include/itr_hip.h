@@ -243,11 +243,11 @@ int itr_camera_summarize(const float *smry, const float *X, float *out, int64_t 
  * S[i,c] in (0,1).  max_len = longest caption (<= 63).  workspace: itr_sgraf_workspace_bytes(...).
  * node_group_*: optional plan for SGR's fused graph steps (GraphReasoning x sgr_step, Fusionmodule.py:564-597, in one
  * workgroup per group of captions): itr_sgr_plan_node_groups (pure CPU) bins whole captions by the node count of their
- * graph (cap_len[c] + 1) into groups of <= 16 captions -- captions of <= 31 words into groups of <= 32 node rows (two
- * workgroups per CU), longer ones into groups of <= 64; pass its group_begin / group_order arrays (device copies) and the
- * group count.  Any plan with <= 16 captions and <= 64 node rows per group is accepted (e.g. itr_scan_plan_tiles run on
- * cap_len + 1, the round-3 planner); a group that breaks these bounds is not scored and its captions' columns of S are
- * filled with NaN.  NULL / 0: the steps run one kernel chain per step (also taken for sim_dim != 256). */
+ * graph (cap_len[c] + 1) into groups of <= 16 captions and <= 64 node rows (small_rows = 64: one workgroup per CU, the
+ * default) or, for captions of <= 31 words, <= 32 node rows (small_rows = 32: two workgroups per CU; same scores); pass
+ * its group_begin / group_order arrays (device copies) and the group count.  Any plan with <= 16 captions and <= 64 node
+ * rows per group is accepted; a group that breaks these bounds is not scored and its captions' columns of S are filled
+ * with NaN.  NULL / 0: the steps run one kernel chain per step (also taken for sim_dim != 256). */
 typedef struct {
     /* v_global_w (VisualSA :464-507) */
     const float *v_loc_w, *v_loc_b, *v_loc_bn_w, *v_loc_bn_b, *v_loc_bn_mean, *v_loc_bn_var; /* Linear[D,D], BN(36) */
@@ -262,8 +262,8 @@ typedef struct {
     /* SGR_module.sgr{k}.graph_query_w / graph_key_w / sim_graph_w [S,S] (:573-576) */
     const float *sgr_q_w[8], *sgr_q_b[8], *sgr_k_w[8], *sgr_k_b[8], *sgr_g_w[8], *sgr_g_b[8];
 } itr_sgraf_weights;
-int itr_sgr_plan_node_groups(const int32_t *cap_len_host, int64_t Nc, int32_t *group_begin_host,
-                             int32_t *group_order_host, int64_t *n_groups);
+int itr_sgr_plan_node_groups(const int32_t *cap_len_host, int64_t Nc, int small_rows /* 64 or 32 */,
+                             int32_t *group_begin_host, int32_t *group_order_host, int64_t *n_groups);
 size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_rows, int64_t n_tiles, int D, int S,
                                  int module);
 int itr_sgraf_scores(const float *img, const float *words, const int64_t *cap_off, const int32_t *cap_len,

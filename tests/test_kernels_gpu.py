@@ -512,6 +512,43 @@ def test_sgr_fused_graph_steps(dev, case, steps):
     finally:
         del os.environ["ITR_SGR_PERSISTENT"]
     assert torch.equal(per_item, got)                           # same arithmetic per item: bit-identical
+    # the two-class plan (round 4): captions of <= 31 words in groups of <= 32 node rows (two workgroups per CU), longer ones in groups of
+    # <= 64 -- a caption's graph is computed with the same arithmetic whatever group and class it lands in
+    os.environ["ITR_SGR_GROUP_ROWS"] = "32"
+    try:
+        small = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
+    finally:
+        del os.environ["ITR_SGR_GROUP_ROWS"]
+    assert torch.equal(small, got)
+
+
+def test_sgr_refused_group_is_nan_not_garbage(dev):
+    """a hand-made node-group plan that breaks the bounds (here: 17 captions in one group) is refused on the device; the
+    captions of that group come back NaN -- never a column of uninitialised memory -- and every other caption is scored as usual."""
+    torch.manual_seed(3)
+    D, S, steps = 64, 256, 2
+    lens = [2] * 17 + [5, 7, 9]
+    Ni, Nc, L = 5, len(lens), max(lens)
+    img = O.l2norm(torch.randn(Ni, 36, D), -1)
+    cap = O.l2norm(torch.randn(Nc, L, D), -1)
+    w = _sgraf_weights(D, S, steps)
+    wd = {k: v.to(dev) for k, v in w.items()}
+    good = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
+    assert torch.isfinite(good).all()
+    real = ops.ScanPlan.node_groups
+
+    def bad_plan(self):
+        # kernel caption ids: ScanPlan keeps the caller's order for captions that all fit the kernel
+        tb = np.asarray([0, 17, 20], np.int32)
+        order = np.arange(20, dtype=np.int32)
+        return ops.h2d(tb, self.device), ops.h2d(order, self.device), 2
+    ops.ScanPlan.node_groups = bad_plan
+    try:
+        out = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
+    finally:
+        ops.ScanPlan.node_groups = real
+    assert torch.isnan(out[:, :17]).all()
+    assert torch.equal(out[:, 17:], good[:, 17:])
 
 
 # ------------------------------------------------------------------------------------------ GRU

@@ -6,7 +6,7 @@ mkdir -p $OUT
 ARGS="--workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-variants --no-other-configs"
 for i in $(seq 1 $N); do
   python3 tools/ab/r3/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-variants > $OUT/r3_$i.json 2>$OUT/err.log
-  python3 bench.py $ARGS > $OUT/new32_$i.json 2>>$OUT/err.log
-  ITR_SGR_PLAN64=1 python3 bench.py $ARGS > $OUT/new64_$i.json 2>>$OUT/err.log
+  ITR_SGR_GROUP_ROWS=32 python3 bench.py $ARGS > $OUT/new32_$i.json 2>>$OUT/err.log
+  python3 bench.py $ARGS > $OUT/new64_$i.json 2>>$OUT/err.log
 done
 for f in $OUT/*.json; do echo "$(basename $f) $(grep -o '"ms_per_step": [0-9.]*' $f) $(grep -o '"kernel_ms": [0-9.]*' $f)"; done

@@ -29,7 +29,7 @@ for _ in range(2):
     ops.sgraf_scores(img, words, plan, w, "SGR", 3)
 torch.cuda.synchronize()
 
-ROWS = int(os.environ.get("SGR_TRACE_ROWS", "32"))      # which class of groups: 32 (two workgroups per CU) or 64 (ITR_SGR_PLAN64=1)
+ROWS = int(os.environ.get("ITR_SGR_GROUP_ROWS", "64"))      # which class of groups: 64 (default) or 32 (ITR_SGR_GROUP_ROWS=32: two workgroups per CU)
 rec = np.fromfile("%s.%d" % (TRACE, ROWS), dtype=np.uint64).reshape(-1, 20)
 rec = rec[rec[:, 2] != 0]
 shape = rec[:, 1]
