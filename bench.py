@@ -324,6 +324,7 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
             cap_sorted = towers.encode_captions(toks, tok_off, lens_sorted, gather_last=True)
             send = torch.empty(max(cap_counts), cap_sorted.shape[1], device=dev, dtype=torch.float32)
             send[order_dev] = cap_sorted                     # back to the dataset order, in the head of the exchange's send buffer
+            send[cap_sorted.shape[0]:].zero_()               # (the tail -- at most a few rows -- travels with the exchange: defined values)
             if peers is not None:
                 comm.peer_blocks = {}
                 for q, p in peers.items():

@@ -993,6 +993,8 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
                              void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
                              int64_t img_count, void *bf16_ws, int f16, itr_stream_t stream);
 
+int allow_dynamic_lds(const void *kernel, size_t bytes);      // scan_train.hip
+
 int scan_scores_impl(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
                      int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
                      void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
@@ -1051,15 +1053,11 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
     const int64_t PI = ceil_div(img_tiles, 8), PJ = ceil_div(n_tiles, 8);
     const int64_t nblk = ceil_div(PI * PJ, 8) * 64 * 8;
     ITR_UNSUPPORTED(nblk > 0x7fffffffLL, "itr_scan_xattn_scores: grid too large; shard the call");
-    static bool attr_set = false;
-    if (!attr_set) {
-        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<0, 0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<0, 1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    {   // once per (kernel, device), under a mutex (scan_train.hip): a process may drive several devices
+        int rc = allow_dynamic_lds(reinterpret_cast<const void *>(scan_xattn_kernel<0, 0>), 160 * 1024);
+        if (rc == ITR_OK) rc = allow_dynamic_lds(reinterpret_cast<const void *>(scan_xattn_kernel<0, 1>), 160 * 1024);
+        if (rc == ITR_OK) rc = allow_dynamic_lds(reinterpret_cast<const void *>(scan_xattn_kernel<1>), 160 * 1024);
+        if (rc != ITR_OK) return rc;
     }
     size_t lds = sizeof(ScanSmem);
     if (const char *ex = getenv("ITR_SCAN_LDS_EXTRA")) lds += (size_t)atoi(ex);   // occupancy experiments only
@@ -1093,10 +1091,9 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
             ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipLaunchKernelGGL(scan_xattn_kernel<9>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
         } else if (f16) {
-            static bool attr3 = false;
-            if (!attr3) {
-                ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr3 = true;
+            {
+                const int rc = allow_dynamic_lds(reinterpret_cast<const void *>(scan_xattn_kernel<3>), 160 * 1024);
+                if (rc != ITR_OK) return rc;
             }
             hipLaunchKernelGGL(scan_xattn_kernel<3>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
         } else

@@ -171,18 +171,14 @@ __global__ __launch_bounds__(256, 2) void sgraf_loc_kernel(LocArgs g) {
     }
 }
 
+int allow_dynamic_lds(const void *kernel, size_t bytes);      // scan_train.hip
+
 int sgraf_loc_fused(const float *P, const float *cn, const float *img, const float *wtiled, const float *W, const float *bias,
                     float *X, int64_t nb, int64_t n_tiles, int D, hipStream_t st) {
     static_assert(sizeof(LocSmem) == 80 * 1024, "two workgroups per CU");
-    static bool attr_done = false;   // idempotent: racing callers set the same value
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sgraf_loc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(LocSmem));
-        if (e != hipSuccess) {
-            set_error("sgraf_loc: cannot reserve %zu B of LDS: %s", sizeof(LocSmem), hipGetErrorString(e));
-            return ITR_ERR_HIP;
-        }
-        attr_done = true;
+    {   // once per (kernel, device), under a mutex (scan_train.hip): a process may drive several devices
+        const int rc = allow_dynamic_lds(reinterpret_cast<const void *>(sgraf_loc_kernel), sizeof(LocSmem));
+        if (rc != ITR_OK) return rc;
     }
     if (nb == 0 || n_tiles == 0) return ITR_OK;
     LocArgs g{P, cn, img, wtiled, W, bias, X, nb, n_tiles, D, nullptr};

@@ -336,9 +336,13 @@ class GruModelEval:
             offs = [m[1 + maxcap:1 + maxcap + cap_counts[q]] for q, m in enumerate(metas)]
         maxtok = max(tok_counts)
         # -- step 1: towers (text first: it needs no image, and the first feature block may still be on its way).  The word
-        # embeddings land in the head of the send buffer of the exchange (maxtok rows; the tail is never read).
+        # embeddings land in the head of the send buffer of the exchange (maxtok rows).  The tail (at most a few rows: the owners'
+        # token counts are balanced) is zeroed: it is shipped to every rank, and a consumer that reduces over all the gathered rows
+        # (e.g. the tensor absmax of the opt-in split-precision variants) must not see uninitialised memory.
         D_emb = self.wt['rnn.weight_hh_l0'].shape[1]
         send = torch.empty(maxtok, D_emb, device=dev, dtype=torch.float32)
+        if maxtok > n_tok:
+            send[n_tok:].zero_()
         words = self.encode_captions(tokens_packed, tok_off, lengths_sorted, out=send[:n_tok])
         if torch.is_tensor(feats_local):
             blocks = [(0, feats_local.shape[0], feats_local)]
@@ -524,6 +528,7 @@ class PooledModelEval:
         else:
             send = torch.empty((maxrows,) + tuple(cap_emb.shape[1:]), device=cap_emb.device, dtype=cap_emb.dtype)
             send[:cap_emb.shape[0]] = cap_emb
+            send[cap_emb.shape[0]:].zero_()       # (the tail travels with the exchange: defined values)
         img = self.encode_images(images, boxes, imgs_wh)
         S = exchange_score(comm, img, send, ranges, n_cap_total, self._score, timers)
         row0 = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)[0]
@@ -729,6 +734,7 @@ def evaluate_precomp(model, dataset, comm=None, fold=None, batch=4096, block_row
                 counts = [hi - lo for lo, hi in ranges]
                 send = torch.empty(max(counts), cap_sorted.shape[1], device=dev, dtype=torch.float32)
                 send[torch.from_numpy(np.ascontiguousarray(order)).to(dev)] = cap_sorted      # dataset order, head of the send buffer
+                send[cap_sorted.shape[0]:].zero_()                                           # (the tail travels with the exchange)
                 # ranked with the similarity the model was trained for: criterion.sim = cosine_sim or order_sim
                 # (Objectives.py:45-50; the reference's cal_sims calls model.criterion.sim, evaluation.py:128-131)
                 if cfg.get('measure', 'cosine') == 'order':
