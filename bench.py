@@ -226,14 +226,21 @@ def bert_files(tmp):
     from itr_amd.modalmodule import bert
     os.makedirs(tmp, exist_ok=True)
     cfg_file, ckpt, trans = (os.path.join(tmp, n) for n in ("bert_config.json", "pytorch_model.bin", "trans_cfg.json"))
-    json.dump(BERT_BASE, open(cfg_file, "w"))
-    json.dump(dict(BERT_BASE, hidden_size=256, num_attention_heads=4, intermediate_size=1024), open(trans, "w"))
+    for path, obj in ((cfg_file, BERT_BASE), (trans, dict(BERT_BASE, hidden_size=256, num_attention_heads=4, intermediate_size=1024))):
+        tmp_json = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp_json, "w") as f:
+            json.dump(obj, f)
+        os.replace(tmp_json, path)
     if not os.path.exists(ckpt):
+        # several ranks may arrive here together: everyone writes its own temporary file and renames it into place (atomic; the
+        # contents are identical: seeded), nobody ever reads a half-written checkpoint
         torch.manual_seed(1)
         m = bert.BertModel(bert.BertConfig.from_dict(BERT_BASE))
         for p_ in m.parameters():
             p_.data.normal_(0, 0.02)
-        torch.save(m.state_dict(), ckpt)
+        tmp_ckpt = "%s.%d.tmp" % (ckpt, os.getpid())
+        torch.save(m.state_dict(), tmp_ckpt)
+        os.replace(tmp_ckpt, ckpt)
     return cfg_file, ckpt, trans
 
 
@@ -665,18 +672,33 @@ def main():
         # model families (/root/reference/itr/metricmodule/evaluation.py:124-153).
         others = {}
         small = os.environ.get("ITR_BENCH_OTHER") == "small"      # tests: the 1k x 5k forms only
+        t_other = time.perf_counter()
         for name, k, w in OTHER_CONFIGS:
             if small and not name.endswith("f30k1k"):
                 continue
+            # never at the price of the line itself: a config that raises is recorded and skipped on every rank (the ranks agree on
+            # it through one tiny all-reduce), and nothing more is started once these runs have taken five minutes
+            ok, err, o = 1, None, None
             a2 = argparse.Namespace(**dict(vars(args), workload=name, steps=k, warmup=w, no_cpu_baseline=True, no_variants=True))
             t0 = time.perf_counter()
-            o = run_workload(a2, world, rank, dev, use_dist, backend, primary=False)
+            try:
+                o = run_workload(a2, world, rank, dev, use_dist, backend, primary=False)
+            except Exception as e:      # noqa: BLE001
+                ok, err = 0, "%s: %s" % (type(e).__name__, e)
+            flag = torch.tensor([ok, int(time.perf_counter() - t_other < 300.0)], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            if use_dist:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if rank == 0:
-                rf = o["roofline"]
-                others[name] = {"baseline_config": BASELINE_CONFIG_OF[name], "steps": k, "warmup": w, "ms_per_step": o["ms_per_step"],
-                                "pairs_per_s": o["value"], "n_img": o["config"]["n_img"], "n_cap": o["config"]["n_cap"], "frac": rf["frac"],
-                                "achieved_tflops": rf["achieved"], "kernel_ms": rf.get("kernel_ms", rf.get("score_kernel_ms")),
-                                "recall": o["recall"], "rank_checksum": o["rank_checksum"], "wall_s": round(time.perf_counter() - t0, 2)}
+                if int(flag[0]) and o is not None:
+                    rf = o["roofline"]
+                    others[name] = {"baseline_config": BASELINE_CONFIG_OF[name], "steps": k, "warmup": w, "ms_per_step": o["ms_per_step"],
+                                    "pairs_per_s": o["value"], "n_img": o["config"]["n_img"], "n_cap": o["config"]["n_cap"], "frac": rf["frac"],
+                                    "achieved_tflops": rf["achieved"], "kernel_ms": rf.get("kernel_ms", rf.get("score_kernel_ms")),
+                                    "recall": o["recall"], "rank_checksum": o["rank_checksum"], "wall_s": round(time.perf_counter() - t0, 2)}
+                else:
+                    others[name] = {"baseline_config": BASELINE_CONFIG_OF[name], "error": err or "failed on another rank"}
+            if not int(flag[1]):
+                break
         if rank == 0:
             out["other_configs"] = others
     if rank == 0:
@@ -844,6 +866,11 @@ def main_words(args, world, rank, dev, use_dist, backend, primary=True):
                          "algorithmic_equiv_frac": alg_flop / (k_ms * 1e-3) / 1e12 / peak,
                          "note": note},
         }
+        if "exchange_wait" in timers:
+            # N > 1 (or the virtual split): time the scoring stream still had to wait for the all-gather after its own-column launch
+            out["exchange"] = {"bytes_gathered": timers["exchange_bytes"], "own_launch_ms": timers["segments"][0][0].elapsed_time(timers["segments"][0][1]),
+                               "wait_after_own_launch_ms": timers["exchange_wait"][0].elapsed_time(timers["exchange_wait"][1]),
+                               "note": "last timed step, rank 0; ~0 = the collective ran under the own-column launch"}
         if comm.virtual:
             out["virtual_split"] = "%d:%d" % (comm.cap_world, comm.cap_rank)
             out["config"]["parallelism"] = "1 process, caption axis split over %d virtual owners (this one: %d): TEST HOOK, time is not a result" % (

@@ -28,6 +28,16 @@ __global__ void gather_gt_kernel(const float *__restrict__ S, int64_t ldS, int64
     if (g >= 0 && g < nrows) s_gt[j] = S[g * ldS + j];
 }
 
+// (score, index) as ONE 64-bit key: larger score first, then the larger index -- exactly the tie rule of the counts
+// (#{S_k > S_gt} + #{k > gt : S_k == S_gt} = #{key_k > key_gt}) and of the top-1 (np.argsort(...)[::-1]: the higher index wins).
+// e + 0.0f folds -0.0 into +0.0 (they compare equal as floats, their bit patterns do not).  Round 4: the counts were five float
+// compare chains with 64-bit index compares per element (~50 vector instructions per element: the row pass was bound by the vector
+// ALU at 2.6 TB/s, not by HBM); one v_cmp_gt_u64 + one add per GT caption now, and only im_div of them (template G).
+__device__ __forceinline__ unsigned long long rank_key(float e, unsigned idx) {
+    return ((unsigned long long)float_order_key(e + 0.0f) << 32) | idx;
+}
+
+template <int G>
 __global__ __launch_bounds__(RANK_THREADS) void i2t_rank_kernel(const float *__restrict__ S, int64_t ldS,
                                                                 int64_t row0, int64_t Nc, int im_div,
                                                                 int32_t *__restrict__ rank_out,
@@ -37,17 +47,16 @@ __global__ __launch_bounds__(RANK_THREADS) void i2t_rank_kernel(const float *__r
     const int64_t r = blockIdx.x;
     const float *row = S + r * ldS;
     const int64_t gi = row0 + r;  // global image index
-    float gt[MAX_IMDIV];
-    int64_t gidx[MAX_IMDIV];
-    int cnt[MAX_IMDIV];
+    unsigned long long gkey[G];
+    int cnt[G];
 #pragma unroll
-    for (int g = 0; g < MAX_IMDIV; ++g) {
-        gidx[g] = gi * im_div + g;
-        const bool ok = g < im_div && gidx[g] < Nc;
-        gt[g] = ok ? row[gidx[g]] : INFINITY;
+    for (int g = 0; g < G; ++g) {
+        const int64_t gidx = gi * im_div + g;
+        // a GT caption past the end of the matrix: nothing is larger than its key (its count is not read)
+        gkey[g] = gidx < Nc ? rank_key(row[gidx], (unsigned)gidx) : ~0ull;
         cnt[g] = 0;
     }
-    unsigned long long best = 0;  // (ordered score << 32) | index ; max => highest index on ties
+    unsigned long long best = 0;  // max => highest index on ties
     const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
     const int64_t nvec = vec ? (Nc >> 2) : 0;
     for (int64_t c = threadIdx.x; c < nvec; c += RANK_THREADS) {
@@ -55,24 +64,21 @@ __global__ __launch_bounds__(RANK_THREADS) void i2t_rank_kernel(const float *__r
         const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int64_t k = c * 4 + u;
-            const unsigned long long key = ((unsigned long long)float_order_key(e[u]) << 32) | (unsigned)k;
+            const unsigned long long key = rank_key(e[u], (unsigned)(c * 4 + u));
             best = key > best ? key : best;
 #pragma unroll
-            for (int g = 0; g < MAX_IMDIV; ++g)
-                cnt[g] += (e[u] > gt[g]) || (e[u] == gt[g] && k > gidx[g]);
+            for (int g = 0; g < G; ++g) cnt[g] += key > gkey[g];
         }
     }
     for (int64_t k = nvec * 4 + threadIdx.x; k < Nc; k += RANK_THREADS) {
-        const float e = row[k];
-        const unsigned long long key = ((unsigned long long)float_order_key(e) << 32) | (unsigned)k;
+        const unsigned long long key = rank_key(row[k], (unsigned)k);
         best = key > best ? key : best;
 #pragma unroll
-        for (int g = 0; g < MAX_IMDIV; ++g) cnt[g] += (e > gt[g]) || (e == gt[g] && k > gidx[g]);
+        for (int g = 0; g < G; ++g) cnt[g] += key > gkey[g];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int g = 0; g < MAX_IMDIV; ++g) cnt[g] = wave_sum_i(cnt[g]);
+    for (int g = 0; g < G; ++g) cnt[g] = wave_sum_i(cnt[g]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(best, o, 64);
@@ -80,13 +86,13 @@ __global__ __launch_bounds__(RANK_THREADS) void i2t_rank_kernel(const float *__r
     }
     if (lane == 0) {
 #pragma unroll
-        for (int g = 0; g < MAX_IMDIV; ++g) s_cnt[wave][g] = cnt[g];
+        for (int g = 0; g < G; ++g) s_cnt[wave][g] = cnt[g];
         s_best[wave] = best;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         int rank = 0x7fffffff;
-        for (int g = 0; g < im_div; ++g) {
+        for (int g = 0; g < G; ++g) {
             if (gi * im_div + g >= Nc) break;
             int t = 0;
             for (int w = 0; w < RANK_THREADS / 64; ++w) t += s_cnt[w][g];
@@ -111,15 +117,12 @@ __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__r
     const int64_t r_begin = (int64_t)blockIdx.y * T2I_ROWS;
     const int64_t r_end = (r_begin + T2I_ROWS < nrows) ? r_begin + T2I_ROWS : nrows;
     const int ncol = (Nc - c0 >= 4) ? 4 : (int)(Nc - c0);
-    float gt[4];
-    int64_t gimg[4];
+    unsigned long long gkey[4];
     int cnt[4] = {0, 0, 0, 0};
     unsigned long long best[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        gt[u] = u < ncol ? s_gt[c0 + u] : INFINITY;
-        gimg[u] = (c0 + u) / im_div;
-    }
+    for (int u = 0; u < 4; ++u)      // (score of the GT image, its row): a row counts when its key is larger (rank_key: the tie rule)
+        gkey[u] = u < ncol ? rank_key(s_gt[c0 + u], (unsigned)((c0 + u) / im_div)) : ~0ull;
     const bool vec = (ncol == 4) && ((ldS & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
     for (int64_t r = r_begin; r < r_end; ++r) {
         const float *p = S + r * ldS + c0;
@@ -131,11 +134,11 @@ __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__r
 #pragma unroll
             for (int u = 0; u < 4; ++u) e[u] = u < ncol ? p[u] : -INFINITY;
         }
-        const int64_t gr = row0 + r;
+        const unsigned gr = (unsigned)(row0 + r);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            cnt[u] += (e[u] > gt[u]) || (e[u] == gt[u] && gr > gimg[u]);
-            const unsigned long long key = ((unsigned long long)float_order_key(e[u]) << 32) | (unsigned)gr;
+            const unsigned long long key = rank_key(e[u], gr);
+            cnt[u] += key > gkey[u];
             best[u] = key > best[u] ? key : best[u];
         }
     }
@@ -376,8 +379,12 @@ extern "C" int itr_rank_counts(const float *S, int64_t ldS, int64_t row0, int64_
     ITR_REQUIRE(Nc < 0x7fffffffLL && row0 + n_rows_local < 0x7fffffffLL, "itr_rank_counts: index overflow");
     if (Nc == 0 || n_rows_local == 0) return ITR_OK;
     hipStream_t st = itr::as_stream(stream);
-    hipLaunchKernelGGL(itr::i2t_rank_kernel, dim3((unsigned)n_rows_local), dim3(itr::RANK_THREADS), 0, st, S,
-                       ldS, row0, Nc, im_div, i2t_rank, i2t_top1);
+    switch (im_div) {      // the row pass keeps one counter per GT caption of the image: exactly im_div of them
+#define ITR_I2T(G) case G: hipLaunchKernelGGL(itr::i2t_rank_kernel<G>, dim3((unsigned)n_rows_local), dim3(itr::RANK_THREADS), 0, st, S, \
+                                             ldS, row0, Nc, im_div, i2t_rank, i2t_top1); break;
+        ITR_I2T(1) ITR_I2T(2) ITR_I2T(3) ITR_I2T(4) ITR_I2T(5) ITR_I2T(6) ITR_I2T(7) ITR_I2T(8)
+#undef ITR_I2T
+    }
     ITR_CHECK_LAUNCH("i2t_rank");
     dim3 grid((unsigned)itr::ceil_div(Nc, (int64_t)itr::RANK_THREADS * 4),
               (unsigned)itr::ceil_div(n_rows_local, itr::T2I_ROWS));

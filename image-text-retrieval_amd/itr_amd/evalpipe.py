@@ -404,7 +404,16 @@ class GruModelEval:
                 c0, c1 = ranges[kr]
                 if c1 > c0:
                     plan = score(img, 'own', words, off_loc, len_loc, S[r0:r1, c0:c1])
+                if timers is not None:
+                    # how long the current stream still waits for the exchange AFTER the own-column launch has finished: ~0 when the
+                    # collective made progress under the scoring grid, ~ its stand-alone time when it was starved of CUs
+                    ex = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ex[0].record()
                 wait()
+                if timers is not None:
+                    ex[1].record()
+                    timers['exchange_wait'] = ex
+                    timers['exchange_bytes'] = int(words_all.numel()) * 4
                 waited = True
                 for key, lo, hi in (('left', 0, c0), ('right', c1, n_cap_total)):
                     if hi > lo:

@@ -198,7 +198,7 @@ def _bench_line(args, env=None, launcher=None, timeout=900):
 
 
 def _base_args(workload):
-    return ["--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-variants"]
+    return ["--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-variants", "--no-other-configs"]
 
 
 @pytest.mark.gpu
@@ -292,6 +292,20 @@ def test_other_configs_ride_along_with_the_default_line():
     for name, o in oc.items():
         assert o["ms_per_step"] > 0 and o["pairs_per_s"] > 0 and 0 < o["frac"] < 1 and len(o["rank_checksum"]) == 4, name
     assert oc["scan_t2i_f30k1k"]["rank_checksum"] == _bench_line(_base_args("scan_t2i_f30k1k"))["rank_checksum"]
+    # the same with two ranks (started by bench.py itself; gloo: they share the GPU): every config runs sharded, same rank vectors
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-variants"], env=dict(env, ITR_DIST_BACKEND="gloo", ITR_BENCH_OTHER="small"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    two = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert two["n_gpus"] == 2 and two["rank_checksum"] == out["rank_checksum"]
+    for name, o in two["other_configs"].items():
+        assert "error" not in o, (name, o)
+        assert o["rank_checksum"] == oc[name]["rank_checksum"], name
 
 
 @pytest.mark.gpu

@@ -27,7 +27,18 @@ args = ap.parse_args()
 wl = bench.WORKLOADS[args.workload]
 dev = torch.device("cuda", 0)
 n_img, n_cap = wl["n_img"], 5 * wl["n_img"]
-cfg = dict(wl, bi_gru=True, no_txtnorm=True, no_imgnorm=False)
+is_sgraf = "sgraf" in wl                  # BASELINE config [4]: SGRAF (the 8-GPU config) -- the same order of work, its own scorer
+cfg = dict(wl, bi_gru=True, no_txtnorm=not is_sgraf, no_imgnorm=False)
+sim_w = {k: v.to(dev) for k, v in bench.make_sgraf_weights(wl["sgraf"]).items()} if is_sgraf else None
+
+
+def score(img, words_t, off, lens, out):
+    plan = ops.ScanPlan(off, lens, words_t.shape[0], dev)
+    if is_sgraf:
+        ops.sgraf_scores(img, words_t, plan, sim_w, wl["sgraf"], 3, out=out)
+    else:
+        ws = ops.scan_prepare(img, words_t, plan, "t2i")
+        ops.scan_xattn_scores(img, words_t, plan, cross_attn="t2i", workspace=ws, out=out)
 wi, wt = bench.make_weights(wl["vocab"])
 g = torch.Generator(device=dev); g.manual_seed(0)
 feats = ops.l2norm(torch.randn(n_img, 36, 2048, device=dev, generator=g))
@@ -36,6 +47,8 @@ P = args.shard
 i0, i1 = evalpipe.block_range(n_img, P, 0, 4)
 ranges = evalpipe.caption_ranges(n_cap, P, lengths)
 c0, c1 = ranges[0]
+if is_sgraf:
+    cfg.update(module_name=wl["sgraf"], sgr_step=3)
 model = evalpipe.GruModelEval({k: v.to(dev) for k, v in wi.items()}, {k: v.to(dev) for k, v in wt.items()}, cfg)
 feats_local = feats[i0:i1].contiguous()
 toks, tok_off, lens_sorted, order = bench.shard_captions(lengths, tokens, c0, c1, dev)
@@ -56,14 +69,10 @@ def staged():
     ls_loc = np.zeros(c1 - c0, np.int64); off_loc = np.zeros(c1 - c0, np.int64)
     lsrt = np.asarray(lens_sorted, np.int64)
     ls_loc[np.asarray(order)] = lsrt; off_loc[np.asarray(order)] = np.concatenate([[0], np.cumsum(lsrt)[:-1]])
-    plan = ops.ScanPlan(off_loc, ls_loc, words.shape[0], dev)
-    ws = ops.scan_prepare(img, words, plan, "t2i")
-    ops.scan_xattn_scores(img, words, plan, cross_attn="t2i", workspace=ws, out=S[:, c0:c1]); t.append(sync())
+    score(img, words, off_loc, ls_loc, S[:, c0:c1]); t.append(sync())
     # stand-in for the gathered buffer: the full packed word matrix (encoded once outside the timing)
     if c1 < n_cap:
-        plan = ops.ScanPlan(cap_off_all[c1:], cap_len_all[c1:], words_all.shape[0], dev)
-        ws = ops.scan_prepare(img, words_all, plan, "t2i")
-        ops.scan_xattn_scores(img, words_all, plan, cross_attn="t2i", workspace=ws, out=S[:, c1:])
+        score(img, words_all, cap_off_all[c1:], cap_len_all[c1:], S[:, c1:])
     t.append(sync())
     r = evalpipe.finalize_ranks(evalpipe.Comm(), S, 0, n_img if P == 1 else (i1 - i0)); t.append(sync())
     return np.diff(t) * 1e3
@@ -93,7 +102,7 @@ if P > 1:
 
 if P == 1:
     def step():
-        model.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap)
+        model.scan_eval(feats_local, toks, tok_off, lens_sorted, order, n_img, n_cap, sgraf_weights=sim_w)
     step()
     t0 = sync(); step(); t1 = sync()
     print("unstaged step: %.1f ms" % ((t1 - t0) * 1e3))
