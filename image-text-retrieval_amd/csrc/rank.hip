@@ -124,7 +124,30 @@ __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__r
     for (int u = 0; u < 4; ++u)      // (score of the GT image, its row): a row counts when its key is larger (rank_key: the tie rule)
         gkey[u] = u < ncol ? rank_key(s_gt[c0 + u], (unsigned)((c0 + u) / im_div)) : ~0ull;
     const bool vec = (ncol == 4) && ((ldS & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
-    for (int64_t r = r_begin; r < r_end; ++r) {
+    auto take = [&](const float (&e)[4], int64_t r) {
+        const unsigned gr = (unsigned)(row0 + r);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long key = rank_key(e[u], gr);
+            cnt[u] += key > gkey[u];
+            best[u] = key > best[u] ? key : best[u];
+        }
+    };
+    int64_t r = r_begin;
+    if (vec) {
+        // eight rows (100 KB apart) requested before the first is used: the column pass is latency-bound otherwise (round 3: 3.9 TB/s)
+        for (; r + 8 <= r_end; r += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4 *>(S + (r + q) * ldS + c0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                take(e, r + q);
+            }
+        }
+    }
+    for (; r < r_end; ++r) {
         const float *p = S + r * ldS + c0;
         float e[4];
         if (vec) {
@@ -134,13 +157,7 @@ __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__r
 #pragma unroll
             for (int u = 0; u < 4; ++u) e[u] = u < ncol ? p[u] : -INFINITY;
         }
-        const unsigned gr = (unsigned)(row0 + r);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned long long key = rank_key(e[u], gr);
-            cnt[u] += key > gkey[u];
-            best[u] = key > best[u] ? key : best[u];
-        }
+        take(e, r);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
