@@ -221,8 +221,13 @@ __device__ __forceinline__ void sf_kblock(unsigned baddr, const float4 *const (&
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (KS < 15) {
+#ifdef SF_EXP_SAME_BLOCK      // timing experiment (tools/ab_build.sh): every k-block re-reads the weights of block 0 (L1 hits; results are garbage)
+        SF_GLOAD(n0, wp[0][0], 0);
+        SF_GLOAD(n1, wp[1][0], 0);
+#else
         SF_GLOAD(n0, wp[0][(KS + 1) / 4], ((KS + 1) % 4) * 1024);
         SF_GLOAD(n1, wp[1][(KS + 1) / 4], ((KS + 1) % 4) * 1024);
+#endif
         SF_LREAD(nb[0], baddr, 64 * (KS + 1));
         if constexpr (NG > 1) SF_LREAD(nb[1], baddr, 16 * SF_LD * 4 + 64 * (KS + 1));
         if constexpr (NG > 2) SF_LREAD(nb[2], baddr, 2 * 16 * SF_LD * 4 + 64 * (KS + 1));
