@@ -101,6 +101,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// One GRU cell update, gate order (r, z, n) of torch.nn.GRU (TextEncoder.py:38-70 runs nn.GRU):
+//   r = s(gi_r + gh_r); z = s(gi_z + gh_z); n = tanh(gi_n + r * gh_n); h' = (1 - z) * n + z * h
+// THE definition of the evaluation forward: the stand-alone gate kernel (towers.hip) and the gate epilogue of the recurrence GEMM
+// (gemm_f32.hip) both call it, with explicit fmaf -- hipcc is otherwise free to contract "a * b + c * d" either way, and the two
+// paths (and with them a sharded and a single-process evaluation) must agree bit for bit.
+__device__ __forceinline__ float gru_cell(float ir, float iz, float in, float hr, float hz, float hn, float hp) {
+    const float r = 1.f / (1.f + expf(-(ir + hr)));
+    const float z = 1.f / (1.f + expf(-(iz + hz)));
+    const float n = tanhf(fmaf(r, hn, in));
+    return fmaf(z, hp, (1.f - z) * n);
+}
+
 // Order-preserving map float -> uint32 (larger float <=> larger key).
 __device__ __forceinline__ uint32_t float_order_key(float f) {
     uint32_t u = __float_as_uint(f);

@@ -626,7 +626,6 @@ __device__ __forceinline__ void sf_last_attend(const float *__restrict__ xb, con
     for (int a = 0; a < NTC; ++a) { e[a] = fast_exp(e[a] - mx); den += e[a]; }       // (exp(-inf) = 0 for the keys past the graph)
     const float inv = fast_rcp(sf_row16_sum(den));
     float4 y{0.f, 0.f, 0.f, 0.f};
-#pragma unroll UNR
     for (int n = 0; n < nn; ++n) {                                                   // (n is wave-uniform)
         float pv = e[0];
 #pragma unroll
