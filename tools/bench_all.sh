@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): every bench workload once -> gpurun_out/bench_<tag>/<workload>.json, kernel stats for the pooled ones.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/bench_$TAG
 mkdir -p $OUT
 cd /tmp 2>/dev/null; cd - >/dev/null
