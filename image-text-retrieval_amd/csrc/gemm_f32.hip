@@ -45,18 +45,7 @@ struct GemmArgs {
     // towers.hip): tiles [ntile, 2 ntile) of the persistent tile order read A2 / B2 / bias2 and write C2
     const float *A2, *B2, *bias2;
     float *C2;
-    // optional GRU-gate epilogue (round 4; towers.hip: one time step of the recurrence in ONE launch).  A = h_in [M][D] (the state of
-    // the still-active captions), B = the recurrent weight with its rows PERMUTED so that a 128-column tile holds the r, z and n
-    // pre-activations of the same GRU_TILE_UNITS hidden units (gru_permute_whh_kernel), bias permuted alike.  The epilogue stages the
-    // tile in LDS and runs the cell update there: gh never goes to memory, and the gate kernel's launch -- and the
-    // GEMM -> gates -> GEMM bubbles of a 40-launch chain -- are gone.  gru_gi != nullptr selects it; C is not written.
-    const float *gru_gi;            // [n_tok][3 D] input pre-activations
-    float *gru_hout, *gru_out;      // new state [M][D] (NOT the buffer A reads), sequence output [n_tok][D]
-    const int64_t *gru_tok_off;
-    const int32_t *gru_len;
-    int gru_t, gru_rev, gru_D;
 };
-constexpr int GRU_TILE_UNITS = 42;   // 3 gates x 42 units = 126 of a tile's 128 columns
 
 template <bool ALIGNED>
 __device__ __forceinline__ float4 load4(const float *base, int64_t row, int64_t nrows, int64_t ld,
@@ -81,48 +70,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2
                                               int64_t m0, int64_t n0, int64_t m_end) {
     float4(*lds)[2][NPLANE][BM] = reinterpret_cast<float4(*)[2][NPLANE][BM]>(lds_raw);
     // ---- epilogue ---------------------------------------------------------------------
-    if (g.gru_gi) {
-        // GRU gates on the tile: columns [0, 42) = gh_r, [42, 84) = gh_z, [84, 126) = gh_n of hidden units u0 .. u0 + 41
-        __syncthreads();
-        float *tile = reinterpret_cast<float *>(&lds[0][0][0][0]);  // [128][128]
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    tile[row * BN + col] = acc[i][j][r];
-                }
-            }
-        __syncthreads();
-        constexpr int GU = GRU_TILE_UNITS;
-        const int D = g.gru_D;
-        const int64_t u0 = (n0 / BN) * GU;
-        const int nrow = (int)(m_end - m0);
-        const float *bt = g.bias + n0;
-        for (int idx = tid; idx < nrow * (GU / 2); idx += GEMM_THREADS) {      // one thread per (caption, pair of hidden units)
-            const int rl = idx / (GU / 2), ul = 2 * (idx % (GU / 2));
-            const int64_t u = u0 + ul;
-            if (u >= D) continue;                                               // (D is even: the pair is inside or outside)
-            const int64_t b = m0 + rl;
-            const int64_t row = g.gru_tok_off[b] + (g.gru_rev ? (g.gru_len[b] - 1 - g.gru_t) : g.gru_t);
-            const float *gir = g.gru_gi + row * 3 * D + u;
-            const float2 ir = *reinterpret_cast<const float2 *>(gir), iz = *reinterpret_cast<const float2 *>(gir + D);
-            const float2 in = *reinterpret_cast<const float2 *>(gir + 2 * D);
-            const float2 hp = *reinterpret_cast<const float2 *>(g.A + b * g.lda + u);
-            const float *tr = tile + rl * BN + ul;
-            // gh = acc + bias: the value the separate GEMM would have stored
-            float2 hn;
-            hn.x = gru_cell(ir.x, iz.x, in.x, tr[0] + bt[ul], tr[GU] + bt[GU + ul], tr[2 * GU] + bt[2 * GU + ul], hp.x);
-            hn.y = gru_cell(ir.y, iz.y, in.y, tr[1] + bt[ul + 1], tr[GU + 1] + bt[GU + ul + 1], tr[2 * GU + 1] + bt[2 * GU + ul + 1], hp.y);
-            *reinterpret_cast<float2 *>(g.gru_hout + b * D + u) = hn;
-            *reinterpret_cast<float2 *>(g.gru_out + row * D + u) = hn;
-        }
-        __syncthreads();     // the persistent loop's next tile overwrites the LDS block
-        return;
-    }
     if (g.group <= 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -481,35 +428,6 @@ int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const floa
         return launch_gemm(gt, st);
     }
     GemmArgs g{A, B, bias, C, lda, ldb, ldc, M, N, K, act, 1, BM, nullptr, nullptr, 0, 0, 0, nullptr};
-    return launch_gemm(g, st);
-}
-
-// ---- GRU recurrence with the gates in the epilogue -------------------------------------------------------------------
-// W_hh [3 D][D] (rows r | z | n) -> Wp [tiles x 128][D]: tile t holds rows r, z, n of hidden units 42 t .. 42 t + 41 (zero rows
-// where the unit does not exist and in the two spare columns); bias alike.
-__global__ __launch_bounds__(256) void gru_permute_whh_kernel(const float *__restrict__ W, const float *__restrict__ bias, int D, float *__restrict__ Wp,
-                                                              float *__restrict__ bp) {
-    const int64_t rowp = blockIdx.x;                 // output row = tile * 128 + column inside the tile
-    const int c = (int)(rowp % BN), gate = c / GRU_TILE_UNITS, ul = c % GRU_TILE_UNITS;
-    const int64_t u = (rowp / BN) * GRU_TILE_UNITS + ul;
-    const bool live = gate < 3 && u < D;
-    const float *src = W + ((int64_t)gate * D + u) * D;
-    for (int k = threadIdx.x; k < D; k += 256) Wp[rowp * D + k] = live ? src[k] : 0.f;
-    if (threadIdx.x == 0) bp[rowp] = live ? bias[(int64_t)gate * D + u] : 0.f;
-}
-int64_t gru_gate_gemm_cols(int D) { return ceil_div((int64_t)D, (int64_t)GRU_TILE_UNITS) * BN; }
-// the shapes the fused step takes: the fast kernel's (K = D a multiple of 32, 16-byte rows) and an even D (8-byte pair accesses)
-bool gru_gate_gemm_ok(int D) { return D % BK == 0 && D >= BK && (uint64_t)D * 4u * BM < (1ull << 32); }
-int gru_permute_whh(const float *W, const float *bias, int D, float *Wp, float *bp, hipStream_t st) {
-    hipLaunchKernelGGL(gru_permute_whh_kernel, dim3((unsigned)gru_gate_gemm_cols(D)), dim3(256), 0, st, W, bias, D, Wp, bp);
-    ITR_CHECK_LAUNCH("gru_permute_whh");
-    return ITR_OK;
-}
-// One time step for the active prefix [0, n_act): h_out = cell(gi[row(b, t)], h_in W_hh^T + b_hh, h_in), out[row] = h_out.
-int gemm_nt_gru_step(const float *h_in, const float *Wp, const float *bp, int64_t n_act, int D, const float *gi, float *h_out, float *out,
-                     const int64_t *tok_off, const int32_t *len, int t, int reverse, hipStream_t st) {
-    GemmArgs g{h_in, Wp, bp, nullptr, D, D, 0, n_act, gru_gate_gemm_cols(D), D, 0, 1, BM, nullptr, nullptr, 0, 0, 0, nullptr,
-               nullptr, nullptr, nullptr, nullptr, gi, h_out, out, tok_off, len, t, reverse, D};
     return launch_gemm(g, st);
 }
 

@@ -18,12 +18,6 @@ int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const floa
             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
 // the two directions of a bi-GRU time step in one launch (gemm_f32.hip)
 bool gemm_pair_ok(int64_t lda, int64_t ldb, int64_t K);
-// the recurrence with the gates in the GEMM's epilogue (gemm_f32.hip)
-int64_t gru_gate_gemm_cols(int D);
-bool gru_gate_gemm_ok(int D);
-int gru_permute_whh(const float *W, const float *bias, int D, float *Wp, float *bp, hipStream_t st);
-int gemm_nt_gru_step(const float *h_in, const float *Wp, const float *bp, int64_t n_act, int D, const float *gi, float *h_out, float *out,
-                     const int64_t *tok_off, const int32_t *len, int t, int reverse, hipStream_t st);
 int gemm_nt_pair(const float *A, const float *A2, int64_t lda, const float *B, const float *B2, int64_t ldb, const float *bias, const float *bias2,
                  float *C, float *C2, int64_t ldc, int64_t M, int64_t N, int64_t K, hipStream_t st);
 int norm_rows(const float *x, float *y, int64_t rows, int dim, float eps, int kind, int take_abs,
@@ -165,10 +159,9 @@ static bool side_stream(SideStream &s) {
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GruWs {
-    float *x, *gi, *gh, *h, *out_tmp, *wpad, *skbuf, *wperm, *bperm;
+    float *x, *gi, *gh, *h, *out_tmp, *wpad, *skbuf;
     int *bad;
 };
-static inline size_t gru_wperm_bytes(int D) { return gru_gate_gemm_ok(D) ? (size_t)gru_gate_gemm_cols(D) * (size_t)(D + 1) * 4 : 0; }
 
 // split-K scratch only for batches that need it (<= 1024 captions: 16 slices x B x 3D floats <= 200 MB)
 static inline size_t gru_splitk_bytes(int64_t B, int D) { return B <= 1024 ? gemm_splitk_scratch_bytes(B, 3 * D, 16) : 0; }
@@ -185,9 +178,6 @@ static GruWs carve(void *ws, int64_t n_tok, int64_t B, int E, int D) {
     w.out_tmp = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * D * 4);
     w.wpad = reinterpret_cast<float *>(p); p += al256((size_t)3 * D * pad32(E) * 4);
     w.skbuf = reinterpret_cast<float *>(p); p += al256(gru_splitk_bytes(B, D));
-    w.wperm = reinterpret_cast<float *>(p);                                   // the recurrent weight in gate-tile order + its bias
-    w.bperm = w.wperm + (gru_gate_gemm_ok(D) ? (size_t)gru_gate_gemm_cols(D) * D : 0);
-    p += al256(gru_wperm_bytes(D));
     w.bad = reinterpret_cast<int *>(p);
     return w;
 }
@@ -214,7 +204,7 @@ static size_t gru_ws_one(int64_t n_tok, int64_t B, int E, int D) {
     using itr::al256;
     return al256((size_t)n_tok * itr::pad32(E) * 4) + al256((size_t)n_tok * 3 * D * 4) + al256((size_t)B * 3 * D * 4) +
            al256((size_t)B * D * 4) + al256((size_t)n_tok * D * 4) + al256((size_t)3 * D * itr::pad32(E) * 4) +
-           al256(itr::gru_splitk_bytes(B, D)) + al256(itr::gru_wperm_bytes(D)) + 256;
+           al256(itr::gru_splitk_bytes(B, D)) + 256;
 }
 
 extern "C" size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional) {
@@ -313,12 +303,9 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
         ITR_CHECK_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
         side->forked = true;
     }
-    // ITR_GRU_FUSED_GATES=1 (round 4, an experiment that did not win): the gates in the recurrence GEMM's epilogue, ONE launch per time
-    // step (possible whenever the step is one plain GEMM of a shape the fast kernel takes).  Bit-identical outputs, but no faster: VSE++
-    // 1k x 5k 10.13 ms against 10.06 for GEMM + gate kernel, the 5k x 25k SCAN step 973.5 against 970.0 (same box) -- with two streams
-    // the gate kernels already run inside the other direction's GEMM, and in the epilogue their 14 dependent memory operations per
-    // (caption, unit pair) sit on the tile's critical path (profiles/r04/NOTES.md).
-    const bool fused_gates = !paired && splits_h == 1 && gru_gate_gemm_ok(D) && getenv("ITR_GRU_FUSED_GATES") != nullptr;
+    // (Round 4 measured the gates in the recurrence GEMM's epilogue -- one launch per time step, bit-identical -- and removed it again:
+    // VSE++ 1k x 5k 10.13 ms against 10.06 for GEMM + gate kernel, and the larger argument block cost the plain GEMM 0.4 %;
+    // profiles/r04/NOTES.md 4b, commit "GRU: gates in the recurrence GEMM's epilogue".)
     auto directions = [&]() -> int {
         for (int dir = 0; dir < (paired ? 0 : bi ? 2 : 1); ++dir) {
             const float *wh = dir ? w_hh_rev : w_hh, *bh = dir ? b_hh_rev : b_hh;
@@ -328,22 +315,6 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             int rc = ITR_OK;
             if (!input_first && (rc = input_projection(dir, sd)) != ITR_OK) return rc;
             int64_t n_act = B;
-            if (fused_gates) {
-                // Opt-in (see fused_gates above): one launch per time step -- the recurrence GEMM with the cell update in its epilogue (gemm_f32.hip).  The
-                // state ping-pongs between ww.h and the (now unused) gh buffer: a tile reads ALL of h_in's columns while another tile
-                // of the same rows already writes its 42 units of the new state.  Same arithmetic per element as GEMM + gate kernel
-                // (gru_cell): bit-identical outputs (tests run both forms).
-                rc = gru_permute_whh(wh, bh, D, ww.wperm, ww.bperm, sd);
-                if (rc != ITR_OK) return rc;
-                float *h_cur = ww.h, *h_nxt = ww.gh;
-                for (int t = 0; t < Lmax; ++t) {
-                    while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
-                    rc = gemm_nt_gru_step(h_cur, ww.wperm, ww.bperm, n_act, D, ww.gi, h_nxt, dst, tok_off, len_dev, t, dir, sd);
-                    if (rc != ITR_OK) return rc;
-                    float *tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
-                }
-                continue;
-            }
             for (int t = 0; t < Lmax; ++t) {
                 while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
                 rc = (splits_h > 1) ? gemm_nt_splitk(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, ww.skbuf, sd)

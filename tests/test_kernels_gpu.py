@@ -618,8 +618,7 @@ def test_bigru_launch_forms_are_bit_identical(dev, monkeypatch, V, E, D, B, lo, 
     kw = dict(batch_invariant=True) if B <= 1024 else {}          # small batches take the paired form only without split-K
     got = ops.gru_encode(toks, off, lengths, wd, True, **kw)
     got_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, **kw)
-    # (round 4) ITR_GRU_FUSED_GATES=1: the gates in the recurrence GEMM's epilogue, one launch per time step
-    for env in ("ITR_GRU_PAIRED", "ITR_GRU_INPUT_AFTER_FORK", "ITR_GRU_FUSED_GATES"):
+    for env in ("ITR_GRU_PAIRED", "ITR_GRU_INPUT_AFTER_FORK"):
         monkeypatch.setenv(env, "1")
         two = ops.gru_encode(toks, off, lengths, wd, True, **kw)
         two_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, **kw)
@@ -630,39 +629,6 @@ def test_bigru_launch_forms_are_bit_identical(dev, monkeypatch, V, E, D, B, lo, 
     o = 0
     for b in range(n):
         assert maxdiff(got[o:o + lengths[b]].cpu(), want[b, :lengths[b]]) <= 5e-6
-        o += lengths[b]
-
-
-@pytest.mark.parametrize("bi", [False, True])
-@pytest.mark.parametrize("V,E,D,B,lo,hi", [(300, 48, 64, 37, 1, 11), (300, 32, 96, 200, 2, 30), (500, 300, 1024, 2600, 4, 22), (200, 20, 1056, 9, 1, 5)])
-def test_gru_gate_epilogue_equals_gate_kernel(dev, monkeypatch, bi, V, E, D, B, lo, hi):
-    """Round 4 (opt-in, ITR_GRU_FUSED_GATES=1: measured no faster): one launch per GRU time step -- the recurrence GEMM with the cell update
-    in its epilogue (42 hidden units x (r, z, n) per 128-column tile of the permuted weight, csrc/gemm_f32.hip) -- against the default
-    GEMM + gate-kernel chain: the same fmaf chain
-    and the same gru_cell per element, so the outputs are bit-identical.  D = 64 / 96 (2 / 3 tiles, the last one partly empty), 1024
-    (the BASELINE width: 25 tiles), 1056 (exactly 25.14 -> 26 tiles); batches of 9 .. 2 600 captions; uni- and bi-directional."""
-    rng = np.random.RandomState(D + B)
-    torch.manual_seed(D + B)
-    lengths = sorted([int(x) for x in rng.randint(lo, hi + 1, size=B)], reverse=True)
-    ids = torch.from_numpy(rng.randint(0, V, size=(B, max(lengths))))
-    rnn = torch.nn.GRU(E, D, 1, batch_first=True, bidirectional=bi)
-    w = {'embed.weight': torch.empty(V, E).uniform_(-0.1, 0.1)}
-    w.update({'rnn.' + k: v.detach() for k, v in rnn.state_dict().items()})
-    wd = {k: v.to(dev) for k, v in w.items()}
-    toks, off = pack(ids, lengths, dev)
-    kw = dict(batch_invariant=True)
-    chain = ops.gru_encode(toks, off, lengths, wd, bi, **kw)
-    chain_last = ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True, **kw)
-    monkeypatch.setenv("ITR_GRU_FUSED_GATES", "1")
-    fused = ops.gru_encode(toks, off, lengths, wd, bi, **kw)
-    fused_last = ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True, **kw)
-    monkeypatch.delenv("ITR_GRU_FUSED_GATES")
-    assert torch.equal(fused, chain) and torch.equal(fused_last, chain_last)
-    n = min(B, 12)
-    want, _ = O.encoder_text(ids[:n], lengths[:n], w, bi, False, False, None)
-    o = 0
-    for b in range(n):
-        assert maxdiff(fused[o:o + lengths[b]].cpu(), want[b, :lengths[b]]) <= 5e-6
         o += lengths[b]
 
 
