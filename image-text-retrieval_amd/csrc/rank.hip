@@ -133,21 +133,9 @@ __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__r
             best[u] = key > best[u] ? key : best[u];
         }
     };
-    int64_t r = r_begin;
-    if (vec) {
-        // eight rows (100 KB apart) requested before the first is used: the column pass is latency-bound otherwise (round 3: 3.9 TB/s)
-        for (; r + 8 <= r_end; r += 8) {
-            float4 v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4 *>(S + (r + q) * ldS + c0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-                take(e, r + q);
-            }
-        }
-    }
-    for (; r < r_end; ++r) {
+    // (round 4: eight row loads in flight per lane, requested before the first is used, were SLOWER -- 146.8 against 127.7 us at
+    // 5k x 25k: the pass is not latency-bound per lane; 64 rows x 25 column blocks already give the chip 1 975 independent workgroups)
+    for (int64_t r = r_begin; r < r_end; ++r) {
         const float *p = S + r * ldS + c0;
         float e[4];
         if (vec) {
