@@ -105,54 +105,68 @@ __global__ __launch_bounds__(RANK_THREADS) void i2t_rank_kernel(const float *__r
     }
 }
 
-constexpr int T2I_ROWS = 64;  // image rows per workgroup
+constexpr int T2I_ROWS = 16;   // image rows per workgroup
+constexpr int T2I_QUADS = 4;   // float4 column groups per lane, 1 024 columns apart: a workgroup reads 16 KB CONTIGUOUS per row
 
+// Column pass.  Round 4: a workgroup covers 4 096 consecutive columns x 16 rows (lane t owns columns 1024 q + 4 t .. + 3 of the block for
+// q = 0..3) instead of 1 024 columns x 64 rows: the same bytes per workgroup, but 16 KB instead of 4 KB contiguous per row (rows are
+// 100 KB apart) and four independent 16-byte loads per lane and row.
 __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__restrict__ S, int64_t ldS,
                                                                 int64_t row0, int64_t nrows, int64_t Nc,
                                                                 int im_div, const float *__restrict__ s_gt,
                                                                 int32_t *__restrict__ rank_acc,
                                                                 unsigned long long *__restrict__ best_acc) {
-    const int64_t c0 = ((int64_t)blockIdx.x * RANK_THREADS + threadIdx.x) * 4;
-    if (c0 >= Nc) return;
+    const int64_t cb = (int64_t)blockIdx.x * (RANK_THREADS * 4 * T2I_QUADS) + threadIdx.x * 4;
     const int64_t r_begin = (int64_t)blockIdx.y * T2I_ROWS;
     const int64_t r_end = (r_begin + T2I_ROWS < nrows) ? r_begin + T2I_ROWS : nrows;
-    const int ncol = (Nc - c0 >= 4) ? 4 : (int)(Nc - c0);
-    unsigned long long gkey[4];
-    int cnt[4] = {0, 0, 0, 0};
-    unsigned long long best[4] = {0, 0, 0, 0};
+    unsigned long long gkey[T2I_QUADS][4], best[T2I_QUADS][4];
+    int cnt[T2I_QUADS][4];
+    int ncol[T2I_QUADS];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)      // (score of the GT image, its row): a row counts when its key is larger (rank_key: the tie rule)
-        gkey[u] = u < ncol ? rank_key(s_gt[c0 + u], (unsigned)((c0 + u) / im_div)) : ~0ull;
-    const bool vec = (ncol == 4) && ((ldS & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
-    auto take = [&](const float (&e)[4], int64_t r) {
+    for (int q = 0; q < T2I_QUADS; ++q) {
+        const int64_t c0 = cb + (int64_t)q * RANK_THREADS * 4;
+        ncol[q] = c0 >= Nc ? 0 : ((Nc - c0 >= 4) ? 4 : (int)(Nc - c0));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {      // (score of the GT image, its row): a row counts when its key is larger (rank_key: the tie rule)
+            gkey[q][u] = u < ncol[q] ? rank_key(s_gt[c0 + u], (unsigned)((c0 + u) / im_div)) : ~0ull;
+            best[q][u] = 0;
+            cnt[q][u] = 0;
+        }
+    }
+    const bool vec = ((ldS & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
+    for (int64_t r = r_begin; r < r_end; ++r) {
+        const float *p = S + r * ldS + cb;
+        float e[T2I_QUADS][4];
+#pragma unroll
+        for (int q = 0; q < T2I_QUADS; ++q) {
+            const float *pq = p + q * RANK_THREADS * 4;
+            if (vec && ncol[q] == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(pq);
+                e[q][0] = v.x; e[q][1] = v.y; e[q][2] = v.z; e[q][3] = v.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[q][u] = u < ncol[q] ? pq[u] : -INFINITY;
+            }
+        }
         const unsigned gr = (unsigned)(row0 + r);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned long long key = rank_key(e[u], gr);
-            cnt[u] += key > gkey[u];
-            best[u] = key > best[u] ? key : best[u];
-        }
-    };
-    // (round 4: eight row loads in flight per lane, requested before the first is used, were SLOWER -- 146.8 against 127.7 us at
-    // 5k x 25k: the pass is not latency-bound per lane; 64 rows x 25 column blocks already give the chip 1 975 independent workgroups)
-    for (int64_t r = r_begin; r < r_end; ++r) {
-        const float *p = S + r * ldS + c0;
-        float e[4];
-        if (vec) {
-            const float4 v = *reinterpret_cast<const float4 *>(p);
-            e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
-        } else {
+        for (int q = 0; q < T2I_QUADS; ++q)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) e[u] = u < ncol ? p[u] : -INFINITY;
-        }
-        take(e, r);
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long key = rank_key(e[q][u], gr);
+                cnt[q][u] += key > gkey[q][u];
+                best[q][u] = key > best[q][u] ? key : best[q][u];
+            }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (u < ncol) {
-            if (cnt[u]) atomicAdd(&rank_acc[c0 + u], cnt[u]);
-            atomicMax(&best_acc[c0 + u], best[u]);
-        }
+    for (int q = 0; q < T2I_QUADS; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < ncol[q]) {
+                const int64_t c = cb + (int64_t)q * RANK_THREADS * 4 + u;
+                if (cnt[q][u]) atomicAdd(&rank_acc[c], cnt[q][u]);
+                atomicMax(&best_acc[c], best[q][u]);
+            }
 }
 
 // ---- float64 similarity matrices ------------------------------------------------------------
@@ -391,7 +405,7 @@ extern "C" int itr_rank_counts(const float *S, int64_t ldS, int64_t row0, int64_
 #undef ITR_I2T
     }
     ITR_CHECK_LAUNCH("i2t_rank");
-    dim3 grid((unsigned)itr::ceil_div(Nc, (int64_t)itr::RANK_THREADS * 4),
+    dim3 grid((unsigned)itr::ceil_div(Nc, (int64_t)itr::RANK_THREADS * 4 * itr::T2I_QUADS),
               (unsigned)itr::ceil_div(n_rows_local, itr::T2I_ROWS));
     hipLaunchKernelGGL(itr::t2i_rank_kernel, grid, dim3(itr::RANK_THREADS), 0, st, S, ldS, row0, n_rows_local,
                        Nc, im_div, s_gt, t2i_rank, reinterpret_cast<unsigned long long *>(t2i_best));
