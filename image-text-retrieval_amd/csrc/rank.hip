@@ -105,12 +105,20 @@ __global__ __launch_bounds__(RANK_THREADS) void i2t_rank_kernel(const float *__r
     }
 }
 
-constexpr int T2I_ROWS = 16;   // image rows per workgroup
-constexpr int T2I_QUADS = 4;   // float4 column groups per lane, 1 024 columns apart: a workgroup reads 16 KB CONTIGUOUS per row
+#ifndef ITR_T2I_ROWS
+#define ITR_T2I_ROWS 128
+#endif
+#ifndef ITR_T2I_QUADS
+#define ITR_T2I_QUADS 1
+#endif
+constexpr int T2I_ROWS = ITR_T2I_ROWS;     // image rows per workgroup (one pair of atomics per column and workgroup: fewer rows = more atomics)
+constexpr int T2I_QUADS = ITR_T2I_QUADS;   // float4 column groups per lane, 1 024 columns apart (a workgroup reads QUADS x 4 KB contiguous per row)
 
-// Column pass.  Round 4: a workgroup covers 4 096 consecutive columns x 16 rows (lane t owns columns 1024 q + 4 t .. + 3 of the block for
-// q = 0..3) instead of 1 024 columns x 64 rows: the same bytes per workgroup, but 16 KB instead of 4 KB contiguous per row (rows are
-// 100 KB apart) and four independent 16-byte loads per lane and row.
+// Column pass: a workgroup covers QUADS x 1 024 consecutive columns x ROWS rows (lane t owns columns 1024 q + 4 t .. + 3 of the block).
+// Round 4 sweep on one box (5 000 x 25 000, us per launch; tools/ab_build.sh -DITR_T2I_QUADS / -DITR_T2I_ROWS): QUADS x ROWS =
+// 1 x 64: 127.0 (rounds 1-3), 1 x 128: 121.8 (now), 1 x 256: 176.9, 2 x 64: 155.7, 2 x 128: 188.0, 4 x 64: 220.3, 4 x 16: 331 --
+// wider contiguous reads per row LOSE (fewer workgroups in flight), fewer rows per workgroup lose to the atomics (one pair per
+// column and workgroup, executed at the memory side).  ~4 TB/s = half of the HBM peak is where this layout ends.
 __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__restrict__ S, int64_t ldS,
                                                                 int64_t row0, int64_t nrows, int64_t Nc,
                                                                 int im_div, const float *__restrict__ s_gt,

@@ -343,22 +343,7 @@ class GruModelEval:
         send = torch.empty(maxtok, D_emb, device=dev, dtype=torch.float32)
         if maxtok > n_tok:
             send[n_tok:].zero_()
-        # Resident features: the image projection (one large GEMM) runs on a side stream NEXT TO the text tower, whose recurrence is
-        # 40 launches of shrinking GEMMs (a time step only has as many rows as captions still running) -- the projection's tiles
-        # fill the CUs those leave idle.  Same kernels, same arithmetic; joined before the first scoring launch.
-        # (ITR_EVAL_NO_TOWER_OVERLAP=1: one after the other, for A/B timing.)
-        img_pre = None
-        if torch.is_tensor(feats_local) and feats_local.is_cuda and feats_local.shape[0] and not os.environ.get("ITR_EVAL_NO_TOWER_OVERLAP"):
-            cur = torch.cuda.current_stream(dev)
-            if getattr(self, "_img_stream", None) is None:
-                self._img_stream = torch.cuda.Stream(device=dev)
-            self._img_stream.wait_stream(cur)
-            with torch.cuda.stream(self._img_stream):
-                img_pre = self.encode_images(feats_local)
-            img_pre.record_stream(cur)
         words = self.encode_captions(tokens_packed, tok_off, lengths_sorted, out=send[:n_tok])
-        if img_pre is not None:
-            torch.cuda.current_stream(dev).wait_stream(self._img_stream)
         if torch.is_tensor(feats_local):
             blocks = [(0, feats_local.shape[0], feats_local)]
             n_img_local = feats_local.shape[0]
@@ -409,7 +394,7 @@ class GruModelEval:
         plan = None
         waited = False
         for r0, r1, fblock in blocks:
-            img = img_pre if img_pre is not None else self.encode_images(fblock)
+            img = self.encode_images(fblock)
             if not overlap or waited:
                 if not waited:
                     wait()
