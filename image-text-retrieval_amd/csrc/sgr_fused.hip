@@ -590,6 +590,10 @@ __device__ __forceinline__ void sf_last_project(const float *__restrict__ src, f
     }
 }
 
+// (Round 4 also measured a second form for the one-workgroup-per-CU kernel -- wave = k slice, lane = output quad, x broadcast with
+// v_readlane, the eight k-slice partials summed through LDS: no 16-byte LDS broadcasts and fully contiguous 1 KB weight loads, but
+// two more barriers per item: 725.2 ms against 720.8 for the form above, same box.  Removed; profiles/r04/NOTES.md.)
+
 // Attention of node 0 of caption slot `ci` (one wave): e_j = q' . x_j over the graph's nodes, softmax, y = sum_j p_j x_j -> the Q'/Y row
 // of the global node.  Scores: lane = (key fi = lane & 15 of key tile a, feature quarter fq = lane >> 4), 16-byte LDS reads in the
 // conflict-free pattern of the MFMA fragment reads, the four quarters summed by sf_rows_sum.  Values: lane = feature quad, the weight

@@ -414,9 +414,19 @@ __global__ __launch_bounds__(256) void sgr_final_kernel(const float *__restrict_
 }
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
-// images per block of the pair stage (a multiple of the SCAN image tile).  16 gives every launch of the chain >= 4k
-// workgroups at Flickr size; the unfused fallback (sim_dim != 256) materialises (ctx - E)^2 and stays at 4.
-static inline int64_t sgraf_ib(int S) { return S == 256 ? 16 : 4; }
+// images per block of the pair stage (a multiple of the SCAN image tile).  Round 4: 64 (rounds 1-3: 16) -- a quarter of the launches, and
+// the persistent SGR kernel's tail (the last, partial round of items over the CUs) is a quarter as large: SGR 1k x 5k 735.8 -> 723.5 ms,
+// SAF 373.3 -> 371.3 (same box; 32: 732.9 / 372.7).  The workspace grows with it (5k x 25k: SAF 38 GB, SGR 85 GB of the 288 GB);
+// ITR_SGRAF_IB=16|32|64 overrides it (read once per process: several ranks sharing ONE GPU in the tests).  Scores do not depend on it.
+// The unfused fallback (sim_dim != 256) materialises (ctx - E)^2 and stays at 4.
+static inline int64_t sgraf_ib(int S) {
+    static const int ib = [] {
+        const char *e = getenv("ITR_SGRAF_IB");
+        const int v = e ? atoi(e) : 64;
+        return (v == 16 || v == 32 || v == 64) ? v : 64;
+    }();
+    return S == 256 ? ib : 4;
+}
 
 }  // namespace itr
 
