@@ -19,8 +19,9 @@
 //         Y^T[d, i] = sum_j X[j, d] P^T[j, i]  A = X columns, B = the softmax registers as they are
 //       Y overwrites the Q' rows of the same 16 nodes (nobody else reads them).
 //   P3  X'^T[o, n] = relu(W_g[o, :] . Y[n, :] + b)    as P1, from the Q'/Y buffer back into the X buffer.
-// The last step needs node 0 only (Fusionmodule.py:443 reads sim_emb[:, 0]): P1 / P3 run on the first 16 rows (the global nodes of
-// the group's captions live there), P2 computes one query column per caption.  Then sigmoid(sim_eval_w . x_0 + b) -> S.
+// The last step needs node 0 only (Fusionmodule.py:443 reads sim_emb[:, 0]): its query projection and its one softmax row per caption
+// run on the vector ALU (sf_last_project / sf_last_attend below), and y of node 0 leaves the kernel -- the last graph projection and
+// sigmoid(sim_eval_w . x_0 + b) are one GEMM + one small kernel over all the graphs of the image block (sgraf.hip).
 // v_mfma_f32_16x16x4_f32 throughout (exact fp32).  LDS: two [ROWS][264] fp32 buffers (row stride 264 = 2 mod 16 sixteen-byte slots:
 // the ds_read_b128 lane groups of a 16-row x 4-slot fragment read hit 16 distinct slots) + the group records + the softmax tiles.
 //
@@ -50,7 +51,7 @@ struct alignas(16) SgrGroupMeta {
     uint8_t unit_tile[SF_MAXUNIT];
     int32_t row_src[SF_ROWS];            // rows < ncap: caption id (global node); others: tile-packed column of the word
     uint8_t unit_poff[SF_MAXUNIT];       // first 1 KB softmax tile of a unit in the P^T scratch (prefix sum of the units' key-tile counts)
-    uint8_t cap_poff[SF_MAXCAP];         // the same for the last step, whose units are the captions
+    uint8_t cap_poff[SF_MAXCAP];         // (rounds 1-3: the same for the last step's MFMA units; unused since the last step runs on the vector ALU)
     int32_t pad1[6];
 };
 static_assert(sizeof(SgrGroupMeta) == 512, "one 512-byte record per group");
@@ -180,11 +181,8 @@ struct SgrFusedArgs {
     const float *vq[8], *bg[8];
     const float *wqT_last;               // the LAST step's folded query weight, transposed: [k][o] (sgr_transpose_weight_kernel)
     int steps;
-    const float *eval_w, *eval_b;
     float *y0;                           // [nb][Nc][256]: y of node 0 after the last step's attention (the last graph projection and the score
                                          // run as ONE GEMM over all the graphs of the image block afterwards: sgraf.hip)
-    float *S;
-    int64_t ldS, img_index0;
     unsigned long long *trace;           // debug (ITR_SGR_TRACE): [grid][20] = hardware id, group shape, s_memtime at entry / after the load / after every phase
 };
 
@@ -367,16 +365,16 @@ __device__ __forceinline__ void sf_eblock(unsigned qaddr, const unsigned (&kaddr
     }
 }
 
-// P2, first half.  One unit = the 16 query nodes of tile `tile` of caption slot `ci` (tile 0 with query = node 0 only when `last`)
+// P2, first half.  One unit = the 16 query nodes of tile `tile` of caption slot `ci`
 // against the caption's NTC key tiles: E^T, softmax over the keys, P^T -> LDS (`pt`: NTC tiles of [4 fq][16 fi] float4 -- a lane
 // stores its accumulator registers as they are and the second half reads them back as MFMA B operands).
 template <int NTC>
-__device__ __forceinline__ void sf_attend_e(unsigned xb_lds, unsigned qy_lds, const SgrGroupMeta &m, int ci, int tile, bool last, int lane,
+__device__ __forceinline__ void sf_attend_e(unsigned xb_lds, unsigned qy_lds, const SgrGroupMeta &m, int ci, int tile, int lane,
                                             float4 *__restrict__ pt) {
     const int fi = lane & 15, fq = lane >> 4;
     const int nn = m.nn[ci], ws = m.wstart[ci];
     auto row_of = [&](int n) { n = n < nn ? n : nn - 1; return n == 0 ? ci : ws + n - 1; };   // rows past the graph re-read its last node (masked)
-    const unsigned qaddr = qy_lds + (unsigned)(row_of(last ? 0 : 16 * tile + fi) * SF_LD + 4 * fq) * 4u;
+    const unsigned qaddr = qy_lds + (unsigned)(row_of(16 * tile + fi) * SF_LD + 4 * fq) * 4u;
     unsigned kaddr[NTC];
 #pragma unroll
     for (int a = 0; a < NTC; ++a) kaddr[a] = xb_lds + (unsigned)(row_of(16 * a + fi) * SF_LD + 4 * fq) * 4u;
@@ -470,7 +468,7 @@ __device__ __forceinline__ void sf_yquarter(const unsigned (&vaddr)[NTC][4], con
 }
 
 template <int NTC>
-__device__ __forceinline__ void sf_attend_y(unsigned xb_lds, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int tile, bool last, int half,
+__device__ __forceinline__ void sf_attend_y(unsigned xb_lds, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int tile, int half,
                                             int lane, const float4 *__restrict__ pt) {
     const int fi = lane & 15, fq = lane >> 4;
     const int nn = m.nn[ci], ws = m.wstart[ci];
@@ -483,8 +481,8 @@ __device__ __forceinline__ void sf_attend_y(unsigned xb_lds, float *__restrict__
     float4 p[NTC];
 #pragma unroll
     for (int a = 0; a < NTC; ++a) p[a] = pt[a * 64 + lane];
-    const bool wr = last ? (fi == 0) : (16 * tile + fi < nn);
-    float *yrow = qy + row_of(last ? 0 : 16 * tile + fi) * SF_LD + 128 * half + 4 * fq;
+    const bool wr = 16 * tile + fi < nn;
+    float *yrow = qy + row_of(16 * tile + fi) * SF_LD + 128 * half + 4 * fq;
     sf_yquarter<NTC, 0>(vaddr, p, yrow, wr);
     sf_yquarter<NTC, 256>(vaddr, p, yrow, wr);
 }
@@ -526,7 +524,7 @@ __device__ __forceinline__ void sf_last_weights0(const float *__restrict__ wT, i
 #pragma unroll
     for (int j = 0; j < KB; ++j) w[j] = wp[j * 64];
 }
-template <bool RELU, int NR, int KB>
+template <int NR, int KB>
 __device__ __forceinline__ void sf_last_project(const float *__restrict__ src, float *__restrict__ dst, const float *__restrict__ wT,
                                                 const float *__restrict__ bias, int ncap, int wave, int lane, float4 (&w)[KB]) {
     const int oq = lane & 7, ks = lane >> 3, o0 = 32 * wave + 4 * oq;
@@ -582,7 +580,6 @@ __device__ __forceinline__ void sf_last_project(const float *__restrict__ src, f
                     v.y = sf_rows_sum(acc[r].y + sf_dpp<0x128>(acc[r].y)) + bv.y;
                     v.z = sf_rows_sum(acc[r].z + sf_dpp<0x128>(acc[r].z)) + bv.z;
                     v.w = sf_rows_sum(acc[r].w + sf_dpp<0x128>(acc[r].w)) + bv.w;
-                    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (ks == 0 && n0 + r < ncap) *reinterpret_cast<float4 *>(dst + (n0 + r) * SF_LD + o0) = v;
                 }
             }
@@ -660,33 +657,33 @@ __device__ __forceinline__ void sf_last_attend_n(const float *__restrict__ xb, c
 // P2 dispatch on a caption's key-tile count (a ROWS = 32 group has graphs of at most two tiles: the wider instantiations would only
 // raise the kernel's register count past the 128 that two workgroups per CU leave a wave)
 template <int ROWS>
-__device__ __forceinline__ void sf_attend_e_n(int ntc, unsigned xb_lds, unsigned qy_lds, const SgrGroupMeta &m, int ci, int tile, bool last, int lane,
+__device__ __forceinline__ void sf_attend_e_n(int ntc, unsigned xb_lds, unsigned qy_lds, const SgrGroupMeta &m, int ci, int tile, int lane,
                                               float4 *__restrict__ pt) {
     if constexpr (ROWS > SF_SMALL) {
         switch (ntc) {
-            case 1: sf_attend_e<1>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-            case 2: sf_attend_e<2>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-            case 3: sf_attend_e<3>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
-            default: sf_attend_e<4>(xb_lds, qy_lds, m, ci, tile, last, lane, pt); break;
+            case 1: sf_attend_e<1>(xb_lds, qy_lds, m, ci, tile, lane, pt); break;
+            case 2: sf_attend_e<2>(xb_lds, qy_lds, m, ci, tile, lane, pt); break;
+            case 3: sf_attend_e<3>(xb_lds, qy_lds, m, ci, tile, lane, pt); break;
+            default: sf_attend_e<4>(xb_lds, qy_lds, m, ci, tile, lane, pt); break;
         }
     } else {
-        if (ntc == 1) sf_attend_e<1>(xb_lds, qy_lds, m, ci, tile, last, lane, pt);
-        else sf_attend_e<2>(xb_lds, qy_lds, m, ci, tile, last, lane, pt);
+        if (ntc == 1) sf_attend_e<1>(xb_lds, qy_lds, m, ci, tile, lane, pt);
+        else sf_attend_e<2>(xb_lds, qy_lds, m, ci, tile, lane, pt);
     }
 }
 template <int ROWS>
-__device__ __forceinline__ void sf_attend_y_n(int ntc, unsigned xb_lds, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int tile, bool last,
+__device__ __forceinline__ void sf_attend_y_n(int ntc, unsigned xb_lds, float *__restrict__ qy, const SgrGroupMeta &m, int ci, int tile,
                                               int half, int lane, const float4 *__restrict__ pt) {
     if constexpr (ROWS > SF_SMALL) {
         switch (ntc) {
-            case 1: sf_attend_y<1>(xb_lds, qy, m, ci, tile, last, half, lane, pt); break;
-            case 2: sf_attend_y<2>(xb_lds, qy, m, ci, tile, last, half, lane, pt); break;
-            case 3: sf_attend_y<3>(xb_lds, qy, m, ci, tile, last, half, lane, pt); break;
-            default: sf_attend_y<4>(xb_lds, qy, m, ci, tile, last, half, lane, pt); break;
+            case 1: sf_attend_y<1>(xb_lds, qy, m, ci, tile, half, lane, pt); break;
+            case 2: sf_attend_y<2>(xb_lds, qy, m, ci, tile, half, lane, pt); break;
+            case 3: sf_attend_y<3>(xb_lds, qy, m, ci, tile, half, lane, pt); break;
+            default: sf_attend_y<4>(xb_lds, qy, m, ci, tile, half, lane, pt); break;
         }
     } else {
-        if (ntc == 1) sf_attend_y<1>(xb_lds, qy, m, ci, tile, last, half, lane, pt);
-        else sf_attend_y<2>(xb_lds, qy, m, ci, tile, last, half, lane, pt);
+        if (ntc == 1) sf_attend_y<1>(xb_lds, qy, m, ci, tile, half, lane, pt);
+        else sf_attend_y<2>(xb_lds, qy, m, ci, tile, half, lane, pt);
     }
 }
 
@@ -750,7 +747,7 @@ __global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_kernel(Sg
             if (wv != wave) continue;
             const int ci = m.unit_cap[u], tile = m.unit_tile[u];
             float4 *pt = ptile + (size_t)m.unit_poff[u] * 64;
-            sf_attend_e_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy_lds, m, ci, tile, false, lane, pt);
+            sf_attend_e_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy_lds, m, ci, tile, lane, pt);
         }
         __syncthreads();
         SF_STAMP()
@@ -760,7 +757,7 @@ __global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_kernel(Sg
             const int u = t >> 1, dq = t & 1;
             const int ci = m.unit_cap[u], tile = m.unit_tile[u];
             const float4 *pt = ptile + (size_t)m.unit_poff[u] * 64;
-            sf_attend_y_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy, m, ci, tile, false, dq, lane, pt);
+            sf_attend_y_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy, m, ci, tile, dq, lane, pt);
         }
         __syncthreads();
         SF_STAMP()
@@ -772,7 +769,7 @@ __global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_kernel(Sg
     constexpr int LNR = ROWS > SF_SMALL ? 8 : 4, LKB = ROWS > SF_SMALL ? 8 : 4;
     float4 lw[LKB];
     sf_last_weights0<LKB>(g.wqT_last, wave, lane, lw);
-    sf_last_project<false, LNR, LKB>(xb, qy, g.wqT_last, g.vq[g.steps - 1], ncap, wave, lane, lw);
+    sf_last_project<LNR, LKB>(xb, qy, g.wqT_last, g.vq[g.steps - 1], ncap, wave, lane, lw);
     __syncthreads();
     SF_STAMP()
     // y of node 0 -> memory; X'_0 = relu(W_g y + b) and sigmoid(sim_eval_w . x_0 + b) (Fusionmodule.py:443-444) run as one GEMM + one
@@ -872,14 +869,14 @@ __global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_persisten
                 if (wv != wave) continue;
                 const int ci = m.unit_cap[u], tile = m.unit_tile[u];
                 float4 *pt = ptile + (size_t)m.unit_poff[u] * 64;
-                sf_attend_e_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy_lds, m, ci, tile, false, lane, pt);
+                sf_attend_e_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy_lds, m, ci, tile, lane, pt);
             }
             __syncthreads();
             for (int t = wave; t < 2 * nu; t += SF_WAVES) {
                 const int u = t >> 1, dq = t & 1;
                 const int ci = m.unit_cap[u], tile = m.unit_tile[u];
                 const float4 *pt = ptile + (size_t)m.unit_poff[u] * 64;
-                sf_attend_y_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy, m, ci, tile, false, dq, lane, pt);
+                sf_attend_y_n<ROWS>((m.nn[ci] + 15) >> 4, xb_lds, qy, m, ci, tile, dq, lane, pt);
             }
             __syncthreads();
             // (the last MFMA projection of the item hands over the first fragments of the NEXT item's first projection)
@@ -889,7 +886,7 @@ __global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_persisten
         }
         if (!early) sf_last_weights0<LKB>(g.wqT_last, wave, lane, lw);
         // ---- the last step: node 0 of every graph only, on the vector ALU (see sf_last_project)
-        sf_last_project<false, LNR, LKB>(xb, qy, g.wqT_last, g.vq[g.steps - 1], ncap, wave, lane, lw);
+        sf_last_project<LNR, LKB>(xb, qy, g.wqT_last, g.vq[g.steps - 1], ncap, wave, lane, lw);
         __syncthreads();
         f32x4 pre[ROWS / SF_WAVES];
         if (has_next) {
@@ -1039,8 +1036,7 @@ static int sgr_fused_launch_class(SgrFusedArgs g, int cls_index, int64_t n_group
 // Runs the graph steps up to the last step's attention; y0 [nb][Nc][256] receives y of node 0 of every graph.  The caller finishes:
 // x_0 = relu(W_g y + b) as one GEMM over nb * Nc rows, then sigmoid(sim_eval_w . x_0 + b) (sgraf.hip).
 int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t n_caps, int64_t nb, int64_t Nc, int64_t ncols,
-                     const float *const *vq, const float *const *bg, int sgr_step, const float *eval_w, const float *eval_b, float *y0, float *S,
-                     int64_t ldS, int64_t img_index0, int max_len, hipStream_t st) {
+                     const float *const *vq, const float *const *bg, int sgr_step, float *y0, hipStream_t st) {
     if (nb == 0 || n_groups == 0) return ITR_OK;
     const SgrWs w = sgr_carve(ws, n_groups, n_caps, sgr_step);
     SgrFusedArgs g;
@@ -1057,7 +1053,6 @@ int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_g
     g.steps = sgr_step;
     g.wqT_last = w.wT;
     g.y0 = y0;
-    g.eval_w = eval_w; g.eval_b = eval_b; g.S = S; g.ldS = ldS; g.img_index0 = img_index0;
     static const char *trace_env = getenv("ITR_SGR_TRACE");
     const char *trace_path = (trace_env && *trace_env) ? trace_env : nullptr;
     const char *pers_env = getenv("ITR_SGR_PERSISTENT");      // (read per call: the tests run both forms in one process)
@@ -1066,7 +1061,6 @@ int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_g
     // its workgroups read a zero count and leave), then the small one
     int rc = sgr_fused_launch_class<SF_ROWS, 1>(g, 1, n_groups, w, persistent, trace_path, st);
     if (rc != ITR_OK) return rc;
-    (void)max_len;
     return sgr_fused_launch_class<SF_SMALL, 2>(g, 0, n_groups, w, persistent, trace_path, st);
 }
 

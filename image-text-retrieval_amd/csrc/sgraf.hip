@@ -36,8 +36,7 @@ size_t sgr_fused_workspace_bytes(int64_t n_groups, int64_t n_caps, int sgr_step)
 int sgr_fused_prepare(const int32_t *grp_begin, const int32_t *grp_order, int64_t n_groups, int64_t n_caps, const int32_t *cap_len,
                       const int32_t *cap_col, const float *const *wq, const float *const *wg, int sgr_step, void *ws, int *bad_flag, hipStream_t st);
 int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t n_caps, int64_t nb, int64_t Nc, int64_t ncols,
-                     const float *const *vq, const float *const *bg, int sgr_step, const float *eval_w, const float *eval_b, float *y0, float *S,
-                     int64_t ldS, int64_t img_index0, int max_len, hipStream_t st);
+                     const float *const *vq, const float *const *bg, int sgr_step, float *y0, hipStream_t st);
 int sgr_fused_finish(void *ws, int64_t n_groups, int64_t n_caps, int sgr_step, int64_t Ni, float *S, int64_t ldS, hipStream_t st);
 
 constexpr float BN_EPS = 1e-5f;
@@ -625,8 +624,7 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
         } else if (fused_sgr) {
             // all the graph steps up to the last step's attention in one workgroup per group of captions; the last step's graph
             // projection of node 0 (the only node read afterwards, Fusionmodule.py:443) for ALL the graphs of the block as one GEMM
-            SG_TRY(sgr_fused_scores(Xloc, Xglo, fused_ws, n_node_groups, Nc, nb, ldg, ncols, vfold, w->sgr_g_b, sgr_step, w->eval_w, w->eval_b,
-                                    Yglo, Sout, ldS, i0, max_len, st));
+            SG_TRY(sgr_fused_scores(Xloc, Xglo, fused_ws, n_node_groups, Nc, nb, ldg, ncols, vfold, w->sgr_g_b, sgr_step, Yglo, st));
             SG_TRY(gemm_nt(Yglo, S, w->sgr_g_w[sgr_step - 1], S, w->sgr_g_b[sgr_step - 1], Xglo, S, nb * ldg, S, S, 1 /*relu*/, st));
             hipLaunchKernelGGL(sgr_final_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), 0, st, Xglo, Nc, S, w->eval_w, w->eval_b,
                                npairs, Sout, ldS, i0, ldg);
