@@ -22,8 +22,7 @@
 // The last step needs node 0 only (Fusionmodule.py:443 reads sim_emb[:, 0]): its query projection and its one softmax row per caption
 // run on the vector ALU (sf_last_project / sf_last_attend below), and y of node 0 leaves the kernel -- the last graph projection and
 // sigmoid(sim_eval_w . x_0 + b) are one GEMM + one small kernel over all the graphs of the image block (sgraf.hip).
-// v_mfma_f32_16x16x4_f32 throughout (exact fp32).  LDS: two [ROWS][264] fp32 buffers (row stride 264 = 2 mod 16 sixteen-byte slots:
-// the ds_read_b128 lane groups of a 16-row x 4-slot fragment read hit 16 distinct slots) + the group records + the softmax tiles.
+// v_mfma_f32_16x16x4_f32 throughout (exact fp32).  LDS: two [ROWS][SF_LD = 260] fp32 buffers + the group records + the softmax tiles.
 //
 // Two sizes of group (round 4).  ROWS = 32 (the planner's default: every caption of at most 31 words): 79 KB of LDS, TWO 512-thread
 // workgroups per CU -- while one of them sits in its attention phase (block-diagonal 16 x 16 tiles, at best half of the matrix pipe)
@@ -38,7 +37,14 @@
 
 namespace itr {
 
-constexpr int SF_ROWS = 64, SF_S = 256, SF_LD = 264, SF_MAXCAP = 16, SF_MAXUNIT = 24, SF_THREADS = 512, SF_WAVES = 8;
+// Row stride of the two node-row buffers, in floats.  260 = 65 sixteen-byte slots: the 16 rows of a ds_read_b128 fragment read
+// (lanes fi = 0..15 of one quarter-wave) start in 16 distinct slots mod 16, and the four rows 4 fq + r of the value gathers of P2
+// (ds_read_b32, 4 x 260 floats apart = 16 banks) no longer pair up on the same banks as they did at 264 (4 x 264 = 32 banks: the
+// 2-way conflicts of round 3's PMC).  Same-box A/B: 723.7 -> 721.2 ms at 1k x 5k (268: 722.6).
+#ifndef ITR_SF_LD
+#define ITR_SF_LD 260
+#endif
+constexpr int SF_ROWS = 64, SF_S = 256, SF_LD = ITR_SF_LD, SF_MAXCAP = 16, SF_MAXUNIT = 24, SF_THREADS = 512, SF_WAVES = 8;
 constexpr int SF_SMALL = 32;             // node rows of the small class of groups (two workgroups per CU)
 
 // One record per group of captions (built on the device from the host's bin plan: sgr_group_meta_kernel).
