@@ -41,6 +41,12 @@ namespace itr {
 // (lanes fi = 0..15 of one quarter-wave) start in 16 distinct slots mod 16, and the four rows 4 fq + r of the value gathers of P2
 // (ds_read_b32, 4 x 260 floats apart = 16 banks) no longer pair up on the same banks as they did at 264 (4 x 264 = 32 banks: the
 // 2-way conflicts of round 3's PMC).  Same-box A/B: 723.7 -> 721.2 ms at 1k x 5k (268: 722.6).
+#ifndef ITR_SF_LNR          // rows per pass / k per weight batch of the last step's VALU projection in the one-per-CU kernel
+#define ITR_SF_LNR 8
+#endif
+#ifndef ITR_SF_LKB
+#define ITR_SF_LKB 8
+#endif
 #ifndef ITR_SF_LD
 #define ITR_SF_LD 260
 #endif
@@ -649,8 +655,11 @@ __device__ __forceinline__ void sf_last_attend_n(const float *__restrict__ xb, c
     const int ntc = (m.nn[ci] + 15) >> 4;
     if constexpr (ROWS > SF_SMALL) {
         switch (ntc) {
-            case 1: sf_last_attend<1, 4>(xb, qy, m, ci, lane, yout); break;
-            case 2: sf_last_attend<2, 4>(xb, qy, m, ci, lane, yout); break;
+#ifndef ITR_SF_UNR
+#define ITR_SF_UNR 4
+#endif
+            case 1: sf_last_attend<1, ITR_SF_UNR>(xb, qy, m, ci, lane, yout); break;
+            case 2: sf_last_attend<2, ITR_SF_UNR>(xb, qy, m, ci, lane, yout); break;
             case 3: sf_last_attend<3, 2>(xb, qy, m, ci, lane, yout); break;
             default: sf_last_attend<4, 2>(xb, qy, m, ci, lane, yout); break;
         }
@@ -772,7 +781,7 @@ __global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_kernel(Sg
         SF_STAMP()
     }
     // ---- the last step: node 0 of every graph only, on the vector ALU (see sf_last_project)
-    constexpr int LNR = ROWS > SF_SMALL ? 8 : 4, LKB = ROWS > SF_SMALL ? 8 : 4;
+    constexpr int LNR = ROWS > SF_SMALL ? ITR_SF_LNR : 4, LKB = ROWS > SF_SMALL ? ITR_SF_LKB : 4;
     float4 lw[LKB];
     sf_last_weights0<LKB>(g.wqT_last, wave, lane, lw);
     sf_last_project<LNR, LKB>(xb, qy, g.wqT_last, g.vq[g.steps - 1], ncap, wave, lane, lw);
@@ -858,7 +867,7 @@ __global__ __launch_bounds__(SF_THREADS, 2 * WG_PER_CU) void sgr_fused_persisten
         const bool meta_wave = has_next && wave >= 6;
         if (meta_wave && g.steps == 1)      // a single step is also the last one: the record must be there before its attention phase
             reinterpret_cast<int32_t *>(&m2[cur ^ 1])[tid - 384] = reinterpret_cast<const int32_t *>(g.meta + g.glist[nxt / g.nb])[tid - 384];
-        constexpr int LNR = ROWS > SF_SMALL ? 8 : 4, LKB = ROWS > SF_SMALL ? 8 : 4;
+        constexpr int LNR = ROWS > SF_SMALL ? ITR_SF_LNR : 4, LKB = ROWS > SF_SMALL ? ITR_SF_LKB : 4;
         float4 lw[LKB];          // first batch of the last step's weights: requested ahead of the barrier that precedes their projection
         constexpr bool early = ROWS > SF_SMALL;      // (two workgroups per CU: no registers to spare, and the other workgroup hides the trip)
         if (early && g.steps == 1) sf_last_weights0<LKB>(g.wqT_last, wave, lane, lw);
