@@ -45,6 +45,26 @@ __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_log
 __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
 __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 
+// v[l] (+ | max) v[l ^ 16] and v[l] (+ | max) v[l ^ 32] in registers (gfx950 v_permlane16_swap / v_permlane32_swap): two vector
+// instructions instead of a ds_bpermute round trip through the LDS crossbar, which an epilogue wave shares with the co-resident
+// workgroup's main loop.  The operation is commutative, so the result is bit-identical to `v + __shfl_xor(v, 16 | 32)`.
+__device__ __forceinline__ float xor16_add(float v) {
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float xor32_add(float v) {
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 #define SC_TICK(slot)                                                                              \
     if (g.dbg_cycles && tid == 0) {                                                                \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();                              \

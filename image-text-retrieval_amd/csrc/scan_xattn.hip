@@ -382,8 +382,13 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                         tail = fmaf(e2[j], tacc[2][nt][j], tail);
                     }
                     part += (fg == 0) ? tail : 0.f;
+#ifdef ITR_SCAN_SHFL_LDS            // A/B build: the round-3 form (two LDS-crossbar round trips per column tile)
                     part += __shfl_xor(part, 16, 64);
                     part += __shfl_xor(part, 32, 64);
+#else
+                    part = xor16_add(part);       // (bit-identical to the shuffles: see scan_common.h)
+                    part = xor32_add(part);
+#endif
                     qn[nt] = part;
                 }
                 // this lane's own column is w = fg*16 + fi -> n-tile fg
@@ -625,11 +630,11 @@ __device__ __forceinline__ void scan_xattn_body(const ScanArgs &g) {
                 for (int t = 0; t < SC_R / 4; ++t) r += rsim[(ii * SC_R + part * (SC_R / 4) + t) * SC_MAXCAP + k];
             }
             if (g.agg == 1) {
-                r = fmaxf(r, __shfl_xor(r, 16, 64));
-                r = fmaxf(r, __shfl_xor(r, 32, 64));
+                r = xor16_max(r);
+                r = xor32_max(r);
             } else {
-                r += __shfl_xor(r, 16, 64);
-                r += __shfl_xor(r, 32, 64);
+                r = xor16_add(r);
+                r = xor32_add(r);
             }
             if (g.agg == 0) r = fast_log(r) / g.lambda_lse;
             else if (g.agg == 3) r /= (float)SC_R;
