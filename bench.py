@@ -68,7 +68,7 @@ WORKLOADS = {
 # Short runs of the other BASELINE.json configs carried by the default workload's line: (workload, timed steps, warm-up steps).
 # config [1] VSE++ f30k 1k x 5k; [2] is the line itself (+ its f30k fold); [3] SAEM and CAMERA on BERT-base at coco size;
 # [4] SGRAF SAF and SGR at the full 5k x 25k (the 8-GPU config) and on the 1k x 5k fold.
-OTHER_CONFIGS = [("vsepp_f30k1k", 20, 3), ("scan_t2i_f30k1k", 3, 1), ("scan_i2t_coco5k", 1, 1), ("saem_coco5k", 1, 1), ("camera_coco5k", 1, 1),
+OTHER_CONFIGS = [("vsepp_f30k1k", 20, 5), ("scan_t2i_f30k1k", 3, 1), ("scan_i2t_coco5k", 1, 1), ("saem_coco5k", 1, 1), ("camera_coco5k", 1, 1),
                  ("sgraf_saf_f30k1k", 2, 1), ("sgraf_sgr_f30k1k", 2, 1), ("sgraf_saf_coco5k", 1, 1), ("sgraf_sgr_coco5k", 1, 1)]
 BASELINE_CONFIG_OF = {"vsepp_f30k1k": 1, "scan_t2i_f30k1k": 2, "scan_i2t_coco5k": 2, "saem_coco5k": 3, "camera_coco5k": 3,
                       "sgraf_saf_f30k1k": 4, "sgraf_sgr_f30k1k": 4, "sgraf_saf_coco5k": 4, "sgraf_sgr_coco5k": 4}
