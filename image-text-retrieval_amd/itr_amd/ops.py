@@ -5,6 +5,7 @@ raw device pointers + sizes to libitr_hip.so.  CPU tensors are rejected -- there
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -809,6 +810,9 @@ def sgraf_padded(images, captions, cap_lens, weights, module_name='SAF', sgr_ste
     return sgraf_scores(images, _dev(captions, name="captions").reshape(Nc * L, D), plan, weights, module_name, sgr_step)
 
 
+_TOKENS_CHECKED = {}         # id(tensor) -> (weak reference, (version counter, vocabulary size)) of token tensors whose id range has been checked
+
+
 def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtnorm=False, use_abs=False,
                gather_last=False, out=None, batch_invariant=False):
     """EncoderText.forward on packed captions (TextEncoder.py:38-70).
@@ -828,9 +832,16 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
     emb = _dev(weights['embed.weight'], name="embed.weight")
     V, E = emb.shape
     if n_tok:
-        lo, hi = torch.aminmax(tokens_packed)          # nn.Embedding raises on ids outside [0, V) (TextEncoder.py:41)
-        if int(lo) < 0 or int(hi) >= V:
-            raise IndexError("index out of range in self")
+        # nn.Embedding raises on ids outside [0, V) (TextEncoder.py:41).  The check costs a device -> host round trip, so a token tensor
+        # that has been checked is not checked again until it is written to (an evaluation loop encodes the same tokens every step)
+        ent = _TOKENS_CHECKED.get(id(tokens_packed))
+        if not (ent is not None and ent[0]() is tokens_packed and ent[1] == (tokens_packed._version, int(V))):
+            lo, hi = torch.aminmax(tokens_packed)
+            if int(lo) < 0 or int(hi) >= V:
+                raise IndexError("index out of range in self")
+            if len(_TOKENS_CHECKED) >= 16:
+                _TOKENS_CHECKED.clear()
+            _TOKENS_CHECKED[id(tokens_packed)] = (weakref.ref(tokens_packed), (tokens_packed._version, int(V)))
     w_ih = _dev(weights['rnn.weight_ih_l0'])
     w_hh = _dev(weights['rnn.weight_hh_l0'])
     b_ih = _dev(weights['rnn.bias_ih_l0'])

@@ -632,6 +632,25 @@ def test_bigru_launch_forms_are_bit_identical(dev, monkeypatch, V, E, D, B, lo, 
         o += lengths[b]
 
 
+def test_gru_token_range_check_is_cached_but_never_stale(dev):
+    """nn.Embedding raises IndexError on ids outside [0, V) (TextEncoder.py:41).  The check is cached per token tensor (a device -> host round
+    trip per encode otherwise) and must come back the moment the tensor is written to, or another tensor is passed."""
+    V, E, D = 50, 16, 32
+    rnn = torch.nn.GRU(E, D, 1, batch_first=True, bidirectional=False)
+    w = {'embed.weight': torch.empty(V, E).uniform_(-0.1, 0.1).to(dev)}
+    w.update({'rnn.' + k: v.detach().to(dev) for k, v in rnn.state_dict().items()})
+    toks = torch.tensor([1, 2, 3, 4, 5], dtype=torch.int64, device=dev)
+    off = torch.tensor([0, 3], dtype=torch.int64, device=dev)
+    a = ops.gru_encode(toks, off, [3, 2], w, False)
+    b = ops.gru_encode(toks, off, [3, 2], w, False)            # second call: the cached check
+    assert torch.equal(a, b)
+    toks[4] = V                                                # in-place write: the version counter moves, the check runs again
+    with pytest.raises(IndexError):
+        ops.gru_encode(toks, off, [3, 2], w, False)
+    with pytest.raises(IndexError):
+        ops.gru_encode(torch.tensor([1, 2, 3, 4, -1], dtype=torch.int64, device=dev), off, [3, 2], w, False)
+
+
 def test_gru_rejects_unsorted(dev):
     w = {'embed.weight': torch.zeros(10, 4, device=dev), 'rnn.weight_ih_l0': torch.zeros(12, 4, device=dev),
          'rnn.weight_hh_l0': torch.zeros(12, 4, device=dev), 'rnn.bias_ih_l0': torch.zeros(12, device=dev),
