@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: same-box, interleaved A/B of one bench workload: the round-3 tree (tools/ab/r3, built beforehand) against this tree
-# under two environments.   tools/ab_sgr.sh <workload> <out dir> [rounds]
+# under two environments (build the old tree first: tools/ab_checkout.sh 0807f13 r3).   tools/ab_sgr.sh <workload> <out dir> [rounds]
 WL=${1:-sgraf_sgr_f30k1k}; OUT=${2:-gpurun_out/ab}; N=${3:-2}
 mkdir -p $OUT
 ARGS="--workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-variants --no-other-configs"
