@@ -208,6 +208,62 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_world"] == 2 and out["launched_by"] == "bench.py"
     assert [x["rank"] for x in out["ranks"]] == [0, 1] and len({x["pid"] for x in out["ranks"]}) == 2
+    # VERDICT r4 #3c: after the rank table the launch check runs the exchange's two collectives on a real payload, checks what
+    # arrived and reports a rate per rank (16 MiB here; 1.33 GB on GPUs)
+    fab = out["fabric"]
+    assert fab["all_gather_into_tensor"]["ok"] and fab["all_reduce_counts"]["ok"]
+    assert fab["all_gather_into_tensor"]["bytes_total"] == 16 << 20 and len(fab["all_gather_into_tensor"]["gb_per_s_received_per_rank"]) == 2
+    assert all(v > 0 for v in fab["all_gather_into_tensor"]["ms_per_rank"] + fab["all_reduce_counts"]["ms_per_rank"])
+
+
+def test_bench_launch_deadline_kills_the_ranks_and_names_the_stuck_one():
+    """VERDICT r4 #3b: a rank that never gets through process-group start-up must not hang the command silently.  Rank 1 stops at
+    `pg_init` (test hook); the parent's init deadline passes, it prints what every rank last reported, kills the CHILD process
+    group and exits 124 with no result line -- and none of the ranks survives."""
+    import time
+    t0 = time.time()
+    r = _run_bench(["--gpus", "2", "--launch-check", "--init-deadline", "30"], dict(ITR_DIST_BACKEND="gloo", ITR_BENCH_TEST_HANG="1:pg_init",
+                                                                                  ITR_DIST_TIMEOUT_S="600"),
+                   drop=("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 120
+    assert '{"metric"' not in r.stdout
+    assert "DEADLINE" in r.stderr and "rank 1  stage=pg_init" in r.stderr, r.stderr[-2000:]
+    pids = [int(ln.split("pid=")[1]) for ln in r.stderr.splitlines() if "pid=" in ln and "pid=None" not in ln]
+    assert pids
+    time.sleep(1.0)
+    for pid in pids:
+        assert not os.path.exists("/proc/%d" % pid) or open("/proc/%d/stat" % pid).read().split()[2] == "Z", pid
+
+
+def test_bench_line_survives_failing_other_configs(monkeypatch, capsys):
+    """the primary workload's line is printed exactly once whatever the secondary configs do -- a config that
+    raises is recorded as its error, an exception that escapes still leaves the line (main()'s finally), and the watchdog's emit
+    and the normal emit cannot both print."""
+    import importlib
+    import json
+    import types
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    line = bench.LineOnce()
+    line.out = {"metric": bench.METRIC, "value": 1.0}
+    calls = []
+
+    def fake(a2, *rest, **kw):
+        calls.append(a2.workload)
+        if a2.workload == "scan_i2t_coco5k":
+            raise RuntimeError("boom")
+        return {"ms_per_step": 1.0, "value": 2.0, "config": {"n_img": 1, "n_cap": 5}, "recall": {}, "rank_checksum": [0],
+                "roofline": {"frac": 0.5, "achieved": 1.0, "kernel_ms": 1.0}}
+    monkeypatch.setattr(bench, "run_workload", fake)
+    args = types.SimpleNamespace(workload=bench.DEFAULT_WORKLOAD, steps=1, warmup=0)
+    bench.other_configs(args, 2, 0, torch.device("cpu"), False, "gloo", line)      # world 2: the in-process form
+    assert calls == [n for n, _, _ in bench.OTHER_CONFIGS]
+    oc = line.out["other_configs"]
+    assert "boom" in oc["scan_i2t_coco5k"]["error"] and oc["vsepp_f30k1k"]["frac"] == 0.5
+    assert line.emit() and not line.emit() and not line.emit({"other_configs_error": "late watchdog"})
+    printed = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('{"metric"')]
+    assert len(printed) == 1 and "other_configs_error" not in json.loads(printed[0])
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():

@@ -293,6 +293,8 @@ def test_other_configs_ride_along_with_the_default_line():
     for name, o in oc.items():
         assert o["ms_per_step"] > 0 and o["pairs_per_s"] > 0 and 0 < o["frac"] < 1 and len(o["rank_checksum"]) == 4, name
     assert oc["scan_t2i_f30k1k"]["rank_checksum"] == _bench_line(_base_args("scan_t2i_f30k1k"))["rank_checksum"]
+    # one process: every other config ran in its own child process (a fault there cannot take the primary line with it)
+    assert all(o["process"] == "child" for o in oc.values())
     # the same with two ranks (started by bench.py itself; gloo: they share the GPU): every config runs sharded, same rank vectors
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     import json
@@ -307,6 +309,36 @@ def test_other_configs_ride_along_with_the_default_line():
     for name, o in two["other_configs"].items():
         assert "error" not in o, (name, o)
         assert o["rank_checksum"] == oc[name]["rank_checksum"], name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["scan_t2i_f30k1k", "vsepp_f30k1k", "sgraf_saf_f30k1k"])
+def test_bench_line_carries_recall_parity_and_a_repeatable_cpu_baseline(workload):
+    """the metric is "pairs/sec + Recall@1 parity" -- the line's cpu_baseline carries Recall@1/5/10 of the
+    reference's argsort ranker on the CPU path's scores next to the HIP ranker's on the HIP path's scores for the same sample
+    block (|dR@K| <= 0.1 or the run exits 4), the HIP ranker alone reproduces the argsort rank vectors on the CPU's matrix, and the
+    CPU leg is timed more than once with the host it ran on recorded."""
+    out = _bench_line(["--workload", workload, "--steps", "1", "--warmup", "0", "--no-variants", "--no-other-configs",
+                       "--cpu-sample-images", "40", "--cpu-repeats", "2"])
+    cb = out["cpu_baseline"]
+    rp = cb["recall_parity"]
+    assert rp["ok"] and rp["max_abs_recall_diff"] <= 0.1 and rp["hip_ranker_on_cpu_scores_equals_argsort"]
+    assert set(rp["gpu"]) == set(rp["cpu"]) == {"i2t_r1", "i2t_r5", "i2t_r10", "t2i_r1", "t2i_r5", "t2i_r10"}
+    assert rp["rank_entries"] == 40 + 200 and rp["rank_entries_differing"] <= 2
+    h = cb["host"]
+    assert h["repeats"] >= 2 and h["logical_cpus"] >= 1 and h["threads_used"] == cb["cores"] and cb["value"] > 0
+    assert str(cb["cores"]) in h["seconds_by_threads"] and cb["max_abs_diff_vs_gpu"] <= 2e-5
+
+
+@pytest.mark.gpu
+def test_launch_check_runs_the_exchange_collectives_over_rccl():
+    """VERDICT r4 #3c, the form a 1-GPU box can run: `--launch-check` with a 1-rank RCCL group moves the REAL payloads -- the
+    1.33 GB packed-word all_gather_into_tensor and the 25 000-int32 sum all-reduce -- checks the contents and reports a rate."""
+    out = _bench_line(["--launch-check"], env=dict(ITR_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547"))
+    assert out["launch_check"] and out["value"] is None and out["dist_backend"] == "nccl"
+    fab = out["fabric"]
+    assert fab["all_gather_into_tensor"]["ok"] and fab["all_reduce_counts"]["ok"]
+    assert fab["all_gather_into_tensor"]["bytes_total"] >= 1.3e9 and fab["all_gather_into_tensor"]["gb_per_s_received_per_rank"][0] > 50
 
 
 @pytest.mark.gpu
