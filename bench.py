@@ -242,8 +242,9 @@ def cpu_baseline_record(ns, ncs, st):
 
 def scan_sustained_clock(model, feats_local, toks, tok_off, lens_sorted, order, cfg, dev):
     """Shader clock the chip sustains UNDER the SCAN kernel (MI355X is power-managed: the fp32-MFMA loop runs below the 2 400 MHz
-    the peak is quoted at).  One extra, untimed launch with ITR_SCAN_DEBUG=16: every workgroup adds its s_memtime (shader cycles)
-    and s_memrealtime (100 MHz) deltas into eight counters at the head of a scratch score buffer; clock = cycles / realtime.
+    the peak is quoted at).  One extra, untimed launch through the library's explicit diagnostic entry point
+    (itr_debug_scan_clock_probe -> ops.scan_clock_probe; no environment switch): every workgroup adds its s_memtime (shader
+    cycles) and s_memrealtime (100 MHz) deltas into eight counters at the head of a scratch buffer; clock = cycles / realtime.
     (The stamps themselves cost the kernel a few percent: the launch is not the timed one.)"""
     from itr_amd import ops
     img = model.encode_images(feats_local)
@@ -254,21 +255,9 @@ def scan_sustained_clock(model, feats_local, toks, tok_off, lens_sorted, order, 
     lens[np.asarray(order)] = ls
     off[np.asarray(order)] = np.cumsum(ls) - ls
     plan = ops.ScanPlan(off, lens, words_sorted.shape[0], dev)
-    xa = cfg.get("cross_attn", "t2i")
-    ws = ops.scan_prepare(img, words_sorted, plan, xa)
-    # the instrumented launch adds its eight int64 counters at the head of the buffer it is handed as `out`: a scratch with an EVEN
-    # fp32 row width, so that the int64 view below exists whatever Nc is (never the score matrix of the timed run)
-    scratch = torch.zeros(img.shape[0], plan.Nc + 64 + (plan.Nc & 1), device=dev)
-    os.environ["ITR_SCAN_DEBUG"] = "16"
-    try:
-        ops.scan_xattn_scores(img, words_sorted, plan, cross_attn=xa, raw_feature_norm=cfg.get("raw_feature_norm", "clipped_l2norm"),
-                              agg_func=cfg.get("agg_func", "LogSumExp"), lambda_lse=cfg.get("lambda_lse", 6.0),
-                              lambda_softmax=cfg.get("lambda_softmax", 9.0), out=scratch, workspace=ws)
-        torch.cuda.synchronize()
-    finally:
-        del os.environ["ITR_SCAN_DEBUG"]
-    c = scratch.view(torch.int64).flatten()[:8].cpu().numpy().astype(np.float64)
-    return 100.0 * c[:7].sum() / c[7] if c[7] > 0 else None
+    return ops.scan_clock_probe(img, words_sorted, plan, cross_attn=cfg.get("cross_attn", "t2i"),
+                                raw_feature_norm=cfg.get("raw_feature_norm", "clipped_l2norm"), agg_func=cfg.get("agg_func", "LogSumExp"),
+                                lambda_lse=cfg.get("lambda_lse", 6.0), lambda_softmax=cfg.get("lambda_softmax", 9.0))
 
 
 def cpu_fold_record(workload):
@@ -1194,7 +1183,7 @@ def main_words(args, world, rank, dev, use_dist, backend, primary=True):
             model_name = "SGRAF-%s bi-GRU" % wl["sgraf"]
             kernel_name = ("sgraf pair stage (scan_xattn_kernel emit + sgraf_loc_kernel + " +
                            ("sgr_fused_kernel: all graph steps of a caption group in one workgroup)" if wl["sgraf"] == "SGR" else "saf_pair_kernel)"))
-            note = ("time = the whole itr_sgraf_scores call (global nodes + per-16-image pair stage); algorithmic_* = SURVEY 8d K8; "
+            note = ("time = the whole itr_sgraf_scores call (global nodes + the pair stage in image blocks); algorithmic_* = SURVEY 8d K8; "
                     "achieved/frac = the flop executed: K8 minus the folded key projection of the SGR steps and minus the last step's work on "
                     "nodes other than node 0, which nothing reads (nothing is subtracted for SAF)")
         dtype, peak = "f32", FP32_MFMA_PEAK_TFLOPS
@@ -1237,6 +1226,8 @@ def main_words(args, world, rank, dev, use_dist, backend, primary=True):
         }
         out["per_rank_step_ms"] = [dict(rank=q, min=round(r[0], 2), max=round(r[1], 2), mean=round(r[2], 2), score_kernels=round(r[3], 2),
                                         exchange_wait_after_own_launch=round(r[4], 3)) for q, r in enumerate(per_rank)]
+        if is_sgraf:
+            out["sgraf_block"] = dict(_ops.SGRAF_LAST_BLOCK)      # the image block the free memory admitted, and its workspace
         if "exchange_wait" in timers:
             # N > 1 (or the virtual split): time the scoring stream still had to wait for the all-gather after its own-column launch
             out["exchange"] = {"bytes_gathered": timers["exchange_bytes"], "own_launch_ms": timers["segments"][0][0].elapsed_time(timers["segments"][0][1]),

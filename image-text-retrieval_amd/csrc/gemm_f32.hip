@@ -414,13 +414,19 @@ int gemm_nt_splitk_partials(const float *A, int64_t lda, const float *B, int64_t
 }
 
 bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M,
-                    int64_t N, int64_t K, int act, hipStream_t st, int *rc);      // gemm_stream.hip
+                    int64_t N, int64_t K, int act, hipStream_t st, int *rc, int algo);      // gemm_stream.hip
 
+static int gemm_nt_algo(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                        int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st, int algo);
 int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
+    return gemm_nt_algo(A, lda, B, ldb, bias, C, ldc, M, N, K, act, st, 0);
+}
+static int gemm_nt_algo(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
+                        int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st, int algo) {
     // short K, many row tiles: the streaming kernel takes the whole 128-row tiles, the tile kernel the remaining rows
     int rc = ITR_OK;
-    if (gemm_nt_stream(A, lda, B, ldb, bias, C, ldc, M, N, K, act, st, &rc)) {
+    if (gemm_nt_stream(A, lda, B, ldb, bias, C, ldc, M, N, K, act, st, &rc, algo)) {
         if (rc != ITR_OK) return rc;
         const int64_t done = M / BM * BM;
         if (done == M) return ITR_OK;
@@ -473,6 +479,18 @@ extern "C" int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t 
     ITR_REQUIRE(lda >= 1 && ldb >= K && ldc >= N, "itr_gemm_nt: leading dimension smaller than row");
     ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt: unknown activation %d", act);
     return itr::gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream));
+}
+
+extern "C" int itr_gemm_nt_algo(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                                float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, int algo,
+                                itr_stream_t stream) {
+    ITR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "itr_gemm_nt_algo: negative dimension");
+    if (M == 0 || N == 0) return ITR_OK;
+    ITR_REQUIRE(A && B && C, "itr_gemm_nt_algo: null pointer");
+    ITR_REQUIRE(lda >= 1 && ldb >= K && ldc >= N, "itr_gemm_nt_algo: leading dimension smaller than row");
+    ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt_algo: unknown activation %d", act);
+    ITR_REQUIRE(algo >= 0 && algo <= 3, "itr_gemm_nt_algo: algo must be 0 (auto), 1 (tile), 2 (stream, plain map) or 3 (stream, XCD map)");
+    return itr::gemm_nt_algo(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream), algo);
 }
 
 extern "C" int itr_gemm_nt_acc(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,

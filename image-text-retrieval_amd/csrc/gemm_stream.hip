@@ -80,9 +80,12 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gemm_nt_stream_kernel(GemmStrea
 }
 
 // Host side: true when the streaming kernel took the call (otherwise the caller falls back to the tile kernels).
+// algo (itr_gemm_nt_algo): 0 = the selection rule below, 1 = never (the caller runs the tile kernel), 2 = streaming with the plain
+// tile map wherever the shape admits it, 3 = streaming with the XCD-aware map wherever the shape admits it.
 bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M,
-                    int64_t N, int64_t K, int act, hipStream_t st, int *rc) {
+                    int64_t N, int64_t K, int act, hipStream_t st, int *rc, int algo) {
     *rc = ITR_OK;
+    if (algo == 1) return false;
     // resident workgroups of THIS device: CUs x what the occupancy query admits per CU (2 on gfx950: 64 KB of LDS each), cached
     // per device under a lock (several host threads / devices may call at once)
     static std::mutex mu;
@@ -102,21 +105,21 @@ bool gemm_nt_stream(const float *A, int64_t lda, const float *B, int64_t ldb, co
         }
         resident = resident_of[dev];
     }
-    static const bool off = getenv("ITR_GEMM_STREAM") && atoi(getenv("ITR_GEMM_STREAM")) == 0;
+    const bool off = ITR_EXP_ENV("ITR_GEMM_STREAM") && atoi(ITR_EXP_ENV("ITR_GEMM_STREAM")) == 0;
     // (measured: ahead of the tile kernel at every K -- 179 200 x 1 024 x 2 048: 132 -> 147 TFLOP/s, 800 000 x 2 304 x 768: 120 -> 135,
     // 265 000 x 256 x 256: 79 -> 104; tools/gemm_stream_check.py.  ITR_GEMM_STREAM_KMAX caps K for experiments.)
-    static const int64_t kmax = getenv("ITR_GEMM_STREAM_KMAX") ? atoll(getenv("ITR_GEMM_STREAM_KMAX")) : (1ll << 40);
+    const int64_t kmax = ITR_EXP_ENV("ITR_GEMM_STREAM_KMAX") ? atoll(ITR_EXP_ENV("ITR_GEMM_STREAM_KMAX")) : (1ll << 40);
     if (off || (act != 0 && act != 1 && act != 4) || K % 64 != 0 || K < 128 || K > kmax || N % GS_BM != 0 || M < GS_BM) return false;
     if ((lda % 4) || (ldb % 4) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return false;
     if ((uint64_t)lda * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldb * 4u * GS_BM >= (1ull << 31) || (uint64_t)ldc * 4u * GS_BM >= (1ull << 31)) return false;
     const int64_t tiles_m = M / GS_BM, tiles_n = N / GS_BM;      // whole row tiles; a remainder of rows goes to the tile kernel
-    static const int64_t min_rounds = getenv("ITR_GEMM_STREAM_MINROUNDS") ? atoll(getenv("ITR_GEMM_STREAM_MINROUNDS")) : 2;
+    const int64_t min_rounds = algo >= 2 ? 0 : ITR_EXP_ENV("ITR_GEMM_STREAM_MINROUNDS") ? atoll(ITR_EXP_ENV("ITR_GEMM_STREAM_MINROUNDS")) : 2;
     // streaming pays when every workgroup gets at least two tiles (measured: 16 384 x 1 024 x 1 024 = 2 rounds 130 -> 142 TFLOP/s,
     // 12 800 x 2 304 x 768 = 3.5 rounds 114 -> 132; at one round 5 000 x 3 072 x 1 024 loses 104 -> 96)
     if (tiles_m * tiles_n < min_rounds * resident) return false;
     int64_t grid = resident / tiles_n * tiles_n;
     if (grid < tiles_n) grid = tiles_n;
-    static const bool xcd_off = getenv("ITR_GEMM_STREAM_XCD") && atoi(getenv("ITR_GEMM_STREAM_XCD")) == 0;
+    const bool xcd_off = algo == 2 || (ITR_EXP_ENV("ITR_GEMM_STREAM_XCD") && atoi(ITR_EXP_ENV("ITR_GEMM_STREAM_XCD")) == 0);
     // (measured: +2-3 % from 4 column tiles up -- 179 200 x 1 024 x 2 048: 142 -> 147 TFLOP/s; nothing at 2)
     const int xcd_map = (!xcd_off && tiles_n >= 4 && grid % 8 == 0 && (grid / 8) % tiles_n == 0) ? 1 : 0;
     GemmStreamArgs g{A, B, bias, C, lda, ldb, ldc, tiles_m, tiles_n, (int)K, xcd_map};

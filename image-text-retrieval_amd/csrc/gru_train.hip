@@ -201,7 +201,7 @@ extern "C" int itr_gru_fwd_train(const int64_t *tokens, const int64_t *tok_off, 
     float *skbuf = reinterpret_cast<float *>(static_cast<char *>(workspace) + itr_gru_train_workspace_bytes(n_tok, B, E, D) -
                                              al256(gemm_splitk_scratch_bytes(B, 3 * D, 16)));
     const int splits_h = gemm_splitk_choice(B, 3 * D, D);
-    const bool fuse = getenv("ITR_GRU_REDUCE_KERNEL") == nullptr;   // tools/ A/B switch: separate reduction kernel
+    const bool fuse = ITR_EXP_ENV("ITR_GRU_REDUCE_KERNEL") == nullptr;   // tools/ A/B switch: separate reduction kernel
     const int Lmax = len_host[0];
     ITR_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
     hipLaunchKernelGGL(embed_gather_train_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, x, bad);
@@ -261,7 +261,7 @@ extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const 
     float *skbuf = reinterpret_cast<float *>(static_cast<char *>(workspace) + itr_gru_train_workspace_bytes(n_tok, B, E, D) -
                                              al256(gemm_splitk_scratch_bytes(B, 3 * D, 16)));
     const int splits_c = gemm_splitk_choice(B, D, 3 * D);
-    const bool fuse = getenv("ITR_GRU_REDUCE_KERNEL") == nullptr;
+    const bool fuse = ITR_EXP_ENV("ITR_GRU_REDUCE_KERNEL") == nullptr;
     const int Lmax = len_host[0];
     const int64_t nparts = ceil_div(n_tok, 256);
     ITR_UNSUPPORTED(nparts > 65535, "itr_gru_bwd: more than 16M tokens");

@@ -7,6 +7,18 @@
 
 #include "../../include/itr_hip.h"
 
+// Experiment switches (ablations, phase traces, scheduling variants that lost in earlier rounds) exist ONLY in builds made with
+// -DITR_EXPERIMENT (tools/ab_build.sh): there ITR_EXP_ENV("NAME") is getenv("NAME").  In the shipped library it is a null constant --
+// the library reads NO environment variable (re-entrant, no global mutable state beyond the error string), the switch
+// names do not appear in the binary, and the compiler folds the alternative paths away.  Variants the tests cross-check against
+// (the step-by-step SGR chain, the tile GEMM, the paired GRU launch order ...) are explicit ARGUMENTS of the ABI instead.
+#ifdef ITR_EXPERIMENT
+#include <stdlib.h>
+#define ITR_EXP_ENV(name) ::getenv(name)
+#else
+#define ITR_EXP_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 namespace itr {
 
 void set_error(const char *fmt, ...);
@@ -103,9 +115,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // One GRU cell update, gate order (r, z, n) of torch.nn.GRU (TextEncoder.py:38-70 runs nn.GRU):
 //   r = s(gi_r + gh_r); z = s(gi_z + gh_z); n = tanh(gi_n + r * gh_n); h' = (1 - z) * n + z * h
-// THE definition of the evaluation forward: the stand-alone gate kernel (towers.hip) and the gate epilogue of the recurrence GEMM
-// (gemm_f32.hip) both call it, with explicit fmaf -- hipcc is otherwise free to contract "a * b + c * d" either way, and the two
-// paths (and with them a sharded and a single-process evaluation) must agree bit for bit.
+// THE definition of the evaluation forward: every gate kernel (towers.hip: the per-step kernel and the persistent recurrence) calls
+// it, with explicit fmaf -- hipcc is otherwise free to contract "a * b + c * d" either way, and all forms (and with them a sharded
+// and a single-process evaluation) must agree bit for bit.
 __device__ __forceinline__ float gru_cell(float ir, float iz, float in, float hr, float hz, float hn, float hp) {
     const float r = 1.f / (1.f + expf(-(ir + hr)));
     const float z = 1.f / (1.f + expf(-(iz + hz)));

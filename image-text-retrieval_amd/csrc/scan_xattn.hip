@@ -996,7 +996,7 @@ namespace itr {
 static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
                              int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
                              void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
-                             int64_t img_count, void *bf16_ws, int f16, itr_stream_t stream);
+                             int64_t img_count, void *bf16_ws, int f16, itr_stream_t stream, int debug_bits = 0);
 
 int allow_dynamic_lds(const void *kernel, size_t bytes);      // scan_train.hip
 
@@ -1016,7 +1016,7 @@ static size_t scan_bf16_ws_bytes(int64_t Ni, int R, int64_t n_tiles, int D) {
 static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D,
                              int mode, int norm, int agg, float lambda_softmax, float lambda_lse, float *S, int64_t ldS,
                              void *workspace, size_t workspace_bytes, float *emit_p, float *emit_cn, int64_t img_index0,
-                             int64_t img_count, void *bf16_ws, int f16, itr_stream_t stream) {
+                             int64_t img_count, void *bf16_ws, int f16, itr_stream_t stream, int debug_bits) {
     ITR_REQUIRE(img && S && workspace, "itr_scan_xattn_scores: null pointer");
     ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && n_tiles >= 0 && ldS >= Nc, "itr_scan_xattn_scores: bad shape");
     if (mode != 0 && mode != 1) { set_error("unknown cross_attn mode %d", mode); return ITR_ERR_BADARG; }
@@ -1047,7 +1047,8 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
         Ni = img_count;
         if (Ni == 0) return ITR_OK;
     }
-    if (const char *dbg = getenv("ITR_SCAN_DEBUG")) a.debug = atoi(dbg);
+    a.debug = debug_bits;      // 0, or 16 from itr_debug_scan_clock_probe; the ablation bits exist in experiment builds only
+    if (const char *dbg = ITR_EXP_ENV("ITR_SCAN_DEBUG")) a.debug = atoi(dbg);
     if (a.debug & 16) {   // phase timing: the caller reads the 8 counters placed at the start of S (S is garbage then)
         a.dbg_cycles = reinterpret_cast<unsigned long long *>(S);
         ITR_CHECK_HIP(hipMemsetAsync(S, 0, 64, st));
@@ -1065,11 +1066,11 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
         if (rc != ITR_OK) return rc;
     }
     size_t lds = sizeof(ScanSmem);
-    if (const char *ex = getenv("ITR_SCAN_LDS_EXTRA")) lds += (size_t)atoi(ex);   // occupancy experiments only
+    if (const char *ex = ITR_EXP_ENV("ITR_SCAN_LDS_EXTRA")) lds += (size_t)atoi(ex);   // occupancy experiments only
     // tiles per workgroup (ITR_SCAN_TPW overrides, tools/scan_ablate2.py).  Measured at 1k x 5k: 37.13 / 36.89 / 36.94 / 36.85 ms
     // for 1 / 2 / 4 / 8 -- the launch gaps of one-tile workgroups are already covered by the co-resident workgroup.
     a.tpw = 2;
-    if (const char *te = getenv("ITR_SCAN_TPW")) a.tpw = atoi(te) > 0 ? atoi(te) : 1;
+    if (const char *te = ITR_EXP_ENV("ITR_SCAN_TPW")) a.tpw = atoi(te) > 0 ? atoi(te) : 1;
     const int64_t grid = ceil_div(ceil_div(PI * PJ, 8), (int64_t)a.tpw) * 64 * 8;
     if (bf16_ws) {
         ITR_UNSUPPORTED((uint64_t)Ni * R * D * 4 >= (1ull << 32) || (uint64_t)SC_NT * D * 4 >= (1ull << 32),
@@ -1088,7 +1089,7 @@ static int scan_scores_impl2(const float *img, int64_t n_tiles, int64_t Ni, int6
         a.img_bf = img_bf;
         a.wt_bf = wt_bf;
         // ablation builds of the main loop (tools/scan_ablate2.py bf16x3): 5 = no global loads, 9 = no MFMAs -- results are garbage
-        const int abl = getenv("ITR_SCAN_BF16_ABLATE") ? atoi(getenv("ITR_SCAN_BF16_ABLATE")) : 0;
+        const int abl = ITR_EXP_ENV("ITR_SCAN_BF16_ABLATE") ? atoi(ITR_EXP_ENV("ITR_SCAN_BF16_ABLATE")) : 0;
         if (abl == 5) {
             ITR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_xattn_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipLaunchKernelGGL(scan_xattn_kernel<5>, dim3((unsigned)grid), dim3(SC_THREADS), lds, st, a);
@@ -1134,6 +1135,18 @@ extern "C" int itr_scan_xattn_scores_bf16x3(const float *img, int64_t n_tiles, i
     ITR_REQUIRE(split_format == 0 || split_format == 1, "itr_scan_xattn_scores_bf16x3: split_format 0 (bf16) or 1 (fp16)");
     return itr::scan_scores_impl2(img, n_tiles, Ni, Nc, n_rows, R, D, mode, norm, agg, lambda_softmax, lambda_lse, S, ldS, workspace,
                                   workspace_bytes, nullptr, nullptr, 0, -1, bf16_workspace, split_format, stream);
+}
+
+// Diagnostics: ONE instrumented launch of the SCAN kernel (bench.py's sustained-clock probe).  Same arguments as
+// itr_scan_xattn_scores, but `scratch` is NOT a score matrix afterwards: its first 64 bytes hold eight uint64 counters -- [0..6] the
+// sum over all workgroups of the s_memtime (shader-clock) cycles spent per phase, [7] the sum of the s_memrealtime (100 MHz) ticks --
+// and the rest is undefined.  sustained clock = 100 MHz * sum(c[0..6]) / c[7].  scratch: Ni rows of ld_scratch >= Nc + 64 floats.
+extern "C" int itr_debug_scan_clock_probe(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D, int mode,
+                                          int norm, int agg, float lambda_softmax, float lambda_lse, float *scratch, int64_t ld_scratch,
+                                          void *workspace, size_t workspace_bytes, itr_stream_t stream) {
+    ITR_REQUIRE(ld_scratch >= Nc + 64, "itr_debug_scan_clock_probe: scratch rows must hold Nc + 64 floats");
+    return itr::scan_scores_impl2(img, n_tiles, Ni, Nc, n_rows, R, D, mode, norm, agg, lambda_softmax, lambda_lse, scratch, ld_scratch, workspace,
+                                  workspace_bytes, nullptr, nullptr, 0, -1, nullptr, 0, stream, 16);
 }
 
 // Diagnostics for tools/: resident workgroups per CU of the SCAN kernel as the runtime sees it.

@@ -24,12 +24,14 @@
 // sigmoid(sim_eval_w . x_0 + b) are one GEMM + one small kernel over all the graphs of the image block (sgraf.hip).
 // v_mfma_f32_16x16x4_f32 throughout (exact fp32).  LDS: two [ROWS][SF_LD = 260] fp32 buffers + the group records + the softmax tiles.
 //
-// Two sizes of group (round 4).  ROWS = 32 (the planner's default: every caption of at most 31 words): 79 KB of LDS, TWO 512-thread
-// workgroups per CU -- while one of them sits in its attention phase (block-diagonal 16 x 16 tiles, at best half of the matrix pipe)
-// or at one of its barriers, the other one's projection MFMAs fill the pipe, which a single resident workgroup cannot do (round 3:
-// 80.5 % pipe busy, waves parked 28 %).  ROWS = 64 (captions of 32..63 words, and any hand-made plan with larger groups): 157 KB,
-// one workgroup per CU, as in round 3.  The groups of a call are sorted into the two classes ON THE DEVICE (sgr_group_meta_kernel +
-// sgr_group_classify_kernel: no host round trip); a class's persistent launch reads its item count from device memory.
+// Two sizes of group (round 4).  ROWS = 64 (the planner's default, itr_sgr_plan_node_groups(small_rows = 64)): 157 KB of LDS, one
+// 512-thread workgroup per CU.  ROWS = 32 (opt-in: small_rows = 32 puts every caption of at most 31 words into groups of <= 32 node
+// rows; the Python layer's ITR_SGR_GROUP_ROWS=32): 79 KB, TWO workgroups per CU -- while one of them sits in its attention phase or at
+// a barrier the other one's projection MFMAs can fill the pipe.  Measured in round 4: same scores bit for bit, 740 ms against 731 ms
+// at 1k x 5k -- the second resident workgroup does not raise the matrix pipe's busy fraction (the limit is ALU time, and halving the
+// group doubles the per-item last step and the weight stream), so 64 stayed the default.  The groups of a call are sorted into the two
+// classes ON THE DEVICE (sgr_group_meta_kernel + sgr_group_classify_kernel: no host round trip); a class's persistent launch reads
+// its item count from device memory.
 #include "scan_common.h"
 #include <string.h>
 #include <stdlib.h>
@@ -1051,7 +1053,7 @@ static int sgr_fused_launch_class(SgrFusedArgs g, int cls_index, int64_t n_group
 // Runs the graph steps up to the last step's attention; y0 [nb][Nc][256] receives y of node 0 of every graph.  The caller finishes:
 // x_0 = relu(W_g y + b) as one GEMM over nb * Nc rows, then sigmoid(sim_eval_w . x_0 + b) (sgraf.hip).
 int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t n_caps, int64_t nb, int64_t Nc, int64_t ncols,
-                     const float *const *vq, const float *const *bg, int sgr_step, float *y0, hipStream_t st) {
+                     const float *const *vq, const float *const *bg, int sgr_step, float *y0, bool persistent_walk, hipStream_t st) {
     if (nb == 0 || n_groups == 0) return ITR_OK;
     const SgrWs w = sgr_carve(ws, n_groups, n_caps, sgr_step);
     SgrFusedArgs g;
@@ -1068,10 +1070,9 @@ int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_g
     g.steps = sgr_step;
     g.wqT_last = w.wT;
     g.y0 = y0;
-    static const char *trace_env = getenv("ITR_SGR_TRACE");
+    static const char *trace_env = ITR_EXP_ENV("ITR_SGR_TRACE");
     const char *trace_path = (trace_env && *trace_env) ? trace_env : nullptr;
-    const char *pers_env = getenv("ITR_SGR_PERSISTENT");      // (read per call: the tests run both forms in one process)
-    const bool persistent = !(pers_env && atoi(pers_env) == 0);
+    const bool persistent = persistent_walk;      // (itr_sgraf_scores flag ITR_SGRAF_NON_PERSISTENT: one workgroup per (image, group))
     // the large class first (it is empty for every caption set of at most 31 words when the plan comes from itr_sgr_plan_node_groups:
     // its workgroups read a zero count and leave), then the small one
     int rc = sgr_fused_launch_class<SF_ROWS, 1>(g, 1, n_groups, w, persistent, trace_path, st);

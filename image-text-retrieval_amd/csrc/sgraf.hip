@@ -36,7 +36,7 @@ size_t sgr_fused_workspace_bytes(int64_t n_groups, int64_t n_caps, int sgr_step)
 int sgr_fused_prepare(const int32_t *grp_begin, const int32_t *grp_order, int64_t n_groups, int64_t n_caps, const int32_t *cap_len,
                       const int32_t *cap_col, const float *const *wq, const float *const *wg, int sgr_step, void *ws, int *bad_flag, hipStream_t st);
 int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_groups, int64_t n_caps, int64_t nb, int64_t Nc, int64_t ncols,
-                     const float *const *vq, const float *const *bg, int sgr_step, float *y0, hipStream_t st);
+                     const float *const *vq, const float *const *bg, int sgr_step, float *y0, bool persistent_walk, hipStream_t st);
 int sgr_fused_finish(void *ws, int64_t n_groups, int64_t n_caps, int sgr_step, int64_t Ni, float *S, int64_t ldS, hipStream_t st);
 
 constexpr float BN_EPS = 1e-5f;
@@ -413,47 +413,85 @@ __global__ __launch_bounds__(256) void sgr_final_kernel(const float *__restrict_
 }
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
-// images per block of the pair stage (a multiple of the SCAN image tile).  Round 4: 64 (rounds 1-3: 16) -- a quarter of the launches, and
-// the persistent SGR kernel's tail (the last, partial round of items over the CUs) is a quarter as large: SGR 1k x 5k 735.8 -> 723.5 ms,
-// SAF 373.3 -> 371.3 (same box; 32: 732.9 / 372.7).  The workspace grows with it (5k x 25k: SAF 38 GB, SGR 85 GB of the 288 GB);
-// ITR_SGRAF_IB=16|32|64 overrides it (read once per process: several ranks sharing ONE GPU in the tests).  Scores do not depend on it.
-// The unfused fallback (sim_dim != 256) materialises (ctx - E)^2 and stays at 4.
-static inline int64_t sgraf_ib(int S) {
-    static const int ib = [] {
-        const char *e = getenv("ITR_SGRAF_IB");
-        const int v = e ? atoi(e) : 64;
-        return (v == 16 || v == 32 || v == 64) ? v : 64;
-    }();
-    return S == 256 ? ib : 4;
+// Images per block of the pair stage (a multiple of the SCAN image tile).  64 by default since round 4 (rounds 1-3: 16) -- a quarter of
+// the launches, and the persistent SGR kernel's tail (the last, partial round of items over the CUs) is a quarter as large: SGR 1k x 5k
+// 735.8 -> 723.5 ms, SAF 373.3 -> 371.3 (same box; 32: 732.9 / 372.7).  The workspace grows with it (5k x 25k at 64: SAF 38 GB, SGR
+// 42 GB fused), so the block is an ARGUMENT: the caller sizes it to the memory it has (itr_sgraf_pick_image_block) -- a validation pass
+// inside a training process does not own the whole HBM.  Never larger than the call's image count rounded up to the image tile: small
+// calls do not pay for 64 images.  Scores do not depend on it.  The unfused fallback (sim_dim != 256) materialises (ctx - E)^2: 4.
+static inline int64_t sgraf_ib(int S, int64_t Ni, int image_block) {
+    if (S != 256) return 4;
+    int64_t ib = image_block > 0 ? image_block : ITR_SGRAF_DEFAULT_IMAGE_BLOCK;
+    const int64_t need = (Ni + SC_IMGS - 1) / SC_IMGS * SC_IMGS;
+    if (ib > need) ib = need;
+    return ib < SC_IMGS ? SC_IMGS : ib;
 }
+static inline bool sgraf_block_ok(int image_block) {
+    return image_block == 0 || (image_block >= SC_IMGS && image_block <= 64 && image_block % SC_IMGS == 0);
+}
+// (ctx_glo - cap_glo)^2 rows of the global nodes: only the GEMM chain of sim_dim != 256 (experiment builds can select that chain at 256 too)
+static inline bool sgraf_needs_aglo(int S) {
+#ifdef ITR_EXPERIMENT
+    (void)S;
+    return true;
+#else
+    return S != 256;
+#endif
+}
+// the fused graph steps need neither the query nor the aggregate rows of the word nodes in memory (they live in the workgroup's LDS)
+static inline bool sgraf_fused_layout(int module, int S, int flags) { return module == 1 && S == 256 && !(flags & ITR_SGRAF_UNFUSED_STEPS); }
 
 }  // namespace itr
 
 extern "C" size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_rows, int64_t n_tiles, int D, int S,
-                                            int module) {
+                                            int module, int image_block, int flags) {
     using namespace itr;
-    const int64_t ncols = n_tiles * SC_NT, IB = sgraf_ib(S);
+    const int64_t ncols = n_tiles * SC_NT, IB = sgraf_ib(S, Ni, image_block);
+    const bool fused = sgraf_fused_layout(module, S, flags);
     size_t b = itr_scan_workspace_bytes(Ni, SC_R, n_rows, Nc, n_tiles, D) + 256;
     b += al((size_t)Ni * D * 4) * 3 + al((size_t)Ni * SC_R * D * 4) * 2;        // img_ave, g_emb_v, img_glo; l_emb_v, imgT
     b += al((size_t)n_rows * D * 4) + al((size_t)Nc * D * 4) * 3;                // l_emb_t; cap_ave, g_emb_t, cap_glo
     b += al((size_t)Nc * 4) + al((size_t)Nc * 8);                                // cap_col, seg offsets (unused slot)
     b += al((size_t)IB * ncols * SC_R * 4) + al((size_t)IB * ncols * 4) + al((size_t)IB * Nc * 4);   // P, cn, scan scratch
     const int64_t NcP = (Nc + SC_NT - 1) / SC_NT * SC_NT;                        // captions rounded up to whole 64-row tiles
-    b += (S == 256 ? 0 : al((size_t)IB * ncols * D * 4)) + al((size_t)IB * Nc * D * 4);   // Aloc (unfused path only), Aglo
+    b += (S == 256 ? 0 : al((size_t)IB * ncols * D * 4)) + (sgraf_needs_aglo(S) ? al((size_t)IB * Nc * D * 4) : 0);   // Aloc, Aglo (sim_dim != 256 only)
     b += al((size_t)(NcP - Nc) * D * 4) + al((size_t)IB * NcP * SC_R * 4) + al((size_t)IB * NcP * 4) + al((size_t)IB * SC_R * D * 4);   // cap_glo tail, one-hot weights, unit norms, global "regions"
-    const int nbuf = module == 1 ? 3 : 1;                                        // X (+ Q', Y for SGR)
-    b += (al((size_t)IB * ncols * S * 4) + al((size_t)IB * NcP * S * 4)) * nbuf;
-    if (module == 1) b += al((size_t)S * S * 4) * 2 + (al((size_t)S * S * 4) + al((size_t)S * 4)) * 8;   // W^T scratch, folded query weights
-    if (module == 1 && S == 256) b += al(sgr_fused_workspace_bytes(Nc, Nc, 8)) + 256;                       // group records (<= one per caption), weight fragments, flag
+    b += al((size_t)IB * ncols * S * 4) + al((size_t)IB * NcP * S * 4);         // Xloc, Xglo
+    if (module == 1) {
+        b += al((size_t)IB * NcP * S * 4);                                       // Yglo
+        if (!fused) b += al((size_t)IB * ncols * S * 4) * 2 + al((size_t)IB * NcP * S * 4);   // Qloc, Yloc, Qglo (step-by-step chain only)
+        b += al((size_t)S * S * 4) * 2 + (al((size_t)S * S * 4) + al((size_t)S * 4)) * 8;   // W^T scratch, folded query weights
+        if (S == 256) b += al(sgr_fused_workspace_bytes(Nc, Nc, 8)) + 256;       // group records (<= one per caption), weight fragments, flag
+    }
     return b;
+}
+
+extern "C" int itr_sgraf_pick_image_block(int64_t Ni, int64_t Nc, int64_t n_rows, int64_t n_tiles, int D, int S, int module, int flags,
+                                          size_t max_workspace_bytes, size_t *workspace_bytes) {
+    using namespace itr;
+    ITR_REQUIRE(Ni >= 0 && Nc >= 0 && n_rows >= 0 && n_tiles >= 0 && D > 0 && S > 0, "itr_sgraf_pick_image_block: bad shape");
+    static const int cand[] = {64, 32, 16, 8, 4};
+    int last = 0;
+    for (int c : cand) {
+        const int ib = (int)sgraf_ib(S, Ni, c);
+        if (ib == last) continue;               // (clamped to the image count: the same block as the previous candidate)
+        last = ib;
+        const size_t b = itr_sgraf_workspace_bytes(Ni, Nc, n_rows, n_tiles, D, S, module, ib, flags);
+        if (b <= max_workspace_bytes) {
+            if (workspace_bytes) *workspace_bytes = b;
+            return ib;
+        }
+    }
+    set_error("itr_sgraf_pick_image_block: even a %d-image block needs more than the %zu bytes allowed", last, max_workspace_bytes);
+    return ITR_ERR_UNSUPPORTED;
 }
 
 extern "C" int itr_sgraf_scores(const float *img, const float *words, const int64_t *cap_off, const int32_t *cap_len,
                                 const int32_t *tile_begin_dev, const int32_t *cap_order_dev, int64_t n_tiles,
                                 int64_t Ni, int64_t Nc, int64_t n_rows, int max_len, int R, int D, int S, int module,
                                 int sgr_step, const itr_sgraf_weights *w, const int32_t *node_group_begin_dev,
-                                const int32_t *node_group_order_dev, int64_t n_node_groups, float *Sout, int64_t ldS, void *workspace,
-                                size_t workspace_bytes, itr_stream_t stream) {
+                                const int32_t *node_group_order_dev, int64_t n_node_groups, int image_block, int flags, float *Sout,
+                                int64_t ldS, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
     using namespace itr;
     ITR_REQUIRE(img && words && cap_off && cap_len && tile_begin_dev && cap_order_dev && w && Sout && workspace,
                 "itr_sgraf_scores: null pointer");
@@ -463,15 +501,21 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     ITR_UNSUPPORTED(S > 1024 || (D % SC_BK) != 0, "itr_sgraf_scores: need sim_dim <= 1024 and embed dim %% 32 == 0");
     ITR_UNSUPPORTED(module == 1 && (sgr_step < 1 || sgr_step > 8), "itr_sgraf_scores: sgr_step must be in [1, 8]");
     ITR_UNSUPPORTED(max_len < 1 || max_len > 63, "itr_sgraf_scores: captions of 1..63 words are supported");
-    ITR_REQUIRE(workspace_bytes >= itr_sgraf_workspace_bytes(Ni, Nc, n_rows, n_tiles, D, S, module),
-                "itr_sgraf_scores: workspace too small");
+    ITR_REQUIRE(sgraf_block_ok(image_block), "itr_sgraf_scores: image_block must be 0 (default) or a multiple of %d in [%d, 64], got %d", SC_IMGS,
+                SC_IMGS, image_block);
+    ITR_REQUIRE((flags & ~(ITR_SGRAF_UNFUSED_STEPS | ITR_SGRAF_NON_PERSISTENT)) == 0, "itr_sgraf_scores: unknown flag bits %d", flags);
+    ITR_REQUIRE(n_node_groups >= 0 && n_node_groups <= Nc, "itr_sgraf_scores: bad node-group count");
+    // SGR with the configured sim_dim and a node-group plan: the graph steps run fused (sgr_fused.hip); otherwise step by step
+    const bool have_plan = node_group_begin_dev && node_group_order_dev && n_node_groups > 0;
+    if (module == 1 && S == 256 && !have_plan) flags |= ITR_SGRAF_UNFUSED_STEPS;      // no plan: the chain (and its larger workspace)
+    const bool fused_sgr = sgraf_fused_layout(module, S, flags) && !ITR_EXP_ENV("ITR_SGR_UNFUSED");
+    ITR_REQUIRE(workspace_bytes >= itr_sgraf_workspace_bytes(Ni, Nc, n_rows, n_tiles, D, S, module, image_block, flags),
+                "itr_sgraf_scores: workspace too small (size it with the same image_block and flags; without a node-group plan the step-by-step "
+                "chain runs: ITR_SGRAF_UNFUSED_STEPS)");
     if (Ni == 0 || Nc == 0) return ITR_OK;
     hipStream_t st = as_stream(stream);
-    const int64_t ncols = n_tiles * SC_NT, IB = sgraf_ib(S);
-    // SGR with the configured sim_dim and a node-group plan: the graph steps run fused (sgr_fused.hip); otherwise step by step
-    ITR_REQUIRE(n_node_groups >= 0 && n_node_groups <= Nc, "itr_sgraf_scores: bad node-group count");
-    const bool fused_sgr = module == 1 && S == 256 && node_group_begin_dev && node_group_order_dev && n_node_groups > 0 &&
-                           !getenv("ITR_SGR_UNFUSED");
+    const int64_t ncols = n_tiles * SC_NT, IB = sgraf_ib(S, Ni, image_block);
+    const bool fused_layout = sgraf_fused_layout(module, S, flags);      // (what the workspace was sized for)
 
     // ---- carve
     char *p = static_cast<char *>(workspace);
@@ -486,7 +530,7 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     const int64_t NcP = (Nc + SC_NT - 1) / SC_NT * SC_NT;
     // sim_dim 256: the global nodes come from the local-node kernel (ITR_SGRAF_GLO_GEMM=1: the (a - b)^2 kernel + GEMM + l2norm chain
     // of rounds 1-2, for A/B timing); their rows then lie in whole 64-caption tiles: ldg = NcP rows per image
-    const bool glo_loc = (S == 256) && !getenv("ITR_SGRAF_GLO_GEMM");
+    const bool glo_loc = (S == 256) && !ITR_EXP_ENV("ITR_SGRAF_GLO_GEMM");
     const int64_t ldg = glo_loc ? NcP : Nc;
     float *cap_glo = (float *)take((size_t)Nc * D * 4 + (size_t)(NcP - Nc) * D * 4);       // + zero rows up to the last tile
     int32_t *cap_col = (int32_t *)take((size_t)Nc * 4);
@@ -494,15 +538,18 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     float *P = (float *)take((size_t)IB * ncols * SC_R * 4), *cn = (float *)take((size_t)IB * ncols * 4);
     float *sscr = (float *)take((size_t)IB * Nc * 4);
     float *Aloc = (S == 256) ? nullptr : (float *)take((size_t)IB * ncols * D * 4);
-    float *Aglo = (float *)take((size_t)IB * Nc * D * 4);
+    float *Aglo = sgraf_needs_aglo(S) ? (float *)take((size_t)IB * Nc * D * 4) : nullptr;
     float *Pg = (float *)take((size_t)IB * NcP * SC_R * 4), *cng = (float *)take((size_t)IB * NcP * 4);
     float *gimg = (float *)take((size_t)IB * SC_R * D * 4);
     float *Xloc = (float *)take((size_t)IB * ncols * S * 4), *Xglo = (float *)take((size_t)IB * NcP * S * 4);
     float *Qloc = nullptr, *Qglo = nullptr, *Yloc = nullptr, *Yglo = nullptr;
     float *WqT = nullptr, *WkT = nullptr, *Wfold[8] = {nullptr}, *vfold[8] = {nullptr};
     if (module == 1) {
-        Qloc = (float *)take((size_t)IB * ncols * S * 4); Qglo = (float *)take((size_t)IB * NcP * S * 4);
-        Yloc = (float *)take((size_t)IB * ncols * S * 4); Yglo = (float *)take((size_t)IB * NcP * S * 4);
+        Yglo = (float *)take((size_t)IB * NcP * S * 4);
+        if (!fused_layout) {
+            Qloc = (float *)take((size_t)IB * ncols * S * 4); Yloc = (float *)take((size_t)IB * ncols * S * 4);
+            Qglo = (float *)take((size_t)IB * NcP * S * 4);
+        }
         WqT = (float *)take((size_t)S * S * 4); WkT = (float *)take((size_t)S * S * 4);
         for (int k = 0; k < 8; ++k) { Wfold[k] = (float *)take((size_t)S * S * 4); vfold[k] = (float *)take((size_t)S * 4); }
     }
@@ -573,8 +620,8 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     if (module == 1) {
         // rows of captions Nc .. NcP - 1 (and of refused groups) are never written by the pair / fused kernels but run through the GEMMs of
         // the steps: defined values, not uninitialised workspace
+        // (Qglo -- step-by-step chain only -- is a GEMM output: every row the pair kernel reads is written first)
         ITR_CHECK_HIP(hipMemsetAsync(Yglo, 0, (size_t)IB * NcP * S * 4, st));
-        ITR_CHECK_HIP(hipMemsetAsync(Qglo, 0, (size_t)IB * NcP * S * 4, st));
     }
     if (fused_sgr) {
         ITR_CHECK_HIP(hipMemsetAsync(fused_bad, 0, sizeof(int), st));
@@ -624,7 +671,8 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
         } else if (fused_sgr) {
             // all the graph steps up to the last step's attention in one workgroup per group of captions; the last step's graph
             // projection of node 0 (the only node read afterwards, Fusionmodule.py:443) for ALL the graphs of the block as one GEMM
-            SG_TRY(sgr_fused_scores(Xloc, Xglo, fused_ws, n_node_groups, Nc, nb, ldg, ncols, vfold, w->sgr_g_b, sgr_step, Yglo, st));
+            SG_TRY(sgr_fused_scores(Xloc, Xglo, fused_ws, n_node_groups, Nc, nb, ldg, ncols, vfold, w->sgr_g_b, sgr_step, Yglo,
+                                    !(flags & ITR_SGRAF_NON_PERSISTENT), st));
             SG_TRY(gemm_nt(Yglo, S, w->sgr_g_w[sgr_step - 1], S, w->sgr_g_b[sgr_step - 1], Xglo, S, nb * ldg, S, S, 1 /*relu*/, st));
             hipLaunchKernelGGL(sgr_final_kernel, dim3((unsigned)ceil_div(npairs, 4)), dim3(256), 0, st, Xglo, Nc, S, w->eval_w, w->eval_b,
                                npairs, Sout, ldS, i0, ldg);

@@ -185,9 +185,9 @@ int sgraf_loc_fused(const float *P, const float *cn, const float *img, const flo
     const int64_t grid = ceil_div(n_tiles, (int64_t)8) * 8 * nb;
     // Debug only (tools/loc_trace.py): ITR_LOC_TRACE=<file> makes every launch synchronous and rewrites <file> with one record
     // per workgroup (hardware id + four s_memtime stamps), from which the tool rebuilds each CU's timeline.
-    static const char *trace_path = getenv("ITR_LOC_TRACE");
+    static const char *trace_path = ITR_EXP_ENV("ITR_LOC_TRACE");
     // (experiment: ITR_LOC_ONE_PER_CU=1 asks for 82 KB of LDS, so only one workgroup fits a CU -- the loop's speed without a neighbour)
-    static const size_t lds_bytes = (getenv("ITR_LOC_ONE_PER_CU") && atoi(getenv("ITR_LOC_ONE_PER_CU"))) ? 82 * 1024 : sizeof(LocSmem);
+    static const size_t lds_bytes = (ITR_EXP_ENV("ITR_LOC_ONE_PER_CU") && atoi(ITR_EXP_ENV("ITR_LOC_ONE_PER_CU"))) ? 82 * 1024 : sizeof(LocSmem);
     if (lds_bytes != sizeof(LocSmem)) {
         static bool big_done = false;
         if (!big_done) {

@@ -220,6 +220,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
                            float *out_last, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
     using namespace itr;
     const bool batch_invariant = (gather_last & ITR_GRU_BATCH_INVARIANT) != 0;
+    const bool want_paired = (gather_last & ITR_GRU_PAIRED_DIRECTIONS) != 0, want_input_after_fork = (gather_last & ITR_GRU_INPUT_AFTER_FORK) != 0;
     gather_last &= ITR_GRU_GATHER_LAST;
     ITR_REQUIRE(tokens && tok_off && len_dev && len_host && embed && w_ih && w_hh && b_ih && b_hh && workspace,
                 "itr_gru_fwd: null pointer");
@@ -246,7 +247,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     const int Ep = pad32(E);
     // (split-K sums a dot product in slices: the result depends on the batch size through the slice count -- never with
     // ITR_GRU_BATCH_INVARIANT; the plain kernels all run the same fmaf chain per output element whatever M is)
-    const int splits_h = (B <= 1024 && !batch_invariant && !getenv("ITR_GRU_NO_SPLITK")) ? gemm_splitk_choice(B, 3 * D, D) : 1;   // env: A/B switch for tools/
+    const int splits_h = (B <= 1024 && !batch_invariant && !ITR_EXP_ENV("ITR_GRU_NO_SPLITK")) ? gemm_splitk_choice(B, 3 * D, D) : 1;   // env: A/B switch for tools/
     hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, Ep, w.x,
                        w.bad);
     ITR_CHECK_LAUNCH("embed_gather");
@@ -258,8 +259,8 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     }
     // Both input projections first, on the caller's stream (each fills the chip by itself), THEN the fork: the two recurrences start
     // together and their short last steps (a few hundred active captions: less than one round of tiles) overlap each other instead
-    // of the reverse direction's tail running alone (ITR_GRU_INPUT_AFTER_FORK=1: the round-2 order, for A/B timing).
-    const bool input_first = bi && !getenv("ITR_GRU_INPUT_AFTER_FORK");
+    // of the reverse direction's tail running alone (flag ITR_GRU_INPUT_AFTER_FORK: the round-2 order, kept as a cross-check).
+    const bool input_first = bi && !want_input_after_fork;
     auto input_projection = [&](int dir, hipStream_t sd) -> int {
         const GruWs &ww = dir ? w2 : w;
         const float *wi_use = dir ? w_ih_rev : w_ih;
@@ -278,11 +279,11 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             const int rc = input_projection(dir, st);
             if (rc != ITR_OK) return rc;
         }
-    // ITR_GRU_PAIRED=1 (an experiment that lost, DESIGN.md 9: 10.26 against 9.92 ms on VSE++ 1k x 5k, same box): ONE GEMM launch and
+    // flag ITR_GRU_PAIRED_DIRECTIONS (an experiment that lost: 10.26 against 9.92 ms on VSE++ 1k x 5k, same box): ONE GEMM launch and
     // ONE gate launch per time step for both directions.  The active prefix of step t is the same for both, so the pair is a GEMM
     // of twice the tiles; but GEMM -> gates -> GEMM is then a strict chain, while two streams let one direction's gate kernel run
     // in the other direction's last round of tiles.  Bit-identical results either way (same fmaf chain per element).
-    const bool paired = input_first && splits_h == 1 && D % 4 == 0 && gemm_pair_ok(D, D, D) && getenv("ITR_GRU_PAIRED");
+    const bool paired = input_first && splits_h == 1 && D % 4 == 0 && gemm_pair_ok(D, D, D) && want_paired;
     if (paired) {
         const int64_t dir_stride = (int64_t)(gru_ws_one(n_tok, B, E, D) / 4);
         int64_t n_act = B;
@@ -297,7 +298,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     }
     // the reverse direction's recurrence on a second stream with its own buffers (ITR_GRU_NO_OVERLAP=1: one after the other, for A/B timing)
     SideStream side_obj;
-    SideStream *side = (bi && !paired && !getenv("ITR_GRU_NO_OVERLAP") && side_stream(side_obj)) ? &side_obj : nullptr;
+    SideStream *side = (bi && !paired && !ITR_EXP_ENV("ITR_GRU_NO_OVERLAP") && side_stream(side_obj)) ? &side_obj : nullptr;
     if (side) {
         ITR_CHECK_HIP(hipEventRecord(side->fork, st));
         ITR_CHECK_HIP(hipStreamWaitEvent(side->st, side->fork, 0));

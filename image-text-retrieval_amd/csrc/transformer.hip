@@ -439,7 +439,7 @@ static int dispatch_mha_mfma(const float *q, const float *k, const float *v, int
                              float *out, int64_t ldo, int64_t B, int L, int heads, float scale, hipStream_t st) {
     const int nt = (L + 15) / 16;
     // the register-only kernel: 16-byte context stores (ITR_MHA_LDS=1: the LDS kernel, for A/B timing)
-    if (ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !getenv("ITR_MHA_LDS")) {
+    if (ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !ITR_EXP_ENV("ITR_MHA_LDS")) {
         const int64_t npairs = B * heads;
         const dim3 grid((unsigned)ceil_div(npairs, (int64_t)4));
 #define ITR_MHA_REG(NT_)                                                                                                          \
@@ -513,7 +513,7 @@ extern "C" int itr_mha_small(const float *q, const float *k, const float *v, int
     // matrix-core path: 16-byte aligned head slices (every fused-QKV / separate-projection layout of the path)
     const bool al = (ldq % 4 == 0) && (ldk % 4 == 0) && (ldv % 4 == 0) && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
                      reinterpret_cast<uintptr_t>(v)) & 15) == 0;
-    if (al && !getenv("ITR_MHA_VALU")) {
+    if (al && !ITR_EXP_ENV("ITR_MHA_VALU")) {
         if (dk == 16) return itr::dispatch_mha_mfma<16>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
         if (dk == 32) return itr::dispatch_mha_mfma<32>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);
         return itr::dispatch_mha_mfma<64>(q, k, v, ldq, ldk, ldv, mask, out, ldo, B, L, heads, scale, st);

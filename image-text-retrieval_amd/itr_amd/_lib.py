@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -63,6 +63,7 @@ SIGNATURES = {
     "itr_row_sqnorm": (i32, [vp, vp, i64, i32, vp]),
     "itr_pdist_finish": (i32, [vp, vp, vp, i64, i64, vp]),
     "itr_gemm_nt": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
+    "itr_gemm_nt_algo": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, i32, vp]),
     "itr_proj_l2norm": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "itr_gru_workspace_bytes": (sz, [i64, i64, i32, i32, i32]),
     "itr_gru_fwd": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp,
@@ -89,9 +90,11 @@ SIGNATURES = {
     "itr_affine_cols": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "itr_camera_posenc": (i32, [vp, vp, vp, i64, i32, vp]),
     "itr_camera_summarize": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
-    "itr_sgraf_workspace_bytes": (sz, [i64, i64, i64, i64, i32, i32, i32]),
-    "itr_sgraf_scores": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp, i64, vp, sz, vp]),
+    "itr_sgraf_workspace_bytes": (sz, [i64, i64, i64, i64, i32, i32, i32, i32, i32]),
+    "itr_sgraf_pick_image_block": (i32, [i64, i64, i64, i64, i32, i32, i32, i32, sz, vp]),
+    "itr_sgraf_scores": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, vp, i64, vp, sz, vp]),
     "itr_debug_scan_occupancy": (i32, [vp, vp]),
+    "itr_debug_scan_clock_probe": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp, sz, vp]),
     "itr_rank_gather_gt": (i32, [vp, i64, i64, i64, i64, i32, vp, vp]),
     "itr_rank_counts": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
     "itr_rank_gather_gt_f64": (i32, [vp, i64, i64, i64, i64, i32, vp, vp]),

@@ -107,8 +107,12 @@ def _weight_planes(w):
     return split_bf16(w)
 
 
-def linear(x, weight, bias=None, act=None):
-    """act(x @ weight^T + bias) on the fp32 MFMA GEMM.  x (..., K), weight (N, K)."""
+GEMM_ALGOS = {None: 0, "auto": 0, "tile": 1, "stream_plain": 2, "stream_xcd": 3}
+
+
+def linear(x, weight, bias=None, act=None, algo=None):
+    """act(x @ weight^T + bias) on the fp32 MFMA GEMM.  x (..., K), weight (N, K).  algo: None = the library's own choice;
+    "tile" / "stream_plain" / "stream_xcd" force a kernel (itr_gemm_nt_algo: cross-checks, bit-identical results)."""
     lib = _lib.load()
     x = _dev(x, name="x")
     weight = _dev(weight, name="weight")
@@ -124,6 +128,9 @@ def linear(x, weight, bias=None, act=None):
         return out
     if BF16X3 and M and N and K % 32 == 0:
         gemm_nt_bf16(split_bf16(x.reshape(M, K)), _weight_planes(weight), b, 3, act, out=out.view(M, N))
+        return out
+    if algo is not None:
+        _lib.check(lib.itr_gemm_nt_algo(_p(x), K, _p(weight), K, _p(b), _p(out), N, M, N, K, _ACTS[act], GEMM_ALGOS[algo], _stream()))
         return out
     _lib.check(lib.itr_gemm_nt(_p(x), K, _p(weight), K, _p(b), _p(out), N, M, N, K, _ACTS[act], _stream()))
     return out
@@ -440,7 +447,7 @@ def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='c
     """xattn_score_t2i / _i2t (Objectives.py:329-417).  images (Ni, R, D); words (n_rows, D) with the
     caption layout described by `plan` (ScanPlan).  -> (Ni, Nc).  R = 36 (every reference configuration): the fused kernel;
     any other R <= 100: the one-workgroup-per-pair kernels of the training path (_scan_scores_pairwise), same results.
-    precision='bf16x3' / 'fp16x3' (opt-in study variants): the region x word dot products run on the 16-bit
+    precision='bf16x3' / 'fp16x3' (opt-in study variants, STUDY_SPLIT_PRECISION.md): the region x word dot products run on the 16-bit
     matrix core from split operands (hi.hi + hi.lo + lo.hi, fp32 accumulation; bf16 planes: ~3e-6, fp16 planes: ~1e-7 of the
     fp32 result, fp16 needs |x| <= 65504); everything else is unchanged."""
     lib = _lib.load()
@@ -486,6 +493,28 @@ def scan_xattn_scores(images, words, plan, cross_attn='t2i', raw_feature_norm='c
         _NORMS[raw_feature_norm], _AGGS[agg_func], float(lambda_softmax), float(lambda_lse), _p(out), out.stride(0),
         _p(ws), ws.numel(), _stream()))
     return out
+
+
+def scan_clock_probe(images, words, plan, cross_attn='t2i', raw_feature_norm='clipped_l2norm', agg_func='LogSumExp', lambda_lse=6.0,
+                     lambda_softmax=9.0, workspace=None):
+    """Shader clock [MHz] the chip sustains UNDER the SCAN kernel: one extra INSTRUMENTED launch (itr_debug_scan_clock_probe; the
+    stamps cost the kernel a few percent, so it is never the timed launch).  Every workgroup adds its s_memtime (shader cycles) and
+    s_memrealtime (100 MHz) deltas into eight counters at the head of a scratch buffer; clock = 100 * cycles / ticks."""
+    lib = _lib.load()
+    images = _dev(images, name="images")
+    words = _dev(words, name="words")
+    Ni, R, D = images.shape
+    if R != SCAN_R or plan.long_idx is not None or Ni == 0 or plan.Nc == 0:
+        return None
+    ws = workspace if workspace is not None else scan_prepare(images, words, plan, cross_attn)
+    ld = plan.Nc + 64 + (plan.Nc & 1)                      # an even row width: the int64 view of the head exists whatever Nc is
+    scratch = torch.zeros(Ni, ld, device=images.device, dtype=torch.float32)
+    _lib.check(lib.itr_debug_scan_clock_probe(
+        _p(images), plan.n_tiles, Ni, plan.Nc, words.shape[0], R, D, 0 if cross_attn == 't2i' else 1, _NORMS[raw_feature_norm],
+        _AGGS[agg_func], float(lambda_softmax), float(lambda_lse), _p(scratch), ld, _p(ws), ws.numel(), _stream()))
+    torch.cuda.synchronize()
+    c = scratch.view(torch.int64).flatten()[:8].cpu().numpy().astype(np.float64)
+    return 100.0 * float(c[:7].sum()) / float(c[7]) if c[7] > 0 else None
 
 
 def _scan_scores_with_long_captions(images, words, plan, cross_attn, norm, agg, lambda_lse, lambda_softmax, out, workspace):
@@ -574,15 +603,19 @@ def add_layernorm(x, residual, gamma, beta, eps=1e-12):
     return out
 
 
-def mha_small(q, k, v, mask, B, L, heads, dk, scale):
+def mha_small(q, k, v, mask, B, L, heads, dk, scale, out=None):
     """q, k, v: 2-D views [B*L, *] (last dim contiguous, head h at columns h*dk .. h*dk+dk-1; they may be column
-    slices of one fused QKV buffer).  mask: (B, L) float 0/1 or None.  -> (B*L, heads*dk)."""
+    slices of one fused QKV buffer).  mask: (B, L) float 0/1 or None.  -> (B*L, heads*dk).  `out`: a (B*L, heads*dk) view with a
+    contiguous last dim (a column block of a wider buffer; rows that are not 16-byte aligned take the LDS-staged kernel)."""
     lib = _lib.load()
     for t in (q, k, v):
         if not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
             raise ValueError("mha_small: q/k/v must be fp32 CUDA tensors with a contiguous last dim")
     m = _dev(mask.to(torch.float32), name="mask") if mask is not None else None
-    out = torch.empty(B * L, heads * dk, device=q.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B * L, heads * dk, device=q.device, dtype=torch.float32)
+    elif not (out.is_cuda and out.dtype == torch.float32 and out.stride(-1) == 1 and tuple(out.shape) == (B * L, heads * dk)):
+        raise ValueError("mha_small: out must be a fp32 CUDA (B*L, heads*dk) view with a contiguous last dim")
     _lib.check(lib.itr_mha_small(_p(q), _p(k), _p(v), q.stride(0), k.stride(0), v.stride(0), _p(m), _p(out),
                                  out.stride(0), B, L, heads, dk, float(scale), _stream()))
     return out
@@ -726,9 +759,52 @@ SGRAF_MAX_WORDS = 63      # fused pair kernels: 63 words + the global node = one
 SGRAF_COMPOSED_MAX_WORDS = 191   # the per-caption composition: 191 words + the global node = the 192 graph nodes itr_smry_fwd holds
 
 
-def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, out=None):
+SGRAF_FLAGS = {"unfused_steps": 1, "non_persistent": 2}       # include/itr_hip.h: ITR_SGRAF_UNFUSED_STEPS, ITR_SGRAF_NON_PERSISTENT
+SGRAF_LAST_BLOCK = {}          # diagnostics: what the last sgraf_scores call ran with (image_block, workspace_bytes, budget)
+
+
+def _sgraf_workspace(lib, dev, Ni, Nc, n_rows, n_tiles, D, S_dim, mod, flags, image_block, max_workspace_bytes):
+    """Pick the pair stage's image block for the memory this process can have and allocate the workspace (a
+    validation pass inside a training process -- optimizer state and activations resident -- or a co-tenant must shrink the
+    block, not die).  Budget = `max_workspace_bytes` if given, else 90 % of (free device memory + what torch's caching allocator
+    holds unused); the largest of 64 / 32 / 16 / 8 / 4 images whose workspace fits is taken (itr_sgraf_pick_image_block), and an
+    allocation that still fails falls back to the next smaller block.  image_block / ITR_SGRAF_IB pin the block instead.
+    -> (workspace tensor, image_block)."""
+    if image_block is None and os.environ.get("ITR_SGRAF_IB"):
+        image_block = int(os.environ["ITR_SGRAF_IB"])          # Python-layer knob (several ranks sharing ONE GPU in the tests)
+    if image_block is not None:
+        wsb = lib.itr_sgraf_workspace_bytes(Ni, Nc, n_rows, n_tiles, D, S_dim, mod, int(image_block), flags)
+        SGRAF_LAST_BLOCK.update(image_block=int(image_block), workspace_bytes=int(wsb), budget_bytes=None, pinned=True)
+        return torch.empty(wsb, device=dev, dtype=torch.uint8), int(image_block)
+    if max_workspace_bytes is None:
+        free, _total = torch.cuda.mem_get_info(dev)
+        cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        budget = int(0.9 * (free + cached))
+    else:
+        budget = int(max_workspace_bytes)
+    while True:
+        wsb = C.c_size_t(0)
+        ib = lib.itr_sgraf_pick_image_block(Ni, Nc, n_rows, n_tiles, D, S_dim, mod, flags, max(0, budget), C.byref(wsb))
+        if ib < 0:
+            raise torch.cuda.OutOfMemoryError("sgraf_scores: %s" % lib.itr_last_error().decode())
+        try:
+            ws = torch.empty(wsb.value, device=dev, dtype=torch.uint8)
+        except torch.cuda.OutOfMemoryError:
+            if max_workspace_bytes is not None and budget < wsb.value:
+                raise
+            torch.cuda.empty_cache()
+            budget = wsb.value - 1                             # the next smaller block
+            continue
+        SGRAF_LAST_BLOCK.update(image_block=int(ib), workspace_bytes=int(wsb.value), budget_bytes=budget, pinned=False)
+        return ws, int(ib)
+
+
+def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, out=None, image_block=None, max_workspace_bytes=None,
+                 variant=()):
     """EncoderSimilarity.forward (Fusionmodule.py:406-451), eval mode.  images (Ni, 36, D); words (n_rows, D)
-    with the caption layout of `plan` (ScanPlan on the WORD lengths); weights: the module's state_dict."""
+    with the caption layout of `plan` (ScanPlan on the WORD lengths); weights: the module's state_dict.
+    image_block / max_workspace_bytes: see _sgraf_workspace (default: the largest block the free memory admits).
+    variant: names from SGRAF_FLAGS -- the step-by-step / non-persistent forms the fused kernel is cross-checked against."""
     lib = _lib.load()
     if module_name not in ('SAF', 'SGR'):
         raise ValueError('Invalid input of config.module_name in configs.py')
@@ -756,28 +832,32 @@ def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, ou
             st.sgr_k_w[k] = ptr(pre + "graph_key_w.weight"); st.sgr_k_b[k] = ptr(pre + "graph_key_w.bias")
             st.sgr_g_w[k] = ptr(pre + "sim_graph_w.weight"); st.sgr_g_b[k] = ptr(pre + "sim_graph_w.bias")
     mod = 0 if module_name == 'SAF' else 1
+    flags = 0
+    for v in ((variant,) if isinstance(variant, str) else variant):
+        flags |= SGRAF_FLAGS[v]
+    dev = images.device
     if out is None:
-        out = torch.empty(Ni, plan.Nc, device=images.device, dtype=torch.float32)
-    wsb = lib.itr_sgraf_workspace_bytes(Ni, plan.Nc, words.shape[0], plan.n_tiles, D, S_dim, mod)
-    ws = torch.empty(wsb, device=images.device, dtype=torch.uint8)
+        out = torch.empty(Ni, plan.Nc, device=dev, dtype=torch.float32)
     if plan.Nc and int(plan.len_host.max()) > SGRAF_MAX_WORDS:
         plan = ScanPlan(plan.off_host, plan.len_host, plan.n_rows, plan.device, max_kernel_len=SGRAF_MAX_WORDS)
+
+    def fused_call(Nc_k, max_len, dst):
+        grp = plan.node_groups() if mod == 1 else None      # SGR: the graph steps of a group of captions run in one workgroup
+        fl = flags | (SGRAF_FLAGS["unfused_steps"] if (mod == 1 and not grp) else 0)
+        ws, ib = _sgraf_workspace(lib, dev, Ni, Nc_k, words.shape[0], plan.n_tiles, D, S_dim, mod, fl, image_block, max_workspace_bytes)
+        _lib.check(lib.itr_sgraf_scores(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
+                                        _p(plan.cap_order), plan.n_tiles, Ni, Nc_k, words.shape[0], max_len, R, D, S_dim,
+                                        mod, int(sgr_step), C.byref(st), _p(grp[0]) if grp else None, _p(grp[1]) if grp else None,
+                                        grp[2] if grp else 0, ib, fl, _p(dst), dst.stride(0), _p(ws), ws.numel(), _stream()))
+
     if plan.long_idx is not None:
         # Captions of more than 63 words (Flickr30k has a few, up to 82 tokens) do not fit the 64-node tiles of the fused pair
         # kernels: the others are scored by the fused path, these by the per-caption composition of the training path run in
         # evaluation mode (Fusionmodule.encoder_similarity_train(training=False): same arithmetic, HIP kernels, up to 191 words).
         from .modalmodule import Fusionmodule
-        dev = images.device
         if plan.Nc_kernel:
             part = torch.empty(Ni, plan.Nc_kernel, device=dev, dtype=torch.float32)
-            wsb = lib.itr_sgraf_workspace_bytes(Ni, plan.Nc_kernel, words.shape[0], plan.n_tiles, D, S_dim, mod)
-            ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-            max_len = int(plan.len_host[plan.short_idx].max())
-            grp = plan.node_groups() if mod == 1 else None
-            _lib.check(lib.itr_sgraf_scores(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
-                                            _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc_kernel, words.shape[0], max_len, R, D, S_dim,
-                                            mod, int(sgr_step), C.byref(st), _p(grp[0]) if grp else None, _p(grp[1]) if grp else None,
-                                            grp[2] if grp else 0, _p(part), part.stride(0), _p(ws), wsb, _stream()))
+            fused_call(plan.Nc_kernel, int(plan.len_host[plan.short_idx].max()), part)
             out[:, torch.from_numpy(plan.short_idx).to(dev)] = part
         sim_enc = Fusionmodule.EncoderSimilarity(D, S_dim, module_name, sgr_step)
         own = sim_enc.state_dict()
@@ -793,35 +873,34 @@ def sgraf_scores(images, words, plan, weights, module_name='SAF', sgr_step=3, ou
             out[:, torch.from_numpy(plan.long_idx).to(dev)] = Fusionmodule.encoder_similarity_train(sim_enc, images, w_long, off, lens, None,
                                                                                                    training=False)
         return out
-    max_len = int(plan.len_host.max()) if plan.Nc else 1
-    grp = plan.node_groups() if mod == 1 else None      # SGR: the graph steps of a group of captions run in one workgroup
-    _lib.check(lib.itr_sgraf_scores(_p(images), _p(words), _p(plan.cap_off), _p(plan.cap_len), _p(plan.tile_begin),
-                                    _p(plan.cap_order), plan.n_tiles, Ni, plan.Nc, words.shape[0], max_len, R, D, S_dim,
-                                    mod, int(sgr_step), C.byref(st), _p(grp[0]) if grp else None, _p(grp[1]) if grp else None,
-                                    grp[2] if grp else 0, _p(out), out.stride(0), _p(ws), wsb, _stream()))
+    fused_call(plan.Nc, int(plan.len_host.max()) if plan.Nc else 1, out)
     return out
 
 
-def sgraf_padded(images, captions, cap_lens, weights, module_name='SAF', sgr_step=3):
-    """Reference call shape: captions (Nc, L, D) padded + cap_lens (Fusionmodule.py:406)."""
+def sgraf_padded(images, captions, cap_lens, weights, module_name='SAF', sgr_step=3, **kw):
+    """Reference call shape: captions (Nc, L, D) padded + cap_lens (Fusionmodule.py:406).  kw: sgraf_scores' image_block /
+    max_workspace_bytes / variant."""
     Nc, L, D = captions.shape
     lens = [int(x) for x in cap_lens][:Nc]
     plan = ScanPlan(np.arange(Nc, dtype=np.int64) * L, lens, Nc * L, captions.device)
-    return sgraf_scores(images, _dev(captions, name="captions").reshape(Nc * L, D), plan, weights, module_name, sgr_step)
+    return sgraf_scores(images, _dev(captions, name="captions").reshape(Nc * L, D), plan, weights, module_name, sgr_step, **kw)
 
 
 _TOKENS_CHECKED = {}         # id(tensor) -> (weak reference, (version counter, vocabulary size)) of token tensors whose id range has been checked
 
 
 def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtnorm=False, use_abs=False,
-               gather_last=False, out=None, batch_invariant=False):
+               gather_last=False, out=None, batch_invariant=False, launch_form=None):
     """EncoderText.forward on packed captions (TextEncoder.py:38-70).
     tokens_packed (n_tok,) int64 cuda; tok_off (B,) int64; lengths: host list sorted descending.
     weights: dict with the reference's state_dict names.  -> (n_tok, D) packed word embeddings, or
     (B, D) when gather_last.  `out`: the caller's contiguous (n_tok, D) / (B, D) result buffer -- e.g. the head of the
     send buffer of the sharded evaluation's all-gather (evalpipe.py).  batch_invariant: a caption's embedding does not
-    depend, bit for bit, on which other captions share its batch (ITR_GRU_BATCH_INVARIANT, include/itr_hip.h)."""
+    depend, bit for bit, on which other captions share its batch (ITR_GRU_BATCH_INVARIANT, include/itr_hip.h).
+    launch_form: None (default), "paired" or "input_after_fork" -- the bi-GRU launch orders kept as bit-identical cross-checks
+    (ITR_GRU_PAIRED_DIRECTIONS / ITR_GRU_INPUT_AFTER_FORK flag bits)."""
     lib = _lib.load()
+    form_bits = {None: 0, "paired": 4, "input_after_fork": 8}[launch_form]
     tokens_packed = _dev(tokens_packed, torch.int64, "tokens")
     len_host = _host_i32(lengths)
     B = len(len_host)
@@ -834,14 +913,18 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
     if n_tok:
         # nn.Embedding raises on ids outside [0, V) (TextEncoder.py:41).  The check costs a device -> host round trip, so a token tensor
         # that has been checked is not checked again until it is written to (an evaluation loop encodes the same tokens every step)
-        ent = _TOKENS_CHECKED.get(id(tokens_packed))
-        if not (ent is not None and ent[0]() is tokens_packed and ent[1] == (tokens_packed._version, int(V))):
+        # (The cache trusts torch's version counter: writes through .data, raw pointers or DLPack do not bump it -- such a caller must
+        # pass a fresh tensor.  Inference-mode tensors have no version counter: they are checked every time.)
+        ver = None if tokens_packed.is_inference() else tokens_packed._version
+        ent = _TOKENS_CHECKED.get(id(tokens_packed)) if ver is not None else None
+        if not (ent is not None and ent[0]() is tokens_packed and ent[1] == (ver, int(V))):
             lo, hi = torch.aminmax(tokens_packed)
             if int(lo) < 0 or int(hi) >= V:
                 raise IndexError("index out of range in self")
-            if len(_TOKENS_CHECKED) >= 16:
-                _TOKENS_CHECKED.clear()
-            _TOKENS_CHECKED[id(tokens_packed)] = (weakref.ref(tokens_packed), (tokens_packed._version, int(V)))
+            if ver is not None:
+                if len(_TOKENS_CHECKED) >= 16:
+                    _TOKENS_CHECKED.clear()
+                _TOKENS_CHECKED[id(tokens_packed)] = (weakref.ref(tokens_packed), (ver, int(V)))
     w_ih = _dev(weights['rnn.weight_ih_l0'])
     w_hh = _dev(weights['rnn.weight_hh_l0'])
     b_ih = _dev(weights['rnn.bias_ih_l0'])
@@ -861,7 +944,7 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
     out_last = (res if res is not None else torch.empty(B, D, device=dev, dtype=torch.float32)) if gather_last else None
     _lib.check(lib.itr_gru_fwd(_p(tokens_packed), _p(tok_off), _p(len_dev), len_host.ctypes.data_as(C.c_void_p), B,
                                n_tok, _p(emb), V, E, D, _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), _p(rev[0]),
-                               _p(rev[1]), _p(rev[2]), _p(rev[3]), int(no_txtnorm), int(use_abs), int(bool(gather_last)) | (2 if batch_invariant else 0),
+                               _p(rev[1]), _p(rev[2]), _p(rev[3]), int(no_txtnorm), int(use_abs), int(bool(gather_last)) | (2 if batch_invariant else 0) | form_bits,
                                _p(out), _p(out_last), _p(ws), wsb, _stream()))
     return out_last if gather_last else out
 

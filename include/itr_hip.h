@@ -79,6 +79,13 @@ int itr_gcn_relation(const float *tpg, int64_t ld, float *y, int64_t ldy, int64_
 int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
                 float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
                 itr_stream_t stream);
+/* The same product with the kernel chosen by the CALLER (cross-checks and timing; results are bit-identical for every choice):
+ * algo 0 = itr_gemm_nt's own selection rule, 1 = the 128 x 128 tile kernel, 2 / 3 = the streaming kernel (plain / XCD-aware tile
+ * map) for every shape it admits (N % 128 == 0, K % 64 == 0, K >= 128, 16-byte rows, act in {none, relu, gelu}; other shapes
+ * fall through to the tile kernel). */
+int itr_gemm_nt_algo(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
+                     float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, int algo,
+                     itr_stream_t stream);
 
 /* ---- split-bf16 GEMM (study, opt-in; SURVEY.md 8d "bf16-in / fp32-acc variant reported separately") -------------
  * itr_split_bf16: x [rows, K] fp32 -> out [rows][K / 32][hi (32 bf16) | lo (32 bf16)], hi = bf16(x), lo = bf16(x - hi), both
@@ -121,6 +128,11 @@ int itr_proj_l2norm(const float *x, const float *W, const float *b, float *out, 
  * workspace: itr_gru_workspace_bytes(n_tok, B, E, D, bi) bytes. */
 #define ITR_GRU_GATHER_LAST 1
 #define ITR_GRU_BATCH_INVARIANT 2
+/* launch-order variants of the bi-GRU kept as cross-checks (bit-identical results; both measured slower than the default):
+ * bit 2: ONE recurrence GEMM and ONE gate launch per time step for both directions; bit 3: each direction's input projection
+ * on its own stream after the fork (the round-2 order). */
+#define ITR_GRU_PAIRED_DIRECTIONS 4
+#define ITR_GRU_INPUT_AFTER_FORK 8
 size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional);
 int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev,
                 const int32_t *len_host, int64_t B, int64_t n_tok, const float *embed, int64_t V,
@@ -264,17 +276,37 @@ typedef struct {
 } itr_sgraf_weights;
 int itr_sgr_plan_node_groups(const int32_t *cap_len_host, int64_t Nc, int small_rows /* 64 or 32 */,
                              int32_t *group_begin_host, int32_t *group_order_host, int64_t *n_groups);
+/* image_block: images per block of the pair stage -- 0 = ITR_SGRAF_DEFAULT_IMAGE_BLOCK, else a multiple of 4 in [4, 64]; never more than
+ * the call's image count rounded up to 4.  The workspace grows with it (5k x 25k: 64 -> SAF 38 GB, SGR 42 GB; 16 -> 13 / 14 GB) and
+ * the scores do not depend on it: the caller picks it for the memory it has -- itr_sgraf_pick_image_block returns the largest of
+ * 64 / 32 / 16 / 8 / 4 whose workspace fits max_workspace_bytes (and that size in *workspace_bytes), or ITR_ERR_UNSUPPORTED when even a
+ * 4-image block does not fit (the reference's own loop is O(tile) in memory: Fusionmodule.py:406-451 scores one caption at a time).
+ * flags: ITR_SGRAF_UNFUSED_STEPS = SGR's graph steps as the step-by-step kernel chain even when a node-group plan is given (the form
+ * the fused kernel is cross-checked against; also what runs -- and what the workspace must be sized for -- when NO plan is passed);
+ * ITR_SGRAF_NON_PERSISTENT = fused SGR with one workgroup per (image, group) instead of the persistent walk.  Same scores. */
+#define ITR_SGRAF_DEFAULT_IMAGE_BLOCK 64
+#define ITR_SGRAF_UNFUSED_STEPS 1
+#define ITR_SGRAF_NON_PERSISTENT 2
 size_t itr_sgraf_workspace_bytes(int64_t Ni, int64_t Nc, int64_t n_rows, int64_t n_tiles, int D, int S,
-                                 int module);
+                                 int module, int image_block, int flags);
+int itr_sgraf_pick_image_block(int64_t Ni, int64_t Nc, int64_t n_rows, int64_t n_tiles, int D, int S, int module, int flags,
+                               size_t max_workspace_bytes, size_t *workspace_bytes /* host, may be NULL */);
 int itr_sgraf_scores(const float *img, const float *words, const int64_t *cap_off, const int32_t *cap_len,
                      const int32_t *tile_begin_dev, const int32_t *cap_order_dev, int64_t n_tiles,
                      int64_t Ni, int64_t Nc, int64_t n_rows, int max_len, int R, int D, int S, int module,
                      int sgr_step, const itr_sgraf_weights *w, const int32_t *node_group_begin_dev,
-                     const int32_t *node_group_order_dev, int64_t n_node_groups, float *S_out, int64_t ldS, void *workspace,
-                     size_t workspace_bytes, itr_stream_t stream);
+                     const int32_t *node_group_order_dev, int64_t n_node_groups, int image_block, int flags, float *S_out,
+                     int64_t ldS, void *workspace, size_t workspace_bytes, itr_stream_t stream);
 
 /* diagnostics (tools/): occupancy of the SCAN kernel as reported by the HIP runtime */
 int itr_debug_scan_occupancy(int *blocks_per_cu, int *lds_bytes);
+/* diagnostics (bench.py's sustained-clock probe): one INSTRUMENTED launch of the SCAN kernel with the arguments of
+ * itr_scan_xattn_scores.  `scratch` [Ni, ld_scratch >= Nc + 64] is not a score matrix afterwards: its first 64 bytes hold eight
+ * uint64 counters summed over all workgroups -- [0..6] shader-clock cycles (s_memtime) per phase, [7] 100 MHz ticks
+ * (s_memrealtime); the rest is undefined.  sustained clock [MHz] = 100 * sum(c[0..6]) / c[7]. */
+int itr_debug_scan_clock_probe(const float *img, int64_t n_tiles, int64_t Ni, int64_t Nc, int64_t n_rows, int R, int D, int mode,
+                               int norm, int agg, float lambda_softmax, float lambda_lse, float *scratch, int64_t ld_scratch,
+                               void *workspace, size_t workspace_bytes, itr_stream_t stream);
 
 /* ---- a17: i2t / t2i ranker (itr/metricmodule/evaluation.py:156-222) --------------------
  * Sort-free: rank(query, gt) = #{k: S_k > S_gt} + #{k > gt: S_k == S_gt}; i2t takes the min

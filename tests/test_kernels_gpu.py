@@ -470,7 +470,7 @@ def _sgraf_weights(D, S, steps, seed=5):
 def test_sgr_fused_graph_steps(dev, case, steps):
     """csrc/sgr_fused.hip (all graph-reasoning steps of a group of captions in one workgroup; GraphReasoning.forward,
     Fusionmodule.py:564-597) against the CPU oracle AND against the step-by-step kernel chain it replaces
-    (ITR_SGR_UNFUSED=1), on caption sets that exercise the group plan: graphs of 1..4 node tiles in one group (captions of up
+    (flag ITR_SGRAF_UNFUSED_STEPS), on caption sets that exercise the group plan: graphs of 1..4 node tiles in one group (captions of up
     to 63 words), groups of sixteen one- and two-word captions (every row of the first 16 a global node), a single caption,
     sgr_step 1 / 2 / 3 / 5 / 8 = the most the ABI takes (the last step only computes node 0; with one step it is also the first)."""
     import os
@@ -497,21 +497,17 @@ def test_sgr_fused_graph_steps(dev, case, steps):
     want = O.sgraf_similarity(w, img, cap, lens, 'SGR', steps)
     got = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
     assert maxdiff(got, want) <= 5e-6
-    os.environ["ITR_SGR_UNFUSED"] = "1"
-    try:
-        chain = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
-    finally:
-        del os.environ["ITR_SGR_UNFUSED"]
+    chain = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps, variant="unfused_steps")      # flag ITR_SGRAF_UNFUSED_STEPS
     assert maxdiff(chain, want) <= 5e-6
     assert float((got - chain).abs().max()) <= 2e-6            # two summation orders of the same fp32 arithmetic
     again = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
     assert torch.equal(again, got)                              # run-to-run bit-identical
-    os.environ["ITR_SGR_PERSISTENT"] = "0"                      # one workgroup per (image, group) instead of the persistent walk
-    try:
-        per_item = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
-    finally:
-        del os.environ["ITR_SGR_PERSISTENT"]
+    # one workgroup per (image, group) instead of the persistent walk (flag ITR_SGRAF_NON_PERSISTENT)
+    per_item = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps, variant="non_persistent")
     assert torch.equal(per_item, got)                           # same arithmetic per item: bit-identical
+    # the image block is an argument (memory-aware by default): the scores do not depend on it
+    for ib in (4, 8):
+        assert torch.equal(ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps, image_block=ib), got), ib
     # the two-class plan (round 4): captions of <= 31 words in groups of <= 32 node rows (two workgroups per CU), longer ones in groups of
     # <= 64 -- a caption's graph is computed with the same arithmetic whatever group and class it lands in
     os.environ["ITR_SGR_GROUP_ROWS"] = "32"
@@ -602,7 +598,7 @@ def test_gru_full_size_vs_oracle(dev):
 @pytest.mark.parametrize("V,E,D,B,lo,hi", [(11353, 300, 1024, 1500, 3, 24), (500, 64, 256, 1100, 1, 9), (800, 300, 1024, 24, 6, 21)])
 def test_bigru_launch_forms_are_bit_identical(dev, monkeypatch, V, E, D, B, lo, hi):
     """The three ways csrc/towers.hip can issue a bi-GRU -- default: both input projections, then the two recurrences on two
-    streams; ITR_GRU_INPUT_AFTER_FORK=1: each direction's projection on its own stream (round 2); ITR_GRU_PAIRED=1: ONE GEMM and ONE
+    streams; flag ITR_GRU_INPUT_AFTER_FORK: each direction's projection on its own stream (round 2); ITR_GRU_PAIRED_DIRECTIONS: ONE GEMM and ONE
     gate launch per time step for both directions (the second problem of `gemm_nt_fast_kernel`, blockIdx.z of the gate kernel) --
     run the same arithmetic per element: bit-identical sequence outputs and last states, and equal to the oracle (EncoderText,
     TextEncoder.py:38-70) on the rows it can afford."""
@@ -618,12 +614,10 @@ def test_bigru_launch_forms_are_bit_identical(dev, monkeypatch, V, E, D, B, lo, 
     kw = dict(batch_invariant=True) if B <= 1024 else {}          # small batches take the paired form only without split-K
     got = ops.gru_encode(toks, off, lengths, wd, True, **kw)
     got_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, **kw)
-    for env in ("ITR_GRU_PAIRED", "ITR_GRU_INPUT_AFTER_FORK"):
-        monkeypatch.setenv(env, "1")
-        two = ops.gru_encode(toks, off, lengths, wd, True, **kw)
-        two_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, **kw)
-        monkeypatch.delenv(env)
-        assert torch.equal(got, two) and torch.equal(got_last, two_last), env
+    for form in ("paired", "input_after_fork"):                  # explicit flag bits of itr_gru_fwd (no environment switch)
+        two = ops.gru_encode(toks, off, lengths, wd, True, launch_form=form, **kw)
+        two_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, launch_form=form, **kw)
+        assert torch.equal(got, two) and torch.equal(got_last, two_last), form
     n = 20                                                         # the oracle on the 20 longest captions (a GRU row depends on no other row)
     want, _ = O.encoder_text(ids[:n], lengths[:n], w, True, False, False, None)
     o = 0
