@@ -6,11 +6,12 @@
 // (with np.argsort(...)[::-1] the higher index wins exact ties), so one streaming
 // pass over S per direction is enough: integer compares, HBM-bound (4 bytes/pair/direction).
 //
-//   i2t : one workgroup per image row; 5 GT captions -> 5 counters per lane, float4 loads,
-//         wave + LDS reduction, min over the 5.
+// fp32 matrices: ONE kernel reads every element once and serves both directions (rank_fused_kernel below).
 //   t2i : one lane owns 4 consecutive caption columns (float4, coalesced across the wave) and
 //         walks down a chunk of image rows; partial counts are added with one atomic per column
 //         so row blocks (other workgroups, or other GPUs after an all-reduce) just sum.
+//   i2t : the same elements against the row's best ground-truth key, counted with lane masks on the scalar unit.
+// float64 matrices (ensemble averages) keep one pass per direction.
 // S may be a row block of the global matrix (multi-GPU row sharding): row0 is the global index
 // of its first row, and s_gt[] carries the GT score of every caption (gathered over ranks).
 #include "itr_common.h"
@@ -30,151 +31,205 @@ __global__ void gather_gt_kernel(const float *__restrict__ S, int64_t ldS, int64
 
 // (score, index) as ONE 64-bit key: larger score first, then the larger index -- exactly the tie rule of the counts
 // (#{S_k > S_gt} + #{k > gt : S_k == S_gt} = #{key_k > key_gt}) and of the top-1 (np.argsort(...)[::-1]: the higher index wins).
-// e + 0.0f folds -0.0 into +0.0 (they compare equal as floats, their bit patterns do not).  Round 4: the counts were five float
-// compare chains with 64-bit index compares per element (~50 vector instructions per element: the row pass was bound by the vector
-// ALU at 2.6 TB/s, not by HBM); one v_cmp_gt_u64 + one add per GT caption now, and only im_div of them (template G).
-__device__ __forceinline__ unsigned long long rank_key(float e, unsigned idx) {
-    return ((unsigned long long)float_order_key(e + 0.0f) << 32) | idx;
+// Keys of distinct elements are distinct, so the counts are those of a TOTAL order -- which is what makes i2t cheap: the best of an
+// image's im_div ground-truth captions is the one with the LARGEST key, and  min_g #{key > gkey_g} = #{key > max_g gkey_g}:
+// ONE compare per element instead of im_div.
+// score_key canonicalises first: e + 0.0f folds -0.0 into +0.0 (equal as floats, different bit patterns) and fminf(., inf) maps NaN
+// to +inf: a NaN score sorts as the LARGEST value, like np.argsort (NaN last ascending = first after [::-1]); the float64 kernels use
+// the same rule.
+__device__ __forceinline__ uint32_t score_key(float e) {
+    const uint32_t u = __float_as_uint(fminf(e + 0.0f, INFINITY));
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);      // = float_order_key, as three integer instructions
+}
+__device__ __forceinline__ unsigned long long key64(uint32_t hi, uint32_t lo) { return ((unsigned long long)hi << 32) | lo; }
+__device__ __forceinline__ unsigned long long rank_key(float e, unsigned idx) { return key64(score_key(e), idx); }
+
+// ---- ONE pass over S for both directions (round 5) ----------------------------------------------------------
+// Rounds 1-4 read the score matrix twice (a row pass for i2t, a column pass for t2i: 1.0 GB for the 0.5 GB matrix of 5k x 25k,
+// 94 + 122 us).  Now a workgroup owns a tile of RF_ROWS rows x 1 024 columns and every element it loads serves both directions:
+//   t2i (columns): a lane owns 4 consecutive columns (one float4 per row, coalesced across the wave) and keeps, per column, the
+//       count #{key > gkey_col} and the running best (score key, row) while it walks down the rows -- as before;
+//   i2t (rows):    the row's ONE ground-truth key (above) sits in scalar registers; per element one v_cmp_gt_u64 whose lane mask
+//       is counted on the SCALAR unit (s_bcnt1) -- no per-lane counters, no cross-lane reduction of counts; the row's top-1 is a
+//       6-step DPP max of the lane maxima.  Row results are parked in lane (row mod 64) of three registers (v_writelane) and
+//       leave the workgroup once per 64 rows: the four waves are combined through LDS, then one atomicAdd / one 64-bit
+//       atomicMax per row (other column blocks -- and nobody else -- add to the same row).
+// RF_U rows are requested before the first is consumed (the old kernels had one 16-byte load per lane in flight and relied on
+// occupancy alone: they were latency-bound, not ALU- or HBM-bound).
+constexpr int RF_ROWS = 128;      // rows per workgroup: one pair of column atomics per column and workgroup
+constexpr int RF_U = 8;           // rows in flight per lane
+constexpr int RF_COLS = RANK_THREADS * 4;
+
+// max over the wave of a u32 (identity 0), returned uniform.  row_shr within the rows of 16 lanes, then the two row broadcasts.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));   // row_shr:1
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));   // row_shr:2
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));   // row_shr:4
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));   // row_shr:8  -> lane 15 of every row: the row's max
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));   // row_bcast:15 into rows 1 and 3
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-template <int G>
-__global__ __launch_bounds__(RANK_THREADS) void i2t_rank_kernel(const float *__restrict__ S, int64_t ldS,
-                                                                int64_t row0, int64_t Nc, int im_div,
-                                                                int32_t *__restrict__ rank_out,
-                                                                int32_t *__restrict__ top1_out) {
-    __shared__ int s_cnt[RANK_THREADS / 64][MAX_IMDIV];
-    __shared__ unsigned long long s_best[RANK_THREADS / 64];
-    const int64_t r = blockIdx.x;
-    const float *row = S + r * ldS;
-    const int64_t gi = row0 + r;  // global image index
-    unsigned long long gkey[G];
-    int cnt[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int64_t gidx = gi * im_div + g;
-        // a GT caption past the end of the matrix: nothing is larger than its key (its count is not read)
-        gkey[g] = gidx < Nc ? rank_key(row[gidx], (unsigned)gidx) : ~0ull;
-        cnt[g] = 0;
+// per local row: the key of its best ground-truth caption (~0: the image has none inside the matrix), zeroed accumulators
+__global__ void rank_rows_prepare_kernel(const float *__restrict__ S, int64_t ldS, int64_t row0, int64_t nrows, int64_t Nc, int im_div,
+                                         unsigned long long *__restrict__ row_gkey, unsigned long long *__restrict__ row_best,
+                                         int32_t *__restrict__ i2t_cnt) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const int64_t gi = row0 + r;
+    unsigned long long gk = 0;
+    bool any = false;
+    for (int g = 0; g < im_div; ++g) {
+        const int64_t c = gi * im_div + g;
+        if (c >= Nc) break;
+        const unsigned long long k = rank_key(S[r * ldS + c], (unsigned)c);
+        gk = k > gk ? k : gk;
+        any = true;
     }
-    unsigned long long best = 0;  // max => highest index on ties
-    const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
-    const int64_t nvec = vec ? (Nc >> 2) : 0;
-    for (int64_t c = threadIdx.x; c < nvec; c += RANK_THREADS) {
-        const float4 v = reinterpret_cast<const float4 *>(row)[c];
+    row_gkey[r] = any ? gk : ~0ull;
+    row_best[r] = 0;
+    i2t_cnt[r] = 0;
+}
+
+__global__ void rank_rows_finish_kernel(int64_t row0, int64_t nrows, int64_t Nc, int im_div, const unsigned long long *__restrict__ row_best,
+                                        int32_t *__restrict__ i2t_rank, int32_t *__restrict__ i2t_top1) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    i2t_top1[r] = (int32_t)(row_best[r] & 0xffffffffu);
+    if ((row0 + r) * im_div >= Nc) i2t_rank[r] = 0x7fffffff;      // no ground-truth caption inside the matrix (as rounds 1-4)
+}
+
+// FULL: every lane of the workgroup owns four valid columns and the rows are 16-byte aligned (all but the last column block of an
+// aligned matrix): plain float4 loads, no per-lane column guards.  Otherwise the guarded form (scalar loads, key 0 for columns
+// past the end).
+// DIAG: the tile may contain ground-truth pairs (the rows' GT columns / the columns' GT rows fall inside it: 1 tile in 40 at
+// 5k x 25k).  Everywhere else the index half of a 64-bit key compare is the SAME for the whole tile -- every column of the tile
+// lies on one side of the row's GT column, every row on one side of a column's GT row -- and
+//     key64(ok, idx) > key64(g_ok, g_idx)   <=>   ok > g_ok - (idx > g_idx)
+// becomes a 32-bit compare against a threshold fixed per row (scalar) / per column (once per tile).
+template <bool FULL, bool DIAG>
+__device__ __forceinline__ void rank_tile(const float *__restrict__ S, int64_t ldS, int64_t row0, int64_t r_begin, int64_t r_end, int64_t Nc,
+                                          int im_div, const float *__restrict__ s_gt, const unsigned long long *__restrict__ row_gkey,
+                                          int32_t *__restrict__ i2t_cnt, unsigned long long *__restrict__ row_best,
+                                          int32_t *__restrict__ t2i_cnt, unsigned long long *__restrict__ t2i_best,
+                                          uint32_t (*s_rows)[RANK_THREADS / 64][64]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t cb = (int64_t)blockIdx.x * RF_COLS;
+    const int64_t cw = cb + wave * 256;      // first column of this wave
+    const int64_t c0 = cw + lane * 4;
+    const int ncol = FULL ? 4 : (c0 >= Nc ? 0 : ((Nc - c0 >= 4) ? 4 : (int)(Nc - c0)));
+    uint32_t cg_ok[4], cg_row[4], c_thr[4], b_ok[4], b_row[4];
+    int cnt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {      // (score of the column's GT image, its row): a row counts when its key is larger
+        cg_ok[u] = u < ncol ? score_key(s_gt[c0 + u]) : 0xffffffffu;
+        cg_row[u] = u < ncol ? (uint32_t)((c0 + u) / im_div) : 0xffffffffu;
+        c_thr[u] = u < ncol ? cg_ok[u] - ((uint32_t)(row0 + r_begin) > cg_row[u] ? 1u : 0u) : 0xffffffffu;      // (!DIAG)
+        b_ok[u] = 0; b_row[u] = 0; cnt[u] = 0;
+    }
+    const uint32_t col0 = (uint32_t)c0;
+    uint32_t rv_cnt = 0, rv_ok = 0, rv_col = 0;
+    int64_t rc = r_begin;
+    // one row of the tile (v = this lane's four scores of it)
+    auto row_step = [&](const float4 &v, int64_t r) {
+        const unsigned long long gk = row_gkey[r];                            // uniform address: a scalar load
+        const uint32_t grow = (uint32_t)(row0 + r);
+        const uint32_t r_thr = (uint32_t)(gk >> 32) - ((uint32_t)cb > (uint32_t)gk ? 1u : 0u);      // (!DIAG; scalar)
         const float e[4] = {v.x, v.y, v.z, v.w};
+        uint32_t ok[4];
+        int scnt = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const unsigned long long key = rank_key(e[u], (unsigned)(c * 4 + u));
-            best = key > best ? key : best;
+            ok[u] = u < ncol ? score_key(e[u]) : 0u;                          // key 0 is below every real key: never counted, never the best
+            // i2t: one compare against the row's GT key; the lane mask is counted on the scalar unit
+            const bool above = DIAG ? key64(ok[u], u < ncol ? col0 + u : 0u) > gk : ok[u] > r_thr;
+            scnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(above));
+            // t2i: count + running best of the column (rows ascend: >= keeps the higher row among equal scores)
+            cnt[u] += DIAG ? key64(ok[u], grow) > key64(cg_ok[u], cg_row[u]) : ok[u] > c_thr[u];
+            const bool ge = ok[u] >= b_ok[u];
+            b_ok[u] = ge ? ok[u] : b_ok[u];
+            b_row[u] = ge ? grow : b_row[u];
+        }
+        // i2t top-1: the wave's maximum, the highest lane holding it, the highest of that lane's columns holding it (scalar unit)
+        uint32_t lm = ok[0] > ok[1] ? ok[0] : ok[1];
+        const uint32_t lm2 = ok[2] > ok[3] ? ok[2] : ok[3];
+        lm = lm > lm2 ? lm : lm2;
+        const uint32_t wm = wave_max_u32(lm);
+        const int hl = 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(lm == wm));      // (non-empty: lm == wm on at least one lane)
+        const uint32_t o3 = (uint32_t)__builtin_amdgcn_readlane((int)ok[3], hl), o2 = (uint32_t)__builtin_amdgcn_readlane((int)ok[2], hl),
+                       o1 = (uint32_t)__builtin_amdgcn_readlane((int)ok[1], hl);
+        const uint32_t wcol = (uint32_t)cw + (uint32_t)hl * 4u + (o3 == wm ? 3u : o2 == wm ? 2u : o1 == wm ? 1u : 0u);
+        // three uniform values into lane (r - rc) of the row registers (gfx9's v_writelane takes ONE scalar operand besides m0: a lane
+        // compare + three selects are as cheap)
+        const bool mine = lane == (int)(r - rc);
+        rv_cnt = mine ? (uint32_t)scnt : rv_cnt;
+        rv_ok = mine ? wm : rv_ok;
+        rv_col = mine ? wcol : rv_col;
+    };
+    auto load_row = [&](int64_t r) -> float4 {
+        const float *p = S + r * ldS + c0;
+        if (FULL) return *reinterpret_cast<const float4 *>(p);
+        float4 v;
+        v.x = ncol > 0 ? p[0] : 0.f; v.y = ncol > 1 ? p[1] : 0.f; v.z = ncol > 2 ? p[2] : 0.f; v.w = ncol > 3 ? p[3] : 0.f;
+        return v;
+    };
+    for (; rc < r_end; rc += 64) {       // 64 rows: their results live in lane (row - rc) of rv_*
+        rv_cnt = 0; rv_ok = 0; rv_col = 0;
+        const int64_t rc_end = (rc + 64 < r_end) ? rc + 64 : r_end;
+        int64_t r = rc;
+        for (; r + RF_U <= rc_end; r += RF_U) {                               // RF_U rows requested before the first is consumed
+            float4 v[RF_U];
 #pragma unroll
-            for (int g = 0; g < G; ++g) cnt[g] += key > gkey[g];
+            for (int k = 0; k < RF_U; ++k) v[k] = load_row(r + k);
+#pragma unroll
+            for (int k = 0; k < RF_U; ++k) row_step(v[k], r + k);
+        }
+        for (; r < rc_end; ++r) row_step(load_row(r), r);                     // the matrix's last rows (nrows % 8)
+        // the four waves hold the same 64 rows over four column ranges: combine through LDS, one atomic pair per row
+        __syncthreads();                                                      // (the previous chunk's readers are done)
+        s_rows[0][wave][lane] = rv_cnt; s_rows[1][wave][lane] = rv_ok; s_rows[2][wave][lane] = rv_col;
+        __syncthreads();
+        if (wave == 0 && rc + lane < rc_end) {
+            uint32_t c = 0;
+            unsigned long long best = 0;
+#pragma unroll
+            for (int w = 0; w < RANK_THREADS / 64; ++w) {
+                c += s_rows[0][w][lane];
+                const unsigned long long k = key64(s_rows[1][w][lane], s_rows[2][w][lane]);
+                best = k > best ? k : best;
+            }
+            if (c) atomicAdd(&i2t_cnt[rc + lane], (int)c);
+            if (best) atomicMax(&row_best[rc + lane], best);
         }
     }
-    for (int64_t k = nvec * 4 + threadIdx.x; k < Nc; k += RANK_THREADS) {
-        const unsigned long long key = rank_key(row[k], (unsigned)k);
-        best = key > best ? key : best;
 #pragma unroll
-        for (int g = 0; g < G; ++g) cnt[g] += key > gkey[g];
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int g = 0; g < G; ++g) cnt[g] = wave_sum_i(cnt[g]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(best, o, 64);
-        best = other > best ? other : best;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) s_cnt[wave][g] = cnt[g];
-        s_best[wave] = best;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int rank = 0x7fffffff;
-        for (int g = 0; g < G; ++g) {
-            if (gi * im_div + g >= Nc) break;
-            int t = 0;
-            for (int w = 0; w < RANK_THREADS / 64; ++w) t += s_cnt[w][g];
-            rank = t < rank ? t : rank;
+    for (int u = 0; u < 4; ++u)
+        if (u < ncol) {
+            if (cnt[u]) atomicAdd(&t2i_cnt[c0 + u], cnt[u]);
+            atomicMax(&t2i_best[c0 + u], key64(b_ok[u], b_row[u]));
         }
-        unsigned long long b = 0;
-        for (int w = 0; w < RANK_THREADS / 64; ++w) b = s_best[w] > b ? s_best[w] : b;
-        rank_out[r] = rank;
-        top1_out[r] = (int32_t)(b & 0xffffffffu);
-    }
 }
 
-#ifndef ITR_T2I_ROWS
-#define ITR_T2I_ROWS 128
-#endif
-#ifndef ITR_T2I_QUADS
-#define ITR_T2I_QUADS 1
-#endif
-constexpr int T2I_ROWS = ITR_T2I_ROWS;     // image rows per workgroup (one pair of atomics per column and workgroup: fewer rows = more atomics)
-constexpr int T2I_QUADS = ITR_T2I_QUADS;   // float4 column groups per lane, 1 024 columns apart (a workgroup reads QUADS x 4 KB contiguous per row)
-
-// Column pass: a workgroup covers QUADS x 1 024 consecutive columns x ROWS rows (lane t owns columns 1024 q + 4 t .. + 3 of the block).
-// Round 4 sweep on one box (5 000 x 25 000, us per launch; tools/ab_build.sh -DITR_T2I_QUADS / -DITR_T2I_ROWS): QUADS x ROWS =
-// 1 x 64: 127.0 (rounds 1-3), 1 x 128: 121.8 (now), 1 x 256: 176.9, 2 x 64: 155.7, 2 x 128: 188.0, 4 x 64: 220.3, 4 x 16: 331 --
-// wider contiguous reads per row LOSE (fewer workgroups in flight), fewer rows per workgroup lose to the atomics (one pair per
-// column and workgroup, executed at the memory side).  ~4 TB/s = half of the HBM peak is where this layout ends.
-__global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__restrict__ S, int64_t ldS,
-                                                                int64_t row0, int64_t nrows, int64_t Nc,
-                                                                int im_div, const float *__restrict__ s_gt,
-                                                                int32_t *__restrict__ rank_acc,
-                                                                unsigned long long *__restrict__ best_acc) {
-    const int64_t cb = (int64_t)blockIdx.x * (RANK_THREADS * 4 * T2I_QUADS) + threadIdx.x * 4;
-    const int64_t r_begin = (int64_t)blockIdx.y * T2I_ROWS;
-    const int64_t r_end = (r_begin + T2I_ROWS < nrows) ? r_begin + T2I_ROWS : nrows;
-    unsigned long long gkey[T2I_QUADS][4], best[T2I_QUADS][4];
-    int cnt[T2I_QUADS][4];
-    int ncol[T2I_QUADS];
-#pragma unroll
-    for (int q = 0; q < T2I_QUADS; ++q) {
-        const int64_t c0 = cb + (int64_t)q * RANK_THREADS * 4;
-        ncol[q] = c0 >= Nc ? 0 : ((Nc - c0 >= 4) ? 4 : (int)(Nc - c0));
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {      // (score of the GT image, its row): a row counts when its key is larger (rank_key: the tie rule)
-            gkey[q][u] = u < ncol[q] ? rank_key(s_gt[c0 + u], (unsigned)((c0 + u) / im_div)) : ~0ull;
-            best[q][u] = 0;
-            cnt[q][u] = 0;
-        }
-    }
-    const bool vec = ((ldS & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
-    for (int64_t r = r_begin; r < r_end; ++r) {
-        const float *p = S + r * ldS + cb;
-        float e[T2I_QUADS][4];
-#pragma unroll
-        for (int q = 0; q < T2I_QUADS; ++q) {
-            const float *pq = p + q * RANK_THREADS * 4;
-            if (vec && ncol[q] == 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(pq);
-                e[q][0] = v.x; e[q][1] = v.y; e[q][2] = v.z; e[q][3] = v.w;
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) e[q][u] = u < ncol[q] ? pq[u] : -INFINITY;
-            }
-        }
-        const unsigned gr = (unsigned)(row0 + r);
-#pragma unroll
-        for (int q = 0; q < T2I_QUADS; ++q)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned long long key = rank_key(e[q][u], gr);
-                cnt[q][u] += key > gkey[q][u];
-                best[q][u] = key > best[q][u] ? key : best[q][u];
-            }
-    }
-#pragma unroll
-    for (int q = 0; q < T2I_QUADS; ++q)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u < ncol[q]) {
-                const int64_t c = cb + (int64_t)q * RANK_THREADS * 4 + u;
-                if (cnt[q][u]) atomicAdd(&rank_acc[c], cnt[q][u]);
-                atomicMax(&best_acc[c], best[q][u]);
-            }
+__global__ __launch_bounds__(RANK_THREADS) void rank_fused_kernel(const float *__restrict__ S, int64_t ldS, int64_t row0, int64_t nrows,
+                                                                  int64_t Nc, int im_div, const float *__restrict__ s_gt,
+                                                                  const unsigned long long *__restrict__ row_gkey,
+                                                                  int32_t *__restrict__ i2t_cnt, unsigned long long *__restrict__ row_best,
+                                                                  int32_t *__restrict__ t2i_cnt, unsigned long long *__restrict__ t2i_best) {
+    __shared__ uint32_t s_rows[3][RANK_THREADS / 64][64];
+    const int64_t cb = (int64_t)blockIdx.x * RF_COLS;
+    const int64_t r_begin = (int64_t)blockIdx.y * RF_ROWS;
+    const int64_t r_end = (r_begin + RF_ROWS < nrows) ? r_begin + RF_ROWS : nrows;
+    const bool full = (cb + RF_COLS <= Nc) && ((ldS & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
+    // ground-truth pairs inside the tile?  rows R0 .. R1-1 have their GT columns in [im_div R0, im_div R1); columns cb .. cb+1023
+    // have their GT rows in [cb / im_div, (cb + 1023) / im_div].  (Conservative: a tile flagged without need only runs the exact form.)
+    const int64_t R0 = row0 + r_begin, R1 = row0 + r_end;
+    const bool diag = (im_div * R0 <= cb + RF_COLS - 1) && (im_div * R1 - 1 >= cb);
+#define ITR_RANK_TILE(F, D) rank_tile<F, D>(S, ldS, row0, r_begin, r_end, Nc, im_div, s_gt, row_gkey, i2t_cnt, row_best, t2i_cnt, t2i_best, s_rows)
+    if (full) { if (diag) ITR_RANK_TILE(true, true); else ITR_RANK_TILE(true, false); }
+    else      { if (diag) ITR_RANK_TILE(false, true); else ITR_RANK_TILE(false, false); }
+#undef ITR_RANK_TILE
 }
 
 // ---- float64 similarity matrices ------------------------------------------------------------
@@ -184,6 +239,9 @@ __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_kernel(const float *__r
 // with 16-byte double2 loads; the arg-max key (64-bit ordered score) no longer fits next to the
 // index, so t2i's top-1 takes a second pass: max key per column first, then the highest row
 // holding it.
+constexpr int T2I_ROWS = 128;      // image rows per workgroup of the float64 column pass
+// canon_f64: -0.0 -> +0.0 and NaN -> +inf (the fp32 kernels' rule, np.argsort's order); applied to every score the kernels load
+__device__ __forceinline__ double canon_f64(double d) { return fmin(d + 0.0, (double)INFINITY); }
 __device__ __forceinline__ unsigned long long double_order_key(double d) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(d);
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
@@ -214,7 +272,7 @@ __global__ __launch_bounds__(RANK_THREADS) void i2t_rank_f64_kernel(const double
     for (int g = 0; g < MAX_IMDIV; ++g) {
         gidx[g] = gi * im_div + g;
         const bool ok = g < im_div && gidx[g] < Nc;
-        gt[g] = ok ? row[gidx[g]] : (double)INFINITY;
+        gt[g] = ok ? canon_f64(row[gidx[g]]) : (double)INFINITY;
         cnt[g] = 0;
     }
     unsigned long long bkey = 0;
@@ -223,7 +281,7 @@ __global__ __launch_bounds__(RANK_THREADS) void i2t_rank_f64_kernel(const double
     const int64_t nvec = vec ? (Nc >> 1) : 0;
     for (int64_t c = threadIdx.x; c < nvec; c += RANK_THREADS) {
         const double2 v = reinterpret_cast<const double2 *>(row)[c];
-        const double e[2] = {v.x, v.y};
+        const double e[2] = {canon_f64(v.x), canon_f64(v.y)};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t k = c * 2 + u;
@@ -235,7 +293,7 @@ __global__ __launch_bounds__(RANK_THREADS) void i2t_rank_f64_kernel(const double
         }
     }
     for (int64_t k = nvec * 2 + threadIdx.x; k < Nc; k += RANK_THREADS) {
-        const double e = row[k];
+        const double e = canon_f64(row[k]);
         const unsigned long long key = double_order_key(e);
         if (key >= bkey) { bkey = key; bidx = (int)k; }
 #pragma unroll
@@ -294,7 +352,7 @@ __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_f64_kernel(const double
     int brow[2] = {-1, -1};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        gt[u] = (PASS == 0 && u < ncol) ? s_gt[c0 + u] : (double)INFINITY;
+        gt[u] = (PASS == 0 && u < ncol) ? canon_f64(s_gt[c0 + u]) : (double)INFINITY;
         gimg[u] = (c0 + u) / im_div;
         if (PASS == 1 && u < ncol) best[u] = best_key[c0 + u];
     }
@@ -309,6 +367,7 @@ __global__ __launch_bounds__(RANK_THREADS) void t2i_rank_f64_kernel(const double
             e[0] = p[0];
             e[1] = ncol == 2 ? p[1] : -(double)INFINITY;
         }
+        e[0] = canon_f64(e[0]); e[1] = canon_f64(e[1]);
         const int64_t gr = row0 + r;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -396,28 +455,35 @@ extern "C" int itr_rank_gather_gt(const float *S, int64_t ldS, int64_t row0, int
     return ITR_OK;
 }
 
+extern "C" size_t itr_rank_workspace_bytes(int64_t n_rows_local) {
+    return (size_t)(n_rows_local > 0 ? n_rows_local : 0) * 16 + 256;      // per local row: its best GT key + its running top-1 key
+}
+
 extern "C" int itr_rank_counts(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
                                int im_div, const float *s_gt, int32_t *i2t_rank, int32_t *i2t_top1,
-                               int32_t *t2i_rank, uint64_t *t2i_best, itr_stream_t stream) {
+                               int32_t *t2i_rank, uint64_t *t2i_best, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
     ITR_REQUIRE(S && s_gt && i2t_rank && i2t_top1 && t2i_rank && t2i_best, "itr_rank_counts: null pointer");
     ITR_REQUIRE(im_div >= 1 && im_div <= itr::MAX_IMDIV, "itr_rank_counts: im_div must be in [1, %d]",
                 itr::MAX_IMDIV);
     ITR_REQUIRE(Nc >= 0 && ldS >= Nc && row0 >= 0 && n_rows_local >= 0, "itr_rank_counts: bad shape");
     ITR_REQUIRE(Nc < 0x7fffffffLL && row0 + n_rows_local < 0x7fffffffLL, "itr_rank_counts: index overflow");
     if (Nc == 0 || n_rows_local == 0) return ITR_OK;
+    ITR_REQUIRE(workspace && workspace_bytes >= itr_rank_workspace_bytes(n_rows_local) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+                "itr_rank_counts: workspace missing, misaligned or smaller than itr_rank_workspace_bytes");
     hipStream_t st = itr::as_stream(stream);
-    switch (im_div) {      // the row pass keeps one counter per GT caption of the image: exactly im_div of them
-#define ITR_I2T(G) case G: hipLaunchKernelGGL(itr::i2t_rank_kernel<G>, dim3((unsigned)n_rows_local), dim3(itr::RANK_THREADS), 0, st, S, \
-                                             ldS, row0, Nc, im_div, i2t_rank, i2t_top1); break;
-        ITR_I2T(1) ITR_I2T(2) ITR_I2T(3) ITR_I2T(4) ITR_I2T(5) ITR_I2T(6) ITR_I2T(7) ITR_I2T(8)
-#undef ITR_I2T
-    }
-    ITR_CHECK_LAUNCH("i2t_rank");
-    dim3 grid((unsigned)itr::ceil_div(Nc, (int64_t)itr::RANK_THREADS * 4 * itr::T2I_QUADS),
-              (unsigned)itr::ceil_div(n_rows_local, itr::T2I_ROWS));
-    hipLaunchKernelGGL(itr::t2i_rank_kernel, grid, dim3(itr::RANK_THREADS), 0, st, S, ldS, row0, n_rows_local,
-                       Nc, im_div, s_gt, t2i_rank, reinterpret_cast<unsigned long long *>(t2i_best));
-    ITR_CHECK_LAUNCH("t2i_rank");
+    unsigned long long *row_gkey = static_cast<unsigned long long *>(workspace), *row_best = row_gkey + n_rows_local;
+    const unsigned rb = (unsigned)itr::ceil_div(n_rows_local, (int64_t)256);
+    hipLaunchKernelGGL(itr::rank_rows_prepare_kernel, dim3(rb), dim3(256), 0, st, S, ldS, row0, n_rows_local, Nc, im_div, row_gkey, row_best,
+                       i2t_rank);
+    ITR_CHECK_LAUNCH("rank_rows_prepare");
+    const int64_t gy = itr::ceil_div(n_rows_local, (int64_t)itr::RF_ROWS);
+    ITR_REQUIRE(gy <= 65535, "itr_rank_counts: at most %d local rows per call", 65535 * itr::RF_ROWS);
+    dim3 grid((unsigned)itr::ceil_div(Nc, (int64_t)itr::RF_COLS), (unsigned)gy);
+    hipLaunchKernelGGL(itr::rank_fused_kernel, grid, dim3(itr::RANK_THREADS), 0, st, S, ldS, row0, n_rows_local, Nc, im_div, s_gt, row_gkey,
+                       i2t_rank, row_best, t2i_rank, reinterpret_cast<unsigned long long *>(t2i_best));
+    ITR_CHECK_LAUNCH("rank_fused");
+    hipLaunchKernelGGL(itr::rank_rows_finish_kernel, dim3(rb), dim3(256), 0, st, row0, n_rows_local, Nc, im_div, row_best, i2t_rank, i2t_top1);
+    ITR_CHECK_LAUNCH("rank_rows_finish");
     return ITR_OK;
 }
 

@@ -968,8 +968,10 @@ def rank_counts(S, im_div=5, row0=0, s_gt=None, t2i_rank=None, t2i_best=None):
         t2i_rank = torch.zeros(Nc, device=dev, dtype=torch.int32)
     if t2i_best is None:
         t2i_best = torch.zeros(Nc, device=dev, dtype=torch.int64)
+    wsb = lib.itr_rank_workspace_bytes(n_rows)
+    ws = torch.empty(wsb // 8, device=dev, dtype=torch.int64)
     _lib.check(lib.itr_rank_counts(_p(S), S.stride(0), row0, n_rows, Nc, im_div, _p(s_gt), _p(i2t_rank), _p(i2t_top1),
-                                   _p(t2i_rank), _p(t2i_best), _stream()))
+                                   _p(t2i_rank), _p(t2i_best), _p(ws), wsb, _stream()))
     return i2t_rank, i2t_top1, t2i_rank, t2i_best, s_gt
 
 

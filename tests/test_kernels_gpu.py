@@ -220,6 +220,43 @@ def test_i2t_t2i_dtype_dispatch(golden, dev):
         assert (ranks_t == g["t2i_ranks"]).all() and (top_t == g["t2i_top1"]).all()
 
 
+@pytest.mark.parametrize("shape", [(40, 200), (300, 1500), (129, 645), (820, 4100), (7, 35), (411, 2055)])
+def test_ranker_nan_inf_and_signed_zero_follow_numpy(dev, shape):
+    """Order of special values (ADVICE r4): the reference ranks with np.argsort(...)[::-1] (evaluation.py:169, :209), where NaN is the
+    LARGEST value (last ascending, first after the reversal), -0.0 == +0.0 and +-inf order as usual.  One NaN per affected row /
+    column keeps numpy's own tie order out of the comparison; ranks are compared against the argsort restatement, fp32 and fp64."""
+    Ni, Nc = shape
+    rng = np.random.RandomState(Ni + Nc)
+    s = rng.randn(Ni, Nc).astype(np.float32)
+    s[rng.randint(0, Ni, 40), rng.randint(0, Nc, 40)] = np.inf
+    s[rng.randint(0, Ni, 40), rng.randint(0, Nc, 40)] = -np.inf
+    zr = rng.randint(0, Ni, 60), rng.randint(0, Nc, 60)
+    s[zr] = 0.0
+    s[zr[0][::2], zr[1][::2]] = -0.0
+    nan_rows = rng.choice(Ni, size=min(Ni, 5), replace=False)
+    nan_cols = rng.choice(Nc, size=min(Nc, 5), replace=False)
+    s[nan_rows, nan_cols] = np.nan                        # distinct rows and distinct columns: at most one NaN per row / column
+    s[1 % Ni, 5 * (1 % Ni) + 2] = np.nan                  # a ground-truth pair that is NaN: it ranks first in both directions
+    for mat, fn in ((s, ops.rank_counts), (s.astype(np.float64), ops.rank_counts_f64)):
+        has_nan = np.isnan(mat)
+        assert has_nan.sum(1).max() <= 2 and has_nan.sum(0).max() <= 2
+        got = fn(torch.from_numpy(mat).to(dev))
+        gi, gt = got[0].cpu().numpy(), got[2].cpu().numpy()
+        cnt = O.rank_counts(np.where(has_nan, np.inf, mat))          # the count form with NaN read as +inf: the documented rule, everywhere
+        assert (gi == cnt[0]).all() and (gt == cnt[2]).all()
+        assert (got[1].cpu().numpy() == cnt[1]).all()
+        # and numpy's argsort (the reference's ranker) agrees wherever ITS order is determined: lines whose ground-truth values occur
+        # once (NaN read as +inf for the purpose of "equal"), so that no tie involves them
+        (_, (wi, _)), (_, (wt, _)) = O.i2t_argsort(mat, True), O.t2i_argsort(mat, True)
+        m = np.where(has_nan, np.inf, mat)
+        clean_r = np.array([all((m[i] == m[i, c]).sum() == 1 for c in range(5 * i, min(5 * i + 5, Nc))) for i in range(Ni)])
+        clean_c = np.array([(m[:, c] == m[c // 5, c]).sum() == 1 for c in range(Nc)])
+        assert clean_r.sum() >= Ni // 2 and (gi[clean_r] == wi.astype(np.int64)[clean_r]).all()
+        assert clean_c.sum() >= Nc // 2 and (gt[clean_c] == wt.astype(np.int64)[clean_c]).all()
+        assert clean_r[1 % Ni] and clean_c[5 * (1 % Ni) + 2]          # the NaN ground-truth pair is among the lines compared with numpy
+    assert int(gi[1 % Ni]) == 0 and int(gt[5 * (1 % Ni) + 2]) == 0
+
+
 @pytest.mark.parametrize("Ni", [1, 7, 41, 257])
 def test_ranker_ragged_shapes(dev, Ni):
     rng = np.random.RandomState(Ni)
@@ -249,6 +286,36 @@ def test_ranker_row_blocks_sum_to_full(dev):
     assert (np.concatenate(i_rank) == full[0]).all()
     assert (t_rank.cpu().numpy() == full[2]).all()
     assert ((t_best & 0xffffffff).cpu().numpy() == full[3]).all()
+
+
+@pytest.mark.parametrize("Ni,cuts", [(1000, (0, 333, 777, 1000)), (613, (0, 128, 130, 613)), (1300, (0, 1300))])
+def test_ranker_one_pass_tiles_and_row_blocks(dev, Ni, cuts):
+    """The one-pass kernel (round 5: every element of S is read once and serves both directions) on matrices of several
+    1 024-column blocks and several 128-row blocks: full and ragged column blocks, row tails that are not multiples of 8 / 64,
+    tiles on and off the ground-truth diagonal (32-bit threshold compares off it, exact 64-bit keys on it), many exact ties, and
+    row blocks with row0 > 0 whose partial t2i counts add up -- all bit-equal to the oracle's counts."""
+    rng = np.random.RandomState(Ni)
+    Nc = 5 * Ni
+    sims = rng.randn(Ni, Nc).astype(np.float32)
+    sims[:, ::3] = np.round(sims[:, ::3] * 2) / 2                 # exact ties, incl. with ground-truth scores, -0.0 among them
+    want = O.rank_counts(sims)
+    got = run_ranker(sims, dev)
+    for a, b in zip(got, want):
+        assert (a == b).all()
+    S = torch.from_numpy(sims).to(dev)
+    s_gt = torch.full((Nc,), float('-inf'), device=dev)
+    blocks = list(zip(cuts[:-1], cuts[1:]))
+    for r0, r1 in blocks:
+        ops.gather_gt(S[r0:r1], 5, r0, s_gt)
+    t_rank = torch.zeros(Nc, dtype=torch.int32, device=dev)
+    t_best = torch.zeros(Nc, dtype=torch.int64, device=dev)
+    i_rank, i_top = [], []
+    for r0, r1 in blocks:
+        ir, it, _, _, _ = ops.rank_counts(S[r0:r1], 5, r0, s_gt, t_rank, t_best)
+        i_rank.append(ir.cpu().numpy()); i_top.append(it.cpu().numpy())
+    assert (np.concatenate(i_rank) == want[0]).all() and (np.concatenate(i_top) == want[1]).all()
+    assert (t_rank.cpu().numpy() == want[2]).all()
+    assert ((t_best & 0xffffffff).cpu().numpy() == want[3]).all()
 
 
 # ------------------------------------------------------------------------------------------ SCAN
@@ -545,6 +612,51 @@ def test_sgr_refused_group_is_nan_not_garbage(dev):
         ops.ScanPlan.node_groups = real
     assert torch.isnan(out[:, :17]).all()
     assert torch.equal(out[:, 17:], good[:, 17:])
+
+
+@pytest.mark.parametrize("mod", ["SAF", "SGR"])
+def test_sgraf_block_shrinks_to_the_memory_that_is_free(dev, mod):
+    """the pair stage's image block follows the memory the process can have.  (a) an explicit byte budget that only
+    admits a 16-image block; (b) HBM really taken away: a tensor is allocated so that the 64-image workspace cannot fit -- in both
+    cases ops.sgraf_scores runs (no out-of-memory error) with a smaller block and returns bit-identical scores."""
+    from itr_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(9)
+    torch.manual_seed(9)
+    D, S, steps, Ni, Nc = 1024, 256, 3, 130, 400
+    lens = [int(x) for x in rng.randint(3, 21, size=Nc)]
+    img = O.l2norm(torch.randn(Ni, 36, D), -1).to(dev)
+    cap = O.l2norm(torch.randn(Nc, max(lens), D), -1).to(dev)
+    w = _sgraf_weights(D, S, steps)
+    g = torch.Generator().manual_seed(1)
+    w["SAF_module.attn_sim_w.weight"] = torch.randn(1, S, generator=g) * 0.1; w["SAF_module.attn_sim_w.bias"] = torch.zeros(1)
+    w["SAF_module.bn.weight"] = torch.ones(1); w["SAF_module.bn.bias"] = torch.zeros(1)
+    w["SAF_module.bn.running_mean"] = torch.zeros(1); w["SAF_module.bn.running_var"] = torch.ones(1)
+    wd = {k: v.to(dev) for k, v in w.items()}
+    ref = ops.sgraf_padded(img, cap, lens, wd, mod, steps)
+    assert ops.SGRAF_LAST_BLOCK["image_block"] == 64 and not ops.SGRAF_LAST_BLOCK["pinned"]
+    ws64 = ops.SGRAF_LAST_BLOCK["workspace_bytes"]
+    plan = ops.ScanPlan(np.arange(Nc, dtype=np.int64) * max(lens), lens, Nc * max(lens), dev)
+    ws = {ib: lib.itr_sgraf_workspace_bytes(Ni, Nc, Nc * max(lens), plan.n_tiles, D, S, 1 if mod == "SGR" else 0, ib, 0) for ib in (64, 32, 16)}
+    assert ws[64] == ws64 and ws[64] > ws[32] > ws[16]
+    # (a) a budget that admits 16 images but not 32
+    got = ops.sgraf_padded(img, cap, lens, wd, mod, steps, max_workspace_bytes=ws[32] - 1)
+    assert ops.SGRAF_LAST_BLOCK["image_block"] == 16 and torch.equal(got, ref)
+    with pytest.raises(torch.cuda.OutOfMemoryError):
+        ops.sgraf_padded(img, cap, lens, wd, mod, steps, max_workspace_bytes=1 << 20)
+    # (b) take the memory away for real: leave less than the 64-image workspace needs (but room for a smaller block)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(dev)
+    keep = ws[32] + (ws[64] - ws[32]) // 2                       # between the two sizes: 0.9 x keep admits at most 32 images
+    hog = torch.empty(free - keep, device=dev, dtype=torch.uint8)
+    try:
+        got = ops.sgraf_padded(img, cap, lens, wd, mod, steps)
+        assert ops.SGRAF_LAST_BLOCK["image_block"] in (16, 32) and not ops.SGRAF_LAST_BLOCK["pinned"]
+        assert torch.equal(got, ref)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------------------------------ GRU

@@ -322,7 +322,7 @@ def test_bench_line_carries_recall_parity_and_a_repeatable_cpu_baseline(workload
                        "--cpu-sample-images", "40", "--cpu-repeats", "2"])
     cb = out["cpu_baseline"]
     rp = cb["recall_parity"]
-    assert rp["ok"] and rp["max_abs_recall_diff"] <= 0.1 and rp["hip_ranker_on_cpu_scores_equals_argsort"]
+    assert rp["ok"] and rp["max_abs_recall_diff"] <= 0.1 and rp["hip_ranker_on_cpu_scores_equals_argsort"], rp
     assert set(rp["gpu"]) == set(rp["cpu"]) == {"i2t_r1", "i2t_r5", "i2t_r10", "t2i_r1", "t2i_r5", "t2i_r10"}
     assert rp["rank_entries"] == 40 + 200 and rp["rank_entries_differing"] <= 2
     h = cb["host"]

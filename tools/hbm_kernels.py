@@ -34,13 +34,18 @@ x = torch.randn(5000 * 36, 2048, device=dev)
 ms = timed(lambda: ops.l2norm(x))         # (allocates its output from torch's caching pool: no hipMalloc inside the timed region after the warm-ups)
 rows.append(("norm_rows_kernel (l2norm, 180 000 x 2048)", 2 * x.numel() * 4, ms))
 del x
-# K9 rank counts (metricmodule/evaluation.py:156-222): i2t row pass + t2i column pass over the 5 000 x 25 000 fp32 matrix (one read each)
+# K9 rank counts (metricmodule/evaluation.py:156-222): ONE pass over the 5 000 x 25 000 fp32 matrix serves both directions (round 5)
 S = torch.randn(5000, 25000, device=dev)
 ms_both = timed(lambda: ops.rank_counts(S))
-rows.append(("i2t_rank_kernel + t2i_rank_kernel (+ the GT gather), 5 000 x 25 000", 2 * S.numel() * 4, ms_both))
+rows.append(("rank stage as the step runs it: GT gather + row prepare + rank_fused_kernel + row finish (+ 5 small allocations), 5 000 x 25 000",
+             S.numel() * 4, ms_both))
+s_gt = ops.gather_gt(S)
+bufs = ops.rank_counts(S, s_gt=s_gt)
+ms_k = timed(lambda: ops.rank_counts(S, s_gt=s_gt, t2i_rank=bufs[2], t2i_best=bufs[3]))
+rows.append(("row prepare + rank_fused_kernel + row finish alone (GT scores given, accumulators reused)", S.numel() * 4, ms_k))
 print("| kernel (launch) | algorithmic bytes | median ms | GB/s | of 8 TB/s |")
 print("|---|---|---|---|---|")
 for name, b, ms in rows:
     print("| %s | %.3f GB | %.4f | %.0f | %.3f |" % (name, b / 1e9, ms, b / ms / 1e6, b / ms / 1e6 / HBM_PEAK))
 print()
-print("(the two rank kernels separately: rocprofv3 kernel table of the same round, profiles/rNN/README.md)")
+print("(rank_fused_kernel alone: rocprofv3 kernel table of the same round, profiles/rNN/README.md)")
