@@ -228,18 +228,21 @@ def test_ranker_nan_inf_and_signed_zero_follow_numpy(dev, shape):
     Ni, Nc = shape
     rng = np.random.RandomState(Ni + Nc)
     s = rng.randn(Ni, Nc).astype(np.float32)
-    s[rng.randint(0, Ni, 40), rng.randint(0, Nc, 40)] = np.inf
-    s[rng.randint(0, Ni, 40), rng.randint(0, Nc, 40)] = -np.inf
-    zr = rng.randint(0, Ni, 60), rng.randint(0, Nc, 60)
+    k = max(2, min(40, Ni * Nc // 60))                    # (few enough special values that most lines keep a determined order)
+    s[rng.randint(0, Ni, k), rng.randint(0, Nc, k)] = np.inf
+    s[rng.randint(0, Ni, k), rng.randint(0, Nc, k)] = -np.inf
+    zr = rng.randint(0, Ni, k + k // 2), rng.randint(0, Nc, k + k // 2)
     s[zr] = 0.0
     s[zr[0][::2], zr[1][::2]] = -0.0
-    nan_rows = rng.choice(Ni, size=min(Ni, 5), replace=False)
-    nan_cols = rng.choice(Nc, size=min(Nc, 5), replace=False)
+    gr, gc = 1 % Ni, 5 * (1 % Ni) + 2
+    nan_rows = rng.choice([r for r in range(Ni) if r != gr], size=min(Ni - 1, 5), replace=False)
+    nan_cols = rng.choice([c for c in range(Nc) if c != gc], size=len(nan_rows), replace=False)
     s[nan_rows, nan_cols] = np.nan                        # distinct rows and distinct columns: at most one NaN per row / column
-    s[1 % Ni, 5 * (1 % Ni) + 2] = np.nan                  # a ground-truth pair that is NaN: it ranks first in both directions
+    s[gr] = np.where(np.isinf(s[gr]), 1.5, s[gr]); s[:, gc] = np.where(np.isinf(s[:, gc]), -1.5, s[:, gc])
+    s[gr, gc] = np.nan                                    # a ground-truth pair that is NaN: it ranks first in both directions
     for mat, fn in ((s, ops.rank_counts), (s.astype(np.float64), ops.rank_counts_f64)):
         has_nan = np.isnan(mat)
-        assert has_nan.sum(1).max() <= 2 and has_nan.sum(0).max() <= 2
+        assert has_nan.sum(1).max() <= 1 and has_nan.sum(0).max() <= 1
         got = fn(torch.from_numpy(mat).to(dev))
         gi, gt = got[0].cpu().numpy(), got[2].cpu().numpy()
         cnt = O.rank_counts(np.where(has_nan, np.inf, mat))          # the count form with NaN read as +inf: the documented rule, everywhere
@@ -251,7 +254,7 @@ def test_ranker_nan_inf_and_signed_zero_follow_numpy(dev, shape):
         m = np.where(has_nan, np.inf, mat)
         clean_r = np.array([all((m[i] == m[i, c]).sum() == 1 for c in range(5 * i, min(5 * i + 5, Nc))) for i in range(Ni)])
         clean_c = np.array([(m[:, c] == m[c // 5, c]).sum() == 1 for c in range(Nc)])
-        assert clean_r.sum() >= Ni // 2 and (gi[clean_r] == wi.astype(np.int64)[clean_r]).all()
+        assert clean_r.sum() >= Ni // 3 and (gi[clean_r] == wi.astype(np.int64)[clean_r]).all()
         assert clean_c.sum() >= Nc // 2 and (gt[clean_c] == wt.astype(np.int64)[clean_c]).all()
         assert clean_r[1 % Ni] and clean_c[5 * (1 % Ni) + 2]          # the NaN ground-truth pair is among the lines compared with numpy
     assert int(gi[1 % Ni]) == 0 and int(gt[5 * (1 % Ni) + 2]) == 0
@@ -647,12 +650,19 @@ def test_sgraf_block_shrinks_to_the_memory_that_is_free(dev, mod):
     # (b) take the memory away for real: leave less than the 64-image workspace needs (but room for a smaller block)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
-    free, _ = torch.cuda.mem_get_info(dev)
     keep = ws[32] + (ws[64] - ws[32]) // 2                       # between the two sizes: 0.9 x keep admits at most 32 images
-    hog = torch.empty(free - keep, device=dev, dtype=torch.uint8)
+    hog = []
     try:
+        while True:                                              # (in pieces: one 280 GB request can fail on a fragmented address space)
+            free, _ = torch.cuda.mem_get_info(dev)
+            take = min(free - keep, 8 << 30)
+            if take < (1 << 20):
+                break
+            hog.append(torch.empty(take, device=dev, dtype=torch.uint8))
+        free, _ = torch.cuda.mem_get_info(dev)
+        assert free < ws[64], (free, ws)
         got = ops.sgraf_padded(img, cap, lens, wd, mod, steps)
-        assert ops.SGRAF_LAST_BLOCK["image_block"] in (16, 32) and not ops.SGRAF_LAST_BLOCK["pinned"]
+        assert ops.SGRAF_LAST_BLOCK["image_block"] in (8, 16, 32) and not ops.SGRAF_LAST_BLOCK["pinned"], (ops.SGRAF_LAST_BLOCK, free, ws)
         assert torch.equal(got, ref)
     finally:
         del hog
