@@ -55,6 +55,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 //   r = s(gi_r + gh_r); z = s(gi_z + gh_z); n = tanh(gi_n + r * gh_n); h' = (1 - z) * n + z * h
 // mode 0: out[row] = h'            (forward direction, or uni-directional)
 // mode 1: out[row] = (out[row] + h') / 2   (reverse direction of a bi-GRU, TextEncoder.py:54-55)
+// mode 2: only the state h is updated (last-state callers: the sequence is never read)
 // VEC = 4: one thread per four consecutive hidden units, 16-byte accesses (D % 4 == 0); VEC = 1: any D.
 // gridDim.z == 2: both directions of a bi-GRU in one launch -- z = 1 is the reverse direction, its gi / gh / h are `dir_stride`
 // floats behind the forward direction's (the two halves of the workspace are carved identically) and its output is out2.
@@ -95,7 +96,28 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__
         ov[k] = mode ? (ov[k] + hn) / 2.f : hn;
     }
     st(hrow, hp);
-    st(o, ov);
+    if (mode != 2) st(o, ov);
+}
+
+// Last-state output of a bi-GRU (method_name in {VSE++, VSRN}: TextEncoder.py:57-60 gathers position len - 1 of (fwd + bwd) / 2).
+// At position len - 1 the BACKWARD direction has seen exactly one token -- it starts there, from h = 0 -- so its whole recurrence is
+// one cell update per caption with gh = W_hh 0 + b_hh = b_hh: no recurrence GEMM, and its input projection is needed for the
+// captions' last tokens only.  Same arithmetic as the general path (gru_cell on the same operands): bit-identical results.
+__global__ void gather_last_rows_kernel(const float *__restrict__ x, const int64_t *__restrict__ tok_off, const int32_t *__restrict__ len,
+                                        int Ep, float *__restrict__ x_last) {
+    const int64_t b = blockIdx.x;
+    const float *src = x + (tok_off[b] + len[b] - 1) * Ep;
+    for (int k = threadIdx.x; k < Ep; k += blockDim.x) x_last[b * Ep + k] = src[k];
+}
+// out_last[b] = (h_fwd[b] + gru_cell(gi_last[b], b_hh, h = 0)) / 2
+__global__ __launch_bounds__(256) void gru_last_state_bi_kernel(const float *__restrict__ gi_last, const float *__restrict__ b_hh,
+                                                                const float *__restrict__ h_fwd, int D, float *__restrict__ out_last) {
+    const int64_t b = blockIdx.x;
+    for (int j = threadIdx.x; j < D; j += blockDim.x) {
+        const float *g = gi_last + b * 3 * D;
+        const float hb = gru_cell(g[j], g[D + j], g[2 * D + j], b_hh[j], b_hh[D + j], b_hh[2 * D + j], 0.f);
+        out_last[b * D + j] = (h_fwd[b * D + j] + hb) / 2.f;
+    }
 }
 
 __global__ void gather_last_kernel(const float *__restrict__ out, const int64_t *__restrict__ tok_off,
@@ -256,6 +278,55 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     if (bi) {
         w2 = carve(static_cast<char *>(workspace) + gru_ws_one(n_tok, B, E, D), n_tok, B, E, D);
         w2.x = w.x;                      // the gathered embeddings are shared (read-only)
+    }
+    // ---- last-state output (VSE++ / VSRN): the forward recurrence without sequence stores; of the backward direction only its first
+    // step (see gru_last_state_bi_kernel).  Round 5: half of the recurrence of BASELINE config [1] was work nothing reads.
+    if (gather_last && !want_paired && !want_input_after_fork) {
+        auto project = [&](const float *xin, int64_t rows, const float *wi, const float *bi_, float *wpad, float *dst) -> int {
+            const float *wi_use = wi;
+            if (Ep != E) {
+                hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)(3 * D)), dim3(128), 0, st, wi, (int64_t)3 * D, E, Ep, wpad);
+                ITR_CHECK_LAUNCH("pad_cols");
+                wi_use = wpad;
+            }
+            return gemm_nt(xin, Ep, wi_use, Ep, bi_, dst, 3 * D, rows, 3 * D, Ep, 0, st);
+        };
+        int rc = project(w.x, n_tok, w_ih, b_ih, w.wpad, w.gi);
+        if (rc != ITR_OK) return rc;
+        ITR_CHECK_HIP(hipMemsetAsync(w.h, 0, (size_t)B * D * 4, st));
+        if (bi) {      // the backward direction's one step: projection of the B last tokens (the second workspace half's unused x region)
+            float *x_last = reinterpret_cast<float *>(static_cast<char *>(workspace) + gru_ws_one(n_tok, B, E, D));
+            hipLaunchKernelGGL(gather_last_rows_kernel, dim3((unsigned)B), dim3(128), 0, st, w.x, tok_off, len_dev, Ep, x_last);
+            ITR_CHECK_LAUNCH("gather_last_rows");
+            rc = project(x_last, B, w_ih_rev, b_ih_rev, w2.wpad, w2.gi);
+            if (rc != ITR_OK) return rc;
+        }
+        int64_t n_act = B;
+        for (int t = 0; t < Lmax; ++t) {
+            while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
+            rc = (splits_h > 1) ? gemm_nt_splitk(w.h, D, w_hh, D, b_hh, w.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, w.skbuf, st)
+                                : gemm_nt(w.h, D, w_hh, D, b_hh, w.gh, 3 * D, n_act, 3 * D, D, 0, st);
+            if (rc != ITR_OK) return rc;
+            if (D % 4 == 0)
+                hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, st, w.gi, w.gh, w.h,
+                                   w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_act, (int64_t)0, (float *)nullptr);
+            else
+                hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, w.gi, w.gh, w.h,
+                                   w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_act, (int64_t)0, (float *)nullptr);
+            ITR_CHECK_LAUNCH("gru_gate (state only)");
+        }
+        // a caption's row of h is not touched after its last step: it IS the state at position len - 1
+        if (bi) {
+            hipLaunchKernelGGL(gru_last_state_bi_kernel, dim3((unsigned)B), dim3(256), 0, st, w2.gi, b_hh_rev, w.h, D, out_last);
+            ITR_CHECK_LAUNCH("gru_last_state_bi");
+        } else {
+            ITR_CHECK_HIP(hipMemcpyAsync(out_last, w.h, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+        }
+        if (!no_txtnorm) {
+            rc = norm_rows(out_last, out_last, B, D, 1e-8f, 0, use_abs, st);
+            if (rc != ITR_OK) return rc;
+        }
+        return ITR_OK;
     }
     // Both input projections first, on the caller's stream (each fills the chip by itself), THEN the fork: the two recurrences start
     // together and their short last steps (a few hundred active captions: less than one round of tiles) overlap each other instead

@@ -23,7 +23,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
         for k in acc:
-            if any(s in k for s in ("scan_xattn", "gemm_nt", "rank_kernel", "gru_gate", "scan_pack", "gram_kernel", "sgr_fused", "sgraf_loc")):
+            if any(s in k for s in ("scan_xattn", "gemm_nt", "rank_kernel", "rank_fused", "gru_gate", "scan_pack", "gram_kernel", "sgr_fused", "sgraf_loc")):
                 n = max(1, len(disp[k]))
                 print("   %s   (%d dispatches)" % (k, n))
                 for c, v in sorted(acc[k].items()):
