@@ -147,6 +147,9 @@ def host_info():
                 loadavg_1min_before=load1)
 
 
+CPU_THREADS = None      # --cpu-threads: restrict the thread counts of the CPU leg (the 1k x 5k fold record: minutes per pass)
+
+
 def time_cpu_leg(leg, repeats):
     """Run the CPU leg up to `repeats` times at torch's default thread count AND at 64 / 32 / 16 threads where the host has more (the
     160 x 800 sample does not feed 128 threads: an oversubscribed pass is 6x slower than a 32-thread one and moved the figure by 4x
@@ -154,7 +157,7 @@ def time_cpu_leg(leg, repeats):
     of the passes at that count.  -> (result of the last pass, stats)."""
     host = host_info()
     n_default = torch.get_num_threads()
-    counts = [n_default] + [n for n in (64, 32, 16) if n < n_default]
+    counts = CPU_THREADS or ([n_default] + [n for n in (64, 32, 16) if n < n_default])
     by_threads, res = {}, None
     try:
         for nt in counts:
@@ -890,6 +893,8 @@ def main():
                     help="skip the short runs of the other BASELINE.json configs that the default workload's line carries in `other_configs`")
     ap.add_argument("--cpu-sample-images", type=int, default=160)
     ap.add_argument("--cpu-repeats", type=int, default=3, help="passes of the CPU leg (the minimum is reported, with the spread)")
+    ap.add_argument("--cpu-threads", default=None, metavar="N[,N...]",
+                    help="thread counts of the CPU leg (default: torch's own count and 64 / 32 / 16 where the host has more)")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, build the process group, all-gather the rank table, run the exchange's two collectives on their "
                          "real payload sizes (fabric check), print the line with value = null and stop (no kernel of the path runs)")
@@ -909,6 +914,9 @@ def main():
                     help="time the file -> rank path on a precomp dataset directory written by tools/make_synth_precomp.py (SCAN t2i): "
                          "memory-mapped .npy -> pinned -> HBM, tokenise, encode, score, rank; reported next to the resident-input number")
     args = ap.parse_args()
+    if args.cpu_threads:
+        global CPU_THREADS
+        CPU_THREADS = [int(x) for x in args.cpu_threads.split(",")]
 
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")

@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned long long rank_key(float e, unsigned idx) { 
 #ifndef ITR_RF_WAVES              // waves per SIMD the register allocation must admit
 #define ITR_RF_WAVES 4
 #endif
-constexpr int RF_U = ITR_RF_U;    // rows per load group; two groups in flight per lane
+constexpr int RF_U = ITR_RF_U;    // rows in the register ring of a lane (RF_U - 1 in flight at all times); divides 64
 // rows per workgroup: a multiple of 64 chosen per launch (itr_rank_counts) so that the grid fits the resident slots of the chip in ONE
 // round where it can (1 000 workgroups of 128 rows on 768 slots were two rounds for 1.3 rounds of work)
 constexpr int RF_COLS = RANK_THREADS * 4;
@@ -81,32 +81,33 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 // per local row: the key of its best ground-truth caption (~0: the image has none inside the matrix), zeroed accumulators
-__global__ void rank_rows_prepare_kernel(const float *__restrict__ S, int64_t ldS, int64_t row0, int64_t nrows, int64_t Nc, int im_div,
-                                         unsigned long long *__restrict__ row_gkey, unsigned long long *__restrict__ row_best,
-                                         int32_t *__restrict__ i2t_cnt) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    const int64_t gi = row0 + r;
-    unsigned long long gk = 0;
-    bool any = false;
-    for (int g = 0; g < im_div; ++g) {
-        const int64_t c = gi * im_div + g;
-        if (c >= Nc) break;
-        const unsigned long long k = rank_key(S[r * ldS + c], (unsigned)c);
-        gk = k > gk ? k : gk;
-        any = true;
+// ONE launch ahead of the fused kernel: per local row the key of its best ground-truth caption (~0: the image has none inside the
+// matrix) and zeroed row accumulators; per column (single-call use: flags) the ground-truth score read from S itself and zeroed
+// column accumulators -- a gather launch and three fill launches of ~5 us each went into that before, next to a 113 us kernel.
+__global__ void rank_prepare_kernel(const float *__restrict__ S, int64_t ldS, int64_t row0, int64_t nrows, int64_t Nc, int im_div,
+                                    unsigned long long *__restrict__ row_gkey, unsigned long long *__restrict__ row_best,
+                                    int32_t *__restrict__ i2t_cnt, float *__restrict__ s_gt_out,
+                                    int32_t *__restrict__ t2i_cnt, unsigned long long *__restrict__ t2i_best, int init_cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows) {
+        const int64_t gi = row0 + i;
+        unsigned long long gk = 0;
+        bool any = false;
+        for (int g = 0; g < im_div; ++g) {
+            const int64_t c = gi * im_div + g;
+            if (c >= Nc) break;
+            const unsigned long long k = rank_key(S[i * ldS + c], (unsigned)c);
+            gk = k > gk ? k : gk;
+            any = true;
+        }
+        row_gkey[i] = any ? gk : ~0ull;
+        row_best[i] = 0;
+        i2t_cnt[i] = 0;
     }
-    row_gkey[r] = any ? gk : ~0ull;
-    row_best[r] = 0;
-    i2t_cnt[r] = 0;
-}
-
-__global__ void rank_rows_finish_kernel(int64_t row0, int64_t nrows, int64_t Nc, int im_div, const unsigned long long *__restrict__ row_best,
-                                        int32_t *__restrict__ i2t_rank, int32_t *__restrict__ i2t_top1) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    i2t_top1[r] = (int32_t)(row_best[r] & 0xffffffffu);
-    if ((row0 + r) * im_div >= Nc) i2t_rank[r] = 0x7fffffff;      // no ground-truth caption inside the matrix (as rounds 1-4)
+    if (i < Nc) {
+        if (s_gt_out) s_gt_out[i] = S[(i / im_div - row0) * ldS + i];      // (every ground-truth row is local: checked by the caller)
+        if (init_cols) { t2i_cnt[i] = 0; t2i_best[i] = 0; }
+    }
 }
 
 // FULL: every lane of the workgroup owns four valid columns and the rows are 16-byte aligned (all but the last column block of an
@@ -117,7 +118,7 @@ __global__ void rank_rows_finish_kernel(int64_t row0, int64_t nrows, int64_t Nc,
 // lies on one side of the row's GT column, every row on one side of a column's GT row -- and
 //     key64(ok, idx) > key64(g_ok, g_idx)   <=>   ok > g_ok - (idx > g_idx)
 // becomes a 32-bit compare against a threshold fixed per row (scalar) / per column (once per tile).
-template <bool FULL, bool DIAG>
+template <bool FULL, bool DIAG, int U>
 __device__ __forceinline__ void rank_tile(const float *__restrict__ S, int64_t ldS, int64_t row0, int64_t r_begin, int64_t r_end, int64_t Nc,
                                           int im_div, const float *__restrict__ s_gt, const unsigned long long *__restrict__ row_gkey,
                                           int32_t *__restrict__ i2t_cnt, unsigned long long *__restrict__ row_best,
@@ -204,31 +205,27 @@ __device__ __forceinline__ void rank_tile(const float *__restrict__ S, int64_t l
         rc = r_to;
         rv_cnt = 0; rv_ok = 0; rv_col = 0;
     };
-    // Groups of RF_U rows, double-buffered: the loads of group g + 1 are in flight while group g is consumed (one group at a time left
-    // every wave idle for a full memory round trip per group: 29 % ALU issue, 50 % of the wave time in s_waitcnt -- r05 PMC).
-    // A group's rows past the end are clamped to the last row (loaded again, never consumed).
-    const int64_t n_groups = (r_end - r_begin) / RF_U;
-    auto load_group = [&](float4 (&v)[RF_U], int64_t rg) {
+    // A ring of U rows in registers: row r + U is requested the moment row r has been consumed, so U - 1 rows are in flight
+    // per lane at ALL times.  (v1 loaded a group of rows, then consumed it: every wave idled for a full memory round trip per group --
+    // 29 % ALU issue, 50 % of the wave time in s_waitcnt.  Two alternating groups of four left loads in flight only about half
+    // of the time: the rate of a streaming read follows the bytes in flight, tools/ubench/read_tiles.hip.)
+    // Rows past the end are clamped to the last row (loaded again, never consumed).
+    float4 ring[U];
 #pragma unroll
-        for (int k = 0; k < RF_U; ++k) v[k] = load_row(rg + k < r_end ? rg + k : r_end - 1);
-    };
-    auto use_group = [&](const float4 (&v)[RF_U], int64_t rg) {
-#pragma unroll
-        for (int k = 0; k < RF_U; ++k) row_step(v[k], rg + k);
-        if (((rg + RF_U - r_begin) & 63) == 0) flush(rg + RF_U);
-    };
-    float4 va[RF_U], vb[RF_U];
+    for (int k = 0; k < U; ++k) ring[k] = load_row(r_begin + k < r_end ? r_begin + k : r_end - 1);
     int64_t r = r_begin;
-    if (n_groups > 0) load_group(va, r);
-    for (int64_t g = 0; g + 1 < n_groups; g += 2) {
-        load_group(vb, r + RF_U);
-        use_group(va, r);
-        load_group(va, r + 2 * RF_U);                                         // (past the last group: clamped re-reads, not consumed)
-        use_group(vb, r + RF_U);
-        r += 2 * RF_U;
+    for (; r + U <= r_end; r += U) {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            row_step(ring[k], r + k);
+            const int64_t rn = r + U + k;
+            ring[k] = load_row(rn < r_end ? rn : r_end - 1);
+        }
+        if (((r + U - r_begin) & 63) == 0) flush(r + U);
     }
-    if (n_groups & 1) { use_group(va, r); r += RF_U; }
-    for (; r < r_end; ++r) row_step(load_row(r), r);                          // the matrix's last rows (nrows % RF_U)
+#pragma unroll
+    for (int k = 0; k < U; ++k)                                            // the matrix's last rows (nrows % U): already in the ring
+        if (r + k < r_end) row_step(ring[k], r + k);
     if (rc < r_end) flush(r_end);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -253,10 +250,22 @@ __global__ __launch_bounds__(RANK_THREADS, ITR_RF_WAVES) void rank_fused_kernel(
     // have their GT rows in [cb / im_div, (cb + 1023) / im_div].  (Conservative: a tile flagged without need only runs the exact form.)
     const int64_t R0 = row0 + r_begin, R1 = row0 + r_end;
     const bool diag = (im_div * R0 <= cb + RF_COLS - 1) && (im_div * R1 - 1 >= cb);
-#define ITR_RANK_TILE(F, D) rank_tile<F, D>(S, ldS, row0, r_begin, r_end, Nc, im_div, s_gt, row_gkey, i2t_cnt, row_best, t2i_cnt, t2i_best, s_rows)
+// (the exact-compare and the guarded forms run on a few tiles in a hundred: a ring of 4 keeps them inside the register budget)
+#define ITR_RANK_TILE(F, D) rank_tile<F, D, ((F) && !(D)) ? RF_U : 4>(S, ldS, row0, r_begin, r_end, Nc, im_div, s_gt, row_gkey, i2t_cnt, row_best, t2i_cnt, t2i_best, s_rows)
     if (full) { if (diag) ITR_RANK_TILE(true, true); else ITR_RANK_TILE(true, false); }
     else      { if (diag) ITR_RANK_TILE(false, true); else ITR_RANK_TILE(false, false); }
 #undef ITR_RANK_TILE
+}
+
+// After the pass: the rows' accumulated top-1 keys -> column indices.  (A "last workgroup of the row block finishes" scheme inside the
+// pass was built and measured: it needs a device-scope fence per workgroup, which on this multi-XCD part writes back and invalidates the
+// XCD's L2 -- 122 -> 287 us.  A 5 us launch is the cheaper fence.)
+__global__ void rank_rows_finish_kernel(int64_t row0, int64_t nrows, int64_t Nc, int im_div, const unsigned long long *__restrict__ row_best,
+                                        int32_t *__restrict__ i2t_rank, int32_t *__restrict__ i2t_top1) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    i2t_top1[r] = (int32_t)(row_best[r] & 0xffffffffu);
+    if ((row0 + r) * im_div >= Nc) i2t_rank[r] = 0x7fffffff;      // no ground-truth caption inside the matrix (as rounds 1-4)
 }
 
 // workgroups of rank_fused_kernel the device holds at once (CUs x the occupancy the runtime reports), cached per device
@@ -501,27 +510,34 @@ extern "C" int itr_rank_gather_gt(const float *S, int64_t ldS, int64_t row0, int
     return ITR_OK;
 }
 
-extern "C" size_t itr_rank_workspace_bytes(int64_t n_rows_local) {
-    return (size_t)(n_rows_local > 0 ? n_rows_local : 0) * 16 + 256;      // per local row: its best GT key + its running top-1 key
+static inline size_t rank_al(size_t v) { return (v + 255) & ~(size_t)255; }
+extern "C" size_t itr_rank_workspace_bytes(int64_t n_rows_local, int64_t Nc) {
+    const size_t nr = (size_t)(n_rows_local > 0 ? n_rows_local : 0), nc = (size_t)(Nc > 0 ? Nc : 0);
+    // per local row: its best GT key + its running top-1 key; per column: the GT score when the call gathers it itself
+    return rank_al(nr * 16) + rank_al(nc * 4) + 256;
 }
 
 extern "C" int itr_rank_counts(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
                                int im_div, const float *s_gt, int32_t *i2t_rank, int32_t *i2t_top1,
-                               int32_t *t2i_rank, uint64_t *t2i_best, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
-    ITR_REQUIRE(S && s_gt && i2t_rank && i2t_top1 && t2i_rank && t2i_best, "itr_rank_counts: null pointer");
+                               int32_t *t2i_rank, uint64_t *t2i_best, int flags, void *workspace, size_t workspace_bytes,
+                               itr_stream_t stream) {
+    ITR_REQUIRE(S && i2t_rank && i2t_top1 && t2i_rank && t2i_best, "itr_rank_counts: null pointer");
     ITR_REQUIRE(im_div >= 1 && im_div <= itr::MAX_IMDIV, "itr_rank_counts: im_div must be in [1, %d]",
                 itr::MAX_IMDIV);
     ITR_REQUIRE(Nc >= 0 && ldS >= Nc && row0 >= 0 && n_rows_local >= 0, "itr_rank_counts: bad shape");
     ITR_REQUIRE(Nc < 0x7fffffffLL && row0 + n_rows_local < 0x7fffffffLL, "itr_rank_counts: index overflow");
+    ITR_REQUIRE((flags & ~ITR_RANK_INIT_COLUMNS) == 0, "itr_rank_counts: unknown flag bits %d", flags);
+    // s_gt == NULL: the ground-truth scores are read from S itself -- every ground-truth row must be local
+    ITR_REQUIRE(s_gt || (row0 == 0 && n_rows_local * im_div >= Nc),
+                "itr_rank_counts: s_gt may only be NULL when the block holds every ground-truth row (row0 = 0, n_rows_local * im_div >= Nc)");
     if (Nc == 0 || n_rows_local == 0) return ITR_OK;
-    ITR_REQUIRE(workspace && workspace_bytes >= itr_rank_workspace_bytes(n_rows_local) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+    ITR_REQUIRE(workspace && workspace_bytes >= itr_rank_workspace_bytes(n_rows_local, Nc) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
                 "itr_rank_counts: workspace missing, misaligned or smaller than itr_rank_workspace_bytes");
     hipStream_t st = itr::as_stream(stream);
-    unsigned long long *row_gkey = static_cast<unsigned long long *>(workspace), *row_best = row_gkey + n_rows_local;
-    const unsigned rb = (unsigned)itr::ceil_div(n_rows_local, (int64_t)256);
-    hipLaunchKernelGGL(itr::rank_rows_prepare_kernel, dim3(rb), dim3(256), 0, st, S, ldS, row0, n_rows_local, Nc, im_div, row_gkey, row_best,
-                       i2t_rank);
-    ITR_CHECK_LAUNCH("rank_rows_prepare");
+    char *wp = static_cast<char *>(workspace);
+    unsigned long long *row_gkey = reinterpret_cast<unsigned long long *>(wp), *row_best = row_gkey + n_rows_local;
+    wp += rank_al((size_t)n_rows_local * 16);
+    float *gt_own = reinterpret_cast<float *>(wp);
     // rows per workgroup: the smallest multiple of 64 for which the grid fits the chip's resident workgroups in one round
     int64_t slots = 0;
     {
@@ -534,11 +550,17 @@ extern "C" int itr_rank_counts(const float *S, int64_t ldS, int64_t row0, int64_
     if (rpw > 1024) rpw = 1024;
     const int64_t gy = itr::ceil_div(n_rows_local, rpw);
     ITR_REQUIRE(gy <= 65535, "itr_rank_counts: too many local rows per call");
+    const int64_t n_prep = n_rows_local > Nc ? n_rows_local : Nc;
+    hipLaunchKernelGGL(itr::rank_prepare_kernel, dim3((unsigned)itr::ceil_div(n_prep, (int64_t)256)), dim3(256), 0, st, S, ldS, row0, n_rows_local,
+                       Nc, im_div, row_gkey, row_best, i2t_rank, s_gt ? (float *)nullptr : gt_own, t2i_rank,
+                       reinterpret_cast<unsigned long long *>(t2i_best), (flags & ITR_RANK_INIT_COLUMNS) ? 1 : 0);
+    ITR_CHECK_LAUNCH("rank_prepare");
     dim3 grid((unsigned)ncb, (unsigned)gy);
-    hipLaunchKernelGGL(itr::rank_fused_kernel, grid, dim3(itr::RANK_THREADS), 0, st, S, ldS, row0, n_rows_local, Nc, im_div, s_gt, row_gkey,
-                       i2t_rank, row_best, t2i_rank, reinterpret_cast<unsigned long long *>(t2i_best), (int)rpw);
+    hipLaunchKernelGGL(itr::rank_fused_kernel, grid, dim3(itr::RANK_THREADS), 0, st, S, ldS, row0, n_rows_local, Nc, im_div, s_gt ? s_gt : gt_own,
+                       row_gkey, i2t_rank, row_best, t2i_rank, reinterpret_cast<unsigned long long *>(t2i_best), (int)rpw);
     ITR_CHECK_LAUNCH("rank_fused");
-    hipLaunchKernelGGL(itr::rank_rows_finish_kernel, dim3(rb), dim3(256), 0, st, row0, n_rows_local, Nc, im_div, row_best, i2t_rank, i2t_top1);
+    hipLaunchKernelGGL(itr::rank_rows_finish_kernel, dim3((unsigned)itr::ceil_div(n_rows_local, (int64_t)256)), dim3(256), 0, st, row0,
+                       n_rows_local, Nc, im_div, row_best, i2t_rank, i2t_top1);
     ITR_CHECK_LAUNCH("rank_rows_finish");
     return ITR_OK;
 }

@@ -96,8 +96,8 @@ SIGNATURES = {
     "itr_debug_scan_occupancy": (i32, [vp, vp]),
     "itr_debug_scan_clock_probe": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, f32, f32, vp, i64, vp, sz, vp]),
     "itr_rank_gather_gt": (i32, [vp, i64, i64, i64, i64, i32, vp, vp]),
-    "itr_rank_workspace_bytes": (sz, [i64]),
-    "itr_rank_counts": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "itr_rank_workspace_bytes": (sz, [i64, i64]),
+    "itr_rank_counts": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
     "itr_rank_gather_gt_f64": (i32, [vp, i64, i64, i64, i64, i32, vp, vp]),
     "itr_rank_counts_f64": (i32, [vp, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp]),
     "itr_rank_t2i_top1_f64": (i32, [vp, i64, i64, i64, i64, vp, vp, vp]),

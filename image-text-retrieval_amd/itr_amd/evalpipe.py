@@ -206,9 +206,15 @@ def finalize_ranks(comm, S_local, row0, n_img_total, im_div=5, rank_fn=None, gat
     """Step 4 above.  Returns host arrays (i2t_rank[Ni], i2t_top1[Ni], t2i_rank[Nc], t2i_top1[Nc]).
     rank_fn / gather_fn default to the HIP kernels; the gloo CPU tests inject reference versions to
     exercise exactly this collective logic."""
+    n_local, Nc = S_local.shape
+    if rank_fn is None and gather_fn is None and not comm.on and row0 == 0 and n_local * im_div >= Nc:
+        # one process holding every row: two launches (preparation + the one pass over S); the library reads the ground-truth scores
+        # from S itself and zeroes the column accumulators inside the call -- no gather, no fills
+        i_rank, i_top, t_rank, t_best, _ = ops.rank_counts(S_local, im_div)
+        return (i_rank.cpu().numpy().astype(np.int64), i_top.cpu().numpy().astype(np.int64), t_rank.cpu().numpy().astype(np.int64),
+                (t_best & 0xffffffff).cpu().numpy())
     rank_fn = rank_fn or ops.rank_counts
     gather_fn = gather_fn or ops.gather_gt
-    n_local, Nc = S_local.shape
     s_gt = torch.full((Nc,), float('-inf'), device=S_local.device, dtype=torch.float32)
     if n_local:
         gather_fn(S_local, im_div, row0, s_gt)

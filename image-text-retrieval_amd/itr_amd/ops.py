@@ -951,27 +951,34 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
 
 # ------------------------------------------------------------------------------------------
 def rank_counts(S, im_div=5, row0=0, s_gt=None, t2i_rank=None, t2i_best=None):
-    """Sort-free ranks of a (local row block of a) similarity matrix.
+    """Sort-free ranks of a (local row block of a) similarity matrix, ONE pass over S for both directions.
     -> (i2t_rank int32[n_rows], i2t_top1 int32[n_rows], t2i_rank int32[Nc], t2i_best uint64-as-int64[Nc], s_gt)
     For a single GPU (row0 = 0, all rows local) t2i_rank is final and t2i_top1 = t2i_best & 0xffffffff.
+    s_gt None: when the block holds every ground-truth row (the single-GPU call) the library reads the GT scores from S itself
+    (no gather launch; the returned s_gt is then None); otherwise they are gathered here for the local rows (the sharded
+    evaluation gathers, max-reduces over ranks and passes them in).  t2i_rank / t2i_best None: allocated here and zeroed INSIDE
+    the call (ITR_RANK_INIT_COLUMNS); pass them to accumulate over several row blocks.
     A float64 matrix (the reference's cal_sims output, an ensemble average) is ranked in float64: `rank_counts_f64`."""
     lib = _lib.load()
     S = _dev(S, name="S")
     n_rows, Nc = S.shape
     dev = S.device
-    if s_gt is None:
+    if s_gt is None and not (row0 == 0 and n_rows * im_div >= Nc):
         s_gt = torch.full((Nc,), float('-inf'), device=dev, dtype=torch.float32)
         _lib.check(lib.itr_rank_gather_gt(_p(S), S.stride(0), row0, n_rows, Nc, im_div, _p(s_gt), _stream()))
     i2t_rank = torch.empty(n_rows, device=dev, dtype=torch.int32)
     i2t_top1 = torch.empty(n_rows, device=dev, dtype=torch.int32)
+    if (t2i_rank is None) != (t2i_best is None):
+        raise ValueError("rank_counts: pass both t2i_rank and t2i_best (accumulators of several row blocks) or neither")
+    flags = 0
     if t2i_rank is None:
-        t2i_rank = torch.zeros(Nc, device=dev, dtype=torch.int32)
-    if t2i_best is None:
-        t2i_best = torch.zeros(Nc, device=dev, dtype=torch.int64)
-    wsb = lib.itr_rank_workspace_bytes(n_rows)
-    ws = torch.empty(wsb // 8, device=dev, dtype=torch.int64)
+        t2i_rank = torch.empty(Nc, device=dev, dtype=torch.int32)
+        t2i_best = torch.empty(Nc, device=dev, dtype=torch.int64)
+        flags = 1                      # ITR_RANK_INIT_COLUMNS
+    wsb = lib.itr_rank_workspace_bytes(n_rows, Nc)
+    ws = torch.empty(wsb // 8 + 1, device=dev, dtype=torch.int64)
     _lib.check(lib.itr_rank_counts(_p(S), S.stride(0), row0, n_rows, Nc, im_div, _p(s_gt), _p(i2t_rank), _p(i2t_top1),
-                                   _p(t2i_rank), _p(t2i_best), _p(ws), wsb, _stream()))
+                                   _p(t2i_rank), _p(t2i_best), flags, _p(ws), wsb, _stream()))
     return i2t_rank, i2t_top1, t2i_rank, t2i_best, s_gt
 
 

@@ -319,16 +319,21 @@ int itr_debug_scan_clock_probe(const float *img, int64_t n_tiles, int64_t Ni, in
  *   t2i_best[Nc] (uint64 key = ordered(score) << 32 | row; zero it first), so a sum /
  *   max all-reduce over ranks completes them.  itr_rank_gather_gt fills s_gt for the GT
  *   rows this rank owns (others left untouched; buffer pre-filled with -inf + max-reduce).
- * ONE pass over S serves both directions (every element is read once: 4 bytes per pair).  workspace:
- * itr_rank_workspace_bytes(n_rows_local) bytes, 8-byte aligned (per-row GT keys and running top-1 keys).
+ * ONE pass over S serves both directions (every element is read once: 4 bytes per pair), between a small preparation and a
+ * small finishing kernel.  workspace: itr_rank_workspace_bytes(n_rows_local, Nc) bytes, 8-byte aligned (per-row GT keys and running
+ * top-1 keys, the GT scores when the call gathers them itself).
+ * s_gt may be NULL when the block holds EVERY ground-truth row (row0 = 0 and n_rows_local * im_div >= Nc: the single-GPU call):
+ * the scores are then read from S itself -- no itr_rank_gather_gt launch.  flags: ITR_RANK_INIT_COLUMNS = zero t2i_rank / t2i_best
+ * inside the call (single-call use; leave it out when several row blocks -- or several ranks -- accumulate into them).
  * Order of scores: -0.0 == +0.0; NaN sorts as the LARGEST value (np.argsort's order: NaN last ascending, first after
  * [::-1]), ties -- also among NaN / +inf -- go to the higher index; the float64 entry points use the same rule. */
+#define ITR_RANK_INIT_COLUMNS 1
 int itr_rank_gather_gt(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
                        int im_div, float *s_gt, itr_stream_t stream);
-size_t itr_rank_workspace_bytes(int64_t n_rows_local);
+size_t itr_rank_workspace_bytes(int64_t n_rows_local, int64_t Nc);
 int itr_rank_counts(const float *S, int64_t ldS, int64_t row0, int64_t n_rows_local, int64_t Nc,
                     int im_div, const float *s_gt, int32_t *i2t_rank, int32_t *i2t_top1,
-                    int32_t *t2i_rank, uint64_t *t2i_best, void *workspace, size_t workspace_bytes, itr_stream_t stream);
+                    int32_t *t2i_rank, uint64_t *t2i_best, int flags, void *workspace, size_t workspace_bytes, itr_stream_t stream);
 /* float64 matrices.  The reference ranks the float64 array cal_sims returns (evaluation.py:169, :209), and
  * evalrank_ensemble averages two models' matrices in float64 before ranking (evaluation.py:380, :398): such
  * scores are not fp32-representable, so they are counted in float64 -- same counts, same tie rule, index-exact.

@@ -145,7 +145,7 @@ def test_badarg_codes_without_gpu():
     # null pointers / bad enums are rejected before anything touches the device
     assert lib.itr_gemm_nt(None, 4, None, 4, None, None, 4, 1, 1, 4, 0, None) == -1
     assert lib.itr_l2norm_rows(None, None, 1, 4, 1e-8, 0, 0, None) == -1
-    assert lib.itr_rank_counts(None, 0, 0, 0, 0, 5, None, None, None, None, None, None, 0, None) == -1
+    assert lib.itr_rank_counts(None, 0, 0, 0, 0, 5, None, None, None, None, None, 0, None, 0, None) == -1
     assert b"null" in lib.itr_last_error()
 
 

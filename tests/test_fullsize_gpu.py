@@ -77,7 +77,8 @@ def test_ranker_full_size(dev):
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     S = torch.randn(n_img, n_cap, device=dev, generator=g)
-    i_rank, i_top, t_rank, t_best, s_gt = ops.rank_counts(S)
+    i_rank, i_top, t_rank, t_best, _ = ops.rank_counts(S)
+    s_gt = ops.gather_gt(S)
     i_rank, i_top, t_rank = i_rank.cpu().numpy(), i_top.cpu().numpy(), t_rank.cpu().numpy()
     t_top = (t_best & 0xffffffff).cpu().numpy()
     rng = np.random.RandomState(0)

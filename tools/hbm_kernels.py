@@ -37,12 +37,12 @@ del x
 # K9 rank counts (metricmodule/evaluation.py:156-222): ONE pass over the 5 000 x 25 000 fp32 matrix serves both directions (round 5)
 S = torch.randn(5000, 25000, device=dev)
 ms_both = timed(lambda: ops.rank_counts(S))
-rows.append(("rank stage as the step runs it: GT gather + row prepare + rank_fused_kernel + row finish (+ 5 small allocations), 5 000 x 25 000",
+rows.append(("rank stage as the step runs it (ops.rank_counts(S): rank_prepare_kernel + rank_fused_kernel + rank_rows_finish_kernel, 5 small allocations), 5 000 x 25 000",
              S.numel() * 4, ms_both))
 s_gt = ops.gather_gt(S)
 bufs = ops.rank_counts(S, s_gt=s_gt)
 ms_k = timed(lambda: ops.rank_counts(S, s_gt=s_gt, t2i_rank=bufs[2], t2i_best=bufs[3]))
-rows.append(("row prepare + rank_fused_kernel + row finish alone (GT scores given, accumulators reused)", S.numel() * 4, ms_k))
+rows.append(("the sharded form: GT scores given, caller-owned column accumulators (the same three kernels)", S.numel() * 4, ms_k))
 print("| kernel (launch) | algorithmic bytes | median ms | GB/s | of 8 TB/s |")
 print("|---|---|---|---|---|")
 for name, b, ms in rows:
