@@ -1,0 +1,92 @@
+// Host-side bin planner shared by itr_scan_plan_tiles (scan_xattn.hip: whole captions into 64-word column tiles) and
+// itr_sgr_plan_node_groups (sgr_fused.hip: whole graphs into 64-row node groups).  Pure CPU, no HIP.
+//
+// Rounds 1-4 packed best-fit-decreasing: 97.9 % full bins on the bench's captions (5 193 tiles where 5 088 would hold the words) --
+// and every padding column is MFMA work that computes nothing: the kernels' time follows the tile count.  Round 5: bins are FILLED
+// EXACTLY where the remaining items allow it.  The largest remaining item opens a bin; a bounded subset-sum over the remaining
+// size histogram (sizes are small integers: capacity x distinct sizes x copies, a few thousand steps) finds the fewest items that fill
+// the rest of the bin exactly, or the fullest reachable sum; the found pattern is repeated for as long as the histogram holds it, so
+// 25 000 captions take ~25 solves.  Result on the bench's captions: 5 097 tiles (99.8 % full), 99.99 % on a COCO-like length
+// distribution; never worse than one bin per `maxn` items of the degenerate all-ones input.  Deterministic (no randomness, ids in
+// ascending order inside a size class).  A pair's score does not depend on the bin its caption lands in
+// (tests: test_*_do_not_depend_on_the_tile_packing).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+namespace itr {
+
+constexpr int PACK_MAXN = 16;      // = SC_MAXCAP = SF_MAXCAP
+struct PackBin {
+    int32_t n;
+    int32_t item[PACK_MAXN];
+};
+
+// by_size[w] = ids of the items of size w (1 <= w <= cap), consumed front to back.  Appends the bins to `bins`.
+inline void pack_exact_fill(const std::vector<std::vector<int32_t>> &by_size, int cap, int maxn, std::vector<PackBin> &bins) {
+    if (maxn > PACK_MAXN) maxn = PACK_MAXN;
+    std::vector<int64_t> avail((size_t)cap + 1, 0), head((size_t)cap + 1, 0);
+    int64_t remaining = 0;
+    for (int w = 1; w <= cap; ++w) {
+        avail[w] = (int64_t)by_size[w].size();
+        remaining += avail[w];
+    }
+    constexpr uint8_t INF = 255;
+    std::vector<uint8_t> best((size_t)cap + 1), nb((size_t)cap + 1);
+    std::vector<uint8_t> choice((size_t)(cap + 1) * (cap + 1));      // [stage][sum] = copies of the stage's size in the best way to `sum`
+    std::vector<int> stage_w((size_t)cap + 1), cnt((size_t)cap + 1);
+    int hi = cap;
+    while (remaining > 0) {
+        while (avail[hi] == 0) --hi;
+        const int L = hi, rem = cap - L;
+        avail[L] -= 1;                       // the bin's first item
+        int n_stage = 0;
+        memset(best.data(), INF, best.size());
+        best[0] = 0;
+        for (int w = (L < rem ? L : rem); w >= 1; --w) {
+            if (avail[w] == 0) continue;
+            uint8_t *ch = &choice[(size_t)n_stage * (cap + 1)];
+            memset(ch, 0, (size_t)cap + 1);
+            memcpy(nb.data(), best.data(), best.size());
+            for (int s = 0; s + w <= rem; ++s) {
+                if (best[s] == INF) continue;
+                for (int k = 1; k <= avail[w] && s + k * w <= rem && best[s] + k <= maxn - 1; ++k)
+                    if (best[s] + k < nb[s + k * w]) {
+                        nb[s + k * w] = (uint8_t)(best[s] + k);
+                        ch[s + k * w] = (uint8_t)k;
+                    }
+            }
+            best.swap(nb);
+            stage_w[n_stage++] = w;
+        }
+        int s = rem;
+        while (best[s] == INF) --s;          // (best[0] = 0: terminates)
+        memset(cnt.data(), 0, cnt.size() * sizeof(int));
+        for (int st = n_stage - 1; st >= 0; --st) {
+            const int k = choice[(size_t)st * (cap + 1) + s];
+            cnt[stage_w[st]] += k;
+            s -= k * stage_w[st];
+        }
+        avail[L] += 1;
+        cnt[L] += 1;
+        int64_t reps = remaining;
+        for (int w = 1; w <= L; ++w)
+            if (cnt[w] && avail[w] / cnt[w] < reps) reps = avail[w] / cnt[w];
+        if (reps < 1) reps = 1;              // (cannot happen: the pattern was found inside the histogram)
+        for (int64_t r = 0; r < reps; ++r) {
+            PackBin b;
+            b.n = 0;
+            for (int w = L; w >= 1; --w)     // largest first, as the kernels' unit tables expect nothing else
+                for (int k = 0; k < cnt[w]; ++k) b.item[b.n++] = by_size[w][(size_t)head[w]++];
+            bins.push_back(b);
+        }
+        for (int w = 1; w <= L; ++w) {
+            avail[w] -= reps * cnt[w];
+            remaining -= reps * cnt[w];
+        }
+    }
+}
+
+}  // namespace itr

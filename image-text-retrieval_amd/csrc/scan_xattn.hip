@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "scan_common.h"
+#include "pack_plan.h"
 
 namespace itr {
 
@@ -894,8 +895,8 @@ static ScanWs scan_carve(void *workspace, int64_t Ni, int R, int64_t n_rows, int
 
 extern "C" int itr_scan_plan_tiles(const int32_t *len_host, int64_t Nc, int nt, int32_t *tile_begin_host,
                                    int32_t *cap_order_host, int64_t *n_tiles) {
-    // Best-fit-decreasing bin packing of whole captions into column tiles of `nt` words and at most
-    // SC_MAXCAP captions (lengths are small integers, so "best fit" is a bucket lookup: O(Nc * nt)).
+    // Whole captions into column tiles of `nt` words and at most SC_MAXCAP captions, tiles filled exactly where the
+    // lengths allow it (pack_plan.h; rounds 1-4: best fit decreasing, 2 % more tiles on the bench's captions).
     // Output: cap_order_host[Nc] = caption ids grouped by tile, tile_begin_host[n_tiles + 1] into it.
     ITR_REQUIRE(len_host && tile_begin_host && cap_order_host && n_tiles, "itr_scan_plan_tiles: null pointer");
     ITR_REQUIRE(nt == ITR_SCAN_NT, "itr_scan_plan_tiles: nt must be %d", ITR_SCAN_NT);
@@ -908,30 +909,13 @@ extern "C" int itr_scan_plan_tiles(const int32_t *len_host, int64_t Nc, int nt, 
                         (long long)c, w, nt);
         by_len[w].push_back((int32_t)c);
     }
-    struct Tile { int32_t n; int32_t cap[itr::SC_MAXCAP]; };
-    std::vector<Tile> tiles;
-    std::vector<std::vector<int32_t>> open(nt + 1);  // open[r] = tiles with r free columns and < MAXCAP captions
-    for (int w = nt; w >= 1; --w)
-        for (int32_t c : by_len[w]) {
-            int r = w;
-            while (r <= nt && open[r].empty()) ++r;
-            int32_t t;
-            if (r <= nt) {
-                t = open[r].back();
-                open[r].pop_back();
-            } else {
-                t = (int32_t)tiles.size();
-                tiles.push_back(Tile{0, {}});
-                r = nt;
-            }
-            Tile &T = tiles[t];
-            T.cap[T.n++] = c;
-            if (T.n < itr::SC_MAXCAP && r - w > 0) open[r - w].push_back(t);
-        }
+    static_assert(itr::PACK_MAXN == itr::SC_MAXCAP, "planner bins hold SC_MAXCAP captions");
+    std::vector<itr::PackBin> tiles;
+    itr::pack_exact_fill(by_len, nt, itr::SC_MAXCAP, tiles);
     int64_t pos = 0;
     for (size_t t = 0; t < tiles.size(); ++t) {
         tile_begin_host[t] = (int32_t)pos;
-        for (int k = 0; k < tiles[t].n; ++k) cap_order_host[pos++] = tiles[t].cap[k];
+        for (int k = 0; k < tiles[t].n; ++k) cap_order_host[pos++] = tiles[t].item[k];
     }
     tile_begin_host[tiles.size()] = (int32_t)pos;
     *n_tiles = (int64_t)tiles.size();

@@ -33,6 +33,7 @@
 // classes ON THE DEVICE (sgr_group_meta_kernel + sgr_group_classify_kernel: no host round trip); a class's persistent launch reads
 // its item count from device memory.
 #include "scan_common.h"
+#include "pack_plan.h"
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
@@ -1082,7 +1083,7 @@ int sgr_fused_scores(const float *xloc, const float *xglo, void *ws, int64_t n_g
 
 }  // namespace itr
 
-// Pure CPU.  The planner of SGR's fused graph steps: whole captions are bin-packed (best fit decreasing, like itr_scan_plan_tiles) by
+// Pure CPU.  The planner of SGR's fused graph steps: whole captions are bin-packed (exact fill, pack_plan.h, like itr_scan_plan_tiles) by
 // NODE count = words + 1 into groups of at most 16 captions and at most 64 node rows (one workgroup per CU).  small_rows = 64: that is
 // all (the default of the Python layer: measured fastest).  small_rows = 32: captions of at most 31 words go into
 // groups of <= 32 node rows instead, which run two workgroups per CU (kept: same scores, 1.2 % slower on the bench captions).
@@ -1093,8 +1094,8 @@ extern "C" int itr_sgr_plan_node_groups(const int32_t *cap_len_host, int64_t Nc,
     ITR_REQUIRE(cap_len_host && group_begin_host && group_order_host && n_groups, "itr_sgr_plan_node_groups: null pointer");
     ITR_REQUIRE(small_rows == SF_SMALL || small_rows == SF_ROWS, "itr_sgr_plan_node_groups: small_rows must be %d or %d", SF_SMALL, SF_ROWS);
     ITR_REQUIRE(Nc >= 0 && Nc < 0x7fffffffLL, "itr_sgr_plan_node_groups: bad caption count");
-    struct Bin { int32_t n; int32_t cap[SF_MAXCAP]; };
-    std::vector<Bin> bins;
+    static_assert(PACK_MAXN == SF_MAXCAP, "planner bins hold SF_MAXCAP graphs");
+    std::vector<PackBin> bins;
     for (int pass = (small_rows == SF_ROWS ? 1 : 0); pass < 2; ++pass) {
         const int cap_rows = pass == 0 ? SF_SMALL : SF_ROWS, lo = (pass == 0 || small_rows == SF_ROWS) ? 2 : SF_SMALL + 1;
         std::vector<std::vector<int32_t>> by_n(cap_rows + 1);
@@ -1105,29 +1106,12 @@ extern "C" int itr_sgr_plan_node_groups(const int32_t *cap_len_host, int64_t Nc,
                             n - 1, SF_ROWS - 1);
             if (n >= lo && n <= cap_rows) by_n[n].push_back((int32_t)c);
         }
-        std::vector<std::vector<int32_t>> open(cap_rows + 1);      // open[r] = bins of this pass with r free rows and < 16 captions
-        for (int n = cap_rows; n >= lo; --n)
-            for (int32_t c : by_n[n]) {
-                int r = n;
-                while (r <= cap_rows && open[r].empty()) ++r;
-                int32_t t;
-                if (r <= cap_rows) {
-                    t = open[r].back();
-                    open[r].pop_back();
-                } else {
-                    t = (int32_t)bins.size();
-                    bins.push_back(Bin{0, {}});
-                    r = cap_rows;
-                }
-                Bin &B = bins[t];
-                B.cap[B.n++] = c;
-                if (B.n < SF_MAXCAP && r - n >= 2) open[r - n].push_back(t);
-            }
+        pack_exact_fill(by_n, cap_rows, SF_MAXCAP, bins);      // (graphs have >= 2 nodes: a last free row stays free)
     }
     int64_t pos = 0;
     for (size_t t = 0; t < bins.size(); ++t) {
         group_begin_host[t] = (int32_t)pos;
-        for (int k = 0; k < bins[t].n; ++k) group_order_host[pos++] = bins[t].cap[k];
+        for (int k = 0; k < bins[t].n; ++k) group_order_host[pos++] = bins[t].item[k];
     }
     group_begin_host[bins.size()] = (int32_t)pos;
     *n_groups = (int64_t)bins.size();

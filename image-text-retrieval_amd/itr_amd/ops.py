@@ -397,7 +397,7 @@ class ScanPlan:
 
     def node_groups(self):
         """SGRAF-SGR's fused graph steps (csrc/sgr_fused.hip): groups of whole captions binned by NODE count (words + the global
-        node), at most 64 node rows and 16 captions per group (itr_sgr_plan_node_groups, best fit decreasing).
+        node), at most 64 node rows and 16 captions per group (itr_sgr_plan_node_groups, exact fill).
         -> (group_begin int32[n + 1], group_order int32[Nc_kernel], n) on the device, or None when a caption has more than 63
         words (its graph does not fit one workgroup)."""
         if self._node_groups is None:

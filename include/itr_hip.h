@@ -171,7 +171,7 @@ int itr_hinge_maxviol_bwd(const float *S, int B, int64_t ldS, float margin, int 
  * mode: 0 t2i, 1 i2t.  norm: 0 clipped_l2norm, 1 l2norm, 2 softmax, 3 no_norm, 4 clipped,
  * 5 l1norm, 6 clipped_l1norm.  agg: 0 LogSumExp, 1 Max, 2 Sum, 3 Mean.
  * Three steps:
- *  1. itr_scan_plan_tiles (pure CPU): whole captions are bin-packed (best fit decreasing) into column
+ *  1. itr_scan_plan_tiles (pure CPU): whole captions are bin-packed (tiles filled exactly where the lengths allow it) into column
  *     tiles of <= ITR_SCAN_NT words: cap_order[Nc] lists the caption ids tile by tile and
  *     tile_begin[n_tiles+1] indexes it; the caller copies both to the device.
  *  2. itr_scan_prepare: once per (image block, caption set, mode) -- re-packs the word embeddings tile

@@ -67,10 +67,13 @@ def test_scan_tile_planner():
         for a, b in zip(tb[:-1], tb[1:]):
             assert 1 <= b - a <= 16                              # <= SC_MAXCAP captions per tile
             assert lens[order[a:b]].sum() <= 64                  # whole captions only, <= 64 words
-    # the BASELINE length distribution packs to >= 97 % column occupancy
-    lens = rng.randint(6, 21, size=25000)
-    rc, tb, order = plan(lens)
-    assert lens.sum() / (64.0 * (len(tb) - 1)) >= 0.97
+    # Tiles are filled exactly where the lengths allow it (csrc/pack_plan.h): the BASELINE length distribution and a COCO-like one
+    # (gamma-shaped, long tail) pack to >= 99.5 % column occupancy -- best fit decreasing (rounds 1-4) reached 97.9 %, and every empty
+    # column is MFMA time in the kernels.  Also on a rank's eighth of the captions, and never worse than one tile per 16 captions.
+    for lens in (rng.randint(6, 21, size=25000), rng.randint(6, 21, size=3125),
+                 np.clip(np.round(rng.gamma(9.0, 1.3, size=25000) + 2).astype(int), 3, 60)):
+        rc, tb, order = plan(lens)
+        assert rc == 0 and lens.sum() / (64.0 * (len(tb) - 1)) >= 0.995, lens.sum() / (64.0 * (len(tb) - 1))
     rc, tb, order = plan([])
     assert rc == 0 and len(tb) == 1
     rc, tb, order = plan([1] * 40)                               # 1-word captions: the caption cap splits them
@@ -94,7 +97,7 @@ def test_sgr_node_group_plan():
             worst = max(worst, int((((nodes + 15) // 16) ** 2).sum()))
         assert worst <= 24
         if (lo, hi) == (6, 21):
-            assert (lens + 1).sum() / (64.0 * (len(tb) - 1)) >= 0.97
+            assert (lens + 1).sum() / (64.0 * (len(tb) - 1)) >= 0.995
     # the two extreme groups by construction: a 33-node graph + fifteen 2-node ones; a 49-node graph + seven 2-node ones
     for lens in ([32] + [1] * 15, [48] + [1] * 7):
         rc, tb, order = plan(np.asarray(lens) + 1)
