@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__
                                                        float *__restrict__ h, float *__restrict__ out,
                                                        const int64_t *__restrict__ tok_off,
                                                        const int32_t *__restrict__ len, int t, int reverse,
-                                                       int mode, int D, int64_t n_act, int64_t dir_stride, float *__restrict__ out2) {
+                                                       int mode, int D, int64_t n_act, int64_t dir_stride, float *__restrict__ out2,
+                                                       const int64_t *__restrict__ tok_ids, int64_t V) {
     const int64_t b = blockIdx.x;
     const int j = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
     if (b >= n_act || j >= D) return;
@@ -73,7 +74,13 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__
         gi += dir_stride; gh += dir_stride; h += dir_stride; out = out2;
     }
     const int64_t row = tok_off[b] + (reverse ? (len[b] - 1 - t) : t);
-    const float *gir = gi + row * 3 * D + j;
+    // gi is [n_tok, 3D] (one row per token) or, with tok_ids, the VOCABULARY table [V, 3D] (see itr_gru_fwd): the row of the token's id
+    int64_t girow = row;
+    if (tok_ids) {
+        const int64_t id = tok_ids[row];
+        girow = (id < 0 || id >= V) ? 0 : id;      // (nn.Embedding would raise: the Python layer checks the range; here memory stays safe)
+    }
+    const float *gir = gi + girow * 3 * D + j;
     const float *ghr = gh + b * 3 * D + j;
     float ir[VEC], iz[VEC], in[VEC], hr[VEC], hz[VEC], hn_[VEC], hp[VEC], ov[VEC];
     float *hrow = h + b * D + j, *o = out + row * D + j;
@@ -107,6 +114,16 @@ __global__ void gather_last_rows_kernel(const float *__restrict__ x, const int64
                                         int Ep, float *__restrict__ x_last) {
     const int64_t b = blockIdx.x;
     const float *src = x + (tok_off[b] + len[b] - 1) * Ep;
+    for (int k = threadIdx.x; k < Ep; k += blockDim.x) x_last[b * Ep + k] = src[k];
+}
+// the same from the padded embedding TABLE [V, Ep] (the vocabulary-table form of the input projection, itr_gru_fwd)
+__global__ void gather_last_rows_tab_kernel(const float *__restrict__ xtab, const int64_t *__restrict__ tokens, int64_t V,
+                                            const int64_t *__restrict__ tok_off, const int32_t *__restrict__ len, int Ep,
+                                            float *__restrict__ x_last) {
+    const int64_t b = blockIdx.x;
+    int64_t id = tokens[tok_off[b] + len[b] - 1];
+    if (id < 0 || id >= V) id = 0;
+    const float *src = xtab + id * Ep;
     for (int k = threadIdx.x; k < Ep; k += blockDim.x) x_last[b * Ep + k] = src[k];
 }
 // out_last[b] = (h_fwd[b] + gru_cell(gi_last[b], b_hh, h = 0)) / 2
@@ -243,6 +260,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     using namespace itr;
     const bool batch_invariant = (gather_last & ITR_GRU_BATCH_INVARIANT) != 0;
     const bool want_paired = (gather_last & ITR_GRU_PAIRED_DIRECTIONS) != 0, want_input_after_fork = (gather_last & ITR_GRU_INPUT_AFTER_FORK) != 0;
+    const bool want_per_token = (gather_last & ITR_GRU_PER_TOKEN_INPUT) != 0;
     gather_last &= ITR_GRU_GATHER_LAST;
     ITR_REQUIRE(tokens && tok_off && len_dev && len_host && embed && w_ih && w_hh && b_ih && b_hh && workspace,
                 "itr_gru_fwd: null pointer");
@@ -270,9 +288,25 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     // (split-K sums a dot product in slices: the result depends on the batch size through the slice count -- never with
     // ITR_GRU_BATCH_INVARIANT; the plain kernels all run the same fmaf chain per output element whatever M is)
     const int splits_h = (B <= 1024 && !batch_invariant && !ITR_EXP_ENV("ITR_GRU_NO_SPLITK")) ? gemm_splitk_choice(B, 3 * D, D) : 1;   // env: A/B switch for tools/
-    hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, Ep, w.x,
-                       w.bad);
-    ITR_CHECK_LAUNCH("embed_gather");
+    // The input projection of a token is a function of its ID alone: gi[token] = W_ih emb[id] + b_ih.  When the call has more tokens
+    // than the vocabulary has words (an evaluation: 325 623 tokens over 11 353 words at 5k x 25k; Flickr30k 1k x 5k: 64 952 over 8 481)
+    // the projection runs ONCE PER WORD -- a [V, Ep] x [Ep, 3D] GEMM into the head of the gi region -- and the gate kernel reads the
+    // row of the token's id.  Same GEMM kernels, same fmaf chain per output element: bit-identical to the per-token projection
+    // (tests/test_kernels_gpu.py: test_gru_vocabulary_table_is_bit_identical).  Round 5: the per-token GEMM was 8 ms of the 5k x 25k
+    // step and 0.9 of VSE++'s 5.9 ms, the table GEMM is 0.3 / 0.2 ms; the 2 x 4 GB of per-token pre-activations are neither written
+    // nor streamed back (the tables are 2 x 140 MB and stay in the Infinity Cache).  flag ITR_GRU_PER_TOKEN_INPUT: the per-token
+    // form, kept as the cross-check.
+    const bool table = 2 * V <= n_tok && !want_per_token;
+    const int64_t x_rows = table ? V : n_tok;
+    const int64_t *gi_ids = table ? tokens : nullptr;
+    if (table) {
+        hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)V), dim3(128), 0, st, embed, V, E, Ep, w.x);
+        ITR_CHECK_LAUNCH("embed table");
+    } else {
+        hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, Ep, w.x,
+                           w.bad);
+        ITR_CHECK_LAUNCH("embed_gather");
+    }
 
     GruWs w2 = w;
     if (bi) {
@@ -291,12 +325,15 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             }
             return gemm_nt(xin, Ep, wi_use, Ep, bi_, dst, 3 * D, rows, 3 * D, Ep, 0, st);
         };
-        int rc = project(w.x, n_tok, w_ih, b_ih, w.wpad, w.gi);
+        int rc = project(w.x, x_rows, w_ih, b_ih, w.wpad, w.gi);
         if (rc != ITR_OK) return rc;
         ITR_CHECK_HIP(hipMemsetAsync(w.h, 0, (size_t)B * D * 4, st));
         if (bi) {      // the backward direction's one step: projection of the B last tokens (the second workspace half's unused x region)
             float *x_last = reinterpret_cast<float *>(static_cast<char *>(workspace) + gru_ws_one(n_tok, B, E, D));
-            hipLaunchKernelGGL(gather_last_rows_kernel, dim3((unsigned)B), dim3(128), 0, st, w.x, tok_off, len_dev, Ep, x_last);
+            if (table)
+                hipLaunchKernelGGL(gather_last_rows_tab_kernel, dim3((unsigned)B), dim3(128), 0, st, w.x, tokens, V, tok_off, len_dev, Ep, x_last);
+            else
+                hipLaunchKernelGGL(gather_last_rows_kernel, dim3((unsigned)B), dim3(128), 0, st, w.x, tok_off, len_dev, Ep, x_last);
             ITR_CHECK_LAUNCH("gather_last_rows");
             rc = project(x_last, B, w_ih_rev, b_ih_rev, w2.wpad, w2.gi);
             if (rc != ITR_OK) return rc;
@@ -309,10 +346,10 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             if (rc != ITR_OK) return rc;
             if (D % 4 == 0)
                 hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, st, w.gi, w.gh, w.h,
-                                   w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_act, (int64_t)0, (float *)nullptr);
+                                   w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V);
             else
                 hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, w.gi, w.gh, w.h,
-                                   w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_act, (int64_t)0, (float *)nullptr);
+                                   w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V);
             ITR_CHECK_LAUNCH("gru_gate (state only)");
         }
         // a caption's row of h is not touched after its last step: it IS the state at position len - 1
@@ -340,7 +377,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             ITR_CHECK_LAUNCH("pad_cols");
             wi_use = ww.wpad;
         }
-        int rc = gemm_nt(w.x, Ep, wi_use, Ep, dir ? b_ih_rev : b_ih, ww.gi, 3 * D, n_tok, 3 * D, Ep, 0, sd);
+        int rc = gemm_nt(w.x, Ep, wi_use, Ep, dir ? b_ih_rev : b_ih, ww.gi, 3 * D, x_rows, 3 * D, Ep, 0, sd);
         if (rc != ITR_OK) return rc;
         ITR_CHECK_HIP(hipMemsetAsync(ww.h, 0, (size_t)B * D * 4, sd));
         return ITR_OK;
@@ -363,7 +400,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             int rc = gemm_nt_pair(w.h, w2.h, D, w_hh, w_hh_rev, D, b_hh, b_hh_rev, w.gh, w2.gh, 3 * D, n_act, 3 * D, D, st);
             if (rc != ITR_OK) return rc;
             hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024), 2u), dim3(256), 0, st, w.gi, w.gh, w.h,
-                               seq, tok_off, len_dev, t, 0, 0, D, n_act, dir_stride, w2.out_tmp);
+                               seq, tok_off, len_dev, t, 0, 0, D, n_act, dir_stride, w2.out_tmp, gi_ids, V);
             ITR_CHECK_LAUNCH("gru_gate (both directions)");
         }
     }
@@ -394,10 +431,10 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
                 if (rc != ITR_OK) return rc;
                 if (D % 4 == 0)
                     hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
-                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr);
+                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V);
                 else
                     hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
-                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr);
+                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V);
                 ITR_CHECK_LAUNCH("gru_gate");
             }
         }

@@ -898,9 +898,11 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
     send buffer of the sharded evaluation's all-gather (evalpipe.py).  batch_invariant: a caption's embedding does not
     depend, bit for bit, on which other captions share its batch (ITR_GRU_BATCH_INVARIANT, include/itr_hip.h).
     launch_form: None (default), "paired" or "input_after_fork" -- the bi-GRU launch orders kept as bit-identical cross-checks
-    (ITR_GRU_PAIRED_DIRECTIONS / ITR_GRU_INPUT_AFTER_FORK flag bits)."""
+    (ITR_GRU_PAIRED_DIRECTIONS / ITR_GRU_INPUT_AFTER_FORK flag bits); "per_token": the input projection as one GEMM row per TOKEN
+    even where the call would project the vocabulary once (ITR_GRU_PER_TOKEN_INPUT; >= 2 tokens per vocabulary word) -- the
+    cross-check of that form."""
     lib = _lib.load()
-    form_bits = {None: 0, "paired": 4, "input_after_fork": 8}[launch_form]
+    form_bits = {None: 0, "paired": 4, "input_after_fork": 8, "per_token": 16, "paired+per_token": 20}[launch_form]
     tokens_packed = _dev(tokens_packed, torch.int64, "tokens")
     len_host = _host_i32(lengths)
     B = len(len_host)

@@ -133,6 +133,10 @@ int itr_proj_l2norm(const float *x, const float *W, const float *b, float *out, 
  * on its own stream after the fork (the round-2 order). */
 #define ITR_GRU_PAIRED_DIRECTIONS 4
 #define ITR_GRU_INPUT_AFTER_FORK 8
+/* The input projection W_ih emb[id] + b_ih depends on the token's id alone: a call with at least twice as many tokens as the
+ * vocabulary has words (an evaluation) projects the V embedding rows once and the gate kernel reads the row of the token's id
+ * (bit-identical: the same GEMM kernels on the same rows).  bit 4 forces the per-token projection (the cross-check). */
+#define ITR_GRU_PER_TOKEN_INPUT 16
 size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional);
 int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev,
                 const int32_t *len_host, int64_t B, int64_t n_tok, const float *embed, int64_t V,

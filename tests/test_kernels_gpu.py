@@ -740,12 +740,44 @@ def test_bigru_launch_forms_are_bit_identical(dev, monkeypatch, V, E, D, B, lo, 
     kw = dict(batch_invariant=True) if B <= 1024 else {}          # small batches take the paired form only without split-K
     got = ops.gru_encode(toks, off, lengths, wd, True, **kw)
     got_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, **kw)
-    for form in ("paired", "input_after_fork"):                  # explicit flag bits of itr_gru_fwd (no environment switch)
+    # (the second shape has >= 2 tokens per vocabulary word: its default form projects the VOCABULARY once, "per_token" is the cross-check)
+    for form in ("paired", "input_after_fork", "per_token", "paired+per_token"):      # explicit flag bits of itr_gru_fwd (no environment switch)
         two = ops.gru_encode(toks, off, lengths, wd, True, launch_form=form, **kw)
         two_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, launch_form=form, **kw)
         assert torch.equal(got, two) and torch.equal(got_last, two_last), form
     n = 20                                                         # the oracle on the 20 longest captions (a GRU row depends on no other row)
     want, _ = O.encoder_text(ids[:n], lengths[:n], w, True, False, False, None)
+    o = 0
+    for b in range(n):
+        assert maxdiff(got[o:o + lengths[b]].cpu(), want[b, :lengths[b]]) <= 5e-6
+        o += lengths[b]
+
+
+@pytest.mark.parametrize("V,E,D,B,bi", [(300, 300, 1024, 400, True), (64, 64, 66, 300, False), (1000, 300, 256, 2500, True), (40, 20, 32, 90, True)])
+def test_gru_vocabulary_table_is_bit_identical(dev, V, E, D, B, bi):
+    """Round 5: with >= 2 tokens per vocabulary word the input projection W_ih emb[id] + b_ih runs once per WORD ([V, Ep] x [Ep, 3D])
+    and the gate kernel reads the row of the token's id, instead of one GEMM row per token (csrc/towers.hip).  Same GEMM kernels on the
+    same rows: sequence outputs and last states must be bit-identical to the per-token form (flag ITR_GRU_PER_TOKEN_INPUT), for
+    uni- / bi-directional GRUs, padded (300 -> 320) and unpadded embedding widths, D % 4 != 0 -- and equal to the oracle."""
+    rng = np.random.RandomState(V + B)
+    torch.manual_seed(V)
+    lengths = sorted([int(x) for x in rng.randint(1, 22, size=B)], reverse=True)
+    assert sum(lengths) >= 2 * V
+    ids = torch.from_numpy(rng.randint(0, V, size=(B, max(lengths))))
+    rnn = torch.nn.GRU(E, D, 1, batch_first=True, bidirectional=bi)
+    w = {'embed.weight': torch.empty(V, E).uniform_(-0.1, 0.1)}
+    w.update({'rnn.' + k: v.detach() for k, v in rnn.state_dict().items()})
+    wd = {k: v.to(dev) for k, v in w.items()}
+    toks, off = pack(ids, lengths, dev)
+    for kw in (dict(), dict(batch_invariant=True), dict(no_txtnorm=True)):
+        tab = ops.gru_encode(toks, off, lengths, wd, bi, **kw)
+        per = ops.gru_encode(toks, off, lengths, wd, bi, launch_form="per_token", **kw)
+        tab_last = ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True, **kw)
+        per_last = ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True, launch_form="per_token", **kw)
+        assert torch.equal(tab, per) and torch.equal(tab_last, per_last), kw
+    n = 12
+    want, _ = O.encoder_text(ids[:n], lengths[:n], w, bi, False, False, None)
+    got = ops.gru_encode(toks, off, lengths, wd, bi)
     o = 0
     for b in range(n):
         assert maxdiff(got[o:o + lengths[b]].cpu(), want[b, :lengths[b]]) <= 5e-6
