@@ -65,10 +65,13 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__
                                                        const int64_t *__restrict__ tok_off,
                                                        const int32_t *__restrict__ len, int t, int reverse,
                                                        int mode, int D, int64_t n_act, int64_t dir_stride, float *__restrict__ out2,
-                                                       const int64_t *__restrict__ tok_ids, int64_t V) {
-    const int64_t b = blockIdx.x;
+                                                       const int64_t *__restrict__ tok_ids, int64_t V, int cap_stride, int cap_off) {
+    // (cap_stride > 1: this launch is ONE of `cap_stride` interleaved caption chains of a time step -- workgroup x is caption
+    // x * cap_stride + cap_off; n_act counts the chain's captions.  All buffers stay in caption order.)
+    if ((int64_t)blockIdx.x >= n_act) return;
+    const int64_t b = (int64_t)blockIdx.x * cap_stride + cap_off;
     const int j = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
-    if (b >= n_act || j >= D) return;
+    if (j >= D) return;
     if (blockIdx.z) {
         reverse = 1;
         gi += dir_stride; gh += dir_stride; h += dir_stride; out = out2;
@@ -181,15 +184,16 @@ struct SideStream {
         if (join) (void)hipEventDestroy(join);
     }
 };
-static bool side_stream(SideStream &s) {
+constexpr int GRU_MAX_CHAINS = 4;      // interleaved caption chains of the last-state recurrence (below): the caller's stream + 3
+static bool side_stream(SideStream &s, int k = 0) {
     static std::mutex mu;
-    static hipStream_t per_dev[16] = {};
+    static hipStream_t per_dev[16][GRU_MAX_CHAINS - 1] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || k < 0 || k >= GRU_MAX_CHAINS - 1) return false;
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (!per_dev[dev] && hipStreamCreateWithFlags(&per_dev[dev], hipStreamNonBlocking) != hipSuccess) { per_dev[dev] = nullptr; return false; }
-        s.st = per_dev[dev];
+        if (!per_dev[dev][k] && hipStreamCreateWithFlags(&per_dev[dev][k], hipStreamNonBlocking) != hipSuccess) { per_dev[dev][k] = nullptr; return false; }
+        s.st = per_dev[dev][k];
     }
     return hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
@@ -261,6 +265,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     const bool batch_invariant = (gather_last & ITR_GRU_BATCH_INVARIANT) != 0;
     const bool want_paired = (gather_last & ITR_GRU_PAIRED_DIRECTIONS) != 0, want_input_after_fork = (gather_last & ITR_GRU_INPUT_AFTER_FORK) != 0;
     const bool want_per_token = (gather_last & ITR_GRU_PER_TOKEN_INPUT) != 0;
+    const int chains_arg = (gather_last >> 5) & 7;      // ITR_GRU_CHAINS(n): 0 = the library's choice
     gather_last &= ITR_GRU_GATHER_LAST;
     ITR_REQUIRE(tokens && tok_off && len_dev && len_host && embed && w_ih && w_hh && b_ih && b_hh && workspace,
                 "itr_gru_fwd: null pointer");
@@ -338,20 +343,51 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             rc = project(x_last, B, w_ih_rev, b_ih_rev, w2.wpad, w2.gi);
             if (rc != ITR_OK) return rc;
         }
-        int64_t n_act = B;
-        for (int t = 0; t < Lmax; ++t) {
-            while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
-            rc = (splits_h > 1) ? gemm_nt_splitk(w.h, D, w_hh, D, b_hh, w.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, w.skbuf, st)
-                                : gemm_nt(w.h, D, w_hh, D, b_hh, w.gh, 3 * D, n_act, 3 * D, D, 0, st);
-            if (rc != ITR_OK) return rc;
-            if (D % 4 == 0)
-                hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, st, w.gi, w.gh, w.h,
-                                   w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V);
-            else
-                hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, w.gi, w.gh, w.h,
-                                   w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V);
-            ITR_CHECK_LAUNCH("gru_gate (state only)");
+        // The recurrence of a caption depends on no other caption: the batch is cut into `nch` INTERLEAVED chains (caption c belongs to
+        // chain c mod nch: equal length mixes), each with its own GEMM -> gates -> GEMM sequence on its own stream.  A time step of ONE
+        // chain is a strict sequence of dependent launches -- the chip drains after every GEMM (332 us per 5 000-row step in the VSE++
+        // trace against 256 us for the same GEMM issued back to back) -- while the chains fill each other's drains, as the two
+        // directions of the word-level models do.  Rows of h / gh stay in caption order (the GEMM's lda / ldc = nch rows); every
+        // output element is the same fmaf chain: bit-identical to one chain (test_gru_chains_are_bit_identical).
+        const int nch = splits_h > 1 ? 1 : (chains_arg > 0 ? (chains_arg < GRU_MAX_CHAINS ? chains_arg : GRU_MAX_CHAINS) : (B >= 4096 ? 2 : 1));
+        SideStream chain_side[GRU_MAX_CHAINS - 1];
+        int n_side = 0;
+        for (int k = 0; k + 1 < nch; ++k) {
+            if (!side_stream(chain_side[k], k)) break;
+            ++n_side;
         }
+        const int nchains = n_side + 1;
+        for (int k = 0; k < n_side; ++k) {
+            ITR_CHECK_HIP(hipEventRecord(chain_side[k].fork, st));
+            ITR_CHECK_HIP(hipStreamWaitEvent(chain_side[k].st, chain_side[k].fork, 0));
+            chain_side[k].forked = true;
+        }
+        auto run_chains = [&]() -> int {
+            int64_t n_act = B;
+            for (int t = 0; t < Lmax; ++t) {
+                while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
+                for (int p = 0; p < nchains; ++p) {
+                    const int64_t n_p = n_act > p ? (n_act - p + nchains - 1) / nchains : 0;      // captions c < n_act with c mod nchains == p
+                    if (n_p == 0) continue;
+                    hipStream_t sp = p ? chain_side[p - 1].st : st;
+                    int rc2 = (splits_h > 1) ? gemm_nt_splitk(w.h, D, w_hh, D, b_hh, w.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, w.skbuf, sp)
+                                             : gemm_nt(w.h + (size_t)p * D, (int64_t)nchains * D, w_hh, D, b_hh, w.gh + (size_t)p * 3 * D,
+                                                       (int64_t)nchains * 3 * D, n_p, 3 * D, D, 0, sp);
+                    if (rc2 != ITR_OK) return rc2;
+                    if (D % 4 == 0)
+                        hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_p, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sp, w.gi, w.gh, w.h,
+                                           w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_p, (int64_t)0, (float *)nullptr, gi_ids, V, nchains, p);
+                    else
+                        hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_p, (unsigned)ceil_div(D, 256)), dim3(256), 0, sp, w.gi, w.gh, w.h,
+                                           w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_p, (int64_t)0, (float *)nullptr, gi_ids, V, nchains, p);
+                    ITR_CHECK_LAUNCH("gru_gate (state only)");
+                }
+            }
+            return ITR_OK;
+        };
+        rc = run_chains();
+        for (int k = 0; k < n_side; ++k) chain_side[k].join_into(st);      // also on the error path: nothing stays queued behind our back
+        if (rc != ITR_OK) return rc;
         // a caption's row of h is not touched after its last step: it IS the state at position len - 1
         if (bi) {
             hipLaunchKernelGGL(gru_last_state_bi_kernel, dim3((unsigned)B), dim3(256), 0, st, w2.gi, b_hh_rev, w.h, D, out_last);
@@ -400,7 +436,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             int rc = gemm_nt_pair(w.h, w2.h, D, w_hh, w_hh_rev, D, b_hh, b_hh_rev, w.gh, w2.gh, 3 * D, n_act, 3 * D, D, st);
             if (rc != ITR_OK) return rc;
             hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024), 2u), dim3(256), 0, st, w.gi, w.gh, w.h,
-                               seq, tok_off, len_dev, t, 0, 0, D, n_act, dir_stride, w2.out_tmp, gi_ids, V);
+                               seq, tok_off, len_dev, t, 0, 0, D, n_act, dir_stride, w2.out_tmp, gi_ids, V, 1, 0);
             ITR_CHECK_LAUNCH("gru_gate (both directions)");
         }
     }
@@ -431,10 +467,10 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
                 if (rc != ITR_OK) return rc;
                 if (D % 4 == 0)
                     hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
-                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V);
+                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V, 1, 0);
                 else
                     hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
-                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V);
+                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V, 1, 0);
                 ITR_CHECK_LAUNCH("gru_gate");
             }
         }

@@ -890,7 +890,7 @@ _TOKENS_CHECKED = {}         # id(tensor) -> (weak reference, (version counter, 
 
 
 def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtnorm=False, use_abs=False,
-               gather_last=False, out=None, batch_invariant=False, launch_form=None):
+               gather_last=False, out=None, batch_invariant=False, launch_form=None, chains=0):
     """EncoderText.forward on packed captions (TextEncoder.py:38-70).
     tokens_packed (n_tok,) int64 cuda; tok_off (B,) int64; lengths: host list sorted descending.
     weights: dict with the reference's state_dict names.  -> (n_tok, D) packed word embeddings, or
@@ -900,7 +900,7 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
     launch_form: None (default), "paired" or "input_after_fork" -- the bi-GRU launch orders kept as bit-identical cross-checks
     (ITR_GRU_PAIRED_DIRECTIONS / ITR_GRU_INPUT_AFTER_FORK flag bits); "per_token": the input projection as one GEMM row per TOKEN
     even where the call would project the vocabulary once (ITR_GRU_PER_TOKEN_INPUT; >= 2 tokens per vocabulary word) -- the
-    cross-check of that form."""
+    cross-check of that form.  chains: interleaved caption chains of the last-state recurrence (ITR_GRU_CHAINS; 0 = the library's choice)."""
     lib = _lib.load()
     form_bits = {None: 0, "paired": 4, "input_after_fork": 8, "per_token": 16, "paired+per_token": 20}[launch_form]
     tokens_packed = _dev(tokens_packed, torch.int64, "tokens")
@@ -946,7 +946,7 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
     out_last = (res if res is not None else torch.empty(B, D, device=dev, dtype=torch.float32)) if gather_last else None
     _lib.check(lib.itr_gru_fwd(_p(tokens_packed), _p(tok_off), _p(len_dev), len_host.ctypes.data_as(C.c_void_p), B,
                                n_tok, _p(emb), V, E, D, _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), _p(rev[0]),
-                               _p(rev[1]), _p(rev[2]), _p(rev[3]), int(no_txtnorm), int(use_abs), int(bool(gather_last)) | (2 if batch_invariant else 0) | form_bits,
+                               _p(rev[1]), _p(rev[2]), _p(rev[3]), int(no_txtnorm), int(use_abs), int(bool(gather_last)) | (2 if batch_invariant else 0) | form_bits | ((int(chains) & 7) << 5),
                                _p(out), _p(out_last), _p(ws), wsb, _stream()))
     return out_last if gather_last else out
 

