@@ -804,13 +804,10 @@ def test_gru_chains_are_bit_identical(dev, V, E, D, B, bi):
             got = ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True, chains=n, launch_form=form)
             assert torch.equal(one, got), (n, form)
     assert torch.equal(one, ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True))
-    n = 16
-    _, want = O.encoder_text(ids[:n], lengths[:n], w, bi, False, False, None, method_name='VSE++') if False else (None, None)
-    seq = ops.gru_encode(toks, off, lengths, wd, bi)          # the sequence form's position len - 1 is the same state
-    o = 0
-    for b in range(B):
-        if b < 64:
-            assert torch.equal(seq[o + lengths[b] - 1], one[b]) or maxdiff(seq[o + lengths[b] - 1], one[b]) <= 2e-6
+    seq = ops.gru_encode(toks, off, lengths, wd, bi)          # the sequence form's position len - 1 is the same state (and it is
+    o = 0                                                      # checked against the oracle in the tests above)
+    for b in range(64):
+        assert maxdiff(seq[o + lengths[b] - 1], one[b]) <= 2e-6
         o += lengths[b]
 
 
