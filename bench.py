@@ -479,7 +479,12 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
         flop = (i1 - i0) * 2 * 2048 * 1024 + n_tok * 16.27e6 + float(i1 - i0) * n_cap * 2 * 1024
         # executed (round 5): VSE++ reads the bi-GRU at position len - 1 only (TextEncoder.py:57-60), where the backward direction has
         # seen ONE token: the forward recurrence (half of SURVEY 8d's 16.27 MFLOP per token) + one backward input projection per caption
-        exe_flop = (i1 - i0) * 2 * 2048 * 1024 + n_tok * 8.135e6 + (c1 - c0) * 2.0 * 3 * 1024 * 300 + float(i1 - i0) * n_cap * 2 * 1024
+        # -- and of that: the input projection once per vocabulary WORD when the shard has >= 2 tokens per word (csrc/towers.hip), and no
+        # recurrence GEMM for a caption's first step (h = 0: the product is b_hh)
+        n_loc = float(c1 - c0)
+        in_rows = float(wl["vocab"]) if 2 * wl["vocab"] <= n_tok else n_tok
+        exe_flop = ((i1 - i0) * 2 * 2048 * 1024 + in_rows * 2.0 * 3 * 1024 * 300 + (n_tok - n_loc) * 2.0 * 3 * 1024 * 1024
+                    + n_loc * 2.0 * 3 * 1024 * 300 + float(i1 - i0) * n_cap * 2 * 1024)
         model_name, dims = "VSE++ bi-GRU (mean-pooled regions)", 1024
     elif kind == "VSRN":
         n_tok = float(lengths[c0:c1].sum())
@@ -510,7 +515,8 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
                         "algorithmic_equiv_frac": flop / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                         "note": "time = the whole step (the towers are hundreds of GEMM launches); achieved / frac = the flop EXECUTED "
                                 "(= SURVEY 8d's per-unit figures, except VSE++: its last-state output needs one step of the backward GRU, "
-                                "not its recurrence); algorithmic_equiv_frac = SURVEY 8d's flop over the same time"}}
+                                "not its recurrence, the input projection runs once per vocabulary word and a caption's first step has no "
+                                "recurrence product); algorithmic_equiv_frac = SURVEY 8d's flop over the same time"}}
     if comm.virtual:
         out["virtual_split"] = "%d:%d" % (comm.cap_world, comm.cap_rank)
         out["config"]["parallelism"] = "1 process, caption axis split over %d virtual owners (this one: %d): TEST HOOK, time is not a result" % (

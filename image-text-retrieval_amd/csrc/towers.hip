@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__
                                                        const int64_t *__restrict__ tok_off,
                                                        const int32_t *__restrict__ len, int t, int reverse,
                                                        int mode, int D, int64_t n_act, int64_t dir_stride, float *__restrict__ out2,
-                                                       const int64_t *__restrict__ tok_ids, int64_t V, int cap_stride, int cap_off) {
+                                                       const int64_t *__restrict__ tok_ids, int64_t V, int cap_stride, int cap_off,
+                                                       int64_t gh_stride) {
     // (cap_stride > 1: this launch is ONE of `cap_stride` interleaved caption chains of a time step -- workgroup x is caption
     // x * cap_stride + cap_off; n_act counts the chain's captions.  All buffers stay in caption order.)
     if ((int64_t)blockIdx.x >= n_act) return;
@@ -84,7 +85,9 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const float *__restrict__
         girow = (id < 0 || id >= V) ? 0 : id;      // (nn.Embedding would raise: the Python layer checks the range; here memory stays safe)
     }
     const float *gir = gi + girow * 3 * D + j;
-    const float *ghr = gh + b * 3 * D + j;
+    // gh_stride = 3 D: the recurrence GEMM's row of caption b.  gh_stride = 0: the FIRST step of a direction -- h = 0, so
+    // W_hh h + b_hh is b_hh itself for every caption (a GEMM of zero rows sums to +0 exactly): no GEMM is launched and gh = b_hh.
+    const float *ghr = gh + b * gh_stride + j;
     float ir[VEC], iz[VEC], in[VEC], hr[VEC], hz[VEC], hn_[VEC], hp[VEC], ov[VEC];
     float *hrow = h + b * D + j, *o = out + row * D + j;
     auto ld = [](float (&d)[VEC], const float *p) {
@@ -266,6 +269,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     const bool want_paired = (gather_last & ITR_GRU_PAIRED_DIRECTIONS) != 0, want_input_after_fork = (gather_last & ITR_GRU_INPUT_AFTER_FORK) != 0;
     const bool want_per_token = (gather_last & ITR_GRU_PER_TOKEN_INPUT) != 0;
     const int chains_arg = (gather_last >> 5) & 7;      // ITR_GRU_CHAINS(n): 0 = the library's choice
+    const bool want_first_gemm = (gather_last & ITR_GRU_FIRST_STEP_GEMM) != 0;
     gather_last &= ITR_GRU_GATHER_LAST;
     ITR_REQUIRE(tokens && tok_off && len_dev && len_host && embed && w_ih && w_hh && b_ih && b_hh && workspace,
                 "itr_gru_fwd: null pointer");
@@ -370,16 +374,21 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
                     const int64_t n_p = n_act > p ? (n_act - p + nchains - 1) / nchains : 0;      // captions c < n_act with c mod nchains == p
                     if (n_p == 0) continue;
                     hipStream_t sp = p ? chain_side[p - 1].st : st;
-                    int rc2 = (splits_h > 1) ? gemm_nt_splitk(w.h, D, w_hh, D, b_hh, w.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, w.skbuf, sp)
-                                             : gemm_nt(w.h + (size_t)p * D, (int64_t)nchains * D, w_hh, D, b_hh, w.gh + (size_t)p * 3 * D,
-                                                       (int64_t)nchains * 3 * D, n_p, 3 * D, D, 0, sp);
-                    if (rc2 != ITR_OK) return rc2;
+                    const bool first = t == 0 && !want_first_gemm;      // h = 0: W_hh h + b_hh = b_hh, no GEMM
+                    if (!first) {
+                        int rc2 = (splits_h > 1) ? gemm_nt_splitk(w.h, D, w_hh, D, b_hh, w.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, w.skbuf, sp)
+                                                 : gemm_nt(w.h + (size_t)p * D, (int64_t)nchains * D, w_hh, D, b_hh, w.gh + (size_t)p * 3 * D,
+                                                           (int64_t)nchains * 3 * D, n_p, 3 * D, D, 0, sp);
+                        if (rc2 != ITR_OK) return rc2;
+                    }
+                    const float *gh_use = first ? b_hh : w.gh;
+                    const int64_t gh_stride = first ? 0 : (int64_t)3 * D;
                     if (D % 4 == 0)
-                        hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_p, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sp, w.gi, w.gh, w.h,
-                                           w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_p, (int64_t)0, (float *)nullptr, gi_ids, V, nchains, p);
+                        hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_p, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sp, w.gi, gh_use, w.h,
+                                           w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_p, (int64_t)0, (float *)nullptr, gi_ids, V, nchains, p, gh_stride);
                     else
-                        hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_p, (unsigned)ceil_div(D, 256)), dim3(256), 0, sp, w.gi, w.gh, w.h,
-                                           w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_p, (int64_t)0, (float *)nullptr, gi_ids, V, nchains, p);
+                        hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_p, (unsigned)ceil_div(D, 256)), dim3(256), 0, sp, w.gi, gh_use, w.h,
+                                           w.out_tmp, tok_off, len_dev, t, 0, 2, D, n_p, (int64_t)0, (float *)nullptr, gi_ids, V, nchains, p, gh_stride);
                     ITR_CHECK_LAUNCH("gru_gate (state only)");
                 }
             }
@@ -436,7 +445,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             int rc = gemm_nt_pair(w.h, w2.h, D, w_hh, w_hh_rev, D, b_hh, b_hh_rev, w.gh, w2.gh, 3 * D, n_act, 3 * D, D, st);
             if (rc != ITR_OK) return rc;
             hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024), 2u), dim3(256), 0, st, w.gi, w.gh, w.h,
-                               seq, tok_off, len_dev, t, 0, 0, D, n_act, dir_stride, w2.out_tmp, gi_ids, V, 1, 0);
+                               seq, tok_off, len_dev, t, 0, 0, D, n_act, dir_stride, w2.out_tmp, gi_ids, V, 1, 0, (int64_t)3 * D);
             ITR_CHECK_LAUNCH("gru_gate (both directions)");
         }
     }
@@ -462,15 +471,21 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             int64_t n_act = B;
             for (int t = 0; t < Lmax; ++t) {
                 while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
-                rc = (splits_h > 1) ? gemm_nt_splitk(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, ww.skbuf, sd)
-                                    : gemm_nt(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, sd);
-                if (rc != ITR_OK) return rc;
+                // (t = 0: h = 0, the recurrence product is b_hh for every caption -- the largest GEMM of the direction is not launched)
+                const bool first = t == 0 && !want_first_gemm;
+                if (!first) {
+                    rc = (splits_h > 1) ? gemm_nt_splitk(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, ww.skbuf, sd)
+                                        : gemm_nt(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, sd);
+                    if (rc != ITR_OK) return rc;
+                }
+                const float *gh_use = first ? bh : ww.gh;
+                const int64_t gh_stride = first ? 0 : (int64_t)3 * D;
                 if (D % 4 == 0)
-                    hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
-                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V, 1, 0);
+                    hipLaunchKernelGGL(gru_gate_kernel<4>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 1024)), dim3(256), 0, sd, ww.gi, gh_use, ww.h,
+                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V, 1, 0, gh_stride);
                 else
-                    hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, sd, ww.gi, ww.gh, ww.h,
-                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V, 1, 0);
+                    hipLaunchKernelGGL(gru_gate_kernel<1>, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, sd, ww.gi, gh_use, ww.h,
+                                       dst, tok_off, len_dev, t, dir, 0, D, n_act, (int64_t)0, (float *)nullptr, gi_ids, V, 1, 0, gh_stride);
                 ITR_CHECK_LAUNCH("gru_gate");
             }
         }

@@ -900,9 +900,11 @@ def gru_encode(tokens_packed, tok_off, lengths, weights, bidirectional, no_txtno
     launch_form: None (default), "paired" or "input_after_fork" -- the bi-GRU launch orders kept as bit-identical cross-checks
     (ITR_GRU_PAIRED_DIRECTIONS / ITR_GRU_INPUT_AFTER_FORK flag bits); "per_token": the input projection as one GEMM row per TOKEN
     even where the call would project the vocabulary once (ITR_GRU_PER_TOKEN_INPUT; >= 2 tokens per vocabulary word) -- the
-    cross-check of that form.  chains: interleaved caption chains of the last-state recurrence (ITR_GRU_CHAINS; 0 = the library's choice)."""
+    cross-check of that form; "first_step_gemm": the recurrence GEMM of step 0 is launched although h = 0 makes it b_hh
+    (ITR_GRU_FIRST_STEP_GEMM), the cross-check of skipping it.  chains: interleaved caption chains of the last-state recurrence (ITR_GRU_CHAINS; 0 = the library's choice)."""
     lib = _lib.load()
-    form_bits = {None: 0, "paired": 4, "input_after_fork": 8, "per_token": 16, "paired+per_token": 20}[launch_form]
+    form_bits = {None: 0, "paired": 4, "input_after_fork": 8, "per_token": 16, "paired+per_token": 20, "first_step_gemm": 256,
+                 "per_token+first_step_gemm": 272}[launch_form]
     tokens_packed = _dev(tokens_packed, torch.int64, "tokens")
     len_host = _host_i32(lengths)
     B = len(len_host)

@@ -141,6 +141,10 @@ int itr_proj_l2norm(const float *x, const float *W, const float *b, float *out, 
  * on its own stream, so that one chain's launches fill the drains of the others (bit-identical for every n).  bits 5-7: n = 1..4;
  * 0 = the library's choice (2 chains from 4 096 captions on). */
 #define ITR_GRU_CHAINS(n) (((n) & 7) << 5)
+/* The first time step of a direction starts from h = 0: W_hh h + b_hh is b_hh itself (a product of zero rows sums to +0 exactly), so
+ * the step's recurrence GEMM -- the largest of the direction, all captions are still running -- is not launched.  bit 8 launches it
+ * anyway (the cross-check; bit-identical). */
+#define ITR_GRU_FIRST_STEP_GEMM 256
 size_t itr_gru_workspace_bytes(int64_t n_tok, int64_t B, int E, int D, int bidirectional);
 int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev,
                 const int32_t *len_host, int64_t B, int64_t n_tok, const float *embed, int64_t V,

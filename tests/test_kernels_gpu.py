@@ -741,7 +741,7 @@ def test_bigru_launch_forms_are_bit_identical(dev, monkeypatch, V, E, D, B, lo, 
     got = ops.gru_encode(toks, off, lengths, wd, True, **kw)
     got_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, **kw)
     # (the second shape has >= 2 tokens per vocabulary word: its default form projects the VOCABULARY once, "per_token" is the cross-check)
-    for form in ("paired", "input_after_fork", "per_token", "paired+per_token"):      # explicit flag bits of itr_gru_fwd (no environment switch)
+    for form in ("paired", "input_after_fork", "per_token", "paired+per_token", "first_step_gemm"):      # explicit flag bits of itr_gru_fwd (no environment switch)
         two = ops.gru_encode(toks, off, lengths, wd, True, launch_form=form, **kw)
         two_last = ops.gru_encode(toks, off, lengths, wd, True, gather_last=True, launch_form=form, **kw)
         assert torch.equal(got, two) and torch.equal(got_last, two_last), form
@@ -775,6 +775,10 @@ def test_gru_vocabulary_table_is_bit_identical(dev, V, E, D, B, bi):
         tab_last = ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True, **kw)
         per_last = ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True, launch_form="per_token", **kw)
         assert torch.equal(tab, per) and torch.equal(tab_last, per_last), kw
+        # the first step's recurrence GEMM (h = 0: its result is b_hh) is skipped by default; launching it changes nothing
+        for form in ("first_step_gemm", "per_token+first_step_gemm"):
+            assert torch.equal(tab, ops.gru_encode(toks, off, lengths, wd, bi, launch_form=form, **kw)), (form, kw)
+            assert torch.equal(tab_last, ops.gru_encode(toks, off, lengths, wd, bi, gather_last=True, launch_form=form, **kw)), (form, kw)
     n = 12
     want, _ = O.encoder_text(ids[:n], lengths[:n], w, bi, False, False, None)
     got = ops.gru_encode(toks, off, lengths, wd, bi)
