@@ -89,4 +89,40 @@ inline void pack_exact_fill(const std::vector<std::vector<int32_t>> &by_size, in
     }
 }
 
+// Best fit decreasing (the planner of rounds 1-4): "best fit" is a bucket lookup on the free capacity.
+inline void pack_best_fit_decreasing(const std::vector<std::vector<int32_t>> &by_size, int cap, int maxn, std::vector<PackBin> &bins) {
+    if (maxn > PACK_MAXN) maxn = PACK_MAXN;
+    const size_t first = bins.size();
+    std::vector<std::vector<int32_t>> open((size_t)cap + 1);      // open[r] = bins (index - first) with r free and < maxn items
+    for (int w = cap; w >= 1; --w)
+        for (int32_t c : by_size[w]) {
+            int r = w;
+            while (r <= cap && open[r].empty()) ++r;
+            int32_t t;
+            if (r <= cap) {
+                t = open[r].back();
+                open[r].pop_back();
+            } else {
+                t = (int32_t)(bins.size() - first);
+                PackBin nb;
+                nb.n = 0;
+                bins.push_back(nb);
+                r = cap;
+            }
+            PackBin &B = bins[first + (size_t)t];
+            B.item[B.n++] = c;
+            if (B.n < maxn && r - w > 0) open[r - w].push_back(t);
+        }
+}
+
+// The planner the two entry points call: exact fill, unless best fit decreasing needs fewer bins (the greedy exact fill is myopic on a
+// few length sets -- lengths drawn from {7, 13, 31, 32, 33, 64}: 1 % more bins; uniform 1..64: 0.1 % -- found by fuzzing both).
+inline void pack_bins(const std::vector<std::vector<int32_t>> &by_size, int cap, int maxn, std::vector<PackBin> &bins) {
+    std::vector<PackBin> a, b;
+    pack_exact_fill(by_size, cap, maxn, a);
+    pack_best_fit_decreasing(by_size, cap, maxn, b);
+    const std::vector<PackBin> &best = b.size() < a.size() ? b : a;
+    bins.insert(bins.end(), best.begin(), best.end());
+}
+
 }  // namespace itr

@@ -911,7 +911,7 @@ extern "C" int itr_scan_plan_tiles(const int32_t *len_host, int64_t Nc, int nt, 
     }
     static_assert(itr::PACK_MAXN == itr::SC_MAXCAP, "planner bins hold SC_MAXCAP captions");
     std::vector<itr::PackBin> tiles;
-    itr::pack_exact_fill(by_len, nt, itr::SC_MAXCAP, tiles);
+    itr::pack_bins(by_len, nt, itr::SC_MAXCAP, tiles);
     int64_t pos = 0;
     for (size_t t = 0; t < tiles.size(); ++t) {
         tile_begin_host[t] = (int32_t)pos;

@@ -1106,7 +1106,7 @@ extern "C" int itr_sgr_plan_node_groups(const int32_t *cap_len_host, int64_t Nc,
                             n - 1, SF_ROWS - 1);
             if (n >= lo && n <= cap_rows) by_n[n].push_back((int32_t)c);
         }
-        pack_exact_fill(by_n, cap_rows, SF_MAXCAP, bins);      // (graphs have >= 2 nodes: a last free row stays free)
+        pack_bins(by_n, cap_rows, SF_MAXCAP, bins);      // (graphs have >= 2 nodes: a last free row stays free)
     }
     int64_t pos = 0;
     for (size_t t = 0; t < bins.size(); ++t) {

@@ -80,6 +80,33 @@ def test_scan_tile_planner():
     assert rc == 0 and list(tb) == [0, 16, 32, 40]
 
 
+def test_scan_tile_planner_is_never_worse_than_best_fit_decreasing():
+    """The exact-fill planner is a greedy and loses to best fit decreasing on a few length sets (found by fuzzing: lengths drawn from
+    {7, 13, 31, 32, 33, 64}: 1 % more tiles): itr_scan_plan_tiles runs both and keeps the better (csrc/pack_plan.h::pack_bins)."""
+    def bfd(lens):
+        open_, tiles = [[] for _ in range(65)], []
+        for w in sorted(lens, reverse=True):
+            r = w
+            while r <= 64 and not open_[r]:
+                r += 1
+            if r <= 64:
+                t = open_[r].pop()
+            else:
+                t = len(tiles)
+                tiles.append(0)
+                r = 64
+            tiles[t] += 1
+            if tiles[t] < 16 and r - w > 0:
+                open_[r - w].append(t)
+        return len(tiles)
+    rng = np.random.RandomState(3)
+    for it in range(40):
+        n = int(rng.randint(1, 2500))
+        lens = (rng.choice([7, 13, 64, 32, 33, 31], size=n) if it % 2 else rng.randint(1, 65, size=n)).astype(np.int64)
+        rc, tb, order = plan(lens)
+        assert rc == 0 and len(tb) - 1 <= bfd(lens.tolist()), (it, n)
+
+
 def test_sgr_node_group_plan():
     """The plan of SGR's fused graph steps (csrc/sgr_fused.hip) is the same planner run on NODE counts (words + the global node):
     whole captions, at most 64 node rows and 16 captions per group, every caption exactly once; the BASELINE length distribution
