@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -108,6 +108,8 @@ SIGNATURES = {
     "itr_transpose2d": (i32, [vp, vp, i64, i64, vp]),
     "itr_colsum_workspace_bytes": (sz, [i64, i64]),
     "itr_colsum": (i32, [vp, vp, i64, i64, i32, vp, sz, vp]),
+    "itr_gemm_tn_workspace_bytes": (sz, [i64, i64, i64]),
+    "itr_gemm_tn": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp, sz, vp]),
     "itr_embed_scatter_add": (i32, [vp, vp, i64, i64, i32, vp, vp]),
     "itr_gather_rows": (i32, [vp, i64, vp, i64, i32, vp, vp, vp]),
     "itr_sq_sum_blocks": (i32, [i64]),

@@ -60,6 +60,20 @@ def _gemm_nt(a, b, out=None, accumulate=False):
     return out
 
 
+def _gemm_tn(a, b, out=None, accumulate=False):
+    """a [R, P]^T . b [R, Q] -> [P, Q]: the weight gradient dY^T X, reduced over the rows in slices (csrc/gemm_tn.hip)."""
+    lib = _lib.load()
+    R, P = a.shape
+    Q = b.shape[1]
+    assert b.shape[0] == R
+    if out is None:
+        out = _f32(P, Q, dev=a.device)
+    wsb = lib.itr_gemm_tn_workspace_bytes(R, P, Q)
+    ws = torch.empty(max(wsb, 1), device=a.device, dtype=torch.uint8)
+    _lib.check(lib.itr_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), R, P, Q, int(accumulate), _p(ws), wsb, _stream()))
+    return out
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -86,7 +100,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _gemm_nt(dy2, transpose2d(w)).reshape(ctx.xshape)        # dy [M, N] . (W^T [K, N])^T
         if ctx.needs_input_grad[1]:
-            dw = _gemm_nt(transpose2d(dy2), transpose2d(x2))             # dy^T [N, M] . (x^T [K, M])^T
+            dw = _gemm_tn(dy2, x2)                                        # dy^T [N, M] . x [M, K], split over the rows
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy2)
         return dx, dw, db
@@ -230,7 +244,7 @@ class _Cosine(torch.autograd.Function):
         im, s = ctx.saved_tensors
         dS = dS.contiguous()
         d_im = _gemm_nt(dS, transpose2d(s)) if ctx.needs_input_grad[0] else None          # dS [Ni, Nc] . s [Nc, D]
-        d_s = _gemm_nt(transpose2d(dS), transpose2d(im)) if ctx.needs_input_grad[1] else None
+        d_s = _gemm_tn(dS, im) if ctx.needs_input_grad[1] else None                       # dS^T [Nc, Ni] . im [Ni, D]
         return d_im, d_s
 
 
@@ -305,7 +319,7 @@ class _ScanT2I(torch.autograd.Function):
         _lib.check(lib.itr_scan_train_bwd(_p(A), ntp, _p(G), _p(enorm), _p(cap_off), _p(cap_len), Bi, Bc, ntp, R, D, max_len, norm,
                                           agg, ls, ll, _p(dS), _p(dA), _p(dGp), _p(denp), _stream()))
         dV = _gemm_nt(dA, transpose2d(Ep))                            # dA [Bi*36, ntp] . E [ntp, D]
-        dE = _gemm_nt(transpose2d(dA), transpose2d(V2))               # dA^T [ntp, Bi*36] . V [Bi*36, D]
+        dE = _gemm_tn(dA, V2)                                         # dA^T [ntp, Bi*36] . V [Bi*36, D]
         den = colsum(denp)
         _lib.check(lib.itr_scan_train_finish(_p(dGp), Bi, Bc, _p(V2), _p(Ep), _p(enorm), _p(den), ntp, R, D, _p(dV), _p(dE), _stream()))
         return dV.reshape(Bi, R, D), dE[:n_tok], None, None, None, None, None, None, None
@@ -367,7 +381,7 @@ class _ScanI2T(torch.autograd.Function):
         _lib.check(lib.itr_scan_train_i2t_bwd(_p(A), ntp, _p(H), _p(h_off), h_total, _p(vnorm), _p(cap_off), _p(cap_len), Bi, Bc, ntp, R, D,
                                               max_len, norm, agg, ls, ll, _p(dS), _p(dA), _p(dHp), _p(dvnp), _stream()))
         dV = _gemm_nt(dA, transpose2d(Ep))
-        dE = _gemm_nt(transpose2d(dA), transpose2d(V2))
+        dE = _gemm_tn(dA, V2)
         dH = colsum(dHp)
         dvn = colsum(dvnp)
         _lib.check(lib.itr_scan_train_i2t_finish(_p(dH), _p(h_off), _p(cap_off), _p(cap_len), Bc, _p(Ep), _p(V2), _p(vnorm), _p(dvn), Bi, R, D,

@@ -377,6 +377,12 @@ int itr_transpose2d(const float *in, float *out, int64_t rows, int64_t cols, itr
 size_t itr_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int itr_colsum(const float *x, float *out, int64_t rows, int64_t cols, int accumulate, void *workspace,
                size_t workspace_bytes, itr_stream_t stream);
+/* Weight gradient of a dense layer, dW = dY^T X:  C[P, Q] (+)= A[R, P]^T B[R, Q] (row-major, the REDUCED index is the row of
+ * both operands: no transposed copies).  The rows are split into slices whose partial products (workspace) are added in slice
+ * order: deterministic.  accumulate != 0 adds to C.  Exact fp32 MFMA (csrc/gemm_tn.hip). */
+size_t itr_gemm_tn_workspace_bytes(int64_t R, int64_t P, int64_t Q);
+int itr_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t R, int64_t P, int64_t Q,
+                int accumulate, void *workspace, size_t workspace_bytes, itr_stream_t stream);
 /* nn.Embedding backward: dE[tokens[r], :] += dx[r, :] (atomic adds). */
 int itr_embed_scatter_add(const int64_t *tokens, const float *dx, int64_t n_tok, int64_t V, int E, float *dE,
                           itr_stream_t stream);

@@ -1,0 +1,61 @@
+"""GPU: the weight-gradient GEMM dW = dY^T X with a split row reduction (csrc/gemm_tn.hip) against a float64 torch reference:
+all three tile sizes, ragged edges (unaligned scalar path), one slice / many slices, accumulate, strided operands, and through
+autograd.linear's backward (the caller: every dense layer of model.train_emb, Models.py:139-144)."""
+import pytest
+import torch
+
+from itr_amd import autograd as ag
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("R,P,Q", [(295000, 32, 32),      # CAMERA's gate layers: one workgroup for 15.8 ms on the NT kernel
+                                   (213000, 256, 1024),   # SGRAF sim_tranloc_w at batch 128
+                                   (4608, 2048, 2048), (229376, 256, 256), (1664, 1024, 1024),
+                                   (5000, 1, 256), (300, 12, 1024), (777, 300, 6), (129, 70, 50), (16, 64, 64), (1, 33, 17), (0, 8, 8)])
+def test_gemm_tn_vs_float64(dev, R, P, Q):
+    torch.manual_seed(R % 997 + P + Q)
+    a = torch.randn(R, P, device=dev)
+    b = torch.randn(R, Q, device=dev)
+    got = ag._gemm_tn(a, b)
+    want = a.double().t() @ b.double()
+    scale = max(1.0, float(R) ** 0.5)
+    assert got.shape == (P, Q)
+    assert float((got.double() - want).abs().max()) <= 2e-5 * scale + 1e-6 * R ** 0.5
+    # accumulate onto an existing matrix; bit-identical partial sums (deterministic slice order)
+    base = torch.randn(P, Q, device=dev)
+    acc = ag._gemm_tn(a, b, out=base.clone(), accumulate=True)
+    assert float((acc.double() - base.double() - want).abs().max()) <= 2e-5 * scale + 1e-6 * R ** 0.5 + 1e-6
+    assert torch.equal(ag._gemm_tn(a, b), got)
+
+
+def test_gemm_tn_strided_operands(dev):
+    torch.manual_seed(3)
+    big_a = torch.randn(3000, 200, device=dev)
+    big_b = torch.randn(3000, 400, device=dev)
+    a, b = big_a[:, 8:136], big_b[:, 100:356]                  # row stride > width, 16-byte aligned start
+    got = ag._gemm_tn(a, b)
+    assert float((got.double() - a.double().t() @ b.double()).abs().max()) <= 2e-3
+    a2, b2 = big_a[:, 3:70], big_b[:, 1:98]                    # unaligned start and ragged widths: the scalar path
+    got2 = ag._gemm_tn(a2, b2)
+    assert float((got2.double() - a2.double().t() @ b2.double()).abs().max()) <= 2e-3
+
+
+@pytest.mark.parametrize("rows,K,N,bias", [(70000, 32, 32, True), (5000, 256, 1, True), (999, 300, 1024, False)])
+def test_linear_backward_uses_the_split_reduction(dev, rows, K, N, bias):
+    torch.manual_seed(rows + K)
+    x = torch.randn(rows, K, device=dev, requires_grad=True)
+    w = (torch.randn(N, K, device=dev) * 0.1).requires_grad_()
+    bv = torch.randn(N, device=dev).requires_grad_() if bias else None
+    y = ag.linear(x, w, bv)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xd, wd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    bd = bv.detach().double().requires_grad_() if bias else None
+    yd = torch.nn.functional.linear(xd, wd, bd)
+    yd.backward(g.double())
+    assert float((y.detach().double() - yd.detach()).abs().max()) <= 1e-4
+    assert float((w.grad.double() - wd.grad).abs().max()) <= 3e-5 * rows ** 0.5
+    assert float((x.grad.double() - xd.grad).abs().max()) <= 1e-4
+    if bias:
+        assert float((bv.grad.double() - bd.grad).abs().max()) <= 3e-5 * rows ** 0.5
