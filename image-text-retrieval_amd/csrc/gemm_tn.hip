@@ -22,7 +22,7 @@ constexpr int TN_MAXSLICES = 512;
 template <int WM, bool ALIGNED>
 __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
                                                              float *__restrict__ out, int64_t ldo, int64_t slice_stride, int64_t R, int P, int Q,
-                                                             int64_t rows_per_slice) {
+                                                             int64_t rows_per_slice, int64_t batch_a, int64_t batch_b, int64_t batch_o) {
     constexpr int T = 32 * WM;           // tile extent in both output dimensions: 2 x 2 waves of WM x WM MFMA tiles
     constexpr int LD = T + 16;           // LDS row stride: the four k rows of an operand read land on four different 16-bank groups
     constexpr int NV = 4 * T;            // float4 per operand and chunk
@@ -31,6 +31,9 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const float *__rest
     __shared__ __attribute__((aligned(16))) float Bs[2][TN_RK][LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave >> 1, wq = wave & 1;
+    A += (int64_t)blockIdx.z * batch_a;          // batched form (one problem per blockIdx.z, a single slice each)
+    B += (int64_t)blockIdx.z * batch_b;
+    out += (int64_t)blockIdx.z * batch_o;
     const int tiles_q = (Q + T - 1) / T;
     const int p0 = (int)(blockIdx.x / tiles_q) * T, q0 = (int)(blockIdx.x % tiles_q) * T;
     const int64_t r_begin = (int64_t)blockIdx.y * rows_per_slice;
@@ -163,11 +166,11 @@ size_t gemm_tn_workspace_bytes(int64_t R, int P, int Q) {
 
 template <int WM>
 static void tn_launch(bool aligned, dim3 grid, hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, float *out, int64_t ldo,
-                      int64_t slice_stride, int64_t R, int P, int Q, int64_t rps) {
+                      int64_t slice_stride, int64_t R, int P, int Q, int64_t rps, int64_t ba = 0, int64_t bb = 0, int64_t bo = 0) {
     if (aligned)
-        hipLaunchKernelGGL((gemm_tn_kernel<WM, true>), grid, dim3(TN_THREADS), 0, st, A, lda, B, ldb, out, ldo, slice_stride, R, P, Q, rps);
+        hipLaunchKernelGGL((gemm_tn_kernel<WM, true>), grid, dim3(TN_THREADS), 0, st, A, lda, B, ldb, out, ldo, slice_stride, R, P, Q, rps, ba, bb, bo);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<WM, false>), grid, dim3(TN_THREADS), 0, st, A, lda, B, ldb, out, ldo, slice_stride, R, P, Q, rps);
+        hipLaunchKernelGGL((gemm_tn_kernel<WM, false>), grid, dim3(TN_THREADS), 0, st, A, lda, B, ldb, out, ldo, slice_stride, R, P, Q, rps, ba, bb, bo);
 }
 
 int gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t R, int P, int Q, int accumulate,
@@ -197,7 +200,31 @@ int gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, 
     return ITR_OK;
 }
 
+// `batch` independent problems of one shape in one launch, each reduced by a single workgroup row (no slices): C_z = A_z^T B_z.
+int gemm_tn_batched(const float *A, int64_t lda, int64_t batch_a, const float *B, int64_t ldb, int64_t batch_b, float *C, int64_t ldc, int64_t batch_c,
+                    int64_t R, int P, int Q, int batch, hipStream_t st) {
+    const int T = tn_tile(P, Q);
+    const bool aligned = lda % 4 == 0 && ldb % 4 == 0 && P % 4 == 0 && Q % 4 == 0 && batch_a % 4 == 0 && batch_b % 4 == 0 &&
+                         (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+    const int64_t rps = R > 0 ? ceil_div(R, (int64_t)TN_RK) * TN_RK : TN_RK;
+    const dim3 grid((unsigned)(ceil_div(P, T) * ceil_div(Q, T)), 1, (unsigned)batch);
+    if (T == 128) tn_launch<4>(aligned, grid, st, A, lda, B, ldb, C, ldc, 0, R, P, Q, rps, batch_a, batch_b, batch_c);
+    else if (T == 64) tn_launch<2>(aligned, grid, st, A, lda, B, ldb, C, ldc, 0, R, P, Q, rps, batch_a, batch_b, batch_c);
+    else tn_launch<1>(aligned, grid, st, A, lda, B, ldb, C, ldc, 0, R, P, Q, rps, batch_a, batch_b, batch_c);
+    ITR_CHECK_LAUNCH("gemm_tn_batched");
+    return ITR_OK;
+}
+
 }  // namespace itr
+
+extern "C" int itr_gemm_tn_batched(const float *A, int64_t lda, int64_t batch_a, const float *B, int64_t ldb, int64_t batch_b, float *C, int64_t ldc,
+                                   int64_t batch_c, int64_t R, int64_t P, int64_t Q, int64_t batch, itr_stream_t stream) {
+    ITR_REQUIRE(R >= 0 && P >= 0 && Q >= 0 && P <= 0x3fffffff && Q <= 0x3fffffff && batch >= 0 && batch <= 65535, "itr_gemm_tn_batched: bad shape");
+    if (P == 0 || Q == 0 || batch == 0) return ITR_OK;
+    ITR_REQUIRE(C && (R == 0 || (A && B)), "itr_gemm_tn_batched: null pointer");
+    ITR_REQUIRE(lda >= P && ldb >= Q && ldc >= Q, "itr_gemm_tn_batched: leading dimension smaller than row");
+    return itr::gemm_tn_batched(A, lda, batch_a, B, ldb, batch_b, C, ldc, batch_c, R, (int)P, (int)Q, (int)batch, itr::as_stream(stream));
+}
 
 extern "C" size_t itr_gemm_tn_workspace_bytes(int64_t R, int64_t P, int64_t Q) {
     if (R < 0 || P < 1 || Q < 1 || P > 0x3fffffff || Q > 0x3fffffff) return 0;

@@ -20,7 +20,6 @@
 namespace itr {
 
 int allow_dynamic_lds(const void *kernel, size_t bytes);      // scan_train.hip
-int gemm_tn_sum_slices(const float *part, int nsl, int64_t n, float *out, hipStream_t st);      // below
 
 __device__ __forceinline__ float block_sum_256(float v, float *red4) {       // red4: 4 floats of LDS; all 256 threads call
     v = wave_sum(v);
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(256) void sgt_ctx_fwd_kernel(const float *__restric
     float4 *X4 = reinterpret_cast<float4 *>(X);
 #pragma unroll
     for (int i = 0; i < SGT_TW; ++i) {
-        if (i >= nt) break;
+        if (i >= nt) continue;
         const float n = sqrtf(red[i * 4] + red[i * 4 + 1] + red[i * 4 + 2] + red[i * 4 + 3]);
         if (tid == 0) cnorm[(int64_t)b * T + t0 + i] = n;
         const float ne = n + eps;
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(256) void sgt_ctx_bwd_kernel(const float *__restric
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < SGT_TB; ++i) {
-            if (i >= nt) break;
+            if (i >= nt) continue;
             const float n = cnorm[(int64_t)b * T + t0 + i], ne = n + eps;
             const float sd = red[i * 4] + red[i * 4 + 1] + red[i * 4 + 2] + red[i * 4 + 3];
             const float coef = n > 0.f ? sd / (n * ne * ne) : 0.f;
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(256) void sgt_ctx_bwd_kernel(const float *__restric
     float4 *dwp = reinterpret_cast<float4 *>(dwpart) + (int64_t)blockIdx.y * T * D4;
 #pragma unroll
     for (int i = 0; i < SGT_TB; ++i) {
-        if (i >= nt) break;
+        if (i >= nt) continue;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const int col = tid + v * 256;
@@ -636,22 +635,23 @@ __global__ __launch_bounds__(256) void sgt_saf_pool_bwd_kernel(const float *__re
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// K10 / K11  TextSA on packed captions (Fusionmodule.py:549-564): the caption mean, and softmax(logits over the words of a caption) . words
-__global__ __launch_bounds__(256) void sgt_seg_mean_fwd_kernel(const float *__restrict__ words, const int32_t *__restrict__ cap_off, int D,
+// K10 / K11  TextSA on packed captions (Fusionmodule.py:549-564): the caption mean (or sum) and its transpose -- one caption row spread over
+//     the caption's words (the g_emb.repeat of :556, no atomics) --, and softmax(logits over the words of a caption) . words
+__global__ __launch_bounds__(256) void sgt_seg_mean_fwd_kernel(const float *__restrict__ words, const int32_t *__restrict__ cap_off, int D, int mean,
                                                                float *__restrict__ out) {
     const int c = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
     if (d >= D) return;
     const int off = cap_off[c], W = cap_off[c + 1] - off;
     float s = 0.f;
     for (int w = 0; w < W; ++w) s += words[(int64_t)(off + w) * D + d];
-    out[(int64_t)c * D + d] = s / W;
+    out[(int64_t)c * D + d] = mean ? s / W : s;
 }
-__global__ __launch_bounds__(256) void sgt_seg_mean_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ cap_off, int D,
+__global__ __launch_bounds__(256) void sgt_seg_mean_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ cap_off, int D, int mean,
                                                                float *__restrict__ dwords) {
     const int c = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
     if (d >= D) return;
     const int off = cap_off[c], W = cap_off[c + 1] - off;
-    const float v = dout[(int64_t)c * D + d] / W;
+    const float v = mean ? dout[(int64_t)c * D + d] / W : dout[(int64_t)c * D + d];
     for (int w = 0; w < W; ++w) dwords[(int64_t)(off + w) * D + d] = v;
 }
 __global__ __launch_bounds__(256) void sgt_seg_smry_fwd_kernel(const float *__restrict__ logit, const float *__restrict__ words,
@@ -931,13 +931,13 @@ extern "C" int itr_sgt_saf_pool_bwd(const float *y, const float *nodes, const fl
     return ITR_OK;
 }
 
-extern "C" int itr_sgt_seg_mean(const float *in, const int32_t *cap_off, int C, int D, float *out, int backward, itr_stream_t stream) {
+extern "C" int itr_sgt_seg_mean(const float *in, const int32_t *cap_off, int C, int D, float *out, int spread, int mean, itr_stream_t stream) {
     SGT_SHAPE(C >= 0 && C <= 65535 && D >= 1, "itr_sgt_seg_mean");
     if (C == 0) return ITR_OK;
     ITR_REQUIRE(in && cap_off && out, "itr_sgt_seg_mean: null pointer");
     const dim3 grid((unsigned)ceil_div(D, 256), (unsigned)C);
-    if (backward) hipLaunchKernelGGL(sgt_seg_mean_bwd_kernel, grid, dim3(256), 0, as_stream(stream), in, cap_off, D, out);
-    else hipLaunchKernelGGL(sgt_seg_mean_fwd_kernel, grid, dim3(256), 0, as_stream(stream), in, cap_off, D, out);
+    if (spread) hipLaunchKernelGGL(sgt_seg_mean_bwd_kernel, grid, dim3(256), 0, as_stream(stream), in, cap_off, D, mean, out);
+    else hipLaunchKernelGGL(sgt_seg_mean_fwd_kernel, grid, dim3(256), 0, as_stream(stream), in, cap_off, D, mean, out);
     ITR_CHECK_LAUNCH("sgt_seg_mean");
     return ITR_OK;
 }

@@ -110,6 +110,25 @@ SIGNATURES = {
     "itr_colsum": (i32, [vp, vp, i64, i64, i32, vp, sz, vp]),
     "itr_gemm_tn_workspace_bytes": (sz, [i64, i64, i64]),
     "itr_gemm_tn": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp, sz, vp]),
+    "itr_gemm_tn_batched": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp]),
+    "itr_sgt_attn_fwd": (i32, [vp, i64, vp, i32, i32, i32, i32, i32, f32, f32, vp, vp]),
+    "itr_sgt_attn_bwd": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp, vp]),
+    "itr_sgt_ctx_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
+    "itr_sgt_ctx_bwd_workspace_bytes": (sz, [i32, i32, i32]),
+    "itr_sgt_ctx_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, sz, vp]),
+    "itr_sgt_dp": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+    "itr_sgt_pair_sqdiff_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "itr_sgt_pair_sqdiff_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "itr_sgt_nodes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "itr_sgt_graph_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "itr_sgt_graph_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "itr_sgt_segbn_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp]),
+    "itr_sgt_segbn_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "itr_sgt_saf_pool_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]),
+    "itr_sgt_saf_pool_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
+    "itr_sgt_seg_mean": (i32, [vp, vp, i32, i32, vp, i32, i32, vp]),
+    "itr_sgt_seg_smry_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "itr_sgt_seg_smry_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "itr_embed_scatter_add": (i32, [vp, vp, i64, i64, i32, vp, vp]),
     "itr_gather_rows": (i32, [vp, i64, vp, i64, i32, vp, vp, vp]),
     "itr_sq_sum_blocks": (i32, [i64]),

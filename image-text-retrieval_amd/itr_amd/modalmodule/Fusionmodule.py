@@ -116,12 +116,10 @@ class EncoderSimilarity(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Training-mode forward of EncoderSimilarity on the autograd tape (SGRAF.train_emb).  Unlike the fused evaluation kernels
-# (csrc/sgraf*.hip) this follows the reference's own structure -- a loop over the captions of the batch (Fusionmodule.py:415-447)
-# -- because training mode is per-caption by construction: TextSA and AttentionFiltration see one caption at a time, and
-# AttentionFiltration's BatchNorm1d(1) takes its batch statistics (and updates its running statistics) once per caption.
-# Every dense contraction is a HIP kernel (MFMA GEMM, the small batched products, the softmax-weighted sums); the remaining
-# elementwise glue of this training-only path ((a - b)^2, the l1 normalisation, concatenations) are torch ops on the tape.
+# Training-mode forward of EncoderSimilarity on the autograd tape (SGRAF.train_emb).  Training mode is per-caption by construction in
+# the reference (a loop over the captions of the batch, Fusionmodule.py:415-447: TextSA and AttentionFiltration see one caption at a
+# time, and AttentionFiltration's BatchNorm1d(1) takes its batch statistics once per caption).  encoder_similarity_train_batched keeps
+# those semantics on ragged whole-batch kernels; encoder_similarity_train_grouped is the loop itself, shared between equal lengths.
 def _seq_linear(x2d, seq, idx=0):
     from .. import autograd as ag
     return ag.linear(x2d, seq[idx].weight, seq[idx].bias)
@@ -215,10 +213,66 @@ def _saf_train(saf, x, G, training):
     return ag.l2norm_rows(sim_saf, eps=1e-8)
 
 
-def encoder_similarity_train(sim_enc, img_emb, words, tok_off, lens, seeds, training=True, max_group=32, seeds_global=None):
+def encoder_similarity_train(sim_enc, img_emb, words, tok_off, lens, seeds, training=True, max_group=32, seeds_global=None, batched=None):
     """EncoderSimilarity.forward in training mode: img_emb [B, 36, D], packed word embeddings words [n_tok, D] with caption c at
-    rows tok_off[c] .. tok_off[c] + lens[c] -> sims [B, n_caption].  Consecutive captions of the same length (collate_fn sorts by
-    length) are processed as one group: the arithmetic per caption is the reference's, the launches are shared."""
+    rows tok_off[c] .. tok_off[c] + lens[c] -> sims [B, n_caption].  All pairs at once on the ragged kernels of csrc/sgraf_train.hip
+    (encoder_similarity_train_batched); shapes those do not take (captions of more than 96 words, D > 2048 ...) and `batched=False`
+    (the cross-check of the tests) run the grouped restatement of the reference's per-caption loop below."""
+    from .. import sgraf_train as sgt
+    lens = [int(x) for x in lens]
+    packed = bool(np.array_equal(np.asarray(tok_off, dtype=np.int64)[:len(lens)], np.concatenate([[0], np.cumsum(lens)[:-1]]))) and \
+        words.shape[0] == int(np.sum(lens))
+    ok = packed and training and sgt.supported(img_emb.shape[2], img_emb.shape[1], sim_enc.sim_eval_w.in_features, lens)
+    if batched is None:
+        batched = ok
+    if batched:
+        if not ok:
+            raise NotImplementedError("encoder_similarity_train: this batch does not fit the batched kernels (csrc/sgraf_train.hip)")
+        return encoder_similarity_train_batched(sim_enc, img_emb, words, lens, seeds, seeds_global)
+    return encoder_similarity_train_grouped(sim_enc, img_emb, words, tok_off, lens, seeds, training, max_group, seeds_global)
+
+
+def encoder_similarity_train_batched(sim_enc, img_emb, words, lens, seeds, seeds_global=None):
+    """Training-mode EncoderSimilarity.forward (Fusionmodule.py:406-451) for ALL B x C pairs in one pass: image-major ragged matrices
+    (itr_amd/sgraf_train.py), one launch per stage, the dense layers as whole-batch GEMMs.  Same arithmetic per pair as the reference's
+    per-caption loop; AttentionFiltration's BatchNorm1d(1) keeps its per-caption batch statistics and running-statistic updates."""
+    from .. import autograd as ag
+    from .. import sgraf_train as sgt
+    B, R, D = img_emb.shape
+    lay = sgt.Layout(lens, img_emb.device)
+    C = lay.C
+    img_glo = _sa_train(sim_enc.v_global_w, img_emb, ag.mean_mid(img_emb), seeds_global or seeds, True)            # (B, D)
+    # TextSA on the packed captions (Fusionmodule.py:549-564)
+    t = sim_enc.t_global_w
+    p = float(t.embedding_local[-1].p)
+    le = ag.dropout(ag.act(_seq_linear(words, t.embedding_local), 'tanh'), p, seeds, True)                          # (T, D)
+    ge = ag.dropout(ag.act(_seq_linear(sgt.seg_mean(words, lay), t.embedding_global), 'tanh'), p, seeds, True)      # (C, D)
+    logit = _seq_linear(ag.mul(le, sgt.seg_spread(ge, lay)), t.embedding_common).reshape(-1)                        # (T,)
+    cap_glo = ag.l2norm_rows(sgt.seg_smry(logit, words, lay), eps=1e-8)                                              # (C, D)
+    # local alignments: attention of every word over the regions of every image, context, squared difference (:421-427)
+    A = ag.cosine_scores(img_emb.reshape(B * R, D), words)                                                           # (B R, T)
+    X = sgt.loc_ctx(sgt.loc_attn(A, lay, B, R, 9.0), img_emb, words)                                                 # (B T, D)
+    sim_loc = ag.l2norm_rows(ag.linear(X, sim_enc.sim_tranloc_w.weight, sim_enc.sim_tranloc_w.bias), eps=1e-8)
+    sim_glo = ag.l2norm_rows(ag.linear(sgt.pair_sqdiff(img_glo, cap_glo), sim_enc.sim_tranglo_w.weight, sim_enc.sim_tranglo_w.bias), eps=1e-8)
+    nodes = sgt.assemble_nodes(sim_glo, sim_loc, lay, B)                                                             # (B (T + C), S)
+    if sim_enc.module_name == 'SGR':
+        for gr in sim_enc.SGR_module:
+            q = ag.linear(nodes, gr.graph_query_w.weight, gr.graph_query_w.bias)
+            k = ag.linear(nodes, gr.graph_key_w.weight, gr.graph_key_w.bias)
+            nodes = ag.act(ag.linear(sgt.graph_attn(q, k, nodes, lay, B), gr.sim_graph_w.weight, gr.sim_graph_w.bias), 'relu')
+        sim_vec = ag.gather_rows(nodes, lay.node0_rows(B))                                                           # node 0 of every pair
+    else:
+        saf = sim_enc.SAF_module
+        a = ag.linear(nodes, saf.attn_sim_w.weight, saf.attn_sim_w.bias).reshape(-1)
+        sim_vec = ag.l2norm_rows(sgt.saf_pool(sgt.seg_bn_train(a, saf.bn, lay, B), nodes, lay, B), eps=1e-8)
+    sims = ag.act(ag.linear(sim_vec, sim_enc.sim_eval_w.weight, sim_enc.sim_eval_w.bias), 'sigmoid')               # (B C, 1)
+    return sims.view(B, C)
+
+
+def encoder_similarity_train_grouped(sim_enc, img_emb, words, tok_off, lens, seeds, training=True, max_group=32, seeds_global=None):
+    """The reference's per-caption loop on the tape: consecutive captions of the same length (collate_fn sorts by length) are
+    processed as one group -- the arithmetic per caption is the reference's, the launches are shared.  Rounds 1-5 trained through
+    this (85 / 224 ms per 128 x 128 step); it stays as the path for shapes the batched kernels do not take and as their cross-check."""
     from .. import autograd as ag
     B, R, D = img_emb.shape
     # (data parallel: every rank computes the global image vectors of the whole batch, with the same dropout masks -- seeds_global)

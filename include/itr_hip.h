@@ -383,6 +383,59 @@ int itr_colsum(const float *x, float *out, int64_t rows, int64_t cols, int accum
 size_t itr_gemm_tn_workspace_bytes(int64_t R, int64_t P, int64_t Q);
 int itr_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t R, int64_t P, int64_t Q,
                 int accumulate, void *workspace, size_t workspace_bytes, itr_stream_t stream);
+/* `batch` problems of one shape in one launch (operand z at A + z batch_a ...), each C_z = A_z^T B_z reduced in one pass. */
+int itr_gemm_tn_batched(const float *A, int64_t lda, int64_t batch_a, const float *B, int64_t ldb, int64_t batch_b, float *C, int64_t ldc,
+                        int64_t batch_c, int64_t R, int64_t P, int64_t Q, int64_t batch, itr_stream_t stream);
+
+/* ---- a7 / a14: SGRAF.train_emb's similarity module on ALL pairs of the batch at once (EncoderSimilarity.forward in training mode and its
+ * backward: itr/modalmodule/Fusionmodule.py:406-451, SCAN_attention :632-664, GraphReasoning :579-586, AttentionFiltration :613-618,
+ * TextSA :549-564; caller Models.py:518-546).  Ragged IMAGE-MAJOR matrices over B images and C captions with T words in total
+ * (cap_off[C + 1] = int32 word offsets, device):
+ *   local rows b T + t;   node rows b (T + C) + cap_off[c] + c + j (j = 0 the global alignment, 1 .. W_c the words);   pair rows b C + c.
+ * The dense layers between these stages are itr_gemm_nt / itr_gemm_tn; csrc/sgraf_train.hip holds the stages themselves:
+ *   attn    P[(b,t), r] = softmax_r(smooth * l2norm_w(LeakyReLU_0.1(A[(b,r), t])))      A [B R, ldA] = regions . words^T
+ *   ctx     X[(b,t), :] = (l2norm(sum_r P r img[b,r,:]) - words[t,:])^2,  cnorm = the context norms;  backward: d ctx [B T, D], d words
+ *           (summed over the images; workspace = itr_sgt_ctx_bwd_workspace_bytes), then d P = itr_sgt_dp and d regions = itr_gemm_tn_batched
+ *   pair_sqdiff  X[(b,c), :] = (img_glo[b] - cap_glo[c])^2
+ *   nodes   scatter of the global / local alignment rows into the node matrix (backward != 0: the inverse copy)
+ *   graph   E = softmax_r(q_v . k_r), Z_v = sum_r E[v,r] x_r per pair; E saved at b e_off[C] + e_off[c] (e_off = prefix sums of n_c^2)
+ *   segbn   BatchNorm1d(1) with the batch statistics of ONE caption's B (W_c + 1) attention logits (the reference calls it per caption)
+ *   saf_pool  sigmoid -> l1norm over the nodes of a pair -> weighted node sum
+ *   seg_mean / seg_smry  caption mean; softmax(logit over the words of a caption) . words      (TextSA on packed captions)
+ * Limits (ITR_ERR_UNSUPPORTED beyond; the caller then takes the grouped path): D % 4 == 0, D <= 2048, R <= 64, S % 4 == 0, LDS per pair. */
+int itr_sgt_attn_fwd(const float *A, int64_t ldA, const int32_t *cap_off, int B, int C, int T, int R, int Wmax, float smooth, float eps,
+                     float *P, itr_stream_t stream);
+int itr_sgt_attn_bwd(const float *A, int64_t ldA, const float *P, const float *dP, const int32_t *cap_off, int B, int C, int T, int R,
+                     int Wmax, float smooth, float eps, float *dA, itr_stream_t stream);
+int itr_sgt_ctx_fwd(const float *P, const float *img, const float *words, int B, int T, int R, int D, float eps, float *X, float *cnorm,
+                    itr_stream_t stream);
+size_t itr_sgt_ctx_bwd_workspace_bytes(int B, int T, int D);
+int itr_sgt_ctx_bwd(const float *P, const float *img, const float *words, const float *cnorm, const float *dX, int B, int T, int R, int D,
+                    float eps, float *dctx, float *dwords, void *workspace, size_t workspace_bytes, itr_stream_t stream);
+int itr_sgt_dp(const float *dctx, const float *img, int B, int T, int R, int D, float *dP, itr_stream_t stream);
+int itr_sgt_pair_sqdiff_fwd(const float *img_glo, const float *cap_glo, int B, int C, int D, float *X, itr_stream_t stream);
+int itr_sgt_pair_sqdiff_bwd(const float *img_glo, const float *cap_glo, const float *dX, int B, int C, int D, float *dimg_glo,
+                            float *dcap_glo, itr_stream_t stream);
+int itr_sgt_nodes(float *glo, float *loc, float *nodes, const int32_t *cap_off, const int32_t *node_cap, int B, int C, int T, int S,
+                  int backward, itr_stream_t stream);
+int itr_sgt_graph_fwd(const float *q, const float *k, const float *x, const int32_t *cap_off, const int32_t *e_off, int B, int C, int T, int S,
+                      int nmax, float *E, float *Z, itr_stream_t stream);
+int itr_sgt_graph_bwd(const float *q, const float *k, const float *x, const float *E, const float *dZ, const int32_t *cap_off,
+                      const int32_t *e_off, int B, int C, int T, int S, int nmax, float *dq, float *dk, float *dx, itr_stream_t stream);
+int itr_sgt_segbn_fwd(const float *a, const int32_t *cap_off, int B, int C, int T, const float *gamma, const float *beta, float eps, float *y,
+                      float *mean, float *var, float *invstd, itr_stream_t stream);
+int itr_sgt_segbn_bwd(const float *dy, const float *a, const int32_t *cap_off, int B, int C, int T, const float *gamma, const float *mean,
+                      const float *invstd, float *da, float *dgamma_c, float *dbeta_c, itr_stream_t stream);
+int itr_sgt_saf_pool_fwd(const float *y, const float *nodes, const int32_t *cap_off, int B, int C, int T, int S, int nmax, float eps, float *out,
+                         itr_stream_t stream);
+int itr_sgt_saf_pool_bwd(const float *y, const float *nodes, const float *dout, const int32_t *cap_off, int B, int C, int T, int S, int nmax,
+                         float eps, float *dy, float *dnodes, itr_stream_t stream);
+/* spread == 0: out[c] = sum (mean != 0: mean) of the caption's rows of in [T, D]; spread != 0: out[t] = in[caption of t] (/ W_c if mean) */
+int itr_sgt_seg_mean(const float *in, const int32_t *cap_off, int C, int D, float *out, int spread, int mean, itr_stream_t stream);
+int itr_sgt_seg_smry_fwd(const float *logit, const float *words, const int32_t *cap_off, int C, int D, int Wmax, float *p, float *out,
+                         itr_stream_t stream);
+int itr_sgt_seg_smry_bwd(const float *p, const float *words, const float *dout, const int32_t *cap_off, int C, int D, int Wmax, float *dlogit,
+                         float *dwords, itr_stream_t stream);
 /* nn.Embedding backward: dE[tokens[r], :] += dx[r, :] (atomic adds). */
 int itr_embed_scatter_add(const int64_t *tokens, const float *dx, int64_t n_tok, int64_t V, int E, float *dE,
                           itr_stream_t stream);
