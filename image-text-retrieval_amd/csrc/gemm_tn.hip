@@ -22,7 +22,8 @@ constexpr int TN_MAXSLICES = 512;
 template <int WM, bool ALIGNED>
 __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
                                                              float *__restrict__ out, int64_t ldo, int64_t slice_stride, int64_t R, int P, int Q,
-                                                             int64_t rows_per_slice, int64_t batch_a, int64_t batch_b, int64_t batch_o) {
+                                                             int64_t rows_per_slice, int64_t batch_a, int64_t batch_b, int64_t batch_o,
+                                                             float *__restrict__ colsum) {
     constexpr int T = 32 * WM;           // tile extent in both output dimensions: 2 x 2 waves of WM x WM MFMA tiles
     constexpr int LD = T + 16;           // LDS row stride: the four k rows of an operand read land on four different 16-bank groups
     constexpr int NV = 4 * T;            // float4 per operand and chunk
@@ -45,6 +46,10 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const float *__rest
 #pragma unroll
         for (int j = 0; j < WM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // optional bias gradient: the column sums of A (db = sum_r dY[r, :]) ride along in the workgroups of the first column tile -- a thread
+    // always loads the same four columns (256 % (T / 4) == 0), so it sums what it loads and the workgroup folds the 16 row slots at the end
+    const bool do_cs = colsum != nullptr && q0 == 0;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 ra[NL], rb[NL];
     auto fetch = [&](int64_t r0) {
 #pragma unroll
@@ -72,6 +77,7 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const float *__rest
                     }
                 }
             }
+            if (do_cs) { cs.x += ra[l].x; cs.y += ra[l].y; cs.z += ra[l].z; cs.w += ra[l].w; }
         }
     };
     auto park = [&](int buf) {
@@ -110,6 +116,16 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const float *__rest
             if (more) park(buf ^ 1);
             __syncthreads();
             buf ^= 1;
+        }
+    }
+    if (do_cs) {          // (the last __syncthreads of the loop has passed: the operand buffers are free)
+        float *red = &As[0][0][0];
+        *reinterpret_cast<float4 *>(red + tid * 4) = cs;
+        __syncthreads();
+        if (tid < T && p0 + tid < P) {
+            float t = 0.f;
+            for (int j = tid >> 2; j < TN_THREADS; j += T / 4) t += red[j * 4 + (tid & 3)];
+            colsum[(int64_t)blockIdx.y * P + p0 + tid] = t;
         }
     }
     float *o = out + (int64_t)blockIdx.y * slice_stride;
@@ -161,40 +177,44 @@ size_t gemm_tn_workspace_bytes(int64_t R, int P, int Q) {
     int T, nsl;
     int64_t rps;
     tn_plan(R, P, Q, &T, &nsl, &rps);
-    return (size_t)nsl * P * Q * sizeof(float);      // (one slice: needed only when accumulating)
+    return (size_t)nsl * P * ((size_t)Q + 1) * sizeof(float);      // partial products + partial column sums
 }
 
 template <int WM>
 static void tn_launch(bool aligned, dim3 grid, hipStream_t st, const float *A, int64_t lda, const float *B, int64_t ldb, float *out, int64_t ldo,
-                      int64_t slice_stride, int64_t R, int P, int Q, int64_t rps, int64_t ba = 0, int64_t bb = 0, int64_t bo = 0) {
+                      int64_t slice_stride, int64_t R, int P, int Q, int64_t rps, int64_t ba = 0, int64_t bb = 0, int64_t bo = 0, float *cs = nullptr) {
     if (aligned)
-        hipLaunchKernelGGL((gemm_tn_kernel<WM, true>), grid, dim3(TN_THREADS), 0, st, A, lda, B, ldb, out, ldo, slice_stride, R, P, Q, rps, ba, bb, bo);
+        hipLaunchKernelGGL((gemm_tn_kernel<WM, true>), grid, dim3(TN_THREADS), 0, st, A, lda, B, ldb, out, ldo, slice_stride, R, P, Q, rps, ba, bb, bo, cs);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<WM, false>), grid, dim3(TN_THREADS), 0, st, A, lda, B, ldb, out, ldo, slice_stride, R, P, Q, rps, ba, bb, bo);
+        hipLaunchKernelGGL((gemm_tn_kernel<WM, false>), grid, dim3(TN_THREADS), 0, st, A, lda, B, ldb, out, ldo, slice_stride, R, P, Q, rps, ba, bb, bo, cs);
 }
 
 int gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t R, int P, int Q, int accumulate,
-            void *workspace, size_t workspace_bytes, hipStream_t st) {
+            float *colsum_a, void *workspace, size_t workspace_bytes, hipStream_t st) {
     int T, nsl;
     int64_t rps;
     tn_plan(R, P, Q, &T, &nsl, &rps);
     const bool aligned = lda % 4 == 0 && ldb % 4 == 0 && P % 4 == 0 && Q % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(B) & 15) == 0;
     const bool direct = nsl == 1 && !accumulate;
-    if (!direct && workspace_bytes < (size_t)nsl * P * Q * sizeof(float)) {
-        set_error("gemm_tn: workspace of %zu bytes, %zu needed (itr_gemm_tn_workspace_bytes)", workspace_bytes, (size_t)nsl * P * Q * sizeof(float));
+    if (!direct && workspace_bytes < (size_t)nsl * P * ((size_t)Q + 1) * sizeof(float)) {
+        set_error("gemm_tn: workspace of %zu bytes, %zu needed (itr_gemm_tn_workspace_bytes)", workspace_bytes, (size_t)nsl * P * ((size_t)Q + 1) * sizeof(float));
         return ITR_ERR_BADARG;
     }
     float *out = direct ? C : static_cast<float *>(workspace);
+    float *cs = !colsum_a ? nullptr : (direct ? colsum_a : static_cast<float *>(workspace) + (size_t)nsl * P * Q);
     const int64_t ldo = direct ? ldc : Q;
     const dim3 grid((unsigned)(ceil_div(P, T) * ceil_div(Q, T)), (unsigned)nsl);
-    if (T == 128) tn_launch<4>(aligned, grid, st, A, lda, B, ldb, out, ldo, (int64_t)P * Q, R, P, Q, rps);
-    else if (T == 64) tn_launch<2>(aligned, grid, st, A, lda, B, ldb, out, ldo, (int64_t)P * Q, R, P, Q, rps);
-    else tn_launch<1>(aligned, grid, st, A, lda, B, ldb, out, ldo, (int64_t)P * Q, R, P, Q, rps);
+    if (T == 128) tn_launch<4>(aligned, grid, st, A, lda, B, ldb, out, ldo, (int64_t)P * Q, R, P, Q, rps, 0, 0, 0, cs);
+    else if (T == 64) tn_launch<2>(aligned, grid, st, A, lda, B, ldb, out, ldo, (int64_t)P * Q, R, P, Q, rps, 0, 0, 0, cs);
+    else tn_launch<1>(aligned, grid, st, A, lda, B, ldb, out, ldo, (int64_t)P * Q, R, P, Q, rps, 0, 0, 0, cs);
     ITR_CHECK_LAUNCH("gemm_tn");
     if (!direct) {
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div((int64_t)P * Q, (int64_t)256)), dim3(256), 0, st, (const float *)out, nsl, P, Q,
                            C, ldc, accumulate);
+        if (cs)
+            hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div((int64_t)P, (int64_t)256)), dim3(256), 0, st, (const float *)cs, nsl, 1, P,
+                               colsum_a, (int64_t)P, 0);
         ITR_CHECK_LAUNCH("gemm_tn_reduce");
     }
     return ITR_OK;
@@ -232,11 +252,11 @@ extern "C" size_t itr_gemm_tn_workspace_bytes(int64_t R, int64_t P, int64_t Q) {
 }
 
 extern "C" int itr_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t R, int64_t P, int64_t Q,
-                           int accumulate, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
+                           int accumulate, float *colsum_a, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
     ITR_REQUIRE(R >= 0 && P >= 0 && Q >= 0 && P <= 0x3fffffff && Q <= 0x3fffffff, "itr_gemm_tn: bad shape");
     if (P == 0 || Q == 0) return ITR_OK;
     ITR_REQUIRE(C && (R == 0 || (A && B)), "itr_gemm_tn: null pointer");
     ITR_REQUIRE(lda >= P && ldb >= Q && ldc >= Q, "itr_gemm_tn: leading dimension smaller than row");
     ITR_REQUIRE(P * Q <= (int64_t)0x7fffffff * 256, "itr_gemm_tn: output too large");
-    return itr::gemm_tn(A, lda, B, ldb, C, ldc, R, (int)P, (int)Q, accumulate ? 1 : 0, workspace, workspace_bytes, itr::as_stream(stream));
+    return itr::gemm_tn(A, lda, B, ldb, C, ldc, R, (int)P, (int)Q, accumulate ? 1 : 0, colsum_a, workspace, workspace_bytes, itr::as_stream(stream));
 }

@@ -428,11 +428,11 @@ __device__ __forceinline__ void sgt_stage(const float *__restrict__ src, int64_t
         *reinterpret_cast<float4 *>(dst + row * SCP + c4 * 4) = v;
     }
 }
-// M[v n + r] (+)= sum over the staged columns of a[v][.] b[r][.]
-__device__ __forceinline__ void sgt_dots(const float *a, const float *b, float *M, int n, int SC, bool first) {
+// M[v nr + r] (+)= sum over the staged columns of a[v][.] b[r][.]   (v < nv query rows, r < nr key rows)
+__device__ __forceinline__ void sgt_dots(const float *a, const float *b, float *M, int nv, int nr, int SC, bool first) {
     const int SCP = SC + 4;
-    for (int e = threadIdx.x; e < n * n; e += 256) {
-        const int v = e / n, r = e - v * n;
+    for (int e = threadIdx.x; e < nv * nr; e += 256) {
+        const int v = e / nr, r = e - v * nr;
         const float4 *pa = reinterpret_cast<const float4 *>(a + v * SCP), *pb = reinterpret_cast<const float4 *>(b + r * SCP);
         float s = 0.f;
         for (int k = 0; k < (SC >> 2); ++k) {
@@ -445,42 +445,49 @@ __device__ __forceinline__ void sgt_dots(const float *a, const float *b, float *
         M[e] = first ? s : M[e] + s;
     }
 }
-// out[row0 + v, s] = sum_r Mx(v, r) in[row0 + r, s],  Mx(v, r) = trans ? M[r n + v] : M[v n + r];  a thread owns columns s
-__device__ __forceinline__ void sgt_colmix(const float *M, bool trans, const float *__restrict__ in, float *__restrict__ out, int64_t row0, int n, int S) {
+// out[o, s] = sum_i Mx(o, i) in[i, s] with M [nv, nr]:  trans == false: o < nv, i < nr, Mx = M[o nr + i];  trans == true: o < nr, i < nv,
+// Mx = M[i nr + o].  `in` / `out` point at row 0 of their blocks; a thread owns columns s.
+__device__ __forceinline__ void sgt_colmix(const float *M, bool trans, int nv, int nr, const float *__restrict__ in, float *__restrict__ out, int S) {
+    const int no = trans ? nr : nv, ni = trans ? nv : nr;
     for (int s = threadIdx.x; s < S; s += 256) {
-        for (int v0 = 0; v0 < n; v0 += 16) {
+        for (int o0 = 0; o0 < no; o0 += 16) {
             float acc[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            for (int r = 0; r < n; ++r) {
-                const float x = in[(row0 + r) * S + s];
+            for (int r = 0; r < ni; ++r) {
+                const float x = in[(int64_t)r * S + s];
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (v0 + i < n) acc[i] = fmaf(trans ? M[r * n + v0 + i] : M[(v0 + i) * n + r], x, acc[i]);
+                    if (o0 + i < no) acc[i] = fmaf(trans ? M[r * nr + o0 + i] : M[(o0 + i) * nr + r], x, acc[i]);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (v0 + i < n) out[(row0 + v0 + i) * S + s] = acc[i];
+                if (o0 + i < no) out[(int64_t)(o0 + i) * S + s] = acc[i];
         }
     }
 }
+// ROW0: only node 0 of every pair asks (the LAST reasoning step: the reference reads sim_emb[:, 0, :] of its output, Fusionmodule.py:437-438) --
+// q / Z / dq are then pair rows (b C + c) and E is one row of n edge weights, saved in node order.
+template <bool ROW0>
 __global__ __launch_bounds__(256) void sgt_graph_fwd_kernel(SgtGraph g, const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ x,
                                                             float *__restrict__ Esave, float *__restrict__ Z) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int c = blockIdx.x, b = blockIdx.y;
     const int n = g.cap_off[c + 1] - g.cap_off[c] + 1;
+    const int nv = ROW0 ? 1 : n;
     const int64_t row0 = (int64_t)b * (g.T + g.C) + g.cap_off[c] + c;
-    const int nn4 = (n * n + 3) & ~3;
-    float *E = sm, *qs = sm + nn4, *ks = qs + n * (g.SC + 4);
+    const int64_t qrow = ROW0 ? (int64_t)b * g.C + c : row0;
+    const int nn4 = (nv * n + 3) & ~3;
+    float *E = sm, *qs = sm + nn4, *ks = qs + nv * (g.SC + 4);
     for (int s0 = 0; s0 < g.S; s0 += g.SC) {
         __syncthreads();
-        sgt_stage(q, row0, n, g.S, s0, g.SC, qs);
+        sgt_stage(q, qrow, nv, g.S, s0, g.SC, qs);
         sgt_stage(k, row0, n, g.S, s0, g.SC, ks);
         __syncthreads();
-        sgt_dots(qs, ks, E, n, g.SC, s0 == 0);
+        sgt_dots(qs, ks, E, nv, n, g.SC, s0 == 0);
     }
     __syncthreads();
-    for (int v = threadIdx.x; v < n; v += 256) {
+    for (int v = threadIdx.x; v < nv; v += 256) {
         float m = -INFINITY;
         for (int r = 0; r < n; ++r) m = fmaxf(m, E[v * n + r]);
         float den = 0.f;
@@ -492,38 +499,41 @@ __global__ __launch_bounds__(256) void sgt_graph_fwd_kernel(SgtGraph g, const fl
         for (int r = 0; r < n; ++r) E[v * n + r] /= den;
     }
     __syncthreads();
-    float *Eo = Esave + (int64_t)b * g.e_off[g.C] + g.e_off[c];
-    for (int e = threadIdx.x; e < n * n; e += 256) Eo[e] = E[e];
-    sgt_colmix(E, false, x, Z, row0, n, g.S);
+    float *Eo = ROW0 ? Esave + row0 : Esave + (int64_t)b * g.e_off[g.C] + g.e_off[c];
+    for (int e = threadIdx.x; e < nv * n; e += 256) Eo[e] = E[e];
+    sgt_colmix(E, false, nv, n, x + row0 * g.S, Z + qrow * g.S, g.S);
 }
+template <bool ROW0>
 __global__ __launch_bounds__(256) void sgt_graph_bwd_kernel(SgtGraph g, const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ x,
                                                             const float *__restrict__ Esave, const float *__restrict__ dZ, float *__restrict__ dq,
                                                             float *__restrict__ dk, float *__restrict__ dx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int c = blockIdx.x, b = blockIdx.y;
     const int n = g.cap_off[c + 1] - g.cap_off[c] + 1;
+    const int nv = ROW0 ? 1 : n;
     const int64_t row0 = (int64_t)b * (g.T + g.C) + g.cap_off[c] + c;
-    const int nn4 = (n * n + 3) & ~3;
-    float *E = sm, *dE = sm + nn4, *as = dE + nn4, *bs = as + n * (g.SC + 4);
-    const float *Ei = Esave + (int64_t)b * g.e_off[g.C] + g.e_off[c];
-    for (int e = threadIdx.x; e < n * n; e += 256) E[e] = Ei[e];
+    const int64_t qrow = ROW0 ? (int64_t)b * g.C + c : row0;
+    const int nn4 = (nv * n + 3) & ~3;
+    float *E = sm, *dE = sm + nn4, *as = dE + nn4, *bs = as + nv * (g.SC + 4);
+    const float *Ei = ROW0 ? Esave + row0 : Esave + (int64_t)b * g.e_off[g.C] + g.e_off[c];
+    for (int e = threadIdx.x; e < nv * n; e += 256) E[e] = Ei[e];
     for (int s0 = 0; s0 < g.S; s0 += g.SC) {          // dE[v, r] = dZ_v . x_r
         __syncthreads();
-        sgt_stage(dZ, row0, n, g.S, s0, g.SC, as);
+        sgt_stage(dZ, qrow, nv, g.S, s0, g.SC, as);
         sgt_stage(x, row0, n, g.S, s0, g.SC, bs);
         __syncthreads();
-        sgt_dots(as, bs, dE, n, g.SC, s0 == 0);
+        sgt_dots(as, bs, dE, nv, n, g.SC, s0 == 0);
     }
     __syncthreads();
-    sgt_colmix(E, true, dZ, dx, row0, n, g.S);         // dx_r = sum_v E[v, r] dZ_v   (the mixing path only; the caller adds the q / k paths)
-    for (int v = threadIdx.x; v < n; v += 256) {       // softmax backward per query row
+    sgt_colmix(E, true, nv, n, dZ + qrow * g.S, dx + row0 * g.S, g.S);      // dx_r = sum_v E[v, r] dZ_v   (the mixing path only; autograd adds the q / k paths)
+    for (int v = threadIdx.x; v < nv; v += 256) {                            // softmax backward per query row
         float dot = 0.f;
         for (int r = 0; r < n; ++r) dot = fmaf(dE[v * n + r], E[v * n + r], dot);
         for (int r = 0; r < n; ++r) dE[v * n + r] = E[v * n + r] * (dE[v * n + r] - dot);
     }
     __syncthreads();
-    sgt_colmix(dE, false, k, dq, row0, n, g.S);        // dq_v = sum_r dS[v, r] k_r
-    sgt_colmix(dE, true, q, dk, row0, n, g.S);         // dk_r = sum_v dS[v, r] q_v
+    sgt_colmix(dE, false, nv, n, k + row0 * g.S, dq + qrow * g.S, g.S);      // dq_v = sum_r dS[v, r] k_r
+    sgt_colmix(dE, true, nv, n, q + qrow * g.S, dk + row0 * g.S, g.S);       // dk_r = sum_v dS[v, r] q_v
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -862,32 +872,37 @@ extern "C" int itr_sgt_nodes(float *glo, float *loc, float *nodes, const int32_t
 }
 
 extern "C" int itr_sgt_graph_fwd(const float *q, const float *k, const float *x, const int32_t *cap_off, const int32_t *e_off, int B, int C, int T, int S,
-                                 int nmax, float *E, float *Z, itr_stream_t stream) {
+                                 int nmax, int row0_only, float *E, float *Z, itr_stream_t stream) {
     SGT_SHAPE(B >= 0 && B <= 65535 && C >= 0 && C <= 65535 && T >= 0 && S >= 4 && nmax >= 1, "itr_sgt_graph_fwd");
     ITR_UNSUPPORTED(S % 4 != 0, "itr_sgt_graph_fwd: sim_dim %d is not a multiple of 4", S);
     if (B == 0 || C == 0) return ITR_OK;
     ITR_REQUIRE(q && k && x && cap_off && e_off && E && Z, "itr_sgt_graph_fwd: null pointer");
     const int SC = sgt_graph_chunk(nmax, S);
     const size_t lds = ((size_t)((nmax * nmax + 3) & ~3) + 2 * (size_t)nmax * (SC + 4)) * sizeof(float);
-    const int rc = sgt_lds(reinterpret_cast<const void *>(sgt_graph_fwd_kernel), lds, "itr_sgt_graph_fwd");
+    const void *kern = row0_only ? reinterpret_cast<const void *>(sgt_graph_fwd_kernel<true>) : reinterpret_cast<const void *>(sgt_graph_fwd_kernel<false>);
+    const int rc = sgt_lds(kern, lds, "itr_sgt_graph_fwd");
     if (rc != ITR_OK) return rc;
     const SgtGraph g{cap_off, e_off, C, T, S, SC};
-    hipLaunchKernelGGL(sgt_graph_fwd_kernel, dim3(C, B), dim3(256), lds, as_stream(stream), g, q, k, x, E, Z);
+    if (row0_only) hipLaunchKernelGGL(sgt_graph_fwd_kernel<true>, dim3(C, B), dim3(256), lds, as_stream(stream), g, q, k, x, E, Z);
+    else hipLaunchKernelGGL(sgt_graph_fwd_kernel<false>, dim3(C, B), dim3(256), lds, as_stream(stream), g, q, k, x, E, Z);
     ITR_CHECK_LAUNCH("sgt_graph_fwd");
     return ITR_OK;
 }
 extern "C" int itr_sgt_graph_bwd(const float *q, const float *k, const float *x, const float *E, const float *dZ, const int32_t *cap_off,
-                                 const int32_t *e_off, int B, int C, int T, int S, int nmax, float *dq, float *dk, float *dx, itr_stream_t stream) {
+                                 const int32_t *e_off, int B, int C, int T, int S, int nmax, int row0_only, float *dq, float *dk, float *dx,
+                                 itr_stream_t stream) {
     SGT_SHAPE(B >= 0 && B <= 65535 && C >= 0 && C <= 65535 && T >= 0 && S >= 4 && nmax >= 1, "itr_sgt_graph_bwd");
     ITR_UNSUPPORTED(S % 4 != 0, "itr_sgt_graph_bwd: sim_dim %d is not a multiple of 4", S);
     if (B == 0 || C == 0) return ITR_OK;
     ITR_REQUIRE(q && k && x && E && dZ && cap_off && e_off && dq && dk && dx, "itr_sgt_graph_bwd: null pointer");
     const int SC = sgt_graph_chunk(nmax, S);
     const size_t lds = (2 * (size_t)((nmax * nmax + 3) & ~3) + 2 * (size_t)nmax * (SC + 4)) * sizeof(float);
-    const int rc = sgt_lds(reinterpret_cast<const void *>(sgt_graph_bwd_kernel), lds, "itr_sgt_graph_bwd");
+    const void *kern = row0_only ? reinterpret_cast<const void *>(sgt_graph_bwd_kernel<true>) : reinterpret_cast<const void *>(sgt_graph_bwd_kernel<false>);
+    const int rc = sgt_lds(kern, lds, "itr_sgt_graph_bwd");
     if (rc != ITR_OK) return rc;
     const SgtGraph g{cap_off, e_off, C, T, S, SC};
-    hipLaunchKernelGGL(sgt_graph_bwd_kernel, dim3(C, B), dim3(256), lds, as_stream(stream), g, q, k, x, E, dZ, dq, dk, dx);
+    if (row0_only) hipLaunchKernelGGL(sgt_graph_bwd_kernel<true>, dim3(C, B), dim3(256), lds, as_stream(stream), g, q, k, x, E, dZ, dq, dk, dx);
+    else hipLaunchKernelGGL(sgt_graph_bwd_kernel<false>, dim3(C, B), dim3(256), lds, as_stream(stream), g, q, k, x, E, dZ, dq, dk, dx);
     ITR_CHECK_LAUNCH("sgt_graph_bwd");
     return ITR_OK;
 }

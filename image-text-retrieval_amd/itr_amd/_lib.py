@@ -109,7 +109,7 @@ SIGNATURES = {
     "itr_colsum_workspace_bytes": (sz, [i64, i64]),
     "itr_colsum": (i32, [vp, vp, i64, i64, i32, vp, sz, vp]),
     "itr_gemm_tn_workspace_bytes": (sz, [i64, i64, i64]),
-    "itr_gemm_tn": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp, sz, vp]),
+    "itr_gemm_tn": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp, vp, sz, vp]),
     "itr_gemm_tn_batched": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp]),
     "itr_sgt_attn_fwd": (i32, [vp, i64, vp, i32, i32, i32, i32, i32, f32, f32, vp, vp]),
     "itr_sgt_attn_bwd": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp, vp]),
@@ -120,8 +120,8 @@ SIGNATURES = {
     "itr_sgt_pair_sqdiff_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "itr_sgt_pair_sqdiff_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "itr_sgt_nodes": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    "itr_sgt_graph_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
-    "itr_sgt_graph_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "itr_sgt_graph_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "itr_sgt_graph_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "itr_sgt_segbn_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp]),
     "itr_sgt_segbn_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "itr_sgt_saf_pool_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]),

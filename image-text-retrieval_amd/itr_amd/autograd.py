@@ -60,8 +60,9 @@ def _gemm_nt(a, b, out=None, accumulate=False):
     return out
 
 
-def _gemm_tn(a, b, out=None, accumulate=False):
-    """a [R, P]^T . b [R, Q] -> [P, Q]: the weight gradient dY^T X, reduced over the rows in slices (csrc/gemm_tn.hip)."""
+def _gemm_tn(a, b, out=None, accumulate=False, colsum_a=None):
+    """a [R, P]^T . b [R, Q] -> [P, Q]: the weight gradient dY^T X, reduced over the rows in slices (csrc/gemm_tn.hip); colsum_a [P]
+    (optional) receives the column sums of a -- the bias gradient -- from the same pass."""
     lib = _lib.load()
     R, P = a.shape
     Q = b.shape[1]
@@ -70,7 +71,7 @@ def _gemm_tn(a, b, out=None, accumulate=False):
         out = _f32(P, Q, dev=a.device)
     wsb = lib.itr_gemm_tn_workspace_bytes(R, P, Q)
     ws = torch.empty(max(wsb, 1), device=a.device, dtype=torch.uint8)
-    _lib.check(lib.itr_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), R, P, Q, int(accumulate), _p(ws), wsb, _stream()))
+    _lib.check(lib.itr_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), R, P, Q, int(accumulate), _p(colsum_a), _p(ws), wsb, _stream()))
     return out
 
 
@@ -99,9 +100,11 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _gemm_nt(dy2, transpose2d(w)).reshape(ctx.xshape)        # dy [M, N] . (W^T [K, N])^T
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = _gemm_tn(dy2, x2)                                        # dy^T [N, M] . x [M, K], split over the rows
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _f32(dy2.shape[1], dev=dy2.device) if want_db else None
+            dw = _gemm_tn(dy2, x2, colsum_a=db)                           # dy^T [N, M] . x [M, K], split over the rows; db = colsum(dy) rides along
+        elif want_db:
             db = colsum(dy2)
         return dx, dw, db
 

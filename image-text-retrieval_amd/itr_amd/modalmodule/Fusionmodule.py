@@ -256,11 +256,16 @@ def encoder_similarity_train_batched(sim_enc, img_emb, words, lens, seeds, seeds
     sim_glo = ag.l2norm_rows(ag.linear(sgt.pair_sqdiff(img_glo, cap_glo), sim_enc.sim_tranglo_w.weight, sim_enc.sim_tranglo_w.bias), eps=1e-8)
     nodes = sgt.assemble_nodes(sim_glo, sim_loc, lay, B)                                                             # (B (T + C), S)
     if sim_enc.module_name == 'SGR':
-        for gr in sim_enc.SGR_module:
+        steps = list(sim_enc.SGR_module)
+        for gr in steps[:-1]:
             q = ag.linear(nodes, gr.graph_query_w.weight, gr.graph_query_w.bias)
             k = ag.linear(nodes, gr.graph_key_w.weight, gr.graph_key_w.bias)
             nodes = ag.act(ag.linear(sgt.graph_attn(q, k, nodes, lay, B), gr.sim_graph_w.weight, gr.sim_graph_w.bias), 'relu')
-        sim_vec = ag.gather_rows(nodes, lay.node0_rows(B))                                                           # node 0 of every pair
+        # the last step is read at node 0 only (sim_emb[:, 0, :], Fusionmodule.py:437-438): one query row per pair, keys from all nodes
+        gr = steps[-1]
+        q0 = ag.linear(ag.gather_rows(nodes, lay.node0_rows(B)), gr.graph_query_w.weight, gr.graph_query_w.bias)      # (B C, S)
+        k = ag.linear(nodes, gr.graph_key_w.weight, gr.graph_key_w.bias)
+        sim_vec = ag.act(ag.linear(sgt.graph_attn(q0, k, nodes, lay, B, row0=True), gr.sim_graph_w.weight, gr.sim_graph_w.bias), 'relu')
     else:
         saf = sim_enc.SAF_module
         a = ag.linear(nodes, saf.attn_sim_w.weight, saf.attn_sim_w.bias).reshape(-1)

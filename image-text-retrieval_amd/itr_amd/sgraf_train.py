@@ -178,15 +178,19 @@ class _GraphAttn(torch.autograd.Function):
     """softmax(q k^T) x inside every pair's graph (GraphReasoning.forward, Fusionmodule.py:582-584)."""
 
     @staticmethod
-    def forward(ctx, q, k, x, lay, B):
+    def forward(ctx, q, k, x, lay, B, row0):
         lib = _lib.load()
         q, k, x = _dev(q, name="q"), _dev(k, name="k"), _dev(x, name="x")
         S = x.shape[1]
-        E = _f32(B * lay.E_per_image, dev=x.device)
-        Z = torch.empty_like(x)
-        _lib.check(lib.itr_sgt_graph_fwd(_p(q), _p(k), _p(x), _p(lay.cap_off), _p(lay.e_off), B, lay.C, lay.T, S, lay.nmax, _p(E), _p(Z), _stream()))
+        if q.shape[0] != (B * lay.C if row0 else B * lay.NT) or k.shape[0] != B * lay.NT or x.shape[0] != B * lay.NT:
+            raise ValueError("graph_attn: q %s, k %s, x %s for %d images, %d captions, %d words" % (tuple(q.shape), tuple(k.shape), tuple(x.shape), B,
+                                                                                                  lay.C, lay.T))
+        E = _f32(B * (lay.NT if row0 else lay.E_per_image), dev=x.device)
+        Z = torch.empty_like(q)
+        _lib.check(lib.itr_sgt_graph_fwd(_p(q), _p(k), _p(x), _p(lay.cap_off), _p(lay.e_off), B, lay.C, lay.T, S, lay.nmax, int(row0), _p(E), _p(Z),
+                                         _stream()))
         ctx.save_for_backward(q, k, x, E)
-        ctx.lay, ctx.B = lay, B
+        ctx.lay, ctx.B, ctx.row0 = lay, B, int(row0)
         return Z
 
     @staticmethod
@@ -196,12 +200,13 @@ class _GraphAttn(torch.autograd.Function):
         lay = ctx.lay
         dq, dk, dx = torch.empty_like(q), torch.empty_like(k), torch.empty_like(x)
         _lib.check(lib.itr_sgt_graph_bwd(_p(q), _p(k), _p(x), _p(E), _p(dZ.contiguous()), _p(lay.cap_off), _p(lay.e_off), ctx.B, lay.C, lay.T,
-                                         x.shape[1], lay.nmax, _p(dq), _p(dk), _p(dx), _stream()))
-        return dq, dk, dx, None, None
+                                         x.shape[1], lay.nmax, ctx.row0, _p(dq), _p(dk), _p(dx), _stream()))
+        return dq, dk, dx, None, None, None
 
 
-def graph_attn(q, k, x, lay, B):
-    return _GraphAttn.apply(q, k, x, lay, B)
+def graph_attn(q, k, x, lay, B, row0=False):
+    """row0: q [B C, S] holds only the query of node 0 of every pair (the last reasoning step) -> Z [B C, S]."""
+    return _GraphAttn.apply(q, k, x, lay, B, row0)
 
 
 class _SegBN(torch.autograd.Function):

@@ -379,10 +379,11 @@ int itr_colsum(const float *x, float *out, int64_t rows, int64_t cols, int accum
                size_t workspace_bytes, itr_stream_t stream);
 /* Weight gradient of a dense layer, dW = dY^T X:  C[P, Q] (+)= A[R, P]^T B[R, Q] (row-major, the REDUCED index is the row of
  * both operands: no transposed copies).  The rows are split into slices whose partial products (workspace) are added in slice
- * order: deterministic.  accumulate != 0 adds to C.  Exact fp32 MFMA (csrc/gemm_tn.hip). */
+ * order: deterministic.  accumulate != 0 adds to C.  colsum_a (may be NULL) receives sum_r A[r, :] -- the bias gradient, from the
+ * operand tiles the product loads anyway.  Exact fp32 MFMA (csrc/gemm_tn.hip). */
 size_t itr_gemm_tn_workspace_bytes(int64_t R, int64_t P, int64_t Q);
 int itr_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t R, int64_t P, int64_t Q,
-                int accumulate, void *workspace, size_t workspace_bytes, itr_stream_t stream);
+                int accumulate, float *colsum_a, void *workspace, size_t workspace_bytes, itr_stream_t stream);
 /* `batch` problems of one shape in one launch (operand z at A + z batch_a ...), each C_z = A_z^T B_z reduced in one pass. */
 int itr_gemm_tn_batched(const float *A, int64_t lda, int64_t batch_a, const float *B, int64_t ldb, int64_t batch_b, float *C, int64_t ldc,
                         int64_t batch_c, int64_t R, int64_t P, int64_t Q, int64_t batch, itr_stream_t stream);
@@ -418,10 +419,13 @@ int itr_sgt_pair_sqdiff_bwd(const float *img_glo, const float *cap_glo, const fl
                             float *dcap_glo, itr_stream_t stream);
 int itr_sgt_nodes(float *glo, float *loc, float *nodes, const int32_t *cap_off, const int32_t *node_cap, int B, int C, int T, int S,
                   int backward, itr_stream_t stream);
+/* row0_only != 0: only node 0 of every pair is a query (the last reasoning step, whose output the reference reads at [:, 0, :]):
+ * q / Z / dq are pair rows [B C, S], E one row of n weights per pair at its node offset [B (T + C)]. */
 int itr_sgt_graph_fwd(const float *q, const float *k, const float *x, const int32_t *cap_off, const int32_t *e_off, int B, int C, int T, int S,
-                      int nmax, float *E, float *Z, itr_stream_t stream);
+                      int nmax, int row0_only, float *E, float *Z, itr_stream_t stream);
 int itr_sgt_graph_bwd(const float *q, const float *k, const float *x, const float *E, const float *dZ, const int32_t *cap_off,
-                      const int32_t *e_off, int B, int C, int T, int S, int nmax, float *dq, float *dk, float *dx, itr_stream_t stream);
+                      const int32_t *e_off, int B, int C, int T, int S, int nmax, int row0_only, float *dq, float *dk, float *dx,
+                      itr_stream_t stream);
 int itr_sgt_segbn_fwd(const float *a, const int32_t *cap_off, int B, int C, int T, const float *gamma, const float *beta, float eps, float *y,
                       float *mean, float *var, float *invstd, itr_stream_t stream);
 int itr_sgt_segbn_bwd(const float *dy, const float *a, const int32_t *cap_off, int B, int C, int T, const float *gamma, const float *mean,

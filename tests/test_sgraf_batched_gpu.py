@@ -129,6 +129,31 @@ def test_graph_and_filtration_stages_vs_float64(dev, B, C, S):
     assert int(bn.num_batches_tracked) == C
 
 
+@pytest.mark.parametrize("B,C,S", [(3, 5, 16), (4, 6, 256)])
+def test_last_reasoning_step_asks_only_node_zero(dev, B, C, S):
+    """row0 form (the last GraphReasoning step, read at [:, 0, :]) == node 0 of the full form: values and every gradient."""
+    rng = np.random.RandomState(S)
+    torch.manual_seed(S + 1)
+    lens = _lens(rng, C, 1, 22)
+    lay = sgt.Layout(lens, dev)
+    rows0 = lay.node0_rows(B)
+    res = []
+    for row0 in (False, True):
+        torch.manual_seed(4)
+        x = torch.randn(B * lay.NT, S, device=dev, requires_grad=True)
+        q = (torch.randn(B * lay.NT, S, device=dev) * 0.3).requires_grad_()
+        k = (torch.randn(B * lay.NT, S, device=dev) * 0.3).requires_grad_()
+        if row0:
+            z0 = sgt.graph_attn(ag.gather_rows(q, rows0), k, x, lay, B, row0=True)
+        else:
+            z0 = ag.gather_rows(sgt.graph_attn(q, k, x, lay, B), rows0)
+        g = torch.randn(B * C, S, device=dev, generator=torch.Generator(device=dev).manual_seed(8))
+        (z0 * g).sum().backward()
+        res.append((z0.detach(), x.grad, q.grad, k.grad))
+    for name, a, b in zip(("Z0", "d x", "d q", "d k"), res[0], res[1]):
+        _close(b, a, 1e-5, name)
+
+
 @pytest.mark.parametrize("C,D", [(5, 32), (9, 1024), (1, 12)])
 def test_text_self_attention_stages_vs_float64(dev, C, D):
     rng = np.random.RandomState(C)
