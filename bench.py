@@ -887,6 +887,28 @@ def other_config_in_child(name, k, w, timeout_s):
     return json.loads(lines[0]), None
 
 
+def train_configs_in_child(timeout_s):
+    """SURVEY 8 f3, measured: one model.train_emb step of every model family at the reference's training shape (batch 128, SAEM 64;
+    the reference times every training batch, /root/reference/itr/utils.py:80-102), in a fresh child process after the timed region
+    (tools/train_bench.py --all --json --cpu): ms per step, forward / backward / optimizer split, pairs scored per second, the flop
+    model as a fraction of the fp32 MFMA peak, and the oracle's training step on the host cores beside VSE++ / SCAN."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--all", "--json", "--cpu", "--steps", "10", "--warmup", "3", "--budget",
+           str(int(timeout_s * 0.6))]
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("ITR_BENCH_PROGRESS_DIR",)}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "child process exceeded %d s and was killed" % timeout_s}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"train_configs"')]
+    if r.returncode != 0 or len(lines) != 1:
+        tail = (r.stderr or "").strip().splitlines()
+        return {"error": "child process exit code %d: %s" % (r.returncode, tail[-1] if tail else "no message")}
+    o = json.loads(lines[0])
+    o["train_configs"]["wall_s"] = o["wall_s"]
+    return o["train_configs"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -897,6 +919,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the separately reported fp16x3 variant of the SCAN workloads")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of the other BASELINE.json configs that the default workload's line carries in `other_configs`")
+    ap.add_argument("--no-train-configs", action="store_true",
+                    help="skip the training-step timings (model.train_emb of every family, tools/train_bench.py in a child process) that the "
+                         "default workload's line carries in `train_configs`")
     ap.add_argument("--cpu-sample-images", type=int, default=160)
     ap.add_argument("--cpu-repeats", type=int, default=3, help="passes of the CPU leg (the minimum is reported, with the spread)")
     ap.add_argument("--cpu-threads", default=None, metavar="N[,N...]",
@@ -940,8 +965,14 @@ def main():
               "`python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d`" % (args.gpus, world, args.gpus, args.gpus, args.gpus),
               file=sys.stderr)
         sys.exit(2)
+    # The harness translates ITS switches (flags, and the variables the tests hand to a bench child process) into explicit settings of
+    # the package: itr_amd itself reads no environment variable.
+    from itr_amd.settings import SETTINGS
     if args.virtual_split:
-        os.environ["ITR_FORCE_SPLIT"] = args.virtual_split
+        SETTINGS.virtual_split = args.virtual_split
+    SETTINGS.force_collectives = os.environ.get("ITR_FORCE_COLLECTIVES") == "1"
+    if os.environ.get("ITR_SGRAF_IB"):
+        SETTINGS.sgraf_image_block = int(os.environ["ITR_SGRAF_IB"])
     backend = os.environ.get("ITR_DIST_BACKEND", "nccl")   # "gloo": several ranks on ONE GPU (tests); collectives staged through the host
     have_gpu = not args.launch_check or torch.cuda.is_available()
     if backend == "gloo":
@@ -1028,6 +1059,10 @@ def main():
                 rc = 4
         if args.workload == DEFAULT_WORKLOAD and not args.no_other_configs and not args.virtual_split:
             other_configs(args, world, rank, dev, use_dist, backend, line)
+        if (args.workload == DEFAULT_WORKLOAD and not args.no_train_configs and not args.no_other_configs and not args.virtual_split and world == 1
+                and not use_dist and dev.type == "cuda" and os.environ.get("ITR_BENCH_OTHER") != "small"):
+            progress("train_configs")
+            line.out["train_configs"] = train_configs_in_child(240)
     finally:
         # the primary workload's line, whatever the secondary runs did (an exception on this rank lands here too)
         if rank == 0:

@@ -13,13 +13,13 @@ Partitioning:
      the single-GPU one by construction.
 With world_size == 1 every collective is skipped.
 """
-import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import ops
+from .settings import SETTINGS
 
 _SIGN = -(1 << 63)  # XOR flips unsigned 64-bit order into signed int64 order for the max all-reduce
 
@@ -58,7 +58,7 @@ class Comm:
     """Minimal collective layer: torch.distributed (backend nccl == RCCL over xGMI on ROCm, gloo in
     the CPU tests) or a no-op for a single process.
 
-    Virtual caption split (`virtual_split="k[:v]"` or ITR_FORCE_SPLIT, single real rank only): the caption axis is treated as
+    Virtual caption split (`virtual_split="k[:v]"` or SETTINGS.virtual_split, single real rank only): the caption axis is treated as
     owned by k ranks of which this process is owner v.  The images stay whole (one real rank), the k - 1 other owners' embedding
     blocks are handed over in `peer_blocks`, and the exchange is a REAL asynchronous all-gather on the backend's stream (1-rank
     RCCL group when one is initialised, a side-stream copy otherwise) -- so the N > 1 order of work (gather in flight while the
@@ -66,7 +66,7 @@ class Comm:
 
     def __init__(self, group=None, virtual_split=None):
         self.on = dist.is_available() and dist.is_initialized() and (
-            dist.get_world_size(group) > 1 or os.environ.get("ITR_FORCE_COLLECTIVES") == "1")
+            dist.get_world_size(group) > 1 or SETTINGS.force_collectives)
         self.group = group
         self.rank = dist.get_rank(group) if self.on else 0
         self.world = dist.get_world_size(group) if self.on else 1
@@ -75,7 +75,7 @@ class Comm:
         self.host_staged = self.on and dist.get_backend(group) == "gloo"
         self.cap_world, self.cap_rank = self.world, self.rank        # owners of the caption axis (= the ranks, unless virtual)
         self.peer_blocks = None                                      # virtual split: {owner q: its block}, set by the caller per step
-        vs = virtual_split if virtual_split is not None else os.environ.get("ITR_FORCE_SPLIT")
+        vs = virtual_split if virtual_split is not None else SETTINGS.virtual_split
         if vs:
             k, _, v = str(vs).partition(":")
             k = int(k)
@@ -124,7 +124,7 @@ class Comm:
             dist.all_gather(parts, send.cpu(), group=self.group)
             out.copy_(torch.cat(parts, 0))
             return out, maxrows, (lambda: None)
-        if os.environ.get("ITR_EXCHANGE") == "p2p":
+        if SETTINGS.exchange == "p2p":
             # Opt-in: the exchange as world - 1 point-to-point sends and receives per rank, batched -- on RCCL one
             # ncclGroup of ncclSend / ncclRecv pairs, i.e. every xGMI link of the fully connected node carries one block at once,
             # instead of whatever algorithm RCCL picks for all_gather.  Not the default: it has only ever run over gloo

@@ -3,12 +3,12 @@ attention (AGSA), dilated-convolution multi-view summarisation, box position enc
 HIP forward (evaluation mode: BatchNorm running statistics, dropout off)."""
 import copy
 import math
-import os
 
 import torch
 from torch import nn
 
 from .. import ops
+from ..settings import SETTINGS
 
 
 def clones(module, N):
@@ -52,7 +52,7 @@ class GatedQueryAttLayer(nn.Module):
         dk = self.d_k
         q, k, v = [_lin(inp.reshape(B * L, D), l) for l in self.linears]       # (B*L, D) each
         q2, k2 = q.view(-1, dk), k.view(-1, dk)                                # (B*L*h, dk): heads are contiguous
-        if dk in (16, 32) and not os.environ.get("ITR_AGSA_UNFUSED"):          # one kernel for the gate (csrc/agsa_gate.hip); env: A/B switch
+        if dk in (16, 32) and SETTINGS.agsa_fused:                             # one kernel for the gate (csrc/agsa_gate.hip)
             q2, k2 = ops.agsa_gate(q2, k2, (self.fc_q.weight, self.fc_q.bias), (self.fc_k.weight, self.fc_k.bias),
                                    (self.fc_g.weight, self.fc_g.bias))
         else:

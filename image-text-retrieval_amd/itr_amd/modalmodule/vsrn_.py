@@ -2,12 +2,12 @@
 (`g`, `theta`, `phi` = Conv1d(k=1), `W` = Sequential(Conv1d(k=1), BatchNorm1d) with gamma = beta = 0 at init), arithmetic
 on the HIP kernels.  The towers keep regions as ROWS ((B, N, D), a kernel-size-1 convolution over (B, D, N) is a Linear
 over the last axis), so the reference's permutes disappear."""
-import os
 
 import torch
 from torch import nn
 
 from .. import ops
+from ..settings import SETTINGS
 
 
 class Rs_GCN(nn.Module):
@@ -64,7 +64,7 @@ class Rs_GCN(nn.Module):
         B, N, D = v.shape
         tpg = ops.linear(v.reshape(B * N, D), w3, b3)                        # [B*N, 3C]: theta | phi | g
         y = ops.gcn_relation(tpg, B, N, self.inter_channels)                 # (theta phi^T / N) g
-        if os.environ.get("ITR_VSRN_CLONE"):                                 # A/B switch: copy v, accumulate onto the copy (round 2)
+        if not SETTINGS.vsrn_residual_in_epilogue:                           # cross-check form: copy v, accumulate onto the copy (round 2)
             out = v.reshape(B * N, D).clone()
             ops.gemm_acc(y, y.shape[1], B * N, self.inter_channels, ww, wb, out)
         else:

@@ -4,13 +4,13 @@ torch is plumbing here: it owns device memory and the current HIP stream; every 
 raw device pointers + sizes to libitr_hip.so.  CPU tensors are rejected -- there is no fallback.
 """
 import ctypes as C
-import os
 import weakref
 
 import numpy as np
 import torch
 
 from . import _lib
+from .settings import SETTINGS
 
 SCAN_NT = 64
 SCAN_R = 36            # regions per image the fused SCAN / SGRAF kernels are built for (csrc/scan_common.h SC_R)
@@ -94,10 +94,11 @@ def mean_mid(x):
     return y
 
 
-# STUDY switch: ITR_GEMM_BF16X3=1 routes the plain tower / score GEMMs (linear, linear_strided,
-# cosine_scores) through the split-bf16 kernel (terms = 3, ~1e-6 of fp32).  Default off: the product GEMM is exact fp32.
-BF16X3 = os.environ.get("ITR_GEMM_BF16X3") == "1"
-FP16X3 = os.environ.get("ITR_GEMM_FP16X3") == "1"      # the fp16-plane variant: fp32-rounding-level error, same speed
+# STUDY switches: True routes the plain tower / score GEMMs (linear, linear_strided, cosine_scores) through the
+# split-bf16 kernel (terms = 3, ~1e-6 of fp32) / its fp16-plane variant.  Set by the study tools and their tests in their own
+# process, never from the environment: the product GEMM is exact fp32.
+BF16X3 = False
+FP16X3 = False
 
 
 def _weight_planes(w):
@@ -409,8 +410,8 @@ class ScanPlan:
                 tb = np.zeros(self.Nc_kernel + 1, dtype=np.int32)
                 order = np.zeros(self.Nc_kernel, dtype=np.int32)
                 nt = C.c_int64(0)
-                # ITR_SGR_GROUP_ROWS=32 (A/B switch): captions of <= 31 words in groups of <= 32 node rows, two workgroups per CU
-                small = 32 if os.environ.get("ITR_SGR_GROUP_ROWS") == "32" else SCAN_NT
+                # SETTINGS.sgr_group_rows = 32 (cross-check): captions of <= 31 words in groups of <= 32 node rows, two workgroups per CU
+                small = 32 if SETTINGS.sgr_group_rows == 32 else SCAN_NT
                 _lib.check(lib.itr_sgr_plan_node_groups(lens.ctypes.data_as(C.c_void_p), self.Nc_kernel, small, tb.ctypes.data_as(C.c_void_p),
                                                         order.ctypes.data_as(C.c_void_p), C.byref(nt)))
                 n = int(nt.value)
@@ -768,10 +769,10 @@ def _sgraf_workspace(lib, dev, Ni, Nc, n_rows, n_tiles, D, S_dim, mod, flags, im
     validation pass inside a training process -- optimizer state and activations resident -- or a co-tenant must shrink the
     block, not die).  Budget = `max_workspace_bytes` if given, else 90 % of (free device memory + what torch's caching allocator
     holds unused); the largest of 64 / 32 / 16 / 8 / 4 images whose workspace fits is taken (itr_sgraf_pick_image_block), and an
-    allocation that still fails falls back to the next smaller block.  image_block / ITR_SGRAF_IB pin the block instead.
+    allocation that still fails falls back to the next smaller block.  image_block / SETTINGS.sgraf_image_block pin the block instead.
     -> (workspace tensor, image_block)."""
-    if image_block is None and os.environ.get("ITR_SGRAF_IB"):
-        image_block = int(os.environ["ITR_SGRAF_IB"])          # Python-layer knob (several ranks sharing ONE GPU in the tests)
+    if image_block is None and SETTINGS.sgraf_image_block:
+        image_block = int(SETTINGS.sgraf_image_block)          # explicit knob (several ranks sharing ONE GPU in the tests)
     if image_block is not None:
         wsb = lib.itr_sgraf_workspace_bytes(Ni, Nc, n_rows, n_tiles, D, S_dim, mod, int(image_block), flags)
         SGRAF_LAST_BLOCK.update(image_block=int(image_block), workspace_bytes=int(wsb), budget_bytes=None, pinned=True)

@@ -36,6 +36,8 @@ if world > 1 or forced:
     dist.init_process_group(backend)
 
 from itr_amd import config as C                                   # noqa: E402
+from itr_amd.settings import SETTINGS                             # noqa: E402
+SETTINGS.force_collectives = forced
 from itr_amd.modalmodule import get_model                         # noqa: E402
 from itr_amd.metricmodule.evaluation import LogCollector          # noqa: E402
 

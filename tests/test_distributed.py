@@ -90,10 +90,11 @@ def _worker(rank, world, port, ni, tmp):
         return out
     S = evalpipe.exchange_score(comm, img, send, ranges, n_cap, score)
     ok = ok and bool(torch.allclose(S, img @ emb.t(), rtol=0, atol=1e-6))
-    # the same exchange as point-to-point sends / receives (ITR_EXCHANGE=p2p)
-    os.environ["ITR_EXCHANGE"] = "p2p"
+    # the same exchange as point-to-point sends / receives (SETTINGS.exchange = "p2p")
+    from itr_amd.settings import SETTINGS
+    SETTINGS.exchange = "p2p"
     S2 = evalpipe.exchange_score(comm, img, send, ranges, n_cap, score)
-    del os.environ["ITR_EXCHANGE"]
+    SETTINGS.exchange = "all_gather"
     ok = ok and bool(torch.equal(S2, S))
     open(os.path.join(tmp, "ok_%d" % rank), "w").write("1" if ok else "0")
     dist.destroy_process_group()

@@ -580,11 +580,12 @@ def test_sgr_fused_graph_steps(dev, case, steps):
         assert torch.equal(ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps, image_block=ib), got), ib
     # the two-class plan (round 4): captions of <= 31 words in groups of <= 32 node rows (two workgroups per CU), longer ones in groups of
     # <= 64 -- a caption's graph is computed with the same arithmetic whatever group and class it lands in
-    os.environ["ITR_SGR_GROUP_ROWS"] = "32"
+    from itr_amd.settings import SETTINGS
+    SETTINGS.sgr_group_rows = 32
     try:
         small = ops.sgraf_padded(img.to(dev), cap.to(dev), lens, wd, 'SGR', steps)
     finally:
-        del os.environ["ITR_SGR_GROUP_ROWS"]
+        SETTINGS.reset()
     assert torch.equal(small, got)
 
 
