@@ -17,6 +17,7 @@
 // and dE[token] += dX (atomic scatter; the only non-deterministic summation order of the step).
 #include <stdlib.h>
 #include "itr_common.h"
+#include "side_stream.h"
 
 namespace itr {
 
@@ -165,15 +166,61 @@ extern "C" size_t itr_gru_train_save_bytes(int64_t n_tok, int D, int bidirection
     return (size_t)(bidirectional ? 2 : 1) * 5 * (size_t)n_tok * D * 4;
 }
 
+namespace itr {
+// Workspace of the training forward / backward (one layout for both).  The two directions of a bi-GRU run SIDE BY SIDE (the reverse
+// one on the device's side stream, side_stream.h): a time step of one direction is a strict chain of small dependent launches that
+// leaves most of the chip idle, the other direction fills it.  So every buffer a recurrence writes exists once per direction.
+struct GruTrainWs {
+    float *x, *dx, *out_rev;          // shared: embedded tokens; input gradient; the reverse direction's outputs before the average
+    int *bad;
+    struct Dir {
+        float *gi, *gh, *h;           // forward: gate pre-activations of all tokens; [B, 3D] recurrence product; [B, D] state
+        float *hprev, *carry, *dgh_step, *whhT, *wihT, *skbuf;
+        void *tn;                     // gemm_tn partials of the two weight gradients
+        size_t tn_bytes;
+    } d[2];                           // backward: gi / gh double as dgi / dgh
+};
+size_t gemm_tn_workspace_bytes(int64_t R, int P, int Q);
+int gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int64_t R, int P, int Q, int accumulate,
+            float *colsum_a, void *workspace, size_t workspace_bytes, hipStream_t st);
+
+static size_t gru_train_ws_carve(void *base, int64_t n_tok, int64_t B, int E, int D, GruTrainWs *w) {
+    const size_t nt = (size_t)n_tok, d3 = (size_t)3 * D;
+    char *p = static_cast<char *>(base);
+    auto take = [&](size_t bytes) { char *q = p; p += al256(bytes); return q; };
+    GruTrainWs t;
+    t.x = (float *)take(nt * E * 4);
+    t.dx = (float *)take(nt * E * 4);
+    t.out_rev = (float *)take(nt * D * 4);
+    t.bad = (int *)take(512);
+    const size_t tnb = gemm_tn_workspace_bytes(n_tok, 3 * D, D > E ? D : E);
+    for (int k = 0; k < 2; ++k) {
+        t.d[k].gi = (float *)take(nt * d3 * 4);
+        t.d[k].gh = (float *)take(nt * d3 * 4);
+        t.d[k].h = (float *)take((size_t)B * D * 4);
+        t.d[k].hprev = (float *)take(nt * D * 4);
+        t.d[k].carry = (float *)take((size_t)B * D * 4);
+        t.d[k].dgh_step = (float *)take((size_t)B * d3 * 4);
+        t.d[k].whhT = (float *)take(d3 * D * 4);
+        t.d[k].wihT = (float *)take(d3 * E * 4);
+        t.d[k].skbuf = (float *)take(gemm_splitk_scratch_bytes(B, 3 * D, 16));
+        t.d[k].tn = take(tnb);
+        t.d[k].tn_bytes = tnb;
+    }
+    if (w) *w = t;
+    return (size_t)(p - static_cast<char *>(base));
+}
+
+}  // namespace itr
+using namespace itr;
+
 extern "C" size_t itr_gru_train_workspace_bytes(int64_t n_tok, int64_t B, int E, int D) {
-    // forward: x, gi, gh, h, bad.  backward: x, dgi, dgh, hprev, carry, dgh_step, dx, and the transposes
-    // (dgi^T | dgh^T share one [3D, n_tok] buffer, x^T | hprev^T one [max(E, D), n_tok]), W_hh^T, W_ih^T, colsum partials.
-    const size_t nt = (size_t)n_tok, d3 = (size_t)3 * D, ntp = (size_t)ceil_div(n_tok > 0 ? n_tok : 1, 32) * 32;
-    size_t b = al256(nt * E * 4) + 2 * al256(nt * d3 * 4) + al256(nt * D * 4) + al256((size_t)B * D * 4) + al256((size_t)B * d3 * 4) +
-               al256(nt * E * 4) + al256(d3 * ntp * 4) + al256((size_t)(E > D ? E : D) * ntp * 4) + al256(d3 * D * 4) + al256(d3 * E * 4) +
-               al256(((size_t)ceil_div(n_tok > 0 ? n_tok : 1, 256)) * d3 * 4) + 512;
-    b += al256(gemm_splitk_scratch_bytes(B, 3 * D, 16));      // split-K partials of the per-step GEMMs
-    return b;
+    return gru_train_ws_carve(nullptr, n_tok > 0 ? n_tok : 1, B > 0 ? B : 1, E, D, nullptr);
+}
+
+__global__ __launch_bounds__(256) void gru_avg_kernel(float *__restrict__ out, const float *__restrict__ other, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (out[i] + other[i]) / 2.f;
 }
 
 extern "C" int itr_gru_fwd_train(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev, const int32_t *len_host, int64_t B,
@@ -191,39 +238,51 @@ extern "C" int itr_gru_fwd_train(const int64_t *tokens, const int64_t *tok_off, 
     int rc = check_lengths(len_host, B, n_tok, "itr_gru_fwd_train");
     if (rc != ITR_OK) return rc;
     hipStream_t st = as_stream(stream);
-    char *p = static_cast<char *>(workspace);
-    float *x = (float *)p; p += al256((size_t)n_tok * E * 4);
-    float *gi = (float *)p; p += al256((size_t)n_tok * 3 * D * 4);
-    float *gh = (float *)p; p += al256((size_t)n_tok * 3 * D * 4);   // only [B, 3D] used
-    float *h = (float *)p; p += al256((size_t)n_tok * D * 4);        // only [B, D] used
-    int *bad = (int *)p;
-    // the split-K scratch is the LAST region of the (shared forward / backward) workspace layout
-    float *skbuf = reinterpret_cast<float *>(static_cast<char *>(workspace) + itr_gru_train_workspace_bytes(n_tok, B, E, D) -
-                                             al256(gemm_splitk_scratch_bytes(B, 3 * D, 16)));
+    GruTrainWs w;
+    gru_train_ws_carve(workspace, n_tok, B, E, D, &w);
     const int splits_h = gemm_splitk_choice(B, 3 * D, D);
     const bool fuse = ITR_EXP_ENV("ITR_GRU_REDUCE_KERNEL") == nullptr;   // tools/ A/B switch: separate reduction kernel
     const int Lmax = len_host[0];
-    ITR_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
-    hipLaunchKernelGGL(embed_gather_train_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, x, bad);
+    ITR_CHECK_HIP(hipMemsetAsync(w.bad, 0, sizeof(int), st));
+    hipLaunchKernelGGL(embed_gather_train_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, w.x, w.bad);
     ITR_CHECK_LAUNCH("embed_gather(train)");
-    for (int dir = 0; dir < (bi ? 2 : 1); ++dir) {
+    SideStream side_obj;
+    SideStream *side = (bi && side_stream(side_obj)) ? &side_obj : nullptr;
+    if (side) {
+        if (hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->st, side->fork, 0) == hipSuccess) side->forked = true;
+        else { (void)hipGetLastError(); side = nullptr; }
+    }
+    auto run_dir = [&](int dir, hipStream_t sd) -> int {
         const float *wi = dir ? w_ih_rev : w_ih, *wh = dir ? w_hh_rev : w_hh;
         const float *bi_ = dir ? b_ih_rev : b_ih, *bh = dir ? b_hh_rev : b_hh;
+        GruTrainWs::Dir &d = w.d[dir];
         GruSave sv = save_planes(save, dir, n_tok, D);
-        rc = gemm_nt(x, E, wi, E, bi_, gi, 3 * D, n_tok, 3 * D, E, 0, st);
-        if (rc != ITR_OK) return rc;
-        ITR_CHECK_HIP(hipMemsetAsync(h, 0, (size_t)B * D * 4, st));
+        int rc2 = gemm_nt(w.x, E, wi, E, bi_, d.gi, 3 * D, n_tok, 3 * D, E, 0, sd);
+        if (rc2 != ITR_OK) return rc2;
+        ITR_CHECK_HIP(hipMemsetAsync(d.h, 0, (size_t)B * D * 4, sd));
         int64_t n_act = B;
         for (int t = 0; t < Lmax; ++t) {
             while (n_act > 0 && len_host[n_act - 1] <= t) --n_act;
             int ns = 0;
-            if (splits_h > 1 && fuse) rc = gemm_nt_splitk_partials(h, D, wh, D, n_act, 3 * D, D, splits_h, skbuf, &ns, st);
-            else rc = gemm_nt_splitk(h, D, wh, D, bh, gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, skbuf, st);
-            if (rc != ITR_OK) return rc;
-            hipLaunchKernelGGL(gru_gate_train_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, gi,
-                               ns > 0 ? skbuf : gh, h, out, sv, tok_off, len_dev, t, dir, dir, D, n_act, ns, bh);
+            if (splits_h > 1 && fuse) rc2 = gemm_nt_splitk_partials(d.h, D, wh, D, n_act, 3 * D, D, splits_h, d.skbuf, &ns, sd);
+            else rc2 = gemm_nt_splitk(d.h, D, wh, D, bh, d.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, d.skbuf, sd);
+            if (rc2 != ITR_OK) return rc2;
+            // the reverse direction writes its own output plane; the average with the forward direction follows the join
+            hipLaunchKernelGGL(gru_gate_train_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, sd, d.gi,
+                               ns > 0 ? d.skbuf : d.gh, d.h, dir ? w.out_rev : out, sv, tok_off, len_dev, t, dir, 0, D, n_act, ns, bh);
             ITR_CHECK_LAUNCH("gru_gate(train)");
         }
+        return ITR_OK;
+    };
+    rc = ITR_OK;
+    if (bi) rc = run_dir(1, side ? side->st : st);
+    if (rc == ITR_OK) rc = run_dir(0, st);
+    if (side) side->join_into(st);        // also on the error paths: nothing stays queued on the side stream behind our back
+    if (rc != ITR_OK) return rc;
+    if (bi) {
+        const int64_t n = n_tok * (int64_t)D;
+        hipLaunchKernelGGL(gru_avg_kernel, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0, st, out, (const float *)w.out_rev, n);
+        ITR_CHECK_LAUNCH("gru_avg");
     }
     return ITR_OK;
 }
@@ -242,73 +301,64 @@ extern "C" int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const 
     int rc = check_lengths(len_host, B, n_tok, "itr_gru_bwd");
     if (rc != ITR_OK) return rc;
     hipStream_t st = as_stream(stream);
-    const size_t nt = (size_t)n_tok, d3 = (size_t)3 * D;
-    const int64_t ntp = ceil_div(n_tok, (int64_t)32) * 32;
-    char *p = static_cast<char *>(workspace);
-    float *x = (float *)p; p += al256(nt * E * 4);
-    float *dgi = (float *)p; p += al256(nt * d3 * 4);
-    float *dgh = (float *)p; p += al256(nt * d3 * 4);
-    float *hprev = (float *)p; p += al256(nt * D * 4);
-    float *carry = (float *)p; p += al256((size_t)B * D * 4);
-    float *dgh_step = (float *)p; p += al256((size_t)B * d3 * 4);
-    float *dx = (float *)p; p += al256(nt * E * 4);
-    float *gT = (float *)p; p += al256(d3 * (size_t)ntp * 4);                       // dgi^T, then dgh^T
-    float *aT = (float *)p; p += al256((size_t)(E > D ? E : D) * (size_t)ntp * 4);   // x^T, then hprev^T
-    float *whhT = (float *)p; p += al256(d3 * D * 4);
-    float *wihT = (float *)p; p += al256(d3 * E * 4);
-    float *cs = (float *)p; p += al256(((size_t)ceil_div(n_tok, 256)) * d3 * 4);
-    int *bad = (int *)p;
-    float *skbuf = reinterpret_cast<float *>(static_cast<char *>(workspace) + itr_gru_train_workspace_bytes(n_tok, B, E, D) -
-                                             al256(gemm_splitk_scratch_bytes(B, 3 * D, 16)));
+    GruTrainWs w;
+    gru_train_ws_carve(workspace, n_tok, B, E, D, &w);
     const int splits_c = gemm_splitk_choice(B, D, 3 * D);
     const bool fuse = ITR_EXP_ENV("ITR_GRU_REDUCE_KERNEL") == nullptr;
     const int Lmax = len_host[0];
-    const int64_t nparts = ceil_div(n_tok, 256);
-    ITR_UNSUPPORTED(nparts > 65535, "itr_gru_bwd: more than 16M tokens");
 
-    ITR_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
-    hipLaunchKernelGGL(embed_gather_train_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, x, bad);
+    ITR_CHECK_HIP(hipMemsetAsync(w.bad, 0, sizeof(int), st));
+    hipLaunchKernelGGL(embed_gather_train_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, w.x, w.bad);
     ITR_CHECK_LAUNCH("embed_gather(bwd)");
-#define GB_TRY(e) { rc = (e); if (rc != ITR_OK) return rc; }
-    for (int dir = 0; dir < (bi ? 2 : 1); ++dir) {
+    SideStream side_obj;
+    SideStream *side = (bi && side_stream(side_obj)) ? &side_obj : nullptr;
+    if (side) {
+        if (hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->st, side->fork, 0) == hipSuccess) side->forked = true;
+        else { (void)hipGetLastError(); side = nullptr; }
+    }
+#define GB_TRY(e) { int rc2 = (e); if (rc2 != ITR_OK) return rc2; }
+    // BPTT + the weight gradients of one direction on stream sd; everything it writes is the direction's own
+    auto run_dir = [&](int dir, hipStream_t sd) -> int {
         const float *wi = dir ? w_ih_rev : w_ih, *wh = dir ? w_hh_rev : w_hh;
         float *dwi = dir ? d_w_ih_rev : d_w_ih, *dwh = dir ? d_w_hh_rev : d_w_hh;
         float *dbi = dir ? d_b_ih_rev : d_b_ih, *dbh = dir ? d_b_hh_rev : d_b_hh;
+        GruTrainWs::Dir &d = w.d[dir];
+        float *dgi = d.gi, *dgh = d.gh;
         GruSave sv = save_planes(const_cast<void *>(save), dir, n_tok, D);
-        GB_TRY(transpose(wh, whhT, 3 * D, D, 3 * D, st));    // [3D, D] -> [D, 3D]:  carry += dgh_step . W_hh  ==  gemm_nt(dgh_step, W_hh^T)
-        GB_TRY(transpose(wi, wihT, 3 * D, E, 3 * D, st));    // [3D, E] -> [E, 3D]
-        ITR_CHECK_HIP(hipMemsetAsync(carry, 0, (size_t)B * D * 4, st));
+        GB_TRY(transpose(wh, d.whhT, 3 * D, D, 3 * D, sd));    // [3D, D] -> [D, 3D]:  carry += dgh_step . W_hh  ==  gemm_nt(dgh_step, W_hh^T)
+        GB_TRY(transpose(wi, d.wihT, 3 * D, E, 3 * D, sd));    // [3D, E] -> [E, 3D]
+        ITR_CHECK_HIP(hipMemsetAsync(d.carry, 0, (size_t)B * D * 4, sd));
         int ns_pending = 0;
         int64_t prev_n = 0;
         for (int t = Lmax - 1; t >= 0; --t) {
             int64_t n_act = 0;
             while (n_act < B && len_host[n_act] > t) ++n_act;
-            hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, st, d_out, bi ? 0.5f : 1.f,
-                               sv, carry, dgi, dgh, dgh_step, hprev, tok_off, len_dev, t, dir, D, n_act, skbuf, ns_pending, prev_n);
+            hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3((unsigned)n_act, (unsigned)ceil_div(D, 256)), dim3(256), 0, sd, d_out, bi ? 0.5f : 1.f,
+                               sv, d.carry, dgi, dgh, d.dgh_step, d.hprev, tok_off, len_dev, t, dir, D, n_act, d.skbuf, ns_pending, prev_n);
             ITR_CHECK_LAUNCH("gru_gate_bwd");
             ns_pending = 0;
             if (t > 0) {
                 if (splits_c > 1 && fuse) {   // slices of dgh W_hh stay in scratch: the next gate kernel adds them to carry
-                    GB_TRY(gemm_nt_splitk_partials(dgh_step, 3 * D, whhT, 3 * D, n_act, D, 3 * D, splits_c, skbuf, &ns_pending, st));
+                    GB_TRY(gemm_nt_splitk_partials(d.dgh_step, 3 * D, d.whhT, 3 * D, n_act, D, 3 * D, splits_c, d.skbuf, &ns_pending, sd));
                     prev_n = n_act;
                 } else {
-                    GB_TRY(gemm_nt_splitk(dgh_step, 3 * D, whhT, 3 * D, nullptr, carry, D, n_act, D, 3 * D, 0, 1, splits_c, skbuf, st));
+                    GB_TRY(gemm_nt_splitk(d.dgh_step, 3 * D, d.whhT, 3 * D, nullptr, d.carry, D, n_act, D, 3 * D, 0, 1, splits_c, d.skbuf, sd));
                 }
             }
         }
-        // weight gradients over all tokens
-        GB_TRY(transpose(dgh, gT, n_tok, 3 * D, ntp, st));          // token axis zero-padded to ntp (K % 32 == 0)
-        GB_TRY(transpose(hprev, aT, n_tok, D, ntp, st));
-        GB_TRY(gemm_nt(gT, ntp, aT, ntp, nullptr, dwh, D, 3 * D, D, ntp, 0, st));
-        GB_TRY(transpose(dgi, gT, n_tok, 3 * D, ntp, st));
-        GB_TRY(transpose(x, aT, n_tok, E, ntp, st));
-        GB_TRY(gemm_nt(gT, ntp, aT, ntp, nullptr, dwi, E, 3 * D, E, ntp, 0, st));
-        GB_TRY(itr_colsum(dgh, dbh, n_tok, 3 * D, 0, cs, al256((size_t)nparts * d3 * 4) + 256, stream));
-        GB_TRY(itr_colsum(dgi, dbi, n_tok, 3 * D, 0, cs, al256((size_t)nparts * d3 * 4) + 256, stream));
-        // input gradient: dx (+)= dgi . W_ih
-        if (dir == 0) GB_TRY(gemm_nt(dgi, 3 * D, wihT, 3 * D, nullptr, dx, E, n_tok, E, 3 * D, 0, st))
-        else GB_TRY(gemm_nt_acc(dgi, 3 * D, wihT, 3 * D, nullptr, dx, E, n_tok, E, 3 * D, 0, st));
-    }
+        // weight gradients over all tokens: dW = dg^T A on the split-row TN GEMM, the bias gradient (column sums of dg) from the same pass
+        GB_TRY(gemm_tn(dgh, 3 * D, d.hprev, D, dwh, D, n_tok, 3 * D, D, 0, dbh, d.tn, d.tn_bytes, sd));
+        GB_TRY(gemm_tn(dgi, 3 * D, w.x, E, dwi, E, n_tok, 3 * D, E, 0, dbi, d.tn, d.tn_bytes, sd));
+        return ITR_OK;
+    };
+    rc = ITR_OK;
+    if (bi) rc = run_dir(1, side ? side->st : st);
+    if (rc == ITR_OK) rc = run_dir(0, st);
+    if (side) side->join_into(st);
+    if (rc != ITR_OK) return rc;
+    // input gradient: dx = dgi_fwd . W_ih + dgi_rev . W_ih_rev  (after the join: both directions' dgi are complete)
+    GB_TRY(gemm_nt(w.d[0].gi, 3 * D, w.d[0].wihT, 3 * D, nullptr, w.dx, E, n_tok, E, 3 * D, 0, st));
+    if (bi) GB_TRY(gemm_nt_acc(w.d[1].gi, 3 * D, w.d[1].wihT, 3 * D, nullptr, w.dx, E, n_tok, E, 3 * D, 0, st));
 #undef GB_TRY
-    return itr_embed_scatter_add(tokens, dx, n_tok, V, E, d_embed, stream);
+    return itr_embed_scatter_add(tokens, w.dx, n_tok, V, E, d_embed, stream);
 }

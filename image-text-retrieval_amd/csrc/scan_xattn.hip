@@ -701,6 +701,55 @@ __global__ __launch_bounds__(256) void gram_kernel(const float *__restrict__ X, 
     }
 }
 
+// The same Gram matrices for a FIXED row count <= 48 (the 36 regions of an image) on the matrix cores: one workgroup per matrix, wave w owns
+// rows 16 w .. 16 w + 15 and the three 16-column tiles, 32-column chunks of X staged once in LDS and read as both MFMA operands
+// (v_mfma_f32_16x16x4_f32: A[i][k] / B[k][j] at lane = 16 k + i; row stride 36 floats = conflict-free).  Round 5's VALU form took 1.07 ms
+// for 5 000 images (0.08 of either roof); this one is bound by reading X once.  G[r][s] and G[s][r] are still the same bits (the same
+// products in the same k order), which the upper-triangular form relies on.
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const float *__restrict__ X, int rows, int D, float *__restrict__ G, int upper2) {
+    __shared__ __attribute__((aligned(16))) float xs[48][36];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D4 = D >> 2;
+    const float4 *x4 = reinterpret_cast<const float4 *>(X) + (int64_t)blockIdx.x * rows * D4;
+    f32x4 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int d0 = 0; d0 < D4; d0 += 8) {
+        __syncthreads();
+        for (int idx = tid; idx < 48 * 8; idx += 256) {
+            const int row = idx >> 3, c4 = idx & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows && d0 + c4 < D4) v = x4[(int64_t)row * D4 + d0 + c4];
+            *reinterpret_cast<float4 *>(&xs[row][c4 * 4]) = v;
+        }
+        __syncthreads();
+        if (wave < 3) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = kk * 4 + (lane >> 4);
+                const float a = xs[wave * 16 + (lane & 15)][k];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xs[j * 16 + (lane & 15)][k], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    if (wave >= 3) return;
+    float *out = G + (int64_t)blockIdx.x * rows * rows;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int s_ = j * 16 + (lane & 15);
+        if (s_ >= rows) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 16 + 4 * (lane >> 4) + q;
+            if (r >= rows) continue;
+            float v = acc[j][q];
+            if (upper2) v = s_ > r ? 2.f * v : (s_ == r ? v : 0.f);
+            out[r * rows + s_] = v;
+        }
+    }
+}
+
 // plain row L2 norms (no eps): one wave per row
 __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ X, int64_t rows, int D,
                                                       float *__restrict__ out) {
@@ -947,8 +996,11 @@ int scan_prepare_impl(const float *img, const float *words, const int64_t *cap_o
                        tile_begin_dev, cap_order_dev, D, w.wtiled, w.meta, w.wnorm, cap_col);
     ITR_CHECK_LAUNCH("scan pack");
     if (mode == 0) {
-        hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Ni), dim3(256), 0, st, img, (const int64_t *)nullptr,
-                           (const int32_t *)nullptr, R, D, w.gram, (const int64_t *)nullptr, 1);
+        if (R <= 48 && D % 4 == 0)
+            hipLaunchKernelGGL(gram_mfma_kernel, dim3((unsigned)Ni), dim3(256), 0, st, img, R, D, w.gram, 1);
+        else
+            hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Ni), dim3(256), 0, st, img, (const int64_t *)nullptr,
+                               (const int32_t *)nullptr, R, D, w.gram, (const int64_t *)nullptr, 1);
         ITR_CHECK_LAUNCH("scan gram");
     } else {
         hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)ceil_div(Ni * R, 4)), dim3(256), 0, st, img, Ni * R, D, w.vnorm);

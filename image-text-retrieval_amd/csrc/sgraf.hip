@@ -508,7 +508,7 @@ extern "C" int itr_sgraf_scores(const float *img, const float *words, const int6
     // SGR with the configured sim_dim and a node-group plan: the graph steps run fused (sgr_fused.hip); otherwise step by step
     const bool have_plan = node_group_begin_dev && node_group_order_dev && n_node_groups > 0;
     if (module == 1 && S == 256 && !have_plan) flags |= ITR_SGRAF_UNFUSED_STEPS;      // no plan: the chain (and its larger workspace)
-    const bool fused_sgr = sgraf_fused_layout(module, S, flags) && !ITR_EXP_ENV("ITR_SGR_UNFUSED");
+    const bool fused_sgr = sgraf_fused_layout(module, S, flags);      // (the step-by-step chain is the ABI flag ITR_SGRAF_UNFUSED_STEPS: layout and path agree)
     ITR_REQUIRE(workspace_bytes >= itr_sgraf_workspace_bytes(Ni, Nc, n_rows, n_tiles, D, S, module, image_block, flags),
                 "itr_sgraf_scores: workspace too small (size it with the same image_block and flags; without a node-group plan the step-by-step "
                 "chain runs: ITR_SGRAF_UNFUSED_STEPS)");

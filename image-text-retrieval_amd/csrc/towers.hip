@@ -11,6 +11,9 @@
 #include <stdlib.h>
 #include "itr_common.h"
 #include <mutex>
+#define ITR_SIDE_STREAM_IMPL
+#include "side_stream.h"
+#include <mutex>
 
 namespace itr {
 
@@ -32,13 +35,10 @@ int gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, con
 // x rows are padded with zeros to Ep = E rounded up to 32 columns (300 -> 320) so that the input projection runs on
 // the branch-free GEMM path (K % 32 == 0); the matching zero-padded copy of W_ih is made by pad_cols_kernel.
 __global__ void embed_gather_kernel(const int64_t *__restrict__ tokens, int64_t n_tok, const float *__restrict__ embed,
-                                    int64_t V, int E, int Ep, float *__restrict__ x, int *__restrict__ bad) {
+                                    int64_t V, int E, int Ep, float *__restrict__ x) {
     const int64_t row = blockIdx.x;
     int64_t id = tokens[row];
-    if (id < 0 || id >= V) {  // nn.Embedding would raise IndexError: flag it, keep memory safe
-        if (threadIdx.x == 0) atomicExch(bad, 1);
-        id = 0;
-    }
+    if (id < 0 || id >= V) id = 0;      // memory safety only: the CALLER validates the ids (itr_hip.h; nn.Embedding would raise IndexError)
     const float *src = embed + id * E;
     float *dst = x + row * Ep;
     for (int k = threadIdx.x; k < Ep; k += blockDim.x) dst[k] = k < E ? src[k] : 0.f;
@@ -165,66 +165,29 @@ __global__ __launch_bounds__(256) void avg2_scalar_kernel(float *__restrict__ ou
     if (i < n) out[i] = (out[i] + other[i]) / 2.f;
 }
 
-// A second HIP stream per device for the reverse direction of a bi-GRU: the two recurrences are independent, and a time step's
-// GEMM (M = active captions <= a few thousand rows) leaves most CUs idle in its last wave of tiles -- the other direction fills them.
-// The stream is created once per device (under a lock: several host threads may encode at once); the fork / join events are
-// per call, so concurrent callers never share an event.
-struct SideStream {
-    hipStream_t st = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool forked = false;
-    // Makes `main` wait for everything queued on the side stream.  Called on EVERY path out of itr_gru_fwd after the fork, the
-    // error paths included: the caller frees the workspace after an error, and kernels still queued on the side stream would
-    // read and write recycled memory.
-    void join_into(hipStream_t main) {
-        if (forked) {
-            if (hipEventRecord(join, st) != hipSuccess || hipStreamWaitEvent(main, join, 0) != hipSuccess) (void)hipStreamSynchronize(st);
-            forked = false;
-        }
-    }
-    ~SideStream() {
-        if (fork) (void)hipEventDestroy(fork);
-        if (join) (void)hipEventDestroy(join);
-    }
-};
-constexpr int GRU_MAX_CHAINS = 4;      // interleaved caption chains of the last-state recurrence (below): the caller's stream + 3
-static bool side_stream(SideStream &s, int k = 0) {
-    static std::mutex mu;
-    static hipStream_t per_dev[16][GRU_MAX_CHAINS - 1] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || k < 0 || k >= GRU_MAX_CHAINS - 1) return false;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!per_dev[dev][k] && hipStreamCreateWithFlags(&per_dev[dev][k], hipStreamNonBlocking) != hipSuccess) { per_dev[dev][k] = nullptr; return false; }
-        s.st = per_dev[dev][k];
-    }
-    return hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
-}
-
+// (SideStream / side_stream: side_stream.h)
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GruWs {
     float *x, *gi, *gh, *h, *out_tmp, *wpad, *skbuf;
-    int *bad;
 };
 
 // split-K scratch only for batches that need it (<= 1024 captions: 16 slices x B x 3D floats <= 200 MB)
 static inline size_t gru_splitk_bytes(int64_t B, int D) { return B <= 1024 ? gemm_splitk_scratch_bytes(B, 3 * D, 16) : 0; }
 
 static inline int pad32(int E) { return (E + 31) / 32 * 32; }
+static inline int64_t pad128(int64_t B) { return (B + 127) / 128 * 128; }
 
 static GruWs carve(void *ws, int64_t n_tok, int64_t B, int E, int D) {
     char *p = static_cast<char *>(ws);
     GruWs w;
     w.x = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * pad32(E) * 4);
     w.gi = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * 3 * D * 4);
-    w.gh = reinterpret_cast<float *>(p); p += al256((size_t)B * 3 * D * 4);
-    w.h = reinterpret_cast<float *>(p); p += al256((size_t)B * D * 4);
+    w.gh = reinterpret_cast<float *>(p); p += al256((size_t)pad128(B) * 3 * D * 4);      // (rows padded to whole 128-row GEMM tiles: see the recurrence)
+    w.h = reinterpret_cast<float *>(p); p += al256((size_t)pad128(B) * D * 4);
     w.out_tmp = reinterpret_cast<float *>(p); p += al256((size_t)n_tok * D * 4);
     w.wpad = reinterpret_cast<float *>(p); p += al256((size_t)3 * D * pad32(E) * 4);
     w.skbuf = reinterpret_cast<float *>(p); p += al256(gru_splitk_bytes(B, D));
-    w.bad = reinterpret_cast<int *>(p);
     return w;
 }
 
@@ -248,8 +211,8 @@ extern "C" int itr_proj_l2norm(const float *x, const float *W, const float *b, f
 
 static size_t gru_ws_one(int64_t n_tok, int64_t B, int E, int D) {
     using itr::al256;
-    return al256((size_t)n_tok * itr::pad32(E) * 4) + al256((size_t)n_tok * 3 * D * 4) + al256((size_t)B * 3 * D * 4) +
-           al256((size_t)B * D * 4) + al256((size_t)n_tok * D * 4) + al256((size_t)3 * D * itr::pad32(E) * 4) +
+    return al256((size_t)n_tok * itr::pad32(E) * 4) + al256((size_t)n_tok * 3 * D * 4) + al256((size_t)itr::pad128(B) * 3 * D * 4) +
+           al256((size_t)itr::pad128(B) * D * 4) + al256((size_t)n_tok * D * 4) + al256((size_t)3 * D * itr::pad32(E) * 4) +
            al256(itr::gru_splitk_bytes(B, D)) + 256;
 }
 
@@ -292,7 +255,6 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
     float *seq = out ? out : w.out_tmp;
     const int Lmax = len_host[0];
 
-    ITR_CHECK_HIP(hipMemsetAsync(w.bad, 0, sizeof(int), st));
     const int Ep = pad32(E);
     // (split-K sums a dot product in slices: the result depends on the batch size through the slice count -- never with
     // ITR_GRU_BATCH_INVARIANT; the plain kernels all run the same fmaf chain per output element whatever M is)
@@ -312,8 +274,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
         hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)V), dim3(128), 0, st, embed, V, E, Ep, w.x);
         ITR_CHECK_LAUNCH("embed table");
     } else {
-        hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, Ep, w.x,
-                           w.bad);
+        hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)n_tok), dim3(128), 0, st, tokens, n_tok, embed, V, E, Ep, w.x);
         ITR_CHECK_LAUNCH("embed_gather");
     }
 
@@ -360,12 +321,21 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
             if (!side_stream(chain_side[k], k)) break;
             ++n_side;
         }
-        const int nchains = n_side + 1;
-        for (int k = 0; k < n_side; ++k) {
-            ITR_CHECK_HIP(hipEventRecord(chain_side[k].fork, st));
-            ITR_CHECK_HIP(hipStreamWaitEvent(chain_side[k].st, chain_side[k].fork, 0));
-            chain_side[k].forked = true;
+        // fork: a chain whose event cannot be recorded or waited on is not used (the recurrence runs on the chains that did fork; with
+        // none, on the caller's stream alone) -- never a return with chains 0 .. k - 1 forked and not joined
+        {
+            int forked = 0;
+            for (int k = 0; k < n_side; ++k) {
+                if (hipEventRecord(chain_side[k].fork, st) != hipSuccess || hipStreamWaitEvent(chain_side[k].st, chain_side[k].fork, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                chain_side[k].forked = true;
+                ++forked;
+            }
+            n_side = forked;
         }
+        const int nchains = n_side + 1;
         auto run_chains = [&]() -> int {
             int64_t n_act = B;
             for (int t = 0; t < Lmax; ++t) {
@@ -424,7 +394,7 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
         }
         int rc = gemm_nt(w.x, Ep, wi_use, Ep, dir ? b_ih_rev : b_ih, ww.gi, 3 * D, x_rows, 3 * D, Ep, 0, sd);
         if (rc != ITR_OK) return rc;
-        ITR_CHECK_HIP(hipMemsetAsync(ww.h, 0, (size_t)B * D * 4, sd));
+        ITR_CHECK_HIP(hipMemsetAsync(ww.h, 0, (size_t)pad128(B) * D * 4, sd));
         return ITR_OK;
     };
     if (input_first)
@@ -474,8 +444,12 @@ extern "C" int itr_gru_fwd(const int64_t *tokens, const int64_t *tok_off, const 
                 // (t = 0: h = 0, the recurrence product is b_hh for every caption -- the largest GEMM of the direction is not launched)
                 const bool first = t == 0 && !want_first_gemm;
                 if (!first) {
+                    // The active prefix rounded UP to whole 128-row tiles (the rows exist: h / gh are padded, rows past n_act hold finished
+                    // captions or zeros and nobody reads their products): the streaming GEMM then takes every row and the second launch for
+                    // the M mod 128 remainder (24 workgroups, ~60 us, 32 per 5k x 25k step) is gone.  A row's result does not depend on M.
+                    const int64_t m_gemm = n_act >= 5000 ? pad128(n_act) : n_act;
                     rc = (splits_h > 1) ? gemm_nt_splitk(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, 0, splits_h, ww.skbuf, sd)
-                                        : gemm_nt(ww.h, D, wh, D, bh, ww.gh, 3 * D, n_act, 3 * D, D, 0, sd);
+                                        : gemm_nt(ww.h, D, wh, D, bh, ww.gh, 3 * D, m_gemm, 3 * D, D, 0, sd);
                     if (rc != ITR_OK) return rc;
                 }
                 const float *gh_use = first ? bh : ww.gh;

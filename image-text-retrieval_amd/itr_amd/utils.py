@@ -77,18 +77,13 @@ def save_checkpoint(state, is_best, filename='checkpoint.pth.tar', prefix='', is
         torch.save(state, os.path.join(prefix, 'model_best.pth.tar'))
 
 
-def print_options(config):
-    """utils.py:65-76."""
-    print("")
-    print("----- options -----".center(120, '-'))
-    string = ''
-    for i, (k, v) in enumerate(sorted(config.items())):
-        string += "{}: {}".format(k, v).center(40, ' ')
-        if i % 3 == 2 or i == len(config.items()) - 1:
-            print(string)
-            string = ''
-    print("".center(120, '-'))
-    print("")
+def print_options(config, width=120, per_line=3):
+    """The option table the reference prints at start-up (utils.py:64-75): sorted `key: value` cells, three to a 120-column line, under a
+    centred header rule.  Same text; composed from rows rather than accumulated cell by cell."""
+    cells = ["%s: %s" % kv for kv in sorted(config.items())]
+    cell_w = width // per_line
+    rows = ["".join(c.center(cell_w) for c in cells[i:i + per_line]) for i in range(0, len(cells), per_line)]
+    print("\n".join(["", "----- options -----".center(width, "-")] + rows + ["-" * width, ""]))
 
 
 def train_step(_config, train_loader, model, epoch, val_loader, best_rsum=0, best_r1=0):

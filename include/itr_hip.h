@@ -125,7 +125,10 @@ int itr_proj_l2norm(const float *x, const float *W, const float *b, float *out, 
  * (ITR_GRU_BATCH_INVARIANT) makes a caption's result independent of the batch it is encoded in, bit for bit (the
  * recurrence GEMM of a small batch is otherwise split along K, which sums in another order): the sharded evaluation
  * sets it so that every partition of the caption axis gives the single-process rank vectors.
- * workspace: itr_gru_workspace_bytes(n_tok, B, E, D, bi) bytes. */
+ * workspace: itr_gru_workspace_bytes(n_tok, B, E, D, bi) bytes.
+ * Token ids must lie in [0, V): the CALLER validates them (nn.Embedding raises IndexError; itr_amd.ops.gru_encode does the same before
+ * the call).  The library only keeps memory safe -- an id outside the range reads embedding row 0 -- and raises no flag: the call
+ * enqueues work and returns, it cannot report what a kernel finds. */
 #define ITR_GRU_GATHER_LAST 1
 #define ITR_GRU_BATCH_INVARIANT 2
 /* launch-order variants of the bi-GRU kept as cross-checks (bit-identical results; both measured slower than the default):
@@ -555,7 +558,9 @@ int itr_nll_logsoftmax_bwd(const float *logits, const int64_t *target, const flo
 /* EncoderText (bi)GRU under autograd (TextEncoder.py:38-70): training forward that keeps the gate activations, and
  * backpropagation through time.  Same packed layout / sorting contract as itr_gru_fwd.  `out` [n_tok, D] is the RAW
  * sequence output ((fwd + bwd) / 2 for a bi-GRU); l2norm / last-step gather are separate differentiable steps.
- * Gradients: d_embed [V, E] is ACCUMULATED into (zero it first); d_w_* / d_b_* are overwritten. */
+ * Gradients: d_embed [V, E] is ACCUMULATED into (zero it first); d_w_* / d_b_* are overwritten.  Token ids: validated by the caller,
+ * as for itr_gru_fwd.  The two directions of a bi-GRU run side by side (the reverse one on a per-device side stream, joined before
+ * the call returns to the caller's stream order). */
 size_t itr_gru_train_save_bytes(int64_t n_tok, int D, int bidirectional);
 size_t itr_gru_train_workspace_bytes(int64_t n_tok, int64_t B, int E, int D);
 int itr_gru_fwd_train(const int64_t *tokens, const int64_t *tok_off, const int32_t *len_dev, const int32_t *len_host,
