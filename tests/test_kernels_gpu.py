@@ -658,13 +658,17 @@ def test_sgraf_block_shrinks_to_the_memory_that_is_free(dev, mod):
     keep = ws[32] + (ws[64] - ws[32]) // 2                       # between the two sizes: 0.9 x keep admits at most 32 images
     hog = []
     try:
+        # what ops._sgraf_workspace budgets with: free device memory + what torch's caching allocator holds unused (blocks of earlier
+        # calls the allocator can hand out again -- the workspace of call (a) may still sit there whatever empty_cache released)
+        def avail():
+            free_, _ = torch.cuda.mem_get_info(dev)
+            return free_ + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         while True:                                              # (in pieces: one 280 GB request can fail on a fragmented address space)
-            free, _ = torch.cuda.mem_get_info(dev)
-            take = min(free - keep, 8 << 30)
+            take = min(avail() - keep, 8 << 30)
             if take < (1 << 20):
                 break
             hog.append(torch.empty(take, device=dev, dtype=torch.uint8))
-        free, _ = torch.cuda.mem_get_info(dev)
+        free = avail()
         assert free < ws[64], (free, ws)
         got = ops.sgraf_padded(img, cap, lens, wd, mod, steps)
         assert ops.SGRAF_LAST_BLOCK["image_block"] in (8, 16, 32) and not ops.SGRAF_LAST_BLOCK["pinned"], (ops.SGRAF_LAST_BLOCK, free, ws)
