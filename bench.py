@@ -444,7 +444,9 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
     pe = evalpipe.PooledModelEval(model, comm, batch=int(os.environ.get('ITR_POOLED_BATCH', '4096')))
     timers = dict(scan_start=torch.cuda.Event(enable_timing=True), scan_end=torch.cuda.Event(enable_timing=True))
 
-    def step(tm=None):
+    def step(tm=None, keep=True):
+        # --stream-scores (opt-in, one process): the timed steps keep no matrix -- one larger than 64 MB is streamed through the ranker in
+        # cache-sized row blocks (evalpipe.score_rank_streamed; measured slower than writing it once: profiles/r06/NOTES.md); S is None then
         if gru_text:
             if kind == "VSRN":
                 with torch.no_grad():
@@ -462,13 +464,15 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
                     blk = torch.empty_like(e)
                     blk[torch.from_numpy(np.ascontiguousarray(p[3])).to(dev)] = e
                     comm.peer_blocks[q] = blk
+            if not keep and not comm.on and not comm.virtual and 4 * n_img * n_cap > (64 << 20):
+                return None, evalpipe.score_rank_streamed(img, send[:n_cap], ops.cosine_scores, 5, timers=tm)
             S = evalpipe.exchange_score(comm, img, send, cap_ranges, n_cap, ops.cosine_scores, tm)
             return S, evalpipe.finalize_ranks(comm, S, i0, n_img, 5)
         if comm.virtual:
             comm.peer_blocks = {q: pe.encode_captions(ids[lo:hi], mask[lo:hi], types[lo:hi], [int(x) for x in lengths[lo:hi]])
                                 for q, (lo, hi) in enumerate(cap_ranges) if q != comm.cap_rank and hi > lo}
         return pe.eval(feats[i0:i1], boxes[i0:i1], imgs_wh[i0:i1], ids[c0:c1], mask[c0:c1], types[c0:c1], [int(x) for x in lengths[c0:c1]],
-                       n_img, n_cap, timers=tm, cap_ranges=cap_ranges)
+                       n_img, n_cap, timers=tm, cap_ranges=cap_ranges, stream_scores=not keep)
 
     def barrier():
         if use_dist:
@@ -476,14 +480,14 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        step(keep=not args.stream_scores)
     barrier()
     score_ms = []
     t0 = time.perf_counter()
     S = ranks = None
     for _ in range(args.steps):
         S = ranks = None          # as a validation loop would: the previous score matrix is released before the next evaluation
-        S, ranks = step(timers)   # (holding it makes the caching allocator grow by 0.5 GB inside the timed region, once)
+        S, ranks = step(timers, keep=not args.stream_scores)   # (holding it makes the caching allocator grow by 0.5 GB inside the timed region, once)
         score_ms.append(timers["scan_start"].elapsed_time(timers["scan_end"]))
     barrier()
     dt = time.perf_counter() - t0
@@ -491,6 +495,13 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    streamed = S is None
+    if streamed and world == 1:
+        # outside the timed region: the same evaluation with the matrix kept -- the parity legs below read it, and its ranks must be
+        # the streamed ones, entry for entry
+        S, ranks_kept = step(None, keep=True)
+        torch.cuda.synchronize()
+        streamed_equal = all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(ranks, ranks_kept))
     if rank != 0:
         return None
     from itr_amd import ops as _ops
@@ -540,6 +551,13 @@ def main_pooled(args, wl, world, rank, dev, use_dist):
                                 "(= SURVEY 8d's per-unit figures, except VSE++: its last-state output needs one step of the backward GRU, "
                                 "not its recurrence, the input projection runs once per vocabulary word and a caption's first step has no "
                                 "recurrence product); algorithmic_equiv_frac = SURVEY 8d's flop over the same time"}}
+    if streamed and world == 1:
+        out["score_matrix"] = {"materialised": False, "row_block_bytes": 64 << 20,
+                               "ranks_equal_materialised_run": bool(streamed_equal),
+                               "note": "timed steps stream the similarity matrix through the ranker in row blocks (evalpipe.score_rank_streamed); "
+                                       "a run that keeps the matrix (after the timed region) gave the same rank vectors"}
+        if not streamed_equal:
+            print("bench.py: the streamed ranks differ from the ranks of the materialised matrix", file=sys.stderr)
     if comm.virtual:
         out["virtual_split"] = "%d:%d" % (comm.cap_world, comm.cap_rank)
         out["config"]["parallelism"] = "1 process, caption axis split over %d virtual owners (this one: %d): TEST HOOK, time is not a result" % (
@@ -942,6 +960,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the separately reported fp16x3 variant of the SCAN workloads")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of the other BASELINE.json configs that the default workload's line carries in `other_configs`")
+    ap.add_argument("--stream-scores", action="store_true",
+                    help="pooled workloads, one process: the timed steps stream the similarity matrix through the ranker in row blocks instead "
+                         "of storing it (evalpipe.score_rank_streamed); measured slower, off by default")
     ap.add_argument("--no-train-configs", action="store_true",
                     help="skip the training-step timings (model.train_emb of every family, tools/train_bench.py in a child process) that the "
                          "default workload's line carries in `train_configs`")

@@ -477,7 +477,7 @@ extern "C" int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t 
     ITR_REQUIRE(A && B && C, "itr_gemm_nt: null pointer");
     // lda < K is allowed: overlapping A rows express a convolution over consecutive rows (SAEM conv head)
     ITR_REQUIRE(lda >= 1 && ldb >= K && ldc >= N, "itr_gemm_nt: leading dimension smaller than row");
-    ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt: unknown activation %d", act);
+    ITR_REQUIRE(act >= 0 && act <= 6, "itr_gemm_nt: unknown activation %d", act);
     return itr::gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream));
 }
 

@@ -109,6 +109,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case 3: return 1.f / (1.f + expf(-v));
         case 4: return gelu_erf(v);
         case 5: return v > 0.f ? v : 0.1f * v;
+        case 6: return v != v ? 0.f : v;      // NaN -> 0 (pdist_cos: `res[res != res] = 0`, Objectives.py:321)
         default: return v;
     }
 }

@@ -471,6 +471,50 @@ def exchange_score(comm, img, send, ranges, n_cap_total, score_fn, timers=None):
     return S
 
 
+def score_rank_streamed(img, cap, score_fn, im_div=5, budget_bytes=64 << 20, rows_per_block=None, timers=None):
+    """One process, pooled scorers: the Recall ranks of score_fn(img, cap) WITHOUT the similarity matrix in HBM (SURVEY 7 step 3, 2.3 K4
+    "fuse with K9"; the reference builds the full float64 matrix and argsorts it, evaluation.py:124-153, :169, :209).
+
+    The matrix is produced in row blocks of <= budget_bytes (64 MB: a quarter of the 256 MB Infinity Cache) into ONE reused buffer and
+    every block is ranked at once by the one-pass count kernel, whose column accumulators add up over row blocks by design (the same
+    call the row-sharded evaluation makes per rank): the ranker reads what the GEMM has just written from the cache, and the next
+    block overwrites it there -- the 0.5 GB write and read-back of the 5k x 25k matrix never reach HBM as such.  The ground-truth
+    scores the column counts compare against come from a first pass over the diagonal band (block rows x their im_div x rows captions:
+    1 / 20 of the products at 5k x 25k), computed by the same GEMM kernels in the same k order: bit-identical to the band's elements
+    of the full rows (tests/test_kernels_gpu.py checks the ranks against the materialised matrix, ties included).
+    MEASURED (round 6, same box): slower than materialising -- SAEM 5k x 25k score + rank 1.54 ms against 0.99, CAMERA 58.9 ms against
+    51.4: the band is 5 rows_per_block / Nc = 13 % more products at 640-row blocks and eight launches have eight tails, while the
+    0.5 GB round trip it saves is 0.25 ms at HBM speed.  So this is an opt-in (PooledModelEval.eval(stream_scores=True),
+    bench.py --stream-scores), for a process that cannot afford the 0.5 GB; the default writes the matrix once.
+    -> the tuple finalize_ranks returns."""
+    Ni, Nc = img.shape[0], cap.shape[0]
+    dev = img.device
+    rb = rows_per_block or max(128, (budget_bytes // (4 * max(Nc, 1))) // 128 * 128)
+    if timers is not None:
+        timers['scan_start'].record()
+    buf = torch.empty(min(rb, Ni) * Nc, device=dev, dtype=torch.float32)
+    s_gt = torch.full((Nc,), float('-inf'), device=dev, dtype=torch.float32)
+    for r0 in range(0, Ni, rb):                      # pass 1: the band -> ground-truth score of every caption
+        r1 = min(Ni, r0 + rb)
+        c0, c1 = min(Nc, r0 * im_div), min(Nc, r1 * im_div)
+        if c1 > c0:
+            band = score_fn(img[r0:r1], cap[c0:c1], out=buf[:(r1 - r0) * (c1 - c0)].view(r1 - r0, c1 - c0))
+            ops.gather_gt(band, im_div, 0, s_gt[c0:c1])
+    t_rank = torch.zeros(Nc, device=dev, dtype=torch.int32)
+    t_best = torch.zeros(Nc, device=dev, dtype=torch.int64)
+    i_rank, i_top = [], []
+    for r0 in range(0, Ni, rb):                      # pass 2: a row block of scores, ranked while it is still in the cache
+        r1 = min(Ni, r0 + rb)
+        blk = score_fn(img[r0:r1], cap, out=buf[:(r1 - r0) * Nc].view(r1 - r0, Nc))
+        ir, it, _, _, _ = ops.rank_counts(blk, im_div, r0, s_gt, t_rank, t_best)
+        i_rank.append(ir)
+        i_top.append(it)
+    if timers is not None:
+        timers['scan_end'].record()
+    both = torch.stack([torch.cat(i_rank), torch.cat(i_top)], 1).cpu().numpy() if i_rank else np.zeros((0, 2), np.int64)
+    return both[:, 0].astype(np.int64), both[:, 1].astype(np.int64), t_rank.cpu().numpy().astype(np.int64), (t_best & 0xffffffff).cpu().numpy()
+
+
 class PooledModelEval:
     """Sharded evaluation of the models whose caption embedding is ONE vector (VSE++, SAEM, CAMERA):
     rank p encodes its image rows and its caption slice in batches, ONE all-gather moves the caption embeddings
@@ -528,9 +572,11 @@ class PooledModelEval:
         return self.encode_images(images, boxes, imgs_wh), self.encode_captions(captions, captions_mask, captions_type_ids, lengths)
 
     def eval(self, images, boxes, imgs_wh, captions, captions_mask, captions_type_ids, lengths, n_img_total, n_cap_total,
-             im_div=5, timers=None, cap_emb=None, cap_ranges=None):
+             im_div=5, timers=None, cap_emb=None, cap_ranges=None, stream_scores=False):
         """cap_emb: this owner's caption embeddings when the caller has run the text tower already -- its count rows, or
-        a buffer of max-count rows whose head they are."""
+        a buffer of max-count rows whose head they are.  stream_scores=True (one process, opt-in): only the ranks are wanted -- the
+        similarity matrix is streamed through the ranker in cache-sized row blocks and never stored (score_rank_streamed); S is None
+        then.  Not the default: measured SLOWER than writing the matrix once (profiles/r06/NOTES.md)."""
         comm = self.comm
         kw, kr = comm.cap_world, comm.cap_rank
         ranges = cap_ranges or [block_range(n_cap_total, kw, q) for q in range(kw)]
@@ -545,6 +591,8 @@ class PooledModelEval:
             send[:cap_emb.shape[0]] = cap_emb
             send[cap_emb.shape[0]:].zero_()       # (the tail travels with the exchange: defined values)
         img = self.encode_images(images, boxes, imgs_wh)
+        if stream_scores and not comm.on and not comm.virtual and img.shape[0] == n_img_total and 4 * n_img_total * n_cap_total > (64 << 20):
+            return None, score_rank_streamed(img, send[:n_cap_total], self._score, im_div, timers=timers)
         S = exchange_score(comm, img, send, ranges, n_cap_total, self._score, timers)
         row0 = block_range(n_img_total, comm.world, comm.rank, _IMG_ALIGN)[0]
         return S, finalize_ranks(comm, S, row0, n_img_total, im_div)

@@ -17,7 +17,7 @@ SCAN_R = 36            # regions per image the fused SCAN / SGRAF kernels are bu
 _NORMS = {'clipped_l2norm': 0, 'l2norm': 1, 'softmax': 2, 'no_norm': 3, 'clipped': 4, 'l1norm': 5,
           'clipped_l1norm': 6}
 _AGGS = {'LogSumExp': 0, 'Max': 1, 'Sum': 2, 'Mean': 3}
-_ACTS = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'gelu': 4, 'leaky_relu': 5}
+_ACTS = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'gelu': 4, 'leaky_relu': 5, 'nan_to_zero': 6}
 
 
 def _stream():
@@ -203,10 +203,19 @@ def cosine_scores(im, s, out=None):
 
 def pdist_cos(x1, x2, out=None):
     """Objectives.pdist_cos (:310-323): rows / ||row|| (no eps), mm, NaN -> 0."""
+    lib = _lib.load()
     a = _norm(x1, -1, 0.0, 3)
     b = _norm(x2, -1, 0.0, 3)
-    res = cosine_scores(a, b, out=out)
-    return torch.nan_to_num_(res, nan=0.0, posinf=float('inf'), neginf=float('-inf'))
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError("pdist_cos: expected (Ni, D) and (Nc, D), got %s and %s" % (tuple(a.shape), tuple(b.shape)))
+    if FP16X3 or BF16X3:      # study routing: the split-precision GEMMs have no NaN epilogue
+        return torch.nan_to_num_(cosine_scores(a, b, out=out), nan=0.0, posinf=float('inf'), neginf=float('-inf'))
+    # `res[res != res] = 0` (:321) rides in the GEMM's epilogue (activation code 6): no second pass over the matrix
+    S = _score_out(out, a.shape[0], b.shape[0], a.device, "pdist_cos")
+    ldS = S.stride(0) if S.shape[0] > 1 else max(S.shape[1], S.stride(0))
+    _lib.check(lib.itr_gemm_nt(_p(a), a.shape[1], _p(b), a.shape[1], _p(None), _p(S), ldS, a.shape[0], b.shape[0], a.shape[1], _ACTS['nan_to_zero'],
+                               _stream()))
+    return S
 
 
 def split_bf16(x):

@@ -73,7 +73,8 @@ int itr_gcn_relation(const float *tpg, int64_t ld, float *y, int64_t ldy, int64_
 
 /* ---- generic fp32 MFMA GEMM used by the towers ----------------------------------------
  * C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]);  lda/ldb/ldc are row strides in elements.
- * bias may be NULL.  lda < K is allowed (overlapping A rows = a convolution over consecutive rows).  act: 0 none, 1 relu, 2 tanh, 3 sigmoid, 4 gelu(erf), 5 leaky_relu(0.1).
+ * bias may be NULL.  lda < K is allowed (overlapping A rows = a convolution over consecutive rows).  act: 0 none, 1 relu, 2 tanh, 3 sigmoid, 4 gelu(erf), 5 leaky_relu(0.1),
+ * 6 NaN -> 0 (itr_gemm_nt only: pdist_cos' `res[res != res] = 0`, Objectives.py:321, without a second pass over the matrix).
  * Exact fp32 (v_mfma_f32_32x32x2_f32).  Replaces nn.Linear / torch.mm call sites on the path
  * (ImgEncoder.py:137, Objectives.py:21, Fusionmodule.py:427-431 ...). */
 int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,

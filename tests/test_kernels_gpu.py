@@ -85,6 +85,17 @@ def test_mvm_and_pdist_golden(golden, dev):
     assert maxdiff(ops.mvm_scores(imgs, T(g["caps_sq"]).to(dev)), g["mvm_sq"]) <= 2e-6
     assert maxdiff(ops.mvm_scores(imgs, T(g["caps_ns"]).to(dev)), g["mvm_ns"]) <= 2e-6
     assert maxdiff(ops.pdist_cos(T(g["x1"]).to(dev), T(g["x2"]).to(dev)), g["pdist_cos"]) <= 2e-6
+    # a zero row is 0 / 0 = NaN after the eps-free normalisation; the reference zeroes those scores (Objectives.py:321) -- here in the
+    # GEMM's epilogue, for every kernel the shape may select (tile, streaming, unaligned)
+    for Ni, Nc, D in ((5, 7, 12), (300, 1100, 256), (13000, 1300, 256)):
+        torch.manual_seed(Ni)
+        x1, x2 = torch.randn(Ni, D), torch.randn(Nc, D)
+        x1[2] = 0
+        x2[3] = 0
+        got = ops.pdist_cos(x1.to(dev), x2.to(dev))
+        want = O.pdist_cos(x1, x2)
+        assert bool(torch.isfinite(got).all()) and float(got[2].abs().max()) == 0 and float(got[:, 3].abs().max()) == 0
+        assert maxdiff(got, want) <= 2e-6
 
 
 @pytest.mark.parametrize("Ni,k,Nc,D", [(50, 12, 333, 256), (11, 12, 7, 2048), (130, 5, 200, 64)])
@@ -676,6 +687,37 @@ def test_sgraf_block_shrinks_to_the_memory_that_is_free(dev, mod):
     finally:
         del hog
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kind", ["cosine", "cosine_ties", "mvm", "pdist_cos"])
+def test_streamed_score_rank_equals_the_materialised_matrix(dev, kind):
+    """SURVEY 7 step 3 / 2.3 K4 + K9: the pooled scorers' ranks without the similarity matrix in HBM (evalpipe.score_rank_streamed: row
+    blocks through one reused buffer, ranked while cached; ground-truth scores from a first pass over the diagonal band).  Entry for
+    entry the ranks of the materialised matrix -- also with massive exact ties (embeddings quantised to a few values: every
+    comparison against a ground-truth score that is off by one ulp would show), ragged last block, captions of the last image missing."""
+    from itr_amd import evalpipe
+    torch.manual_seed(5)
+    Ni, D = 700, 64
+    Nc = 5 * Ni - 3
+    if kind == "mvm":
+        img = torch.randn(Ni, 12, D, device=dev)
+        fn = ops.mvm_scores
+    else:
+        img = torch.randn(Ni, D, device=dev)
+        fn = ops.pdist_cos if kind == "pdist_cos" else ops.cosine_scores
+    cap = torch.randn(Nc, D, device=dev)
+    if kind == "cosine_ties":
+        img, cap = torch.round(img), torch.round(cap)            # integer-valued: products are exact, scores collide by the thousand
+    if kind == "pdist_cos":
+        cap[17] = 0                                               # a NaN column before the epilogue zeroes it
+    S = fn(img, cap)
+    want = evalpipe.finalize_ranks(evalpipe.Comm(), S, 0, Ni, 5)
+    for rb in (128, 256):
+        got = evalpipe.score_rank_streamed(img, cap, fn, 5, rows_per_block=rb)
+        for a, b, name in zip(got, want, ("i2t_rank", "i2t_top1", "t2i_rank", "t2i_top1")):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), (kind, rb, name, int((np.asarray(a) != np.asarray(b)).sum()))
+    if kind == "cosine_ties":
+        assert len(np.unique(S.cpu().numpy())) < S.numel() // 100        # (the tie case is one)
 
 
 # ------------------------------------------------------------------------------------------ GRU
