@@ -394,10 +394,17 @@ int gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, con
 
 // Slices only: scratch[s][m][n] (s < *n_slices) holds the raw partial products; the CONSUMER adds them (in slice order) --
 // the GRU gate kernels do, which saves one launch and one pass per time step.
+bool gemm_skinny_ok(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int64_t N, int64_t K);      // gemm_skinny.hip
+int gemm_skinny_partials(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int64_t N, int64_t K, int max_slices, float *part,
+                         int *n_slices, hipStream_t st);
 int gemm_nt_splitk_partials(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int64_t N, int64_t K, int splits, float *scratch,
                             int *n_slices, hipStream_t st) {
     *n_slices = 0;
     if (M == 0 || N == 0) return ITR_OK;
+    // M <= 128 rows (a training batch's recurrence): 16-column strips over all rows instead of one 128-row tile per 128 columns
+    // (gemm_skinny.hip); the caller's scratch holds 16 slices of M x N, the consumer adds whatever number of slices comes back
+    if (splits > 1 && !ITR_EXP_ENV("ITR_GEMM_NO_SKINNY") && gemm_skinny_ok(A, lda, B, ldb, M, N, K))
+        return gemm_skinny_partials(A, lda, B, ldb, M, N, K, 16, scratch, n_slices, st);
     const int64_t ksplit = ceil_div(ceil_div(K, (int64_t)(splits > 1 ? splits : 1)), (int64_t)BK) * BK;
     const int ns = (int)ceil_div(K, ksplit);
     GemmArgs g{A, B, nullptr, scratch, lda, ldb, N, M, N, K, 0, 1, BM, nullptr, nullptr, 0, 0, ksplit, scratch};

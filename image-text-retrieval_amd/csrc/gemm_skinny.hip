@@ -1,0 +1,111 @@
+// fp32 NT GEMM for a SKINNY left operand (M <= 128 rows: the GRU recurrence of a training batch, h [n_act, D] . W_hh^T, and its
+// transpose in BPTT -- TextEncoder.py:38-56 under autograd; 80 of them per train_emb step of a bi-GRU model), as raw split-K partials.
+//
+// The 128 x 128 tile kernel sees ONE row tile here: 24 column tiles x 8 K slices of 128 columns each -- a workgroup's life is its
+// prologue and epilogue, 31 us per product against a matrix-core floor of 7 (0.8 GFLOP + tile padding at 157 TFLOP/s).  This kernel
+// turns the shape around: a workgroup owns 16 OUTPUT COLUMNS for all rows and one K slice; the rows' 64-wide K chunks stream through LDS
+// (double buffered, the next chunk's global loads in flight under the MFMAs of the current one), each wave multiplies two 16-row tiles
+// against the one 16-column tile on v_mfma_f32_16x16x4_f32 (operands [row][k] at row stride 68 floats: lane = 16 k + i hits 64 distinct
+// banks).  Grid = (N / 16) x slices, slices chosen for ~1.5 workgroups per CU; the slices' partial products are written one after the other
+// ([slice][m][n]) and summed -- in slice order, with the bias -- by the GRU gate kernels that consume them, exactly as the tile kernel's
+// slices were.  Row tiles past the active prefix are skipped by whole waves.
+#include "itr_common.h"
+
+namespace itr {
+
+constexpr int SK_KC = 64, SK_LD = SK_KC + 4, SK_MAXM = 128;
+
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, int M,
+                                                          int64_t N, int K, int kslice, float *__restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float As[2][SK_MAXM][SK_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16][SK_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    const int k_begin = blockIdx.y * kslice;
+    const int k_end = k_begin + kslice < K ? k_begin + kslice : K;
+    const int rtiles = (M + 15) >> 4;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float4 ra[8], rb;
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 4, c4 = (idx & 15) * 4;
+            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < M && k0 + c4 < k_end) ra[j] = *reinterpret_cast<const float4 *>(A + (int64_t)row * lda + k0 + c4);
+        }
+        {
+            const int row = tid >> 4, c4 = (tid & 15) * 4;
+            rb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + row < N && k0 + c4 < k_end) rb = *reinterpret_cast<const float4 *>(B + (n0 + row) * ldb + k0 + c4);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 4, c4 = (idx & 15) * 4;
+            *reinterpret_cast<float4 *>(&As[buf][row][c4]) = ra[j];
+        }
+        *reinterpret_cast<float4 *>(&Bs[buf][tid >> 4][(tid & 15) * 4]) = rb;
+    };
+    if (k_begin < k_end) {
+        fetch(k_begin);
+        park(0);
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = k_begin; k0 < k_end; k0 += SK_KC) {
+            const bool more = k0 + SK_KC < k_end;
+            if (more) fetch(k0 + SK_KC);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rt = wave + 4 * t;
+                if (rt < rtiles) {
+#pragma unroll
+                    for (int kk = 0; kk < SK_KC / 4; ++kk) {
+                        const int k = kk * 4 + (lane >> 4);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[buf][rt * 16 + (lane & 15)][k], Bs[buf][lane & 15][k], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            if (more) park(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    float *o = part + (int64_t)blockIdx.y * M * N;
+    const int64_t n = n0 + (lane & 15);
+    if (n < N) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int rt = wave + 4 * t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = rt * 16 + 4 * (lane >> 4) + q;
+                if (m < M) o[(int64_t)m * N + n] = acc[t][q];
+            }
+        }
+    }
+}
+
+bool gemm_skinny_ok(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+    return M >= 1 && M <= SK_MAXM && N >= 16 && K >= SK_KC && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && K <= 0x7fffffff &&
+           (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+}
+
+// partial products part[slice][m][n] (row-major, leading dimension N) for *n_slices <= max_slices slices of the K range
+int gemm_skinny_partials(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int64_t N, int64_t K, int max_slices, float *part,
+                         int *n_slices, hipStream_t st) {
+    const int64_t col_tiles = ceil_div(N, (int64_t)16);
+    int64_t s = ceil_div((int64_t)384, col_tiles);                  // ~1.5 workgroups per CU
+    const int64_t by_k = K / (2 * SK_KC) > 0 ? K / (2 * SK_KC) : 1; // a slice is at least two chunks
+    if (s > by_k) s = by_k;
+    if (s > max_slices) s = max_slices;
+    if (s < 1) s = 1;
+    const int kslice = (int)(ceil_div(ceil_div(K, s), (int64_t)SK_KC) * SK_KC);
+    const int ns = (int)ceil_div(K, (int64_t)kslice);
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)col_tiles, (unsigned)ns), dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K, kslice, part);
+    ITR_CHECK_LAUNCH("gemm_skinny");
+    *n_slices = ns;
+    return ITR_OK;
+}
+
+}  // namespace itr
