@@ -264,36 +264,42 @@ __global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
     }
 }
 
-// dG[i] = sum_c dGp[i, c];  then dV[i] += (dG + dG^T) V[i]   (G = V V^T)
+// dG[i] = sum_c dGp[i, c]  (summed into the slot of caption 0: a thread touches only its own element of every slot), then
+// dV[i] += (dG + dG^T) V[i]   (G = V V^T).  Round 6: two launches of (elements / features) x images workgroups -- the one-workgroup-per-
+// image form left half of the chip idle on a 128-image batch (0.34 ms of a 5 ms SCAN step).
+__global__ __launch_bounds__(256) void scan_train_dg_reduce_kernel(float *__restrict__ dGp, int64_t Bc, int RR) {
+    const int64_t i = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= RR) return;
+    float acc = 0.f;
+    for (int64_t c = 0; c < Bc; ++c) acc += dGp[(i * Bc + c) * RR + idx];
+    dGp[(i * Bc) * RR + idx] = acc;
+}
 template <int RMAX, bool FIXED>
 __global__ __launch_bounds__(256) void scan_train_gram_bwd_kernel(const float *__restrict__ dGp, int64_t Bc, const float *__restrict__ V, int D,
                                                                   float *__restrict__ dV, int R_) {
     __shared__ float dg[RMAX][RMAX + 1];
     const int R = FIXED ? RMAX : R_;
-    const int64_t i = blockIdx.x;
-    for (int idx = threadIdx.x; idx < R * R; idx += 256) {
-        float acc = 0.f;
-        for (int64_t c = 0; c < Bc; ++c) acc += dGp[(i * Bc + c) * (R * R) + idx];
-        dg[idx / R][idx % R] = acc;
-    }
+    const int64_t i = blockIdx.y;
+    for (int idx = threadIdx.x; idx < R * R; idx += 256) dg[idx / R][idx % R] = dGp[(i * Bc) * (R * R) + idx];
     __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256) {
-        if constexpr (FIXED) {
-            float v[RMAX];
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    if constexpr (FIXED) {
+        float v[RMAX];
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r) v[r] = V[(i * RMAX + r) * D + d];
-            for (int r = 0; r < RMAX; ++r) {
-                float acc = 0.f;
+        for (int r = 0; r < RMAX; ++r) v[r] = V[(i * RMAX + r) * D + d];
+        for (int r = 0; r < RMAX; ++r) {
+            float acc = 0.f;
 #pragma unroll
-                for (int s2 = 0; s2 < RMAX; ++s2) acc += (dg[r][s2] + dg[s2][r]) * v[s2];
-                dV[(i * RMAX + r) * D + d] += acc;
-            }
-        } else {
-            for (int r = 0; r < R; ++r) {
-                float acc = 0.f;
-                for (int s2 = 0; s2 < R; ++s2) acc += (dg[r][s2] + dg[s2][r]) * V[(i * R + s2) * D + d];
-                dV[(i * R + r) * D + d] += acc;
-            }
+            for (int s2 = 0; s2 < RMAX; ++s2) acc += (dg[r][s2] + dg[s2][r]) * v[s2];
+            dV[(i * RMAX + r) * D + d] += acc;
+        }
+    } else {
+        for (int r = 0; r < R; ++r) {
+            float acc = 0.f;
+            for (int s2 = 0; s2 < R; ++s2) acc += (dg[r][s2] + dg[s2][r]) * V[(i * R + s2) * D + d];
+            dV[(i * R + r) * D + d] += acc;
         }
     }
 }
@@ -333,6 +339,7 @@ __global__ __launch_bounds__(256) void enorm_bwd_kernel(const float *__restrict_
 // LDS-tiled Gram kernel of the evaluation path (scan_xattn.hip): G[n] = X_n X_n^T
 __global__ void gram_kernel(const float *__restrict__ X, const int64_t *__restrict__ row_off, const int32_t *__restrict__ row_cnt, int fixed_rows,
                             int D, float *__restrict__ G, const int64_t *__restrict__ g_off, int upper2);
+__global__ void gram_mfma_kernel(const float *__restrict__ X, int rows, int D, float *__restrict__ G, int upper2);
 
 static int check_train_args(const char *who, int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int norm, int agg, int max_len) {
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && n_tok >= 1 && D > 0, "%s: bad shape", who);
@@ -378,7 +385,9 @@ extern "C" int itr_scan_train_prepare(const float *V, const float *E, int64_t Bi
     ITR_REQUIRE(Bi >= 1 && n_tok >= 1 && D > 0, "itr_scan_train_prepare: bad shape");
     ITR_UNSUPPORTED(R < 1 || R > ST_RMAX, "itr_scan_train_prepare: 1..%d regions per image are supported, got %d", ST_RMAX, R);
     hipStream_t st = as_stream(stream);
-    if (R == SC_R)
+    if (R <= 48 && D % 4 == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0)      // (the evaluation path's matrix-core Gram kernel, scan_xattn.hip)
+        hipLaunchKernelGGL(gram_mfma_kernel, dim3((unsigned)Bi), dim3(256), 0, st, V, R, D, G, 0);
+    else if (R == SC_R)
         hipLaunchKernelGGL(gram_kernel, dim3((unsigned)Bi), dim3(256), 0, st, V, (const int64_t *)nullptr, (const int32_t *)nullptr, SC_R, D, G,
                            (const int64_t *)nullptr, 0);
     else
@@ -430,16 +439,21 @@ extern "C" int itr_scan_train_bwd(const float *A, int64_t ldA, const float *G, c
     return launch_pair<PairBwdSmem<64, ST_RMAX>>(scan_train_bwd_kernel<64, ST_RMAX, false>, "scan_train_bwd", g, st);
 }
 
-extern "C" int itr_scan_train_finish(const float *dG_pairs, int64_t Bi, int64_t Bc, const float *V, const float *E, const float *enorm,
+extern "C" int itr_scan_train_finish(float *dG_pairs, int64_t Bi, int64_t Bc, const float *V, const float *E, const float *enorm,
                                      const float *d_enorm, int64_t n_tok, int R, int D, float *dV, float *dE, itr_stream_t stream) {
     ITR_REQUIRE(dG_pairs && V && E && enorm && d_enorm && dV && dE, "itr_scan_train_finish: null pointer");
     ITR_REQUIRE(Bi >= 1 && Bc >= 1 && n_tok >= 1 && D > 0, "itr_scan_train_finish: bad shape");
     ITR_UNSUPPORTED(R < 1 || R > ST_RMAX, "itr_scan_train_finish: 1..%d regions per image are supported, got %d", ST_RMAX, R);
     ITR_UNSUPPORTED(n_tok > 65535, "itr_scan_train_finish: at most 65535 words per training batch");
     hipStream_t st = as_stream(stream);
-    if (R == SC_R) hipLaunchKernelGGL((scan_train_gram_bwd_kernel<SC_R, true>), dim3((unsigned)Bi), dim3(256), 0, st, dG_pairs, Bc, V, D, dV, R);
-    else if (R < SC_R) hipLaunchKernelGGL((scan_train_gram_bwd_kernel<SC_R, false>), dim3((unsigned)Bi), dim3(256), 0, st, dG_pairs, Bc, V, D, dV, R);
-    else hipLaunchKernelGGL((scan_train_gram_bwd_kernel<ST_RMAX, false>), dim3((unsigned)Bi), dim3(256), 0, st, dG_pairs, Bc, V, D, dV, R);
+    ITR_UNSUPPORTED(Bi > 65535, "itr_scan_train_finish: at most 65535 images per training batch");
+    hipLaunchKernelGGL(scan_train_dg_reduce_kernel, dim3((unsigned)ceil_div(R * R, 256), (unsigned)Bi), dim3(256), 0, st, dG_pairs, Bc,
+                       R * R);
+    ITR_CHECK_LAUNCH("scan_train_dg_reduce");
+    const dim3 gb((unsigned)ceil_div(D, 256), (unsigned)Bi);
+    if (R == SC_R) hipLaunchKernelGGL((scan_train_gram_bwd_kernel<SC_R, true>), gb, dim3(256), 0, st, dG_pairs, Bc, V, D, dV, R);
+    else if (R < SC_R) hipLaunchKernelGGL((scan_train_gram_bwd_kernel<SC_R, false>), gb, dim3(256), 0, st, dG_pairs, Bc, V, D, dV, R);
+    else hipLaunchKernelGGL((scan_train_gram_bwd_kernel<ST_RMAX, false>), gb, dim3(256), 0, st, dG_pairs, Bc, V, D, dV, R);
     ITR_CHECK_LAUNCH("scan_train_gram_bwd");
     hipLaunchKernelGGL(enorm_bwd_kernel, dim3((unsigned)ceil_div(D, 256), (unsigned)n_tok), dim3(256), 0, st, E, enorm, d_enorm, n_tok, D, dE);
     ITR_CHECK_LAUNCH("scan_train_enorm_bwd");

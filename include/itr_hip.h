@@ -585,7 +585,8 @@ int itr_gru_bwd(const int64_t *tokens, const int64_t *tok_off, const int32_t *le
  *   agg in {0 LogSumExp, 1 Max, 2 Sum, 3 Mean}.
  * itr_scan_train_bwd (dS [Bi, Bc]) writes dA [Bi*R, ldA], per-pair Gram gradients dG_pairs [Bi, Bc, R, R] and
  * d_enorm_pairs [Bi, ldA]; the caller finishes with GEMMs  dV = dA E,  dE = dA^T V  and itr_scan_train_finish, which
- * ADDS (sum_c dG + its transpose) V_i to dV and  colsum_i(d_enorm_pairs) e / ||e||  (d_enorm [n_tok]) to dE. */
+ * ADDS (sum_c dG + its transpose) V_i to dV and  colsum_i(d_enorm_pairs) e / ||e||  (d_enorm [n_tok]) to dE; it sums the per-pair
+ * Gram gradients IN PLACE (into the slot of caption 0 of every image: dG_pairs is scratch of the backward pass, not an output). */
 int itr_scan_train_prepare(const float *V, const float *E, int64_t Bi, int64_t n_tok, int R, int D, float *G,
                            float *enorm, itr_stream_t stream);
 int itr_scan_train_fwd(const float *A, int64_t ldA, const float *G, const float *enorm, const int64_t *cap_off,
@@ -595,7 +596,7 @@ int itr_scan_train_bwd(const float *A, int64_t ldA, const float *G, const float 
                        const int32_t *cap_len, int64_t Bi, int64_t Bc, int64_t n_tok, int R, int D, int max_len, int norm,
                        int agg, float lambda_softmax, float lambda_lse, const float *dS, float *dA, float *dG_pairs,
                        float *d_enorm_pairs, itr_stream_t stream);
-int itr_scan_train_finish(const float *dG_pairs, int64_t Bi, int64_t Bc, const float *V, const float *E,
+int itr_scan_train_finish(float *dG_pairs, int64_t Bi, int64_t Bc, const float *V, const float *E,
                           const float *enorm, const float *d_enorm, int64_t n_tok, int R, int D, float *dV, float *dE,
                           itr_stream_t stream);
 
