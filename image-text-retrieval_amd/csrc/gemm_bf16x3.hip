@@ -1,4 +1,4 @@
-// Split-bf16 GEMM study: C[M,N] = A[M,K] B[N,K]^T (+ bias) on the bf16 matrix core with fp32 operands
+// Split-bf16 GEMM study (STUDY_SPLIT_PRECISION.md): C[M,N] = A[M,K] B[N,K]^T (+ bias) on the bf16 matrix core with fp32 operands
 // split into bf16 planes,  x = hi + lo + O(2^-17 |x|):
 //   TERMS = 3   hi.hi + hi.lo + lo.hi   ("bf16x3": dropped terms ~ 2^-17 per product, fp32 accumulation)
 //   TERMS = 1   hi.hi                   (plain bf16 inputs, fp32 accumulation)
@@ -11,7 +11,7 @@
 //
 // Operand format: per row and 32-wide K chunk the 64 B of hi are followed by the 64 B of lo ([rows][K / 32][hi | lo][32] bf16),
 // so one chunk of one row is one full 128-byte line (separate whole-row planes made every load use half a line; the vector
-// L1 path then limits -- found on the SCAN loop).
+// L1 path then limits -- found on the SCAN loop, STUDY_SPLIT_PRECISION.md).
 // Tiling: 128 x 128 per workgroup, 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs);
 // K chunks of 32 staged through LDS (row stride 80 B: 16 consecutive rows hit 16 different 16-byte bank groups), the next
 // chunk's global loads are in flight in registers while the current one is multiplied.

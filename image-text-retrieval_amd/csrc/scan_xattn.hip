@@ -143,7 +143,7 @@ using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
 using f16x8_t = __attribute__((ext_vector_type(8))) _Float16;
 
 // PREC 0: exact fp32 main loop (scan_mainloop.inc).  PREC 1: split-bf16 "bf16x3", PREC 3: split-fp16 "fp16x3" main loop
-// (scan_mainloop_bf16.inc; opt-in, reported separately -- DESIGN.md 9); bits 2 / 3: ablation builds.  The epilogue is shared.
+// (scan_mainloop_bf16.inc; opt-in, reported separately -- STUDY_SPLIT_PRECISION.md); bits 2 / 3: ablation builds.  The epilogue is shared.
 // XA: the attention direction as a compile-time constant for the exact fp32 build (0 = t2i, 1 = i2t: two kernels, so the i2t epilogue's
 // registers and scalar spills do not weigh on the t2i kernel -- adding 60 lines to the i2t branch cost the t2i kernel 0.3 % while both
 // lived in one function); -1 = g.mode at run time (the study variants).

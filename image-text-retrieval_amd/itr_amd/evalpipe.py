@@ -388,7 +388,7 @@ class GruModelEval:
                 ops.scan_xattn_scores(img, words_t, plan_, cross_attn=xa, raw_feature_norm=cfg.get('raw_feature_norm', 'clipped_l2norm'),
                                       agg_func=cfg.get('agg_func', 'LogSumExp'), lambda_lse=cfg.get('lambda_lse', 6.0),
                                       lambda_softmax=cfg.get('lambda_softmax', 9.0), out=out, workspace=ws,
-                                      precision=cfg.get('scan_precision', 'fp32'))    # 'bf16x3': opt-in study variant
+                                      precision=cfg.get('scan_precision', 'fp32'))    # 'bf16x3': opt-in study variant (STUDY_SPLIT_PRECISION.md)
             if timers is not None:
                 ev[1].record()
                 timers['segments'].append(ev)

@@ -94,7 +94,7 @@ def mean_mid(x):
     return y
 
 
-# STUDY switches: True routes the plain tower / score GEMMs (linear, linear_strided, cosine_scores) through the
+# STUDY switches (STUDY_SPLIT_PRECISION.md): True routes the plain tower / score GEMMs (linear, linear_strided, cosine_scores) through the
 # split-bf16 kernel (terms = 3, ~1e-6 of fp32) / its fp16-plane variant.  Set by the study tools and their tests in their own
 # process, never from the environment: the product GEMM is exact fp32.
 BF16X3 = False
@@ -231,7 +231,7 @@ def split_bf16(x):
 
 
 def gemm_nt_bf16(a_il, b_il, bias=None, terms=3, act=None, M=None, K=None, lda=None, out=None):
-    """STUDY / opt-in: A B^T on the bf16 matrix core from split operands (split_bf16), fp32 accumulation.
+    """STUDY / opt-in (STUDY_SPLIT_PRECISION.md): A B^T on the bf16 matrix core from split operands (split_bf16), fp32 accumulation.
     terms = 3: hi.hi + hi.lo + lo.hi; terms = 1: hi.hi.  The product GEMM (linear / cosine_scores) is exact fp32.
     M, K, lda (fp32 elements) describe strided / overlapping rows of a flat operand (linear_strided)."""
     lib = _lib.load()
@@ -262,7 +262,7 @@ def split_f16(x):
 
 
 def gemm_nt_f16x3(a, b, bias=None, act=None, M=None, K=None, lda=None, out=None):
-    """STUDY / opt-in: A B^T from split_f16 operands on the fp16 matrix core, fp32 accumulation, error at the fp32
+    """STUDY / opt-in (STUDY_SPLIT_PRECISION.md): A B^T from split_f16 operands on the fp16 matrix core, fp32 accumulation, error at the fp32
     rounding level.  M, K, lda (fp32 elements) describe strided / overlapping rows of a flat operand (linear_strided)."""
     lib = _lib.load()
     (a_il, sa), (b_il, sb) = a, b

@@ -1,5 +1,5 @@
 """GPU: the split-bf16 GEMM study kernel (csrc/gemm_bf16x3.hip; opt-in, not on any default path): fragment / C-layout
-correctness with asymmetric operands, ragged M / N, bias, and the error bounds that DESIGN.md 9 quotes."""
+correctness with asymmetric operands, ragged M / N, bias, and the error bounds that STUDY_SPLIT_PRECISION.md quotes."""
 import numpy as np
 import pytest
 import torch

@@ -1,4 +1,4 @@
-"""GPU: the opt-in split-operand main loops of the SCAN kernel (csrc/scan_mainloop_bf16.inc): "bf16x3" (bf16
+"""GPU: the opt-in split-operand main loops of the SCAN kernel (csrc/scan_mainloop_bf16.inc, STUDY_SPLIT_PRECISION.md): "bf16x3" (bf16
 planes, ~3e-6 of the fp32 kernel) and "fp16x3" (fp16 planes with scaled lo and a second accumulator set, ~3e-7: fp32 rounding
 level) -- the same scores as the fp32 kernel and the oracle on the unit-norm operands of this path, every epilogue shared."""
 import numpy as np
@@ -60,7 +60,7 @@ def test_scan_bf16x3_full_size_against_fp32(dev):
     Sb = ops.scan_xattn_scores(img[248:376].contiguous(), words, plan, precision='bf16x3')
     assert torch.equal(Sb, S1[248:376])
     # fp16 planes: fp32 rounding level, deterministic (a register-reuse race made this build produce sporadic infinities with
-    # two workgroups per CU until the tail prefetches were drained inside the last chunk -- DESIGN.md 9), three runs identical
+    # two workgroups per CU until the tail prefetches were drained inside the last chunk -- STUDY_SPLIT_PRECISION.md), three runs identical
     S2 = ops.scan_xattn_scores(img, words, plan, workspace=ws, precision='fp16x3')
     assert bool(torch.isfinite(S2).all())
     assert float((S2 - S0).abs().max()) <= 1e-6 and float((S2 - S0).abs().mean()) <= 5e-8

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Split-bf16 ("bf16x3") study on whole workloads: encode + score a sample of a pooled workload twice in ONE
+"""Split-bf16 ("bf16x3") study on whole workloads (STUDY_SPLIT_PRECISION.md): encode + score a sample of a pooled workload twice in ONE
 process -- exact fp32 GEMMs, then ITR_GEMM_BF16X3 routing of linear / linear_strided / cosine_scores -- and report the score
 deviation, the rank agreement and the time of both.  Run on the GPU box:  python tools/bf16x3_study.py SAEM|CAMERA|VSRN|VSE++"""
 import os

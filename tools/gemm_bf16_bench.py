@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Split-bf16 GEMM study: throughput and accuracy of gemm_bf16_kernel (terms 3 / 1) next to the exact fp32
+"""Split-bf16 GEMM study (STUDY_SPLIT_PRECISION.md): throughput and accuracy of gemm_bf16_kernel (terms 3 / 1) next to the exact fp32
 MFMA GEMM on the tower / score shapes of the bench workloads.  Run on the GPU box."""
 import os
 import sys
