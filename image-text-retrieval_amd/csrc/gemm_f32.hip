@@ -429,8 +429,17 @@ int gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const floa
             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
     return gemm_nt_algo(A, lda, B, ldb, bias, C, ldc, M, N, K, act, st, 0);
 }
+int gemm_skinny_direct(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                       int act, hipStream_t st);      // gemm_skinny.hip
 static int gemm_nt_algo(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C,
                         int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st, int algo) {
+    // algo 4 (the training tape's request for a batch of <= 128 rows: a decoder step, a per-caption vector layer): 16-column strips over
+    // all rows -- N / 16 workgroups where the tile kernel has N / 128.  Never chosen by the library itself: a row's result would then
+    // depend on how many rows the call has (another k order), which the sharded evaluation's bit-identity across partitions forbids.
+    if (algo == 4) {
+        if (N >= 64 && K >= 128 && gemm_skinny_ok(A, lda, B, ldb, M, N, K)) return gemm_skinny_direct(A, lda, B, ldb, bias, C, ldc, M, N, K, act, st);
+        algo = 0;
+    }
     // short K, many row tiles: the streaming kernel takes the whole 128-row tiles, the tile kernel the remaining rows
     int rc = ITR_OK;
     if (gemm_nt_stream(A, lda, B, ldb, bias, C, ldc, M, N, K, act, st, &rc, algo)) {
@@ -496,7 +505,7 @@ extern "C" int itr_gemm_nt_algo(const float *A, int64_t lda, const float *B, int
     ITR_REQUIRE(A && B && C, "itr_gemm_nt_algo: null pointer");
     ITR_REQUIRE(lda >= 1 && ldb >= K && ldc >= N, "itr_gemm_nt_algo: leading dimension smaller than row");
     ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt_algo: unknown activation %d", act);
-    ITR_REQUIRE(algo >= 0 && algo <= 3, "itr_gemm_nt_algo: algo must be 0 (auto), 1 (tile), 2 (stream, plain map) or 3 (stream, XCD map)");
+    ITR_REQUIRE(algo >= 0 && algo <= 4, "itr_gemm_nt_algo: algo must be 0 (auto), 1 (tile), 2 (stream, plain map), 3 (stream, XCD map) or 4 (skinny: <= 128 rows)");
     return itr::gemm_nt_algo(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream), algo);
 }
 

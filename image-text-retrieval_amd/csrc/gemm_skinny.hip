@@ -15,8 +15,12 @@ namespace itr {
 
 constexpr int SK_KC = 64, SK_LD = SK_KC + 4, SK_MAXM = 128;
 
+// DIRECT: one slice (the whole K range), the epilogue adds the bias, applies the activation and writes C (leading dimension ldc) -- the
+// per-step products of a decoder / a 128-row training batch that have no consumer kernel to sum slices for them.
+template <bool DIRECT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, int M,
-                                                          int64_t N, int K, int kslice, float *__restrict__ part) {
+                                                          int64_t N, int K, int kslice, float *__restrict__ part, const float *__restrict__ bias,
+                                                          int act, int64_t ldc) {
     __shared__ __attribute__((aligned(16))) float As[2][SK_MAXM][SK_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][16][SK_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,16 +75,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float *__restric
             buf ^= 1;
         }
     }
-    float *o = part + (int64_t)blockIdx.y * M * N;
+    float *o = DIRECT ? part : part + (int64_t)blockIdx.y * M * N;
+    const int64_t ldo = DIRECT ? ldc : N;
     const int64_t n = n0 + (lane & 15);
     if (n < N) {
+        const float bv = (DIRECT && bias) ? bias[n] : 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int rt = wave + 4 * t;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int m = rt * 16 + 4 * (lane >> 4) + q;
-                if (m < M) o[(int64_t)m * N + n] = acc[t][q];
+                if (m < M) o[(int64_t)m * ldo + n] = DIRECT ? apply_act(acc[t][q] + bv, act) : acc[t][q];
             }
         }
     }
@@ -102,9 +108,20 @@ int gemm_skinny_partials(const float *A, int64_t lda, const float *B, int64_t ld
     if (s < 1) s = 1;
     const int kslice = (int)(ceil_div(ceil_div(K, s), (int64_t)SK_KC) * SK_KC);
     const int ns = (int)ceil_div(K, (int64_t)kslice);
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)col_tiles, (unsigned)ns), dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K, kslice, part);
+    hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3((unsigned)col_tiles, (unsigned)ns), dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K, kslice, part,
+                       (const float *)nullptr, 0, (int64_t)0);
     ITR_CHECK_LAUNCH("gemm_skinny");
     *n_slices = ns;
+    return ITR_OK;
+}
+
+// C = act(A B^T + bias) for M <= 128 in one launch (no K slices, no scratch)
+int gemm_skinny_direct(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                       int act, hipStream_t st) {
+    const int kslice = (int)(ceil_div(K, (int64_t)SK_KC) * SK_KC);
+    hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3((unsigned)ceil_div(N, (int64_t)16), 1u), dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K, kslice, C,
+                       bias, act, ldc);
+    ITR_CHECK_LAUNCH("gemm_skinny(direct)");
     return ITR_OK;
 }
 

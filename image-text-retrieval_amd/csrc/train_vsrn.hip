@@ -78,6 +78,37 @@ __global__ __launch_bounds__(256) void nll_logsoftmax_bwd_kernel(const float *__
     dlogits[b * V + v] = g * (expf(logits[b * V + v] - lse[b]) - (v == target[b] ? 1.f : 0.f));
 }
 
+// y[b, n, :] = act(x[b, n, :] + v[b, :]): the decoder attention's first layer, linear1(cat(enc_out, h)) = enc_out W_e^T + h W_h^T + b
+// (Fusionmodule.py:136-140), with the encoder half computed ONCE per caption batch instead of once per decoder step (it does not
+// depend on the step); backward from the output: d pre = dy act'(y), dx = d pre, dv[b] = sum_n d pre[b, n].
+__global__ __launch_bounds__(256) void add_bcast_mid_act_kernel(const float *__restrict__ x, const float *__restrict__ v, float *__restrict__ y,
+                                                                int N, int H, int act) {
+    const int64_t b = blockIdx.y;
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= H) return;
+    const float vv = v[b * H + h];
+    for (int n = 0; n < N; ++n) {
+        const int64_t o = (b * N + n) * (int64_t)H + h;
+        y[o] = apply_act(x[o] + vv, act);
+    }
+}
+__global__ __launch_bounds__(256) void add_bcast_mid_act_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx,
+                                                                    float *__restrict__ dv, int N, int H, int act) {
+    const int64_t b = blockIdx.y;
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= H) return;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const int64_t o = (b * N + n) * (int64_t)H + h;
+        const float yv = y[o];
+        const float d = act == 1 ? (yv > 0.f ? 1.f : 0.f) : act == 2 ? 1.f - yv * yv : act == 3 ? yv * (1.f - yv) : 1.f;
+        const float g = dy[o] * d;
+        dx[o] = g;
+        acc += g;
+    }
+    dv[b * H + h] = acc;
+}
+
 }  // namespace itr
 
 extern "C" int itr_gru_cell_fwd(const float *gi, const float *gh, const float *h, float *h_next, float *gates, int64_t B, int H,
@@ -120,5 +151,25 @@ extern "C" int itr_nll_logsoftmax_bwd(const float *logits, const int64_t *target
     hipLaunchKernelGGL(itr::nll_logsoftmax_bwd_kernel, dim3((unsigned)itr::ceil_div(V, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), logits,
                        target, mask, lse, dloss, dlogits, V);
     ITR_CHECK_LAUNCH("nll_logsoftmax_bwd");
+    return ITR_OK;
+}
+
+extern "C" int itr_add_bcast_mid_act(const float *x, const float *v, float *y, int64_t B, int N, int H, int act, itr_stream_t stream) {
+    ITR_REQUIRE(B >= 0 && B <= 65535 && N >= 1 && H >= 1 && act >= 0 && act <= 3, "itr_add_bcast_mid_act: bad shape or activation (0 none, 1 relu, 2 tanh, 3 sigmoid)");
+    if (B == 0) return ITR_OK;
+    ITR_REQUIRE(x && v && y, "itr_add_bcast_mid_act: null pointer");
+    hipLaunchKernelGGL(itr::add_bcast_mid_act_kernel, dim3((unsigned)itr::ceil_div(H, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), x, v, y, N, H,
+                       act);
+    ITR_CHECK_LAUNCH("add_bcast_mid_act");
+    return ITR_OK;
+}
+
+extern "C" int itr_add_bcast_mid_act_bwd(const float *y, const float *dy, float *dx, float *dv, int64_t B, int N, int H, int act, itr_stream_t stream) {
+    ITR_REQUIRE(B >= 0 && B <= 65535 && N >= 1 && H >= 1 && act >= 0 && act <= 3, "itr_add_bcast_mid_act_bwd: bad shape or activation");
+    if (B == 0) return ITR_OK;
+    ITR_REQUIRE(y && dy && dx && dv, "itr_add_bcast_mid_act_bwd: null pointer");
+    hipLaunchKernelGGL(itr::add_bcast_mid_act_bwd_kernel, dim3((unsigned)itr::ceil_div(H, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), y, dy, dx,
+                       dv, N, H, act);
+    ITR_CHECK_LAUNCH("add_bcast_mid_act_bwd");
     return ITR_OK;
 }

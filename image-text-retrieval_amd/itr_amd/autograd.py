@@ -55,6 +55,9 @@ def _gemm_nt(a, b, out=None, accumulate=False):
     assert b.shape[1] == K
     if out is None:
         out = _f32(M, N, dev=a.device)
+    if not accumulate and M <= 128:      # a batch of <= 128 rows (decoder steps, per-caption vectors): the skinny kernel (algo 4)
+        _lib.check(lib.itr_gemm_nt_algo(_p(a), K, _p(b), K, _p(None), _p(out), N, M, N, K, 0, 4, _stream()))
+        return out
     fn = lib.itr_gemm_nt_acc if accumulate else lib.itr_gemm_nt
     _lib.check(fn(_p(a), K, _p(b), K, _p(None), _p(out), N, M, N, K, 0, _stream()))
     return out
@@ -87,7 +90,10 @@ class _Linear(torch.autograd.Function):
         if w.dim() != 2 or w.shape[1] != K:
             raise ValueError("linear: x (..., %d) vs weight %s" % (K, tuple(w.shape)))
         out = _f32(M, N, dev=x.device)
-        _lib.check(lib.itr_gemm_nt(_p(x2), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, _stream()))
+        if M <= 128:       # (training tape only: the evaluation keeps ONE kernel family per product so that a row does not depend on M)
+            _lib.check(lib.itr_gemm_nt_algo(_p(x2), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, 4, _stream()))
+        else:
+            _lib.check(lib.itr_gemm_nt(_p(x2), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, _stream()))
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.xshape = x.shape
@@ -725,6 +731,37 @@ def act(x, kind):
     return _Act.apply(x, kind)
 
 
+class _AddBcastMidAct(torch.autograd.Function):
+    """act(x [B, N, H] + v [B, H] broadcast over N); the derivative is taken from the output."""
+
+    @staticmethod
+    def forward(ctx, x, v, kind):
+        lib = _lib.load()
+        x, v = _dev(x, name="x"), _dev(v, name="v")
+        B, N, H = x.shape
+        if tuple(v.shape) != (B, H):
+            raise ValueError("add_bcast_mid_act: x %s vs v %s" % (tuple(x.shape), tuple(v.shape)))
+        y = torch.empty_like(x)
+        code = 0 if kind is None else _ACT_CODE[kind]
+        _lib.check(lib.itr_add_bcast_mid_act(_p(x), _p(v), _p(y), B, N, H, code, _stream()))
+        ctx.save_for_backward(y)
+        ctx.code = code
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        y, = ctx.saved_tensors
+        B, N, H = y.shape
+        dx, dv = torch.empty_like(y), _f32(B, H, dev=y.device)
+        _lib.check(lib.itr_add_bcast_mid_act_bwd(_p(y), _p(dy.contiguous()), _p(dx), _p(dv), B, N, H, ctx.code, _stream()))
+        return dx, dv, None
+
+
+def add_bcast_mid_act(x, v, kind=None):
+    return _AddBcastMidAct.apply(x, v, kind)
+
+
 class _GateApply(torch.autograd.Function):
     """q' = q * M[:, :dk], k' = k * M[:, dk:]  (camera_.py:41-44); q, k [rows, dk], M [rows, 2 dk]."""
 
@@ -934,9 +971,22 @@ def summarize(smry, x):
 
 
 def _bmm(A, B, ta, tb, M, N, K):
+    """C[b] (M x N) = op(A[b]) op(B[b]) for a batch of small operands.  On the matrix cores where a batched kernel of the library has
+    the shape (round 6: VSRN's relation products theta phi^T / R g and their gradients were 8.6 ms of its step on the thread-per-element
+    itr_bmm_small): A B^T with <= 64 output columns = itr_sgt_dp; A^T B = itr_gemm_tn_batched; A B = the same on a transposed copy of the
+    (small) left operand."""
     lib = _lib.load()
-    out = _f32(A.shape[0], M, N, dev=A.device)
-    _lib.check(lib.itr_bmm_small(_p(A), _p(B), _p(out), A.shape[0], M, N, K, int(ta), int(tb), _stream()))
+    Bn = A.shape[0]
+    out = _f32(Bn, M, N, dev=A.device)
+    if Bn <= 65535 and not ta and tb and N <= 64 and K % 4 == 0:            # A [Bn, M, K] . B [Bn, N, K]^T
+        _lib.check(lib.itr_sgt_dp(_p(A), _p(B), Bn, M, N, K, _p(out), _stream()))
+        return out
+    if Bn <= 65535 and not tb:
+        if not ta:
+            A = A.transpose(1, 2).contiguous()                              # [Bn, K, M]: the reduced index becomes the row
+        _lib.check(lib.itr_gemm_tn_batched(_p(A), M, K * M, _p(B), N, K * N, _p(out), N, M * N, K, M, N, Bn, _stream()))
+        return out
+    _lib.check(lib.itr_bmm_small(_p(A), _p(B), _p(out), Bn, M, N, K, int(ta), int(tb), _stream()))
     return out
 
 

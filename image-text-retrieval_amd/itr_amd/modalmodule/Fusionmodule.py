@@ -381,11 +381,17 @@ class S2VTAttModel(nn.Module):
         masks = masks.to(dev).to(torch.float32)
         steps = min(dec.max_length - 1, labels.shape[1] - 1)
         att = dec.attention
+        # Attention.forward (Fusionmodule.py:136-140): linear1(cat(encoder_outputs, hidden)) = enc_out W_e^T + b + h W_h^T.  The encoder
+        # half does not depend on the decoder step: it is ONE GEMM per caption batch (4 608 x 2 048 x 2 048) instead of one per step
+        # (60 x 77 GFLOP forward were 2/3 of the step's flop, and as much again twice in the backward); its gradient accumulates over
+        # the steps on the tape and meets W_e / enc_out once.  Same sum up to the order of the two partial products.
+        W1e, W1h = att.linear1.weight[:, :H].contiguous(), att.linear1.weight[:, H:].contiguous()
+        enc_part = ag.linear(enc_out, W1e, att.linear1.bias).view(B, N, H)
         hs = []
         for i in range(steps):
             cur = ag.gather_rows(dec.embedding.weight, labels[:, i].contiguous())
-            inputs = torch.cat([enc_out3, h.unsqueeze(1).expand(B, N, H)], 2).reshape(B * N, 2 * H)
-            e = ag.linear(ag.act(ag.linear(inputs, att.linear1.weight, att.linear1.bias), 'tanh'), att.linear2.weight, None)
+            pre = ag.add_bcast_mid_act(enc_part, ag.linear(h, W1h, None), 'tanh')
+            e = ag.linear(pre.view(B * N, H), att.linear2.weight, None)
             context = ag.summarize(e.view(B, N, 1), enc_out3).view(B, H)                                      # softmax over the regions
             dec_in = ag.dropout(torch.cat([cur, context], 1), dec.input_dropout_p, seeds, training)
             h = ag.gru_cell(dec_in, h, dec.rnn)

@@ -108,7 +108,7 @@ def _weight_planes(w):
     return split_bf16(w)
 
 
-GEMM_ALGOS = {None: 0, "auto": 0, "tile": 1, "stream_plain": 2, "stream_xcd": 3}
+GEMM_ALGOS = {None: 0, "auto": 0, "tile": 1, "stream_plain": 2, "stream_xcd": 3, "skinny": 4}
 
 
 def linear(x, weight, bias=None, act=None, algo=None):

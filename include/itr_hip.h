@@ -83,7 +83,9 @@ int itr_gemm_nt(const float *A, int64_t lda, const float *B, int64_t ldb, const 
 /* The same product with the kernel chosen by the CALLER (cross-checks and timing; results are bit-identical for every choice):
  * algo 0 = itr_gemm_nt's own selection rule, 1 = the 128 x 128 tile kernel, 2 / 3 = the streaming kernel (plain / XCD-aware tile
  * map) for every shape it admits (N % 128 == 0, K % 64 == 0, K >= 128, 16-byte rows, act in {none, relu, gelu}; other shapes
- * fall through to the tile kernel). */
+ * fall through to the tile kernel).  algo 4 = the skinny kernel for M <= 128 rows (N >= 64, K >= 128, 16-byte rows; csrc/gemm_skinny.hip:
+ * 16-column strips over all rows, N / 16 workgroups): NOT bit-identical to the others (another k order) and therefore never the
+ * library's own choice -- the training tape asks for it for decoder steps and per-caption vector layers. */
 int itr_gemm_nt_algo(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias,
                      float *C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, int algo,
                      itr_stream_t stream);
@@ -549,6 +551,11 @@ int itr_gru_cell_fwd(const float *gi, const float *gh, const float *h, float *h_
                      itr_stream_t stream);
 int itr_gru_cell_bwd(const float *dh_next, const float *gates, const float *gh, const float *h, float *dgi, float *dgh, float *dh,
                      int64_t B, int H, itr_stream_t stream);
+/* y[b, n, :] = act(x[b, n, :] + v[b, :]) and its backward from the output (dx = dy act'(y), dv[b] = sum_n dx[b, n]); act 0 none, 1 relu,
+ * 2 tanh, 3 sigmoid.  The decoder attention's linear1(cat(enc_out, h)) (Fusionmodule.py:136-140) = enc_out W_e^T + b (once per batch)
+ * + h W_h^T (per step), added here. */
+int itr_add_bcast_mid_act(const float *x, const float *v, float *y, int64_t B, int N, int H, int act, itr_stream_t stream);
+int itr_add_bcast_mid_act_bwd(const float *y, const float *dy, float *dx, float *dv, int64_t B, int N, int H, int act, itr_stream_t stream);
 /* loss[b] = -mask[b] * log_softmax(logits[b, :])[target[b]]  (F.log_softmax + NLLLoss(reduce=False) * mask); lse keeps the row
  * log-sum-exp for the backward pass dlogits = dloss[b] mask[b] (softmax - onehot). */
 int itr_nll_logsoftmax_fwd(const float *logits, const int64_t *target, const float *mask, float *loss, float *lse, int64_t B, int V,

@@ -59,3 +59,26 @@ def test_linear_backward_uses_the_split_reduction(dev, rows, K, N, bias):
     assert float((x.grad.double() - xd.grad).abs().max()) <= 1e-4
     if bias:
         assert float((bv.grad.double() - bd.grad).abs().max()) <= 3e-5 * rows ** 0.5
+
+
+@pytest.mark.parametrize("M,N,K,bias,act", [(128, 1536, 512, True, None), (128, 512, 2560, True, 'tanh'), (37, 3072, 1024, False, None),
+                                            (1, 64, 128, True, 'relu'), (128, 1000, 300, True, None), (100, 96, 132, False, 'sigmoid')])
+def test_skinny_gemm_vs_float64(dev, M, N, K, bias, act):
+    """itr_gemm_nt_algo(algo = 4): the <= 128-row products of the training tape (decoder steps, per-caption vector layers) on 16-column
+    strips (csrc/gemm_skinny.hip), against float64 -- ragged N (not a multiple of 16), K not a multiple of the 64-wide chunk, M = 1."""
+    from itr_amd import ops
+    torch.manual_seed(M + N)
+    a = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) * 0.1
+    b = torch.randn(N, device=dev) if bias else None
+    got = ops.linear(a, w, b, act=act, algo="skinny")
+    want = a.double() @ w.double().t()
+    if bias:
+        want = want + b.double()
+    want = {None: lambda t: t, 'tanh': torch.tanh, 'relu': torch.relu, 'sigmoid': torch.sigmoid}[act](want)
+    assert float((got.double() - want).abs().max()) <= 2e-5 * K ** 0.5
+    x = a.clone().requires_grad_()
+    y = ag.linear(x, w.clone().requires_grad_(), b)                  # the tape routes M <= 128 through it
+    y.sum().backward()
+    assert float((y.detach().double() - (a.double() @ w.double().t() + (b.double() if bias else 0))).abs().max()) <= 2e-5 * K ** 0.5
+    assert float((x.grad.double() - w.double().sum(0)).abs().max()) <= 2e-4 * N ** 0.5
