@@ -162,7 +162,10 @@ static int tn_tile(int P, int Q) {
 static void tn_plan(int64_t R, int P, int Q, int *T, int *nsl, int64_t *rows_per_slice) {
     *T = tn_tile(P, Q);
     const int64_t tiles = ceil_div(P, *T) * ceil_div(Q, *T);
-    int64_t s = ceil_div((int64_t)1024, tiles);                 // ~4 workgroups per CU
+#ifndef ITR_TN_TARGET
+#define ITR_TN_TARGET 1024
+#endif
+    int64_t s = ceil_div((int64_t)ITR_TN_TARGET, tiles);       // ~4 workgroups per CU
     const int64_t by_rows = ceil_div(R, (int64_t)256);          // a slice is at least 256 rows (16 chunks)
     if (s > by_rows) s = by_rows;
     if (s > TN_MAXSLICES) s = TN_MAXSLICES;

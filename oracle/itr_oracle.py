@@ -383,6 +383,83 @@ def sgraf_similarity(w, img_emb, cap_emb, cap_lens, module_name='SAF', sgr_step=
 
 
 # --------------------------------------------------------------------------------------
+# a7 / a14  SGRAF in TRAINING mode (SGRAF.train_emb, Models.py:518-546): EncoderSimilarity.forward with BatchNorm batch
+# statistics (VisualSA: BatchNorm1d(36) over (B, D) per region and BatchNorm1d(D) over B; AttentionFiltration: BatchNorm1d(1)
+# over the B x (W + 1) logits of ONE caption, because the reference calls it once per caption), dropout at p = 0 (the
+# reference's 0.4 sites draw from torch's generator: the golden G20 switches them off), differentiable (torch autograd).
+# Pinned by G20 = the reference's own SGRAF.train_emb: loss and every clipped gradient (tests/test_oracle_golden.py).
+# --------------------------------------------------------------------------------------
+
+
+def _bn_train(x, w, p, channel_dim, eps=1e-5):
+    dims = [d for d in range(x.dim()) if d != channel_dim]
+    mean = x.mean(dims, keepdim=True)
+    var = x.var(dims, unbiased=False, keepdim=True)
+    shape = [1] * x.dim()
+    shape[channel_dim] = -1
+    return (x - mean) / torch.sqrt(var + eps) * w[p + '.weight'].view(shape) + w[p + '.bias'].view(shape)
+
+
+def sgraf_similarity_train(w, img_emb, cap_emb, cap_lens, module_name='SAF', sgr_step=3):
+    """EncoderSimilarity.forward (Fusionmodule.py:406-451) in training mode -> (Ni, Nc).  Same loop over the captions as the reference."""
+    n_image = img_emb.shape[0]
+    l_emb = torch.tanh(_bn_train(_linear(img_emb, w, 'v_global_w.embedding_local.0'), w, 'v_global_w.embedding_local.1', 1))
+    g_emb = torch.tanh(_bn_train(_linear(img_emb.mean(1), w, 'v_global_w.embedding_global.0'), w, 'v_global_w.embedding_global.1', 1))
+    weights = torch.softmax(_linear(l_emb * g_emb.unsqueeze(1), w, 'v_global_w.embedding_common.0').squeeze(2), dim=1)
+    img_glo = l2norm((weights.unsqueeze(2) * img_emb).sum(1), dim=-1)
+    cols = []
+    for c in range(cap_emb.shape[0]):
+        nw = int(cap_lens[c])
+        cap_i = cap_emb[c, :nw].unsqueeze(0)
+        cap_exp = cap_i.expand(n_image, nw, -1)
+        cap_glo = sgraf_text_sa(w, cap_i, cap_i.mean(1))                 # TextSA has no BatchNorm
+        ctx = sgraf_scan_attention(cap_exp, img_emb, smooth=9.0)
+        sim_loc = l2norm(_linear((ctx - cap_exp).pow(2), w, 'sim_tranloc_w'), dim=-1)
+        sim_glo = l2norm(_linear((img_glo - cap_glo).pow(2), w, 'sim_tranglo_w'), dim=-1)
+        sim_emb = torch.cat([sim_glo.unsqueeze(1), sim_loc], 1)
+        if module_name == 'SGR':
+            for k in range(sgr_step):
+                p = 'SGR_module.sgr%d' % k
+                q = _linear(sim_emb, w, p + '.graph_query_w')
+                kk = _linear(sim_emb, w, p + '.graph_key_w')
+                edge = torch.softmax(torch.bmm(q, kk.transpose(1, 2)), dim=-1)
+                sim_emb = torch.relu(_linear(torch.bmm(edge, sim_emb), w, p + '.sim_graph_w'))
+            sim_vec = sim_emb[:, 0]
+        elif module_name == 'SAF':
+            a = _linear(sim_emb, w, 'SAF_module.attn_sim_w').transpose(1, 2)          # (Ni, 1, nw + 1)
+            a = l1norm(torch.sigmoid(_bn_train(a, w, 'SAF_module.bn', 1)), dim=-1)
+            sim_vec = l2norm(torch.bmm(a, sim_emb).squeeze(1), dim=-1)
+        else:
+            raise ValueError('Invalid input of config.module_name in configs.py')
+        cols.append(torch.sigmoid(_linear(sim_vec, w, 'sim_eval_w')).squeeze(1))
+    return torch.stack(cols, 1)
+
+
+def sgraf_model_train_grads(wi, wt, ws, images, ids, lengths, cfg):
+    """One SGRAF.train_emb step up to the clipped gradients (Models.py:524-546): towers -> training-mode similarity -> hinge ->
+    backward -> clip_grad_norm_.  wi: {'fc.weight', 'fc.bias'}; wt: EncoderText state_dict; ws: EncoderSimilarity state_dict
+    (parameters and BatchNorm buffers).  Returns (loss, {name: clipped gradient}) with names 'img.<k>' / 'txt.<k>' / 'sim.<k>'.
+    Parameter order as the reference builds it: txt_enc, img_enc, sim_enc (Models.py:498-500)."""
+    is_param = lambda k: not (k.endswith('running_mean') or k.endswith('running_var') or k.endswith('num_batches_tracked'))
+    names = [('txt.' + k, wt, k) for k in wt] + [('img.' + k, wi, k) for k in ('fc.weight', 'fc.bias')] + \
+            [('sim.' + k, ws, k) for k in ws if is_param(k)]
+    with torch.enable_grad():
+        leaves = {n: d[k].detach().clone().requires_grad_(True) for n, d, k in names}
+        wi_l = {k: leaves['img.' + k] for k in ('fc.weight', 'fc.bias')}
+        wt_l = {k: leaves['txt.' + k] for k in wt}
+        ws_l = {k: (leaves['sim.' + k] if is_param(k) else ws[k]) for k in ws}
+        img = encoder_image_precomp(images, wi_l['fc.weight'], wi_l['fc.bias'], cfg.get('no_imgnorm', False))
+        cap, cap_len = encoder_text(ids, lengths, wt_l, bool(cfg.get('bi_gru', False)), cfg.get('no_txtnorm', False), False, None)
+        sims = sgraf_similarity_train(ws_l, img, cap, cap_len, cfg.get('module_name', 'SAF'), cfg.get('sgr_step', 3))
+        loss = hinge_loss(sims, cfg.get('margin', 0.2), cfg.get('max_violation', False))
+        loss.backward()
+    grads = [leaves[n].grad if leaves[n].grad is not None else torch.zeros_like(leaves[n]) for n, _, _ in names]
+    if cfg.get('grad_clip', 2.0) > 0:
+        grads, _ = clip_grad_norm(grads, cfg.get('grad_clip', 2.0))
+    return loss.detach(), {n: g for (n, _, _), g in zip(names, grads)}
+
+
+# --------------------------------------------------------------------------------------
 # a17  ranker (itr/metricmodule/evaluation.py:156-259)
 # --------------------------------------------------------------------------------------
 

@@ -7,8 +7,8 @@ batch 128 (SAEM 64), 36 x 2048 region features, coco vocabulary, word_dim 300, e
 
 Per family: ms per step (wall, synchronised), the forward / backward / optimizer split from HIP events on the stream the kernels run
 on, pairs scored per second, a flop model (3 x the forward flop of SURVEY 8(d) for the trained layers, 1 x for the frozen BERT) as a
-fraction of the fp32 MFMA peak, and -- for the families whose training step oracle/itr_oracle.py restates (VSE++, SCAN) -- the oracle's
-step on the host cores beside it.  Run on the GPU box."""
+fraction of the fp32 MFMA peak, and -- for the families whose training step oracle/itr_oracle.py restates (VSE++, SCAN, SGRAF) -- the
+oracle's step on the host cores beside it.  Run on the GPU box."""
 import argparse
 import json
 import os
@@ -87,10 +87,19 @@ def flop_model(model_name, module, B, lens, D=1024, S=256):
     return None
 
 
-def oracle_cpu_step(model_name, batch, cfg):
-    """The oracle's own train_emb restatement (oracle/itr_oracle.py: gru_model_train_step) on the host cores, same shapes."""
+def oracle_cpu_step(model_name, batch, cfg, model=None):
+    """The oracle's own train_emb restatement (oracle/itr_oracle.py: gru_model_train_step; SGRAF: sgraf_model_train_grads, pinned by G20)
+    on the host cores, same shapes."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import itr_oracle as O
+    if model_name == "SGRAF":      # the model's own weights on the host; forward + backward + clip (the Adam update is noise next to them)
+        cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        wi, wt, ws = cpu(model.img_enc), cpu(model.txt_enc), cpu(model.sim_enc)
+        ocfg = dict(bi_gru=True, margin=0.2, max_violation=True, grad_clip=2.0, module_name=cfg['module_name'], sgr_step=cfg.get('sgr_step', 3))
+        feats, ids, lens = batch[0].cpu(), batch[3].cpu(), batch[4]
+        t0 = time.perf_counter()
+        O.sgraf_model_train_grads(wi, wt, ws, feats, ids, lens, ocfg)
+        return time.perf_counter() - t0
     kind = {"VSE_PP": "VSE++", "SCAN": "SCAN"}[model_name]
     torch.manual_seed(0)
     D, E, F_ = 1024, 300, 2048
@@ -168,14 +177,15 @@ def run(model_name, module=None, batch=128, steps=10, warmup=3, cpu=False, dev=N
         row["tflops"] = round(fm / dt / 1e12, 2)
         row["frac_of_fp32_mfma_peak"] = round(fm / dt / 1e12 / PEAK_F32_TFLOPS, 4)
     if cpu:
-        if model_name in ("VSE_PP", "SCAN"):
+        if model_name in ("VSE_PP", "SCAN", "SGRAF"):
             torch.set_num_threads(min(32, os.cpu_count() or 1))
-            s = oracle_cpu_step(model_name, batches[0], cfg)
-            row["cpu_oracle"] = {"ms_per_step": round(s * 1e3, 1), "threads": torch.get_num_threads(), "kind": "port (oracle/itr_oracle.py gru_model_train_step)",
+            s = oracle_cpu_step(model_name, batches[0], cfg, model)
+            fn = "sgraf_model_train_grads (forward, backward, clip)" if model_name == "SGRAF" else "gru_model_train_step"
+            row["cpu_oracle"] = {"ms_per_step": round(s * 1e3, 1), "threads": torch.get_num_threads(), "kind": "port (oracle/itr_oracle.py %s)" % fn,
                                  "sample": "1 step, same shapes", "speedup": round(s / dt, 1)}
         else:
             row["cpu_oracle"] = None
-            row["cpu_oracle_note"] = "oracle/ restates this family's evaluation path only; its training goldens (G18-G21) are the imported reference's own train_emb"
+            row["cpu_oracle_note"] = "oracle/ restates this family's evaluation path only; its training goldens (G18, G19, G21) are the imported reference's own train_emb"
     return row
 
 
