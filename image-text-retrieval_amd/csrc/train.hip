@@ -118,6 +118,46 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float *__restrict__ p, c
     p[i] = p[i] - (lr / bc1) * (mi / denom);
 }
 
+// ---- all tensors of an optimizer step in ONE launch each (round 6: a step of CAMERA / SGRAF / VSRN has 51-67 parameter tensors = twice
+// that many launches of a few microseconds).  `tab`: one record per tensor (device copy of a host table the caller rebuilds per step --
+// gradients are new allocations every step); `blk_tensor[b]` = the tensor workgroup b works on, `blk_first[t]` = its first workgroup.
+// Same arithmetic per element / per partial as the single-tensor kernels (the partials land in the same layout: bit-identical norm).
+struct OptTensor {
+    float *p;
+    const float *g;
+    float *m, *v;
+    int64_t n;
+    int32_t first_blk, nblk;        // sq-sum: workgroups [first_blk, first_blk + nblk) stride over the tensor
+};
+__global__ __launch_bounds__(256) void sq_sum_multi_kernel(const OptTensor *__restrict__ tab, const int32_t *__restrict__ blk_tensor,
+                                                           float *__restrict__ part) {
+    __shared__ float red[4];
+    const OptTensor t = tab[blk_tensor[blockIdx.x]];
+    const int64_t local = (int64_t)blockIdx.x - t.first_blk;
+    float s = 0.f;
+    for (int64_t i = local * 256 + threadIdx.x; i < t.n; i += (int64_t)t.nblk * 256) s += t.g[i] * t.g[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void adam_step_multi_kernel(const OptTensor *__restrict__ tab, const int32_t *__restrict__ blk_tensor,
+                                                              const int32_t *__restrict__ blk_first, float lr, float b1, float b2, float eps,
+                                                              float bc1, float bc2_sqrt, const float *__restrict__ gscale_dev) {
+    const int ti = blk_tensor[blockIdx.x];
+    const OptTensor t = tab[ti];
+    const int64_t i = ((int64_t)blockIdx.x - blk_first[ti]) * 256 + threadIdx.x;
+    if (i >= t.n) return;
+    const float gs = gscale_dev ? gscale_dev[0] : 1.f;
+    const float gi = t.g[i] * gs;
+    const float mi = b1 * t.m[i] + (1.f - b1) * gi;
+    const float vi = b2 * t.v[i] + (1.f - b2) * gi * gi;
+    t.m[i] = mi;
+    t.v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    t.p[i] = t.p[i] - (lr / bc1) * (mi / denom);
+}
+
 // total_norm = sqrt(sum of all partials); coef = min(1, max_norm / (total_norm + 1e-6))   (torch clip_grad_norm_)
 __global__ __launch_bounds__(64) void clip_coef_kernel(const float *__restrict__ part, int64_t nparts, float max_norm, float *__restrict__ out2) {
     const int lane = threadIdx.x;
@@ -228,5 +268,31 @@ extern "C" int itr_adam_step(float *p, const float *g, float *m, float *v, int64
     hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2,
                        eps, (float)bc1, (float)sqrt(bc2), grad_scale_dev);
     ITR_CHECK_LAUNCH("adam_step");
+    return ITR_OK;
+}
+
+/* One record per tensor, 48 bytes: p, g, m, v (device pointers), n (int64), first_blk, nblk (int32: the tensor's range of sq-sum
+ * workgroups, nblk = itr_sq_sum_blocks(n)). */
+extern "C" int itr_sq_sum_multi(const void *table_dev, const int32_t *blk_tensor_dev, int64_t n_blocks, float *partials, itr_stream_t stream) {
+    ITR_REQUIRE(n_blocks >= 0 && n_blocks <= 0x7fffffff, "itr_sq_sum_multi: bad size");
+    if (n_blocks == 0) return ITR_OK;
+    ITR_REQUIRE(table_dev && blk_tensor_dev && partials, "itr_sq_sum_multi: null pointer");
+    static_assert(sizeof(OptTensor) == 48, "OptTensor is the 48-byte record the Python side packs");
+    hipLaunchKernelGGL(sq_sum_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream), static_cast<const OptTensor *>(table_dev),
+                       blk_tensor_dev, partials);
+    ITR_CHECK_LAUNCH("sq_sum_multi");
+    return ITR_OK;
+}
+
+extern "C" int itr_adam_step_multi(const void *table_dev, const int32_t *blk_tensor_dev, const int32_t *blk_first_dev, int64_t n_blocks, float lr,
+                                   float beta1, float beta2, float eps, int64_t step, const float *grad_scale_dev, itr_stream_t stream) {
+    ITR_REQUIRE(n_blocks >= 0 && n_blocks <= 0x7fffffff && step >= 1, "itr_adam_step_multi: bad size / step");
+    if (n_blocks == 0) return ITR_OK;
+    ITR_REQUIRE(table_dev && blk_tensor_dev && blk_first_dev, "itr_adam_step_multi: null pointer");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_step_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream), static_cast<const OptTensor *>(table_dev),
+                       blk_tensor_dev, blk_first_dev, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale_dev);
+    ITR_CHECK_LAUNCH("adam_step_multi");
     return ITR_OK;
 }

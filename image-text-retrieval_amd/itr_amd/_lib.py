@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -137,6 +137,8 @@ SIGNATURES = {
     "itr_sq_sum": (i32, [vp, i64, vp, vp]),
     "itr_clip_coef": (i32, [vp, i64, f32, vp, vp]),
     "itr_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, vp]),
+    "itr_sq_sum_multi": (i32, [vp, vp, i64, vp, vp]),
+    "itr_adam_step_multi": (i32, [vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, vp]),
     "itr_gru_train_save_bytes": (sz, [i64, i32, i32]),
     "itr_gru_train_workspace_bytes": (sz, [i64, i64, i32, i32]),
     "itr_gru_fwd_train": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]),

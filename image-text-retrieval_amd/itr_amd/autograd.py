@@ -1196,39 +1196,57 @@ class Adam(object):
             p.grad = flat[o:o + n].view(p.shape)
             o += n
 
-    def _coef(self, max_norm):
+    def _tables(self, ps):
+        """Block maps of the two multi-tensor launches for this set of tensors (sizes only: cached) and the per-step pointer table."""
         lib = _lib.load()
-        grads = [p.grad for p in self.params if p.grad is not None]
-        dev = grads[0].device
-        counts = [lib.itr_sq_sum_blocks(g.numel()) for g in grads]
-        part = torch.empty(sum(counts), device=dev, dtype=torch.float32)
-        o = 0
-        for g, n in zip(grads, counts):
-            gc = g.contiguous()
-            _lib.check(lib.itr_sq_sum(_p(gc), gc.numel(), C.c_void_p(part.data_ptr() + 4 * o), _stream()))
-            o += n
-        out = torch.empty(2, device=dev, dtype=torch.float32)
-        _lib.check(lib.itr_clip_coef(_p(part), part.numel(), float(max_norm), _p(out), _stream()))
-        return out
-
-    def step(self, max_norm=0.0):
-        lib = _lib.load()
-        self.t += 1
-        g0 = self.param_groups[0]
-        coef = None
-        if self.comm is not None and self.comm.on:
-            self._sync_grads()
-        if any(p.grad is not None for p in self.params):
-            coef = self._coef(max_norm)
-            self.last_grad_norm = coef[1:]
-        for p in self.params:
-            if p.grad is None:
-                continue
-            if not p.is_cuda:
-                raise RuntimeError("Adam: parameter on %s (no CPU fallback)" % p.device)
+        key = tuple((id(p), p.numel()) for p in ps)
+        if getattr(self, '_map_key', None) != key:
+            nsq = [lib.itr_sq_sum_blocks(p.numel()) for p in ps]
+            nad = [(p.numel() + 255) // 256 for p in ps]
+            sq_first = np.concatenate([[0], np.cumsum(nsq)]).astype(np.int64)
+            ad_first = np.concatenate([[0], np.cumsum(nad)]).astype(np.int64)
+            dev = ps[0].device
+            self._maps = dict(nsq=nsq, sq_first=sq_first, n_sq=int(sq_first[-1]), n_ad=int(ad_first[-1]),
+                              sq_blk=h2d(np.repeat(np.arange(len(ps)), nsq).astype(np.int32), dev),
+                              ad_blk=h2d(np.repeat(np.arange(len(ps)), nad).astype(np.int32), dev),
+                              ad_first=h2d(ad_first[:-1].astype(np.int32), dev))
+            self._map_key = key
+        m = self._maps
+        tab = np.zeros((len(ps), 6), dtype=np.int64)          # 48-byte records: p, g, m, v, n, (first_blk | nblk << 32)
+        self._keep = []
+        for i, p in enumerate(ps):
             st = self.state.get(p)
             if st is None:
                 st = self.state[p] = {'exp_avg': torch.zeros_like(p.data), 'exp_avg_sq': torch.zeros_like(p.data)}
             g = p.grad.contiguous()
-            _lib.check(lib.itr_adam_step(_p(p.data), _p(g), _p(st['exp_avg']), _p(st['exp_avg_sq']), p.numel(), float(g0['lr']),
-                                         float(g0['betas'][0]), float(g0['betas'][1]), float(g0['eps']), self.t, _p(coef), _stream()))
+            self._keep.append(g)
+            tab[i] = (p.data.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel(),
+                      int(m['sq_first'][i]) | (int(m['nsq'][i]) << 32))
+        return m, h2d(tab.reshape(-1), ps[0].device)
+
+    def step(self, max_norm=0.0):
+        """clip_grad_norm_(params, max_norm) + Adam over every tensor that has a gradient: the squared norms, the clip coefficient and the
+        update are three launches for ALL tensors (itr_sq_sum_multi, itr_clip_coef, itr_adam_step_multi)."""
+        lib = _lib.load()
+        self.t += 1
+        g0 = self.param_groups[0]
+        if self.comm is not None and self.comm.on:
+            self._sync_grads()
+        ps = [p for p in self.params if p.grad is not None]
+        if not ps:
+            return
+        for p in ps:
+            if not p.is_cuda:
+                raise RuntimeError("Adam: parameter on %s (no CPU fallback)" % p.device)
+            if not p.data.is_contiguous():
+                raise RuntimeError("Adam: non-contiguous parameter")
+        dev = ps[0].device
+        m, tab = self._tables(ps)
+        part = torch.empty(m['n_sq'], device=dev, dtype=torch.float32)
+        _lib.check(lib.itr_sq_sum_multi(_p(tab), _p(m['sq_blk']), m['n_sq'], _p(part), _stream()))
+        coef = torch.empty(2, device=dev, dtype=torch.float32)
+        _lib.check(lib.itr_clip_coef(_p(part), part.numel(), float(max_norm), _p(coef), _stream()))
+        self.last_grad_norm = coef[1:]
+        _lib.check(lib.itr_adam_step_multi(_p(tab), _p(m['ad_blk']), _p(m['ad_first']), m['n_ad'], float(g0['lr']), float(g0['betas'][0]),
+                                           float(g0['betas'][1]), float(g0['eps']), self.t, _p(coef), _stream()))
+        self._keep = None

@@ -464,6 +464,15 @@ int itr_clip_coef(const float *partials, int64_t nparts, float max_norm, float *
 int itr_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
                   int64_t step, const float *grad_scale_dev, itr_stream_t stream);
 
+/* The same two for ALL parameter tensors of a step in one launch each (a step has up to 67 tensors).  table_dev: one 48-byte record per
+ * tensor {float *p; const float *g; float *m, *v; int64 n; int32 first_blk, nblk} (device copy of a host table; [first_blk, first_blk +
+ * nblk) = the tensor's itr_sq_sum_blocks(n) workgroups of itr_sq_sum_multi, partials in the same layout as per-tensor itr_sq_sum calls:
+ * the norm is bit-identical); blk_tensor[b] = tensor of workgroup b.  itr_adam_step_multi has its own maps: one workgroup per 256
+ * elements, blk_first[t] = first workgroup of tensor t. */
+int itr_sq_sum_multi(const void *table_dev, const int32_t *blk_tensor_dev, int64_t n_blocks, float *partials, itr_stream_t stream);
+int itr_adam_step_multi(const void *table_dev, const int32_t *blk_tensor_dev, const int32_t *blk_first_dev, int64_t n_blocks, float lr,
+                        float beta1, float beta2, float eps, int64_t step, const float *grad_scale_dev, itr_stream_t stream);
+
 /* ---- transformer towers under autograd (SAEM: TransformerMapping / BertMapping, ImgEncoder.py:324-350, TextEncoder.py:75-152,
  * bert.py:113-300); the dense layers are itr_gemm_nt on transposed operands as for every other backward pass ----------------
  * nn.Dropout: y = x * keep / (1 - p), keep(i) from a counter-based hash of (seed, offset + i).  Stateless: the backward pass
