@@ -542,3 +542,25 @@ extern "C" int itr_mvm_scores(const float *imgs, const float *caps, float *S, in
     ITR_REQUIRE(k >= 1 && k <= itr::BM, "itr_mvm_scores: number of views must be in [1, %d]", itr::BM);
     return itr::gemm_nt_groupmax(imgs, D, caps, D, S, ldS, Ni, k, Nc, D, itr::as_stream(stream));
 }
+
+// Training tape only (a row's bits depend on the slice count, hence on M and N): the product with its K range cut into slices when the
+// output has too few 128 x 128 tiles to fill the chip -- CAMERA's dilated convolutions as GEMMs are 4 608 x 128 outputs over K = 6 144 /
+// 10 240: 36 tiles, 0.4 ms each on 40 workgroups.  Slices are added in a fixed order (deterministic).
+extern "C" size_t itr_gemm_nt_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M < 1 || N < 1 || K < 1) return 0;
+    const int s_ = itr::gemm_splitk_choice(M, N, K);
+    return s_ > 1 ? itr::gemm_splitk_scratch_bytes(M, N, s_) : 0;
+}
+
+extern "C" int itr_gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M,
+                                  int64_t N, int64_t K, int act, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
+    ITR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "itr_gemm_nt_splitk: negative dimension");
+    if (M == 0 || N == 0) return ITR_OK;
+    ITR_REQUIRE(A && B && C, "itr_gemm_nt_splitk: null pointer");
+    ITR_REQUIRE(lda >= K && ldb >= K && ldc >= N, "itr_gemm_nt_splitk: leading dimension smaller than row");
+    ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt_splitk: unknown activation %d", act);
+    const int s_ = itr::gemm_splitk_choice(M, N, K);
+    if (s_ <= 1) return itr::gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream));
+    ITR_REQUIRE(workspace && workspace_bytes >= itr::gemm_splitk_scratch_bytes(M, N, s_), "itr_gemm_nt_splitk: workspace too small (itr_gemm_nt_splitk_workspace_bytes)");
+    return itr::gemm_nt_splitk(A, lda, B, ldb, bias, C, ldc, M, N, K, act, 0, s_, static_cast<float *>(workspace), itr::as_stream(stream));
+}

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -110,6 +110,8 @@ SIGNATURES = {
     "itr_transpose2d": (i32, [vp, vp, i64, i64, vp]),
     "itr_colsum_workspace_bytes": (sz, [i64, i64]),
     "itr_colsum": (i32, [vp, vp, i64, i64, i32, vp, sz, vp]),
+    "itr_gemm_nt_splitk_workspace_bytes": (sz, [i64, i64, i64]),
+    "itr_gemm_nt_splitk": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, vp, sz, vp]),
     "itr_gemm_tn_workspace_bytes": (sz, [i64, i64, i64]),
     "itr_gemm_tn": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp, vp, sz, vp]),
     "itr_gemm_tn_batched": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp]),

@@ -383,6 +383,12 @@ int itr_transpose2d(const float *in, float *out, int64_t rows, int64_t cols, itr
 size_t itr_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int itr_colsum(const float *x, float *out, int64_t rows, int64_t cols, int accumulate, void *workspace,
                size_t workspace_bytes, itr_stream_t stream);
+/* C = act(A B^T + bias) with the K range cut into slices when the output has too few 128 x 128 tiles to fill the chip (M N small, K long:
+ * CAMERA's dilated convolutions as GEMMs); slices added in a fixed order.  TRAINING TAPE ONLY: a row's bits depend on the slice count,
+ * hence on the shape of the call -- the evaluation keeps itr_gemm_nt.  Falls back to itr_gemm_nt when no split is chosen. */
+size_t itr_gemm_nt_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int itr_gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M,
+                       int64_t N, int64_t K, int act, void *workspace, size_t workspace_bytes, itr_stream_t stream);
 /* Weight gradient of a dense layer, dW = dY^T X:  C[P, Q] (+)= A[R, P]^T B[R, Q] (row-major, the REDUCED index is the row of
  * both operands: no transposed copies).  The rows are split into slices whose partial products (workspace) are added in slice
  * order: deterministic.  accumulate != 0 adds to C.  colsum_a (may be NULL) receives sum_r A[r, :] -- the bias gradient, from the

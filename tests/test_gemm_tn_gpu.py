@@ -82,3 +82,18 @@ def test_skinny_gemm_vs_float64(dev, M, N, K, bias, act):
     y.sum().backward()
     assert float((y.detach().double() - (a.double() @ w.double().t() + (b.double() if bias else 0))).abs().max()) <= 2e-5 * K ** 0.5
     assert float((x.grad.double() - w.double().sum(0)).abs().max()) <= 2e-4 * N ** 0.5
+
+
+@pytest.mark.parametrize("M,N,K", [(4608, 128, 10240), (4608, 256, 2048), (300, 128, 6144), (4608, 1024, 2048)])
+def test_linear_splits_k_when_the_output_has_few_tiles(dev, M, N, K):
+    """itr_gemm_nt_splitk through autograd.linear (CAMERA's dilated convolutions as GEMMs: 4 608 x 128 outputs over K = 6 144 / 10 240);
+    the last shape has enough tiles and takes the plain kernel."""
+    torch.manual_seed(N)
+    x = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) * 0.05
+    b = torch.randn(N, device=dev)
+    y = ag.linear(x, w, b)
+    idx = torch.randint(0, M, (257,), device=dev)
+    want = x[idx].double() @ w.double().t() + b.double()
+    assert float((y[idx].double() - want).abs().max()) <= 2e-5 * K ** 0.5
+    assert torch.equal(y, ag.linear(x, w, b))            # slices are added in a fixed order
