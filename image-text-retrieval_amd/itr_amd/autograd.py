@@ -92,7 +92,8 @@ class _Linear(torch.autograd.Function):
         out = _f32(M, N, dev=x.device)
         if M <= 128:       # (training tape only: the evaluation keeps ONE kernel family per product so that a row does not depend on M)
             _lib.check(lib.itr_gemm_nt_algo(_p(x2), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, 4, _stream()))
-        elif K >= 2048 and ((M + 127) // 128) * ((N + 127) // 128) < 64:      # few output tiles, long K: slices of K (CAMERA's convolutions)
+        elif K >= 512 and ((M + 127) // 128) * ((N + 127) // 128) < 128:      # too few output tiles to fill the chip: slices of K (CAMERA's
+            # convolutions as GEMMs: 36 tiles over K = 10 240; BERT's 768-wide layers at batch 64: 96 tiles); the library picks the slice count
             wsb = lib.itr_gemm_nt_splitk_workspace_bytes(M, N, K)
             ws = torch.empty(max(wsb, 1), device=x.device, dtype=torch.uint8)
             _lib.check(lib.itr_gemm_nt_splitk(_p(x2), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, _p(ws), wsb, _stream()))
