@@ -137,25 +137,32 @@ __global__ __launch_bounds__(256) void sgt_ctx_fwd_kernel(const float *__restric
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 *img4 = reinterpret_cast<const float4 *>(img) + (int64_t)b * R * D4;
-    for (int r = 0; r < R; ++r) {
-        float4 x[VEC];
+    for (int r0 = 0; r0 < R; r0 += 4) {        // four regions' columns requested together (one memory latency per four regions, not per region)
+        float4 xb[4][VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) x[v] = tid + v * 256 < D4 ? img4[(int64_t)r * D4 + tid + v * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 *pr = reinterpret_cast<const float4 *>(Ptt + r * SGT_TW);
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int q = 0; q < SGT_TW / 4; ++q) {
-            const float4 p4 = pr[q];
-            const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+            for (int v = 0; v < VEC; ++v)
+                xb[j][v] = (r0 + j < R && tid + v * 256 < D4) ? img4[(int64_t)(r0 + j) * D4 + tid + v * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + j < R ? r0 + j : R - 1;
+            const float4 *pr = reinterpret_cast<const float4 *>(Ptt + r * SGT_TW);
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    float4 &c = acc[q * 4 + k][v];
-                    c.x = fmaf(pp[k], x[v].x, c.x);
-                    c.y = fmaf(pp[k], x[v].y, c.y);
-                    c.z = fmaf(pp[k], x[v].z, c.z);
-                    c.w = fmaf(pp[k], x[v].w, c.w);
-                }
+            for (int q = 0; q < SGT_TW / 4; ++q) {
+                const float4 p4 = pr[q];
+                const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        float4 &c = acc[q * 4 + k][v];
+                        c.x = fmaf(pp[k], xb[j][v].x, c.x);
+                        c.y = fmaf(pp[k], xb[j][v].y, c.y);
+                        c.z = fmaf(pp[k], xb[j][v].z, c.z);
+                        c.w = fmaf(pp[k], xb[j][v].w, c.w);
+                    }
+            }
         }
     }
 #pragma unroll
@@ -232,8 +239,8 @@ __global__ __launch_bounds__(256) void sgt_ctx_bwd_kernel(const float *__restric
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 *img4 = reinterpret_cast<const float4 *>(img) + (int64_t)b * R * D4;
-        for (int r = 0; r < R; ++r) {
-            float4 x[VEC];
+        for (int r = 0; r < R; ++r) {       // (one region per iteration: requesting four at once, as the forward kernel does, measured SLOWER here --
+            float4 x[VEC];                  //  1 011 -> 1 100-1 260 us: the kernel is at 174 registers already)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) x[v] = tid + v * 256 < D4 ? img4[(int64_t)r * D4 + tid + v * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 *pr = reinterpret_cast<const float4 *>(Ptt + r * SGT_TB);
@@ -454,11 +461,21 @@ __device__ __forceinline__ void sgt_colmix(const float *M, bool trans, int nv, i
             float acc[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            for (int r = 0; r < ni; ++r) {
-                const float x = in[(int64_t)r * S + s];
+            // the column values of eight inner rows are REQUESTED together and then consumed (a load -> 16 fmaf -> load chain paid one
+            // memory latency per inner row: 21 x 3 products x 2 output chunks per workgroup -- most of the kernel's 1.16 ms, round 6)
+            for (int r0 = 0; r0 < ni; r0 += 8) {
+                float x[8];
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (o0 + i < no) acc[i] = fmaf(trans ? M[r * nr + o0 + i] : M[(o0 + i) * nr + r], x, acc[i]);
+                for (int j = 0; j < 8; ++j) x[j] = r0 + j < ni ? in[(int64_t)(r0 + j) * S + s] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = r0 + j;
+                    if (r < ni) {                                         // (uniform over the workgroup)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (o0 + i < no) acc[i] = fmaf(trans ? M[r * nr + o0 + i] : M[(o0 + i) * nr + r], x[j], acc[i]);
+                    }
+                }
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i)
