@@ -155,9 +155,11 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__rest
     C[(int64_t)p * ldc + q] = s;
 }
 
+// the smallest tile that covers the smaller output dimension in ONE tile where it can (<= 128): a 36-row output (d regions = P^T dC per
+// image) on 32-wide tiles read the other operand -- 872 MB -- twice
 static int tn_tile(int P, int Q) {
     const int m = P < Q ? P : Q;
-    return m >= 96 ? 128 : (m >= 48 ? 64 : 32);
+    return m > 64 ? 128 : (m > 32 ? 64 : 32);
 }
 static void tn_plan(int64_t R, int P, int Q, int *T, int *nsl, int64_t *rows_per_slice) {
     *T = tn_tile(P, Q);
