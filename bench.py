@@ -1017,6 +1017,8 @@ def main():
     SETTINGS.force_collectives = os.environ.get("ITR_FORCE_COLLECTIVES") == "1"
     if os.environ.get("ITR_SGRAF_IB"):
         SETTINGS.sgraf_image_block = int(os.environ["ITR_SGRAF_IB"])
+    if os.environ.get("ITR_SGR_GROUP_ROWS") == "32":          # tools/ab_sgr.sh: the two-class node-group plan (same scores)
+        SETTINGS.sgr_group_rows = 32
     backend = os.environ.get("ITR_DIST_BACKEND", "nccl")   # "gloo": several ranks on ONE GPU (tests); collectives staged through the host
     have_gpu = not args.launch_check or torch.cuda.is_available()
     if backend == "gloo":

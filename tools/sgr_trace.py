@@ -24,12 +24,14 @@ n_rows = int(lengths.sum())
 img = ops.l2norm(torch.randn(n_img, 36, D, device=dev))
 words = ops.l2norm(torch.randn(n_rows, D, device=dev))
 w = {k: v.to(dev) for k, v in bench.make_sgraf_weights("SGR", D=D).items()}
+ROWS = int(os.environ.get("ITR_SGR_GROUP_ROWS", "64"))      # which class of groups: 64 (default) or 32 (two workgroups per CU)
+from itr_amd.settings import SETTINGS                        # (the package reads no environment variable: this tool sets the switch)
+SETTINGS.sgr_group_rows = ROWS
 plan = ops.ScanPlan(off, lengths, n_rows, dev)
 for _ in range(2):
     ops.sgraf_scores(img, words, plan, w, "SGR", 3)
 torch.cuda.synchronize()
 
-ROWS = int(os.environ.get("ITR_SGR_GROUP_ROWS", "64"))      # which class of groups: 64 (default) or 32 (ITR_SGR_GROUP_ROWS=32: two workgroups per CU)
 rec = np.fromfile("%s.%d" % (TRACE, ROWS), dtype=np.uint64).reshape(-1, 20)
 rec = rec[rec[:, 2] != 0]
 shape = rec[:, 1]
