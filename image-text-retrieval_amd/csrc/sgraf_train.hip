@@ -16,6 +16,7 @@
 // of the backward pass run along whole axes: d words = sum over b, d regions = sum over t.  The dense layers between these stages are
 // the library's GEMMs (autograd.linear: NT forward / dx, split-row TN for dW); this file is the ragged glue, forward and backward.
 #include "itr_common.h"
+#include <mutex>
 
 namespace itr {
 
@@ -216,15 +217,11 @@ __global__ __launch_bounds__(256) void sgt_ctx_bwd_kernel(const float *__restric
     const float4 *w4 = reinterpret_cast<const float4 *>(words);
     const float4 *dX4 = reinterpret_cast<const float4 *>(dX);
     float4 *dc4 = reinterpret_cast<float4 *>(dctx);
-    float4 wreg[SGT_TB][VEC], dw[SGT_TB][VEC];
+    float4 dw[SGT_TB][VEC];      // (the word rows are re-read per image from the cache: 32 registers less -> one more wave per SIMD)
 #pragma unroll
     for (int i = 0; i < SGT_TB; ++i)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const int col = tid + v * 256;
-            wreg[i][v] = (i < nt && col < D4) ? w4[(int64_t)(t0 + i) * D4 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
-            dw[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int v = 0; v < VEC; ++v) dw[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int b = b0; b < b1; ++b) {
         __syncthreads();
         const float *Pb = P + ((int64_t)b * T + t0) * R;
@@ -270,11 +267,13 @@ __global__ __launch_bounds__(256) void sgt_ctx_bwd_kernel(const float *__restric
                     const int col = tid + v * 256;
                     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (col < D4) d = dX4[((int64_t)b * T + t0 + i) * D4 + col];
+                    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (col < D4) wv = w4[(int64_t)(t0 + i) * D4 + col];
                     float4 q;
-                    q.x = 2.f * (acc[i][v].x / ne - wreg[i][v].x) * d.x;
-                    q.y = 2.f * (acc[i][v].y / ne - wreg[i][v].y) * d.y;
-                    q.z = 2.f * (acc[i][v].z / ne - wreg[i][v].z) * d.z;
-                    q.w = 2.f * (acc[i][v].w / ne - wreg[i][v].w) * d.w;
+                    q.x = 2.f * (acc[i][v].x / ne - wv.x) * d.x;
+                    q.y = 2.f * (acc[i][v].y / ne - wv.y) * d.y;
+                    q.z = 2.f * (acc[i][v].z / ne - wv.z) * d.z;
+                    q.w = 2.f * (acc[i][v].w / ne - wv.w) * d.w;
                     g[i][v] = q;
                     dw[i][v].x -= q.x; dw[i][v].y -= q.y; dw[i][v].z -= q.z; dw[i][v].w -= q.w;
                     s += q.x * acc[i][v].x + q.y * acc[i][v].y + q.z * acc[i][v].z + q.w * acc[i][v].w;
@@ -800,17 +799,39 @@ extern "C" int itr_sgt_ctx_fwd(const float *P, const float *img, const float *wo
     return ITR_OK;
 }
 
-static int sgt_ctx_splits(int B, int T) {
-    const int64_t tiles = ceil_div(T, SGT_TB);
-    int64_t s = ceil_div((int64_t)1024, tiles > 0 ? tiles : 1);
+// Image ranges per word tile of the context backward.  A workgroup walks its images for ~0.5 ms, so the grid should be ONE full round of
+// the chip's resident workgroups (1.24 rounds -- 955 workgroups on 768 slots -- took as long as two: round 6), never a round and a bit:
+// splits = resident slots / word tiles, rounded down (resident = CUs x the occupancy the runtime reports for this kernel, cached per
+// device).  The result only changes the order of the partial sums' final addition.
+static int sgt_ctx_splits(int B, int T, int D) {
+    static std::mutex mu;
+    static int64_t resident_of[16][2] = {};
+    int dev = 0;
+    int64_t resident = 768;
+    const int vi = D <= 1024 ? 0 : 1;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!resident_of[dev][vi]) {
+            hipDeviceProp_t prop;
+            int per_cu = 0;
+            const hipError_t e = vi == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgt_ctx_bwd_kernel<1>, 256, 4096)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sgt_ctx_bwd_kernel<2>, 256, 4096);
+            if (e == hipSuccess && per_cu >= 1 && hipGetDeviceProperties(&prop, dev) == hipSuccess) resident_of[dev][vi] = (int64_t)prop.multiProcessorCount * per_cu;
+            else { (void)hipGetLastError(); resident_of[dev][vi] = 768; }
+        }
+        resident = resident_of[dev][vi];
+    }
+    const int64_t tiles = ceil_div(T > 0 ? T : 1, SGT_TB);
+    int64_t s = resident / tiles;
     if (s > B) s = B;
     if (s > 16) s = 16;
     return (int)(s < 1 ? 1 : s);
 }
 extern "C" size_t itr_sgt_ctx_bwd_workspace_bytes(int B, int T, int D) {
     if (B < 1 || T < 1 || D < 1) return 0;
-    const int s = sgt_ctx_splits(B, T);
-    return (size_t)ceil_div(B, ceil_div(B, s)) * T * D * sizeof(float);
+    (void)sgt_ctx_splits;      // (the split count depends on the device: size for the most it can be)
+    const int s = B < 16 ? B : 16;
+    return (size_t)s * T * D * sizeof(float);
 }
 extern "C" int itr_sgt_ctx_bwd(const float *P, const float *img, const float *words, const float *cnorm, const float *dX, int B, int T, int R, int D,
                                float eps, float *dctx, float *dwords, void *workspace, size_t workspace_bytes, itr_stream_t stream) {
@@ -818,7 +839,7 @@ extern "C" int itr_sgt_ctx_bwd(const float *P, const float *img, const float *wo
     ITR_UNSUPPORTED(D % 4 != 0 || D > 2048, "itr_sgt_ctx_bwd: embedding width %d (a multiple of 4, at most 2048)", D);
     if (B == 0 || T == 0) return ITR_OK;
     ITR_REQUIRE(P && img && words && cnorm && dX && dctx && dwords && workspace, "itr_sgt_ctx_bwd: null pointer");
-    const int bps = (int)ceil_div(B, sgt_ctx_splits(B, T));
+    const int bps = (int)ceil_div(B, sgt_ctx_splits(B, T, D));
     const int ns = (int)ceil_div(B, bps);
     ITR_REQUIRE(workspace_bytes >= (size_t)ns * T * D * sizeof(float), "itr_sgt_ctx_bwd: workspace too small (itr_sgt_ctx_bwd_workspace_bytes)");
     const size_t lds = ((size_t)R * SGT_TB + SGT_TB * 4) * sizeof(float);
