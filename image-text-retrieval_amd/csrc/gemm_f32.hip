@@ -368,6 +368,18 @@ int gemm_splitk_choice(int64_t M, int64_t N, int64_t K) {
     return s_ < 1 ? 1 : (s_ > 16 ? 16 : s_);
 }
 
+// The training tape's choice (itr_gemm_nt_splitk): two workgroups of the tile kernel fit a CU (64 KB of LDS each) and one alone leaves the
+// matrix pipe idle while it waits for LDS, so the launch aims at 2 x 256 resident workgroups and never at a round and a bit -- BERT's
+// 2 048 x 768 products over K = 3 072 are 96 tiles: 5 slices = 480 workgroups (2 slices = 192 took 150 us for a 61 us product: round 6).
+int gemm_splitk_choice_fill(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
+    if (tiles >= 128 || tiles < 1 || K < 256) return 1;     // (128-255 tiles: slicing measured slower on CAMERA's 144-tile products)
+    int s_ = (int)(512 / tiles);
+    if (s_ > 8) s_ = 8;          // (CAMERA's 36-tile products over K = 10 240: 14 slices measured slower than 7 -- the slices' sum grows with them)
+    while (s_ > 1 && K / s_ < 128) --s_;
+    return s_ < 1 ? 1 : s_;
+}
+
 int gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N,
                    int64_t K, int act, int accumulate, int splits, float *scratch, hipStream_t st) {
     if (M == 0 || N == 0) return ITR_OK;
@@ -548,7 +560,7 @@ extern "C" int itr_mvm_scores(const float *imgs, const float *caps, float *S, in
 // 10 240: 36 tiles, 0.4 ms each on 40 workgroups.  Slices are added in a fixed order (deterministic).
 extern "C" size_t itr_gemm_nt_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M < 1 || N < 1 || K < 1) return 0;
-    const int s_ = itr::gemm_splitk_choice(M, N, K);
+    const int s_ = itr::gemm_splitk_choice_fill(M, N, K);
     return s_ > 1 ? itr::gemm_splitk_scratch_bytes(M, N, s_) : 0;
 }
 
@@ -559,7 +571,7 @@ extern "C" int itr_gemm_nt_splitk(const float *A, int64_t lda, const float *B, i
     ITR_REQUIRE(A && B && C, "itr_gemm_nt_splitk: null pointer");
     ITR_REQUIRE(lda >= K && ldb >= K && ldc >= N, "itr_gemm_nt_splitk: leading dimension smaller than row");
     ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt_splitk: unknown activation %d", act);
-    const int s_ = itr::gemm_splitk_choice(M, N, K);
+    const int s_ = itr::gemm_splitk_choice_fill(M, N, K);
     if (s_ <= 1) return itr::gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream));
     ITR_REQUIRE(workspace && workspace_bytes >= itr::gemm_splitk_scratch_bytes(M, N, s_), "itr_gemm_nt_splitk: workspace too small (itr_gemm_nt_splitk_workspace_bytes)");
     return itr::gemm_nt_splitk(A, lda, B, ldb, bias, C, ldc, M, N, K, act, 0, s_, static_cast<float *>(workspace), itr::as_stream(stream));
