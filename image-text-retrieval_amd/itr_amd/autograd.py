@@ -47,6 +47,82 @@ def colsum(x, out=None, accumulate=False):
     return out
 
 
+def _peel_plan(M, N, K):
+    """A dense product of the tape whose 128 x 128 output tiles are a round and a bit of the chip: which part to give to a launch
+    of its own.  The tile kernel keeps at most 2 x 256 workgroups resident (two per CU share the matrix pipe), so 576 tiles -- VSRN's
+    4 608 x 2 048 layers -- take as long as 1 024 (398 us for a 246 us product: round 6).  Peeling whole rows or columns of tiles so that
+    the main launch is exactly one or two per CU, and cutting the few peeled tiles along K so that THEY fill the chip
+    (itr_gemm_nt_splitk), costs a launch and a slice sum.  Returns None, ('rows', main_rows) or ('cols', main_cols); a model in units
+    of one tile's time on a CU of its own.  Training tape only: an element's summation order then depends on the shape of the call."""
+    tm, tn = (M + 127) // 128, (N + 127) // 128
+    tiles = tm * tn
+    if tiles <= 256 or tiles >= 1024 or K < 512:       # (from 1 024 tiles the streaming kernel takes the product)
+        return None
+
+    def cost(t):
+        return 0.0 if t == 0 else (1.0 if t <= 256 else 2.0 * ((t + 511) // 512))
+
+    def tail_cost(t):
+        if t >= 128:
+            return cost(t) + 0.1
+        s = min(8, 512 // t)
+        while s > 1 and K // s < 128:
+            s -= 1
+        w = t * s
+        return (1.0 if w <= 256 else 2.0 * ((w + 511) // 512)) / s + 0.15
+
+    best, plan = cost(tiles) - 0.3, None
+    for r in range(1, tm):
+        c = cost((tm - r) * tn) + tail_cost(r * tn)
+        if c < best:
+            best, plan = c, ('rows', (tm - r) * 128)
+    for q in range(1, tn):
+        c = cost(tm * (tn - q)) + tail_cost(tm * q)
+        if c < best:
+            best, plan = c, ('cols', (tn - q) * 128)
+    return plan
+
+
+def _nt_call(lib, a_ptr, w_ptr, b_ptr, o_ptr, ldc, M, N, K, dev, sliced):
+    """One launch: C [M, N] (row stride ldc) = A [M, K] . W [N, K]^T + b; sliced: cut K so that few tiles fill the chip."""
+    vp = C.c_void_p
+    if sliced:
+        wsb = lib.itr_gemm_nt_splitk_workspace_bytes(M, N, K)
+        ws = torch.empty(max(wsb, 1), device=dev, dtype=torch.uint8)
+        _lib.check(lib.itr_gemm_nt_splitk(vp(a_ptr), K, vp(w_ptr), K, vp(b_ptr), vp(o_ptr), ldc, M, N, K, 0, _p(ws), wsb, _stream()))
+    else:
+        _lib.check(lib.itr_gemm_nt(vp(a_ptr), K, vp(w_ptr), K, vp(b_ptr), vp(o_ptr), ldc, M, N, K, 0, _stream()))
+
+
+def _nt_tape(lib, a, w, b, out):
+    """out [M, N] = a [M, K] . w [N, K]^T + b for the training tape (contiguous operands), by the shape of the product: <= 128 rows ->
+    16-column strips (algo 4); few output tiles -> slices of K; a round and a bit of tiles -> peeled (_peel_plan); else the plain call.
+    (The evaluation keeps ONE kernel family per product so that a row's result does not depend on M.)"""
+    M, K = a.shape
+    N = w.shape[0]
+    if M == 0 or N == 0:
+        return out
+    pa, pw, po = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    pb = b.data_ptr() if b is not None else 0
+    if M <= 128:
+        _lib.check(lib.itr_gemm_nt_algo(_p(a), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, 4, _stream()))
+    elif K >= 512 and ((M + 127) // 128) * ((N + 127) // 128) < 128:      # CAMERA's convolutions as GEMMs: 36 tiles over K = 10 240;
+        _nt_call(lib, pa, pw, pb, po, N, M, N, K, a.device, True)         # BERT's 768-wide layers at batch 64: 96 tiles
+    else:
+        plan = _peel_plan(M, N, K)
+        if plan is None:
+            _nt_call(lib, pa, pw, pb, po, N, M, N, K, a.device, False)
+        elif plan[0] == 'rows':
+            m0 = plan[1]
+            _nt_call(lib, pa, pw, pb, po, N, m0, N, K, a.device, False)
+            _nt_call(lib, pa + 4 * m0 * K, pw, pb, po + 4 * m0 * N, N, M - m0, N, K, a.device, True)
+        else:
+            n0 = plan[1]
+            _nt_call(lib, pa, pw, pb, po, N, M, n0, K, a.device, False)
+            _nt_call(lib, pa, pw + 4 * n0 * K, pb + 4 * n0 if pb else 0, po + 4 * n0, N, M, N - n0, K, a.device, True)
+    return out
+
+
 def _gemm_nt(a, b, out=None, accumulate=False):
     """a [M, K] . b [N, K]^T -> [M, N] on the MFMA GEMM."""
     lib = _lib.load()
@@ -55,11 +131,12 @@ def _gemm_nt(a, b, out=None, accumulate=False):
     assert b.shape[1] == K
     if out is None:
         out = _f32(M, N, dev=a.device)
-    if not accumulate and M <= 128:      # a batch of <= 128 rows (decoder steps, per-caption vectors): the skinny kernel (algo 4)
-        _lib.check(lib.itr_gemm_nt_algo(_p(a), K, _p(b), K, _p(None), _p(out), N, M, N, K, 0, 4, _stream()))
+    if not accumulate:
+        if a.is_contiguous() and b.is_contiguous() and out.is_contiguous():
+            return _nt_tape(lib, a, b, None, out)
+        _lib.check(lib.itr_gemm_nt(_p(a), K, _p(b), K, _p(None), _p(out), N, M, N, K, 0, _stream()))
         return out
-    fn = lib.itr_gemm_nt_acc if accumulate else lib.itr_gemm_nt
-    _lib.check(fn(_p(a), K, _p(b), K, _p(None), _p(out), N, M, N, K, 0, _stream()))
+    _lib.check(lib.itr_gemm_nt_acc(_p(a), K, _p(b), K, _p(None), _p(out), N, M, N, K, 0, _stream()))
     return out
 
 
@@ -90,15 +167,7 @@ class _Linear(torch.autograd.Function):
         if w.dim() != 2 or w.shape[1] != K:
             raise ValueError("linear: x (..., %d) vs weight %s" % (K, tuple(w.shape)))
         out = _f32(M, N, dev=x.device)
-        if M <= 128:       # (training tape only: the evaluation keeps ONE kernel family per product so that a row does not depend on M)
-            _lib.check(lib.itr_gemm_nt_algo(_p(x2), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, 4, _stream()))
-        elif K >= 512 and ((M + 127) // 128) * ((N + 127) // 128) < 128:      # too few output tiles to fill the chip: slices of K (CAMERA's
-            # convolutions as GEMMs: 36 tiles over K = 10 240; BERT's 768-wide layers at batch 64: 96 tiles); the library picks the slice count
-            wsb = lib.itr_gemm_nt_splitk_workspace_bytes(M, N, K)
-            ws = torch.empty(max(wsb, 1), device=x.device, dtype=torch.uint8)
-            _lib.check(lib.itr_gemm_nt_splitk(_p(x2), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, _p(ws), wsb, _stream()))
-        else:
-            _lib.check(lib.itr_gemm_nt(_p(x2), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, _stream()))
+        _nt_tape(lib, x2.contiguous(), w.contiguous(), b, out)
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.xshape = x.shape

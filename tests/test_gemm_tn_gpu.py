@@ -97,3 +97,25 @@ def test_linear_splits_k_when_the_output_has_few_tiles(dev, M, N, K):
     want = x[idx].double() @ w.double().t() + b.double()
     assert float((y[idx].double() - want).abs().max()) <= 2e-5 * K ** 0.5
     assert torch.equal(y, ag.linear(x, w, b))            # slices are added in a fixed order
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(4608, 2048, 2048, True),       # 576 tiles: the last 4 row tiles peeled (VSRN's graph-convolution layers)
+                                        (2048, 2304, 768, True),        # 288 tiles (BERT's fused Q/K/V at batch 64 x 32 tokens)
+                                        (4700, 2000, 1024, False),      # ragged rows and columns, 592 tiles
+                                        (2048, 3072, 768, True)])       # 384 tiles: no plan pays, one launch
+def test_linear_peels_a_round_and_a_bit_of_tiles(dev, M, N, K, bias):
+    """autograd._peel_plan: the main launch and the K-sliced tail together are the product (float64 reference on sampled rows that
+    cover both parts), forward and input gradient, and the same bits on every call."""
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K, device=dev, requires_grad=True)
+    w = (torch.randn(N, K, device=dev) * 0.05).requires_grad_()
+    b = torch.randn(N, device=dev).requires_grad_() if bias else None
+    y = ag.linear(x, w, b)
+    idx = torch.cat([torch.randint(0, M, (200,), device=dev), torch.arange(M - 130, M, device=dev), torch.arange(0, 3, device=dev)])
+    want = x.detach()[idx].double() @ w.detach().double().t() + (b.detach().double() if bias else 0)
+    assert float((y.detach()[idx].double() - want).abs().max()) <= 2e-5 * K ** 0.5
+    assert torch.equal(y, ag.linear(x, w, b))
+    g = torch.randn_like(y)
+    y.backward(g)
+    want_dx = g[idx].double() @ w.detach().double()
+    assert float((x.grad[idx].double() - want_dx).abs().max()) <= 2e-5 * N ** 0.5

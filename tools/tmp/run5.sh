@@ -1,0 +1,4 @@
+for i in 1 2; do
+timeout 300 python3 tools/train_bench.py --model CAMERA --steps 20 2>&1 | tail -1
+timeout 300 python3 tools/train_bench.py --model SAEM --batch 64 --steps 20 2>&1 | tail -1
+done
