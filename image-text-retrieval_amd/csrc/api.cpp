@@ -15,4 +15,4 @@ void set_error(const char *fmt, ...) {
 }  // namespace itr
 
 extern "C" const char *itr_last_error(void) { return itr::g_err; }
-extern "C" int itr_abi_version(void) { return 29; }
+extern "C" int itr_abi_version(void) { return 30; }

@@ -109,6 +109,51 @@ __global__ __launch_bounds__(256) void add_bcast_mid_act_bwd_kernel(const float 
     dv[b * H + h] = acc;
 }
 
+// The decoder attention's scores in one pass (Attention.forward, Fusionmodule.py:136-141: linear2(tanh(linear1(cat(enc, hidden))))):
+//   e[b, n] = sum_h w[h] tanh(x[b, n, h] + v[b, h])        x = the encoder half of linear1 (+ bias), v = the hidden half, w = linear2's row.
+// One wave per (b, n) row.  As three launches (broadcast add + tanh, a 4 608 x 1 "GEMM" over K slices, the slice sum) the tanh tensor
+// crossed HBM twice per decoder step and the backward ran a K = 1 product on the unaligned tile kernel (round 6: 43 + 74 us per step).
+__global__ __launch_bounds__(256) void addattn_score_fwd_kernel(const float *__restrict__ x, const float *__restrict__ v, const float *__restrict__ w,
+                                                                float *__restrict__ e, int64_t rows, int N, int H) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float *xr = x + row * H, *vr = v + (row / N) * H;
+    float acc = 0.f;
+    if ((H & 3) == 0) {
+        for (int h4 = lane; h4 < H / 4; h4 += 64) {
+            const float4 xv = reinterpret_cast<const float4 *>(xr)[h4], vv = reinterpret_cast<const float4 *>(vr)[h4], ww = reinterpret_cast<const float4 *>(w)[h4];
+            acc += ww.x * apply_act(xv.x + vv.x, 2) + ww.y * apply_act(xv.y + vv.y, 2) + ww.z * apply_act(xv.z + vv.z, 2) + ww.w * apply_act(xv.w + vv.w, 2);
+        }
+    } else {
+        for (int h = lane; h < H; h += 64) acc += w[h] * apply_act(xr[h] + vr[h], 2);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) e[row] = acc;
+}
+// Backward from de[b, n] (the tanh is recomputed):  g = de w[h] (1 - p^2);  dx[b, n, h] = g;  dv[b, h] = sum_n g;
+// dw_part[b, h] = sum_n de[b, n] p  (the caller sums dw_part over b: itr_colsum).
+__global__ __launch_bounds__(256) void addattn_score_bwd_kernel(const float *__restrict__ x, const float *__restrict__ v, const float *__restrict__ w,
+                                                                const float *__restrict__ de, float *__restrict__ dx, float *__restrict__ dv,
+                                                                float *__restrict__ dw_part, int N, int H) {
+    const int64_t b = blockIdx.y;
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= H) return;
+    const float vv = v[b * H + h], wv = w[h];
+    float accv = 0.f, accw = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const int64_t o = (b * N + n) * (int64_t)H + h;
+        const float pv = apply_act(x[o] + vv, 2), d = de[b * N + n];
+        const float g = d * wv * (1.f - pv * pv);
+        dx[o] = g;
+        accv += g;
+        accw += d * pv;
+    }
+    dv[b * H + h] = accv;
+    dw_part[b * H + h] = accw;
+}
+
 }  // namespace itr
 
 extern "C" int itr_gru_cell_fwd(const float *gi, const float *gh, const float *h, float *h_next, float *gates, int64_t B, int H,
@@ -171,5 +216,28 @@ extern "C" int itr_add_bcast_mid_act_bwd(const float *y, const float *dy, float 
     hipLaunchKernelGGL(itr::add_bcast_mid_act_bwd_kernel, dim3((unsigned)itr::ceil_div(H, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), y, dy, dx,
                        dv, N, H, act);
     ITR_CHECK_LAUNCH("add_bcast_mid_act_bwd");
+    return ITR_OK;
+}
+
+extern "C" int itr_addattn_score(const float *x, const float *v, const float *w, float *e, int64_t B, int N, int H, itr_stream_t stream) {
+    ITR_REQUIRE(B >= 0 && N >= 1 && H >= 1 && B * N <= 0x7fffffffLL * 4, "itr_addattn_score: bad shape");
+    if (B == 0) return ITR_OK;
+    ITR_REQUIRE(x && v && w && e, "itr_addattn_score: null pointer");
+    ITR_REQUIRE(H % 4 != 0 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0,
+                "itr_addattn_score: rows of a multiple of 4 floats must start on 16 bytes");
+    hipLaunchKernelGGL(itr::addattn_score_fwd_kernel, dim3((unsigned)itr::ceil_div(B * N, (int64_t)4)), dim3(256), 0, itr::as_stream(stream), x, v, w, e,
+                       B * N, N, H);
+    ITR_CHECK_LAUNCH("addattn_score");
+    return ITR_OK;
+}
+
+extern "C" int itr_addattn_score_bwd(const float *x, const float *v, const float *w, const float *de, float *dx, float *dv, float *dw_part, int64_t B,
+                                     int N, int H, itr_stream_t stream) {
+    ITR_REQUIRE(B >= 0 && B <= 65535 && N >= 1 && H >= 1, "itr_addattn_score_bwd: bad shape");
+    if (B == 0) return ITR_OK;
+    ITR_REQUIRE(x && v && w && de && dx && dv && dw_part, "itr_addattn_score_bwd: null pointer");
+    hipLaunchKernelGGL(itr::addattn_score_bwd_kernel, dim3((unsigned)itr::ceil_div(H, 256), (unsigned)B), dim3(256), 0, itr::as_stream(stream), x, v, w, de,
+                       dx, dv, dw_part, N, H);
+    ITR_CHECK_LAUNCH("addattn_score_bwd");
     return ITR_OK;
 }

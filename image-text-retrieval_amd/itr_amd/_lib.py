@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitr_hip.so")
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 i32, i64, f32, vp, sz, u64 = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64
 
@@ -57,6 +57,8 @@ SIGNATURES = {
     "itr_gru_cell_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "itr_add_bcast_mid_act": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
     "itr_add_bcast_mid_act_bwd": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "itr_addattn_score": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
+    "itr_addattn_score_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "itr_nll_logsoftmax_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
     "itr_nll_logsoftmax_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "itr_gcn_relation": (i32, [vp, i64, vp, i64, i64, i32, i32, vp]),

@@ -836,6 +836,36 @@ def add_bcast_mid_act(x, v, kind=None):
     return _AddBcastMidAct.apply(x, v, kind)
 
 
+class _AddAttnScore(torch.autograd.Function):
+    """e[b, n] = sum_h w[h] tanh(x[b, n, h] + v[b, h]): the decoder attention's linear2(tanh(linear1(cat(enc, hidden)))) with the encoder
+    half x computed once per batch (Attention.forward, Fusionmodule.py:136-141).  The tanh tensor is never stored: the backward recomputes it."""
+
+    @staticmethod
+    def forward(ctx, x, v, w):
+        lib = _lib.load()
+        x, v, w = _dev(x, name="x"), _dev(v, name="v"), _dev(w, name="w")
+        B, N, H = x.shape
+        if tuple(v.shape) != (B, H) or w.numel() != H:
+            raise ValueError("addattn_score: x %s vs v %s, w %s" % (tuple(x.shape), tuple(v.shape), tuple(w.shape)))
+        e = _f32(B, N, dev=x.device)
+        _lib.check(lib.itr_addattn_score(_p(x), _p(v), _p(w), _p(e), B, N, H, _stream()))
+        ctx.save_for_backward(x, v, w)
+        return e
+
+    @staticmethod
+    def backward(ctx, de):
+        lib = _lib.load()
+        x, v, w = ctx.saved_tensors
+        B, N, H = x.shape
+        dx, dv, dwp = torch.empty_like(x), _f32(B, H, dev=x.device), _f32(B, H, dev=x.device)
+        _lib.check(lib.itr_addattn_score_bwd(_p(x), _p(v), _p(w), _p(de.contiguous()), _p(dx), _p(dv), _p(dwp), B, N, H, _stream()))
+        return dx, dv, colsum(dwp).reshape(w.shape)
+
+
+def addattn_score(x, v, w):
+    return _AddAttnScore.apply(x, v, w)
+
+
 class _GateApply(torch.autograd.Function):
     """q' = q * M[:, :dk], k' = k * M[:, dk:]  (camera_.py:41-44); q, k [rows, dk], M [rows, 2 dk]."""
 

@@ -390,8 +390,7 @@ class S2VTAttModel(nn.Module):
         hs = []
         for i in range(steps):
             cur = ag.gather_rows(dec.embedding.weight, labels[:, i].contiguous())
-            pre = ag.add_bcast_mid_act(enc_part, ag.linear(h, W1h, None), 'tanh')
-            e = ag.linear(pre.view(B * N, H), att.linear2.weight, None)
+            e = ag.addattn_score(enc_part, ag.linear(h, W1h, None), att.linear2.weight)      # linear2(tanh(.)) in one pass, [B, N]
             context = ag.summarize(e.view(B, N, 1), enc_out3).view(B, H)                                      # softmax over the regions
             dec_in = ag.dropout(torch.cat([cur, context], 1), dec.input_dropout_p, seeds, training)
             h = ag.gru_cell(dec_in, h, dec.rnn)

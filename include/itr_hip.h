@@ -571,6 +571,13 @@ int itr_gru_cell_bwd(const float *dh_next, const float *gates, const float *gh, 
  * + h W_h^T (per step), added here. */
 int itr_add_bcast_mid_act(const float *x, const float *v, float *y, int64_t B, int N, int H, int act, itr_stream_t stream);
 int itr_add_bcast_mid_act_bwd(const float *y, const float *dy, float *dx, float *dv, int64_t B, int N, int H, int act, itr_stream_t stream);
+/* The decoder attention's scores in one pass (ABI 30; Attention.forward, Fusionmodule.py:136-141: linear2(tanh(linear1(cat(enc, hidden))))):
+ *   e[b, n] = sum_h w[h] tanh(x[b, n, h] + v[b, h])     x [B, N, H] = the encoder half of linear1 (+ bias), v [B, H] = the hidden half, w [H].
+ * Backward from de [B, N], the tanh recomputed: dx[b, n, h] = de w[h] (1 - p^2), dv[b, h] = sum_n dx, dw_part[b, h] = sum_n de[b, n] p
+ * (the caller sums dw_part [B, H] over b: itr_colsum).  B <= 65535 in the backward; rows of H % 4 == 0 floats must be 16-byte aligned. */
+int itr_addattn_score(const float *x, const float *v, const float *w, float *e, int64_t B, int N, int H, itr_stream_t stream);
+int itr_addattn_score_bwd(const float *x, const float *v, const float *w, const float *de, float *dx, float *dv, float *dw_part, int64_t B, int N,
+                          int H, itr_stream_t stream);
 /* loss[b] = -mask[b] * log_softmax(logits[b, :])[target[b]]  (F.log_softmax + NLLLoss(reduce=False) * mask); lse keeps the row
  * log-sum-exp for the backward pass dlogits = dloss[b] mask[b] (softmax - onehot). */
 int itr_nll_logsoftmax_fwd(const float *logits, const int64_t *target, const float *mask, float *loss, float *lse, int64_t B, int V,

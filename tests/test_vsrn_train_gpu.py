@@ -71,3 +71,27 @@ def test_vsrn_train_emb_matches_reference(golden, dev):
                 assert float(d.max()) <= 4 * lr + 1e-7, (k, float(d.max()))
             else:
                 assert float(d.max()) <= 2 * lr + 1e-7 and float(d.mean()) <= 2e-4, (k, float(d.max()), float(d.mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,H", [(128, 36, 512), (3, 5, 300), (2, 1, 7), (70, 36, 2048)])
+def test_addattn_score_vs_float64_autograd(B, N, H):
+    """itr_addattn_score(_bwd): e = linear2(tanh(enc_half + hidden_half)) (Attention.forward, Fusionmodule.py:136-141) in one pass, against
+    torch float64 autograd -- the vector path (H % 4 == 0) and the scalar one, one region, the reference's 36 x 512."""
+    from itr_amd import autograd as ag
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B + H)
+    x = torch.randn(B, N, H, device=dev, requires_grad=True)
+    v = torch.randn(B, H, device=dev, requires_grad=True)
+    w = (torch.randn(1, H, device=dev) * 0.1).requires_grad_()
+    e = ag.addattn_score(x, v, w)
+    g = torch.randn_like(e)
+    e.backward(g)
+    xd, vd, wd = (t.detach().double().requires_grad_() for t in (x, v, w))
+    ed = (torch.tanh(xd + vd[:, None, :]) * wd.view(1, 1, H)).sum(-1)
+    ed.backward(g.double())
+    assert e.shape == (B, N)
+    assert float((e.detach().double() - ed.detach()).abs().max()) <= 2e-5 * H ** 0.5
+    assert float((x.grad.double() - xd.grad).abs().max()) <= 1e-5
+    assert float((v.grad.double() - vd.grad).abs().max()) <= 1e-5 * N
+    assert float((w.grad.double() - wd.grad).abs().max()) <= 2e-5 * (B * N) ** 0.5
