@@ -13,61 +13,91 @@
 
 namespace itr {
 
-constexpr int SK_KC = 64, SK_LD = SK_KC + 4, SK_MAXM = 128;
+constexpr int SK_KC = 64, SK_MAXM = 128;
 
 // DIRECT: one slice (the whole K range), the epilogue adds the bias, applies the activation and writes C (leading dimension ldc) -- the
 // per-step products of a decoder / a 128-row training batch that have no consumer kernel to sum slices for them.
-template <bool DIRECT>
+// NC = 16-column tiles per workgroup, KC = k per LDS chunk.  <1, 64> is the original shape.  <2, 32> (round 6) halves the times the 128
+// rows are pulled from L2 -- the kernel's bound: a 128 x 6 144 x 2 048 product moved 442 MB through 384 strips for 50 MB of weights,
+// 57 us at 7.8 TB/s -- and reuses every LDS fragment twice; 46 KB of LDS, three workgroups per CU.  The k order inside a slice (and so
+// a slice's bits) is the same in both.
+template <bool DIRECT, int NC, int KC>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, int M,
                                                           int64_t N, int K, int kslice, float *__restrict__ part, const float *__restrict__ bias,
                                                           int act, int64_t ldc) {
-    __shared__ __attribute__((aligned(16))) float As[2][SK_MAXM][SK_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][16][SK_LD];
+    constexpr int LD = KC + 4, NA = KC / 8, NB = NC * KC / 64, C4 = KC / 4;      // float4 loads per thread and chunk: rows, weights
+    static_assert(NB >= 1 && NA >= 1, "chunk too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) float As[2][SK_MAXM][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16 * NC][LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    const int64_t n0 = (int64_t)blockIdx.x * 16 * NC;
     const int k_begin = blockIdx.y * kslice;
     const int k_end = k_begin + kslice < K ? k_begin + kslice : K;
     const int rtiles = (M + 15) >> 4;
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    float4 ra[8], rb;
+    f32x4 acc[2][NC];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[NA], rb[NB];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 4, c4 = (idx & 15) * 4;
+        for (int j = 0; j < NA; ++j) {
+            const int idx = tid + 256 * j, row = idx / C4, c4 = (idx % C4) * 4;
             ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < M && k0 + c4 < k_end) ra[j] = *reinterpret_cast<const float4 *>(A + (int64_t)row * lda + k0 + c4);
         }
-        {
-            const int row = tid >> 4, c4 = (tid & 15) * 4;
-            rb = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n0 + row < N && k0 + c4 < k_end) rb = *reinterpret_cast<const float4 *>(B + (n0 + row) * ldb + k0 + c4);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = tid + 256 * j, row = idx / C4, c4 = (idx % C4) * 4;
+            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + row < N && k0 + c4 < k_end) rb[j] = *reinterpret_cast<const float4 *>(B + (n0 + row) * ldb + k0 + c4);
         }
     };
     auto park = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 4, c4 = (idx & 15) * 4;
-            *reinterpret_cast<float4 *>(&As[buf][row][c4]) = ra[j];
+        for (int j = 0; j < NA; ++j) {
+            const int idx = tid + 256 * j;
+            *reinterpret_cast<float4 *>(&As[buf][idx / C4][(idx % C4) * 4]) = ra[j];
         }
-        *reinterpret_cast<float4 *>(&Bs[buf][tid >> 4][(tid & 15) * 4]) = rb;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = tid + 256 * j;
+            *reinterpret_cast<float4 *>(&Bs[buf][idx / C4][(idx % C4) * 4]) = rb[j];
+        }
     };
     if (k_begin < k_end) {
         fetch(k_begin);
         park(0);
         __syncthreads();
         int buf = 0;
-        for (int k0 = k_begin; k0 < k_end; k0 += SK_KC) {
-            const bool more = k0 + SK_KC < k_end;
-            if (more) fetch(k0 + SK_KC);
+        const bool t0 = wave < rtiles, t1 = wave + 4 < rtiles;
+        for (int k0 = k_begin; k0 < k_end; k0 += KC) {
+            const bool more = k0 + KC < k_end;
+            if (more) fetch(k0 + KC);
+            // (the two shapes of the loop are separate bodies: a branch inside the unrolled loop ends the scheduler's region at every k-step
+            // and serialises LDS read -> wait -> MFMA: 21.9 -> 30.7 us on the 32-workgroup decoder products when it was tried)
+            if (t1) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int rt = wave + 4 * t;
-                if (rt < rtiles) {
+                for (int kk = 0; kk < KC / 4; ++kk) {
+                    const int k = kk * 4 + (lane >> 4);
+                    float bf[NC];
 #pragma unroll
-                    for (int kk = 0; kk < SK_KC / 4; ++kk) {
-                        const int k = kk * 4 + (lane >> 4);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[buf][rt * 16 + (lane & 15)][k], Bs[buf][lane & 15][k], acc[t], 0, 0, 0);
+                    for (int c = 0; c < NC; ++c) bf[c] = Bs[buf][16 * c + (lane & 15)][k];
+                    const float a0 = As[buf][wave * 16 + (lane & 15)][k], a1 = As[buf][(wave + 4) * 16 + (lane & 15)][k];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf[c], acc[0][c], 0, 0, 0);
+                        acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf[c], acc[1][c], 0, 0, 0);
                     }
+                }
+            } else if (t0) {
+#pragma unroll
+                for (int kk = 0; kk < KC / 4; ++kk) {
+                    const int k = kk * 4 + (lane >> 4);
+                    const float a0 = As[buf][wave * 16 + (lane & 15)][k];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, Bs[buf][16 * c + (lane & 15)][k], acc[0][c], 0, 0, 0);
                 }
             }
             if (more) park(buf ^ 1);
@@ -77,16 +107,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float *__restric
     }
     float *o = DIRECT ? part : part + (int64_t)blockIdx.y * M * N;
     const int64_t ldo = DIRECT ? ldc : N;
-    const int64_t n = n0 + (lane & 15);
-    if (n < N) {
-        const float bv = (DIRECT && bias) ? bias[n] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int rt = wave + 4 * t;
+    for (int c = 0; c < NC; ++c) {
+        const int64_t n = n0 + 16 * c + (lane & 15);
+        if (n < N) {
+            const float bv = (DIRECT && bias) ? bias[n] : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = rt * 16 + 4 * (lane >> 4) + q;
-                if (m < M) o[(int64_t)m * ldo + n] = DIRECT ? apply_act(acc[t][q] + bv, act) : acc[t][q];
+            for (int t = 0; t < 2; ++t) {
+                const int rt = wave + 4 * t;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = rt * 16 + 4 * (lane >> 4) + q;
+                    if (m < M) o[(int64_t)m * ldo + n] = DIRECT ? apply_act(acc[t][c][q] + bv, act) : acc[t][c][q];
+                }
             }
         }
     }
@@ -100,16 +133,23 @@ bool gemm_skinny_ok(const float *A, int64_t lda, const float *B, int64_t ldb, in
 // partial products part[slice][m][n] (row-major, leading dimension N) for *n_slices <= max_slices slices of the K range
 int gemm_skinny_partials(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int64_t N, int64_t K, int max_slices, float *part,
                          int *n_slices, hipStream_t st) {
-    const int64_t col_tiles = ceil_div(N, (int64_t)16);
-    int64_t s = ceil_div((int64_t)384, col_tiles);                  // ~1.5 workgroups per CU
-    const int64_t by_k = K / (2 * SK_KC) > 0 ? K / (2 * SK_KC) : 1; // a slice is at least two chunks
+    // 32-column strips from 1 024 columns up (the recurrence products: 3 D and D columns of a D >= 1 024 GRU); 16-column strips keep the
+    // narrow ones spread over the chip
+    const bool wide = N >= 1024;
+    const int64_t col_tiles = ceil_div(N, (int64_t)(wide ? 32 : 16));
+    int64_t s = ceil_div((int64_t)(wide ? 512 : 384), col_tiles);   // ~1.5 workgroups per CU (2 of the 46 KB ones)
+    const int64_t by_k = K / (2 * SK_KC) > 0 ? K / (2 * SK_KC) : 1; // a slice is at least 128 k
     if (s > by_k) s = by_k;
     if (s > max_slices) s = max_slices;
     if (s < 1) s = 1;
     const int kslice = (int)(ceil_div(ceil_div(K, s), (int64_t)SK_KC) * SK_KC);
     const int ns = (int)ceil_div(K, (int64_t)kslice);
-    hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3((unsigned)col_tiles, (unsigned)ns), dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K, kslice, part,
-                       (const float *)nullptr, 0, (int64_t)0);
+    if (wide)
+        hipLaunchKernelGGL((gemm_skinny_kernel<false, 2, 32>), dim3((unsigned)col_tiles, (unsigned)ns), dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K,
+                           kslice, part, (const float *)nullptr, 0, (int64_t)0);
+    else
+        hipLaunchKernelGGL((gemm_skinny_kernel<false, 1, SK_KC>), dim3((unsigned)col_tiles, (unsigned)ns), dim3(256), 0, st, A, lda, B, ldb, (int)M, N,
+                           (int)K, kslice, part, (const float *)nullptr, 0, (int64_t)0);
     ITR_CHECK_LAUNCH("gemm_skinny");
     *n_slices = ns;
     return ITR_OK;
@@ -119,7 +159,7 @@ int gemm_skinny_partials(const float *A, int64_t lda, const float *B, int64_t ld
 int gemm_skinny_direct(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                        int act, hipStream_t st) {
     const int kslice = (int)(ceil_div(K, (int64_t)SK_KC) * SK_KC);
-    hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3((unsigned)ceil_div(N, (int64_t)16), 1u), dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K, kslice, C,
+    hipLaunchKernelGGL((gemm_skinny_kernel<true, 1, SK_KC>), dim3((unsigned)ceil_div(N, (int64_t)16), 1u), dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K, kslice, C,
                        bias, act, ldc);
     ITR_CHECK_LAUNCH("gemm_skinny(direct)");
     return ITR_OK;
