@@ -560,6 +560,7 @@ extern "C" int itr_mvm_scores(const float *imgs, const float *caps, float *S, in
 // 10 240: 36 tiles, 0.4 ms each on 40 workgroups.  Slices are added in a fixed order (deterministic).
 extern "C" size_t itr_gemm_nt_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M < 1 || N < 1 || K < 1) return 0;
+    if (M <= 128 && N >= 16 && K >= 128) return itr::gemm_splitk_scratch_bytes(M, N, 16);      // the skinny kernel's slices (at most 16)
     const int s_ = itr::gemm_splitk_choice_fill(M, N, K);
     return s_ > 1 ? itr::gemm_splitk_scratch_bytes(M, N, s_) : 0;
 }
@@ -571,6 +572,18 @@ extern "C" int itr_gemm_nt_splitk(const float *A, int64_t lda, const float *B, i
     ITR_REQUIRE(A && B && C, "itr_gemm_nt_splitk: null pointer");
     ITR_REQUIRE(lda >= K && ldb >= K && ldc >= N, "itr_gemm_nt_splitk: leading dimension smaller than row");
     ITR_REQUIRE(act >= 0 && act <= 5, "itr_gemm_nt_splitk: unknown activation %d", act);
+    // <= 128 rows (a decoder step's layers: 16-96 strips of 16 columns, a workgroup's life ~1 us per 64 k): the skinny kernel over K slices
+    // -- 128-384 short workgroups -- and one pass that adds the slices, the bias and the activation (21 -> ~10 us on 128 x 512 x 512)
+    if (M <= 128 && N >= 16 && K >= 128 && itr::gemm_skinny_ok(A, lda, B, ldb, M, N, K) && workspace &&
+        workspace_bytes >= itr::gemm_splitk_scratch_bytes(M, N, 16)) {
+        int ns = 0;
+        const int rc = itr::gemm_skinny_partials(A, lda, B, ldb, M, N, K, 16, static_cast<float *>(workspace), &ns, itr::as_stream(stream));
+        if (rc != ITR_OK) return rc;
+        hipLaunchKernelGGL(itr::splitk_reduce_kernel, dim3((unsigned)itr::ceil_div(M * N, (int64_t)256)), dim3(256), 0, itr::as_stream(stream),
+                           static_cast<const float *>(workspace), ns, M, N, bias, C, ldc, act, 0);
+        ITR_CHECK_LAUNCH("splitk_reduce");
+        return ITR_OK;
+    }
     const int s_ = itr::gemm_splitk_choice_fill(M, N, K);
     if (s_ <= 1) return itr::gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream));
     ITR_REQUIRE(workspace && workspace_bytes >= itr::gemm_splitk_scratch_bytes(M, N, s_), "itr_gemm_nt_splitk: workspace too small (itr_gemm_nt_splitk_workspace_bytes)");

@@ -155,7 +155,11 @@ int gemm_skinny_partials(const float *A, int64_t lda, const float *B, int64_t ld
     return ITR_OK;
 }
 
-// C = act(A B^T + bias) for M <= 128 in one launch (no K slices, no scratch)
+// C = act(A B^T + bias) for M <= 128 in one launch (no K slices, no scratch).  A product with few strips (a 512-wide decoder layer: 32
+// workgroups living ~1 us per 64 k) is better served by itr_gemm_nt_splitk, which runs the slices above and one slice sum (21 -> 10 us).
+// Tried on this kernel in round 6 and not kept: 32-column strips here (half the workgroups: 21 -> 27 us); three register stages of
+// branch-free asm loads with counted waits (no change: the chunk time is not the L2 round trip; plain branch-free loads are sunk to
+// their LDS write by hipcc and ran 2.5 x slower).
 int gemm_skinny_direct(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                        int act, hipStream_t st) {
     const int kslice = (int)(ceil_div(K, (int64_t)SK_KC) * SK_KC);

@@ -104,7 +104,9 @@ def _nt_tape(lib, a, w, b, out):
         return out
     pa, pw, po = a.data_ptr(), w.data_ptr(), out.data_ptr()
     pb = b.data_ptr() if b is not None else 0
-    if M <= 128:
+    if M <= 128 and K >= 256 and 64 <= N < 2048:      # a decoder step's layers: K slices of 16-column strips + one slice sum (the library
+        _nt_call(lib, pa, pw, pb, po, N, M, N, K, a.device, True)      # routes <= 128 rows of itr_gemm_nt_splitk there)
+    elif M <= 128:
         _lib.check(lib.itr_gemm_nt_algo(_p(a), K, _p(w), K, _p(b), _p(out), N, M, N, K, 0, 4, _stream()))
     elif K >= 512 and ((M + 127) // 128) * ((N + 127) // 128) < 128:      # CAMERA's convolutions as GEMMs: 36 tiles over K = 10 240;
         _nt_call(lib, pa, pw, pb, po, N, M, N, K, a.device, True)         # BERT's 768-wide layers at batch 64: 96 tiles

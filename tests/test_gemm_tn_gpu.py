@@ -119,3 +119,17 @@ def test_linear_peels_a_round_and_a_bit_of_tiles(dev, M, N, K, bias):
     y.backward(g)
     want_dx = g[idx].double() @ w.detach().double()
     assert float((x.grad[idx].double() - want_dx).abs().max()) <= 2e-5 * N ** 0.5
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(128, 512, 512, True), (128, 1536, 1024, True), (128, 812, 1536, False), (5, 64, 256, True), (128, 512, 300, False)])
+def test_small_batch_layers_take_k_slices_and_one_sum(dev, M, N, K, bias):
+    """autograd.linear for <= 128 rows with 64 <= N < 2048, K >= 256: itr_gemm_nt_splitk's skinny route (16-column strips x K slices + the
+    slice sum with bias), against float64; the same bits on every call; ragged N and a K that is not a multiple of the 64-wide chunk."""
+    torch.manual_seed(N + K)
+    x = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) * 0.05
+    b = torch.randn(N, device=dev) if bias else None
+    y = ag.linear(x, w, b)
+    want = x.double() @ w.double().t() + (b.double() if bias else 0)
+    assert float((y.double() - want).abs().max()) <= 2e-5 * K ** 0.5
+    assert torch.equal(y, ag.linear(x, w, b))
