@@ -60,24 +60,46 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------- column sums (two deterministic passes)
-constexpr int CS_ROWS = 256;   // rows per partial
+// Rows per partial: 32 up to 2 048 rows, else rows / 64 rounded up to a multiple of 32 -- at most 64 partials, each summed with 16
+// loads in flight.  (Round 6: with 256 rows per partial and one load per loop trip a 128 x 512 sum was two workgroups waiting for 128
+// L2 round trips each, 30 us; the sum stays a fixed order of additions for a given shape.)
+static int64_t cs_rows_per_part(int64_t rows) {
+    if (rows <= 2048) return 32;
+    return ceil_div(ceil_div(rows, (int64_t)64), (int64_t)32) * 32;
+}
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, float *__restrict__ part, int64_t rows,
-                                                             int64_t cols) {
+                                                             int64_t cols, int64_t rpp) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
-    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
-    const int64_t r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += x[r * cols + c];
-    part[(int64_t)blockIdx.y * cols + c] = s;
+    const int64_t r0 = (int64_t)blockIdx.y * rpp;
+    const int64_t r1 = r0 + rpp < rows ? r0 + rpp : rows;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t r = r0;
+    for (; r + 16 <= r1; r += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = x[(r + i) * cols + c];
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
+    }
+    for (; r < r1; ++r) s0 += x[r * cols + c];
+    part[(int64_t)blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, float *__restrict__ out, int64_t nparts,
                                                            int64_t cols, int accumulate) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
-    float s = accumulate ? out[c] : 0.f;
-    for (int64_t p = 0; p < nparts; ++p) s += part[p * cols + c];
-    out[c] = s;
+    float s0 = accumulate ? out[c] : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t p = 0;
+    for (; p + 16 <= nparts; p += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = part[(p + i) * cols + c];
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
+    }
+    for (; p < nparts; ++p) s0 += part[p * cols + c];
+    out[c] = (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------- embedding backward
@@ -207,7 +229,8 @@ extern "C" int itr_transpose2d(const float *in, float *out, int64_t rows, int64_
 }
 
 extern "C" size_t itr_colsum_workspace_bytes(int64_t rows, int64_t cols) {
-    return (size_t)ceil_div(rows > 0 ? rows : 1, CS_ROWS) * (size_t)(cols > 0 ? cols : 1) * 4 + 256;
+    const int64_t r = rows > 0 ? rows : 1;
+    return (size_t)ceil_div(r, cs_rows_per_part(r)) * (size_t)(cols > 0 ? cols : 1) * 4 + 256;
 }
 
 extern "C" int itr_colsum(const float *x, float *out, int64_t rows, int64_t cols, int accumulate, void *workspace, size_t workspace_bytes,
@@ -215,12 +238,12 @@ extern "C" int itr_colsum(const float *x, float *out, int64_t rows, int64_t cols
     ITR_REQUIRE(x && out && workspace, "itr_colsum: null pointer");
     ITR_REQUIRE(rows >= 0 && cols > 0, "itr_colsum: bad shape");
     ITR_REQUIRE(workspace_bytes >= itr_colsum_workspace_bytes(rows, cols), "itr_colsum: workspace too small");
-    const int64_t nparts = ceil_div(rows, CS_ROWS);
-    ITR_UNSUPPORTED(nparts > 65535, "itr_colsum: more than 16M rows");
+    const int64_t rpp = cs_rows_per_part(rows > 0 ? rows : 1);
+    const int64_t nparts = ceil_div(rows, rpp);
     float *part = static_cast<float *>(workspace);
     hipStream_t st = as_stream(stream);
     if (nparts > 0) {
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)ceil_div(cols, 256), (unsigned)nparts), dim3(256), 0, st, x, part, rows, cols);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)ceil_div(cols, 256), (unsigned)nparts), dim3(256), 0, st, x, part, rows, cols, rpp);
         ITR_CHECK_LAUNCH("colsum_partial");
     }
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(cols, 256)), dim3(256), 0, st, part, out, nparts, cols, accumulate);
