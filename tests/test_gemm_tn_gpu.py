@@ -133,3 +133,21 @@ def test_small_batch_layers_take_k_slices_and_one_sum(dev, M, N, K, bias):
     want = x.double() @ w.double().t() + (b.double() if bias else 0)
     assert float((y.double() - want).abs().max()) <= 2e-5 * K ** 0.5
     assert torch.equal(y, ag.linear(x, w, b))
+
+
+def test_linear_backward_with_an_output_width_that_is_not_a_multiple_of_four(dev):
+    """_Linear.backward's transposed route (the vocabulary projection of the caption decoder, Fusionmodule.py:277-292: 9 487 words):
+    dx, dW and db against float64 autograd."""
+    torch.manual_seed(11)
+    M, K, N = 1024, 512, 1303
+    x = torch.randn(M, K, device=dev, requires_grad=True)
+    w = (torch.randn(N, K, device=dev) * 0.05).requires_grad_()
+    b = torch.randn(N, device=dev).requires_grad_()
+    y = ag.linear(x, w, b)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    torch.nn.functional.linear(xd, wd, bd).backward(g.double())
+    assert float((x.grad.double() - xd.grad).abs().max()) <= 2e-5 * N ** 0.5
+    assert float((w.grad.double() - wd.grad).abs().max()) <= 3e-5 * M ** 0.5
+    assert float((b.grad.double() - bd.grad).abs().max()) <= 3e-5 * M ** 0.5
