@@ -385,7 +385,10 @@ int itr_colsum(const float *x, float *out, int64_t rows, int64_t cols, int accum
                size_t workspace_bytes, itr_stream_t stream);
 /* C = act(A B^T + bias) with the K range cut into slices when the output has too few 128 x 128 tiles to fill the chip (M N small, K long:
  * CAMERA's dilated convolutions as GEMMs); slices added in a fixed order.  TRAINING TAPE ONLY: a row's bits depend on the slice count,
- * hence on the shape of the call -- the evaluation keeps itr_gemm_nt.  Falls back to itr_gemm_nt when no split is chosen. */
+ * hence on the shape of the call -- the evaluation keeps itr_gemm_nt.  Falls back to itr_gemm_nt when no split is chosen.  The slice
+ * count aims at two resident workgroups per CU (512 / tiles, at most 8, slices of >= 128 k).  M <= 128 rows (ABI 30: a decoder step's
+ * layers) take the 16-column-strip kernel over K slices and one pass that adds the slices, the bias and the activation; the workspace
+ * for that is 16 M N floats. */
 size_t itr_gemm_nt_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int itr_gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M,
                        int64_t N, int64_t K, int act, void *workspace, size_t workspace_bytes, itr_stream_t stream);
