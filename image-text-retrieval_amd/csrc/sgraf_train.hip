@@ -236,25 +236,34 @@ __global__ __launch_bounds__(256) void sgt_ctx_bwd_kernel(const float *__restric
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 *img4 = reinterpret_cast<const float4 *>(img) + (int64_t)b * R * D4;
-        for (int r = 0; r < R; ++r) {       // (one region per iteration: requesting four at once, as the forward kernel does, measured SLOWER here --
-            float4 x[VEC];                  //  1 011 -> 1 100-1 260 us: the kernel is at 174 registers already)
+        // four regions requested together (one per trip was one L2 round trip per 32 fmaf; at 174 registers the same change measured slower --
+        // it fits since the word rows left the register file)
+        for (int r0 = 0; r0 < R; r0 += 4) {
+            float4 x[4][VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) x[v] = tid + v * 256 < D4 ? img4[(int64_t)r * D4 + tid + v * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 *pr = reinterpret_cast<const float4 *>(Ptt + r * SGT_TB);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int q = 0; q < SGT_TB / 4; ++q) {
-                const float4 p4 = pr[q];
-                const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+                for (int v = 0; v < VEC; ++v)
+                    x[j][v] = (r0 + j < R && tid + v * 256 < D4) ? img4[(int64_t)(r0 + j) * D4 + tid + v * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+            for (int j = 0; j < 4; ++j) {
+                if (r0 + j >= R) continue;
+                const float4 *pr = reinterpret_cast<const float4 *>(Ptt + (r0 + j) * SGT_TB);
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        float4 &c = acc[q * 4 + k][v];
-                        c.x = fmaf(pp[k], x[v].x, c.x);
-                        c.y = fmaf(pp[k], x[v].y, c.y);
-                        c.z = fmaf(pp[k], x[v].z, c.z);
-                        c.w = fmaf(pp[k], x[v].w, c.w);
-                    }
+                for (int q = 0; q < SGT_TB / 4; ++q) {
+                    const float4 p4 = pr[q];
+                    const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            float4 &c = acc[q * 4 + k][v];
+                            c.x = fmaf(pp[k], x[j][v].x, c.x);
+                            c.y = fmaf(pp[k], x[j][v].y, c.y);
+                            c.z = fmaf(pp[k], x[j][v].z, c.z);
+                            c.w = fmaf(pp[k], x[j][v].w, c.w);
+                        }
+                }
             }
         }
 #pragma unroll
