@@ -135,21 +135,27 @@ int gemm_skinny_partials(const float *A, int64_t lda, const float *B, int64_t ld
                          int *n_slices, hipStream_t st) {
     // 32-column strips from 1 024 columns up (the recurrence products: 3 D and D columns of a D >= 1 024 GRU); 16-column strips keep the
     // narrow ones spread over the chip
-    const bool wide = N >= 1024;
-    const int64_t col_tiles = ceil_div(N, (int64_t)(wide ? 32 : 16));
-    int64_t s = ceil_div((int64_t)(wide ? 512 : 384), col_tiles);   // ~1.5 workgroups per CU (2 of the 46 KB ones)
+    // 64-column strips for a D = 2 048 GRU (6 144 gate columns over K = 2 048, 2 048 back over K = 6 144: 45 -> 39 us, 42 -> 38); at D = 1 024
+    // (3 072 x 1 024) they measured slower than 32-column ones (SCAN's forward 1.26 -> 1.33 ms)
+    const int nc = (N >= 4096 || (N >= 2048 && K >= 4096)) ? 4 : (N >= 1024 ? 2 : 1);
+    const int64_t col_tiles = ceil_div(N, (int64_t)(16 * nc));
+    int64_t s = ceil_div((int64_t)(nc > 1 ? 512 : 384), col_tiles); // ~1.5 workgroups per CU (2 of the 46 / 55 KB ones)
     const int64_t by_k = K / (2 * SK_KC) > 0 ? K / (2 * SK_KC) : 1; // a slice is at least 128 k
     if (s > by_k) s = by_k;
     if (s > max_slices) s = max_slices;
     if (s < 1) s = 1;
     const int kslice = (int)(ceil_div(ceil_div(K, s), (int64_t)SK_KC) * SK_KC);
     const int ns = (int)ceil_div(K, (int64_t)kslice);
-    if (wide)
-        hipLaunchKernelGGL((gemm_skinny_kernel<false, 2, 32>), dim3((unsigned)col_tiles, (unsigned)ns), dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K,
-                           kslice, part, (const float *)nullptr, 0, (int64_t)0);
+    const dim3 grid((unsigned)col_tiles, (unsigned)ns);
+    if (nc == 4)
+        hipLaunchKernelGGL((gemm_skinny_kernel<false, 4, 32>), grid, dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K, kslice, part, (const float *)nullptr, 0,
+                           (int64_t)0);
+    else if (nc == 2)
+        hipLaunchKernelGGL((gemm_skinny_kernel<false, 2, 32>), grid, dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K, kslice, part, (const float *)nullptr, 0,
+                           (int64_t)0);
     else
-        hipLaunchKernelGGL((gemm_skinny_kernel<false, 1, SK_KC>), dim3((unsigned)col_tiles, (unsigned)ns), dim3(256), 0, st, A, lda, B, ldb, (int)M, N,
-                           (int)K, kslice, part, (const float *)nullptr, 0, (int64_t)0);
+        hipLaunchKernelGGL((gemm_skinny_kernel<false, 1, SK_KC>), grid, dim3(256), 0, st, A, lda, B, ldb, (int)M, N, (int)K, kslice, part, (const float *)nullptr,
+                           0, (int64_t)0);
     ITR_CHECK_LAUNCH("gemm_skinny");
     *n_slices = ns;
     return ITR_OK;
