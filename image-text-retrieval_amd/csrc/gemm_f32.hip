@@ -145,7 +145,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g_i
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     const int64_t tiles_n = (g.N + BN - 1) / BN;
     const int64_t ntile1 = tiles_m * tiles_n;
-    const int64_t ntile = g_in.A2 ? 2 * ntile1 : ntile1;
+    // K slices (round 6, the training tape's few-tile products): the persistent order runs over (slice, tile) units, a unit multiplies the
+    // K range [slice ksplit, (slice + 1) ksplit) and stores the raw partial tile to part + slice M N; the caller's reduction adds them.
+    const int64_t nsl = g_in.ksplit > 0 ? (g_in.K + g_in.ksplit - 1) / g_in.ksplit : 1;
+    const int64_t ntile = g_in.A2 ? 2 * ntile1 : ntile1 * nsl;
     // PERSISTENT: the grid is at most 2 workgroups per CU (8 XCDs x 64); XCD x owns a contiguous range of the tile order
     // (consecutive tiles walk down a column of M tiles and share the B panel in that XCD's L2) and its resident
     // workgroups stride through it.  A short-K tile lives ~25 us, and a fresh workgroup launch costs ~10 us of an idle
@@ -157,7 +160,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g_i
     const int64_t t_begin = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_);
     const int64_t t_count = q_ + (xcd < r_ ? 1 : 0);
     const int ld_row = tid >> 3, ld_p = tid & 7;
-    const int nk = __builtin_amdgcn_readfirstlane((int)(g.K / BK));
     constexpr unsigned OPER_BYTES = NPLANE * BM * 16u;
     const int fi = lane & 31, fg = lane >> 5;
     // LDS byte addresses of the generated loop (buffer 1, operand B and the 32-row passes are immediates there)
@@ -172,19 +174,27 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_fast_kernel(GemmArgs g_i
 
   for (int64_t tt = slot; tt < t_count; tt += nslots) {
     int64_t bid = t_begin + tt;
-    if (bid >= ntile1) {          // second problem of a paired launch (uniform: bid is a scalar)
+    int64_t k0 = 0, klen = g_in.K;
+    if (g_in.ksplit > 0) {        // a K slice of tile bid % ntile1 (uniform)
+        const int64_t sl = bid / ntile1;
+        bid -= sl * ntile1;
+        k0 = sl * g_in.ksplit;
+        klen = k0 + g_in.ksplit < g_in.K ? g_in.ksplit : g_in.K - k0;
+        g.C = g_in.part + sl * g_in.M * g_in.N; g.ldc = g_in.N; g.bias = nullptr; g.act = 0; g.accumulate = 0; g.Z = nullptr;
+    } else if (bid >= ntile1) {   // second problem of a paired launch (uniform: bid is a scalar)
         bid -= ntile1;
         g.A = g_in.A2; g.B = g_in.B2; g.bias = g_in.bias2; g.C = g_in.C2;
     } else {
         g.A = g_in.A; g.B = g_in.B; g.bias = g_in.bias; g.C = g_in.C;
     }
+    const int nk = __builtin_amdgcn_readfirstlane((int)(klen / BK));
     const int64_t tm = bid % tiles_m, tn = bid / tiles_m;
     const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t m_end = (m0 + BM < g.M) ? m0 + BM : g.M;
 
     f32x16 acc[2][2];
-    const char *abase = reinterpret_cast<const char *>(g.A + m0 * g.lda);
-    const char *bbase = reinterpret_cast<const char *>(g.B + n0 * g.ldb);
+    const char *abase = reinterpret_cast<const char *>(g.A + m0 * g.lda + k0);
+    const char *bbase = reinterpret_cast<const char *>(g.B + n0 * g.ldb + k0);
     unsigned oa0, oa1, oa2, oa3, ob0, ob1, ob2, ob3;    // per-lane byte offsets (host checked: 128 rows * ld * 4 < 2^32)
     {
         auto offa = [&](int s_) -> unsigned {
@@ -404,6 +414,28 @@ int gemm_nt_splitk(const float *A, int64_t lda, const float *B, int64_t ldb, con
     return ITR_OK;
 }
 
+// The same, slices on the persistent asm tile kernel where the shape admits it (K a multiple of 32, aligned rows): the training tape's
+// entry point only (itr_gemm_nt_splitk) -- the evaluation's small-batch recurrence keeps the kernel it was validated bit for bit on.
+// (Round 6: the generic kernel ran the peeled tails and BERT's 96-tile products at ~70 TFLOP/s where the asm loop does ~118.)
+int gemm_nt_splitk_fast(const float *A, int64_t lda, const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int64_t M, int64_t N,
+                        int64_t K, int act, int splits, float *scratch, hipStream_t st) {
+    if (M == 0 || N == 0) return ITR_OK;
+    const int64_t ksplit = ceil_div(ceil_div(K, (int64_t)(splits > 1 ? splits : 1)), (int64_t)BK) * BK;
+    const int ns = (int)ceil_div(K, ksplit);
+    const bool ok = splits > 1 && ns > 1 && (lda % 4 == 0) && (ldb % 4 == 0) && (K % BK == 0) && K >= BK &&
+                    ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) &&
+                    (uint64_t)lda * 4u * BM < (1ull << 32) && (uint64_t)ldb * 4u * BN < (1ull << 32);
+    if (!ok) return gemm_nt_splitk(A, lda, B, ldb, bias, C, ldc, M, N, K, act, 0, splits, scratch, st);
+    GemmArgs g{A, B, nullptr, C, lda, ldb, ldc, M, N, K, 0, 1, BM, nullptr, nullptr, 0, 0, ksplit, scratch};
+    const int64_t units = ceil_div(M, BM) * ceil_div(N, BN) * ns;
+    const int64_t per_xcd = ceil_div(units, 8);
+    hipLaunchKernelGGL(gemm_nt_fast_kernel, dim3(8u * (unsigned)(per_xcd < 64 ? per_xcd : 64)), dim3(GEMM_THREADS), 0, st, g);
+    ITR_CHECK_LAUNCH("gemm_nt_fast(split-K)");
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(M * N, 256)), dim3(256), 0, st, scratch, ns, M, N, bias, C, ldc, act, 0);
+    ITR_CHECK_LAUNCH("splitk_reduce");
+    return ITR_OK;
+}
+
 // Slices only: scratch[s][m][n] (s < *n_slices) holds the raw partial products; the CONSUMER adds them (in slice order) --
 // the GRU gate kernels do, which saves one launch and one pass per time step.
 bool gemm_skinny_ok(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int64_t N, int64_t K);      // gemm_skinny.hip
@@ -587,5 +619,5 @@ extern "C" int itr_gemm_nt_splitk(const float *A, int64_t lda, const float *B, i
     const int s_ = itr::gemm_splitk_choice_fill(M, N, K);
     if (s_ <= 1) return itr::gemm_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, act, itr::as_stream(stream));
     ITR_REQUIRE(workspace && workspace_bytes >= itr::gemm_splitk_scratch_bytes(M, N, s_), "itr_gemm_nt_splitk: workspace too small (itr_gemm_nt_splitk_workspace_bytes)");
-    return itr::gemm_nt_splitk(A, lda, B, ldb, bias, C, ldc, M, N, K, act, 0, s_, static_cast<float *>(workspace), itr::as_stream(stream));
+    return itr::gemm_nt_splitk_fast(A, lda, B, ldb, bias, C, ldc, M, N, K, act, s_, static_cast<float *>(workspace), itr::as_stream(stream));
 }
