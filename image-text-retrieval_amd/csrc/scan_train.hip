@@ -426,6 +426,9 @@ extern "C" int itr_scan_train_fwd(const float *A, int64_t ldA, const float *G, c
     ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, R, norm, agg, lambda_softmax, lambda_lse, S, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = as_stream(stream);
     const bool w64 = max_len <= 64;
+    // captions of at most 32 words (every COCO / F30k training batch but a handful): 20 KB of LDS per pair instead of 35 -- eight resident
+    // pairs per CU instead of four; a pair's life is a chain of short, barrier-separated phases, so residency is what hides it
+    if (R == SC_R && max_len <= 32) return launch_pair<PairSmem<32, SC_R>>(scan_train_fwd_kernel<32, SC_R, true>, "scan_train_fwd", g, st);
     if (R == SC_R)
         return w64 ? launch_pair<PairSmem<64, SC_R>>(scan_train_fwd_kernel<64, SC_R, true>, "scan_train_fwd", g, st)
                    : launch_pair<PairSmem<ST_MAXW, SC_R>>(scan_train_fwd_kernel<ST_MAXW, SC_R, true>, "scan_train_fwd", g, st);
@@ -448,6 +451,7 @@ extern "C" int itr_scan_train_bwd(const float *A, int64_t ldA, const float *G, c
     ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, R, norm, agg, lambda_softmax, lambda_lse, nullptr, dS, dA, dG_pairs, d_enorm_pairs};
     hipStream_t st = as_stream(stream);
     const bool w64 = max_len <= 64;
+    if (R == SC_R && max_len <= 32) return launch_pair<PairBwdSmem<32, SC_R>>(scan_train_bwd_kernel<32, SC_R, true>, "scan_train_bwd", g, st);
     if (R == SC_R)
         return w64 ? launch_pair<PairBwdSmem<64, SC_R>>(scan_train_bwd_kernel<64, SC_R, true>, "scan_train_bwd", g, st)
                    : launch_pair<PairBwdSmem<ST_MAXW, SC_R>>(scan_train_bwd_kernel<ST_MAXW, SC_R, true>, "scan_train_bwd", g, st);
