@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void scan_train_fwd_kernel(ScanTrainArgs g) {
 }
 
 template <int MAXW, int RMAX, bool FIXED>
-__global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
+__device__ __forceinline__ void scan_train_bwd_body(const ScanTrainArgs &g) {
     extern __shared__ __attribute__((aligned(16))) char pair_smem[];
     PairBwdSmem<MAXW, RMAX> &bs = *reinterpret_cast<PairBwdSmem<MAXW, RMAX> *>(pair_smem);
     PairSmem<MAXW, RMAX> &sm = bs.sm;
@@ -271,6 +271,12 @@ __global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) {
         dgp[idx] = acc;
     }
 }
+template <int MAXW, int RMAX, bool FIXED>
+__global__ __launch_bounds__(256) void scan_train_bwd_kernel(ScanTrainArgs g) { scan_train_bwd_body<MAXW, RMAX, FIXED>(g); }
+// the 32-word instantiation: 25 KB of LDS per pair admit six resident workgroups, 110 registers four -- capped at 80 (a few spills) it
+// measured 3.56 -> 3.51 ms on the SCAN step; the larger instantiations are LDS-limited and keep their registers
+template <int MAXW, int RMAX, bool FIXED>
+__global__ __launch_bounds__(256, 6) void scan_train_bwd_dense_kernel(ScanTrainArgs g) { scan_train_bwd_body<MAXW, RMAX, FIXED>(g); }
 
 // dG[i] = sum_c dGp[i, c]  (summed into the slot of caption 0: a thread touches only its own element of every slot), then
 // dV[i] += (dG + dG^T) V[i]   (G = V V^T).  Round 6: two launches of (elements / features) x images workgroups -- the one-workgroup-per-
@@ -451,7 +457,7 @@ extern "C" int itr_scan_train_bwd(const float *A, int64_t ldA, const float *G, c
     ScanTrainArgs g{A, ldA, G, enorm, cap_off, cap_len, Bi, Bc, R, norm, agg, lambda_softmax, lambda_lse, nullptr, dS, dA, dG_pairs, d_enorm_pairs};
     hipStream_t st = as_stream(stream);
     const bool w64 = max_len <= 64;
-    if (R == SC_R && max_len <= 32) return launch_pair<PairBwdSmem<32, SC_R>>(scan_train_bwd_kernel<32, SC_R, true>, "scan_train_bwd", g, st);
+    if (R == SC_R && max_len <= 32) return launch_pair<PairBwdSmem<32, SC_R>>(scan_train_bwd_dense_kernel<32, SC_R, true>, "scan_train_bwd", g, st);
     if (R == SC_R)
         return w64 ? launch_pair<PairBwdSmem<64, SC_R>>(scan_train_bwd_kernel<64, SC_R, true>, "scan_train_bwd", g, st)
                    : launch_pair<PairBwdSmem<ST_MAXW, SC_R>>(scan_train_bwd_kernel<ST_MAXW, SC_R, true>, "scan_train_bwd", g, st);
