@@ -744,11 +744,16 @@ static int sgt_lds(const void *kernel, size_t bytes, const char *what) {
     return ITR_OK;
 }
 
-// the column chunk of the graph kernels: as wide as 32 KB of LDS allow next to the two n x n matrices (at least 32, a multiple of 32,
-// or all of S when S < 32)
+// the column chunk of the graph kernels: as wide as SGT_GRAPH_LDS bytes allow next to the two n x n matrices (at least 32, a multiple of
+// 32, or all of S when S < 32).  16 KB: a graph's workgroup is a chain of staged chunks and barriers, so what hides it is the number of
+// graphs resident on the CU -- 32 KB (5 per CU, two chunks of S = 256) measured 20.4 ms on the SGR step, 16 KB (8 per CU, four chunks)
+// 20.05, 12 KB 20.2
+#ifndef SGT_GRAPH_LDS
+#define SGT_GRAPH_LDS (16 * 1024)
+#endif
 static int sgt_graph_chunk(int nmax, int S) {
     if (S <= 32) return S;
-    int64_t room = (32 * 1024 / 4 - 2 * (int64_t)((nmax * nmax + 3) & ~3)) / (2 * (int64_t)nmax) - 4;
+    int64_t room = (SGT_GRAPH_LDS / 4 - 2 * (int64_t)((nmax * nmax + 3) & ~3)) / (2 * (int64_t)nmax) - 4;
     int sc = (int)(room / 32 * 32);
     if (sc < 32) sc = 32;
     if (sc > S) sc = (S + 3) & ~3;
