@@ -102,7 +102,8 @@ def test_linear_splits_k_when_the_output_has_few_tiles(dev, M, N, K):
 @pytest.mark.parametrize("M,N,K,bias", [(4608, 2048, 2048, True),       # 576 tiles: the last 4 row tiles peeled (VSRN's graph-convolution layers)
                                         (2048, 2304, 768, True),        # 288 tiles (BERT's fused Q/K/V at batch 64 x 32 tokens)
                                         (4700, 2000, 1024, False),      # ragged rows and columns, 592 tiles
-                                        (2048, 3072, 768, True)])       # 384 tiles: no plan pays, one launch
+                                        (2048, 3072, 768, True),        # 384 tiles: no plan pays, one launch
+                                        (4096, 3000, 768, True)])       # 768 tiles: the last 8 COLUMN tiles peeled (ragged: 3 000 columns), BERT's FFN at 4 096 rows
 def test_linear_peels_a_round_and_a_bit_of_tiles(dev, M, N, K, bias):
     """autograd._peel_plan: the main launch and the K-sliced tail together are the product (float64 reference on sampled rows that
     cover both parts), forward and input gradient, and the same bits on every call."""
